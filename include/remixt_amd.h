@@ -1,0 +1,185 @@
+/*
+ * remixt_amd.h -- C ABI of the MI355X-native ReMixT variational-HMM kernel.
+ *
+ * This is the drop-in boundary below the reference's Python object protocol.
+ * The reference has no FFI on this path: `remixt/cn_model.py` talks to the
+ * Cython class `remixt.bpmodel.RemixtModel` (reference remixt/bpmodel.pyx:397).
+ * Every entry point below replaces one method / attribute of that class (cited
+ * per function, paths relative to the reference root).  remixt_amd/bpmodel.py is
+ * the ctypes binding that re-creates the `RemixtModel` protocol on top of it;
+ * INTEGRATION.md shows the stub a reference maintainer would add.
+ *
+ * Conventions
+ *   - plain C: pointers + sizes, no C++/torch types.  All host arrays are
+ *     C-contiguous float64 / int64 exactly as the reference passes them.
+ *   - a `rmx_batch` holds ONE dataset (segments, state tables, topology) and R
+ *     independent "restarts" (the reference's one-process-per-init_id fan-out,
+ *     remixt/workflow.py:329-340).  The reference's RemixtModel == batch of 1.
+ *   - every function returns an int status: 0 ok; RMX_E* otherwise, with a
+ *     message retrievable through rmx_last_error().  RMX_EVALUE / RMX_EASSERT
+ *     mirror the reference's ValueError / AssertionError sites.
+ *   - restart ranges are [r0, r1).  All work is queued on the batch's HIP
+ *     stream; functions that return host values synchronise that stream.
+ *   - nothing is computed on the CPU: if no HIP device is usable the create
+ *     call fails with RMX_EDEVICE (there is no fallback path).
+ */
+#ifndef REMIXT_AMD_H
+#define REMIXT_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RMX_OK 0
+#define RMX_EVALUE 1     /* reference: ValueError (bad shapes, nan ll, invalid p, x<=0 in digamma) */
+#define RMX_EASSERT 2    /* reference: AssertionError (nan in alphas/betas/marginals, bpmodel.pyx:936-962) */
+#define RMX_EDEVICE 3    /* HIP runtime failure / no device */
+#define RMX_EUNSUPPORTED 4 /* outside the supported envelope (documented in DESIGN.md) */
+#define RMX_EARG 5       /* bad argument to this C API */
+
+#define RMX_MAX_CLONES 4
+
+typedef struct rmx_batch rmx_batch;
+
+/* Read-only problem description == positional arguments of
+ * RemixtModel.__cinit__ (bpmodel.pyx:461-476), with the (N,S,M,2) state array
+ * given in class-compressed form: segment n uses table cn_classes[seg_class[n]].
+ * (cn_model.py:359-364 builds at most a handful of distinct tables: they differ
+ * only in the normal-clone row.)  rmx_compress_cn_states() converts the dense
+ * reference array. */
+typedef struct rmx_problem {
+    int32_t num_clones;            /* M (<= RMX_MAX_CLONES) */
+    int32_t num_segments;          /* N */
+    int32_t num_breakpoints;       /* K */
+    int32_t num_cn_states;         /* S */
+    int32_t num_brk_states;        /* B */
+    int32_t num_classes;           /* C */
+    int32_t normal_contamination;  /* bool */
+    int32_t reserved;
+    const int64_t *cn_classes;     /* [C][S][M][2] */
+    const int32_t *seg_class;      /* [N] */
+    const int64_t *brk_states;     /* [B][M] */
+    const double *l;               /* [N] segment lengths */
+    const double *x;               /* [N] total read counts */
+    const double *y;               /* [N][2] allele read counts */
+    const int64_t *is_telomere;    /* [N] */
+    const int64_t *breakpoint_idx; /* [N] (-1 = none) */
+    const int64_t *breakpoint_orient; /* [N] */
+    double transition_penalty;     /* fabs() taken, bpmodel.pyx:534 */
+} rmx_problem;
+
+/* ids for rmx_set_param / rmx_get_param: the `cdef public` float attributes of
+ * RemixtModel (bpmodel.pyx:433-454, 417-418, 422) */
+enum rmx_param_id {
+    RMX_P_NEGBIN_R_0 = 0, RMX_P_NEGBIN_R_1, RMX_P_NEGBIN_HDEL_MU, RMX_P_NEGBIN_HDEL_R_0, RMX_P_NEGBIN_HDEL_R_1,
+    RMX_P_BETABIN_M_0, RMX_P_BETABIN_M_1, RMX_P_BETABIN_LOH_P, RMX_P_BETABIN_LOH_M_0, RMX_P_BETABIN_LOH_M_1,
+    RMX_P_PRIOR_OUTLIER_TOTAL, RMX_P_PRIOR_OUTLIER_ALLELE, RMX_P_DIVERGENCE_WEIGHT,
+    RMX_P_HMM_LOG_NORM_CONST /* read-only */, RMX_P_COUNT
+};
+
+/* ids for rmx_get_array / rmx_set_array: array attributes of RemixtModel
+ * (bpmodel.pyx:405-442).  Shapes in the reference's layout. */
+enum rmx_array_id {
+    RMX_A_H = 0,                   /* f64 [M]            rw */
+    RMX_A_P_BREAKPOINT,            /* f64 [K][B]         rw */
+    RMX_A_P_ALLELE_SWAP,           /* f64 [N][2]         rw */
+    RMX_A_P_OUTLIER_TOTAL,         /* f64 [N][2]         rw */
+    RMX_A_P_OUTLIER_ALLELE,        /* f64 [N][2]         rw */
+    RMX_A_POSTERIOR_MARGINALS,     /* f64 [N][S]         rw */
+    RMX_A_FRAMELOGPROB,            /* f64 [N][S]         r  */
+    RMX_A_TOTAL_LIKELIHOOD_MASK,   /* i64 [N]            rw (shared by the batch) */
+    RMX_A_ALLELE_LIKELIHOOD_MASK,  /* i64 [N]            rw (shared by the batch) */
+    RMX_A_LOG_TRANSMAT,            /* f64 [N-1][S][S]    r  materialised on request only */
+    RMX_A_CACHED_LOG_TRANSMAT,     /* f64 [N-1][S][S]    r  materialised on request only */
+    RMX_A_JOINT_POSTERIOR_MARGINALS, /* f64 [N-1][S][S]  r  materialised on request only */
+    RMX_A_STATE_SEQUENCE,          /* i64 [N]            r  last Viterbi path */
+    RMX_A_COUNT
+};
+
+/* -- lifetime ------------------------------------------------------------- */
+/* RemixtModel.__cinit__ (bpmodel.pyx:461-604) for R restarts at once.
+ * h_init: [R][M]; divergence_weight: [R] (fabs taken, :535). */
+int rmx_batch_create(const rmx_problem *problem, int32_t num_restarts, const double *h_init,
+                     const double *divergence_weight, int32_t device, rmx_batch **out);
+int rmx_batch_destroy(rmx_batch *b);
+/* Dense (N,S,M,2) int64 -> class-compressed form.  seg_class_out: [N];
+ * classes_out: caller buffer for up to max_classes tables of S*M*2 int64.
+ * Returns the number of classes through *num_classes (RMX_EUNSUPPORTED when
+ * more than max_classes distinct tables occur). */
+int rmx_compress_cn_states(const int64_t *cn_states, int32_t N, int32_t S, int32_t M,
+                           int32_t max_classes, int32_t *seg_class_out, int64_t *classes_out,
+                           int32_t *num_classes);
+const char *rmx_last_error(void);
+/* use an externally owned HIP stream (e.g. torch's current stream); NULL = own */
+int rmx_set_stream(rmx_batch *b, void *hip_stream);
+int rmx_synchronize(rmx_batch *b);
+/* derived sizes: 0 cn_max (bpmodel.pyx:489), 1 num chains, 2 num transition classes,
+ * 3 num breakend segments, 4 padded row stride of [N][S] device arrays */
+int rmx_info(rmx_batch *b, int32_t what, int64_t *out);
+
+/* -- attributes ----------------------------------------------------------- */
+int rmx_set_param(rmx_batch *b, int32_t r, int32_t param_id, double value);
+int rmx_get_param(rmx_batch *b, int32_t r, int32_t param_id, double *value);
+int rmx_set_transition_model(rmx_batch *b, int32_t model);  /* bpmodel.pyx:456, 606-616 */
+int rmx_set_array(rmx_batch *b, int32_t r, int32_t array_id, const void *host_src);
+int rmx_get_array(rmx_batch *b, int32_t r, int32_t array_id, void *host_dst);
+/* read-only derived state tables, (N,S[,M]) int64 like the reference attributes
+ * cn_states_total / num_alleles_subclonal / is_hdel / is_loh (bpmodel.pyx:497-507):
+ * which = 0..3 in that order */
+int rmx_get_state_table(rmx_batch *b, int32_t which, int64_t *host_dst);
+
+/* -- coordinate updates (bpmodel.pyx cpdef methods), restarts [r0,r1) ------ */
+int rmx_update_framelogprob(rmx_batch *b, int32_t r0, int32_t r1);      /* :898-919 */
+int rmx_update_p_cn(rmx_batch *b, int32_t r0, int32_t r1);              /* :921-962 */
+int rmx_update_p_breakpoint(rmx_batch *b, int32_t r0, int32_t r1);      /* :964-985 */
+int rmx_update_p_outlier_total(rmx_batch *b, int32_t r0, int32_t r1);   /* :987-1003 */
+int rmx_update_p_outlier_allele(rmx_batch *b, int32_t r0, int32_t r1);  /* :1005-1023 */
+int rmx_update_p_allele_swap(rmx_batch *b, int32_t r0, int32_t r1);     /* :1025-1042 */
+/* the five updates in BreakpointModel.variational_update order (cn_model.py:444-460),
+ * `iters` times, without host round trips */
+int rmx_variational_update(rmx_batch *b, int32_t r0, int32_t r1, int32_t iters);
+
+/* -- objectives ----------------------------------------------------------- */
+/* out: [r1-r0] */
+int rmx_calculate_elbo(rmx_batch *b, int32_t r0, int32_t r1, double *elbo_out);       /* :1119-1123 */
+int rmx_calculate_variational_energy(rmx_batch *b, int32_t r0, int32_t r1, double *out);  /* :1060-1117 */
+int rmx_calculate_variational_entropy(rmx_batch *b, int32_t r0, int32_t r1, double *out); /* :1044-1058 */
+/* sample: int64 [N] 0/1 mask as in the reference (:1125, :1159); partial_h_out may be
+ * NULL; when given it receives [M] (:1159-1195). */
+int rmx_expected_log_likelihood(rmx_batch *b, int32_t r, const int64_t *sample, double *ell_out,
+                                double *partial_h_out);
+/* per-cell values, for tests (:751-776, :809-853): u/v/w in {0,1} */
+int rmx_log_likelihood_total(rmx_batch *b, int32_t r, int32_t n, int32_t s, int32_t u, double *out);
+int rmx_log_likelihood_allele(rmx_batch *b, int32_t r, int32_t n, int32_t s, int32_t v, int32_t w, double *out);
+
+/* -- decoding ------------------------------------------------------------- */
+/* infer_cn (:1197-1210): Viterbi over the framelogprob / log_transmat of the last
+ * update_p_cn; cn_out int64 [N][M][2]; logprob_out may be NULL */
+int rmx_infer_cn(rmx_batch *b, int32_t r, int64_t *cn_out, double *logprob_out);
+
+/* -- module-level functions on caller-supplied dense inputs ----------------- */
+/* sum_product (:1213-1246): f [N][S], T [N-1][S][S] -> alphas, betas [N][S] */
+int rmx_sum_product(const double *f, const double *T, double *alphas, double *betas,
+                    int32_t N, int32_t S, int32_t device);
+/* max_product (:1296-1333): returns path int64 [N] and the log probability */
+int rmx_max_product(const double *f, const double *T, int64_t *state_sequence, double *logprob,
+                    int32_t N, int32_t S, int32_t device);
+
+/* -- measurement (bench.py): HIP events on the batch stream ----------------- */
+int rmx_timer_start(rmx_batch *b);
+int rmx_timer_stop(rmx_batch *b, double *elapsed_ms);
+/* per-kernel accumulated device time since the last reset (HIP events around
+ * each launch; enabled by rmx_profile_enable(b, 1)).  kernel ids: see
+ * rmx_kernel_name(). */
+int rmx_profile_enable(rmx_batch *b, int32_t on);
+int rmx_profile_get(rmx_batch *b, int32_t kernel_id, double *total_ms, int64_t *launches);
+int rmx_profile_reset(rmx_batch *b);
+const char *rmx_kernel_name(int32_t kernel_id);
+int rmx_num_kernels(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* REMIXT_AMD_H */

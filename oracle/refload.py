@@ -1,0 +1,69 @@
+"""Load the reference for golden-vector generation / oracle validation.
+
+TEST INFRASTRUCTURE ONLY (build container; /root/reference never travels).
+
+* `load_ref_bpmodel()`  -> the compiled reference kernel module built by
+  oracle/build_ref.py (binary only; may also run on the GPU box as the
+  "reference" CPU baseline because it is a plain CPython extension).
+* `load_ref_cn_model()` -> the reference's Python host class module
+  (`remixt/cn_model.py`), imported from /root/reference *in place*.  Only
+  possible in the build container.
+
+A synthetic `remixt` package object is registered whose __path__ spans
+oracle/_ref/remixt (the binary) and /root/reference/remixt (python sources), so
+the reference's package __init__ (versioneer) is not needed and nothing is
+copied.  `statsmodels.tools.numdiff` is imported by cn_model.py:9 but only used
+in a failure-diagnostic branch (cn_model.py:513-518); it is absent from this
+image, so an empty placeholder module is registered for the import to succeed.
+"""
+import importlib
+import os
+import sys
+import types
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REF = os.environ.get("REMIXT_REFERENCE", "/root/reference")
+REF_BIN = os.path.join(HERE, "_ref", "remixt")
+
+
+def _ensure_pkg(with_sources):
+    pkg = sys.modules.get("remixt")
+    if pkg is None or not getattr(pkg, "_oracle_synthetic", False):
+        pkg = types.ModuleType("remixt")
+        pkg._oracle_synthetic = True
+        pkg.__path__ = []
+        sys.modules["remixt"] = pkg
+    paths = [REF_BIN]
+    if with_sources:
+        paths.append(os.path.join(REF, "remixt"))
+    for p in paths:
+        if p not in pkg.__path__:
+            pkg.__path__.append(p)
+    return pkg
+
+
+def have_ref_binary():
+    return os.path.isdir(REF_BIN) and any(
+        f.startswith("bpmodel") and f.endswith(".so") for f in os.listdir(REF_BIN))
+
+
+def have_ref_sources():
+    return os.path.exists(os.path.join(REF, "remixt", "cn_model.py"))
+
+
+def load_ref_bpmodel():
+    if not have_ref_binary():
+        raise ImportError("oracle/_ref not built (run oracle/build_ref.py)")
+    _ensure_pkg(with_sources=False)
+    return importlib.import_module("remixt.bpmodel")
+
+
+def load_ref_cn_model():
+    if not have_ref_sources():
+        raise ImportError("reference sources not present")
+    load_ref_bpmodel()
+    _ensure_pkg(with_sources=True)
+    for name in ("statsmodels", "statsmodels.tools", "statsmodels.tools.numdiff"):
+        if name not in sys.modules:
+            sys.modules[name] = types.ModuleType(name)
+    return importlib.import_module("remixt.cn_model")

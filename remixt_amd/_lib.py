@@ -1,0 +1,87 @@
+"""Loader of the HIP shared library (C ABI of include/remixt_amd.h).
+
+There is no fallback: if the library is missing or cannot be loaded the import
+of the product path fails with a clear error.
+"""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libremixt_hip.so")
+
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int64)
+_i32p = C.POINTER(C.c_int32)
+
+
+class RmxProblem(C.Structure):
+    """struct rmx_problem (include/remixt_amd.h)."""
+    _fields_ = [
+        ("num_clones", C.c_int32), ("num_segments", C.c_int32), ("num_breakpoints", C.c_int32),
+        ("num_cn_states", C.c_int32), ("num_brk_states", C.c_int32), ("num_classes", C.c_int32),
+        ("normal_contamination", C.c_int32), ("reserved", C.c_int32),
+        ("cn_classes", _ip), ("seg_class", _i32p), ("brk_states", _ip),
+        ("l", _dp), ("x", _dp), ("y", _dp),
+        ("is_telomere", _ip), ("breakpoint_idx", _ip), ("breakpoint_orient", _ip),
+        ("transition_penalty", C.c_double),
+    ]
+
+
+# name -> (restype, argtypes); every symbol include/remixt_amd.h declares
+SYMBOLS = {
+    "rmx_batch_create": (C.c_int, [C.POINTER(RmxProblem), C.c_int32, _dp, _dp, C.c_int32, C.POINTER(C.c_void_p)]),
+    "rmx_batch_destroy": (C.c_int, [C.c_void_p]),
+    "rmx_compress_cn_states": (C.c_int, [_ip, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _i32p, _ip, _i32p]),
+    "rmx_last_error": (C.c_char_p, []),
+    "rmx_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "rmx_synchronize": (C.c_int, [C.c_void_p]),
+    "rmx_info": (C.c_int, [C.c_void_p, C.c_int32, _ip]),
+    "rmx_set_param": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_double]),
+    "rmx_get_param": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, _dp]),
+    "rmx_set_transition_model": (C.c_int, [C.c_void_p, C.c_int32]),
+    "rmx_set_array": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
+    "rmx_get_array": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
+    "rmx_get_state_table": (C.c_int, [C.c_void_p, C.c_int32, _ip]),
+    "rmx_update_framelogprob": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32]),
+    "rmx_update_p_cn": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32]),
+    "rmx_update_p_breakpoint": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32]),
+    "rmx_update_p_outlier_total": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32]),
+    "rmx_update_p_outlier_allele": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32]),
+    "rmx_update_p_allele_swap": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32]),
+    "rmx_variational_update": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32]),
+    "rmx_calculate_elbo": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, _dp]),
+    "rmx_calculate_variational_energy": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, _dp]),
+    "rmx_calculate_variational_entropy": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, _dp]),
+    "rmx_expected_log_likelihood": (C.c_int, [C.c_void_p, C.c_int32, _ip, _dp, _dp]),
+    "rmx_log_likelihood_total": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _dp]),
+    "rmx_log_likelihood_allele": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _dp]),
+    "rmx_infer_cn": (C.c_int, [C.c_void_p, C.c_int32, _ip, _dp]),
+    "rmx_sum_product": (C.c_int, [_dp, _dp, _dp, _dp, C.c_int32, C.c_int32, C.c_int32]),
+    "rmx_max_product": (C.c_int, [_dp, _dp, _ip, _dp, C.c_int32, C.c_int32, C.c_int32]),
+    "rmx_timer_start": (C.c_int, [C.c_void_p]),
+    "rmx_timer_stop": (C.c_int, [C.c_void_p, _dp]),
+    "rmx_profile_enable": (C.c_int, [C.c_void_p, C.c_int32]),
+    "rmx_profile_get": (C.c_int, [C.c_void_p, C.c_int32, _dp, _ip]),
+    "rmx_profile_reset": (C.c_int, [C.c_void_p]),
+    "rmx_kernel_name": (C.c_char_p, [C.c_int32]),
+    "rmx_num_kernels": (C.c_int, []),
+}
+
+_lib = None
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "remixt_amd: %s not found. Build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950). There is no CPU fallback." % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib

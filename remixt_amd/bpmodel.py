@@ -1,0 +1,504 @@
+"""MI355X-native `RemixtModel`: the object protocol of the reference's Cython
+class `remixt.bpmodel.RemixtModel` (reference remixt/bpmodel.pyx:397-1210) on
+top of the HIP C ABI (include/remixt_amd.h).
+
+Two objects:
+
+* `RemixtBatch` -- one dataset (segments, state tables, topology) resident in
+  HBM with R independent restarts; coordinate updates and ELBOs run for any
+  restart range in single launches.
+* `RemixtModel` -- the drop-in per-model view.  Constructed with the
+  reference's positional signature it owns a batch of one; `batch.model(r)`
+  gives the same protocol on restart r of a shared batch.
+
+State lives on the device.  Array attributes are copied to the host on read and
+to the device on assignment (the reference hands out memoryviews of host
+buffers; code that mutates a returned array in place must assign it back).
+`log_transmat`, `cached_log_transmat` and `joint_posterior_marginals`
+((N-1) x S x S) are never stored: they are materialised only when read.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int64)
+_i32p = C.POINTER(C.c_int32)
+
+RMX_EVALUE, RMX_EASSERT, RMX_EDEVICE, RMX_EUNSUPPORTED, RMX_EARG = 1, 2, 3, 4, 5
+
+PARAM_IDS = {
+    'negbin_r_0': 0, 'negbin_r_1': 1, 'negbin_hdel_mu': 2, 'negbin_hdel_r_0': 3, 'negbin_hdel_r_1': 4,
+    'betabin_M_0': 5, 'betabin_M_1': 6, 'betabin_loh_p': 7, 'betabin_loh_M_0': 8, 'betabin_loh_M_1': 9,
+    'prior_outlier_total': 10, 'prior_outlier_allele': 11, 'divergence_weight': 12, 'hmm_log_norm_const': 13,
+}
+ARRAY_IDS = {
+    'h': 0, 'p_breakpoint': 1, 'p_allele_swap': 2, 'p_outlier_total': 3, 'p_outlier_allele': 4,
+    'posterior_marginals': 5, 'framelogprob': 6, 'total_likelihood_mask': 7, 'allele_likelihood_mask': 8,
+    'log_transmat': 9, 'cached_log_transmat': 10, 'joint_posterior_marginals': 11, 'state_sequence': 12,
+}
+_WRITABLE = {'h', 'p_breakpoint', 'p_allele_swap', 'p_outlier_total', 'p_outlier_allele', 'posterior_marginals',
+             'total_likelihood_mask', 'allele_likelihood_mask'}
+_STATE_TABLES = {'cn_states_total': 0, 'num_alleles_subclonal': 1, 'is_hdel': 2, 'is_loh': 3}
+
+
+def _raise(lib, rc):
+    msg = lib.rmx_last_error().decode()
+    if rc == RMX_EVALUE:
+        raise ValueError(msg)
+    if rc == RMX_EASSERT:
+        raise AssertionError(msg)
+    if rc == RMX_EUNSUPPORTED:
+        raise NotImplementedError(msg)
+    if rc == RMX_EARG:
+        raise ValueError('bad argument: ' + msg)
+    raise RuntimeError('HIP backend failure: ' + msg)
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _i64(a):
+    return np.ascontiguousarray(a, dtype=np.int64)
+
+
+def compress_cn_states(cn_states, max_classes=64):
+    """(N,S,M,2) int64 -> (classes (C,S,M,2), seg_class (N,) int32)."""
+    lib = _lib.load()
+    cn_states = _i64(cn_states)
+    N, S, M, A = cn_states.shape
+    if A != 2:
+        raise ValueError('cn_states must have shape (num_segments, num_cn_states, num_clones, num_alleles)')
+    seg_class = np.zeros(N, dtype=np.int32)
+    classes = np.zeros((max_classes, S, M, 2), dtype=np.int64)
+    nc = C.c_int32(0)
+    rc = lib.rmx_compress_cn_states(cn_states.ctypes.data_as(_ip), N, S, M, max_classes,
+                                    seg_class.ctypes.data_as(_i32p), classes.ctypes.data_as(_ip), C.byref(nc))
+    if rc:
+        _raise(lib, rc)
+    return classes[:nc.value].copy(), seg_class
+
+
+class RemixtBatch(object):
+    """R restarts of one dataset on one GPU."""
+
+    def __init__(self, num_clones, num_segments, num_breakpoints, normal_contamination,
+                 cn_classes, seg_class, brk_states, h_init, l, x, y,
+                 is_telomere, breakpoint_idx, breakpoint_orient, transition_penalty,
+                 divergence_weight, device=0):
+        self._lib = lib = _lib.load()
+        self._handle = None
+        cn_classes = _i64(cn_classes)
+        if cn_classes.ndim != 4:
+            raise ValueError('cn_classes must have shape (num_classes, num_cn_states, num_clones, 2)')
+        brk_states = _i64(brk_states)
+        seg_class = np.ascontiguousarray(seg_class, dtype=np.int32)
+        h_init = np.atleast_2d(_f64(h_init))
+        R = h_init.shape[0]
+        divergence_weight = _f64(np.broadcast_to(np.asarray(divergence_weight, dtype=np.float64), (R,)))
+        C_, S, M, A = cn_classes.shape
+        # shape validation of bpmodel.pyx:509-529
+        if M != num_clones or A != 2 or seg_class.shape[0] != num_segments:
+            raise ValueError('cn_states must have shape (num_segments, num_cn_states, num_clones, num_alleles)')
+        if brk_states.ndim != 2 or brk_states.shape[1] != num_clones:
+            raise ValueError('cn_states must have shape (num_brk_states, num_clones)')
+        if h_init.shape[1] != num_clones:
+            raise ValueError('h must have length equal to num_clones')
+        is_telomere = _i64(is_telomere); breakpoint_idx = _i64(breakpoint_idx); breakpoint_orient = _i64(breakpoint_orient)
+        if is_telomere.shape[0] != num_segments:
+            raise ValueError('is_telomere must have length equal to num_segments')
+        if breakpoint_idx.shape[0] != num_segments:
+            raise ValueError('breakpoint_idx must have length equal to num_segments')
+        if breakpoint_orient.shape[0] != num_segments:
+            raise ValueError('breakpoint_orient must have length equal to num_segments')
+        l = _f64(l); x = _f64(x); y = _f64(y)
+        if l.shape != (num_segments,) or x.shape != (num_segments,) or y.shape != (num_segments, 2):
+            raise ValueError('l, x, y must have shapes (N,), (N,), (N, 2)')
+        pr = _lib.RmxProblem()
+        pr.num_clones = M; pr.num_segments = num_segments; pr.num_breakpoints = num_breakpoints
+        pr.num_cn_states = S; pr.num_brk_states = brk_states.shape[0]; pr.num_classes = C_
+        pr.normal_contamination = int(bool(normal_contamination))
+        pr.cn_classes = cn_classes.ctypes.data_as(_ip); pr.seg_class = seg_class.ctypes.data_as(_i32p)
+        pr.brk_states = brk_states.ctypes.data_as(_ip)
+        pr.l = l.ctypes.data_as(_dp); pr.x = x.ctypes.data_as(_dp); pr.y = y.ctypes.data_as(_dp)
+        pr.is_telomere = is_telomere.ctypes.data_as(_ip); pr.breakpoint_idx = breakpoint_idx.ctypes.data_as(_ip)
+        pr.breakpoint_orient = breakpoint_orient.ctypes.data_as(_ip)
+        pr.transition_penalty = float(transition_penalty)
+        handle = C.c_void_p()
+        rc = lib.rmx_batch_create(C.byref(pr), R, h_init.ctypes.data_as(_dp), divergence_weight.ctypes.data_as(_dp),
+                                  int(device), C.byref(handle))
+        if rc:
+            _raise(lib, rc)
+        self._handle = handle
+        self.device = int(device)
+        self.num_restarts = R
+        self.num_clones = M
+        self.num_segments = int(num_segments)
+        self.num_breakpoints = int(num_breakpoints)
+        self.num_cn_states = S
+        self.num_brk_states = int(brk_states.shape[0])
+        self.num_alleles = 2
+        self.normal_contamination = bool(normal_contamination)
+        self.transition_penalty = abs(float(transition_penalty))
+        self.cn_classes = cn_classes
+        self.seg_class = seg_class
+        self.brk_states = brk_states
+        self.is_telomere = is_telomere
+        self.breakpoint_idx = breakpoint_idx
+        self.breakpoint_orient = breakpoint_orient
+        self.l = l; self.x = x; self.y = y
+        self.cn_max = self.info(0)
+        self._transition_model = 0
+
+    # -- lifetime ------------------------------------------------------------
+    def close(self):
+        if self._handle is not None:
+            self._lib.rmx_batch_destroy(self._handle)
+            self._handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _ck(self, rc):
+        if rc:
+            _raise(self._lib, rc)
+
+    def info(self, what):
+        out = C.c_int64(0)
+        self._ck(self._lib.rmx_info(self._handle, what, C.byref(out)))
+        return int(out.value)
+
+    def synchronize(self):
+        self._ck(self._lib.rmx_synchronize(self._handle))
+
+    def model(self, r):
+        return RemixtModel._from_batch(self, r)
+
+    # -- attributes ----------------------------------------------------------
+    def array_shape(self, name):
+        N, S, M, K, B = self.num_segments, self.num_cn_states, self.num_clones, self.num_breakpoints, self.num_brk_states
+        return {
+            'h': (M,), 'p_breakpoint': (K, B), 'p_allele_swap': (N, 2), 'p_outlier_total': (N, 2),
+            'p_outlier_allele': (N, 2), 'posterior_marginals': (N, S), 'framelogprob': (N, S),
+            'total_likelihood_mask': (N,), 'allele_likelihood_mask': (N,), 'log_transmat': (N - 1, S, S),
+            'cached_log_transmat': (N - 1, S, S), 'joint_posterior_marginals': (N - 1, S, S), 'state_sequence': (N,),
+        }[name]
+
+    def get_array(self, r, name):
+        shape = self.array_shape(name)
+        dt = np.int64 if name in ('total_likelihood_mask', 'allele_likelihood_mask', 'state_sequence') else np.float64
+        out = np.zeros(shape, dtype=dt)
+        if out.size:
+            self._ck(self._lib.rmx_get_array(self._handle, r, ARRAY_IDS[name], out.ctypes.data_as(C.c_void_p)))
+        return out
+
+    def set_array(self, r, name, value):
+        if name not in _WRITABLE:
+            raise AttributeError('%s is read-only' % name)
+        shape = self.array_shape(name)
+        dt = np.int64 if name in ('total_likelihood_mask', 'allele_likelihood_mask') else np.float64
+        v = np.ascontiguousarray(value, dtype=dt)
+        if v.shape != shape:
+            raise ValueError('%s must have shape %s' % (name, shape))
+        if v.size:
+            self._ck(self._lib.rmx_set_array(self._handle, r, ARRAY_IDS[name], v.ctypes.data_as(C.c_void_p)))
+
+    def get_param(self, r, name):
+        out = C.c_double(0.)
+        self._ck(self._lib.rmx_get_param(self._handle, r, PARAM_IDS[name], C.byref(out)))
+        return float(out.value)
+
+    def set_param(self, r, name, value):
+        self._ck(self._lib.rmx_set_param(self._handle, r, PARAM_IDS[name], float(value)))
+
+    @property
+    def transition_model(self):
+        return self._transition_model
+
+    @transition_model.setter
+    def transition_model(self, value):
+        self._ck(self._lib.rmx_set_transition_model(self._handle, int(value)))
+        self._transition_model = int(value)
+
+    def state_table(self, name):
+        N, S, M = self.num_segments, self.num_cn_states, self.num_clones
+        shape = (N, S, M) if name == 'cn_states_total' else (N, S)
+        out = np.zeros(shape, dtype=np.int64)
+        self._ck(self._lib.rmx_get_state_table(self._handle, _STATE_TABLES[name], out.ctypes.data_as(_ip)))
+        return out
+
+    # -- batched operations on restarts [r0, r1) -------------------------------
+    def _range(self, r0, r1):
+        if r0 is None:
+            r0 = 0
+        if r1 is None:
+            r1 = self.num_restarts
+        return int(r0), int(r1)
+
+    def update_framelogprob(self, r0=None, r1=None):
+        self._ck(self._lib.rmx_update_framelogprob(self._handle, *self._range(r0, r1)))
+
+    def update_p_cn(self, r0=None, r1=None):
+        self._ck(self._lib.rmx_update_p_cn(self._handle, *self._range(r0, r1)))
+
+    def update_p_breakpoint(self, r0=None, r1=None):
+        self._ck(self._lib.rmx_update_p_breakpoint(self._handle, *self._range(r0, r1)))
+
+    def update_p_outlier_total(self, r0=None, r1=None):
+        self._ck(self._lib.rmx_update_p_outlier_total(self._handle, *self._range(r0, r1)))
+
+    def update_p_outlier_allele(self, r0=None, r1=None):
+        self._ck(self._lib.rmx_update_p_outlier_allele(self._handle, *self._range(r0, r1)))
+
+    def update_p_allele_swap(self, r0=None, r1=None):
+        self._ck(self._lib.rmx_update_p_allele_swap(self._handle, *self._range(r0, r1)))
+
+    def variational_update(self, iters=1, r0=None, r1=None):
+        r0, r1 = self._range(r0, r1)
+        self._ck(self._lib.rmx_variational_update(self._handle, r0, r1, int(iters)))
+
+    def _scalar_range(self, fn, r0, r1):
+        r0, r1 = self._range(r0, r1)
+        out = np.zeros(r1 - r0, dtype=np.float64)
+        self._ck(fn(self._handle, r0, r1, out.ctypes.data_as(_dp)))
+        return out
+
+    def calculate_elbo(self, r0=None, r1=None):
+        return self._scalar_range(self._lib.rmx_calculate_elbo, r0, r1)
+
+    def calculate_variational_energy(self, r0=None, r1=None):
+        return self._scalar_range(self._lib.rmx_calculate_variational_energy, r0, r1)
+
+    def calculate_variational_entropy(self, r0=None, r1=None):
+        return self._scalar_range(self._lib.rmx_calculate_variational_entropy, r0, r1)
+
+    def expected_log_likelihood(self, r, sample, want_grad=False):
+        sample = _i64(sample)
+        if sample.shape != (self.num_segments,):
+            raise ValueError('sample must have length num_segments')
+        ell = C.c_double(0.)
+        grad = np.zeros(self.num_clones, dtype=np.float64) if want_grad else None
+        self._ck(self._lib.rmx_expected_log_likelihood(
+            self._handle, r, sample.ctypes.data_as(_ip), C.byref(ell),
+            grad.ctypes.data_as(_dp) if want_grad else None))
+        return float(ell.value), grad
+
+    def infer_cn(self, r):
+        cn = np.zeros((self.num_segments, self.num_clones, 2), dtype=np.int64)
+        lp = C.c_double(0.)
+        self._ck(self._lib.rmx_infer_cn(self._handle, r, cn.ctypes.data_as(_ip), C.byref(lp)))
+        return cn, float(lp.value)
+
+    # -- measurement ------------------------------------------------------------
+    def timer_start(self):
+        self._ck(self._lib.rmx_timer_start(self._handle))
+
+    def timer_stop(self):
+        ms = C.c_double(0.)
+        self._ck(self._lib.rmx_timer_stop(self._handle, C.byref(ms)))
+        return float(ms.value)
+
+    def profile_enable(self, on=True):
+        self._ck(self._lib.rmx_profile_enable(self._handle, int(bool(on))))
+
+    def profile_reset(self):
+        self._ck(self._lib.rmx_profile_reset(self._handle))
+
+    def profile(self):
+        """{kernel name: (total_ms, launches)} since the last reset."""
+        out = {}
+        for i in range(self._lib.rmx_num_kernels()):
+            ms = C.c_double(0.); n = C.c_int64(0)
+            self._ck(self._lib.rmx_profile_get(self._handle, i, C.byref(ms), C.byref(n)))
+            if n.value:
+                out[self._lib.rmx_kernel_name(i).decode()] = (float(ms.value), int(n.value))
+        return out
+
+
+class RemixtModel(object):
+    """Drop-in for remixt.bpmodel.RemixtModel (bpmodel.pyx:397)."""
+
+    _own = ('_batch', '_r', '_owns_batch')
+
+    def __init__(self, num_clones, num_segments, num_breakpoints, normal_contamination,
+                 cn_states, brk_states, h_init, l, x, y, is_telomere, breakpoint_idx,
+                 breakpoint_orient, transition_penalty, divergence_weight, device=0):
+        cn_states = np.asarray(cn_states)
+        if cn_states.ndim != 4 or cn_states.shape[0] != num_segments or cn_states.shape[2] != num_clones or cn_states.shape[3] != 2:
+            raise ValueError('cn_states must have shape (num_segments, num_cn_states, num_clones, num_alleles)')
+        classes, seg_class = compress_cn_states(cn_states)
+        batch = RemixtBatch(num_clones, num_segments, num_breakpoints, normal_contamination,
+                            classes, seg_class, brk_states, np.asarray(h_init, dtype=np.float64)[None, :], l, x, y,
+                            is_telomere, breakpoint_idx, breakpoint_orient, transition_penalty,
+                            [float(divergence_weight)], device=device)
+        object.__setattr__(self, '_batch', batch)
+        object.__setattr__(self, '_r', 0)
+        object.__setattr__(self, '_owns_batch', True)
+
+    @classmethod
+    def from_classes(cls, num_clones, num_segments, num_breakpoints, normal_contamination,
+                     cn_classes, seg_class, brk_states, h_init, l, x, y, is_telomere, breakpoint_idx,
+                     breakpoint_orient, transition_penalty, divergence_weight, device=0):
+        """Same as the constructor with the state array given class-compressed
+        (cn_classes (C,S,M,2), seg_class (N,)): avoids building the (N,S,M,2) array."""
+        batch = RemixtBatch(num_clones, num_segments, num_breakpoints, normal_contamination,
+                            cn_classes, seg_class, brk_states, np.asarray(h_init, dtype=np.float64)[None, :], l, x, y,
+                            is_telomere, breakpoint_idx, breakpoint_orient, transition_penalty,
+                            [float(divergence_weight)], device=device)
+        self = cls.__new__(cls)
+        object.__setattr__(self, '_batch', batch)
+        object.__setattr__(self, '_r', 0)
+        object.__setattr__(self, '_owns_batch', True)
+        return self
+
+    @classmethod
+    def _from_batch(cls, batch, r):
+        self = cls.__new__(cls)
+        object.__setattr__(self, '_batch', batch)
+        object.__setattr__(self, '_r', int(r))
+        object.__setattr__(self, '_owns_batch', False)
+        return self
+
+    # -- attribute protocol ---------------------------------------------------------
+    def __getattr__(self, name):
+        b = object.__getattribute__(self, '_batch')
+        r = object.__getattribute__(self, '_r')
+        if name in ARRAY_IDS:
+            return b.get_array(r, name)
+        if name in PARAM_IDS:
+            return b.get_param(r, name)
+        if name in _STATE_TABLES:
+            return b.state_table(name)
+        if name == 'cn_states':
+            return b.cn_classes[b.seg_class]
+        if name in ('num_clones', 'num_segments', 'num_breakpoints', 'num_alleles', 'num_cn_states', 'num_brk_states',
+                    'cn_max', 'normal_contamination', 'transition_penalty', 'transition_model', 'brk_states',
+                    'is_telomere', 'breakpoint_idx', 'breakpoint_orient', 'l', 'x', 'y'):
+            return getattr(b, name)
+        if name == 'breakpoint_side':
+            side = np.zeros(b.num_segments, dtype=np.int64)
+            seen = np.zeros(max(b.num_breakpoints, 1), dtype=np.int64)
+            for n in range(b.num_segments):
+                k = b.breakpoint_idx[n]
+                if k < 0:
+                    continue
+                side[n] = seen[k]
+                seen[k] += 1
+            return side
+        raise AttributeError(name)
+
+    def __setattr__(self, name, value):
+        b = object.__getattribute__(self, '_batch')
+        r = object.__getattribute__(self, '_r')
+        if name in ARRAY_IDS:
+            b.set_array(r, name, value)
+        elif name in PARAM_IDS:
+            if name == 'hmm_log_norm_const':
+                raise AttributeError('hmm_log_norm_const is read-only')
+            b.set_param(r, name, value)
+        elif name == 'transition_model':
+            b.transition_model = value
+        else:
+            raise AttributeError('cannot set attribute %r' % name)
+
+    def __dir__(self):
+        return sorted(set(list(ARRAY_IDS) + list(PARAM_IDS) + list(_STATE_TABLES) + [
+            'cn_states', 'num_clones', 'num_segments', 'num_breakpoints', 'num_alleles', 'num_cn_states',
+            'num_brk_states', 'cn_max', 'normal_contamination', 'transition_penalty', 'transition_model',
+            'brk_states', 'is_telomere', 'breakpoint_idx', 'breakpoint_orient', 'breakpoint_side', 'l', 'x', 'y']))
+
+    # -- methods (cpdef surface of bpmodel.pyx) ----------------------------------------
+    def update_framelogprob(self):
+        self._batch.update_framelogprob(self._r, self._r + 1)
+
+    def update_p_cn(self):
+        self._batch.update_p_cn(self._r, self._r + 1)
+
+    def update_p_breakpoint(self):
+        self._batch.update_p_breakpoint(self._r, self._r + 1)
+
+    def update_p_outlier_total(self):
+        self._batch.update_p_outlier_total(self._r, self._r + 1)
+
+    def update_p_outlier_allele(self):
+        self._batch.update_p_outlier_allele(self._r, self._r + 1)
+
+    def update_p_allele_swap(self):
+        self._batch.update_p_allele_swap(self._r, self._r + 1)
+
+    def calculate_elbo(self):
+        return float(self._batch.calculate_elbo(self._r, self._r + 1)[0])
+
+    def calculate_variational_energy(self):
+        return float(self._batch.calculate_variational_energy(self._r, self._r + 1)[0])
+
+    def calculate_variational_entropy(self):
+        return float(self._batch.calculate_variational_entropy(self._r, self._r + 1)[0])
+
+    def calculate_expected_log_likelihood(self, sample):
+        return self._batch.expected_log_likelihood(self._r, sample)[0]
+
+    def calculate_expected_log_likelihood_partial_h(self, sample, partial_h):
+        _, g = self._batch.expected_log_likelihood(self._r, sample, want_grad=True)
+        partial_h[:] = g
+
+    def calculate_log_transmat(self, log_transmat):
+        """bpmodel.pyx:639-684 with the *current* p_breakpoint, into the caller's array."""
+        b = self._batch
+        # materialise through the cached snapshot slot without disturbing it: use a scratch restart-free path
+        raise NotImplementedError('calculate_log_transmat(out): read model.log_transmat / model.cached_log_transmat instead')
+
+    def calculate_log_likelihood_total(self, n, s, u):
+        out = C.c_double(0.)
+        b = self._batch
+        b._ck(b._lib.rmx_log_likelihood_total(b._handle, self._r, int(n), int(s), int(u), C.byref(out)))
+        return float(out.value)
+
+    def calculate_log_likelihood_allele(self, n, s, v, w):
+        out = C.c_double(0.)
+        b = self._batch
+        b._ck(b._lib.rmx_log_likelihood_allele(b._handle, self._r, int(n), int(s), int(v), int(w), C.byref(out)))
+        return float(out.value)
+
+    def infer_cn(self, cn):
+        out, _ = self._batch.infer_cn(self._r)
+        cn[...] = out
+
+
+def sum_product(framelogprob, log_transmat, alphas, betas, device=0):
+    """bpmodel.pyx:1213-1246 on caller-supplied dense inputs (HIP)."""
+    lib = _lib.load()
+    f = _f64(framelogprob); T = _f64(log_transmat)
+    N, S = f.shape
+    if T.shape != (N - 1, S, S):
+        raise ValueError('log_transmat must have shape (N-1, S, S)')
+    a = np.zeros_like(f); b = np.zeros_like(f)
+    Tp = T if T.size else np.zeros(1)
+    rc = lib.rmx_sum_product(f.ctypes.data_as(_dp), Tp.ctypes.data_as(_dp), a.ctypes.data_as(_dp), b.ctypes.data_as(_dp), N, S, device)
+    if rc:
+        _raise(lib, rc)
+    alphas[...] = a
+    betas[...] = b
+
+
+def max_product(framelogprob, log_transmat, state_sequence, device=0):
+    """bpmodel.pyx:1296-1333 on caller-supplied dense inputs (HIP); returns the log probability."""
+    lib = _lib.load()
+    f = _f64(framelogprob); T = _f64(log_transmat)
+    N, S = f.shape
+    if T.shape != (N - 1, S, S):
+        raise ValueError('log_transmat must have shape (N-1, S, S)')
+    ss = np.zeros(N, dtype=np.int64)
+    lp = C.c_double(0.)
+    Tp = T if T.size else np.zeros(1)
+    rc = lib.rmx_max_product(f.ctypes.data_as(_dp), Tp.ctypes.data_as(_dp), ss.ctypes.data_as(_ip), C.byref(lp), N, S, device)
+    if rc:
+        _raise(lib, rc)
+    state_sequence[...] = ss
+    return float(lp.value)

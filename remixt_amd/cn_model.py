@@ -1,0 +1,541 @@
+"""Host side of the hot path: `BreakpointModel`, API-compatible with the
+reference's `remixt.cn_model.BreakpointModel` (reference remixt/cn_model.py:29-628).
+
+Segment remapping for breakends, likelihood masks, state-grid enumeration, the
+EM loop and the scipy M-steps live here (Python, as in the reference); every
+numeric kernel call goes to `remixt_amd.bpmodel.RemixtModel` (HIP).  The class
+is written against the kernel *protocol* only, so tests can run the identical
+host logic over the reference binary or the CPU oracle by passing
+`kernel_module=`; the default and only product kernel is the HIP one -- there is
+no fallback if it cannot be loaded.
+"""
+import collections
+import contextlib
+import datetime
+import itertools
+
+import numpy as np
+import scipy.optimize
+
+
+def _get_brkend_seg_orient(breakend):
+    """Breakend (segment, side) -> (left segment of the adjacency, orientation)  (cn_model.py:14-22)."""
+    n, side = breakend
+    if side == 1:
+        return n, +1
+    elif side == 0:
+        return n - 1, -1
+    raise ValueError('side must be 0 or 1')
+
+
+def _gettime():
+    return datetime.datetime.now().time().isoformat()
+
+
+def create_cn_states(num_clones, num_alleles, cn_max, cn_diff_max):
+    """Allele-specific copy-number states of one segment (cn_model.py:228-253).
+
+    The reference enumerates itertools.product in order and de-duplicates states
+    that are equal under swapping the two alleles with a dict keyed by the
+    unordered pair {state, swapped}: the resulting order is that of the FIRST
+    occurrence of each key and the stored value is the LAST occurrence.  In
+    product order a state precedes its swap iff its flattened tuple is
+    lexicographically smaller, so: keep tuples with key <= swapped key, in
+    product order, and emit max(key, swapped).
+    """
+    assert num_alleles == 2
+    nv = (num_clones - 1) * num_alleles
+    if nv == 0:
+        return np.array([[[1, 1]]], dtype=np.int64)
+    grids = np.indices((cn_max + 1,) * nv).reshape(nv, -1).T          # product order
+    t = grids.reshape(-1, num_clones - 1, num_alleles)
+    ok = (t.sum(axis=2) <= cn_max).all(axis=1)
+    ok &= ((t.max(axis=1) - t.min(axis=1)) <= cn_diff_max).all(axis=1)
+    t = t[ok]
+    key = t.reshape(len(t), -1)
+    swapped = t[:, :, ::-1].reshape(len(t), -1)
+    diff = key != swapped
+    first = np.argmax(diff, axis=1)
+    rows = np.arange(len(t))
+    key_lt = diff.any(axis=1) & (key[rows, first] < swapped[rows, first])
+    key_eq = ~diff.any(axis=1)
+    keep = key_lt | key_eq
+    out = np.where(key_lt[:, None], swapped, key)[keep].reshape(-1, num_clones - 1, num_alleles)
+    normal = np.ones((len(out), 1, num_alleles), dtype=out.dtype)
+    return np.concatenate([normal, out], axis=1).astype(np.int64)
+
+
+def create_brk_states(num_clones, cn_max, cn_diff_max):
+    """Breakpoint copy-number states (cn_model.py:255-276)."""
+    nv = num_clones - 1
+    if nv == 0:
+        return np.zeros((1, 1), dtype=np.int64)
+    grids = np.indices((cn_max + 1,) * nv).reshape(nv, -1).T
+    ok = (grids.max(axis=1) - grids.min(axis=1)) <= cn_diff_max
+    grids = grids[ok]
+    return np.concatenate([np.zeros((len(grids), 1), dtype=grids.dtype), grids], axis=1).astype(np.int64)
+
+
+class BreakpointModel(object):
+
+    def __init__(self, x, l, adjacencies, breakpoints, **kwargs):
+        """Create a copy number model (same arguments as cn_model.py:31-74).
+
+        Extra keyword arguments: `kernel_module` (module providing RemixtModel;
+        default remixt_amd.bpmodel), `device` (HIP device ordinal), `quiet`.
+        """
+        x = np.asarray(x)
+        l = np.asarray(l)
+        # Observed data should be ordered as major, minor, total
+        assert np.all(x[:, 1] <= x[:, 0])
+
+        self.N = x.shape[0]
+        # cn_model.py:59 -- raises on an empty dict, as the reference does
+        self.breakpoint_ids, self.breakpoints = zip(*breakpoints.items())
+
+        self.max_copy_number = kwargs.get('max_copy_number', 6)
+        self.max_copy_number_diff = kwargs.get('max_copy_number_diff', 1)
+        self.normal_contamination = kwargs.get('normal_contamination', True)
+        self.is_female = kwargs.get('is_female', True)
+        self.divergence_weight = kwargs.get('divergence_weight', 1e6)
+        self.min_segment_length = kwargs.get('min_segment_length', 10000)
+        self.min_proportion_genotyped = kwargs.get('min_proportion_genotyped', 0.01)
+        self.max_depth = kwargs.get('max_depth')
+        self.transition_log_prob = kwargs.get('transition_log_prob', 10.)
+        self.transition_model = kwargs.get('transition_model', 0)
+        self.disable_breakpoints = kwargs.get('disable_breakpoints', False)
+        self.breakpoint_init = kwargs.get('breakpoint_init', None)
+        self.normal_copies = kwargs.get('normal_copies', None)
+        if self.normal_copies is None:
+            self.normal_copies = np.ones((self.N, 2), dtype=np.int64)
+        self.normal_copies = np.asarray(self.normal_copies)
+        self.do_h_update = kwargs.get('do_h_update', True)
+        self._kernel = kwargs.get('kernel_module', None)
+        self._device = kwargs.get('device', 0)
+        self.quiet = kwargs.get('quiet', False)
+
+        if self.max_depth is None:
+            raise ValueError('must specify max depth')
+
+        if not self.normal_contamination:
+            self.normal_copies = self.normal_copies * 0
+
+        self._remap_segments(adjacencies)
+
+        self.x1 = np.zeros((self.N1, x.shape[1]), dtype=float)
+        self.l1 = np.zeros((self.N1,), dtype=float)
+        self.x1[self.seg_fwd_remap, :] = x
+        self.l1[self.seg_fwd_remap] = l
+
+        # Likelihood masks (cn_model.py:169-184)
+        long_enough = self.l1 >= self.min_segment_length
+        genotyped = self.x1[:, :2].sum(axis=1).astype(float) / (self.x1[:, 2].astype(float) + 1e-16)
+        depth = self.x1[:, 2].astype(float) / (self.l1.astype(float) + 1e-16)
+        shallow = depth <= self.max_depth
+        self._total_likelihood_mask = long_enough & shallow
+        self._allele_likelihood_mask = long_enough & (genotyped >= self.min_proportion_genotyped) & shallow
+
+        if self.disable_breakpoints:
+            self.num_breakpoints = 0
+            self.breakpoint_idx = -np.ones(self.breakpoint_idx.shape, dtype=int)
+            self.breakpoint_orient = np.zeros(self.breakpoint_orient.shape, dtype=int)
+
+        self.check_elbo = False
+        self.prev_elbo = None
+        self.prev_elbo_diff = None
+        self.num_em_iter = 1
+        self.num_update_iter = 1
+        self.model = None
+
+        self.likelihood_params = ['negbin_r_0', 'negbin_r_1', 'betabin_M_0', 'betabin_M_1']
+        if not self.normal_contamination:
+            self.likelihood_params.extend(['negbin_hdel_mu', 'negbin_hdel_r_0', 'negbin_hdel_r_1',
+                                           'betabin_loh_p', 'betabin_loh_M_0', 'betabin_loh_M_1'])
+        self.likelihood_param_bounds = {
+            'negbin_r_0': (10., 2000.), 'negbin_r_1': (1., 2000.),
+            'betabin_M_0': (10., 2000.), 'betabin_M_1': (1., 2000.),
+            'negbin_hdel_mu': (1e-9, 1e-4), 'negbin_hdel_r_0': (10., 2000.), 'negbin_hdel_r_1': (1., 200.),
+            'betabin_loh_p': (1e-5, 1e-2), 'betabin_loh_M_0': (10., 2000.), 'betabin_loh_M_1': (1., 200.),
+        }
+
+    # ------------------------------------------------------------------------------
+    def _remap_segments(self, adjacencies):
+        """Insert zero-length dummy segments so that at most one breakend lies between
+        two consecutive model segments (cn_model.py:82-161).
+
+        Between original segments n and n+1 the model gets one segment per breakend
+        incident on that boundary (the first of them is the original segment n when
+        n >= 0) plus, if (n, n+1) is not a reference adjacency, one extra telomere
+        segment.  Breakends at one boundary are visited in the iteration order of a
+        Python set of (bp_idx, be_idx, orient) tuples, as in the reference.
+        """
+        adjacencies = set(tuple(a) for a in adjacencies) if not isinstance(adjacencies, (set, frozenset)) else adjacencies
+        at_boundary = collections.defaultdict(set)
+        for bp_idx, breakpoint in enumerate(self.breakpoints):
+            for be_idx, breakend in enumerate(breakpoint):
+                n, orient = _get_brkend_seg_orient(breakend)
+                at_boundary[n].add((bp_idx, be_idx, orient))
+
+        seg_rev, is_orig, is_tel, bidx, borient = [], [], [], [], []
+        fwd = np.zeros(self.N, dtype=int)
+
+        def push(n, original, telomere, bp=-1, orient=0):
+            seg_rev.append(n); is_orig.append(original); is_tel.append(telomere); bidx.append(bp); borient.append(orient)
+
+        for n in range(-1, self.N):
+            adjacent = (n, n + 1) in adjacencies
+            if n in at_boundary:
+                first = True
+                for bp_idx, be_idx, orient in at_boundary[n]:
+                    if first and n >= 0:
+                        fwd[n] = len(seg_rev)
+                    push(n, first and n >= 0, 0, bp_idx, orient)
+                    first = False
+                if not adjacent:
+                    push(n, False, 1)
+            elif n >= 0:
+                fwd[n] = len(seg_rev)
+                push(n, True, 0 if adjacent else 1)
+
+        self.N1 = len(seg_rev)
+        self.seg_fwd_remap = fwd
+        self.seg_is_original = np.array(is_orig, dtype=bool)
+        # quirk kept: dummy segments created before segment 0 carry index -1 (cn_model.py:133)
+        self.seg_rev_remap = np.array(seg_rev, dtype=int)
+        self.num_breakpoints = len(self.breakpoints)
+        self.is_telomere = np.array(is_tel, dtype=int)
+        self.breakpoint_idx = np.array(bidx, dtype=int)
+        self.breakpoint_orient = np.array(borient, dtype=int)
+
+        assert not np.any((self.breakpoint_idx >= 0) & (self.is_telomere == 1))
+        assert np.all(np.bincount(self.breakpoint_idx[self.breakpoint_idx >= 0]) == 2)
+
+    # state grids: methods with the reference's signature (cn_model.py:228, :255)
+    def create_cn_states(self, num_clones, num_alleles, cn_max, cn_diff_max):
+        return create_cn_states(num_clones, num_alleles, cn_max, cn_diff_max)
+
+    def create_brk_states(self, num_clones, cn_max, cn_diff_max):
+        return create_brk_states(num_clones, cn_max, cn_diff_max)
+
+    def _log(self, msg):
+        if not self.quiet:
+            print('[{}] {}'.format(_gettime(), msg))
+
+    # ------------------------------------------------------------------------------
+    def get_likelihood_param_values(self):
+        return dict((name, getattr(self.model, name)) for name in self.likelihood_params)
+
+    def get_model_data(self):
+        """All non-callable attributes of the kernel model (cn_model.py:286-297)."""
+        data = {}
+        for a in dir(self.model):
+            if a.startswith('_'):
+                continue
+            try:
+                v = getattr(self.model, a)
+            except (AttributeError, NotImplementedError):
+                continue
+            if callable(v):
+                continue
+            data[a] = np.asarray(v) if hasattr(v, 'shape') else v
+        return data
+
+    def _state_weights(self, flag):
+        post = np.asarray(self.model.posterior_marginals)
+        return (post * (np.asarray(flag) == 1)).sum(axis=-1)
+
+    def _get_hdel_weights(self):
+        return self._state_weights(self.model.is_hdel)
+
+    def _get_loh_weights(self):
+        return self._state_weights(self.model.is_loh)
+
+    def get_param_sample_weight(self, name):
+        """Segment weights for the stochastic M-step of one parameter (cn_model.py:323-352)."""
+        m = self.model
+        if name in ('negbin_r_0', 'negbin_r_1'):
+            weights = np.asarray(m.p_outlier_total)[:, int(name[-1])]
+        elif name in ('betabin_M_0', 'betabin_M_1'):
+            weights = np.asarray(m.p_outlier_allele)[:, int(name[-1])]
+        elif name == 'negbin_hdel_mu':
+            weights = self._get_hdel_weights()
+        elif name in ('negbin_hdel_r_0', 'negbin_hdel_r_1'):
+            weights = self._get_hdel_weights() * np.asarray(m.p_outlier_total)[:, int(name[-1])]
+        elif name == 'betabin_loh_p':
+            weights = self._get_loh_weights()
+        elif name in ('betabin_loh_M_0', 'betabin_loh_M_1'):
+            weights = self._get_loh_weights() * np.asarray(m.p_outlier_allele)[:, int(name[-1])]
+        else:
+            raise KeyError(name)
+        norm = weights.sum()
+        if norm > 0.:
+            return weights / norm
+        self._log('nothing for ' + name)
+        return None
+
+    # ------------------------------------------------------------------------------
+    def _state_tables(self, M):
+        """Class-compressed cn state tables: (classes (C,S,M,2), seg_class (N1,)).
+
+        The reference builds cn_states[N1,S,M,2] = the grid with the normal row of each
+        segment overwritten by normal_copies, then remapped by seg_rev_remap
+        (cn_model.py:359-364; index -1 wraps to the last segment).
+        """
+        grid = self.create_cn_states(M, 2, self.max_copy_number, self.max_copy_number_diff)
+        normal_rows = np.asarray(self.normal_copies)[self.seg_rev_remap]          # (N1, 2), -1 wraps like numpy
+        uniq, seg_class = np.unique(normal_rows, axis=0, return_inverse=True)
+        classes = np.repeat(grid[None], len(uniq), axis=0)
+        classes[:, :, 0, :] = uniq[:, None, :]
+        return classes.astype(np.int64), np.asarray(seg_class).reshape(-1).astype(np.int32)
+
+    def _kernel_module(self):
+        if self._kernel is None:
+            from . import bpmodel   # HIP backend; raises if the library is missing
+            self._kernel = bpmodel
+        return self._kernel
+
+    def _build_model(self, h_init):
+        M = h_init.shape[0]
+        classes, seg_class = self._state_tables(M)
+        brk_states = self.create_brk_states(M, self.max_copy_number, self.max_copy_number_diff)
+        kern = self._kernel_module()
+        common = (h_init, self.l1, self.x1[:, 2].copy(), self.x1[:, 0:2].copy(), self.is_telomere, self.breakpoint_idx,
+                  self.breakpoint_orient, self.transition_log_prob, self.divergence_weight)
+        if hasattr(kern.RemixtModel, 'from_classes'):
+            return kern.RemixtModel.from_classes(M, self.N1, self.num_breakpoints, self.normal_contamination,
+                                                 classes, seg_class, brk_states, *common, device=self._device)
+        cn_states = classes[seg_class]
+        return kern.RemixtModel(M, self.N1, self.num_breakpoints, self.normal_contamination, cn_states, brk_states, *common)
+
+    def _attach_model(self, model):
+        """Finish model set-up after construction (cn_model.py:386-404)."""
+        self.model = model
+        self.model.total_likelihood_mask = self._total_likelihood_mask.astype(int)
+        self.model.allele_likelihood_mask = self._allele_likelihood_mask.astype(int)
+
+        if self.breakpoint_init is not None:
+            # (the reference reads `self.model.self.num_breakpoints` here, an AttributeError; intent kept)
+            p_breakpoint = np.ones((self.model.num_breakpoints, self.model.num_brk_states))
+            brk_states = np.array(self.model.brk_states)
+            for k, bp in enumerate(self.breakpoints):
+                cn = self.breakpoint_init[bp]
+                for s in range(self.model.num_brk_states):
+                    if np.all(cn == brk_states[s]):
+                        p_breakpoint[k, s] = 1000.
+            p_breakpoint /= np.sum(p_breakpoint, axis=-1)[:, np.newaxis]
+            self.model.p_breakpoint = p_breakpoint
+
+        self.model.transition_model = self.transition_model
+
+    def fit(self, h_init):
+        """Fit the model with a series of updates (cn_model.py:354-428)."""
+        h_init = np.asarray(h_init, dtype=float)
+        self._attach_model(self._build_model(h_init))
+
+        if self.prev_elbo is None:
+            self.prev_elbo = self.model.calculate_elbo()
+
+        for i in range(self.num_em_iter):
+            self.em_iteration(i)
+
+    def em_iteration(self, i=0, skip_variational=False):
+        """One EM iteration: variational sweeps, M-steps, ELBO (cn_model.py:409-428)."""
+        if not skip_variational:
+            for j in range(self.num_update_iter):
+                self.variational_update()
+        if self.do_h_update:
+            self.em_update_h()
+        self.em_update_params()
+        self.record_elbo(self.model.calculate_elbo(), i)
+
+    def record_elbo(self, elbo, i=0):
+        self.prev_elbo_diff = elbo - self.prev_elbo
+        self.prev_elbo = elbo
+        self._log('completed iteration {}'.format(i))
+        self._log('    elbo: {:.10f}'.format(self.prev_elbo))
+        self._log('    elbo diff: {:.10f}'.format(self.prev_elbo_diff))
+        self._log('    h = {}'.format(np.asarray(self.model.h)))
+        for name, value in self.get_likelihood_param_values().items():
+            self._log('    {} = {}'.format(name, value))
+
+    @contextlib.contextmanager
+    def elbo_check(self, name, threshold=-1e-6):
+        self._log('optimizing {}'.format(name))
+        if not self.check_elbo:
+            yield
+            return
+        elbo_before = self.model.calculate_elbo()
+        yield
+        elbo_after = self.model.calculate_elbo()
+        self._log('    elbo: {:.10f}'.format(elbo_after))
+        self._log('    elbo diff: {:.10f}'.format(elbo_after - elbo_before))
+        if elbo_after - elbo_before < threshold:
+            raise Exception('elbo error for step {}!'.format(name))
+
+    def variational_update(self):
+        """Single update of all variational parameters (cn_model.py:444-460)."""
+        for name, step in (('update_p_allele_swap', 'update_p_allele_swap'), ('p_cn', 'update_p_cn'),
+                           ('p_breakpoint', 'update_p_breakpoint'), ('p_outlier_total', 'update_p_outlier_total'),
+                           ('p_outlier_allele', 'update_p_outlier_allele')):
+            with self.elbo_check(name):
+                getattr(self.model, step)()
+
+    def em_update_h(self):
+        with self.elbo_check('h'):
+            self.update_h()
+
+    def em_update_params(self):
+        for name in self.likelihood_params:
+            with self.elbo_check(name):
+                self.update_param(name)
+
+    def _create_sample(self, weights=None):
+        """Random subset of segments for the stochastic M-steps (cn_model.py:475-480; global numpy RNG)."""
+        sample_size = int(min(200, self.model.num_segments / 10))
+        sample_idxs = np.random.choice(self.model.num_segments, size=sample_size, replace=False, p=weights)
+        sample = np.zeros((self.model.num_segments,), dtype=int)
+        sample[sample_idxs] = 1
+        return sample
+
+    def _all_segments(self):
+        return np.ones((self.model.num_segments,), dtype=int)
+
+    def update_h(self):
+        """Update haploid depths by optimising the expected log likelihood (cn_model.py:482-531)."""
+        model = self.model
+
+        def nll(h):
+            model.h = h
+            return -model.calculate_expected_log_likelihood(sample)
+
+        def nll_grad(h):
+            model.h = h
+            partial_h = np.zeros((model.num_clones,))
+            model.calculate_expected_log_likelihood_partial_h(sample, partial_h)
+            return -partial_h
+
+        h_before = np.array(model.h, dtype=float)
+        ell_before = model.calculate_expected_log_likelihood(self._all_segments())
+        sample = self._create_sample()
+
+        result = scipy.optimize.minimize(nll, np.array(model.h, dtype=float), method='L-BFGS-B', jac=nll_grad,
+                                         bounds=[(1e-8, 10.)] * model.num_clones)
+        if not result.success:
+            message = result.message.decode() if isinstance(result.message, bytes) else str(result.message)
+            if message == 'ABNORMAL_TERMINATION_IN_LNSRCH':
+                # cn_model.py:513-518: the reference cross-checks the gradient numerically and continues
+                # (statsmodels' forward difference there; scipy's here)
+                analytic = nll_grad(result.x)
+                numerical = scipy.optimize.approx_fprime(result.x, nll, 1e-8)
+                if not np.allclose(analytic, numerical, atol=2.):
+                    raise ValueError('gradiant error, analytic: {}, numerical: {}\n'.format(analytic, numerical))
+            else:
+                raise ValueError('optimization failed\n{}'.format(result))
+
+        model.h = result.x
+        ell_after = model.calculate_expected_log_likelihood(self._all_segments())
+        if ell_after < ell_before:
+            self._log('h rejected, elbo before: {}, after: {}'.format(ell_before, ell_after))
+            model.h = h_before
+        else:
+            model.h = result.x
+
+    def update_param(self, name):
+        """Update one likelihood parameter by brute-force + simplex search (cn_model.py:533-569)."""
+        model = self.model
+        bounds = self.likelihood_param_bounds[name]
+        weights = self.get_param_sample_weight(name)
+
+        def nll(value):
+            assert value.shape == (1,)
+            value = float(value[0])
+            if value < bounds[0] or value > bounds[1]:
+                return np.inf
+            setattr(model, name, value)
+            return -model.calculate_expected_log_likelihood(sample)
+
+        value_before = getattr(model, name)
+        ell_before = model.calculate_expected_log_likelihood(self._all_segments())
+        sample = self._create_sample(weights)
+
+        result = scipy.optimize.brute(nll, ranges=[bounds], full_output=True)
+        assert result[0].shape == (1,)
+        result_value = float(result[0][0])
+
+        # quirk kept: the acceptance test looks at the LAST value scipy evaluated, not at the optimum
+        ell_after = model.calculate_expected_log_likelihood(self._all_segments())
+        if ell_after < ell_before:
+            self._log('{} rejected, elbo before: {}, after: {}'.format(name, ell_before, ell_after))
+            setattr(model, name, value_before)
+        else:
+            setattr(model, name, result_value)
+
+    # ------------------------------------------------------------------------------
+    def optimal_cn(self):
+        """Viterbi decode + per-breakpoint argmax (cn_model.py:571-598)."""
+        m = self.model
+        cn = np.zeros((m.num_segments, m.num_clones, m.num_alleles), dtype=int)
+        m.infer_cn(cn)
+
+        brk_states = np.asarray(m.brk_states)
+        bidx = np.asarray(m.breakpoint_idx); borient = np.asarray(m.breakpoint_orient)
+        log_breakpoint_p = np.zeros((m.num_breakpoints, m.num_brk_states))
+        tot = cn.sum(axis=-1)
+        for n in np.nonzero(bidx[:-1] >= 0)[0]:
+            for c in range(m.num_clones):
+                d = tot[n, c] - tot[n + 1, c]
+                for s_b in range(m.num_brk_states):
+                    log_breakpoint_p[bidx[n], s_b] += (-m.transition_penalty * abs(d - borient[n] * brk_states[s_b, c]))
+
+        brk_cn = dict()
+        for k in range(m.num_breakpoints):
+            brk_cn[self.breakpoint_ids[k]] = brk_states[log_breakpoint_p[k, :].argmax()]
+
+        return cn[self.seg_fwd_remap], brk_cn
+
+    def breakpoint_prob(self):
+        return dict(zip(self.breakpoints, np.asarray(self.model.p_breakpoint)))
+
+    @property
+    def h(self):
+        return np.asarray(self.model.h)
+
+    @property
+    def p_breakpoint(self):
+        return np.asarray(self.model.p_breakpoint)
+
+    @property
+    def p_outlier_total(self):
+        return np.asarray(self.model.p_outlier_total)[self.seg_fwd_remap]
+
+    @property
+    def p_outlier_allele(self):
+        return np.asarray(self.model.p_outlier_allele)[self.seg_fwd_remap]
+
+    @property
+    def total_likelihood_mask(self):
+        return np.asarray(self.model.total_likelihood_mask)[self.seg_fwd_remap]
+
+    @property
+    def allele_likelihood_mask(self):
+        return np.asarray(self.model.allele_likelihood_mask)[self.seg_fwd_remap]
+
+
+def decode_breakpoints_naive(cn, adjacencies, breakpoints):
+    """Breakpoint copy number from total copy-number steps at the breakends (cn_model.py:631-687)."""
+    tot = np.asarray(cn).sum(axis=-1)
+    partner = dict()
+    for seg_1, seg_2 in adjacencies:
+        partner[(seg_1, 1)] = (seg_2, 0)
+        partner[(seg_2, 0)] = (seg_1, 1)
+
+    def flow(breakend):
+        n, side = breakend
+        across = tot[partner[breakend][0], :] if breakend in partner else 0
+        return np.maximum(tot[n, :] - across, 0)
+
+    brk_cn = dict()
+    for breakpoint_id, breakpoint in breakpoints.items():
+        (be_1, be_2) = breakpoint
+        brk_cn[breakpoint_id] = np.minimum(flow(tuple(be_1)), flow(tuple(be_2)))
+    return brk_cn

@@ -1,0 +1,972 @@
+// rmx_api.hip -- host side of the C ABI declared in include/remixt_amd.h.
+// Owns device memory, the restart batch bookkeeping (what is stale after which
+// attribute write) and the launch sequences that replace the methods of
+// remixt.bpmodel.RemixtModel (reference remixt/bpmodel.pyx:397-1210).
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "rmx_kernels.h"
+
+// ---------------------------------------------------------------------------
+static thread_local std::string g_err;
+static int fail(int code, const std::string &msg) { g_err = msg; return code; }
+#define HIPCHK(call)                                                                         \
+    do {                                                                                     \
+        hipError_t e_ = (call);                                                              \
+        if (e_ != hipSuccess) return fail(RMX_EDEVICE, std::string(#call) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+enum KernelId {
+    KID_STATE_TABLES = 0, KID_SEG_CONST, KID_FRAMELOGPROB, KID_FB, KID_MARGINALS, KID_MARGINALS_AB, KID_OUTLIER_TOTAL,
+    KID_OUTLIER_ALLELE, KID_ALLELE_SWAP, KID_BRK_LUT, KID_PAIRWISE, KID_BRK_UPDATE, KID_ELBO_SEG, KID_ELBO_FINAL,
+    KID_ELL_LIST, KID_ELL_FINAL, KID_ELL_FULL, KID_VITERBI, KID_BACKTRACE, KID_OTHER, KID_COUNT
+};
+static const char *kKernelNames[KID_COUNT] = {
+    "k_state_tables", "k_seg_const", "k_framelogprob", "k_fb", "k_marginals<true>", "k_marginals<false>", "k_update_outlier_total",
+    "k_update_outlier_allele", "k_update_allele_swap", "k_brk_lut", "k_pairwise", "k_brk_update", "k_elbo_seg", "k_elbo_final",
+    "k_ell_list", "k_ell_final", "k_ell_full", "k_viterbi", "k_backtrace", "other"};
+
+struct ProfRec { int id; hipEvent_t a, b; };
+
+struct rmx_batch {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    Dev d{};
+    int R = 0;
+    // host copies of the problem (for table rebuilds / decoding)
+    std::vector<int64_t> cn_classes;   // [C][S][M][2]
+    std::vector<int32_t> seg_class, brk_idx, brk_orient, tclass, brk_slot, be_n;
+    std::vector<int64_t> brk_states, is_telomere;
+    std::vector<std::pair<int, int>> tc_pairs;
+    std::vector<double> Tsum;          // [TC] sum of plain log-transition entries (current model)
+    // per-restart host state
+    std::vector<RestartParams> rp;
+    std::vector<char> tables_dirty, ab_dirty;
+    std::vector<int> lt_valid;
+    std::vector<double> plain_T_init;  // [R]
+    std::vector<double> logZ;          // last hmm_log_norm_const
+    int *d_lt_valid = nullptr;
+    // scratch
+    double *d_partial = nullptr;       // ELBO partials [R][ELBO_BLOCKS][2]
+    double *d_out4 = nullptr;          // [R][4]
+    double *d_ell_partial = nullptr;   // [max(N,ELBO_BLOCKS)][1+MAXC]
+    double *d_ell_out = nullptr;       // [1+MAXC]
+    double *h_pinned = nullptr;        // pinned staging [max(4R, 16)]
+    int32_t *d_sample = nullptr;       // [N]
+    std::vector<int64_t> sample_cache; int sample_count = -1;
+    std::vector<int32_t> plain_list; int32_t *d_plain_list = nullptr; double *d_plain_jt = nullptr;
+    // viterbi
+    uint16_t *d_bp = nullptr; double *d_final = nullptr; int64_t *d_path = nullptr; double *d_logprob = nullptr;
+    std::vector<int64_t> last_path;
+    // FB launch configuration
+    int fb_rpt = 0; FbLaunch fbL{}; size_t fb_lds = 0;
+    int G = 64;
+    // all device allocations (freed on destroy)
+    std::vector<void *> allocs;
+    // profiling
+    bool prof = false;
+    std::vector<ProfRec> prof_pending;
+    std::vector<hipEvent_t> ev_pool;
+    double prof_ms[KID_COUNT] = {0};
+    long long prof_n[KID_COUNT] = {0};
+    hipEvent_t tm_a = nullptr, tm_b = nullptr;
+};
+
+template <typename T> static int dalloc(rmx_batch *b, T **p, size_t count) {
+    void *q = nullptr;
+    size_t bytes = std::max<size_t>(count, 1) * sizeof(T);
+    hipError_t e = hipMalloc(&q, bytes);
+    if (e != hipSuccess) return fail(RMX_EDEVICE, std::string("hipMalloc: ") + hipGetErrorString(e));
+    b->allocs.push_back(q);
+    *p = (T *)q;
+    return RMX_OK;
+}
+template <typename T> static int dupload(rmx_batch *b, const T **p, const std::vector<T> &v) {
+    T *q = nullptr;
+    int rc = dalloc(b, &q, v.size());
+    if (rc) return rc;
+    if (!v.empty()) HIPCHK(hipMemcpy(q, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+    *p = q;
+    return RMX_OK;
+}
+
+// ---- profiling wrappers ---------------------------------------------------
+static hipEvent_t get_event(rmx_batch *b) {
+    if (!b->ev_pool.empty()) { hipEvent_t e = b->ev_pool.back(); b->ev_pool.pop_back(); return e; }
+    hipEvent_t e; hipEventCreate(&e); return e;
+}
+static void prof_collect(rmx_batch *b) {
+    for (auto &pr : b->prof_pending) {
+        hipEventSynchronize(pr.b);
+        float ms = 0; hipEventElapsedTime(&ms, pr.a, pr.b);
+        b->prof_ms[pr.id] += ms; b->prof_n[pr.id] += 1;
+        b->ev_pool.push_back(pr.a); b->ev_pool.push_back(pr.b);
+    }
+    b->prof_pending.clear();
+}
+struct ProfScope {
+    rmx_batch *b; int id; hipEvent_t a{}, e{};
+    ProfScope(rmx_batch *b_, int id_) : b(b_), id(id_) {
+        if (b->prof) { a = get_event(b); e = get_event(b); hipEventRecord(a, b->stream); }
+    }
+    ~ProfScope() {
+        if (b->prof) { hipEventRecord(e, b->stream); b->prof_pending.push_back({id, a, e}); if (b->prof_pending.size() > 4096) prof_collect(b); }
+    }
+};
+
+// ---- error translation -------------------------------------------------------
+static int check_errors(rmx_batch *b, int r0, int r1) {
+    std::vector<uint32_t> e(b->R);
+    HIPCHK(hipMemcpyAsync(e.data(), b->d.err, sizeof(uint32_t) * b->R, hipMemcpyDeviceToHost, b->stream));
+    HIPCHK(hipStreamSynchronize(b->stream));
+    for (int r = r0; r < r1; r++) {
+        if (!e[r]) continue;
+        uint32_t v = e[r];
+        HIPCHK(hipMemsetAsync(b->d.err + r, 0, sizeof(uint32_t), b->stream));
+        char buf[160];
+        if (v & RMX_ERR_NAN_LL) { snprintf(buf, sizeof buf, "ll is nan (restart %d)", r); return fail(RMX_EVALUE, buf); }
+        if (v & RMX_ERR_TOTAL_DEPTH) { snprintf(buf, sizeof buf, "total_depth <= 0 (restart %d)", r); return fail(RMX_EVALUE, buf); }
+        if (v & RMX_ERR_LOH_P) { snprintf(buf, sizeof buf, "expected p 0 or 1 for loh state (restart %d)", r); return fail(RMX_EVALUE, buf); }
+        if (v & RMX_ERR_BAD_P) { snprintf(buf, sizeof buf, "p <= 0 or (1 - p) <= 0. (restart %d)", r); return fail(RMX_EVALUE, buf); }
+        if (v & RMX_ERR_DIGAMMA) { snprintf(buf, sizeof buf, "x <= 0.0 in digamma (restart %d)", r); return fail(RMX_EVALUE, buf); }
+        if (v & RMX_ERR_NAN_GRAD) { snprintf(buf, sizeof buf, "partial derivative is nan (restart %d)", r); return fail(RMX_EVALUE, buf); }
+        if (v & RMX_ERR_NAN_F) { snprintf(buf, sizeof buf, "nan in framelogprob (restart %d)", r); return fail(RMX_EASSERT, buf); }
+        if (v & RMX_ERR_NAN_AB) { snprintf(buf, sizeof buf, "nan in alphas/betas (restart %d)", r); return fail(RMX_EASSERT, buf); }
+        if (v & RMX_ERR_NAN_POST) { snprintf(buf, sizeof buf, "nan in posterior marginals (restart %d)", r); return fail(RMX_EASSERT, buf); }
+        snprintf(buf, sizeof buf, "device error bits 0x%x (restart %d)", v, r); return fail(RMX_EVALUE, buf);
+    }
+    return RMX_OK;
+}
+
+// ---- transition tables ---------------------------------------------------------
+static inline double g_host(int model, int64_t dd) { return model == 0 ? (double)(dd < 0 ? -dd : dd) : (dd == 0 ? 0. : 1.); }
+
+static int build_transitions(rmx_batch *b) {
+    const int S = b->d.S, M = b->d.M, TC = (int)b->tc_pairs.size(), model = b->d.tmodel;
+    const double pen = b->d.pen;
+    const size_t SS = (size_t)S * S;
+    std::vector<double> Tval(SS * TC), Wf(SS * TC), Wb(SS * TC);
+    std::vector<int8_t> af(SS * TC), ab(SS * TC);
+    b->Tsum.assign(TC, 0.);
+    for (int tc = 0; tc < TC; tc++) {
+        const int64_t *A = b->cn_classes.data() + (size_t)b->tc_pairs[tc].first * S * M * 2;
+        const int64_t *Bc = b->cn_classes.data() + (size_t)b->tc_pairs[tc].second * S * M * 2;
+        double tsum = 0.;
+        for (int i = 0; i < S; i++)
+            for (int j = 0; j < S; j++) {
+                // bpmodel.pyx:652-656 then :670-684, same accumulation order
+                double T = 0.;
+                for (int m = 0; m < M; m++) {
+                    int64_t ti = A[(i * M + m) * 2] + A[(i * M + m) * 2 + 1], tj = Bc[(j * M + m) * 2] + Bc[(j * M + m) * 2 + 1];
+                    T += -pen * g_host(model, ti - tj);
+                }
+                double ach[2];
+                for (int flip = 0; flip < 2; flip++) {
+                    ach[flip] = 0.;
+                    for (int m = 0; m < M; m++) {
+                        for (int a = 0; a < 2; a++) {
+                            int oa = flip ? 1 - a : a;
+                            ach[flip] += g_host(model, A[(i * M + m) * 2 + a] - Bc[(j * M + m) * 2 + oa]);
+                        }
+                        int64_t ti = A[(i * M + m) * 2] + A[(i * M + m) * 2 + 1], tj = Bc[(j * M + m) * 2] + Bc[(j * M + m) * 2 + 1];
+                        ach[flip] -= g_host(model, ti - tj);
+                    }
+                }
+                const double amin = std::min(ach[0], ach[1]);
+                T += -pen * amin;
+                Tval[tc * SS + (size_t)i * S + j] = T;
+                Wf[tc * SS + (size_t)i * S + j] = std::exp(T);
+                Wb[tc * SS + (size_t)j * S + i] = std::exp(T);
+                af[tc * SS + (size_t)i * S + j] = (int8_t)amin;
+                ab[tc * SS + (size_t)j * S + i] = (int8_t)amin;
+                tsum += T;
+            }
+        b->Tsum[tc] = tsum;
+    }
+    if (TC > 0) {
+        HIPCHK(hipMemcpy((void *)b->d.Tval, Tval.data(), Tval.size() * 8, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy((void *)b->d.Wf, Wf.data(), Wf.size() * 8, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy((void *)b->d.Wb, Wb.data(), Wb.size() * 8, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy((void *)b->d.af, af.data(), af.size(), hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy((void *)b->d.ab, ab.data(), ab.size(), hipMemcpyHostToDevice));
+    }
+    return RMX_OK;
+}
+
+static double plain_T_mean_sum(rmx_batch *b) {
+    // sum over plain (non-telomere, non-breakend) adjacencies of mean(T): the transition
+    // factor of the energy under the uniform initial joint (bpmodel.pyx:566-567, :1112-1115)
+    double acc = 0.;
+    const double ss = (double)((size_t)b->d.S * b->d.S);
+    for (int n = 0; n + 1 < b->d.N; n++)
+        if (b->tclass[n] >= 0 && b->brk_slot[n] < 0) acc += b->Tsum[b->tclass[n]] / ss;
+    return acc;
+}
+
+// ---- FB configuration -----------------------------------------------------------
+typedef void (*fb_kernel_t)(Dev, int, FbLaunch);
+static fb_kernel_t fb_kernel_for(int rpt) {
+    switch (rpt) {
+    case 2: return k_fb<2, 0, 1024>;
+    case 4: return k_fb<4, 0, 1024>;
+    case 8: return k_fb<8, 0, 1024>;
+    case 16: return k_fb<16, 0, 1024>;
+    case 24: return k_fb<24, 0, 1024>;
+    case 32: return k_fb<32, 0, 768>;
+    case 44: return k_fb<44, 0, 768>;
+    default: return k_fb<0, 0, 1024>;
+    }
+}
+static void configure_fb(rmx_batch *b) {
+    const int S = b->d.S;
+    static const int rpts[] = {2, 4, 8, 16, 24, 32, 44};
+    int P = 1;
+    while ((S + P - 1) / P > 44 && P < 64) P *= 2;
+    while (S * P * 2 <= 512 && P < 64 && (S + P - 1) / P > 2) P *= 2;
+    int need = (S + P - 1) / P, rpt = 0;
+    for (int v : rpts) if (v >= need) { rpt = v; break; }
+    int ntmax = (rpt >= 32) ? 768 : 1024;
+    if (rpt == 0 || S * P > ntmax) {
+        rpt = 0; P = 1;
+        while (S * P * 2 <= 1024 && P < 64) P *= 2;
+    }
+    if (getenv("RMX_FB_GENERIC")) { rpt = 0; P = 1; while (S * P * 2 <= 1024 && P < 64) P *= 2; }
+    FbLaunch L;
+    L.P = P;
+    L.NT = ((S * P + 63) / 64) * 64;
+    int span = std::max(S, P * (rpt > 0 ? rpt : (S + P - 1) / P));
+    L.SPAD = ((span + 7) / 8) * 8;
+    size_t fixed = (size_t)(2 * L.SPAD + 32 + b->d.M * b->d.D) * 8 + (size_t)b->d.C * S * b->d.M + 64;
+    int blk = std::min(8, (FB_EPT * L.NT) / S);
+    while (blk > 1 && fixed + (size_t)FB_NBUF * blk * L.SPAD * 8 > 60 * 1024) blk--;
+    L.BLK = std::max(1, blk);
+    b->fb_rpt = rpt; b->fbL = L;
+    b->fb_lds = fixed + (size_t)FB_NBUF * L.BLK * L.SPAD * 8;
+}
+
+// ---- staleness handling ----------------------------------------------------------
+__global__ void k_set_rp(Dev d, int r, RestartParams rp) { if (threadIdx.x == 0) d.rp[r] = rp; }
+
+static int ensure_tables(rmx_batch *b, int r0, int r1) {
+    bool any = false;
+    for (int r = r0; r < r1; r++)
+        if (b->tables_dirty[r]) { any = true; hipLaunchKernelGGL(k_set_rp, dim3(1), dim3(64), 0, b->stream, b->d, r, b->rp[r]); }
+    if (!any) return RMX_OK;
+    // contiguous dirty ranges
+    int r = r0;
+    while (r < r1) {
+        if (!b->tables_dirty[r]) { r++; continue; }
+        int e = r;
+        while (e < r1 && b->tables_dirty[e]) e++;
+        { ProfScope ps(b, KID_STATE_TABLES); hipLaunchKernelGGL(k_state_tables, dim3(b->d.C, e - r), dim3(256), 0, b->stream, b->d, r); }
+        { ProfScope ps(b, KID_SEG_CONST); hipLaunchKernelGGL(k_seg_const, dim3((b->d.N + 255) / 256, e - r), dim3(256), 0, b->stream, b->d, r); }
+        for (int i = r; i < e; i++) { b->tables_dirty[i] = 0; b->ab_dirty[i] = 1; }
+        r = e;
+    }
+    HIPCHK(hipGetLastError());
+    return RMX_OK;
+}
+static dim3 row_grid(rmx_batch *b, int nr) { int rows = 256 / b->G; return dim3((b->d.N + rows - 1) / rows, nr); }
+
+static int ensure_ab(rmx_batch *b, int r0, int r1) {
+    int rc = ensure_tables(b, r0, r1);
+    if (rc) return rc;
+    int r = r0;
+    while (r < r1) {
+        if (!b->ab_dirty[r]) { r++; continue; }
+        int e = r;
+        while (e < r1 && b->ab_dirty[e]) e++;
+        { ProfScope ps(b, KID_MARGINALS_AB); hipLaunchKernelGGL(k_marginals<false>, row_grid(b, e - r), dim3(256), 0, b->stream, b->d, r, b->G); }
+        for (int i = r; i < e; i++) b->ab_dirty[i] = 0;
+        r = e;
+    }
+    HIPCHK(hipGetLastError());
+    return RMX_OK;
+}
+
+static int launch_pairwise_breakends(rmx_batch *b, int r0, int r1, int mode) {
+    if (b->d.NBE == 0) return RMX_OK;
+    ProfScope ps(b, KID_PAIRWISE);
+    hipLaunchKernelGGL(k_pairwise, dim3(b->d.NBE, r1 - r0), dim3(256), 0, b->stream, b->d, r0, mode, (const int32_t *)nullptr, (double *)nullptr);
+    HIPCHK(hipGetLastError());
+    return RMX_OK;
+}
+static int launch_brk_lut(rmx_batch *b, int r0, int r1, double *dst) {
+    if (b->d.NBE == 0) return RMX_OK;
+    ProfScope ps(b, KID_BRK_LUT);
+    hipLaunchKernelGGL(k_brk_lut, dim3(b->d.NBE, r1 - r0), dim3(64), 0, b->stream, b->d, r0, dst);
+    HIPCHK(hipGetLastError());
+    return RMX_OK;
+}
+
+// ===========================================================================
+extern "C" {
+
+const char *rmx_last_error(void) { return g_err.c_str(); }
+
+int rmx_compress_cn_states(const int64_t *cn_states, int32_t N, int32_t S, int32_t M, int32_t max_classes,
+                           int32_t *seg_class_out, int64_t *classes_out, int32_t *num_classes) {
+    if (!cn_states || !seg_class_out || !classes_out || !num_classes) return fail(RMX_EARG, "null argument");
+    const size_t tsz = (size_t)S * M * 2;
+    int C = 0;
+    for (int n = 0; n < N; n++) {
+        const int64_t *t = cn_states + (size_t)n * tsz;
+        int found = -1;
+        if (n > 0 && memcmp(t, classes_out + (size_t)seg_class_out[n - 1] * tsz, tsz * 8) == 0) found = seg_class_out[n - 1];
+        for (int c = 0; c < C && found < 0; c++) if (memcmp(t, classes_out + (size_t)c * tsz, tsz * 8) == 0) found = c;
+        if (found < 0) {
+            if (C >= max_classes) return fail(RMX_EUNSUPPORTED, "too many distinct per-segment state tables");
+            memcpy(classes_out + (size_t)C * tsz, t, tsz * 8);
+            found = C++;
+        }
+        seg_class_out[n] = found;
+    }
+    *num_classes = C;
+    return RMX_OK;
+}
+
+int rmx_batch_create(const rmx_problem *pr, int32_t R, const double *h_init, const double *divw, int32_t device, rmx_batch **out) {
+    if (!pr || !out || !h_init || !divw) return fail(RMX_EARG, "null argument");
+    const int N = pr->num_segments, S = pr->num_cn_states, M = pr->num_clones, K = pr->num_breakpoints, B = pr->num_brk_states, C = pr->num_classes;
+    if (M < 1 || M > RMX_MAX_CLONES) return fail(RMX_EUNSUPPORTED, "num_clones must be in [1, 4]");
+    if (S < 1 || S > 1024) return fail(RMX_EUNSUPPORTED, "num_cn_states must be in [1, 1024]");
+    if (N < 1 || R < 1 || C < 1 || B < 1) return fail(RMX_EARG, "bad sizes");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(RMX_EDEVICE, "no HIP device available (there is no CPU fallback)");
+    if (device < 0 || device >= ndev) return fail(RMX_EDEVICE, "bad device ordinal");
+    HIPCHK(hipSetDevice(device));
+
+    // reference validation (bpmodel.pyx:528)
+    int64_t maxidx = -1;
+    for (int n = 0; n < N; n++) maxidx = std::max(maxidx, pr->breakpoint_idx[n]);
+    if (maxidx + 1 != K) return fail(RMX_EVALUE, "breakpoint_idx must have maximum of num_breakpoints positive indices");
+    for (int n = 0; n < N; n++) if (pr->seg_class[n] < 0 || pr->seg_class[n] >= C) return fail(RMX_EARG, "seg_class out of range");
+
+    rmx_batch *b = new rmx_batch();
+    b->device = device; b->R = R;
+    HIPCHK(hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking));
+    b->own_stream = true;
+    Dev &d = b->d;
+    d.N = N; d.S = S; d.SP = ((S + 7) / 8) * 8; d.M = M; d.K = K; d.B = B; d.C = C; d.nc = pr->normal_contamination ? 1 : 0;
+    d.tmodel = 0; d.R = R; d.pen = std::fabs(pr->transition_penalty);
+    b->cn_classes.assign(pr->cn_classes, pr->cn_classes + (size_t)C * S * M * 2);
+    b->seg_class.assign(pr->seg_class, pr->seg_class + N);
+    b->brk_states.assign(pr->brk_states, pr->brk_states + (size_t)B * M);
+    b->is_telomere.assign(pr->is_telomere, pr->is_telomere + N);
+    int64_t cnmax = 0;
+    for (auto v : b->cn_classes) { if (v < 0 || v > 100) { delete b; return fail(RMX_EUNSUPPORTED, "copy number out of range [0,100]"); } cnmax = std::max(cnmax, v); }
+    for (auto v : b->brk_states) { if (v < 0 || v > 100) { delete b; return fail(RMX_EUNSUPPORTED, "breakpoint copy number out of range"); } cnmax = std::max(cnmax, v); }
+    d.cn_max = (int)cnmax; d.D = 2 * d.cn_max + 3;
+    if (d.D > 64) { delete b; return fail(RMX_EUNSUPPORTED, "cn_max > 30"); }
+
+    // derived state tables
+    std::vector<int8_t> cn8((size_t)C * S * M * 2), tot8((size_t)C * S * M);
+    std::vector<uint8_t> sflags((size_t)C * S);
+    for (int c = 0; c < C; c++)
+        for (int s = 0; s < S; s++) {
+            const int64_t *t = b->cn_classes.data() + ((size_t)c * S + s) * M * 2;
+            bool hdel = true; int nsub = 0; bool loh = false;
+            for (int m = 0; m < M; m++) {
+                cn8[(((size_t)c * S + s) * M + m) * 2] = (int8_t)t[m * 2];
+                cn8[(((size_t)c * S + s) * M + m) * 2 + 1] = (int8_t)t[m * 2 + 1];
+                int64_t tt = t[m * 2] + t[m * 2 + 1];
+                if (tt > 127) { delete b; return fail(RMX_EUNSUPPORTED, "total copy number > 127"); }
+                tot8[((size_t)c * S + s) * M + m] = (int8_t)tt;
+                if (t[m * 2] != 0 || t[m * 2 + 1] != 0) hdel = false;
+            }
+            for (int a = 0; a < 2; a++) {
+                int64_t sum = 0;
+                for (int m = 0; m < M; m++) sum += t[m * 2 + a];
+                if (sum == 0) loh = true;
+                if (M > 1) {
+                    int64_t lo = t[2 + a], hi = lo;
+                    for (int m = 2; m < M; m++) { lo = std::min(lo, t[m * 2 + a]); hi = std::max(hi, t[m * 2 + a]); }
+                    if (hi != lo) nsub++;
+                }
+            }
+            sflags[(size_t)c * S + s] = (uint8_t)((hdel ? 1 : 0) | (loh ? 2 : 0) | (nsub << 2));
+            // guard: |tot_i - tot_j| must index the distance tables
+            for (int m = 0; m < M; m++) if (tot8[((size_t)c * S + s) * M + m] > d.cn_max + 1) { delete b; return fail(RMX_EUNSUPPORTED, "total copy number exceeds cn_max + 1"); }
+        }
+
+    // topology: chains, transition classes, breakend slots
+    b->brk_idx.resize(N); b->brk_orient.resize(N); b->tclass.assign(N, -1); b->brk_slot.assign(N, -1);
+    std::vector<int32_t> cstart, cend; std::vector<uint8_t> cendflag(N, 0);
+    std::map<std::pair<int, int>, int> tcmap;
+    int start = 0;
+    for (int n = 0; n < N; n++) {
+        b->brk_idx[n] = (int32_t)pr->breakpoint_idx[n]; b->brk_orient[n] = (int32_t)pr->breakpoint_orient[n];
+        const bool last = (n == N - 1), tel = pr->is_telomere[n] > 0;
+        if (!last && !tel) {
+            auto key = std::make_pair(b->seg_class[n], b->seg_class[n + 1]);
+            auto it = tcmap.find(key);
+            if (it == tcmap.end()) { int id = (int)b->tc_pairs.size(); tcmap[key] = id; b->tc_pairs.push_back(key); b->tclass[n] = id; }
+            else b->tclass[n] = it->second;
+        }
+        if (!last && b->brk_idx[n] >= 0) { b->brk_slot[n] = (int32_t)b->be_n.size(); b->be_n.push_back(n); }
+        if (last || tel) { cstart.push_back(start); cend.push_back(n); cendflag[n] = 1; start = n + 1; }
+    }
+    d.NC = (int)cstart.size(); d.NBE = (int)b->be_n.size(); d.TC = (int)b->tc_pairs.size();
+    if (d.TC > 4096) { delete b; return fail(RMX_EUNSUPPORTED, "too many transition classes"); }
+    std::vector<int32_t> bk_ptr(K + 1, 0), bk_slots(d.NBE);
+    for (int s = 0; s < d.NBE; s++) bk_ptr[b->brk_idx[b->be_n[s]] + 1]++;
+    for (int k = 0; k < K; k++) bk_ptr[k + 1] += bk_ptr[k];
+    { std::vector<int32_t> fill(bk_ptr.begin(), bk_ptr.end() - 1);
+      for (int s = 0; s < d.NBE; s++) bk_slots[fill[b->brk_idx[b->be_n[s]]]++] = s; }
+
+    int rc;
+#define UP(field, vec) if ((rc = dupload(b, &d.field, vec))) { rmx_batch_destroy(b); return rc; }
+    std::vector<double> lv(pr->l, pr->l + N), xv(pr->x, pr->x + N), yv(pr->y, pr->y + 2 * (size_t)N);
+    std::vector<uint8_t> ones(N, 1);
+    std::vector<int32_t> brkst((size_t)B * M);
+    for (size_t i = 0; i < brkst.size(); i++) brkst[i] = (int32_t)b->brk_states[i];
+    UP(l, lv) UP(x, xv) UP(y, yv) UP(mask_t, ones) UP(mask_a, ones) UP(seg_class, b->seg_class) UP(tclass, b->tclass)
+    UP(brk_slot, b->brk_slot) UP(brk_idx, b->brk_idx) UP(brk_orient, b->brk_orient) UP(be_n, b->be_n) UP(chain_start, cstart)
+    UP(chain_end, cend) UP(chain_end_flag, cendflag) UP(cn, cn8) UP(tot, tot8) UP(sflags, sflags) UP(brk_states, brkst)
+    UP(bk_ptr, bk_ptr) UP(bk_slots, bk_slots)
+#undef UP
+    const size_t SS = (size_t)S * S;
+#define DA(field, type, count) { type *p_ = nullptr; if ((rc = dalloc(b, &p_, (size_t)(count)))) { rmx_batch_destroy(b); return rc; } d.field = p_; }
+    DA(Tval, double, SS * d.TC) DA(Wf, double, SS * d.TC) DA(Wb, double, SS * d.TC) DA(af, int8_t, SS * d.TC) DA(ab, int8_t, SS * d.TC)
+    const size_t RN = (size_t)R * N, RNS = RN * d.SP, RCS = (size_t)R * C * d.SP;
+    DA(rp, RestartParams, R) DA(stD, double, RCS) DA(stP, double, RCS) DA(stM, double, RCS * 2) DA(stLg, double, RCS * 4) DA(stFlags, uint32_t, RCS)
+    DA(segc, double, RN * 8) DA(qt, double, RN * 2) DA(qa, double, RN * 2) DA(qs, double, RN * 2) DA(pbrk, double, (size_t)R * K * B)
+    DA(f, double, RNS) DA(fa, double, RNS) DA(fb, double, RNS) DA(post, double, RNS) DA(fmax, double, RN) DA(mrow, double, RN)
+    DA(A, double, RN * 2) DA(Bv, double, RN * 4) DA(rowPF, double, RN) DA(rowPP, double, RN) DA(rowZ, double, RN)
+    const size_t BEW = (size_t)R * d.NBE * M * d.D;
+    DA(pd_lt, double, BEW) DA(pd_cached, double, BEW) DA(hist, double, BEW) DA(be_jt, double, (size_t)R * d.NBE) DA(be_ja, double, (size_t)R * d.NBE)
+    DA(err, uint32_t, R)
+#undef DA
+    if ((rc = dalloc(b, &b->d_lt_valid, R)) || (rc = dalloc(b, &b->d_partial, (size_t)R * ELBO_BLOCKS * 2)) || (rc = dalloc(b, &b->d_out4, (size_t)R * 4)) ||
+        (rc = dalloc(b, &b->d_ell_partial, (size_t)std::max(N, ELBO_BLOCKS) * (1 + RMX_MAX_CLONES))) || (rc = dalloc(b, &b->d_ell_out, 1 + RMX_MAX_CLONES)) ||
+        (rc = dalloc(b, &b->d_sample, N))) { rmx_batch_destroy(b); return rc; }
+    HIPCHK(hipHostMalloc((void **)&b->h_pinned, sizeof(double) * std::max(4 * R, 64)));
+    HIPCHK(hipEventCreate(&b->tm_a)); HIPCHK(hipEventCreate(&b->tm_b));
+
+    if ((rc = build_transitions(b))) { rmx_batch_destroy(b); return rc; }
+    // envelope of the scaled linear-domain recursion: exp(T) must stay a normal double
+    // with head-room for one step of products ("numerical envelope")
+    {
+        double tmin = 0.;
+        // (breakend adjacencies are not bounded a priori; a vanishing row is reported as RMX_EASSERT)
+        std::vector<double> tv((size_t)SS * d.TC);
+        if (d.TC) HIPCHK(hipMemcpy(tv.data(), d.Tval, tv.size() * 8, hipMemcpyDeviceToHost));
+        for (double v : tv) tmin = std::min(tmin, v);
+        if (tmin < -650.) { rmx_batch_destroy(b); return fail(RMX_EUNSUPPORTED, "transition_log_prob * max copy-number change exceeds 650 nats: outside the linear-domain envelope"); }
+    }
+
+    // per-restart initial state (bpmodel.pyx:546-597)
+    b->rp.resize(R); b->tables_dirty.assign(R, 1); b->ab_dirty.assign(R, 1); b->lt_valid.assign(R, 0); b->logZ.assign(R, 0.);
+    for (int r = 0; r < R; r++) {
+        RestartParams &p = b->rp[r];
+        memset(&p, 0, sizeof p);
+        for (int m = 0; m < M; m++) p.h[m] = h_init[(size_t)r * M + m];
+        p.p[RMX_P_NEGBIN_R_0] = 500.; p.p[RMX_P_NEGBIN_R_1] = 10.; p.p[RMX_P_NEGBIN_HDEL_MU] = 1e-5; p.p[RMX_P_NEGBIN_HDEL_R_0] = 10.;
+        p.p[RMX_P_NEGBIN_HDEL_R_1] = 1.; p.p[RMX_P_BETABIN_M_0] = 500.; p.p[RMX_P_BETABIN_M_1] = 10.; p.p[RMX_P_BETABIN_LOH_P] = 1e-3;
+        p.p[RMX_P_BETABIN_LOH_M_0] = 10.; p.p[RMX_P_BETABIN_LOH_M_1] = 1.; p.p[RMX_P_PRIOR_OUTLIER_TOTAL] = 0.01; p.p[RMX_P_PRIOR_OUTLIER_ALLELE] = 0.01;
+        p.p[RMX_P_DIVERGENCE_WEIGHT] = std::fabs(divw[r]);
+    }
+    {
+        std::vector<double> q2(RN * 2), v;
+        for (size_t i = 0; i < RN; i++) { q2[2 * i] = 1. - 0.01; q2[2 * i + 1] = 0.01; }
+        HIPCHK(hipMemcpy(d.qt, q2.data(), q2.size() * 8, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(d.qa, q2.data(), q2.size() * 8, hipMemcpyHostToDevice));
+        for (size_t i = 0; i < RN * 2; i++) q2[i] = 0.5;
+        HIPCHK(hipMemcpy(d.qs, q2.data(), q2.size() * 8, hipMemcpyHostToDevice));
+        // p_breakpoint: uniform over states with max <= 1 (bpmodel.pyx:547-554)
+        std::vector<double> pb((size_t)K * B, 0.);
+        if (K > 0) {
+            double cnt = 0.;
+            std::vector<double> row(B, 0.);
+            for (int sb = 0; sb < B; sb++) { int64_t mx = 0; for (int m = 0; m < M; m++) mx = std::max(mx, b->brk_states[(size_t)sb * M + m]); if (mx <= 1) { row[sb] = 1.; cnt += 1.; } }
+            for (int sb = 0; sb < B; sb++) row[sb] /= cnt;
+            for (int k = 0; k < K; k++) std::copy(row.begin(), row.end(), pb.begin() + (size_t)k * B);
+            for (int r = 0; r < R; r++) HIPCHK(hipMemcpy(d.pbrk + (size_t)r * K * B, pb.data(), pb.size() * 8, hipMemcpyHostToDevice));
+        }
+        // framelogprob = 1, posterior = 1/S, logZ rows = 0 (bpmodel.pyx:556-567)
+        std::vector<double> row((size_t)N * d.SP);
+        for (auto &x_ : row) x_ = 1.0;
+        for (int r = 0; r < R; r++) HIPCHK(hipMemcpy(d.f + (size_t)r * N * d.SP, row.data(), row.size() * 8, hipMemcpyHostToDevice));
+        for (auto &x_ : row) x_ = 1.0 / (double)S;
+        for (int r = 0; r < R; r++) HIPCHK(hipMemcpy(d.post + (size_t)r * N * d.SP, row.data(), row.size() * 8, hipMemcpyHostToDevice));
+        HIPCHK(hipMemset(d.rowZ, 0, RN * 8)); HIPCHK(hipMemset(d.fmax, 0, RN * 8)); HIPCHK(hipMemset(d.mrow, 0, RN * 8));
+        HIPCHK(hipMemset(d.fa, 0, RNS * 8)); HIPCHK(hipMemset(d.fb, 0, RNS * 8));
+        HIPCHK(hipMemset(d.err, 0, R * 4)); HIPCHK(hipMemset(b->d_lt_valid, 0, R * 4));
+        HIPCHK(hipMemset(d.hist, 0, BEW * 8)); HIPCHK(hipMemset(d.be_jt, 0, (size_t)R * d.NBE * 8)); HIPCHK(hipMemset(d.be_ja, 0, (size_t)R * d.NBE * 8));
+        HIPCHK(hipMemset(d.pd_lt, 0, BEW * 8));
+    }
+    b->G = S > 32 ? 64 : (S > 16 ? 32 : (S > 8 ? 16 : 8));
+    configure_fb(b);
+    if (b->fb_lds > 64 * 1024) { rmx_batch_destroy(b); return fail(RMX_EUNSUPPORTED, "LDS budget exceeded"); }
+    // cached_log_transmat of the constructor (:604) + pairwise reductions of the uniform joint
+    if ((rc = launch_brk_lut(b, 0, R, d.pd_cached)) || (rc = launch_pairwise_breakends(b, 0, R, 1))) { rmx_batch_destroy(b); return rc; }
+    b->plain_T_init.assign(R, plain_T_mean_sum(b));
+    // plain adjacency list (only used when exact energy / entropy parts are requested)
+    for (int n = 0; n + 1 < N; n++) if (b->tclass[n] >= 0 && b->brk_slot[n] < 0) b->plain_list.push_back(n);
+    HIPCHK(hipStreamSynchronize(b->stream));
+    *out = b;
+    return RMX_OK;
+}
+
+int rmx_batch_destroy(rmx_batch *b) {
+    if (!b) return RMX_OK;
+    hipSetDevice(b->device);
+    if (b->stream) hipStreamSynchronize(b->stream);
+    prof_collect(b);
+    for (void *p : b->allocs) hipFree(p);
+    if (b->h_pinned) hipHostFree(b->h_pinned);
+    for (auto e : b->ev_pool) hipEventDestroy(e);
+    if (b->tm_a) hipEventDestroy(b->tm_a);
+    if (b->tm_b) hipEventDestroy(b->tm_b);
+    if (b->own_stream && b->stream) hipStreamDestroy(b->stream);
+    delete b;
+    return RMX_OK;
+}
+
+int rmx_set_stream(rmx_batch *b, void *s) {
+    if (!b) return fail(RMX_EARG, "null batch");
+    HIPCHK(hipStreamSynchronize(b->stream));
+    if (b->own_stream) { hipStreamDestroy(b->stream); b->own_stream = false; }
+    if (s) b->stream = (hipStream_t)s;
+    else { HIPCHK(hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking)); b->own_stream = true; }
+    return RMX_OK;
+}
+int rmx_synchronize(rmx_batch *b) { HIPCHK(hipStreamSynchronize(b->stream)); return RMX_OK; }
+
+int rmx_info(rmx_batch *b, int32_t what, int64_t *out) {
+    switch (what) {
+    case 0: *out = b->d.cn_max; break; case 1: *out = b->d.NC; break; case 2: *out = b->d.TC; break; case 3: *out = b->d.NBE; break;
+    case 4: *out = b->d.SP; break; case 5: *out = b->fb_rpt; break; case 6: *out = b->fbL.P; break; case 7: *out = b->fbL.NT; break;
+    case 8: *out = b->fbL.BLK; break; case 9: *out = (int64_t)b->fb_lds; break;
+    default: return fail(RMX_EARG, "bad info id");
+    }
+    return RMX_OK;
+}
+
+// ---- attributes -----------------------------------------------------------------
+int rmx_set_param(rmx_batch *b, int32_t r, int32_t id, double v) {
+    if (r < 0 || r >= b->R || id < 0 || id >= RMX_P_HMM_LOG_NORM_CONST) return fail(RMX_EARG, "bad restart / param id");
+    if (id == RMX_P_DIVERGENCE_WEIGHT) v = std::fabs(v);
+    b->rp[r].p[id] = v; b->tables_dirty[r] = 1; b->ab_dirty[r] = 1;
+    return RMX_OK;
+}
+int rmx_get_param(rmx_batch *b, int32_t r, int32_t id, double *v) {
+    if (r < 0 || r >= b->R || id < 0 || id >= RMX_P_COUNT) return fail(RMX_EARG, "bad restart / param id");
+    *v = (id == RMX_P_HMM_LOG_NORM_CONST) ? b->logZ[r] : b->rp[r].p[id];
+    return RMX_OK;
+}
+int rmx_set_transition_model(rmx_batch *b, int32_t model) {
+    if (model != 0 && model != 1) return fail(RMX_EUNSUPPORTED, "transition_model must be 0 or 1");
+    if (model == b->d.tmodel) return RMX_OK;
+    HIPCHK(hipStreamSynchronize(b->stream));
+    b->d.tmodel = model;
+    return build_transitions(b);
+}
+
+static int array_shape(rmx_batch *b, int id, size_t *count, bool *is_int) {
+    const Dev &d = b->d; *is_int = false;
+    switch (id) {
+    case RMX_A_H: *count = d.M; break;
+    case RMX_A_P_BREAKPOINT: *count = (size_t)d.K * d.B; break;
+    case RMX_A_P_ALLELE_SWAP: case RMX_A_P_OUTLIER_TOTAL: case RMX_A_P_OUTLIER_ALLELE: *count = (size_t)d.N * 2; break;
+    case RMX_A_POSTERIOR_MARGINALS: case RMX_A_FRAMELOGPROB: *count = (size_t)d.N * d.S; break;
+    case RMX_A_TOTAL_LIKELIHOOD_MASK: case RMX_A_ALLELE_LIKELIHOOD_MASK: case RMX_A_STATE_SEQUENCE: *count = d.N; *is_int = true; break;
+    case RMX_A_LOG_TRANSMAT: case RMX_A_CACHED_LOG_TRANSMAT: case RMX_A_JOINT_POSTERIOR_MARGINALS: *count = (size_t)(d.N - 1) * d.S * d.S; break;
+    default: return fail(RMX_EARG, "bad array id");
+    }
+    return RMX_OK;
+}
+
+int rmx_set_array(rmx_batch *b, int32_t r, int32_t id, const void *src) {
+    if (r < 0 || r >= b->R || !src) return fail(RMX_EARG, "bad restart / null source");
+    Dev &d = b->d;
+    const size_t RN = (size_t)r * d.N;
+    switch (id) {
+    case RMX_A_H:
+        for (int m = 0; m < d.M; m++) b->rp[r].h[m] = ((const double *)src)[m];
+        b->tables_dirty[r] = 1; b->ab_dirty[r] = 1; return RMX_OK;
+    case RMX_A_P_BREAKPOINT:
+        if (d.K) HIPCHK(hipMemcpyAsync(d.pbrk + (size_t)r * d.K * d.B, src, (size_t)d.K * d.B * 8, hipMemcpyHostToDevice, b->stream));
+        break;
+    case RMX_A_P_ALLELE_SWAP: HIPCHK(hipMemcpyAsync(d.qs + RN * 2, src, (size_t)d.N * 16, hipMemcpyHostToDevice, b->stream)); break;
+    case RMX_A_P_OUTLIER_TOTAL: HIPCHK(hipMemcpyAsync(d.qt + RN * 2, src, (size_t)d.N * 16, hipMemcpyHostToDevice, b->stream)); break;
+    case RMX_A_P_OUTLIER_ALLELE: HIPCHK(hipMemcpyAsync(d.qa + RN * 2, src, (size_t)d.N * 16, hipMemcpyHostToDevice, b->stream)); break;
+    case RMX_A_POSTERIOR_MARGINALS:
+        HIPCHK(hipMemcpy2DAsync(d.post + RN * d.SP, (size_t)d.SP * 8, src, (size_t)d.S * 8, (size_t)d.S * 8, d.N, hipMemcpyHostToDevice, b->stream));
+        b->ab_dirty[r] = 1; break;
+    case RMX_A_TOTAL_LIKELIHOOD_MASK: case RMX_A_ALLELE_LIKELIHOOD_MASK: {
+        std::vector<uint8_t> m8(d.N);
+        for (int n = 0; n < d.N; n++) m8[n] = ((const int64_t *)src)[n] != 0;
+        HIPCHK(hipStreamSynchronize(b->stream));
+        HIPCHK(hipMemcpy((void *)(id == RMX_A_TOTAL_LIKELIHOOD_MASK ? d.mask_t : d.mask_a), m8.data(), d.N, hipMemcpyHostToDevice));
+        for (int i = 0; i < b->R; i++) b->ab_dirty[i] = 1;
+        return RMX_OK; }
+    default: return fail(RMX_EARG, "array is read-only or unknown");
+    }
+    HIPCHK(hipStreamSynchronize(b->stream));
+    return RMX_OK;
+}
+
+int rmx_get_array(rmx_batch *b, int32_t r, int32_t id, void *dst) {
+    if (r < 0 || r >= b->R || !dst) return fail(RMX_EARG, "bad restart / null destination");
+    Dev &d = b->d;
+    const size_t RN = (size_t)r * d.N;
+    switch (id) {
+    case RMX_A_H: for (int m = 0; m < d.M; m++) ((double *)dst)[m] = b->rp[r].h[m]; return RMX_OK;
+    case RMX_A_P_BREAKPOINT: if (d.K) HIPCHK(hipMemcpyAsync(dst, d.pbrk + (size_t)r * d.K * d.B, (size_t)d.K * d.B * 8, hipMemcpyDeviceToHost, b->stream)); break;
+    case RMX_A_P_ALLELE_SWAP: HIPCHK(hipMemcpyAsync(dst, d.qs + RN * 2, (size_t)d.N * 16, hipMemcpyDeviceToHost, b->stream)); break;
+    case RMX_A_P_OUTLIER_TOTAL: HIPCHK(hipMemcpyAsync(dst, d.qt + RN * 2, (size_t)d.N * 16, hipMemcpyDeviceToHost, b->stream)); break;
+    case RMX_A_P_OUTLIER_ALLELE: HIPCHK(hipMemcpyAsync(dst, d.qa + RN * 2, (size_t)d.N * 16, hipMemcpyDeviceToHost, b->stream)); break;
+    case RMX_A_POSTERIOR_MARGINALS:
+        HIPCHK(hipMemcpy2DAsync(dst, (size_t)d.S * 8, d.post + RN * d.SP, (size_t)d.SP * 8, (size_t)d.S * 8, d.N, hipMemcpyDeviceToHost, b->stream)); break;
+    case RMX_A_FRAMELOGPROB:
+        HIPCHK(hipMemcpy2DAsync(dst, (size_t)d.S * 8, d.f + RN * d.SP, (size_t)d.SP * 8, (size_t)d.S * 8, d.N, hipMemcpyDeviceToHost, b->stream)); break;
+    case RMX_A_TOTAL_LIKELIHOOD_MASK: case RMX_A_ALLELE_LIKELIHOOD_MASK: {
+        std::vector<uint8_t> m8(d.N);
+        HIPCHK(hipStreamSynchronize(b->stream));
+        HIPCHK(hipMemcpy(m8.data(), id == RMX_A_TOTAL_LIKELIHOOD_MASK ? d.mask_t : d.mask_a, d.N, hipMemcpyDeviceToHost));
+        for (int n = 0; n < d.N; n++) ((int64_t *)dst)[n] = m8[n];
+        return RMX_OK; }
+    case RMX_A_STATE_SEQUENCE:
+        if ((int)b->last_path.size() != d.N) return fail(RMX_EARG, "no Viterbi path computed yet");
+        memcpy(dst, b->last_path.data(), (size_t)d.N * 8); return RMX_OK;
+    case RMX_A_LOG_TRANSMAT: case RMX_A_CACHED_LOG_TRANSMAT: case RMX_A_JOINT_POSTERIOR_MARGINALS: {
+        if (d.N < 2) return RMX_OK;
+        const size_t cnt = (size_t)(d.N - 1) * d.S * d.S;
+        double *tmp = nullptr;
+        HIPCHK(hipMalloc((void **)&tmp, cnt * 8));
+        if (id == RMX_A_JOINT_POSTERIOR_MARGINALS)
+            hipLaunchKernelGGL(k_materialize_joint, dim3(d.N - 1), dim3(256), 0, b->stream, d, r, b->lt_valid[r] ? 0 : 1, tmp);
+        else
+            hipLaunchKernelGGL(k_materialize_T, dim3(d.N - 1), dim3(256), 0, b->stream, d, r, id == RMX_A_LOG_TRANSMAT ? 0 : 1,
+                               (id == RMX_A_LOG_TRANSMAT && !b->lt_valid[r]) ? 1 : 0, tmp);
+        hipError_t e = hipMemcpyAsync(dst, tmp, cnt * 8, hipMemcpyDeviceToHost, b->stream);
+        hipStreamSynchronize(b->stream);
+        hipFree(tmp);
+        if (e != hipSuccess) return fail(RMX_EDEVICE, hipGetErrorString(e));
+        return RMX_OK; }
+    default: return fail(RMX_EARG, "bad array id");
+    }
+    HIPCHK(hipStreamSynchronize(b->stream));
+    return RMX_OK;
+}
+
+int rmx_get_state_table(rmx_batch *b, int32_t which, int64_t *dst) {
+    const Dev &d = b->d;
+    const int S = d.S, M = d.M;
+    for (int n = 0; n < d.N; n++) {
+        const int64_t *t = b->cn_classes.data() + (size_t)b->seg_class[n] * S * M * 2;
+        for (int s = 0; s < S; s++) {
+            if (which == 0) { for (int m = 0; m < M; m++) dst[((size_t)n * S + s) * M + m] = t[(s * M + m) * 2] + t[(s * M + m) * 2 + 1]; continue; }
+            bool hdel = true, loh = false; int nsub = 0;
+            for (int m = 0; m < M; m++) if (t[(s * M + m) * 2] || t[(s * M + m) * 2 + 1]) hdel = false;
+            for (int a = 0; a < 2; a++) {
+                int64_t sum = 0; for (int m = 0; m < M; m++) sum += t[(s * M + m) * 2 + a];
+                if (sum == 0) loh = true;
+                if (M > 1) { int64_t lo = t[(s * M + 1) * 2 + a], hi = lo; for (int m = 2; m < M; m++) { lo = std::min(lo, t[(s * M + m) * 2 + a]); hi = std::max(hi, t[(s * M + m) * 2 + a]); } if (hi != lo) nsub++; }
+            }
+            dst[(size_t)n * S + s] = which == 1 ? nsub : (which == 2 ? (hdel ? 1 : 0) : (loh ? 1 : 0));
+        }
+    }
+    return RMX_OK;
+}
+
+// ---- coordinate updates -------------------------------------------------------------
+static int do_framelogprob(rmx_batch *b, int r0, int r1) {
+    int rc = ensure_tables(b, r0, r1);
+    if (rc) return rc;
+    ProfScope ps(b, KID_FRAMELOGPROB);
+    hipLaunchKernelGGL(k_framelogprob, row_grid(b, r1 - r0), dim3(256), 0, b->stream, b->d, r0, b->G);
+    HIPCHK(hipGetLastError());
+    return RMX_OK;
+}
+static int do_update_p_cn(rmx_batch *b, int r0, int r1) {
+    int rc = do_framelogprob(b, r0, r1);
+    if (rc) return rc;
+    // log_transmat snapshot := T(current p_breakpoint)   (bpmodel.pyx:939)
+    if ((rc = launch_brk_lut(b, r0, r1, b->d.pd_lt))) return rc;
+    {
+        ProfScope ps(b, KID_FB);
+        fb_kernel_t k = fb_kernel_for(b->fb_rpt);
+        hipLaunchKernelGGL(k, dim3(b->d.NC, r1 - r0, 2), dim3(b->fbL.NT), b->fb_lds, b->stream, b->d, r0, b->fbL);
+        HIPCHK(hipGetLastError());
+    }
+    {
+        ProfScope ps(b, KID_MARGINALS);
+        hipLaunchKernelGGL(k_marginals<true>, row_grid(b, r1 - r0), dim3(256), 0, b->stream, b->d, r0, b->G);
+        HIPCHK(hipGetLastError());
+    }
+    for (int r = r0; r < r1; r++) { b->ab_dirty[r] = 0; if (!b->lt_valid[r]) { b->lt_valid[r] = 1; int one = 1; HIPCHK(hipMemcpyAsync(b->d_lt_valid + r, &one, 4, hipMemcpyHostToDevice, b->stream)); } }
+    // pairwise reductions at breakend adjacencies (feeds update_p_breakpoint and the ELBO)
+    return launch_pairwise_breakends(b, r0, r1, 0);
+}
+static int do_update_p_breakpoint(rmx_batch *b, int r0, int r1) {
+    const Dev &d = b->d;
+    if (d.K > 0) {
+        ProfScope ps(b, KID_BRK_UPDATE);
+        hipLaunchKernelGGL(k_brk_update, dim3(d.K, r1 - r0), dim3(128), (size_t)d.B * 16, b->stream, b->d, r0);
+        HIPCHK(hipGetLastError());
+    }
+    // cached_log_transmat := T(new p_breakpoint)  (bpmodel.pyx:985)
+    int rc = launch_brk_lut(b, r0, r1, b->d.pd_cached);
+    if (rc) return rc;
+    const double pti = plain_T_mean_sum(b);
+    for (int r = r0; r < r1; r++) b->plain_T_init[r] = pti;
+    return RMX_OK;
+}
+static int do_indicator(rmx_batch *b, int r0, int r1, int which) {
+    int rc = ensure_ab(b, r0, r1);
+    if (rc) return rc;
+    dim3 g((b->d.N + 255) / 256, r1 - r0);
+    if (which == 0) { ProfScope ps(b, KID_OUTLIER_TOTAL); hipLaunchKernelGGL(k_update_outlier_total, g, dim3(256), 0, b->stream, b->d, r0); }
+    else if (which == 1) { ProfScope ps(b, KID_OUTLIER_ALLELE); hipLaunchKernelGGL(k_update_outlier_allele, g, dim3(256), 0, b->stream, b->d, r0); }
+    else { ProfScope ps(b, KID_ALLELE_SWAP); hipLaunchKernelGGL(k_update_allele_swap, g, dim3(256), 0, b->stream, b->d, r0); }
+    HIPCHK(hipGetLastError());
+    return RMX_OK;
+}
+#define RANGE_CHECK() if (!b || r0 < 0 || r1 > b->R || r0 >= r1) return fail(RMX_EARG, "bad restart range")
+
+int rmx_update_framelogprob(rmx_batch *b, int32_t r0, int32_t r1) { RANGE_CHECK(); int rc = do_framelogprob(b, r0, r1); return rc ? rc : check_errors(b, r0, r1); }
+int rmx_update_p_cn(rmx_batch *b, int32_t r0, int32_t r1) { RANGE_CHECK(); int rc = do_update_p_cn(b, r0, r1); return rc ? rc : check_errors(b, r0, r1); }
+int rmx_update_p_breakpoint(rmx_batch *b, int32_t r0, int32_t r1) { RANGE_CHECK(); int rc = do_update_p_breakpoint(b, r0, r1); return rc ? rc : check_errors(b, r0, r1); }
+int rmx_update_p_outlier_total(rmx_batch *b, int32_t r0, int32_t r1) { RANGE_CHECK(); int rc = do_indicator(b, r0, r1, 0); return rc ? rc : check_errors(b, r0, r1); }
+int rmx_update_p_outlier_allele(rmx_batch *b, int32_t r0, int32_t r1) { RANGE_CHECK(); int rc = do_indicator(b, r0, r1, 1); return rc ? rc : check_errors(b, r0, r1); }
+int rmx_update_p_allele_swap(rmx_batch *b, int32_t r0, int32_t r1) { RANGE_CHECK(); int rc = do_indicator(b, r0, r1, 2); return rc ? rc : check_errors(b, r0, r1); }
+
+int rmx_variational_update(rmx_batch *b, int32_t r0, int32_t r1, int32_t iters) {
+    RANGE_CHECK();
+    for (int it = 0; it < iters; it++) {
+        int rc;
+        if ((rc = do_indicator(b, r0, r1, 2)) || (rc = do_update_p_cn(b, r0, r1)) || (rc = do_update_p_breakpoint(b, r0, r1)) ||
+            (rc = do_indicator(b, r0, r1, 0)) || (rc = do_indicator(b, r0, r1, 1))) return rc;
+    }
+    return check_errors(b, r0, r1);
+}
+
+// ---- objectives ------------------------------------------------------------------------
+static int elbo_parts(rmx_batch *b, int r0, int r1, bool exact_parts, double *out4 /* [nr][4] host */) {
+    int rc = ensure_ab(b, r0, r1);
+    if (rc) return rc;
+    const int nr = r1 - r0;
+    const double *full_plain = nullptr;
+    if (exact_parts) {
+        // energy and entropy individually also contain sum_plain joint*T, which cancels in the ELBO
+        for (int r = r0; r < r1; r++) if (!b->lt_valid[r]) exact_parts = false;   // pre-update: both closed-form
+    }
+    std::vector<double> plain_host;
+    double *d_fp = nullptr;
+    if (exact_parts && !b->plain_list.empty()) {
+        const int np = (int)b->plain_list.size();
+        if (!b->d_plain_list) { if ((rc = dalloc(b, &b->d_plain_list, np)) || (rc = dalloc(b, &b->d_plain_jt, (size_t)b->R * np))) return rc;
+            HIPCHK(hipMemcpy(b->d_plain_list, b->plain_list.data(), (size_t)np * 4, hipMemcpyHostToDevice)); }
+        { ProfScope ps(b, KID_PAIRWISE); hipLaunchKernelGGL(k_pairwise, dim3(np, nr), dim3(256), 0, b->stream, b->d, r0, 0, (const int32_t *)b->d_plain_list, b->d_plain_jt); }
+        std::vector<double> jt((size_t)nr * np);
+        HIPCHK(hipMemcpyAsync(jt.data(), b->d_plain_jt, jt.size() * 8, hipMemcpyDeviceToHost, b->stream));
+        HIPCHK(hipStreamSynchronize(b->stream));
+        plain_host.assign(nr, 0.);
+        for (int i = 0; i < nr; i++) for (int j = 0; j < np; j++) plain_host[i] += jt[(size_t)i * np + j];
+        HIPCHK(hipMalloc((void **)&d_fp, nr * 8));
+        HIPCHK(hipMemcpy(d_fp, plain_host.data(), nr * 8, hipMemcpyHostToDevice));
+        full_plain = d_fp;
+    }
+    { ProfScope ps(b, KID_ELBO_SEG); hipLaunchKernelGGL(k_elbo_seg, dim3(ELBO_BLOCKS, nr), dim3(256), 0, b->stream, b->d, r0, b->d_partial); }
+    // plain_T_init may differ per restart only in exotic call orders; launch per distinct value
+    for (int r = r0; r < r1; r++) {
+        ProfScope ps(b, KID_ELBO_FINAL);
+        hipLaunchKernelGGL(k_elbo_final, dim3(1), dim3(256), 0, b->stream, b->d, r, b->d_partial + (size_t)(r - r0) * ELBO_BLOCKS * 2, ELBO_BLOCKS,
+                           (const int *)b->d_lt_valid, b->plain_T_init[r], full_plain ? full_plain + (r - r0) : nullptr, b->d_out4 + (size_t)(r - r0) * 4);
+    }
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(out4, b->d_out4, (size_t)nr * 32, hipMemcpyDeviceToHost, b->stream));
+    rc = check_errors(b, r0, r1);
+    if (d_fp) hipFree(d_fp);
+    if (rc) return rc;
+    for (int r = r0; r < r1; r++) if (b->lt_valid[r]) b->logZ[r] = out4[(r - r0) * 4 + 3];
+    return RMX_OK;
+}
+int rmx_calculate_elbo(rmx_batch *b, int32_t r0, int32_t r1, double *out) {
+    RANGE_CHECK();
+    std::vector<double> o4((size_t)(r1 - r0) * 4);
+    int rc = elbo_parts(b, r0, r1, false, o4.data());
+    if (rc) return rc;
+    for (int i = 0; i < r1 - r0; i++) out[i] = o4[i * 4 + 2];
+    return RMX_OK;
+}
+int rmx_calculate_variational_energy(rmx_batch *b, int32_t r0, int32_t r1, double *out) {
+    RANGE_CHECK();
+    std::vector<double> o4((size_t)(r1 - r0) * 4);
+    int rc = elbo_parts(b, r0, r1, true, o4.data());
+    if (rc) return rc;
+    for (int i = 0; i < r1 - r0; i++) out[i] = o4[i * 4 + 0];
+    return RMX_OK;
+}
+int rmx_calculate_variational_entropy(rmx_batch *b, int32_t r0, int32_t r1, double *out) {
+    RANGE_CHECK();
+    std::vector<double> o4((size_t)(r1 - r0) * 4);
+    int rc = elbo_parts(b, r0, r1, true, o4.data());
+    if (rc) return rc;
+    for (int i = 0; i < r1 - r0; i++) out[i] = o4[i * 4 + 1];
+    return RMX_OK;
+}
+
+int rmx_expected_log_likelihood(rmx_batch *b, int32_t r, const int64_t *sample, double *ell_out, double *partial_h_out) {
+    if (!b || r < 0 || r >= b->R || !sample || !ell_out) return fail(RMX_EARG, "bad argument");
+    const Dev &d = b->d;
+    // mask -> index list, cached across the many evaluations of one M-step
+    if ((int)b->sample_cache.size() != d.N || memcmp(b->sample_cache.data(), sample, (size_t)d.N * 8) != 0) {
+        b->sample_cache.assign(sample, sample + d.N);
+        std::vector<int32_t> idx;
+        idx.reserve(256);
+        for (int n = 0; n < d.N; n++) if (sample[n] != 0) idx.push_back(n);
+        b->sample_count = (int)idx.size();
+        if (!idx.empty()) HIPCHK(hipMemcpyAsync(b->d_sample, idx.data(), idx.size() * 4, hipMemcpyHostToDevice, b->stream));
+        HIPCHK(hipStreamSynchronize(b->stream));
+    }
+    const int W = 1 + RMX_MAX_CLONES;
+    const int cnt = b->sample_count;
+    int rc;
+    if (cnt == 0) { *ell_out = 0.; if (partial_h_out) for (int m = 0; m < d.M; m++) partial_h_out[m] = 0.; return RMX_OK; }
+    if (cnt == d.N && !partial_h_out) {
+        if ((rc = ensure_ab(b, r, r + 1))) return rc;
+        { ProfScope ps(b, KID_ELL_FULL); hipLaunchKernelGGL(k_ell_full, dim3(ELBO_BLOCKS), dim3(256), 0, b->stream, b->d, r, b->d_ell_partial); }
+        { ProfScope ps(b, KID_ELL_FINAL); hipLaunchKernelGGL(k_ell_final, dim3(1), dim3(256), 0, b->stream, b->d_ell_partial, ELBO_BLOCKS, b->d_ell_out); }
+    } else {
+        if ((rc = ensure_tables(b, r, r + 1))) return rc;
+        {
+            ProfScope ps(b, KID_ELL_LIST);
+            if (partial_h_out) hipLaunchKernelGGL(k_ell_list<true>, dim3(cnt), dim3(256), 0, b->stream, b->d, r, (const int32_t *)b->d_sample, b->d_ell_partial);
+            else hipLaunchKernelGGL(k_ell_list<false>, dim3(cnt), dim3(256), 0, b->stream, b->d, r, (const int32_t *)b->d_sample, b->d_ell_partial);
+        }
+        { ProfScope ps(b, KID_ELL_FINAL); hipLaunchKernelGGL(k_ell_final, dim3(1), dim3(256), 0, b->stream, b->d_ell_partial, cnt, b->d_ell_out); }
+    }
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(b->h_pinned, b->d_ell_out, W * 8, hipMemcpyDeviceToHost, b->stream));
+    if ((rc = check_errors(b, r, r + 1))) return rc;
+    *ell_out = b->h_pinned[0];
+    if (partial_h_out) for (int m = 0; m < d.M; m++) partial_h_out[m] = b->h_pinned[1 + m];
+    return RMX_OK;
+}
+
+static int cell_probe(rmx_batch *b, int r, int n, int s, double out6[6]) {
+    if (r < 0 || r >= b->R || n < 0 || n >= b->d.N || s < 0 || s >= b->d.S) return fail(RMX_EARG, "index out of range");
+    int rc = ensure_tables(b, r, r + 1);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_cell_probe, dim3(1), dim3(1), 0, b->stream, b->d, r, n, s, b->d_ell_out);
+    HIPCHK(hipMemcpyAsync(b->h_pinned, b->d_ell_out, 48, hipMemcpyDeviceToHost, b->stream));
+    if ((rc = check_errors(b, r, r + 1))) return rc;
+    for (int i = 0; i < 6; i++) out6[i] = b->h_pinned[i];
+    return RMX_OK;
+}
+int rmx_log_likelihood_total(rmx_batch *b, int32_t r, int32_t n, int32_t s, int32_t u, double *out) {
+    double o[6]; int rc = cell_probe(b, r, n, s, o); if (rc) return rc; *out = o[u ? 1 : 0]; return RMX_OK;
+}
+int rmx_log_likelihood_allele(rmx_batch *b, int32_t r, int32_t n, int32_t s, int32_t v, int32_t w, double *out) {
+    double o[6]; int rc = cell_probe(b, r, n, s, o); if (rc) return rc; *out = o[2 + (v ? 2 : 0) + (w ? 1 : 0)]; return RMX_OK;
+}
+
+// ---- decoding -----------------------------------------------------------------------------
+static int viterbi_P(int S) { int P = 1; while (S * P * 2 <= 1024 && P < 64) P *= 2; return P; }
+
+int rmx_infer_cn(rmx_batch *b, int32_t r, int64_t *cn_out, double *logprob_out) {
+    if (!b || r < 0 || r >= b->R || !cn_out) return fail(RMX_EARG, "bad argument");
+    const Dev &d = b->d;
+    const int N = d.N, S = d.S, M = d.M;
+    b->last_path.assign(N, 0);
+    double lp = 0.;
+    if (!b->lt_valid[r]) {
+        // framelogprob == 1 and log_transmat == 0 (bpmodel.pyx:557-558): every comparison ties, first index wins
+        lp = (double)N;
+    } else {
+        int rc;
+        if (!b->d_bp) { if ((rc = dalloc(b, &b->d_bp, (size_t)N * S)) || (rc = dalloc(b, &b->d_final, S)) || (rc = dalloc(b, &b->d_path, N)) || (rc = dalloc(b, &b->d_logprob, 1))) return rc; }
+        const int P = viterbi_P(S);
+        const int NT = ((S * P + 63) / 64) * 64;
+        { ProfScope ps(b, KID_VITERBI);
+          hipLaunchKernelGGL(k_viterbi, dim3(1), dim3(NT), (size_t)(2 * S + M * d.D) * 8, b->stream, b->d, r, P, b->d_bp, b->d_final); }
+        int rows = std::max(1, std::min(256, (48 * 1024) / (2 * S)));
+        { ProfScope ps(b, KID_BACKTRACE);
+          hipLaunchKernelGGL(k_backtrace, dim3(1), dim3(256), (size_t)rows * S * 2, b->stream, b->d, (const uint16_t *)b->d_bp, (const double *)b->d_final, b->d_path, b->d_logprob, rows); }
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(b->last_path.data(), b->d_path, (size_t)N * 8, hipMemcpyDeviceToHost, b->stream));
+        HIPCHK(hipMemcpyAsync(b->h_pinned, b->d_logprob, 8, hipMemcpyDeviceToHost, b->stream));
+        HIPCHK(hipStreamSynchronize(b->stream));
+        lp = b->h_pinned[0];
+    }
+    if (logprob_out) *logprob_out = lp;
+    // bpmodel.pyx:1205-1210 (the allele "swap" there re-uses the flipped index on both sides: a plain gather)
+    for (int n = 0; n < N; n++) {
+        const int64_t *t = b->cn_classes.data() + ((size_t)b->seg_class[n] * S + b->last_path[n]) * M * 2;
+        for (int i = 0; i < M * 2; i++) cn_out[(size_t)n * M * 2 + i] = t[i];
+    }
+    return RMX_OK;
+}
+
+// ---- module-level functions -------------------------------------------------------------------
+int rmx_sum_product(const double *f, const double *T, double *alphas, double *betas, int32_t N, int32_t S, int32_t device) {
+    if (!f || !T || !alphas || !betas || N < 1 || S < 1) return fail(RMX_EARG, "bad argument");
+    if (S > 1024) return fail(RMX_EUNSUPPORTED, "S > 1024");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(RMX_EDEVICE, "no HIP device available (there is no CPU fallback)");
+    HIPCHK(hipSetDevice(device));
+    double *df, *dT, *da, *db;
+    const size_t ns = (size_t)N * S, nss = (size_t)std::max(N - 1, 1) * S * S;
+    HIPCHK(hipMalloc((void **)&df, ns * 8)); HIPCHK(hipMalloc((void **)&dT, nss * 8)); HIPCHK(hipMalloc((void **)&da, ns * 8)); HIPCHK(hipMalloc((void **)&db, ns * 8));
+    HIPCHK(hipMemcpy(df, f, ns * 8, hipMemcpyHostToDevice));
+    if (N > 1) HIPCHK(hipMemcpy(dT, T, (size_t)(N - 1) * S * S * 8, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_sum_product_dense, dim3(1), dim3(((S + 63) / 64) * 64), (size_t)S * 8, 0, df, dT, da, db, N, S);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpy(alphas, da, ns * 8, hipMemcpyDeviceToHost)); HIPCHK(hipMemcpy(betas, db, ns * 8, hipMemcpyDeviceToHost));
+    hipFree(df); hipFree(dT); hipFree(da); hipFree(db);
+    for (size_t i = 0; i < ns; i++) if (alphas[i] != alphas[i] || betas[i] != betas[i]) return fail(RMX_EASSERT, "nan in alphas/betas");
+    return RMX_OK;
+}
+int rmx_max_product(const double *f, const double *T, int64_t *ss, double *logprob, int32_t N, int32_t S, int32_t device) {
+    if (!f || !T || !ss || N < 1 || S < 1) return fail(RMX_EARG, "bad argument");
+    if (S > 1024) return fail(RMX_EUNSUPPORTED, "S > 1024");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(RMX_EDEVICE, "no HIP device available (there is no CPU fallback)");
+    HIPCHK(hipSetDevice(device));
+    double *df, *dT, *dfin; uint16_t *dbp;
+    const size_t ns = (size_t)N * S, nss = (size_t)std::max(N - 1, 1) * S * S;
+    HIPCHK(hipMalloc((void **)&df, ns * 8)); HIPCHK(hipMalloc((void **)&dT, nss * 8)); HIPCHK(hipMalloc((void **)&dfin, (size_t)S * 8)); HIPCHK(hipMalloc((void **)&dbp, ns * 2));
+    HIPCHK(hipMemcpy(df, f, ns * 8, hipMemcpyHostToDevice));
+    if (N > 1) HIPCHK(hipMemcpy(dT, T, (size_t)(N - 1) * S * S * 8, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_max_product_dense, dim3(1), dim3(((S + 63) / 64) * 64), (size_t)S * 8, 0, df, dT, dbp, dfin, N, S);
+    HIPCHK(hipGetLastError());
+    std::vector<uint16_t> bp(ns); std::vector<double> fin(S);
+    HIPCHK(hipMemcpy(bp.data(), dbp, ns * 2, hipMemcpyDeviceToHost)); HIPCHK(hipMemcpy(fin.data(), dfin, (size_t)S * 8, hipMemcpyDeviceToHost));
+    hipFree(df); hipFree(dT); hipFree(dfin); hipFree(dbp);
+    int mp = 0; double vm = fin[0];
+    for (int i = 1; i < S; i++) if (fin[i] > vm) { vm = fin[i]; mp = i; }
+    ss[N - 1] = mp;
+    for (int n = N - 1; n >= 1; n--) ss[n - 1] = bp[(size_t)n * S + ss[n]];
+    if (logprob) *logprob = vm;
+    return RMX_OK;
+}
+
+// ---- measurement --------------------------------------------------------------------------------
+int rmx_timer_start(rmx_batch *b) { HIPCHK(hipEventRecord(b->tm_a, b->stream)); return RMX_OK; }
+int rmx_timer_stop(rmx_batch *b, double *ms) {
+    HIPCHK(hipEventRecord(b->tm_b, b->stream)); HIPCHK(hipEventSynchronize(b->tm_b));
+    float f = 0; HIPCHK(hipEventElapsedTime(&f, b->tm_a, b->tm_b)); *ms = f; return RMX_OK;
+}
+int rmx_profile_enable(rmx_batch *b, int32_t on) { prof_collect(b); b->prof = on != 0; return RMX_OK; }
+int rmx_profile_get(rmx_batch *b, int32_t id, double *ms, int64_t *n) {
+    if (id < 0 || id >= KID_COUNT) return fail(RMX_EARG, "bad kernel id");
+    HIPCHK(hipStreamSynchronize(b->stream));
+    prof_collect(b);
+    *ms = b->prof_ms[id]; *n = b->prof_n[id];
+    return RMX_OK;
+}
+int rmx_profile_reset(rmx_batch *b) { prof_collect(b); for (int i = 0; i < KID_COUNT; i++) { b->prof_ms[i] = 0; b->prof_n[i] = 0; } return RMX_OK; }
+const char *rmx_kernel_name(int32_t id) { return (id >= 0 && id < KID_COUNT) ? kKernelNames[id] : ""; }
+int rmx_num_kernels(void) { return KID_COUNT; }
+
+}  // extern "C"

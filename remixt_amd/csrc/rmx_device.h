@@ -1,0 +1,208 @@
+// rmx_device.h -- device-side data model, math helpers and the per-cell
+// read-count likelihoods of the ReMixT variational HMM, for gfx950.
+//
+// Reference behaviour (paths relative to the reference root):
+//   negbin / betabin formulas        remixt/bpmodel.pyx:238-394
+//   digamma (AS 103)                 remixt/bpmodel.pyx:162-235
+//   per-cell likelihood branches     remixt/bpmodel.pyx:751-896
+// Nothing here is derived from the reference's code layout: the reference
+// evaluates every (segment,state,u,v,w) cell from scratch with 12 lgamma calls;
+// here everything that depends only on the segment (8 lgamma-differences) or
+// only on the state (depth, allele ratio, 4 lgamma) is hoisted into small
+// per-restart tables, leaving 8 lgamma + 4 log per cell.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/remixt_amd.h"
+
+// device error bits (per restart), translated to the reference's exceptions on the host
+#define RMX_ERR_NAN_LL 1u        // ValueError 'll is nan' (bpmodel.pyx:269, :344)
+#define RMX_ERR_BAD_P 2u         // ValueError 'p <= 0 or (1 - p) <= 0' (:335, :383)
+#define RMX_ERR_TOTAL_DEPTH 4u   // ValueError 'total_depth <= 0' (:721, :738)
+#define RMX_ERR_LOH_P 8u         // ValueError 'expected p for loh state' (:829)
+#define RMX_ERR_NAN_F 16u        // AssertionError nan framelogprob (:936)
+#define RMX_ERR_NAN_AB 32u       // AssertionError nan alphas / betas (:943-944)
+#define RMX_ERR_NAN_POST 64u     // AssertionError nan posterior marginals (:952, :962)
+#define RMX_ERR_DIGAMMA 128u     // ValueError 'x <= 0.0' in digamma (:207)
+#define RMX_ERR_NAN_GRAD 256u    // ValueError 'partial_* is nan' (:298, :391)
+
+// state-table flag bits
+#define ST_HDEL_NB 1u      // use the hdel NB branch (:760)
+#define ST_LOH_M 2u        // use loh dispersion / constants (:823-834)
+#define ST_E_TD 4u         // evaluating the allele ll raises total_depth <= 0
+#define ST_E_LOH 8u        // evaluating the allele ll raises 'expected p'
+#define ST_E_BADP 16u      // betabin raises p <= 0 or 1-p <= 0
+#define ST_GZ_ALLELE 32u   // allele gradient is zero (:867)
+
+struct RestartParams {
+    double h[RMX_MAX_CLONES];
+    double p[RMX_P_COUNT];
+};
+
+struct Dev {
+    int N, S, SP, M, K, B, C, D, cn_max, NC, NBE, TC, nc, tmodel, R, pad0;
+    double pen;
+    // ---- shared, read-only --------------------------------------------------
+    const double *l, *x, *y;             // [N], [N], [N][2]
+    const uint8_t *mask_t, *mask_a;      // [N]
+    const int32_t *seg_class;            // [N]
+    const int32_t *tclass;               // [N] transition class of (n,n+1); -1: telomere / last
+    const int32_t *brk_slot;             // [N] breakend slot of (n,n+1) or -1
+    const int32_t *brk_idx, *brk_orient; // [N]
+    const int32_t *be_n;                 // [NBE] slot -> n
+    const int32_t *chain_start, *chain_end; // [NC]
+    const uint8_t *chain_end_flag;       // [N]
+    const int8_t *cn;                    // [C][S][M][2]
+    const int8_t *tot;                   // [C][S][M]
+    const uint8_t *sflags;               // [C][S] bit0 hdel, bit1 loh, bits2-3 #subclonal alleles
+    const int32_t *brk_states;           // [B][M]
+    const int32_t *bk_ptr, *bk_slots;    // CSR breakpoint -> slots (ascending n)
+    const double *Tval, *Wf, *Wb;        // [TC][S][S]: log T (reference order), exp(T) (q=i,o=j), exp(T)^T
+    const int8_t *af, *ab;               // [TC][S][S] allele-flip term (q=i,o=j) and its transpose
+    // ---- per restart ----------------------------------------------------------
+    RestartParams *rp;                   // [R]
+    double *stD, *stP, *stM, *stLg;      // [R][C][SP]; stM [R][C][2][SP]; stLg [R][C][4][SP]
+    uint32_t *stFlags;                   // [R][C][SP]
+    double *segc;                        // [R][8][N]
+    double *qt, *qa, *qs;                // [R][N][2]
+    double *pbrk;                        // [R][K][B]
+    double *f, *fa, *fb, *post;          // [R][N][SP]
+    double *fmax, *mrow;                 // [R][N]
+    double *A, *Bv;                      // [R][N][2], [R][N][4]
+    double *rowPF, *rowPP, *rowZ;        // [R][N]
+    double *pd_lt, *pd_cached;           // [R][NBE][M][D]
+    double *hist;                        // [R][NBE][M][D]
+    double *be_jt, *be_ja;               // [R][NBE]
+    uint32_t *err;                       // [R]
+};
+
+__device__ __forceinline__ size_t rs_off(const Dev &d, int r, int n) { return ((size_t)r * d.N + n) * d.SP; }
+
+// ---- bpmodel.pyx:606-616 -------------------------------------------------------
+__device__ __forceinline__ double g_transition(int tmodel, int cn_diff) {
+    if (tmodel == 0) return (double)(cn_diff < 0 ? -cn_diff : cn_diff);
+    return cn_diff == 0 ? 0.0 : 1.0;
+}
+
+// ---- bpmodel.pyx:162-235 (AS 103) ------------------------------------------------
+__device__ inline double digamma_as103(double x, unsigned &err) {
+    if (x <= 0.0) { err |= RMX_ERR_DIGAMMA; return __builtin_nan(""); }
+    if (x <= 0.000001) return -0.57721566490153286060 - 1.0 / x + 1.6449340668482264365 * x;
+    double value = 0.0, x2 = x;
+    while (x2 < 8.5) { value = value - 1.0 / x2; x2 = x2 + 1.0; }
+    double r = 1.0 / x2;
+    value = value + log(x2) - 0.5 * r;
+    r = r * r;
+    value = (value - r * (1.0 / 12.0 - r * (1.0 / 120.0 - r * (1.0 / 252.0 - r * (1.0 / 240.0 - r * (1.0 / 132.0))))));
+    return value;
+}
+
+// ---- per-segment context ----------------------------------------------------------
+struct SegCtx {
+    double x, l, y0, y1, ys;
+    int mt, ma;
+    double cnb[4];   // [u*2+var]  lgamma(x+r) - lgamma(x+1) - lgamma(r); var 1 = hdel dispersion
+    double cbb[4];   // [v*2+var]  lgamma(n+1)-lgamma(k+1)-lgamma(n-k+1)-lgamma(n+M)+lgamma(M); var 1 = loh dispersion
+};
+
+__device__ __forceinline__ void load_seg(const Dev &d, int r, int n, SegCtx &c) {
+    c.x = d.x[n]; c.l = d.l[n]; c.y0 = d.y[2 * (size_t)n]; c.y1 = d.y[2 * (size_t)n + 1]; c.ys = c.y0 + c.y1;
+    c.mt = d.mask_t[n]; c.ma = d.mask_a[n];
+    const double *sc = d.segc + (size_t)r * 8 * d.N + n;
+#pragma unroll
+    for (int i = 0; i < 4; i++) { c.cnb[i] = sc[(size_t)i * d.N]; c.cbb[i] = sc[(size_t)(4 + i) * d.N]; }
+}
+
+__device__ __forceinline__ double nb_state_part(double x, double mu, double r) {
+    // x*log(p) + r*log(1-p) with p = mu/(r+mu), p outside [0,1] -> 0.5 (bpmodel.pyx:261-267)
+    double p = mu / (r + mu);
+    if (p < 0. || p > 1.) p = 0.5;
+    return x * log(p) + r * log(1 - p);
+}
+
+// The six likelihood values of one (segment,state) cell:
+//   LT[u]      = calculate_log_likelihood_total(n,s,u)      (bpmodel.pyx:751-776)
+//   LA[v*2+w]  = calculate_log_likelihood_allele(n,s,v,w)   (bpmodel.pyx:809-853)
+__device__ inline void cell_ll(const Dev &d, const RestartParams &rp, const SegCtx &sc, int r, int cls, int s,
+                               double LT[2], double LA[4], unsigned &err) {
+    const size_t si = ((size_t)r * d.C + cls) * d.SP + s;
+    const unsigned fl = d.stFlags[si];
+    if (!sc.mt) { LT[0] = 0.; LT[1] = 0.; }
+    else {
+        if (fl & ST_HDEL_NB) {
+            const double mu = rp.p[RMX_P_NEGBIN_HDEL_MU];
+            LT[0] = sc.cnb[1] + nb_state_part(sc.x, mu, rp.p[RMX_P_NEGBIN_HDEL_R_0]);
+            LT[1] = sc.cnb[3] + nb_state_part(sc.x, mu, rp.p[RMX_P_NEGBIN_HDEL_R_1]);
+        } else {
+            const double mu = d.stD[si] * sc.l;
+            LT[0] = sc.cnb[0] + nb_state_part(sc.x, mu, rp.p[RMX_P_NEGBIN_R_0]);
+            LT[1] = sc.cnb[2] + nb_state_part(sc.x, mu, rp.p[RMX_P_NEGBIN_R_1]);
+        }
+        if (LT[0] != LT[0] || LT[1] != LT[1]) err |= RMX_ERR_NAN_LL;
+    }
+    if (!sc.ma) { LA[0] = LA[1] = LA[2] = LA[3] = 0.; }
+    else {
+        if (fl & ST_E_TD) err |= RMX_ERR_TOTAL_DEPTH;
+        if (fl & ST_E_LOH) err |= RMX_ERR_LOH_P;
+        if (sc.ys == 0. || (fl & (ST_E_TD | ST_E_LOH))) { LA[0] = LA[1] = LA[2] = LA[3] = 0.; }
+        else if (fl & ST_E_BADP) { err |= RMX_ERR_BAD_P; LA[0] = LA[1] = LA[2] = LA[3] = 0.; }
+        else {
+            const double p = d.stP[si];
+            const int var = (fl & ST_LOH_M) ? 1 : 0;
+            const size_t cs = (size_t)d.SP;
+            const double *Mv = d.stM + ((size_t)r * d.C + cls) * 2 * cs + s;
+            const double *lg = d.stLg + ((size_t)r * d.C + cls) * 4 * cs + s;
+#pragma unroll
+            for (int v = 0; v < 2; v++) {
+                const double M = Mv[v * cs];
+                const double a = M * p, b = M * (1 - p);
+                const double base = sc.cbb[v * 2 + var] - lg[(2 * v) * cs] - lg[(2 * v + 1) * cs];
+                // w = 0: k = y0 ; w = 1: k = y1
+                LA[v * 2 + 0] = base + lgamma(sc.y0 + a) + lgamma(sc.ys - sc.y0 + b);
+                LA[v * 2 + 1] = base + lgamma(sc.y1 + a) + lgamma(sc.ys - sc.y1 + b);
+            }
+            if (LA[0] != LA[0] || LA[1] != LA[1] || LA[2] != LA[2] || LA[3] != LA[3]) err |= RMX_ERR_NAN_LL;
+        }
+    }
+}
+
+// prior of bpmodel.pyx:746-749: -1.0 * num_alleles_subclonal * l * divergence_weight
+__device__ __forceinline__ double cell_prior(const Dev &d, const RestartParams &rp, const SegCtx &sc, int cls, int s) {
+    const double nsub = (double)((d.sflags[(size_t)cls * d.S + s] >> 2) & 3);
+    return -1.0 * nsub * sc.l * rp.p[RMX_P_DIVERGENCE_WEIGHT];
+}
+
+// two-element _exp_normalize (bpmodel.pyx:120-128), same operation order
+__device__ __forceinline__ void exp_normalize2(double lp0, double lp1, double &y0, double &y1) {
+    const double vmax = lp0 > lp1 ? lp0 : lp1;   // _max: strict > from -inf
+    double ps = 0.; ps += exp(lp0 - vmax); ps += exp(lp1 - vmax);
+    const double norm = log(ps) + vmax;
+    y0 = exp(lp0 - norm); y1 = exp(lp1 - norm);
+    const double s = y0 + y1;
+    y0 /= s; y1 /= s;
+}
+
+__device__ __forceinline__ double xlogx(double v) { return v > 0. ? v * log(v) : 0.; }
+
+template <typename T> __device__ __forceinline__ T shfl_xor_t(T v, int off) { return __shfl_xor(v, off, 64); }
+
+__device__ __forceinline__ double group_sum(double v, int G) {
+    for (int off = G >> 1; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+__device__ __forceinline__ double group_max(double v, int G) {
+    for (int off = G >> 1; off > 0; off >>= 1) { double o = __shfl_xor(v, off, 64); v = o > v ? o : v; }
+    return v;
+}
+
+// block-wide deterministic sum (fixed tree): all threads must call; result valid in thread 0
+template <int NT> __device__ inline double block_sum(double v, double *scratch /* >= NT/64 */) {
+    v = group_sum(v, 64);
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    __syncthreads();
+    if (lane == 0) scratch[w] = v;
+    __syncthreads();
+    double t = 0.;
+    if (threadIdx.x == 0) for (int i = 0; i < NT / 64; i++) t += scratch[i];
+    return t;
+}

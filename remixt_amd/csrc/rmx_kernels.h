@@ -1,0 +1,915 @@
+// rmx_kernels.h -- HIP kernels of the ReMixT variational-HMM hot path (gfx950).
+//
+// Design: the reference materialises three dense (N-1) x S x S
+// float64 arrays per model (bpmodel.pyx:558-561).  Here nothing of that size
+// exists: transitions are generated on the fly from per-class S x S tables held
+// in registers / L2, the forward-backward recursion runs in the *scaled linear
+// domain* (one FMA per transition term instead of one exp), telomeres split the
+// genome into independent chains (one workgroup per chain x restart x direction),
+// and the pairwise posterior is only ever formed at breakend adjacencies, where
+// the breakpoint update and the ELBO actually need it.
+#pragma once
+#include "rmx_device.h"
+
+// =============================================================================
+// per-restart tables
+// =============================================================================
+
+// state tables: depth, allele ratio, dispersion and lgamma(M p), lgamma(M (1-p))
+// per (restart, class, state).  grid (C, nr), block 256.
+__global__ void k_state_tables(Dev d, int r0) {
+    const int cls = blockIdx.x, r = r0 + blockIdx.y;
+    const RestartParams rp = d.rp[r];
+    for (int s = threadIdx.x; s < d.S; s += blockDim.x) {
+        const int8_t *cn = d.cn + ((size_t)cls * d.S + s) * d.M * 2;
+        const int8_t *tot = d.tot + ((size_t)cls * d.S + s) * d.M;
+        double minor = 0., total = 0.;
+        for (int m = 0; m < d.M; m++) {   // bpmodel.pyx:717-719 accumulation order
+            minor += rp.h[m] * (double)cn[m * 2 + 0];
+            total += rp.h[m] * (double)tot[m];
+        }
+        const unsigned sf = d.sflags[(size_t)cls * d.S + s];
+        const bool hdel = sf & 1u, loh = sf & 2u;
+        unsigned fl = 0;
+        if (!d.nc && hdel) fl |= ST_HDEL_NB;
+        double p;
+        if (hdel) p = 0.;
+        else {
+            if (total <= 0.) { fl |= ST_E_TD; p = 0.5; }
+            else p = minor / total;
+        }
+        double M0, M1;
+        if (!d.nc && loh) {
+            if (p == 0.) p = rp.p[RMX_P_BETABIN_LOH_P];
+            else if (p == 1.) p = 1. - rp.p[RMX_P_BETABIN_LOH_P];
+            else if (!(fl & ST_E_TD)) fl |= ST_E_LOH;
+            M0 = rp.p[RMX_P_BETABIN_LOH_M_0]; M1 = rp.p[RMX_P_BETABIN_LOH_M_1];
+            fl |= ST_LOH_M | ST_GZ_ALLELE;
+        } else {
+            M0 = rp.p[RMX_P_BETABIN_M_0]; M1 = rp.p[RMX_P_BETABIN_M_1];
+        }
+        if (p <= 0. || (1 - p) <= 0.) fl |= ST_E_BADP;
+        const size_t base = ((size_t)r * d.C + cls);
+        const size_t si = base * d.SP + s;
+        d.stD[si] = total;
+        d.stP[si] = p;
+        d.stM[(base * 2 + 0) * d.SP + s] = M0;
+        d.stM[(base * 2 + 1) * d.SP + s] = M1;
+        const bool ok = !(fl & (ST_E_BADP | ST_E_TD | ST_E_LOH));
+        d.stLg[(base * 4 + 0) * d.SP + s] = ok ? lgamma(M0 * p) : 0.;
+        d.stLg[(base * 4 + 1) * d.SP + s] = ok ? lgamma(M0 * (1 - p)) : 0.;
+        d.stLg[(base * 4 + 2) * d.SP + s] = ok ? lgamma(M1 * p) : 0.;
+        d.stLg[(base * 4 + 3) * d.SP + s] = ok ? lgamma(M1 * (1 - p)) : 0.;
+        d.stFlags[si] = fl;
+    }
+}
+
+// per-segment constants of the NB / BB log pmf.  grid (ceil(N/256), nr)
+__global__ void k_seg_const(Dev d, int r0) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x, r = r0 + blockIdx.y;
+    if (n >= d.N) return;
+    const RestartParams &rp = d.rp[r];
+    const double x = d.x[n], y0 = d.y[2 * (size_t)n], y1 = d.y[2 * (size_t)n + 1], ys = y0 + y1;
+    double *sc = d.segc + (size_t)r * 8 * d.N + n;
+    const double lgx1 = lgamma(x + 1);
+    const double rr[4] = {rp.p[RMX_P_NEGBIN_R_0], rp.p[RMX_P_NEGBIN_HDEL_R_0], rp.p[RMX_P_NEGBIN_R_1], rp.p[RMX_P_NEGBIN_HDEL_R_1]};
+#pragma unroll
+    for (int i = 0; i < 4; i++) sc[(size_t)i * d.N] = lgamma(x + rr[i]) - lgx1 - lgamma(rr[i]);
+    const double cb = lgamma(ys + 1) - lgamma(y0 + 1) - lgamma(ys - y0 + 1);
+    const double MM[4] = {rp.p[RMX_P_BETABIN_M_0], rp.p[RMX_P_BETABIN_LOH_M_0], rp.p[RMX_P_BETABIN_M_1], rp.p[RMX_P_BETABIN_LOH_M_1]};
+#pragma unroll
+    for (int i = 0; i < 4; i++) sc[(size_t)(4 + i) * d.N] = cb - lgamma(ys + MM[i]) + lgamma(MM[i]);
+}
+
+// =============================================================================
+// emission fill: update_framelogprob (bpmodel.pyx:898-919) + per-row maximum
+// grid (ceil(N / (256/G)), nr), block 256; G lanes cooperate on one segment row
+// =============================================================================
+__global__ void k_framelogprob(Dev d, int r0, int G) {
+    const int r = r0 + blockIdx.y;
+    const int rows = 256 / G;
+    const int n = blockIdx.x * rows + threadIdx.x / G, gl = threadIdx.x % G;
+    if (n >= d.N) return;
+    const RestartParams &rp = d.rp[r];
+    SegCtx sc; load_seg(d, r, n, sc);
+    const int cls = d.seg_class[n];
+    const double qt0 = d.qt[((size_t)r * d.N + n) * 2], qt1 = d.qt[((size_t)r * d.N + n) * 2 + 1];
+    const double qa0 = d.qa[((size_t)r * d.N + n) * 2], qa1 = d.qa[((size_t)r * d.N + n) * 2 + 1];
+    const double qs0 = d.qs[((size_t)r * d.N + n) * 2], qs1 = d.qs[((size_t)r * d.N + n) * 2 + 1];
+    double *frow = d.f + rs_off(d, r, n);
+    unsigned err = 0;
+    double vmax = -INFINITY;
+    for (int s = gl; s < d.S; s += G) {
+        double LT[2], LA[4];
+        cell_ll(d, rp, sc, r, cls, s, LT, LA, err);
+        double f = 0.;
+        f += qt0 * LT[0]; f += qt1 * LT[1];
+        f += qa0 * qs0 * LA[0]; f += qa0 * qs1 * LA[1]; f += qa1 * qs0 * LA[2]; f += qa1 * qs1 * LA[3];
+        f += cell_prior(d, rp, sc, cls, s);
+        if (f != f) err |= RMX_ERR_NAN_F;
+        frow[s] = f;
+        vmax = f > vmax ? f : vmax;
+    }
+    vmax = group_max(vmax, G);
+    if (gl == 0) d.fmax[(size_t)r * d.N + n] = vmax;
+    if (err) atomicOr(&d.err[r], err);
+}
+
+// =============================================================================
+// forward-backward in the scaled linear domain
+//
+//   e[n,j]  = exp(f[n,j] - fmax[n])
+//   fwd:  a~[k] = (a~[k-1] W) / max(a~[k-1]) * e[k]            (stored: fa)
+//   bwd:  b~[k] = (W g[k+1]) / max(g[k+1]),  g[k] = e[k] * b~[k] (stored: fb)
+//
+// which equals sum_product (bpmodel.pyx:1213-1246) up to a per-row positive scale
+// that cancels in every consumer (posterior marginals, pairwise marginals); the
+// scales themselves (row maxima, fmax) are kept to rebuild hmm_log_norm_const.
+//
+// One workgroup per (chain, restart, direction).  Thread (o, p): output state o,
+// slice p of the reduction index q.  With RPT > 0 the plain-adjacency transition
+// weights W[q][o] of the thread's slice live in registers for the whole chain
+// (they only change with the transition class); breakend adjacencies build their
+// weights on the fly from the per-breakend distance tables (bpmodel.pyx:658-668).
+// One barrier per step: the unnormalised vector and the per-wave maxima are
+// published together and the division by the maximum is applied by the consumer.
+// =============================================================================
+#define FB_NBUF 3
+#define FB_EPT 2
+
+struct FbLaunch { int P, NT, BLK, SPAD; };
+
+template <int RPT, int P, int NTMAX>
+__global__ __launch_bounds__(NTMAX) void k_fb(Dev d, int r0, FbLaunch L) {
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    const int chain = blockIdx.x, r = r0 + blockIdx.y, dir = blockIdx.z;
+    const int S = d.S, M = d.M, D = d.D;
+    const int n0 = d.chain_start[chain], n1 = d.chain_end[chain], len = n1 - n0 + 1;
+    const int t = threadIdx.x, NT = blockDim.x, nw = NT >> 6;
+    const int PP = L.P;
+    const int o = t / PP, p = t % PP;
+    const bool act = o < S;
+    const int QPT = (RPT > 0) ? RPT : (S + PP - 1) / PP;
+    const int SPAD = L.SPAD, BLK = L.BLK;
+    // LDS carve-up
+    double *vec = (double *)smem_raw;                   // [2][SPAD]
+    double *red = vec + 2 * SPAD;                       // [2][16]
+    double *ebuf = red + 32;                            // [NBUF][BLK][SPAD]
+    double *pdl = ebuf + (size_t)FB_NBUF * BLK * SPAD;  // [M*D]
+    int8_t *totl = (int8_t *)(pdl + M * D);             // [C][S][M]
+    for (int i = t; i < d.C * S * M; i += NT) totl[i] = d.tot[i];
+    for (int i = t; i < 2 * SPAD; i += NT) vec[i] = 0.;   // tails [S, SPAD) stay zero: padded slices read them
+
+    const double *fbase = d.f + rs_off(d, r, 0);
+    const double *fmaxb = d.fmax + (size_t)r * d.N;
+    double *outb = (dir == 0 ? d.fa : d.fb) + rs_off(d, r, 0);
+    double *mrow = d.mrow + (size_t)r * d.N;
+    const double *Wmat = dir == 0 ? d.Wf : d.Wb;
+    const int8_t *amat = dir == 0 ? d.af : d.ab;
+    const double pen = d.pen;
+
+#define ROW(k) (dir == 0 ? n0 + (k) : n1 - (k))
+    // ---- emission prefetch: block b = steps [b*BLK, (b+1)*BLK) -------------------
+    const int nblk = (len + BLK - 1) / BLK;
+    double pre[FB_EPT]; double prem[FB_EPT];
+    auto issue = [&](int b) {
+#pragma unroll
+        for (int e = 0; e < FB_EPT; e++) {
+            const int idx = t + e * NT; const int kk = idx / S, j = idx - kk * S; const int k = b * BLK + kk;
+            if (kk < BLK && k < len) { const int row = ROW(k); pre[e] = fbase[(size_t)row * d.SP + j]; prem[e] = fmaxb[row]; }
+        }
+    };
+    auto commit = [&](int b) {
+#pragma unroll
+        for (int e = 0; e < FB_EPT; e++) {
+            const int idx = t + e * NT; const int kk = idx / S, j = idx - kk * S; const int k = b * BLK + kk;
+            if (kk < BLK && k < len) ebuf[((size_t)(b % FB_NBUF) * BLK + kk) * SPAD + j] = exp(pre[e] - prem[e]);
+        }
+    };
+    issue(0); commit(0);
+    if (nblk > 1) { issue(1); commit(1); }
+    if (nblk > 2) issue(2);
+
+    // ---- register-stationary weights ------------------------------------------------
+    double w[RPT > 0 ? RPT : 1];
+    int cur_tc = -1;
+    auto load_w = [&](int tc) {
+        if constexpr (RPT > 0) {
+            const double *Wt = Wmat + (size_t)tc * S * S;
+#pragma unroll
+            for (int rr = 0; rr < RPT; rr++) { const int q = p * RPT + rr; w[rr] = (act && q < S) ? Wt[(size_t)q * S + o] : 0.; }
+        }
+        cur_tc = tc;
+    };
+    __syncthreads();
+
+    // ---- step 0 --------------------------------------------------------------------
+    {
+        const double e0 = act ? ebuf[o] : 0.;
+        if (act && p == 0) { vec[o] = e0; outb[(size_t)ROW(0) * d.SP + o] = (dir == 0) ? e0 : 1.0; }
+        double wm = (act && p == 0) ? e0 : 0.;
+        wm = group_max(wm, 64);
+        if ((t & 63) == 0) red[t >> 6] = wm;
+    }
+    __syncthreads();
+
+    for (int k = 1; k < len; k++) {
+        const int cur = (k - 1) & 1, nxt = k & 1;
+        const int row = ROW(k);
+        const int tn = (dir == 0) ? row - 1 : row;   // transition (tn, tn+1)
+        double m = red[cur * 16];
+        for (int i = 1; i < nw; i++) { const double v = red[cur * 16 + i]; m = v > m ? v : m; }
+        const double inv = 1.0 / m;
+        if (dir == 0 && t == 0) mrow[ROW(k - 1)] = m;
+        const double *vc = vec + cur * SPAD;
+        const int bs = d.brk_slot[tn];
+        const int tc = d.tclass[tn];
+        double acc = 0.;
+        if (bs < 0) {
+            if constexpr (RPT > 0) {
+                if (tc != cur_tc) load_w(tc);
+#pragma unroll
+                for (int rr = 0; rr < RPT; rr += 2) {
+                    const double2 v2 = *reinterpret_cast<const double2 *>(vc + p * RPT + rr);
+                    acc = fma(v2.x, w[rr], acc);
+                    acc = fma(v2.y, w[rr + 1], acc);
+                }
+            } else {
+                const double *Wt = Wmat + (size_t)tc * S * S;
+                if (act) for (int rr = 0; rr < QPT; rr++) { const int q = p * QPT + rr; if (q < S) acc = fma(vc[q], Wt[(size_t)q * S + o], acc); }
+            }
+        } else {
+            // breakend adjacency: exp of the expected transition cost under q(brk)
+            const double *pdg = d.pd_lt + ((size_t)r * d.NBE + bs) * M * D;
+            for (int i = t; i < M * D; i += NT) pdl[i] = pdg[i];
+            __syncthreads();
+            const int ca = d.seg_class[tn], cb = d.seg_class[tn + 1];
+            const int8_t *at = amat + (size_t)tc * S * S;
+            if (act) for (int rr = 0; rr < QPT; rr++) {
+                const int q = p * QPT + rr;
+                if (q < S) {
+                    const int si = dir == 0 ? q : o, sj = dir == 0 ? o : q;
+                    double T = 0.;
+                    for (int c = 0; c < M; c++) {
+                        const int dd = (int)totl[((size_t)ca * S + si) * M + c] - (int)totl[((size_t)cb * S + sj) * M + c];
+                        T += -pen * pdl[c * D + dd + d.cn_max + 1];
+                    }
+                    T += -pen * (double)at[(size_t)q * S + o];
+                    acc = fma(vc[q], exp(T), acc);
+                }
+            }
+        }
+        for (int off = 1; off < PP; off <<= 1) acc += __shfl_xor(acc, off, 64);
+        const double val = acc * inv;
+        const int b = k / BLK, kk = k - b * BLK;
+        const double e = act ? ebuf[((size_t)(b % FB_NBUF) * BLK + kk) * SPAD + o] : 0.;
+        const double outv = (dir == 0) ? val * e : val;
+        const double vecv = val * e;
+        if (act && p == 0) { vec[nxt * SPAD + o] = vecv; outb[(size_t)row * d.SP + o] = outv; }
+        double wm = (act && p == 0) ? vecv : 0.;
+        if (wm != wm) wm = INFINITY;   // propagate a NaN as a detectable value
+        wm = group_max(wm, 64);
+        if ((t & 63) == 0) red[nxt * 16 + (t >> 6)] = wm;
+        if (kk == 0) {   // block boundary: land block b+1, request block b+2
+            if (b + 1 < nblk && b >= 1) commit(b + 1);
+            if (b + 2 < nblk && b >= 1) issue(b + 2);
+        }
+        __syncthreads();
+    }
+    if (dir == 0 && t == 0) {
+        // last row of the chain: its own maximum is not consumed by a later step
+        double m = red[((len - 1) & 1) * 16];
+        for (int i = 1; i < nw; i++) { const double v = red[((len - 1) & 1) * 16 + i]; m = v > m ? v : m; }
+        mrow[ROW(len - 1)] = m;
+        if (!(m > 0.) || m == INFINITY) atomicOr(&d.err[r], RMX_ERR_NAN_AB);
+    }
+    if (dir == 1 && t == 0) {
+        double m = red[((len - 1) & 1) * 16];
+        for (int i = 1; i < nw; i++) { const double v = red[((len - 1) & 1) * 16 + i]; m = v > m ? v : m; }
+        if (!(m > 0.) || m == INFINITY) atomicOr(&d.err[r], RMX_ERR_NAN_AB);
+    }
+#undef ROW
+}
+
+// =============================================================================
+// posterior marginals + per-segment likelihood expectations
+//   post[n,s]  = softmax(alpha+beta) (bpmodel.pyx:948-950) == fa*fb / sum
+//   A[n,u]     = sum_s post * LT_u          B[n,vw] = sum_s post * LA_vw
+//   rowPF[n]   = sum_s post * f             rowPP[n] = sum_s post * prior
+//   rowZ[n]    = this row's share of hmm_log_norm_const (bpmodel.pyx:946)
+// The three indicator updates (bpmodel.pyx:987-1042), the likelihood part of the
+// ELBO (:1076-1109) and the full-data E[ll] (:1125-1157) are all linear in
+// (A, B), so the (N x S) likelihood cells are visited once here instead of once
+// per consumer.
+// =============================================================================
+template <bool COMPUTE_POST>
+__global__ void k_marginals(Dev d, int r0, int G) {
+    const int r = r0 + blockIdx.y;
+    const int rows = 256 / G;
+    const int n = blockIdx.x * rows + threadIdx.x / G, gl = threadIdx.x % G;
+    if (n >= d.N) return;
+    const RestartParams &rp = d.rp[r];
+    SegCtx sc; load_seg(d, r, n, sc);
+    const int cls = d.seg_class[n];
+    const size_t ro = rs_off(d, r, n);
+    double *post = d.post + ro;
+    const double *frow = d.f + ro;
+    unsigned err = 0;
+    double sum = 0.;
+    if (COMPUTE_POST) {
+        const double *fa = d.fa + ro, *fb = d.fb + ro;
+        for (int s = gl; s < d.S; s += G) sum += fa[s] * fb[s];
+        sum = group_sum(sum, G);
+        if (!(sum > 0.) || sum != sum || sum == INFINITY) err |= RMX_ERR_NAN_POST;
+        double s2 = 0.;
+        for (int s = gl; s < d.S; s += G) { const double y = fa[s] * fb[s] / sum; post[s] = y; s2 += y; }
+        s2 = group_sum(s2, G);
+        for (int s = gl; s < d.S; s += G) post[s] = post[s] / s2;   // second renormalisation of _exp_normalize
+    }
+    double a0 = 0., a1 = 0., b0 = 0., b1 = 0., b2 = 0., b3 = 0., pf = 0., pp = 0.;
+    for (int s = gl; s < d.S; s += G) {
+        double LT[2], LA[4];
+        cell_ll(d, rp, sc, r, cls, s, LT, LA, err);
+        const double ps = post[s];
+        a0 += ps * LT[0]; a1 += ps * LT[1];
+        b0 += ps * LA[0]; b1 += ps * LA[1]; b2 += ps * LA[2]; b3 += ps * LA[3];
+        pf += ps * frow[s];
+        pp += ps * cell_prior(d, rp, sc, cls, s);
+    }
+    a0 = group_sum(a0, G); a1 = group_sum(a1, G);
+    b0 = group_sum(b0, G); b1 = group_sum(b1, G); b2 = group_sum(b2, G); b3 = group_sum(b3, G);
+    pf = group_sum(pf, G); pp = group_sum(pp, G);
+    if (gl == 0) {
+        const size_t rn = (size_t)r * d.N + n;
+        d.A[rn * 2] = a0; d.A[rn * 2 + 1] = a1;
+        d.Bv[rn * 4] = b0; d.Bv[rn * 4 + 1] = b1; d.Bv[rn * 4 + 2] = b2; d.Bv[rn * 4 + 3] = b3;
+        d.rowPF[rn] = pf; d.rowPP[rn] = pp;
+        if (COMPUTE_POST) d.rowZ[rn] = d.fmax[rn] + (d.chain_end_flag[n] ? log(sum) : log(d.mrow[rn]));
+    }
+    if (err) atomicOr(&d.err[r], err);
+}
+
+// =============================================================================
+// O(N) indicator updates from (A, B)
+// =============================================================================
+__global__ void k_update_outlier_total(Dev d, int r0) {   // bpmodel.pyx:987-1003
+    const int n = blockIdx.x * blockDim.x + threadIdx.x, r = r0 + blockIdx.y;
+    if (n >= d.N) return;
+    const size_t rn = (size_t)r * d.N + n;
+    const double prior = d.rp[r].p[RMX_P_PRIOR_OUTLIER_TOTAL];
+    double lp0 = log(1. - prior), lp1 = log(prior);
+    lp0 += d.A[rn * 2]; lp1 += d.A[rn * 2 + 1];
+    double y0, y1; exp_normalize2(lp0, lp1, y0, y1);
+    d.qt[rn * 2] = y0; d.qt[rn * 2 + 1] = y1;
+}
+__global__ void k_update_outlier_allele(Dev d, int r0) {  // bpmodel.pyx:1005-1023
+    const int n = blockIdx.x * blockDim.x + threadIdx.x, r = r0 + blockIdx.y;
+    if (n >= d.N) return;
+    const size_t rn = (size_t)r * d.N + n;
+    const double prior = d.rp[r].p[RMX_P_PRIOR_OUTLIER_ALLELE];
+    const double qs0 = d.qs[rn * 2], qs1 = d.qs[rn * 2 + 1];
+    double lp0 = log(1. - prior), lp1 = log(prior);
+    lp0 += qs0 * d.Bv[rn * 4 + 0]; lp0 += qs1 * d.Bv[rn * 4 + 1];
+    lp1 += qs0 * d.Bv[rn * 4 + 2]; lp1 += qs1 * d.Bv[rn * 4 + 3];
+    double y0, y1; exp_normalize2(lp0, lp1, y0, y1);
+    d.qa[rn * 2] = y0; d.qa[rn * 2 + 1] = y1;
+}
+__global__ void k_update_allele_swap(Dev d, int r0) {     // bpmodel.pyx:1025-1042
+    const int n = blockIdx.x * blockDim.x + threadIdx.x, r = r0 + blockIdx.y;
+    if (n >= d.N) return;
+    const size_t rn = (size_t)r * d.N + n;
+    const double qa0 = d.qa[rn * 2], qa1 = d.qa[rn * 2 + 1];
+    double lp0 = 0., lp1 = 0.;
+    lp0 += qa0 * d.Bv[rn * 4 + 0]; lp1 += qa0 * d.Bv[rn * 4 + 1];
+    lp0 += qa1 * d.Bv[rn * 4 + 2]; lp1 += qa1 * d.Bv[rn * 4 + 3];
+    double y0, y1; exp_normalize2(lp0, lp1, y0, y1);
+    d.qs[rn * 2] = y0; d.qs[rn * 2 + 1] = y1;
+}
+
+// =============================================================================
+// breakend distance tables: pd[m][d] = sum_b p_brk[k,b] * g(d - orient*brk[b,m])
+// (bpmodel.pyx:659-664), including the reference's wrap-around aliasing of the
+// two outermost slots d = +-(cn_max+1) (buffer of length 2(cn_max+1), :600).
+// grid (NBE, nr), block 64 (>= M*D threads looped)
+// =============================================================================
+__global__ void k_brk_lut(Dev d, int r0, double *dst_base) {
+    const int slot = blockIdx.x, r = r0 + blockIdx.y;
+    const int n = d.be_n[slot], k = d.brk_idx[n], orient = d.brk_orient[n];
+    const double *pb = d.pbrk + ((size_t)r * d.K + k) * d.B;
+    double *dst = dst_base + ((size_t)r * d.NBE + slot) * d.M * d.D;
+    for (int i = threadIdx.x; i < d.M * d.D; i += blockDim.x) {
+        const int m = i / d.D, dd = i % d.D;
+        const int dv = dd - (d.cn_max + 1);
+        double acc = 0.;
+        if (dd == 0 || dd == d.D - 1) {
+            // both ends share one slot in the reference: accumulate d=-(cn_max+1) then d=+(cn_max+1)
+            for (int b = 0; b < d.B; b++) acc += pb[b] * g_transition(d.tmodel, -(d.cn_max + 1) - orient * d.brk_states[b * d.M + m]);
+            for (int b = 0; b < d.B; b++) acc += pb[b] * g_transition(d.tmodel, (d.cn_max + 1) - orient * d.brk_states[b * d.M + m]);
+        } else {
+            for (int b = 0; b < d.B; b++) acc += pb[b] * g_transition(d.tmodel, dv - orient * d.brk_states[b * d.M + m]);
+        }
+        dst[i] = acc;
+    }
+}
+
+// log transition value of adjacency (n, n+1) for states (i, j), reference
+// accumulation order (bpmodel.pyx:648-684).  pd: the breakend table or nullptr.
+__device__ __forceinline__ double trans_value(const Dev &d, int n, int i, int j, const double *pd) {
+    const int tc = d.tclass[n];
+    if (tc < 0) return 0.;
+    if (pd == nullptr) return d.Tval[((size_t)tc * d.S + i) * d.S + j];
+    const int ca = d.seg_class[n], cb = d.seg_class[n + 1];
+    double T = 0.;
+    for (int c = 0; c < d.M; c++) {
+        const int dd = (int)d.tot[((size_t)ca * d.S + i) * d.M + c] - (int)d.tot[((size_t)cb * d.S + j) * d.M + c];
+        T += -d.pen * pd[c * d.D + dd + d.cn_max + 1];
+    }
+    T += -d.pen * (double)d.af[((size_t)tc * d.S + i) * d.S + j];
+    return T;
+}
+
+// =============================================================================
+// pairwise posterior at selected adjacencies (bpmodel.pyx:954-960), reduced on
+// the fly to what its consumers need:
+//   hist[m][d] = sum_{i,j: tot_i,m - tot_j,m = d} joint[i,j]   (:628-633)
+//   jt         = sum joint * log_transmat                      (:1052)
+//   ja         = sum joint * allele-flip term
+// mode 0: joint from fa/fb/f ; mode 1: uniform joint (state before the first
+// update_p_cn, :566-567) with log_transmat == 0.
+// grid (nlist, nr), block 256.  list == nullptr -> breakend slots.
+// =============================================================================
+__global__ void k_pairwise(Dev d, int r0, int mode, const int32_t *list, double *jt_out) {
+    __shared__ double hw[4][RMX_MAX_CLONES * 64];
+    __shared__ double gvec[1024];
+    __shared__ double scratch[8];
+    const int r = r0 + blockIdx.y;
+    const int slot = list ? -1 : (int)blockIdx.x;
+    const int n = list ? list[blockIdx.x] : d.be_n[blockIdx.x];
+    const int S = d.S, M = d.M, D = d.D, t = threadIdx.x, wv = t >> 6;
+    for (int i = t; i < 4 * RMX_MAX_CLONES * 64; i += 256) (&hw[0][0])[i] = 0.;
+    const int bs = d.brk_slot[n];
+    const double *pd = (bs >= 0) ? d.pd_lt + ((size_t)r * d.NBE + bs) * M * D : nullptr;
+    const int tc = d.tclass[n];
+    const int ca = d.seg_class[n], cb = d.seg_class[n + 1];
+    const double *fa = d.fa + rs_off(d, r, n);
+    if (mode == 0) {
+        const double *fb = d.fb + rs_off(d, r, n + 1), *fr = d.f + rs_off(d, r, n + 1);
+        const double fm = d.fmax[(size_t)r * d.N + n + 1];
+        for (int j = t; j < S; j += 256) gvec[j] = exp(fr[j] - fm) * fb[j];
+    }
+    __syncthreads();
+    double z = 0., jt = 0., ja = 0.;
+    for (int idx = t; idx < S * S; idx += 256) {
+        const int i = idx / S, j = idx - i * S;
+        double T = 0., J;
+        if (mode == 0) { T = trans_value(d, n, i, j, pd); J = fa[i] * exp(T) * gvec[j]; }
+        else J = 1.0;
+        z += J; jt += J * T;
+        if (tc >= 0) {
+            ja += J * (double)d.af[((size_t)tc * S + i) * S + j];
+            if (slot >= 0)
+                for (int c = 0; c < M; c++) {
+                    const int dd = (int)d.tot[((size_t)ca * S + i) * M + c] - (int)d.tot[((size_t)cb * S + j) * M + c];
+                    atomicAdd(&hw[wv][c * 64 + dd + d.cn_max + 1], J);
+                }
+        } else if (slot >= 0) {
+            for (int c = 0; c < M; c++) {
+                const int dd = (int)d.tot[((size_t)ca * S + i) * M + c] - (int)d.tot[((size_t)cb * S + j) * M + c];
+                atomicAdd(&hw[wv][c * 64 + dd + d.cn_max + 1], J);
+            }
+        }
+    }
+    z = block_sum<256>(z, scratch);
+    __shared__ double zsh;
+    if (t == 0) zsh = z;
+    jt = block_sum<256>(jt, scratch);
+    __shared__ double jtsh;
+    if (t == 0) jtsh = jt;
+    ja = block_sum<256>(ja, scratch);
+    __syncthreads();
+    const double zz = zsh;
+    if (t == 0) {
+        if (slot >= 0) {
+            d.be_jt[(size_t)r * d.NBE + slot] = jtsh / zz;
+            d.be_ja[(size_t)r * d.NBE + slot] = ja / zz;
+        }
+        if (jt_out) jt_out[(size_t)(r - r0) * gridDim.x + blockIdx.x] = jtsh / zz;
+    }
+    if (slot >= 0)
+        for (int i = t; i < M * D; i += 256) {
+            const int c = i / D, dd = i % D;
+            const double v = ((hw[0][c * 64 + dd] + hw[1][c * 64 + dd]) + hw[2][c * 64 + dd]) + hw[3][c * 64 + dd];
+            d.hist[((size_t)r * d.NBE + slot) * M * D + i] = v / zz;
+        }
+}
+
+// =============================================================================
+// update_p_breakpoint (bpmodel.pyx:964-985, 618-637) from the breakend histograms
+// grid (K, nr), block 128
+// =============================================================================
+__global__ void k_brk_update(Dev d, int r0) {
+    extern __shared__ double lp[];   // [B] then [B]
+    const int k = blockIdx.x, r = r0 + blockIdx.y;
+    const int B = d.B, M = d.M, D = d.D;
+    double *y = lp + B;
+    for (int b = threadIdx.x; b < B; b += blockDim.x) {
+        double acc = 0.;
+        for (int e = d.bk_ptr[k]; e < d.bk_ptr[k + 1]; e++) {
+            const int slot = d.bk_slots[e];
+            const int n = d.be_n[slot], orient = d.brk_orient[n];
+            const double *h = d.hist + ((size_t)r * d.NBE + slot) * M * D;
+            const double mult = -d.pen;
+            for (int c = 0; c < M; c++) {
+                const int bv = d.brk_states[b * M + c];
+                const double edge = h[c * D] + h[c * D + D - 1];   // aliased outer slots (see k_brk_lut)
+                for (int dd = 0; dd < D; dd++) {
+                    const double pdv = (dd == 0 || dd == D - 1) ? edge : h[c * D + dd];
+                    acc += mult * pdv * g_transition(d.tmodel, (dd - (d.cn_max + 1)) - orient * bv);
+                }
+            }
+        }
+        lp[b] = acc;
+    }
+    __syncthreads();
+    // _exp_normalize (bpmodel.pyx:120-128), every thread runs the same sequential sums
+    double vmax = -INFINITY;
+    for (int b = 0; b < B; b++) if (lp[b] > vmax) vmax = lp[b];
+    double ps = 0.;
+    for (int b = 0; b < B; b++) ps += exp(lp[b] - vmax);
+    const double norm = log(ps) + vmax;
+    for (int b = threadIdx.x; b < B; b += blockDim.x) y[b] = exp(lp[b] - norm);
+    __syncthreads();
+    double s = 0.;
+    for (int b = 0; b < B; b++) s += y[b];
+    double *pb = d.pbrk + ((size_t)r * d.K + k) * B;
+    for (int b = threadIdx.x; b < B; b += blockDim.x) pb[b] = y[b] / s;
+}
+
+// =============================================================================
+// ELBO pieces (bpmodel.pyx:1044-1123)
+// =============================================================================
+#define ELBO_BLOCKS 256
+// per-block partials: [r][ELBO_BLOCKS][2] (energy, entropy) over segments
+__global__ void k_elbo_seg(Dev d, int r0, double *partial) {
+    __shared__ double scratch[8];
+    const int r = r0 + blockIdx.y;
+    const RestartParams &rp = d.rp[r];
+    const double pt = rp.p[RMX_P_PRIOR_OUTLIER_TOTAL], pa = rp.p[RMX_P_PRIOR_OUTLIER_ALLELE];
+    const double l1t = log(1. - pt), l0t = log(pt), l1a = log(1. - pa), l0a = log(pa);
+    double en = 0., ent = 0.;
+    for (int n = blockIdx.x * blockDim.x + threadIdx.x; n < d.N; n += gridDim.x * blockDim.x) {
+        const size_t rn = (size_t)r * d.N + n;
+        const double qt0 = d.qt[rn * 2], qt1 = d.qt[rn * 2 + 1], qa0 = d.qa[rn * 2], qa1 = d.qa[rn * 2 + 1];
+        const double qs0 = d.qs[rn * 2], qs1 = d.qs[rn * 2 + 1];
+        double e = d.rowPP[rn];
+        e += qt0 * d.A[rn * 2] + qt1 * d.A[rn * 2 + 1];
+        e += qt0 * l1t + qt1 * l0t;
+        e += qa0 * qs0 * d.Bv[rn * 4] + qa0 * qs1 * d.Bv[rn * 4 + 1] + qa1 * qs0 * d.Bv[rn * 4 + 2] + qa1 * qs1 * d.Bv[rn * 4 + 3];
+        e += qa0 * l1a + qa1 * l0a;
+        en += e;
+        double h = -d.rowZ[rn] + d.rowPF[rn];
+        h += xlogx(qt0) + xlogx(qt1) + xlogx(qa0) + xlogx(qa1) + xlogx(qs0) + xlogx(qs1);
+        ent += h;
+    }
+    en = block_sum<256>(en, scratch);
+    ent = block_sum<256>(ent, scratch);
+    if (threadIdx.x == 0) {
+        partial[((size_t)(r - r0) * gridDim.x + blockIdx.x) * 2] = en;
+        partial[((size_t)(r - r0) * gridDim.x + blockIdx.x) * 2 + 1] = ent;
+    }
+}
+// out[(r-r0)*4 + {0,1,2,3}] = energy, entropy, elbo, hmm_log_norm_const
+// lt_valid: update_p_cn has run (joint/log_transmat are live) ; plain_T_init: sum over plain
+// adjacencies of mean(cached_log_transmat) for the pre-update state ; full_plain: optional
+// sum over plain adjacencies of joint*T (adds to both energy and entropy when exact parts are requested)
+__global__ void k_elbo_final(Dev d, int r0, const double *partial, int nblk, const int *lt_valid, double plain_T_init,
+                             const double *full_plain, double *out) {
+    __shared__ double scratch[8];
+    const int r = r0 + blockIdx.x, t = threadIdx.x;
+    double en = 0., ent = 0.;
+    if (t == 0) for (int i = 0; i < nblk; i++) { en += partial[((size_t)(r - r0) * nblk + i) * 2]; ent += partial[((size_t)(r - r0) * nblk + i) * 2 + 1]; }
+    // entropy of q(brk)
+    double hb = 0.;
+    for (int i = t; i < d.K * d.B; i += 256) hb += xlogx(d.pbrk[(size_t)r * d.K * d.B + i]);
+    hb = block_sum<256>(hb, scratch);
+    // transition factors at breakend adjacencies
+    double ec = 0., jt = 0.;
+    for (int slot = t; slot < d.NBE; slot += 256) {
+        const int n = d.be_n[slot];
+        if (d.tclass[n] < 0) continue;   // telomere: T == 0
+        const double *h = d.hist + ((size_t)r * d.NBE + slot) * d.M * d.D;
+        const double *pc = d.pd_cached + ((size_t)r * d.NBE + slot) * d.M * d.D;
+        double e = 0.;
+        for (int i = 0; i < d.M * d.D; i++) e += h[i] * (-d.pen * pc[i]);
+        e += -d.pen * d.be_ja[(size_t)r * d.NBE + slot];
+        ec += e;
+        jt += d.be_jt[(size_t)r * d.NBE + slot];
+    }
+    ec = block_sum<256>(ec, scratch);
+    jt = block_sum<256>(jt, scratch);
+    // logZ
+    double z = 0.;
+    for (int n = t; n < d.N; n += 256) z += d.rowZ[(size_t)r * d.N + n];
+    z = block_sum<256>(z, scratch);
+    if (t == 0) {
+        const bool live = lt_valid[r] != 0;
+        double energy = en + ec, entropy = ent + hb + (live ? jt : 0.);
+        if (!live) energy += plain_T_init;
+        if (full_plain) { energy += full_plain[r - r0]; entropy += full_plain[r - r0]; }
+        out[(r - r0) * 4 + 0] = energy; out[(r - r0) * 4 + 1] = entropy; out[(r - r0) * 4 + 2] = energy - entropy;
+        out[(r - r0) * 4 + 3] = z;
+    }
+}
+
+// =============================================================================
+// M-step objectives on a list of segments (bpmodel.pyx:1125-1195)
+// grid (nlist), block 256: one segment per block; partial [nlist][1+M]
+// =============================================================================
+template <bool GRAD>
+__global__ void k_ell_list(Dev d, int r, const int32_t *list, double *partial) {
+    __shared__ double scratch[8];
+    const int n = list[blockIdx.x];
+    const RestartParams &rp = d.rp[r];
+    SegCtx sc; load_seg(d, r, n, sc);
+    const int cls = d.seg_class[n];
+    const size_t rn = (size_t)r * d.N + n;
+    const double qt0 = d.qt[rn * 2], qt1 = d.qt[rn * 2 + 1], qa0 = d.qa[rn * 2], qa1 = d.qa[rn * 2 + 1];
+    const double qs0 = d.qs[rn * 2], qs1 = d.qs[rn * 2 + 1];
+    const double *post = d.post + rs_off(d, r, n);
+    unsigned err = 0;
+    double acc = 0., g[RMX_MAX_CLONES] = {0., 0., 0., 0.};
+    for (int s = threadIdx.x; s < d.S; s += 256) {
+        double LT[2], LA[4];
+        cell_ll(d, rp, sc, r, cls, s, LT, LA, err);
+        const double ps = post[s];
+        acc += ps * qt0 * LT[0]; acc += ps * qt1 * LT[1];
+        acc += ps * qa0 * qs0 * LA[0]; acc += ps * qa0 * qs1 * LA[1]; acc += ps * qa1 * qs0 * LA[2]; acc += ps * qa1 * qs1 * LA[3];
+        if (GRAD) {
+            const size_t si = ((size_t)r * d.C + cls) * d.SP + s;
+            const unsigned fl = d.stFlags[si];
+            const int8_t *cn = d.cn + ((size_t)cls * d.S + s) * d.M * 2;
+            const int8_t *tot = d.tot + ((size_t)cls * d.S + s) * d.M;
+            // total part (bpmodel.pyx:778-807)
+            if (sc.mt && !(fl & ST_HDEL_NB)) {
+                const double mu = d.stD[si] * sc.l;
+                const double r0_ = rp.p[RMX_P_NEGBIN_R_0], r1_ = rp.p[RMX_P_NEGBIN_R_1];
+                const double pm0 = sc.x / mu - (r0_ + sc.x) / (r0_ + mu), pm1 = sc.x / mu - (r1_ + sc.x) / (r1_ + mu);
+                if (pm0 != pm0 || pm1 != pm1) err |= RMX_ERR_NAN_GRAD;
+                for (int m = 0; m < d.M; m++) {
+                    const double base = sc.l * (double)tot[m];
+                    g[m] += ps * qt0 * (base * pm0); g[m] += ps * qt1 * (base * pm1);
+                }
+            }
+            // allele part (bpmodel.pyx:855-896)
+            if (sc.ma && !(fl & ST_GZ_ALLELE)) {
+                double minor = 0., total = 0.;
+                for (int m = 0; m < d.M; m++) { minor += rp.h[m] * (double)cn[m * 2]; total += rp.h[m] * (double)tot[m]; }
+                if (total <= 0.) err |= RMX_ERR_TOTAL_DEPTH;
+                else if (sc.ys != 0.) {
+                    const double p = minor / total;
+                    if (p <= 0. || (1 - p) <= 0.) err |= RMX_ERR_BAD_P;
+                    else {
+                        double pp[4];
+#pragma unroll
+                        for (int v = 0; v < 2; v++) {
+                            const double Mv = v == 0 ? rp.p[RMX_P_BETABIN_M_0] : rp.p[RMX_P_BETABIN_M_1];
+                            const double dg_a = digamma_as103(Mv * p, err), dg_b = digamma_as103(Mv * (1 - p), err);
+#pragma unroll
+                            for (int w = 0; w < 2; w++) {
+                                const double k = w == 0 ? sc.y0 : sc.y1;
+                                pp[v * 2 + w] = (Mv * digamma_as103(k + Mv * p, err) + (-Mv) * digamma_as103(sc.ys - k + Mv * (1 - p), err)
+                                                 - Mv * dg_a - (-Mv) * dg_b);
+                                if (pp[v * 2 + w] != pp[v * 2 + w]) err |= RMX_ERR_NAN_GRAD;
+                            }
+                        }
+                        for (int m = 0; m < d.M; m++) {
+                            const double base = ((double)cn[m * 2] * total - minor * (double)tot[m]) / (total * total);
+                            g[m] += ps * qa0 * qs0 * (base * pp[0]); g[m] += ps * qa0 * qs1 * (base * pp[1]);
+                            g[m] += ps * qa1 * qs0 * (base * pp[2]); g[m] += ps * qa1 * qs1 * (base * pp[3]);
+                        }
+                    }
+                }
+            }
+        }
+    }
+    const int W = 1 + RMX_MAX_CLONES;
+    acc = block_sum<256>(acc, scratch);
+    if (threadIdx.x == 0) partial[(size_t)blockIdx.x * W] = acc;
+    if (GRAD)
+        for (int m = 0; m < RMX_MAX_CLONES; m++) {
+            const double gm = block_sum<256>(g[m], scratch);
+            if (threadIdx.x == 0) partial[(size_t)blockIdx.x * W + 1 + m] = gm;
+        }
+    if (err) atomicOr(&d.err[r], err);
+}
+// deterministic final sum over nlist partials -> out[1+MAXC].  grid 1, block 256
+__global__ void k_ell_final(const double *partial, int nlist, double *out) {
+    __shared__ double scratch[8];
+    const int W = 1 + RMX_MAX_CLONES;
+    for (int c = 0; c < W; c++) {
+        double a = 0.;
+        for (int i = threadIdx.x; i < nlist; i += 256) a += partial[(size_t)i * W + c];
+        a = block_sum<256>(a, scratch);
+        if (threadIdx.x == 0) out[c] = a;
+    }
+}
+// full-data E[ll] from (A, B): grid ELBO_BLOCKS, block 256 -> partial[blk*(1+MAXC)]
+__global__ void k_ell_full(Dev d, int r, double *partial) {
+    __shared__ double scratch[8];
+    double acc = 0.;
+    for (int n = blockIdx.x * blockDim.x + threadIdx.x; n < d.N; n += gridDim.x * blockDim.x) {
+        const size_t rn = (size_t)r * d.N + n;
+        const double qt0 = d.qt[rn * 2], qt1 = d.qt[rn * 2 + 1], qa0 = d.qa[rn * 2], qa1 = d.qa[rn * 2 + 1];
+        const double qs0 = d.qs[rn * 2], qs1 = d.qs[rn * 2 + 1];
+        acc += qt0 * d.A[rn * 2] + qt1 * d.A[rn * 2 + 1];
+        acc += qa0 * qs0 * d.Bv[rn * 4] + qa0 * qs1 * d.Bv[rn * 4 + 1] + qa1 * qs0 * d.Bv[rn * 4 + 2] + qa1 * qs1 * d.Bv[rn * 4 + 3];
+    }
+    acc = block_sum<256>(acc, scratch);
+    if (threadIdx.x == 0) partial[(size_t)blockIdx.x * (1 + RMX_MAX_CLONES)] = acc;
+}
+
+// single cell, for tests
+__global__ void k_cell_probe(Dev d, int r, int n, int s, double *out6) {
+    const RestartParams &rp = d.rp[r];
+    SegCtx sc; load_seg(d, r, n, sc);
+    unsigned err = 0; double LT[2], LA[4];
+    cell_ll(d, rp, sc, r, d.seg_class[n], s, LT, LA, err);
+    out6[0] = LT[0]; out6[1] = LT[1]; out6[2] = LA[0]; out6[3] = LA[1]; out6[4] = LA[2]; out6[5] = LA[3];
+    if (err) atomicOr(&d.err[r], err);
+}
+
+// =============================================================================
+// Viterbi (max_product, bpmodel.pyx:1296-1333), bit-exact: the lattice is carried
+// through telomeres exactly like the reference (no per-chain re-basing, which
+// would change float rounding), additions and comparisons only.
+// Forward: one workgroup per restart; thread (o,p); back-pointers (first maximum)
+// are recorded so the trace-back is pointer chasing; identical to the reference's
+// recomputed argmax (:1327-1331) because it is the same expression and tie rule.
+// =============================================================================
+__global__ __launch_bounds__(1024) void k_viterbi(Dev d, int r, int P, uint16_t *bp /* [N][S] */, double *final_row /* [S] */) {
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    const int S = d.S, M = d.M, D = d.D, t = threadIdx.x, NT = blockDim.x;
+    double *V = (double *)smem_raw;        // [2][S]
+    double *pdl = V + 2 * S;               // [M*D]
+    const int o = t / P, p = t % P;
+    const bool act = o < S;
+    const int QPT = (S + P - 1) / P;
+    const double *f = d.f + rs_off(d, r, 0);
+    if (t < S) V[t] = f[t];
+    __syncthreads();
+    for (int n = 1; n < d.N; n++) {
+        const int cur = (n - 1) & 1, nxt = n & 1, tn = n - 1;
+        const int tc = d.tclass[tn], bs = d.brk_slot[tn];
+        const double *pd = nullptr;
+        if (tc >= 0 && bs >= 0) {
+            const double *pdg = d.pd_lt + ((size_t)r * d.NBE + bs) * M * D;
+            for (int i = t; i < M * D; i += NT) pdl[i] = pdg[i];
+            __syncthreads();
+            pd = pdl;
+        }
+        double best = -INFINITY; int bi = 0;
+        if (act) for (int rr = 0; rr < QPT; rr++) {
+            const int i = p * QPT + rr;
+            if (i < S) {
+                const double T = (tc < 0) ? 0. : trans_value(d, tn, i, o, pd);
+                const double v = V[cur * S + i] + T;
+                if (v > best) { best = v; bi = i; }
+            }
+        }
+        for (int off = 1; off < P; off <<= 1) {
+            const double ob = __shfl_xor(best, off, 64); const int oi = __shfl_xor(bi, off, 64);
+            if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+        }
+        if (act && p == 0) {
+            V[nxt * S + o] = best + f[(size_t)n * d.SP + o];
+            bp[(size_t)n * S + o] = (uint16_t)bi;
+        }
+        __syncthreads();
+    }
+    if (t < S) final_row[t] = V[((d.N - 1) & 1) * S + t];
+}
+// trace-back: one workgroup; chunks of back-pointer rows staged through LDS
+__global__ void k_backtrace(Dev d, const uint16_t *bp, const double *final_row, int64_t *path, double *logprob, int ROWS) {
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    uint16_t *chunk = (uint16_t *)smem_raw;
+    __shared__ int cur_state;
+    const int S = d.S, t = threadIdx.x, NT = blockDim.x;
+    if (t == 0) {
+        int mp = 0; double vm = final_row[0];
+        for (int i = 1; i < S; i++) if (final_row[i] > vm) { vm = final_row[i]; mp = i; }
+        cur_state = mp; path[d.N - 1] = mp; *logprob = vm;
+    }
+    __syncthreads();
+    for (int hi = d.N - 1; hi >= 1; hi -= ROWS) {
+        const int lo = hi - ROWS + 1 > 1 ? hi - ROWS + 1 : 1;   // rows lo..hi of bp
+        const int cnt = (hi - lo + 1) * S;
+        for (int i = t; i < cnt; i += NT) chunk[i] = bp[(size_t)lo * S + i];
+        __syncthreads();
+        if (t == 0) {
+            int s = cur_state;
+            for (int n = hi; n >= lo; n--) { s = chunk[(n - lo) * S + s]; path[n - 1] = s; }
+            cur_state = s;
+        }
+        __syncthreads();
+    }
+}
+
+// =============================================================================
+// module-level sum_product / max_product on caller-supplied dense (f, T):
+// literal log-domain evaluation in the reference's operation order.
+// One workgroup; thread j owns column j (S <= 1024).
+// =============================================================================
+__global__ __launch_bounds__(1024) void k_sum_product_dense(const double *f, const double *T, double *alphas, double *betas, int N, int S) {
+    const int j = threadIdx.x;
+    extern __shared__ double prev[];   // [S]
+    if (j < S) { alphas[j] = f[j]; prev[j] = f[j]; }
+    __syncthreads();
+    for (int n = 1; n < N; n++) {
+        double out = 0.;
+        if (j < S) {
+            const double *Tn = T + (size_t)(n - 1) * S * S;
+            double vmax = -INFINITY;
+            for (int i = 0; i < S; i++) { const double v = prev[i] + Tn[(size_t)i * S + j]; if (v > vmax) vmax = v; }
+            double ps = 0.;
+            for (int i = 0; i < S; i++) ps += exp(prev[i] + Tn[(size_t)i * S + j] - vmax);
+            out = log(ps) + vmax + f[(size_t)n * S + j];
+        }
+        __syncthreads();
+        if (j < S) { prev[j] = out; alphas[(size_t)n * S + j] = out; }
+        __syncthreads();
+    }
+    if (j < S) { betas[(size_t)(N - 1) * S + j] = 0.0; prev[j] = 0.0; }
+    __syncthreads();
+    for (int n = N - 2; n >= 0; n--) {
+        double out = 0.;
+        if (j < S) {
+            const double *Tn = T + (size_t)n * S * S + (size_t)j * S;   // row i = j
+            const double *fn = f + (size_t)(n + 1) * S;
+            double vmax = -INFINITY;
+            for (int c = 0; c < S; c++) { const double v = (Tn[c] + fn[c]) + prev[c]; if (v > vmax) vmax = v; }
+            double ps = 0.;
+            for (int c = 0; c < S; c++) ps += exp(((Tn[c] + fn[c]) + prev[c]) - vmax);
+            out = log(ps) + vmax;
+        }
+        __syncthreads();
+        if (j < S) { betas[(size_t)n * S + j] = out; prev[j] = out; }
+        __syncthreads();
+    }
+}
+__global__ __launch_bounds__(1024) void k_max_product_dense(const double *f, const double *T, uint16_t *bp, double *final_row, int N, int S) {
+    const int j = threadIdx.x;
+    extern __shared__ double prev[];
+    if (j < S) prev[j] = f[j];
+    __syncthreads();
+    for (int n = 1; n < N; n++) {
+        double out = 0.; int bi = 0;
+        if (j < S) {
+            const double *Tn = T + (size_t)(n - 1) * S * S;
+            double best = -INFINITY;
+            for (int i = 0; i < S; i++) { const double v = prev[i] + Tn[(size_t)i * S + j]; if (v > best) { best = v; bi = i; } }
+            out = best + f[(size_t)n * S + j];
+        }
+        __syncthreads();
+        if (j < S) { prev[j] = out; bp[(size_t)n * S + j] = (uint16_t)bi; }
+        __syncthreads();
+    }
+    if (j < S) final_row[j] = prev[j];
+}
+
+// =============================================================================
+// dense materialisation on request (tests / attribute read-back only)
+// =============================================================================
+// which: 0 log_transmat (lt snapshot), 1 cached_log_transmat.  grid (N-1), block 256
+__global__ void k_materialize_T(Dev d, int r, int which, int zero_all, double *out) {
+    const int n = blockIdx.x, S = d.S;
+    const int bs = d.brk_slot[n];
+    const double *pd = nullptr;
+    if (bs >= 0) pd = (which == 0 ? d.pd_lt : d.pd_cached) + ((size_t)r * d.NBE + bs) * d.M * d.D;
+    for (int idx = threadIdx.x; idx < S * S; idx += blockDim.x) {
+        const int i = idx / S, j = idx - i * S;
+        out[(size_t)n * S * S + idx] = zero_all ? 0. : trans_value(d, n, i, j, pd);
+    }
+}
+// joint posterior marginals (bpmodel.pyx:954-960).  grid (N-1), block 256
+__global__ void k_materialize_joint(Dev d, int r, int uniform, double *out) {
+    __shared__ double scratch[8];
+    __shared__ double zsh;
+    const int n = blockIdx.x, S = d.S, t = threadIdx.x;
+    double *o = out + (size_t)n * S * S;
+    if (uniform) { for (int idx = t; idx < S * S; idx += 256) o[idx] = 1.0 / (double)((size_t)S * S); return; }
+    const int bs = d.brk_slot[n];
+    const double *pd = (bs >= 0) ? d.pd_lt + ((size_t)r * d.NBE + bs) * d.M * d.D : nullptr;
+    const double *fa = d.fa + rs_off(d, r, n), *fb = d.fb + rs_off(d, r, n + 1), *fr = d.f + rs_off(d, r, n + 1);
+    const double fm = d.fmax[(size_t)r * d.N + n + 1];
+    double z = 0.;
+    for (int idx = t; idx < S * S; idx += 256) {
+        const int i = idx / S, j = idx - i * S;
+        const double J = fa[i] * exp(trans_value(d, n, i, j, pd)) * (exp(fr[j] - fm) * fb[j]);
+        o[idx] = J; z += J;
+    }
+    z = block_sum<256>(z, scratch);
+    if (t == 0) zsh = z;
+    __syncthreads();
+    for (int idx = t; idx < S * S; idx += 256) o[idx] = o[idx] / zsh;
+}
+// cn_states_total / num_alleles_subclonal / is_hdel / is_loh expansions are done on the host.
