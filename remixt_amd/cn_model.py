@@ -82,7 +82,7 @@ class BreakpointModel(object):
         """Create a copy number model (same arguments as cn_model.py:31-74).
 
         Extra keyword arguments: `kernel_module` (module providing RemixtModel;
-        default remixt_amd.bpmodel), `device` (HIP device ordinal), `quiet`.
+        default remixt_amd.bpmodel), `device` (HIP device ordinal), `quiet`, `rng`.
         """
         x = np.asarray(x)
         l = np.asarray(l)
@@ -113,6 +113,9 @@ class BreakpointModel(object):
         self._kernel = kwargs.get('kernel_module', None)
         self._device = kwargs.get('device', 0)
         self.quiet = kwargs.get('quiet', False)
+        # None: the global numpy RNG, as in the reference (cn_model.py:477); a RandomState gives a
+        # restart its own reproducible stream when several restarts advance in lockstep
+        self.rng = kwargs.get('rng', None)
 
         if self.max_depth is None:
             raise ValueError('must specify max depth')
@@ -392,7 +395,8 @@ class BreakpointModel(object):
     def _create_sample(self, weights=None):
         """Random subset of segments for the stochastic M-steps (cn_model.py:475-480; global numpy RNG)."""
         sample_size = int(min(200, self.model.num_segments / 10))
-        sample_idxs = np.random.choice(self.model.num_segments, size=sample_size, replace=False, p=weights)
+        chooser = self.rng if self.rng is not None else np.random
+        sample_idxs = chooser.choice(self.model.num_segments, size=sample_size, replace=False, p=weights)
         sample = np.zeros((self.model.num_segments,), dtype=int)
         sample[sample_idxs] = 1
         return sample

@@ -1,0 +1,247 @@
+"""Restart fan-out on GPUs.
+
+The reference runs one OS process per (h, divergence weight) initialisation
+(`init_id` axis, reference remixt/workflow.py:329-340) and picks the best ELBO
+afterwards (remixt/analysis/pipeline.py:253-264).  Here all restarts of one GPU
+share a single `RemixtBatch` (data resident once, one launch per coordinate
+update for all restarts) and restarts are sharded over GPUs, one process per
+GPU, with ONE gather of the per-restart results at the end (RCCL over xGMI via
+torch.distributed; no communication during EM).
+"""
+import numpy as np
+
+from .cn_model import BreakpointModel
+from . import synthetic
+
+
+class RestartSet(object):
+    """R restarts of one experiment advancing in lockstep on one device."""
+
+    def __init__(self, experiment, init_params, max_copy_number, num_clones=3, device=0, quiet=True,
+                 kernel_module=None, seeds=None, **model_kwargs):
+        self.experiment = experiment
+        self.init_params = list(init_params)
+        R = len(self.init_params)
+        if R == 0:
+            raise ValueError('no restarts given')
+        max_depths = set(p['max_depth'] for p in self.init_params)
+        if len(max_depths) != 1:
+            # analysis/pipeline.py:82-86: one common max_depth so that objectives are comparable
+            raise ValueError('all restarts must share max_depth')
+        self.num_clones = num_clones
+        self.models = []
+        for i, p in enumerate(self.init_params):
+            rng = np.random.RandomState(seeds[i]) if seeds is not None else None
+            self.models.append(BreakpointModel(
+                experiment.x, experiment.l, experiment.adjacencies, experiment.breakpoints,
+                max_copy_number=max_copy_number, divergence_weight=p['divergence_weight'], max_depth=p['max_depth'],
+                kernel_module=kernel_module, device=device, quiet=quiet, rng=rng, **model_kwargs))
+        self.h_init = np.array([synthetic.h_init_from_params(p, num_clones) for p in self.init_params])
+        m0 = self.models[0]
+        kern = m0._kernel_module()
+        self.batch = None
+        if hasattr(kern, 'RemixtBatch'):
+            classes, seg_class = m0._state_tables(num_clones)
+            brk_states = m0.create_brk_states(num_clones, m0.max_copy_number, m0.max_copy_number_diff)
+            self.batch = kern.RemixtBatch(
+                num_clones, m0.N1, m0.num_breakpoints, m0.normal_contamination, classes, seg_class, brk_states,
+                self.h_init, m0.l1, m0.x1[:, 2].copy(), m0.x1[:, 0:2].copy(), m0.is_telomere, m0.breakpoint_idx,
+                m0.breakpoint_orient, m0.transition_log_prob, [p['divergence_weight'] for p in self.init_params],
+                device=device)
+            for r, m in enumerate(self.models):
+                m._attach_model(self.batch.model(r))
+        else:
+            # kernels without a batch object (CPU oracle in tests): one model per restart, same driver
+            for r, m in enumerate(self.models):
+                m._attach_model(m._build_model(self.h_init[r]))
+
+    @property
+    def num_restarts(self):
+        return len(self.models)
+
+    def calculate_elbo(self):
+        if self.batch is not None:
+            return self.batch.calculate_elbo()
+        return np.array([m.model.calculate_elbo() for m in self.models])
+
+    def variational_update(self, iters=1):
+        if self.batch is not None:
+            self.batch.variational_update(iters)
+        else:
+            for m in self.models:
+                for _ in range(iters):
+                    m.variational_update()
+
+    def em_iteration(self, i=0, num_update_iter=5):
+        """cn_model.py:409-428 for every restart: batched variational sweeps, per-restart
+        scipy M-steps, batched ELBO."""
+        self.variational_update(num_update_iter)
+        for m in self.models:
+            if m.do_h_update:
+                m.em_update_h()
+            m.em_update_params()
+        elbo = self.calculate_elbo()
+        for m, e in zip(self.models, elbo):
+            m.record_elbo(float(e), i)
+        return elbo
+
+    def fit(self, num_em_iter=5, num_update_iter=5):
+        elbo0 = self.calculate_elbo()
+        for m, e in zip(self.models, elbo0):
+            if m.prev_elbo is None:
+                m.prev_elbo = float(e)
+        for i in range(num_em_iter):
+            self.em_iteration(i, num_update_iter)
+        return np.array([m.prev_elbo for m in self.models])
+
+    def results(self):
+        """Per-restart result dicts with the keys of analysis/pipeline.py:198-226."""
+        out = []
+        for m, p in zip(self.models, self.init_params):
+            out.append(collect_fit_results(m, self.experiment, p))
+        return out
+
+
+def collect_fit_results(model, experiment, init_params):
+    """fit_results of analysis/pipeline.py:196-226 from a fitted BreakpointModel."""
+    from .cn_model import decode_breakpoints_naive
+    cn, brk_cn = model.optimal_cn()
+    if model.disable_breakpoints:
+        brk_cn = decode_breakpoints_naive(cn, experiment.adjacencies, experiment.breakpoints)
+    res = dict()
+    res['h'] = model.h
+    res['cn'] = cn
+    res['brk_cn'] = brk_cn
+    res['p_outlier_total'] = model.p_outlier_total
+    res['p_outlier_allele'] = model.p_outlier_allele
+    res['total_likelihood_mask'] = model.total_likelihood_mask
+    res['allele_likelihood_mask'] = model.allele_likelihood_mask
+    stats = dict()
+    stats['elbo'] = model.prev_elbo
+    stats['elbo_diff'] = model.prev_elbo_diff
+    stats['error_message'] = ''
+    stats.update(model.get_likelihood_param_values())
+    l = np.asarray(experiment.l)
+    ploidy = (cn[:, 1:, :].mean(axis=1).T * l).sum() / l.sum()
+    divergent = (cn[:, 1:, :].max(axis=1) != cn[:, 1:, :].min(axis=1)) * 1.
+    stats['num_clones'] = len(model.h)
+    stats['num_segments'] = len(experiment.x)
+    stats['ploidy'] = ploidy
+    stats['proportion_divergent'] = (divergent.T * l).sum() / (2. * l.sum())
+    stats['mode_idx'] = init_params.get('mode_idx', 0)
+    stats['divergence_weight'] = init_params['divergence_weight']
+    res['stats'] = stats
+    return res
+
+
+# ---------------------------------------------------------------------------------
+# multi-GPU: shard restarts, gather results
+# ---------------------------------------------------------------------------------
+def shard_indices(num_items, world_size, rank):
+    """Restart i -> rank i mod world_size."""
+    return list(range(rank, num_items, world_size))
+
+
+def _pack(res, N, M, K, nparams, brk_ids, param_names):
+    """One restart's results as (float64 vector, int8 vector) of fixed length."""
+    f = np.zeros(4 + M + nparams + 4 * N, dtype=np.float64)
+    st = res['stats']
+    f[0] = st['elbo']; f[1] = st['elbo_diff'] if st['elbo_diff'] is not None else np.nan
+    f[2] = st['ploidy']; f[3] = st['proportion_divergent']
+    f[4:4 + M] = res['h']
+    f[4 + M:4 + M + nparams] = [st[k] for k in param_names]
+    o = 4 + M + nparams
+    f[o:o + 2 * N] = res['p_outlier_total'].ravel(); f[o + 2 * N:o + 4 * N] = res['p_outlier_allele'].ravel()
+    i8 = np.zeros(N * M * 2 + K * M + 2 * N, dtype=np.int8)
+    i8[:N * M * 2] = res['cn'].ravel()
+    i8[N * M * 2:N * M * 2 + K * M] = np.array([res['brk_cn'][k] for k in brk_ids]).ravel()
+    i8[N * M * 2 + K * M:N * M * 2 + K * M + N] = res['total_likelihood_mask']
+    i8[N * M * 2 + K * M + N:] = res['allele_likelihood_mask']
+    return f, i8
+
+
+def _unpack(f, i8, N, M, K, nparams, brk_ids, param_names, init_params):
+    res = dict()
+    res['h'] = f[4:4 + M].copy()
+    o = 4 + M + nparams
+    res['p_outlier_total'] = f[o:o + 2 * N].reshape(N, 2).copy()
+    res['p_outlier_allele'] = f[o + 2 * N:o + 4 * N].reshape(N, 2).copy()
+    res['cn'] = i8[:N * M * 2].astype(np.int64).reshape(N, M, 2)
+    bc = i8[N * M * 2:N * M * 2 + K * M].astype(np.int64).reshape(K, M)
+    res['brk_cn'] = dict((k, bc[i]) for i, k in enumerate(brk_ids))
+    res['total_likelihood_mask'] = i8[N * M * 2 + K * M:N * M * 2 + K * M + N].astype(np.int64)
+    res['allele_likelihood_mask'] = i8[N * M * 2 + K * M + N:].astype(np.int64)
+    st = {'elbo': float(f[0]), 'elbo_diff': float(f[1]), 'ploidy': float(f[2]), 'proportion_divergent': float(f[3]),
+          'error_message': '', 'num_clones': M, 'num_segments': N, 'mode_idx': init_params.get('mode_idx', 0),
+          'divergence_weight': init_params['divergence_weight']}
+    for j, k in enumerate(param_names):
+        st[k] = float(f[4 + M + j])
+    res['stats'] = st
+    return res
+
+
+def fit_restarts_distributed(experiment, init_params, max_copy_number, num_clones=3, num_em_iter=5, num_update_iter=5,
+                             device=None, kernel_module=None, seeds=None, quiet=True, **model_kwargs):
+    """Fit all restarts across the ranks of the default torch.distributed group.
+
+    Every rank holds the (small, read-only) experiment; rank g fits restarts
+    g, g+G, g+2G, ... on its own GPU; one all-gather of fixed-size result records
+    returns every restart's results to every rank (`collate` stores all of them,
+    analysis/pipeline.py:289-291).  Works on one process without torch.distributed.
+    """
+    import torch
+    import torch.distributed as dist
+    distributed = dist.is_available() and dist.is_initialized()
+    world = dist.get_world_size() if distributed else 1
+    rank = dist.get_rank() if distributed else 0
+    mine = shard_indices(len(init_params), world, rank)
+    if device is None:
+        device = (torch.cuda.current_device() if torch.cuda.is_available() else 0)
+    N = len(experiment.x); M = num_clones
+    brk_ids = list(experiment.breakpoints.keys()); K = len(brk_ids)
+    local = []
+    param_names = None
+    if mine:
+        rs = RestartSet(experiment, [init_params[i] for i in mine], max_copy_number, num_clones=num_clones, device=device,
+                        quiet=quiet, kernel_module=kernel_module, seeds=[seeds[i] for i in mine] if seeds is not None else None,
+                        **model_kwargs)
+        rs.fit(num_em_iter, num_update_iter)
+        local = rs.results()
+        param_names = list(rs.models[0].likelihood_params)
+    if param_names is None:
+        nc = model_kwargs.get('normal_contamination', True)
+        param_names = ['negbin_r_0', 'negbin_r_1', 'betabin_M_0', 'betabin_M_1'] + (
+            [] if nc else ['negbin_hdel_mu', 'negbin_hdel_r_0', 'negbin_hdel_r_1', 'betabin_loh_p', 'betabin_loh_M_0', 'betabin_loh_M_1'])
+    nparams = len(param_names)
+    per_rank = (len(init_params) + world - 1) // world
+    flen = 4 + M + nparams + 4 * N
+    ilen = N * M * 2 + K * M + 2 * N
+    fbuf = np.full((per_rank, flen), np.nan); ibuf = np.zeros((per_rank, ilen), dtype=np.int8)
+    for j, res in enumerate(local):
+        fbuf[j], ibuf[j] = _pack(res, N, M, K, nparams, brk_ids, param_names)
+    if distributed:
+        on_gpu = dist.get_backend() == 'nccl'
+        dev = torch.device('cuda', device) if on_gpu else torch.device('cpu')
+        ft = torch.from_numpy(fbuf).to(dev); it = torch.from_numpy(ibuf).to(dev)
+        fall = [torch.empty_like(ft) for _ in range(world)]; iall = [torch.empty_like(it) for _ in range(world)]
+        dist.all_gather(fall, ft)     # RCCL over xGMI on the GPU box; gloo in CPU tests
+        dist.all_gather(iall, it)
+        fall = [t.cpu().numpy() for t in fall]; iall = [t.cpu().numpy() for t in iall]
+    else:
+        fall, iall = [fbuf], [ibuf]
+    results = {}
+    for g in range(world):
+        for j, i in enumerate(shard_indices(len(init_params), world, g)):
+            results[i] = _unpack(fall[g][j], iall[g][j], N, M, K, nparams, brk_ids, param_names, init_params[i])
+    return results
+
+
+def select_optimal(results, max_prop_diverge=0.5):
+    """store_optimal_solution (analysis/pipeline.py:253-264): best ELBO among solutions
+    with proportion_divergent < max_prop_diverge (all solutions if none qualifies)."""
+    ids = sorted(results)
+    ok = [i for i in ids if results[i]['stats']['proportion_divergent'] < max_prop_diverge]
+    pool = ok if ok else ids
+    # pandas sort_values(ascending=False) is a stable sort on -elbo: first maximum wins
+    best = max(pool, key=lambda i: (results[i]['stats']['elbo'], -i))
+    return best

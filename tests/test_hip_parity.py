@@ -1,0 +1,149 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle on
+the same seeded inputs.  Tolerance: 1e-6 relative for posteriors / likelihoods
+(north_star), bit-exact for Viterbi paths given identical (f, T)."""
+import numpy as np
+import pytest
+
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def hip():
+    from remixt_amd import bpmodel
+    return bpmodel
+
+
+def _kat4(kernel):
+    from remixt_amd.cn_model import BreakpointModel
+    x = np.array([[600, 400, 10000], [900, 300, 15000], [620, 380, 10100], [500, 500, 9900], [700, 100, 8000]], dtype=float)
+    l = np.ones(5) * 1e5
+    m = BreakpointModel(x, l, {(0, 1), (1, 2), (2, 3)}, {'b0': frozenset([(0, 1), (2, 0)])}, max_copy_number=2, max_depth=1.0,
+                        divergence_weight=1e-6, min_segment_length=0., kernel_module=kernel, quiet=True)
+    m.num_em_iter = 0
+    m.fit(np.array([0.02, 0.03]))
+    return m
+
+
+def test_kat4_known_answers(hip):
+    """SURVEY.md 8c KAT4 values (produced by the reference)."""
+    m = _kat4(hip)
+    assert np.isclose(m.prev_elbo, -876.3848546093834, rtol=1e-9)
+    m.variational_update()
+    assert np.isclose(m.model.calculate_elbo(), -130.2844273873534, rtol=1e-9)
+    assert np.isclose(m.model.hmm_log_norm_const, -187.10488424850666, rtol=1e-9)
+    f = m.model.framelogprob
+    assert np.allclose(f[0], [-281.6558766560208, -54.33495353659991, -42.709943204987134, -17.980631175517097], rtol=1e-9)
+    T = m.model.log_transmat
+    assert np.array_equal(T[0, 0], [-5, -15, -25, -25]) and np.array_equal(T[2, 0], [0, -10, -20, -20])
+    assert np.allclose(m.model.p_breakpoint, [[0.99999999793884642, 2.0611536181901979e-09, 4.2483542465350965e-18]], rtol=1e-6, atol=1e-30)
+    s = np.ones(5, dtype=int)
+    assert np.isclose(m.model.calculate_expected_log_likelihood(s), -74.30206719862542, rtol=1e-9)
+    g = np.zeros(2)
+    m.model.calculate_expected_log_likelihood_partial_h(s, g)
+    assert np.allclose(g, [174.32617346234437, -61.424026009374174], rtol=1e-8)
+    cn, brk = m.optimal_cn()
+    assert np.array_equal(cn[:, 1, :], [[1, 1], [2, 0], [1, 1], [1, 1], [2, 0]])
+    assert np.array_equal(brk['b0'], [0, 0])
+
+
+@pytest.mark.parametrize('M,max_cn,N,chains,nc', [(2, 4, 150, 3, True), (3, 3, 120, 4, True), (3, 4, 90, 1, True),
+                                                 (2, 3, 100, 5, False), (3, 2, 80, 2, False)])
+def test_coordinate_updates_match_oracle(hip, oracle_mod, M, max_cn, N, chains, nc):
+    a, h, _ = H.make_model(hip, N=N, M=M, max_cn=max_cn, chains=chains, seed=M * 10 + max_cn, normal_contamination=nc)
+    b, _, _ = H.make_model(oracle_mod, N=N, M=M, max_cn=max_cn, chains=chains, seed=M * 10 + max_cn, normal_contamination=nc)
+    ma, mb = H.attach(a, h), H.attach(b, h)
+    assert np.isclose(ma.calculate_elbo(), mb.calculate_elbo(), rtol=1e-9)
+    H.compare_models(ma, mb, dense=True, tag='init')
+    for it in range(2):
+        for step in ('update_p_allele_swap', 'update_p_cn', 'update_p_breakpoint', 'update_p_outlier_total', 'update_p_outlier_allele'):
+            getattr(ma, step)(); getattr(mb, step)()
+            H.compare_models(ma, mb, dense=(it == 0), tag='%d/%s' % (it, step))
+            ea, eb = ma.calculate_elbo(), mb.calculate_elbo()
+            assert np.isclose(ea, eb, rtol=1e-8), (it, step, ea, eb)
+        assert np.isclose(ma.hmm_log_norm_const, mb.hmm_log_norm_const, rtol=1e-9)
+    # exact energy / entropy parts
+    assert np.isclose(ma.calculate_variational_energy(), mb.calculate_variational_energy(), rtol=1e-8)
+    assert np.isclose(ma.calculate_variational_entropy(), mb.calculate_variational_entropy(), rtol=1e-8)
+    # M-step objectives on a random sample and on all segments
+    rng = np.random.RandomState(3)
+    for sample in (np.ones(ma.num_segments, dtype=int), (rng.rand(ma.num_segments) < 0.2).astype(int)):
+        assert np.isclose(ma.calculate_expected_log_likelihood(sample), mb.calculate_expected_log_likelihood(sample), rtol=1e-9)
+        if nc:
+            ga, gb = np.zeros(M), np.zeros(M)
+            ma.calculate_expected_log_likelihood_partial_h(sample, ga); mb.calculate_expected_log_likelihood_partial_h(sample, gb)
+            assert np.allclose(ga, gb, rtol=1e-7), (ga, gb)
+    # parameter change propagates
+    ma.negbin_r_0 = 123.; mb.negbin_r_0 = 123.
+    ma.h = np.asarray(h) * 1.1; mb.h = np.asarray(h) * 1.1
+    s = np.ones(ma.num_segments, dtype=int)
+    assert np.isclose(ma.calculate_expected_log_likelihood(s), mb.calculate_expected_log_likelihood(s), rtol=1e-9)
+    assert np.isclose(ma.calculate_elbo(), mb.calculate_elbo(), rtol=1e-8)
+    # Viterbi
+    cna = np.zeros((ma.num_segments, M, 2), dtype=int); cnb = cna.copy()
+    ma.infer_cn(cna); mb.infer_cn(cnb)
+    assert np.array_equal(cna, cnb)
+
+
+def test_module_sum_product_max_product(hip, oracle_mod):
+    rng = np.random.RandomState(0)
+    f = rng.rand(6, 5); T = -rng.rand(5, 5, 5)
+    a = np.zeros((6, 5)); b = np.zeros((6, 5))
+    hip.sum_product(f, T, a, b)
+    from scipy.special import logsumexp
+    assert np.isclose(logsumexp(a[-1]), 11.069206009930824, rtol=1e-12)   # KAT3
+    assert np.allclose(b[0], [8.952942521751636, 8.654865359432627, 8.913017283777442, 9.021467603851274, 8.900114919476255], rtol=1e-12)
+    ss = np.zeros(6, dtype=np.int64)
+    lp = hip.max_product(f, T, ss)
+    assert lp == 4.030771537064376 and list(ss) == [2, 3, 3, 2, 0, 2]
+    # larger, with ties (integer-valued inputs): bit-exact against the oracle
+    for seed, (N, S) in enumerate([(200, 47), (64, 165), (500, 9)]):
+        rng = np.random.RandomState(seed)
+        f = np.floor(rng.rand(N, S) * 8) - 4.
+        T = -np.floor(rng.rand(N - 1, S, S) * 4) * 10.
+        s1 = np.zeros(N, dtype=np.int64); s2 = np.zeros(N, dtype=np.int64)
+        l1 = hip.max_product(f, T, s1); l2 = oracle_mod.max_product(f, T, s2)
+        assert l1 == l2 and np.array_equal(s1, s2)
+        f = rng.randn(N, S) * 5; T = -rng.rand(N - 1, S, S) * 30
+        a1 = np.zeros((N, S)); b1 = np.zeros((N, S)); a2 = np.zeros((N, S)); b2 = np.zeros((N, S))
+        hip.sum_product(f, T, a1, b1); oracle_mod.sum_product(f, T, a2, b2)
+        assert np.allclose(a1, a2, rtol=1e-12, atol=1e-10) and np.allclose(b1, b2, rtol=1e-12, atol=1e-10)
+
+
+def test_full_fit_matches_oracle(hip, oracle_mod):
+    """Seeded EM trajectory (variational sweeps + scipy M-steps) on both kernels."""
+    res = []
+    for kern in (hip, oracle_mod):
+        m, h, e = H.make_model(kern, N=240, M=3, max_cn=3, chains=4, seed=5)
+        m.num_em_iter = 2; m.num_update_iter = 2
+        np.random.seed(11)
+        m.fit(h)
+        cn, brk = m.optimal_cn()
+        res.append((m.prev_elbo, m.h, m.get_likelihood_param_values(), cn, brk, m.p_outlier_total))
+    (e1, h1, p1, cn1, b1, q1), (e2, h2, p2, cn2, b2, q2) = res
+    assert np.isclose(e1, e2, rtol=1e-6), (e1, e2)
+    assert np.allclose(h1, h2, rtol=1e-5)
+    for k in p1:
+        assert np.isclose(p1[k], p2[k], rtol=1e-4), (k, p1[k], p2[k])
+    assert np.array_equal(cn1, cn2)
+    assert all(np.array_equal(b1[k], b2[k]) for k in b1)
+    assert np.allclose(q1, q2, rtol=1e-5, atol=1e-8)
+
+
+def test_batch_equals_single(hip):
+    """R restarts in one batch give the same numbers as R separate models."""
+    from remixt_amd import synthetic
+    e = synthetic.make_experiment(200, num_clones=3, max_copy_number=3, num_chains=4, seed=2)
+    ps = synthetic.make_init_params(e, 3, 3)
+    from remixt_amd.restarts import RestartSet
+    rs = RestartSet(e, ps, max_copy_number=3, num_clones=3, quiet=True)
+    rs.batch.variational_update(2)
+    elbo_b = rs.batch.calculate_elbo()
+    for r, p in enumerate(ps):
+        m, h, _ = H.make_model(hip, N=200, M=3, max_cn=3, chains=4, seed=2, restart=r)
+        mm = H.attach(m, h)
+        for _ in range(2):
+            m.variational_update()
+        assert np.isclose(mm.calculate_elbo(), elbo_b[r], rtol=1e-12), (r, mm.calculate_elbo(), elbo_b[r])
+        assert np.allclose(mm.posterior_marginals, rs.batch.get_array(r, 'posterior_marginals'), rtol=1e-12, atol=1e-300)
