@@ -1,0 +1,205 @@
+#!/usr/bin/env python3
+"""Benchmark of the ReMixT variational-EM hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+One "step" = ONE EM iteration (reference remixt/cn_model.py:409-418: 5
+variational sweeps + the h M-step + the likelihood-parameter M-steps + the ELBO)
+for EVERY restart resident on the GPU.  Workload at N=1 = BASELINE.json
+configs[2]: 50k segments, 3 clones (normal + 2 tumour), max_cn = 8 (165 states),
+16 (h, divergence-weight) restarts.  With N > 1 every rank fits its own 16
+restarts (weak scaling; restarts are independent, reference
+remixt/workflow.py:329-340) and the per-restart results are all-gathered once at
+the end over RCCL.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline`
+(dominant kernel, HIP-event timed on the batch stream) and `cpu_baseline`.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8.0 TB/s spec
+# algorithmic HBM bytes per (segment,state) cell per variational update, split by kernel
+ALG_BYTES_PER_CELL = {
+    'k_framelogprob': 8.0,       # write f
+    'k_fb': 32.0,                # read f (fwd) + write alpha + read f (bwd) + write beta
+    'k_marginals<true>': 48.0,   # read alpha, beta + write posterior + the 3 indicator updates' posterior re-reads it replaces
+}
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=2)
+    ap.add_argument('--warmup', type=int, default=1)
+    ap.add_argument('--segments', type=int, default=50000)
+    ap.add_argument('--clones', type=int, default=3)
+    ap.add_argument('--max-cn', type=int, default=8)
+    ap.add_argument('--restarts', type=int, default=16, help='restarts per GPU')
+    ap.add_argument('--update-iters', type=int, default=5)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-sample-segments', type=int, default=200)
+    ap.add_argument('--no-mstep', action='store_true', help='diagnostic only: variational sweeps without M-steps (NOT the reported metric)')
+    return ap.parse_args()
+
+
+def cpu_baseline(args, cores_note=1):
+    """Reference CPU path timed on this box's host cores on a bounded sample.
+
+    One EM iteration of one restart on `cpu_sample_segments` segments with the same
+    state grid; every loop of the reference is linear in N, so the per-EM-iteration
+    time is scaled by N_full / N_sample.  kind = "reference" when the compiled
+    reference kernel (oracle/_ref, built from /root/reference/remixt/bpmodel.pyx)
+    travelled with the repo, else "port" (oracle/remixt_oracle.c)."""
+    from remixt_amd import synthetic
+    from remixt_amd.cn_model import BreakpointModel
+    from oracle import refload
+    kind = 'port'
+    kern = None
+    if refload.have_ref_binary():
+        try:
+            kern = refload.load_ref_bpmodel(); kind = 'reference'
+        except Exception:
+            kern = None
+    if kern is None:
+        from oracle import oracle as kern
+        kern.build()
+    ns = args.cpu_sample_segments
+    e = synthetic.make_experiment(ns, num_clones=args.clones, max_copy_number=args.max_cn, num_chains=4, seed=123)
+    p = synthetic.make_init_params(e, 1, args.max_cn, num_clones=args.clones)[0]
+    m = BreakpointModel(e.x, e.l, e.adjacencies, e.breakpoints, max_copy_number=args.max_cn,
+                        divergence_weight=p['divergence_weight'], max_depth=p['max_depth'], kernel_module=kern, quiet=True)
+    m.num_update_iter = args.update_iters
+    m._attach_model(m._build_model(synthetic.h_init_from_params(p, args.clones)))
+    m.prev_elbo = m.model.calculate_elbo()
+    np.random.seed(0)
+    t0 = time.time()
+    m.em_iteration(0)
+    dt = time.time() - t0
+    scale = float(args.segments) / float(ns)
+    return {
+        'value': 1.0 / (dt * scale), 'unit': 'EM iterations/s', 'cores': 1, 'kind': kind,
+        'sample': 'one EM iteration of one restart on %d segments x %d states (%.1f s), scaled linearly to %d segments'
+                  % (ns, m.model.num_cn_states, dt, args.segments),
+    }
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world > 1:
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+    device = local_rank if world > 1 else 0
+    torch.cuda.set_device(device)
+
+    from remixt_amd import synthetic
+    from remixt_amd.restarts import RestartSet, _pack
+
+    R = args.restarts
+    e = synthetic.make_experiment(args.segments, num_clones=args.clones, max_copy_number=args.max_cn, num_chains=23, seed=0)
+    all_params = synthetic.make_init_params(e, R * world, args.max_cn, num_clones=args.clones)
+    mine = all_params[rank::world]
+    rs = RestartSet(e, mine, args.max_cn, num_clones=args.clones, device=device, quiet=True,
+                    seeds=[1000 + rank + world * i for i in range(R)])
+    b = rs.batch
+    N1, S = b.num_segments, b.num_cn_states
+    elbo0 = rs.calculate_elbo()
+    for m, v in zip(rs.models, elbo0):
+        m.prev_elbo = float(v)
+
+    def step(i):
+        if args.no_mstep:
+            rs.variational_update(args.update_iters)
+            return rs.calculate_elbo()
+        return rs.em_iteration(i, args.update_iters)
+
+    for i in range(args.warmup):
+        step(i)
+
+    def fence():
+        b.synchronize()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    b.profile_reset(); b.profile_enable(True)
+    fence()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        elbo = step(args.warmup + i)
+    fence()
+    dt = time.perf_counter() - t0
+    b.profile_enable(False)
+    prof = b.profile()
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device='cuda')
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+        # final gather of the per-restart results (outside the timed region: it happens once per fit)
+        res = rs.results()
+        names = list(rs.models[0].likelihood_params)
+        ids = list(e.breakpoints.keys())
+        packs = [_pack(r_, len(e.x), args.clones, len(ids), len(names), ids, names) for r_ in res]
+        ft = torch.from_numpy(np.stack([p_[0] for p_ in packs])).cuda()
+        out = [torch.empty_like(ft) for _ in range(world)]
+        dist.all_gather(out, ft)
+
+    if rank == 0:
+        total_ms = sum(v[0] for v in prof.values())
+        dom = max(prof.items(), key=lambda kv: kv[1][0]) if prof else (None, (0., 0))
+        cells_per_launch = float(N1) * S * R
+        roof = None
+        if dom[0] is not None:
+            name, (ms, n) = dom
+            avg_ms = ms / max(n, 1)
+            alg = ALG_BYTES_PER_CELL.get(name)
+            achieved = (alg * cells_per_launch / (avg_ms * 1e-3) / 1e9) if alg else None
+            roof = {'bound': 'hbm', 'kernel': name, 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                    'frac': (achieved / HBM_PEAK_GBS) if achieved else None, 'traffic': None,
+                    'avg_launch_ms': avg_ms, 'launches': n,
+                    'alg_bytes_per_launch': (alg * cells_per_launch) if alg else None}
+        # whole variational update (all kernels of one sweep) against the 88 B/cell model
+        upd = sum(prof.get(k, (0., 0))[0] for k in ('k_framelogprob', 'k_fb', 'k_marginals<true>', 'k_pairwise', 'k_brk_update',
+                                                       'k_brk_lut', 'k_update_outlier_total', 'k_update_outlier_allele', 'k_update_allele_swap'))
+        nupd = prof.get('k_fb', (0., 1))[1]
+        sweep_ms = upd / max(nupd, 1)
+        line = {
+            'metric': 'EM iterations/sec (50k seg x 165 states x 16 restarts/GPU)',
+            'value': (R * world * args.steps) / dt, 'unit': 'EM iterations/s', 'n_gpus': world, 'steps': args.steps,
+            'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak',
+            'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
+            'config': {'workload': 'BASELINE configs[2]: %d segments (%d after breakend remap), %d clones, max_cn=%d (%d states), %d restarts/GPU, %d variational sweeps + M-steps per EM iteration'
+                                   % (args.segments, N1, args.clones, args.max_cn, S, R, args.update_iters),
+                       'segments': args.segments, 'states': S, 'restarts_per_gpu': R, 'mstep': not args.no_mstep},
+            'seg_state_cells_per_s': cells_per_launch * world * args.update_iters * args.steps / dt,
+            'roofline': roof,
+            'variational_sweep': {'device_ms_per_sweep_all_restarts': sweep_ms,
+                                  'hbm_frac_88B_per_cell': (88.0 * cells_per_launch / (sweep_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if sweep_ms else None},
+            'device_ms_total': total_ms,
+            'kernels': dict((k, {'ms': round(v[0], 3), 'n': v[1]}) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])),
+            'elbo_best': float(np.max(elbo)),
+        }
+        if not args.no_cpu_baseline:
+            line['cpu_baseline'] = cpu_baseline(args)
+        print(json.dumps(line))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -48,7 +48,7 @@ struct rmx_batch {
     std::vector<double> Tsum;          // [TC] sum of plain log-transition entries (current model)
     // per-restart host state
     std::vector<RestartParams> rp;
-    std::vector<char> tables_dirty, ab_dirty;
+    std::vector<char> tables_dirty, segc_dirty, ab_dirty;
     std::vector<int> lt_valid;
     std::vector<double> plain_T_init;  // [R]
     std::vector<double> logZ;          // last hmm_log_norm_const
@@ -67,6 +67,9 @@ struct rmx_batch {
     std::vector<int64_t> last_path;
     // FB launch configuration
     int fb_rpt = 0; FbLaunch fbL{}; size_t fb_lds = 0;
+    FbLaunch fbG{}; size_t fbG_lds = 0;   // generic kernel configuration
+    int n_fast = 0, n_generic = 0, fb_amat_lds = 0;
+    unsigned long long *d_dbg = nullptr;
     int G = 64;
     // all device allocations (freed on destroy)
     std::vector<void *> allocs;
@@ -211,64 +214,86 @@ static double plain_T_mean_sum(rmx_batch *b) {
 }
 
 // ---- FB configuration -----------------------------------------------------------
-typedef void (*fb_kernel_t)(Dev, int, FbLaunch);
+typedef void (*fb_kernel_t)(FbArgs);
 static fb_kernel_t fb_kernel_for(int rpt) {
     switch (rpt) {
-    case 2: return k_fb<2, 0, 1024>;
-    case 4: return k_fb<4, 0, 1024>;
-    case 8: return k_fb<8, 0, 1024>;
-    case 16: return k_fb<16, 0, 1024>;
-    case 24: return k_fb<24, 0, 1024>;
-    case 32: return k_fb<32, 0, 768>;
-    case 44: return k_fb<44, 0, 768>;
-    default: return k_fb<0, 0, 1024>;
+    case 2: return k_fb<2, 1024>;
+    case 4: return k_fb<4, 1024>;
+    case 8: return k_fb<8, 1024>;
+    case 16: return k_fb<16, 1024>;
+    case 24: return k_fb<24, 1024>;
+    case 32: return k_fb<32, 768>;
+    case 42: return k_fb<42, 704>;
+    case 44: return k_fb<44, 704>;
+    default: return k_fb<0, 1024>;
     }
 }
-static void configure_fb(rmx_batch *b) {
+static const size_t kLdsBudget = 150 * 1024;   // of the CU's 160 KiB
+static void fb_layout(rmx_batch *b, int rpt, int P, FbLaunch &L, size_t &lds, int *amat_lds) {
     const int S = b->d.S;
-    static const int rpts[] = {2, 4, 8, 16, 24, 32, 44};
-    int P = 1;
-    while ((S + P - 1) / P > 44 && P < 64) P *= 2;
-    while (S * P * 2 <= 512 && P < 64 && (S + P - 1) / P > 2) P *= 2;
-    int need = (S + P - 1) / P, rpt = 0;
-    for (int v : rpts) if (v >= need) { rpt = v; break; }
-    int ntmax = (rpt >= 32) ? 768 : 1024;
-    if (rpt == 0 || S * P > ntmax) {
-        rpt = 0; P = 1;
-        while (S * P * 2 <= 1024 && P < 64) P *= 2;
-    }
-    if (getenv("RMX_FB_GENERIC")) { rpt = 0; P = 1; while (S * P * 2 <= 1024 && P < 64) P *= 2; }
-    FbLaunch L;
     L.P = P;
     L.NT = ((S * P + 63) / 64) * 64;
     int span = std::max(S, P * (rpt > 0 ? rpt : (S + P - 1) / P));
     L.SPAD = ((span + 7) / 8) * 8;
-    size_t fixed = (size_t)(2 * L.SPAD + 32 + b->d.M * b->d.D) * 8 + (size_t)b->d.C * S * b->d.M + 64;
-    int blk = std::min(8, (FB_EPT * L.NT) / S);
-    while (blk > 1 && fixed + (size_t)FB_NBUF * blk * L.SPAD * 8 > 60 * 1024) blk--;
+    const int mdp = (b->d.M * b->d.D + 1) & ~1;
+    size_t fixed = (size_t)(2 * L.SPAD + (size_t)P * b->d.SP + 4 + mdp + 128) * 8 + (size_t)FB_NBUF * 2 * 64 * 4 +
+                   (((size_t)b->d.C * S * b->d.M + 15) & ~(size_t)15) + 64;
+    if (amat_lds) {
+        *amat_lds = (rpt > 0 && fixed + (size_t)S * S + (size_t)FB_NBUF * 2 * b->d.SP * 8 <= kLdsBudget) ? 1 : 0;
+        if (*amat_lds) fixed += (size_t)S * S;
+    }
+    int blk = 8;
+    while (blk > 1 && fixed + (size_t)FB_NBUF * blk * b->d.SP * 8 > kLdsBudget) blk--;
     L.BLK = std::max(1, blk);
-    b->fb_rpt = rpt; b->fbL = L;
-    b->fb_lds = fixed + (size_t)FB_NBUF * L.BLK * L.SPAD * 8;
+    lds = fixed + (size_t)FB_NBUF * L.BLK * b->d.SP * 8;
+}
+static const int kRpts[] = {2, 4, 8, 16, 24, 32, 42, 44};
+static int fb_ntmax(int rpt) { return rpt >= 42 ? 704 : (rpt >= 32 ? 768 : 1024); }
+static void configure_fb(rmx_batch *b) {
+    const int S = b->d.S;
+    // slices of the reduction index: as few as keep the per-thread weight slice in registers, but
+    // enough threads to give every SIMD of the CU work
+    int P = 1;
+    while ((S + P - 1) / P > 44) P++;
+    while (S * (P + 1) <= 512 && (S + P) / (P + 1) >= 2) P++;
+    int need = (S + P - 1) / P, rpt = 0;
+    for (int v : kRpts) if (v >= need) { rpt = v; break; }
+    int PG = 1;
+    while (S * (PG + 1) <= 1024 && (S + PG) / (PG + 1) >= 1 && PG < 16) PG++;
+    if (rpt == 0 || S * P > fb_ntmax(rpt) || getenv("RMX_FB_GENERIC")) rpt = 0;
+    b->fb_rpt = rpt;
+    if (rpt > 0) fb_layout(b, rpt, P, b->fbL, b->fb_lds, &b->fb_amat_lds);
+    fb_layout(b, 0, PG, b->fbG, b->fbG_lds, nullptr);
+    // more than 64 KiB of dynamic LDS needs an explicit opt-in per kernel
+    if (rpt > 0) hipFuncSetAttribute((const void *)fb_kernel_for(rpt), hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->fb_lds);
+    hipFuncSetAttribute((const void *)fb_kernel_for(0), hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->fbG_lds);
 }
 
 // ---- staleness handling ----------------------------------------------------------
-__global__ void k_set_rp(Dev d, int r, RestartParams rp) { if (threadIdx.x == 0) d.rp[r] = rp; }
+static void fill_logr(RestartParams &rp) { rp.logr[0] = std::log(rp.p[RMX_P_NEGBIN_R_0]); rp.logr[1] = std::log(rp.p[RMX_P_NEGBIN_R_1]); }
 
-static int ensure_tables(rmx_batch *b, int r0, int r1) {
-    bool any = false;
-    for (int r = r0; r < r1; r++)
-        if (b->tables_dirty[r]) { any = true; hipLaunchKernelGGL(k_set_rp, dim3(1), dim3(64), 0, b->stream, b->d, r, b->rp[r]); }
-    if (!any) return RMX_OK;
-    // contiguous dirty ranges
-    int r = r0;
-    while (r < r1) {
-        if (!b->tables_dirty[r]) { r++; continue; }
-        int e = r;
-        while (e < r1 && b->tables_dirty[e]) e++;
-        { ProfScope ps(b, KID_STATE_TABLES); hipLaunchKernelGGL(k_state_tables, dim3(b->d.C, e - r), dim3(256), 0, b->stream, b->d, r); }
-        { ProfScope ps(b, KID_SEG_CONST); hipLaunchKernelGGL(k_seg_const, dim3((b->d.N + 255) / 256, e - r), dim3(256), 0, b->stream, b->d, r); }
-        for (int i = r; i < e; i++) { b->tables_dirty[i] = 0; b->ab_dirty[i] = 1; }
-        r = e;
+// State tables (cheap: C x S entries) are rebuilt whenever h / a likelihood parameter changed; the
+// per-segment constant table ([8][N] lgamma differences) only when a full pass over all segments
+// needs it (need_segc) -- the sampled M-step objective evaluates its own segments' constants.
+static int ensure_tables(rmx_batch *b, int r0, int r1, bool need_segc = true) {
+    for (int r = r0; r < r1; r++) {
+        if (b->tables_dirty[r]) {
+            fill_logr(b->rp[r]);
+            ProfScope ps(b, KID_STATE_TABLES);
+            hipLaunchKernelGGL(k_state_tables_one, dim3(b->d.C), dim3(256), 0, b->stream, b->d, r, b->rp[r]);
+            b->tables_dirty[r] = 0; b->segc_dirty[r] = 1; b->ab_dirty[r] = 1;
+        }
+    }
+    if (need_segc) {
+        int r = r0;
+        while (r < r1) {
+            if (!b->segc_dirty[r]) { r++; continue; }
+            int e = r;
+            while (e < r1 && b->segc_dirty[e]) e++;
+            { ProfScope ps(b, KID_SEG_CONST); hipLaunchKernelGGL(k_seg_const, dim3((b->d.N + 255) / 256, e - r), dim3(256), 0, b->stream, b->d, r); }
+            for (int i = r; i < e; i++) b->segc_dirty[i] = 0;
+            r = e;
+        }
     }
     HIPCHK(hipGetLastError());
     return RMX_OK;
@@ -298,10 +323,10 @@ static int launch_pairwise_breakends(rmx_batch *b, int r0, int r1, int mode) {
     HIPCHK(hipGetLastError());
     return RMX_OK;
 }
-static int launch_brk_lut(rmx_batch *b, int r0, int r1, double *dst) {
+static int launch_brk_lut(rmx_batch *b, int r0, int r1, double *dst, double *edst) {
     if (b->d.NBE == 0) return RMX_OK;
     ProfScope ps(b, KID_BRK_LUT);
-    hipLaunchKernelGGL(k_brk_lut, dim3(b->d.NBE, r1 - r0), dim3(64), 0, b->stream, b->d, r0, dst);
+    hipLaunchKernelGGL(k_brk_lut, dim3(b->d.NBE, r1 - r0), dim3(64), 0, b->stream, b->d, r0, dst, edst);
     HIPCHK(hipGetLastError());
     return RMX_OK;
 }
@@ -414,6 +439,24 @@ int rmx_batch_create(const rmx_problem *pr, int32_t R, const double *h_init, con
         if (last || tel) { cstart.push_back(start); cend.push_back(n); cendflag[n] = 1; start = n + 1; }
     }
     d.NC = (int)cstart.size(); d.NBE = (int)b->be_n.size(); d.TC = (int)b->tc_pairs.size();
+    std::vector<int32_t> chain_tc(d.NC, 0), list_fast, list_gen, list_all(d.NC), be_cls(2 * (size_t)d.NBE);
+    std::vector<int32_t> chain_cls(d.NC, 0);
+    for (int c = 0; c < d.NC; c++) {
+        list_all[c] = c;
+        bool uniform = true;
+        for (int n = cstart[c]; n <= cend[c]; n++) if (b->seg_class[n] != b->seg_class[cstart[c]]) uniform = false;
+        chain_cls[c] = b->seg_class[cstart[c]];
+        // transition class of (cls, cls); a single-segment chain never looks at it
+        int tc0 = -1;
+        if (uniform) {
+            if (cend[c] > cstart[c]) tc0 = b->tclass[cstart[c]];
+            else tc0 = d.TC > 0 ? 0 : -1;
+        }
+        chain_tc[c] = tc0;
+        (tc0 >= 0 ? list_fast : list_gen).push_back(c);
+    }
+    for (int s_ = 0; s_ < d.NBE; s_++) { be_cls[2 * s_] = b->seg_class[b->be_n[s_]]; be_cls[2 * s_ + 1] = b->seg_class[b->be_n[s_] + 1]; }
+    b->n_fast = (int)list_fast.size(); b->n_generic = (int)list_gen.size();
     if (d.TC > 4096) { delete b; return fail(RMX_EUNSUPPORTED, "too many transition classes"); }
     std::vector<int32_t> bk_ptr(K + 1, 0), bk_slots(d.NBE);
     for (int s = 0; s < d.NBE; s++) bk_ptr[b->brk_idx[b->be_n[s]] + 1]++;
@@ -425,23 +468,26 @@ int rmx_batch_create(const rmx_problem *pr, int32_t R, const double *h_init, con
 #define UP(field, vec) if ((rc = dupload(b, &d.field, vec))) { rmx_batch_destroy(b); return rc; }
     std::vector<double> lv(pr->l, pr->l + N), xv(pr->x, pr->x + N), yv(pr->y, pr->y + 2 * (size_t)N);
     std::vector<uint8_t> ones(N, 1);
+    std::vector<double> loglv(N);
+    for (int n = 0; n < N; n++) loglv[n] = std::log(lv[n]);
     std::vector<int32_t> brkst((size_t)B * M);
     for (size_t i = 0; i < brkst.size(); i++) brkst[i] = (int32_t)b->brk_states[i];
-    UP(l, lv) UP(x, xv) UP(y, yv) UP(mask_t, ones) UP(mask_a, ones) UP(seg_class, b->seg_class) UP(tclass, b->tclass)
+    UP(l, lv) UP(logl, loglv) UP(x, xv) UP(y, yv) UP(mask_t, ones) UP(mask_a, ones) UP(seg_class, b->seg_class) UP(tclass, b->tclass)
     UP(brk_slot, b->brk_slot) UP(brk_idx, b->brk_idx) UP(brk_orient, b->brk_orient) UP(be_n, b->be_n) UP(chain_start, cstart)
     UP(chain_end, cend) UP(chain_end_flag, cendflag) UP(cn, cn8) UP(tot, tot8) UP(sflags, sflags) UP(brk_states, brkst)
-    UP(bk_ptr, bk_ptr) UP(bk_slots, bk_slots)
+    UP(bk_ptr, bk_ptr) UP(bk_slots, bk_slots) UP(chain_tc, chain_tc) UP(chain_cls, chain_cls) UP(chain_list_fast, list_fast) UP(chain_list_generic, list_gen)
+    UP(chain_list_all, list_all) UP(be_cls, be_cls)
 #undef UP
     const size_t SS = (size_t)S * S;
 #define DA(field, type, count) { type *p_ = nullptr; if ((rc = dalloc(b, &p_, (size_t)(count)))) { rmx_batch_destroy(b); return rc; } d.field = p_; }
     DA(Tval, double, SS * d.TC) DA(Wf, double, SS * d.TC) DA(Wb, double, SS * d.TC) DA(af, int8_t, SS * d.TC) DA(ab, int8_t, SS * d.TC)
     const size_t RN = (size_t)R * N, RNS = RN * d.SP, RCS = (size_t)R * C * d.SP;
-    DA(rp, RestartParams, R) DA(stD, double, RCS) DA(stP, double, RCS) DA(stM, double, RCS * 2) DA(stLg, double, RCS * 4) DA(stFlags, uint32_t, RCS)
+    DA(rp, RestartParams, R) DA(stLogD, double, RCS) DA(stD, double, RCS) DA(stP, double, RCS) DA(stM, double, RCS * 2) DA(stLg, double, RCS * 4) DA(stFlags, uint32_t, RCS)
     DA(segc, double, RN * 8) DA(qt, double, RN * 2) DA(qa, double, RN * 2) DA(qs, double, RN * 2) DA(pbrk, double, (size_t)R * K * B)
-    DA(f, double, RNS) DA(fa, double, RNS) DA(fb, double, RNS) DA(post, double, RNS) DA(fmax, double, RN) DA(mrow, double, RN)
+    DA(f, double, RNS) DA(fe, double, RNS) DA(fa, double, RNS) DA(fb, double, RNS) DA(post, double, RNS) DA(fmax, double, RN) DA(mrow, double, RN)
     DA(A, double, RN * 2) DA(Bv, double, RN * 4) DA(rowPF, double, RN) DA(rowPP, double, RN) DA(rowZ, double, RN)
     const size_t BEW = (size_t)R * d.NBE * M * d.D;
-    DA(pd_lt, double, BEW) DA(pd_cached, double, BEW) DA(hist, double, BEW) DA(be_jt, double, (size_t)R * d.NBE) DA(be_ja, double, (size_t)R * d.NBE)
+    DA(pd_lt, double, BEW) DA(pe_lt, double, (size_t)R * d.NBE * ((M * d.D + 1) & ~1) + 2) DA(pd_cached, double, BEW) DA(hist, double, BEW) DA(be_jt, double, (size_t)R * d.NBE) DA(be_ja, double, (size_t)R * d.NBE)
     DA(err, uint32_t, R)
 #undef DA
     if ((rc = dalloc(b, &b->d_lt_valid, R)) || (rc = dalloc(b, &b->d_partial, (size_t)R * ELBO_BLOCKS * 2)) || (rc = dalloc(b, &b->d_out4, (size_t)R * 4)) ||
@@ -463,7 +509,7 @@ int rmx_batch_create(const rmx_problem *pr, int32_t R, const double *h_init, con
     }
 
     // per-restart initial state (bpmodel.pyx:546-597)
-    b->rp.resize(R); b->tables_dirty.assign(R, 1); b->ab_dirty.assign(R, 1); b->lt_valid.assign(R, 0); b->logZ.assign(R, 0.);
+    b->rp.resize(R); b->tables_dirty.assign(R, 1); b->segc_dirty.assign(R, 1); b->ab_dirty.assign(R, 1); b->lt_valid.assign(R, 0); b->logZ.assign(R, 0.);
     for (int r = 0; r < R; r++) {
         RestartParams &p = b->rp[r];
         memset(&p, 0, sizeof p);
@@ -497,16 +543,17 @@ int rmx_batch_create(const rmx_problem *pr, int32_t R, const double *h_init, con
         for (auto &x_ : row) x_ = 1.0 / (double)S;
         for (int r = 0; r < R; r++) HIPCHK(hipMemcpy(d.post + (size_t)r * N * d.SP, row.data(), row.size() * 8, hipMemcpyHostToDevice));
         HIPCHK(hipMemset(d.rowZ, 0, RN * 8)); HIPCHK(hipMemset(d.fmax, 0, RN * 8)); HIPCHK(hipMemset(d.mrow, 0, RN * 8));
-        HIPCHK(hipMemset(d.fa, 0, RNS * 8)); HIPCHK(hipMemset(d.fb, 0, RNS * 8));
+        HIPCHK(hipMemset(d.fa, 0, RNS * 8)); HIPCHK(hipMemset(d.fb, 0, RNS * 8)); HIPCHK(hipMemset(d.fe, 0, RNS * 8));
         HIPCHK(hipMemset(d.err, 0, R * 4)); HIPCHK(hipMemset(b->d_lt_valid, 0, R * 4));
         HIPCHK(hipMemset(d.hist, 0, BEW * 8)); HIPCHK(hipMemset(d.be_jt, 0, (size_t)R * d.NBE * 8)); HIPCHK(hipMemset(d.be_ja, 0, (size_t)R * d.NBE * 8));
         HIPCHK(hipMemset(d.pd_lt, 0, BEW * 8));
     }
+    if (getenv("RMX_FB_DEBUG")) { if ((rc = dalloc(b, &b->d_dbg, 32))) { rmx_batch_destroy(b); return rc; } HIPCHK(hipMemset(b->d_dbg, 0, 256)); }
     b->G = S > 32 ? 64 : (S > 16 ? 32 : (S > 8 ? 16 : 8));
     configure_fb(b);
-    if (b->fb_lds > 64 * 1024) { rmx_batch_destroy(b); return fail(RMX_EUNSUPPORTED, "LDS budget exceeded"); }
+    if (b->fb_lds > 160 * 1024 || b->fbG_lds > 160 * 1024) { rmx_batch_destroy(b); return fail(RMX_EUNSUPPORTED, "LDS budget exceeded"); }
     // cached_log_transmat of the constructor (:604) + pairwise reductions of the uniform joint
-    if ((rc = launch_brk_lut(b, 0, R, d.pd_cached)) || (rc = launch_pairwise_breakends(b, 0, R, 1))) { rmx_batch_destroy(b); return rc; }
+    if ((rc = launch_brk_lut(b, 0, R, d.pd_cached, nullptr)) || (rc = launch_pairwise_breakends(b, 0, R, 1))) { rmx_batch_destroy(b); return rc; }
     b->plain_T_init.assign(R, plain_T_mean_sum(b));
     // plain adjacency list (only used when exact energy / entropy parts are requested)
     for (int n = 0; n + 1 < N; n++) if (b->tclass[n] >= 0 && b->brk_slot[n] < 0) b->plain_list.push_back(n);
@@ -544,7 +591,9 @@ int rmx_info(rmx_batch *b, int32_t what, int64_t *out) {
     switch (what) {
     case 0: *out = b->d.cn_max; break; case 1: *out = b->d.NC; break; case 2: *out = b->d.TC; break; case 3: *out = b->d.NBE; break;
     case 4: *out = b->d.SP; break; case 5: *out = b->fb_rpt; break; case 6: *out = b->fbL.P; break; case 7: *out = b->fbL.NT; break;
-    case 8: *out = b->fbL.BLK; break; case 9: *out = (int64_t)b->fb_lds; break;
+    case 8: *out = b->fbL.BLK; break; case 9: *out = (int64_t)b->fb_lds; break; case 10: *out = b->n_fast; break; case 11: *out = b->n_generic; break;
+    case 20: case 21: case 22: case 23: case 24: case 25: case 26: case 27: case 28: case 29: case 30: case 31: case 32: case 33: case 34: case 35: case 36: case 37: case 38: case 39:
+        { if (!b->d_dbg) { *out = 0; break; } unsigned long long v[32]; HIPCHK(hipStreamSynchronize(b->stream)); HIPCHK(hipMemcpy(v, b->d_dbg, 256, hipMemcpyDeviceToHost)); *out = (int64_t)v[what - 20]; break; }
     default: return fail(RMX_EARG, "bad info id");
     }
     return RMX_OK;
@@ -691,11 +740,27 @@ static int do_update_p_cn(rmx_batch *b, int r0, int r1) {
     int rc = do_framelogprob(b, r0, r1);
     if (rc) return rc;
     // log_transmat snapshot := T(current p_breakpoint)   (bpmodel.pyx:939)
-    if ((rc = launch_brk_lut(b, r0, r1, b->d.pd_lt))) return rc;
+    if ((rc = launch_brk_lut(b, r0, r1, b->d.pd_lt, b->d.pe_lt))) return rc;
     {
         ProfScope ps(b, KID_FB);
-        fb_kernel_t k = fb_kernel_for(b->fb_rpt);
-        hipLaunchKernelGGL(k, dim3(b->d.NC, r1 - r0, 2), dim3(b->fbL.NT), b->fb_lds, b->stream, b->d, r0, b->fbL);
+        const Dev &d = b->d;
+        FbArgs a;
+        a.S = d.S; a.SP = d.SP; a.M = d.M; a.D = d.D; a.C = d.C; a.N = d.N; a.NBE = d.NBE; a.cn_max = d.cn_max;
+        a.r0 = r0; a.pen = d.pen;
+        a.chain_start = d.chain_start; a.chain_end = d.chain_end; a.tclass = d.tclass; a.brk_slot = d.brk_slot;
+        a.chain_tc = d.chain_tc; a.chain_cls = d.chain_cls; a.be_cls = d.be_cls; a.amat_lds = 0; a.pad_ = 0;
+        a.fe = d.fe; a.Wf = d.Wf; a.Wb = d.Wb; a.pe_lt = d.pe_lt; a.af = d.af; a.ab = d.ab; a.tot = d.tot;
+        a.fa = d.fa; a.fb = d.fb; a.mrow = d.mrow; a.err = d.err; a.dbg = b->d_dbg;
+        const bool fast = b->fb_rpt > 0;
+        if (fast && b->n_fast > 0) {
+            a.P = b->fbL.P; a.BLK = b->fbL.BLK; a.SPAD = b->fbL.SPAD; a.chain_list = d.chain_list_fast; a.amat_lds = b->fb_amat_lds;
+            hipLaunchKernelGGL(fb_kernel_for(b->fb_rpt), dim3(b->n_fast, r1 - r0, 2), dim3(b->fbL.NT), b->fb_lds, b->stream, a);
+        }
+        const int ngen = fast ? b->n_generic : d.NC;
+        if (ngen > 0) {
+            a.amat_lds = 0; a.P = b->fbG.P; a.BLK = b->fbG.BLK; a.SPAD = b->fbG.SPAD; a.chain_list = fast ? d.chain_list_generic : d.chain_list_all;
+            hipLaunchKernelGGL(fb_kernel_for(0), dim3(ngen, r1 - r0, 2), dim3(b->fbG.NT), b->fbG_lds, b->stream, a);
+        }
         HIPCHK(hipGetLastError());
     }
     {
@@ -715,7 +780,7 @@ static int do_update_p_breakpoint(rmx_batch *b, int r0, int r1) {
         HIPCHK(hipGetLastError());
     }
     // cached_log_transmat := T(new p_breakpoint)  (bpmodel.pyx:985)
-    int rc = launch_brk_lut(b, r0, r1, b->d.pd_cached);
+    int rc = launch_brk_lut(b, r0, r1, b->d.pd_cached, nullptr);
     if (rc) return rc;
     const double pti = plain_T_mean_sum(b);
     for (int r = r0; r < r1; r++) b->plain_T_init[r] = pti;
@@ -838,7 +903,7 @@ int rmx_expected_log_likelihood(rmx_batch *b, int32_t r, const int64_t *sample, 
         { ProfScope ps(b, KID_ELL_FULL); hipLaunchKernelGGL(k_ell_full, dim3(ELBO_BLOCKS), dim3(256), 0, b->stream, b->d, r, b->d_ell_partial); }
         { ProfScope ps(b, KID_ELL_FINAL); hipLaunchKernelGGL(k_ell_final, dim3(1), dim3(256), 0, b->stream, b->d_ell_partial, ELBO_BLOCKS, b->d_ell_out); }
     } else {
-        if ((rc = ensure_tables(b, r, r + 1))) return rc;
+        if ((rc = ensure_tables(b, r, r + 1, false))) return rc;
         {
             ProfScope ps(b, KID_ELL_LIST);
             if (partial_h_out) hipLaunchKernelGGL(k_ell_list<true>, dim3(cnt), dim3(256), 0, b->stream, b->d, r, (const int32_t *)b->d_sample, b->d_ell_partial);

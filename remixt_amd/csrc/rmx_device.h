@@ -37,19 +37,24 @@
 struct RestartParams {
     double h[RMX_MAX_CLONES];
     double p[RMX_P_COUNT];
+    double logr[2];   // log(negbin_r_0), log(negbin_r_1) (filled by the host when uploading)
 };
 
 struct Dev {
     int N, S, SP, M, K, B, C, D, cn_max, NC, NBE, TC, nc, tmodel, R, pad0;
     double pen;
     // ---- shared, read-only --------------------------------------------------
-    const double *l, *x, *y;             // [N], [N], [N][2]
+    const double *l, *x, *y, *logl;      // [N], [N], [N][2], log(l) [N]
     const uint8_t *mask_t, *mask_a;      // [N]
     const int32_t *seg_class;            // [N]
     const int32_t *tclass;               // [N] transition class of (n,n+1); -1: telomere / last
     const int32_t *brk_slot;             // [N] breakend slot of (n,n+1) or -1
     const int32_t *brk_idx, *brk_orient; // [N]
     const int32_t *be_n;                 // [NBE] slot -> n
+    const int32_t *be_cls;               // [NBE][2] state-table class of segments n, n+1
+    const int32_t *chain_tc;             // [NC] transition class of a chain whose segments share one state-table class, or -1
+    const int32_t *chain_cls;            // [NC] that state-table class
+    const int32_t *chain_list_fast, *chain_list_generic, *chain_list_all;  // chains by FB kernel
     const int32_t *chain_start, *chain_end; // [NC]
     const uint8_t *chain_end_flag;       // [N]
     const int8_t *cn;                    // [C][S][M][2]
@@ -62,15 +67,17 @@ struct Dev {
     // ---- per restart ----------------------------------------------------------
     RestartParams *rp;                   // [R]
     double *stD, *stP, *stM, *stLg;      // [R][C][SP]; stM [R][C][2][SP]; stLg [R][C][4][SP]
+    double *stLogD;                      // [R][C][SP] log of the state's expected depth
     uint32_t *stFlags;                   // [R][C][SP]
     double *segc;                        // [R][8][N]
     double *qt, *qa, *qs;                // [R][N][2]
     double *pbrk;                        // [R][K][B]
-    double *f, *fa, *fb, *post;          // [R][N][SP]
+    double *f, *fe, *fa, *fb, *post;     // [R][N][SP]; fe = exp(f - rowmax)
     double *fmax, *mrow;                 // [R][N]
     double *A, *Bv;                      // [R][N][2], [R][N][4]
     double *rowPF, *rowPP, *rowZ;        // [R][N]
     double *pd_lt, *pd_cached;           // [R][NBE][M][D]
+    double *pe_lt;                       // [R][NBE][MDP] exp(-pen * pd_lt), rows padded to 16 bytes
     double *hist;                        // [R][NBE][M][D]
     double *be_jt, *be_ja;               // [R][NBE]
     uint32_t *err;                       // [R]
@@ -97,16 +104,45 @@ __device__ inline double digamma_as103(double x, unsigned &err) {
     return value;
 }
 
+// ---- fast log-gamma for positive arguments -------------------------------------------
+// Stirling series with 6 correction terms for z >= 16 (truncation error < 1e-17
+// relative), upward recurrence below.  Replaces libm lgamma in the per-cell hot
+// loops (8 evaluations per (segment,state) cell); accuracy is pinned against the
+// oracle by the parity tests (well inside the 1e-6 budget).  z <= 0 -> NaN.
+__device__ __forceinline__ double lgamma_pos(double z) {
+    if (!(z > 0.)) return __builtin_nan("");
+    double shift = 1.;
+    bool shifted = false;
+    while (z < 16.) { shift *= z; z += 1.; shifted = true; }
+    const double r = 1.0 / z, r2 = r * r;
+    double c = 691.0 / 360360.0;
+    c = fma(-c, r2, 1.0 / 1188.0);
+    c = fma(-c, r2, 1.0 / 1680.0);
+    c = fma(-c, r2, 1.0 / 1260.0);
+    c = fma(-c, r2, 1.0 / 360.0);
+    c = fma(-c, r2, 1.0 / 12.0);
+    double v = fma(z - 0.5, log(z), -z) + 0.91893853320467274178 + c * r;
+    if (shifted) v -= log(shift);
+    return v;
+}
+
+// reciprocal for scale factors (v_rcp_f64 + one Newton step)
+__device__ __forceinline__ double fast_rcp(double m) {
+    double r = __builtin_amdgcn_rcp(m);
+    const double e = fma(-m, r, 1.0);
+    return fma(r, e, r);
+}
+
 // ---- per-segment context ----------------------------------------------------------
 struct SegCtx {
-    double x, l, y0, y1, ys;
+    double x, l, y0, y1, ys, logl;
     int mt, ma;
     double cnb[4];   // [u*2+var]  lgamma(x+r) - lgamma(x+1) - lgamma(r); var 1 = hdel dispersion
     double cbb[4];   // [v*2+var]  lgamma(n+1)-lgamma(k+1)-lgamma(n-k+1)-lgamma(n+M)+lgamma(M); var 1 = loh dispersion
 };
 
 __device__ __forceinline__ void load_seg(const Dev &d, int r, int n, SegCtx &c) {
-    c.x = d.x[n]; c.l = d.l[n]; c.y0 = d.y[2 * (size_t)n]; c.y1 = d.y[2 * (size_t)n + 1]; c.ys = c.y0 + c.y1;
+    c.x = d.x[n]; c.l = d.l[n]; c.logl = d.logl[n]; c.y0 = d.y[2 * (size_t)n]; c.y1 = d.y[2 * (size_t)n + 1]; c.ys = c.y0 + c.y1;
     c.mt = d.mask_t[n]; c.ma = d.mask_a[n];
     const double *sc = d.segc + (size_t)r * 8 * d.N + n;
 #pragma unroll
@@ -135,8 +171,21 @@ __device__ inline void cell_ll(const Dev &d, const RestartParams &rp, const SegC
             LT[1] = sc.cnb[3] + nb_state_part(sc.x, mu, rp.p[RMX_P_NEGBIN_HDEL_R_1]);
         } else {
             const double mu = d.stD[si] * sc.l;
-            LT[0] = sc.cnb[0] + nb_state_part(sc.x, mu, rp.p[RMX_P_NEGBIN_R_0]);
-            LT[1] = sc.cnb[2] + nb_state_part(sc.x, mu, rp.p[RMX_P_NEGBIN_R_1]);
+            if (mu > 0.) {
+                // x log p + r log(1-p) with p = mu/(r+mu), t = r/mu:
+                //   log p = -log1p(t)            (no cancellation: keeps the objective smooth in h for L-BFGS-B)
+                //   log(1-p) = log t - log1p(t), log t = log r - log l - log D from the tables
+                // -> one log1p per u instead of two logs
+                const double lmu = sc.logl + d.stLogD[si];
+                const double rmu = 1.0 / mu;
+                const double r0_ = rp.p[RMX_P_NEGBIN_R_0], r1_ = rp.p[RMX_P_NEGBIN_R_1];
+                const double L0 = log1p(r0_ * rmu), L1 = log1p(r1_ * rmu);
+                LT[0] = sc.cnb[0] + (r0_ * ((rp.logr[0] - lmu) - L0) - sc.x * L0);
+                LT[1] = sc.cnb[2] + (r1_ * ((rp.logr[1] - lmu) - L1) - sc.x * L1);
+            } else {
+                LT[0] = sc.cnb[0] + nb_state_part(sc.x, mu, rp.p[RMX_P_NEGBIN_R_0]);
+                LT[1] = sc.cnb[2] + nb_state_part(sc.x, mu, rp.p[RMX_P_NEGBIN_R_1]);
+            }
         }
         if (LT[0] != LT[0] || LT[1] != LT[1]) err |= RMX_ERR_NAN_LL;
     }
@@ -158,8 +207,8 @@ __device__ inline void cell_ll(const Dev &d, const RestartParams &rp, const SegC
                 const double a = M * p, b = M * (1 - p);
                 const double base = sc.cbb[v * 2 + var] - lg[(2 * v) * cs] - lg[(2 * v + 1) * cs];
                 // w = 0: k = y0 ; w = 1: k = y1
-                LA[v * 2 + 0] = base + lgamma(sc.y0 + a) + lgamma(sc.ys - sc.y0 + b);
-                LA[v * 2 + 1] = base + lgamma(sc.y1 + a) + lgamma(sc.ys - sc.y1 + b);
+                LA[v * 2 + 0] = base + lgamma_pos(sc.y0 + a) + lgamma_pos(sc.ys - sc.y0 + b);
+                LA[v * 2 + 1] = base + lgamma_pos(sc.y1 + a) + lgamma_pos(sc.ys - sc.y1 + b);
             }
             if (LA[0] != LA[0] || LA[1] != LA[1] || LA[2] != LA[2] || LA[3] != LA[3]) err |= RMX_ERR_NAN_LL;
         }
@@ -193,6 +242,44 @@ __device__ __forceinline__ double group_sum(double v, int G) {
 __device__ __forceinline__ double group_max(double v, int G) {
     for (int off = G >> 1; off > 0; off >>= 1) { double o = __shfl_xor(v, off, 64); v = o > v ? o : v; }
     return v;
+}
+
+// ---- DPP cross-lane helpers (no LDS round trip, unlike __shfl_xor's ds_bpermute) ----------
+template <int CTRL> __device__ __forceinline__ double dpp_mov_f64(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xf, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+// sum over the aligned group of PP lanes (PP a power of two <= 64); every lane of the group gets the sum.
+// xor-1 / xor-2 are quad permutes; once quads (half rows) hold uniform values, the half-row (row)
+// mirror pairs each lane with one of the other quad (half row), which is all a butterfly step needs.
+__device__ __forceinline__ double quad_group_sum(double v, int PP) {
+    if (PP >= 2) v += dpp_mov_f64<0xB1>(v);     // quad_perm [1,0,3,2]
+    if (PP >= 4) v += dpp_mov_f64<0x4E>(v);     // quad_perm [2,3,0,1]
+    if (PP >= 8) v += dpp_mov_f64<0x141>(v);    // row_half_mirror
+    if (PP >= 16) v += dpp_mov_f64<0x140>(v);   // row_mirror
+    if (PP >= 32) v += __shfl_xor(v, 16, 64);
+    if (PP >= 64) v += __shfl_xor(v, 32, 64);
+    return v;
+}
+// maximum over the 64 lanes of a wave of non-negative values; result valid in every lane.
+__device__ __forceinline__ double wave_max_nonneg(double v) {
+    v = fmax(v, dpp_mov_f64<0x121>(v));   // row_ror:1
+    v = fmax(v, dpp_mov_f64<0x122>(v));   // row_ror:2
+    v = fmax(v, dpp_mov_f64<0x124>(v));   // row_ror:4
+    v = fmax(v, dpp_mov_f64<0x128>(v));   // row_ror:8  -> every lane holds its row's (16 lanes) maximum
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    double r = v;
+#pragma unroll
+    for (int row = 0; row < 4; row++)
+        r = fmax(r, __hiloint2double(__builtin_amdgcn_readlane(hi, row * 16), __builtin_amdgcn_readlane(lo, row * 16)));
+    return r;
+}
+// LDS 64-bit unsigned atomic max, one instruction (atomicMax() makes hipcc emit a per-lane scalar loop)
+__device__ __forceinline__ void lds_max_u64(void *lds_ptr, unsigned long long v) {
+    const unsigned addr = (unsigned)(size_t)(__attribute__((address_space(3))) void *)lds_ptr;
+    asm volatile("ds_max_u64 %0, %1" ::"v"(addr), "v"(v) : "memory");
 }
 
 // block-wide deterministic sum (fixed tree): all threads must call; result valid in thread 0

@@ -17,9 +17,7 @@
 
 // state tables: depth, allele ratio, dispersion and lgamma(M p), lgamma(M (1-p))
 // per (restart, class, state).  grid (C, nr), block 256.
-__global__ void k_state_tables(Dev d, int r0) {
-    const int cls = blockIdx.x, r = r0 + blockIdx.y;
-    const RestartParams rp = d.rp[r];
+__device__ __forceinline__ void state_tables_body(const Dev &d, int cls, int r, const RestartParams &rp) {
     for (int s = threadIdx.x; s < d.S; s += blockDim.x) {
         const int8_t *cn = d.cn + ((size_t)cls * d.S + s) * d.M * 2;
         const int8_t *tot = d.tot + ((size_t)cls * d.S + s) * d.M;
@@ -52,6 +50,7 @@ __global__ void k_state_tables(Dev d, int r0) {
         const size_t base = ((size_t)r * d.C + cls);
         const size_t si = base * d.SP + s;
         d.stD[si] = total;
+        d.stLogD[si] = total > 0. ? log(total) : 0.;
         d.stP[si] = p;
         d.stM[(base * 2 + 0) * d.SP + s] = M0;
         d.stM[(base * 2 + 1) * d.SP + s] = M1;
@@ -63,22 +62,35 @@ __global__ void k_state_tables(Dev d, int r0) {
         d.stFlags[si] = fl;
     }
 }
+__global__ void k_state_tables(Dev d, int r0) {
+    const int cls = blockIdx.x, r = r0 + blockIdx.y;
+    const RestartParams rp = d.rp[r];
+    state_tables_body(d, cls, r, rp);
+}
+// single restart, parameters by value: also publishes them to d.rp[r] (one launch fewer per M-step evaluation)
+__global__ void k_state_tables_one(Dev d, int r, RestartParams rp) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) d.rp[r] = rp;
+    state_tables_body(d, blockIdx.x, r, rp);
+}
 
 // per-segment constants of the NB / BB log pmf.  grid (ceil(N/256), nr)
+__device__ __forceinline__ double seg_const_value(const RestartParams &rp, double x, double y0, double ys, int i) {
+    // i in 0..3: NB constants [u*2+var]; i in 4..7: BB constants [v*2+var]
+    if (i < 4) {
+        const double rr = rp.p[i == 0 ? RMX_P_NEGBIN_R_0 : (i == 1 ? RMX_P_NEGBIN_HDEL_R_0 : (i == 2 ? RMX_P_NEGBIN_R_1 : RMX_P_NEGBIN_HDEL_R_1))];
+        return lgamma(x + rr) - lgamma(x + 1) - lgamma(rr);
+    }
+    const double MM = rp.p[i == 4 ? RMX_P_BETABIN_M_0 : (i == 5 ? RMX_P_BETABIN_LOH_M_0 : (i == 6 ? RMX_P_BETABIN_M_1 : RMX_P_BETABIN_LOH_M_1))];
+    return (lgamma(ys + 1) - lgamma(y0 + 1) - lgamma(ys - y0 + 1)) - lgamma(ys + MM) + lgamma(MM);
+}
 __global__ void k_seg_const(Dev d, int r0) {
     const int n = blockIdx.x * blockDim.x + threadIdx.x, r = r0 + blockIdx.y;
     if (n >= d.N) return;
     const RestartParams &rp = d.rp[r];
     const double x = d.x[n], y0 = d.y[2 * (size_t)n], y1 = d.y[2 * (size_t)n + 1], ys = y0 + y1;
     double *sc = d.segc + (size_t)r * 8 * d.N + n;
-    const double lgx1 = lgamma(x + 1);
-    const double rr[4] = {rp.p[RMX_P_NEGBIN_R_0], rp.p[RMX_P_NEGBIN_HDEL_R_0], rp.p[RMX_P_NEGBIN_R_1], rp.p[RMX_P_NEGBIN_HDEL_R_1]};
 #pragma unroll
-    for (int i = 0; i < 4; i++) sc[(size_t)i * d.N] = lgamma(x + rr[i]) - lgx1 - lgamma(rr[i]);
-    const double cb = lgamma(ys + 1) - lgamma(y0 + 1) - lgamma(ys - y0 + 1);
-    const double MM[4] = {rp.p[RMX_P_BETABIN_M_0], rp.p[RMX_P_BETABIN_LOH_M_0], rp.p[RMX_P_BETABIN_M_1], rp.p[RMX_P_BETABIN_LOH_M_1]};
-#pragma unroll
-    for (int i = 0; i < 4; i++) sc[(size_t)(4 + i) * d.N] = cb - lgamma(ys + MM[i]) + lgamma(MM[i]);
+    for (int i = 0; i < 8; i++) sc[(size_t)i * d.N] = seg_const_value(rp, x, y0, ys, i);
 }
 
 // =============================================================================
@@ -112,6 +124,9 @@ __global__ void k_framelogprob(Dev d, int r0, int G) {
     }
     vmax = group_max(vmax, G);
     if (gl == 0) d.fmax[(size_t)r * d.N + n] = vmax;
+    // scaled linear-domain emissions for the forward-backward kernel (each lane re-reads its own stores)
+    double *erow = d.fe + rs_off(d, r, n);
+    for (int s = gl; s < d.SP; s += G) erow[s] = s < d.S ? exp(frow[s] - vmax) : 0.;
     if (err) atomicOr(&d.err[r], err);
 }
 
@@ -135,160 +150,307 @@ __global__ void k_framelogprob(Dev d, int r0, int G) {
 // published together and the division by the maximum is applied by the consumer.
 // =============================================================================
 #define FB_NBUF 3
-#define FB_EPT 2
 
 struct FbLaunch { int P, NT, BLK, SPAD; };
 
-template <int RPT, int P, int NTMAX>
-__global__ __launch_bounds__(NTMAX) void k_fb(Dev d, int r0, FbLaunch L) {
-    extern __shared__ __align__(16) unsigned char smem_raw[];
-    const int chain = blockIdx.x, r = r0 + blockIdx.y, dir = blockIdx.z;
-    const int S = d.S, M = d.M, D = d.D;
-    const int n0 = d.chain_start[chain], n1 = d.chain_end[chain], len = n1 - n0 + 1;
-    const int t = threadIdx.x, NT = blockDim.x, nw = NT >> 6;
-    const int PP = L.P;
-    const int o = t / PP, p = t % PP;
-    const bool act = o < S;
-    const int QPT = (RPT > 0) ? RPT : (S + PP - 1) / PP;
-    const int SPAD = L.SPAD, BLK = L.BLK;
-    // LDS carve-up
-    double *vec = (double *)smem_raw;                   // [2][SPAD]
-    double *red = vec + 2 * SPAD;                       // [2][16]
-    double *ebuf = red + 32;                            // [NBUF][BLK][SPAD]
-    double *pdl = ebuf + (size_t)FB_NBUF * BLK * SPAD;  // [M*D]
-    int8_t *totl = (int8_t *)(pdl + M * D);             // [C][S][M]
-    for (int i = t; i < d.C * S * M; i += NT) totl[i] = d.tot[i];
-    for (int i = t; i < 2 * SPAD; i += NT) vec[i] = 0.;   // tails [S, SPAD) stay zero: padded slices read them
+// compact argument block: only what the recursion touches (keeps the kernel's SGPR footprint small)
+struct FbArgs {
+    int S, SP, M, D, C, N, NBE, cn_max, P, BLK, SPAD, r0, amat_lds, pad_;
+    double pen;
+    const int32_t *chain_start, *chain_end, *tclass, *brk_slot, *chain_list, *chain_tc, *chain_cls, *be_cls;
+    const double *fe, *Wf, *Wb, *pe_lt;
+    const int8_t *af, *ab, *tot;
+    double *fa, *fb, *mrow;
+    uint32_t *err;
+    unsigned long long *dbg;   // optional: [0..3] = shader clock / 100 MHz wall clock at loop start and end of block (0,0,0)
+};
 
-    const double *fbase = d.f + rs_off(d, r, 0);
-    const double *fmaxb = d.fmax + (size_t)r * d.N;
-    double *outb = (dir == 0 ? d.fa : d.fb) + rs_off(d, r, 0);
-    double *mrow = d.mrow + (size_t)r * d.N;
-    const double *Wmat = dir == 0 ? d.Wf : d.Wb;
-    const int8_t *amat = dir == 0 ? d.af : d.ab;
-    const double pen = d.pen;
+typedef const __attribute__((address_space(1))) void *gptr_t;
+typedef __attribute__((address_space(3))) void *lptr_t;
+
+// raw workgroup barrier: LDS traffic of this wave retired, vector-memory traffic (result stores,
+// LDS-DMA prefetch) left in flight
+#define FB_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+
+// LDS-DMA through inline asm (cdna_hip_programming.md 5.7): hipcc must not see a pending LDS write or
+// a pending store in the step loop, or it drains vmcnt(0) -- the result stores' HBM round trip -- in
+// front of the LDS reads of every step.  All vector-memory traffic of the loop is therefore issued
+// here and retired by the explicit waits at the block boundaries.
+__device__ __forceinline__ void glds16(const void *gsrc, unsigned lds_dst_uniform) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst_uniform) : "memory");
+}
+__device__ __forceinline__ void glds4(const void *gsrc, unsigned lds_dst_uniform) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst_uniform) : "memory");
+}
+__device__ __forceinline__ void gstore8(double *dst, double v) {
+    asm volatile("global_store_dwordx2 %0, %1, off\n\ts_nop 1" ::"v"(dst), "v"(v) : "memory");
+}
+__device__ __forceinline__ unsigned lds_addr(const void *p) { return (unsigned)(size_t)(lptr_t)p; }
+
+// RPT > 0: register-stationary weights, only for chains whose segments all share one state-table
+// class (chain_tc[chain] >= 0; the host routes the other chains to the RPT == 0 kernel).
+//
+// Thread t = p * S + o: slice p of the reduction index for output state o (slices are packed
+// back to back, so a wave may straddle two slices).  A step is
+//   phase 1 (all threads): partial[p][o] = sum_{q in slice p} vec[q] * W[q][o]        -> LDS
+//   phase 2 (threads t < S): sum the P partials in fixed order, scale, multiply by the emission,
+//           publish the new vector + its maximum, store the result row
+// with one raw barrier after each phase.  Phase 2 runs on ceil(S/64) waves only, so the per-step
+// bookkeeping is not replicated on every wave of the workgroup.
+#ifdef RMX_FB_STAMPS
+#define FB_STAMP(i_) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); stamp_acc[i_] += t_ - stamp_last; stamp_last = t_; }
+#else
+#define FB_STAMP(i_)
+#endif
+template <int RPT, int NTMAX>
+__global__ __launch_bounds__(NTMAX) void k_fb(FbArgs a) {
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    const int chain = a.chain_list[blockIdx.x], r = a.r0 + blockIdx.y, dir = blockIdx.z;
+    const int S = a.S, M = a.M, D = a.D, SP = a.SP;
+    const int n0 = a.chain_start[chain], n1 = a.chain_end[chain], len = n1 - n0 + 1;
+    const int t = threadIdx.x, NT = blockDim.x;
+    const int PP = a.P;
+    const int p = t / S, o = t - p * S;
+    const bool act = p < PP;                            // thread takes part in phase 1
+    const bool post = t < S;                            // thread takes part in phase 2
+    const int QPT = (RPT > 0) ? RPT : (S + PP - 1) / PP;
+    const int SPAD = a.SPAD, BLK = a.BLK;
+    const int MDP = (M * D + 1) & ~1;                   // breakend table row, padded to 16 bytes
+    // LDS carve-up (one array: see cdna_hip_programming.md 5, trap 4a)
+    double *ebuf = (double *)smem_raw;                  // [NBUF][BLK][SP]   emission ring, filled by LDS-DMA
+    double *vec = ebuf + (size_t)FB_NBUF * BLK * SP;    // [2][SPAD]
+    double *part = vec + 2 * SPAD;                      // [P][SP] partial sums of phase 1
+    double *red = part + (size_t)PP * SP;               // [4]  rotating per-step maxima (as u64)
+    double *pel = red + 4;                              // [MDP]  exp(-pen*pd) of the current breakend (LDS-DMA)
+    double *wa = pel + MDP;                             // [128] exp(-pen*a) for the allele-flip term
+    int *meta = (int *)(wa + 128);                      // [NBUF][2][64]  tclass / brk_slot per step (LDS-DMA)
+    int8_t *totl = (int8_t *)(meta + FB_NBUF * 2 * 64); // [C][S][M]
+    int8_t *atl = totl + ((a.C * S * M + 15) & ~15);    // [S][S] allele-flip term of the chain's class (RPT > 0, if it fits)
+    for (int i = t; i < a.C * S * M; i += NT) totl[i] = a.tot[i];
+    if (RPT > 0 && a.amat_lds) {
+        const int8_t *src = (dir == 0 ? a.af : a.ab) + (size_t)a.chain_tc[chain] * S * S;
+        for (int i = t; i < S * S; i += NT) atl[i] = src[i];
+    }
+    for (int i = t; i < 2 * SPAD; i += NT) vec[i] = 0.;   // tails [S, SPAD) stay zero: padded slices read them
+    for (int i = t; i < 128; i += NT) wa[i] = exp(-a.pen * (double)i);
+    for (int i = t; i < FB_NBUF * 2 * 64; i += NT) meta[i] = -1;
+    unsigned long long *red64 = reinterpret_cast<unsigned long long *>(red);   // [3] used
+    if (t < 4) red64[t] = 0ull;
+
+    const size_t rbase = (size_t)r * a.N;
+    const double *febase = a.fe + rbase * SP;
+    double *outb = (dir == 0 ? a.fa : a.fb) + rbase * SP;
+    double *mrow = a.mrow + rbase;
+    const double *Wmat = dir == 0 ? a.Wf : a.Wb;
+
+    // ---- stationary weights: loaded once, consumed before the loop --------------------
+    double w[RPT > 0 ? RPT : 1];
+    if constexpr (RPT > 0) {
+        const double *Wt = Wmat + (size_t)a.chain_tc[chain] * S * S;
+#pragma unroll
+        for (int rr = 0; rr < RPT; rr++) { const int q = p * RPT + rr; w[rr] = (act && q < S) ? Wt[(size_t)q * S + o] : 0.; }
+        // consume the loads here: a load hipcc believes may still be pending at the loop's first FMA
+        // costs an s_waitcnt vmcnt(0) in EVERY step, which also waits for the result stores
+#pragma unroll
+        for (int rr = 0; rr < RPT; rr++) asm volatile("" ::"v"(w[rr]));
+    }
+    // the chain's state-table class, fetched once (same reason)
+    int chain_cls_ = RPT > 0 ? __builtin_amdgcn_readfirstlane(a.chain_cls[chain]) : 0;
+    asm volatile("" : "+s"(chain_cls_));
+    __syncthreads();   // LDS initialisation done
 
 #define ROW(k) (dir == 0 ? n0 + (k) : n1 - (k))
-    // ---- emission prefetch: block b = steps [b*BLK, (b+1)*BLK) -------------------
+    // ---- prefetch ring: block b = steps [b*BLK, (b+1)*BLK).  A block's emission rows are one
+    // contiguous span of BLK*SP doubles in HBM (ascending rows for either direction) and its
+    // transition metadata one contiguous span of BLK ints; both are copied verbatim into the
+    // block's ring slot by LDS-DMA, lane-linear per wave.  Step kk of a block sits at index kk
+    // (forward) or BLK-1-kk (backward) of the span.
     const int nblk = (len + BLK - 1) / BLK;
-    double pre[FB_EPT]; double prem[FB_EPT];
-    auto issue = [&](int b) {
-#pragma unroll
-        for (int e = 0; e < FB_EPT; e++) {
-            const int idx = t + e * NT; const int kk = idx / S, j = idx - kk * S; const int k = b * BLK + kk;
-            if (kk < BLK && k < len) { const int row = ROW(k); pre[e] = fbase[(size_t)row * d.SP + j]; prem[e] = fmaxb[row]; }
-        }
-    };
-    auto commit = [&](int b) {
-#pragma unroll
-        for (int e = 0; e < FB_EPT; e++) {
-            const int idx = t + e * NT; const int kk = idx / S, j = idx - kk * S; const int k = b * BLK + kk;
-            if (kk < BLK && k < len) ebuf[((size_t)(b % FB_NBUF) * BLK + kk) * SPAD + j] = exp(pre[e] - prem[e]);
-        }
-    };
-    issue(0); commit(0);
-    if (nblk > 1) { issue(1); commit(1); }
-    if (nblk > 2) issue(2);
+    const int elems = BLK * SP / 2;                       // 16-byte elements per block
+    const int wave_base = (t >> 6) << 6;
+#define FB_ISSUE(b_)                                                                                                   \
+    {                                                                                                                  \
+        const int slot_ = (b_) % FB_NBUF;                                                                              \
+        const int rs_ = dir == 0 ? n0 + (b_) * BLK : n1 - (b_) * BLK - (BLK - 1);                                      \
+        for (int i0 = 0; i0 < elems; i0 += NT) {                                                                       \
+            const int idx = i0 + t;                                                                                    \
+            const int row_ = rs_ + (idx * 2) / SP;                                                                     \
+            const unsigned dst_ = __builtin_amdgcn_readfirstlane(lds_addr(ebuf + (size_t)slot_ * BLK * SP + (size_t)(i0 + wave_base) * 2)); \
+            if (idx < elems && row_ >= n0 && row_ <= n1) glds16(febase + (size_t)rs_ * SP + (size_t)idx * 2, dst_);   \
+        }                                                                                                              \
+        if (t < 64) {                                                                                                  \
+            const int tn_ = (dir == 0 ? n0 + (b_) * BLK - 1 : n1 - (b_) * BLK - (BLK - 1)) + t;                        \
+            const unsigned d0_ = __builtin_amdgcn_readfirstlane(lds_addr(meta + (slot_ * 2 + 0) * 64));                 \
+            const unsigned d1_ = __builtin_amdgcn_readfirstlane(lds_addr(meta + (slot_ * 2 + 1) * 64));                 \
+            if (t < BLK && tn_ >= n0 && tn_ < n1) { glds4(a.tclass + tn_, d0_); glds4(a.brk_slot + tn_, d1_); }        \
+        }                                                                                                              \
+    }
 
-    // ---- register-stationary weights ------------------------------------------------
-    double w[RPT > 0 ? RPT : 1];
-    int cur_tc = -1;
-    auto load_w = [&](int tc) {
-        if constexpr (RPT > 0) {
-            const double *Wt = Wmat + (size_t)tc * S * S;
-#pragma unroll
-            for (int rr = 0; rr < RPT; rr++) { const int q = p * RPT + rr; w[rr] = (act && q < S) ? Wt[(size_t)q * S + o] : 0.; }
-        }
-        cur_tc = tc;
-    };
-    __syncthreads();
+    FB_ISSUE(0)
+    if (nblk > 1) FB_ISSUE(1)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (nblk > 2) FB_ISSUE(2)
+    FB_BARRIER();
 
     // ---- step 0 --------------------------------------------------------------------
+    const int rstep = dir == 0 ? SP : -SP;                       // row stride of one step, in doubles
+    double *outp = outb + (size_t)ROW(0) * SP + o;                // this lane's output element of the current row
+    double *mptr = mrow + ROW(0);
+    const int npw = (S + 63) >> 6;                                // waves that take part in phase 2
     {
-        const double e0 = act ? ebuf[o] : 0.;
-        if (act && p == 0) { vec[o] = e0; outb[(size_t)ROW(0) * d.SP + o] = (dir == 0) ? e0 : 1.0; }
-        double wm = (act && p == 0) ? e0 : 0.;
-        wm = group_max(wm, 64);
-        if ((t & 63) == 0) red[t >> 6] = wm;
+        double e0 = 0.;
+        if (post) { e0 = ebuf[(size_t)(dir == 0 ? 0 : BLK - 1) * SP + o]; vec[o] = e0; gstore8(outp, (dir == 0) ? e0 : 1.0); }
+        if ((t >> 6) < npw) {   // wave-uniform: the cross-lane maximum needs every lane of the wave
+            const double wm = wave_max_nonneg(e0);
+            if ((t & 63) == 0) lds_max_u64(&red64[0], (unsigned long long)__double_as_longlong(wm));
+        }
     }
-    __syncthreads();
+    FB_BARRIER();
 
+    // incremental step bookkeeping (no integer division in the loop)
+    int b = 0, kk = 0, slot = 0;          // block of step k, position inside it, ring slot b % FB_NBUF
+    int cur = 0, nxt = 1;                 // vec double buffer
+    int rc = 0;                           // red64 slot written during step k-1
+    if (a.dbg && t == 0 && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0) { a.dbg[0] = clock64(); a.dbg[1] = wall_clock64(); a.dbg[4] = len; }
+#ifdef RMX_FB_STAMPS
+    unsigned long long stamp_acc[6] = {0, 0, 0, 0, 0, 0}, stamp_last;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_last) :: "memory");
+#endif
     for (int k = 1; k < len; k++) {
-        const int cur = (k - 1) & 1, nxt = k & 1;
-        const int row = ROW(k);
-        const int tn = (dir == 0) ? row - 1 : row;   // transition (tn, tn+1)
-        double m = red[cur * 16];
-        for (int i = 1; i < nw; i++) { const double v = red[cur * 16 + i]; m = v > m ? v : m; }
-        const double inv = 1.0 / m;
-        if (dir == 0 && t == 0) mrow[ROW(k - 1)] = m;
+        FB_STAMP(0)
+        if (++kk == BLK) { kk = 0; b++; slot = slot + 1 == FB_NBUF ? 0 : slot + 1; }
+        const int kidx = dir == 0 ? kk : BLK - 1 - kk;            // position of the step inside its span
         const double *vc = vec + cur * SPAD;
-        const int bs = d.brk_slot[tn];
-        const int tc = d.tclass[tn];
+        const int bs = meta[(slot * 2 + 1) * 64 + kidx];
+        // operands of phase 2 that are already final: fetched now, their latency (and the reciprocal)
+        // hides under phase 1
+        const int rn = rc + 1 == 3 ? 0 : rc + 1, rz = rn + 1 == 3 ? 0 : rn + 1;
+        double inv = 0., e = 0.;
+        if ((t >> 6) < npw) {
+            const double m = __longlong_as_double((long long)red64[rc]);
+            if (post) e = ebuf[((size_t)slot * BLK + kidx) * SP + o];
+            inv = fast_rcp(m);
+            if (t == 0) { if (dir == 0) gstore8(mptr, m); red64[rz] = 0ull; }
+        }
+        FB_STAMP(1)
+        // ============================ phase 1: partial products ============================
         double acc = 0.;
         if (bs < 0) {
             if constexpr (RPT > 0) {
-                if (tc != cur_tc) load_w(tc);
+                // 8 rows (4 LDS reads) per stage, software-pipelined one stage ahead; two accumulators
+                // halve the dependent-FMA chain.  sched_barrier pins the stage order so the staged
+                // vector values never occupy more than two stages of registers.
+                double acc2 = 0.;
+                const double *vp = vc + p * RPT;
+                constexpr int NST = (RPT + 7) / 8;
+                double2 st[2][4];
 #pragma unroll
-                for (int rr = 0; rr < RPT; rr += 2) {
-                    const double2 v2 = *reinterpret_cast<const double2 *>(vc + p * RPT + rr);
-                    acc = fma(v2.x, w[rr], acc);
-                    acc = fma(v2.y, w[rr + 1], acc);
+                for (int u = 0; u < 4; u++) if (2 * u < RPT) st[0][u] = *reinterpret_cast<const double2 *>(vp + 2 * u);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int c = 0; c < NST; c++) {
+                    const int c0 = c * 8, n0_ = c0 + 8;
+                    if (c + 1 < NST) {
+#pragma unroll
+                        for (int u = 0; u < 4; u++) if (n0_ + 2 * u < RPT) st[(c + 1) & 1][u] = *reinterpret_cast<const double2 *>(vp + n0_ + 2 * u);
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; u++) if (c0 + 2 * u < RPT) { acc = fma(st[c & 1][u].x, w[c0 + 2 * u], acc); acc2 = fma(st[c & 1][u].y, w[c0 + 2 * u + 1], acc2); }
+                    __builtin_amdgcn_sched_barrier(0);
                 }
+                acc += acc2;
             } else {
-                const double *Wt = Wmat + (size_t)tc * S * S;
+                const double *Wt = Wmat + (size_t)meta[(slot * 2 + 0) * 64 + kidx] * S * S;
                 if (act) for (int rr = 0; rr < QPT; rr++) { const int q = p * QPT + rr; if (q < S) acc = fma(vc[q], Wt[(size_t)q * S + o], acc); }
             }
         } else {
-            // breakend adjacency: exp of the expected transition cost under q(brk)
-            const double *pdg = d.pd_lt + ((size_t)r * d.NBE + bs) * M * D;
-            for (int i = t; i < M * D; i += NT) pdl[i] = pdg[i];
-            __syncthreads();
-            const int ca = d.seg_class[tn], cb = d.seg_class[tn + 1];
-            const int8_t *at = amat + (size_t)tc * S * S;
-            if (act) for (int rr = 0; rr < QPT; rr++) {
-                const int q = p * QPT + rr;
-                if (q < S) {
-                    const int si = dir == 0 ? q : o, sj = dir == 0 ? o : q;
-                    double T = 0.;
-                    for (int c = 0; c < M; c++) {
-                        const int dd = (int)totl[((size_t)ca * S + si) * M + c] - (int)totl[((size_t)cb * S + sj) * M + c];
-                        T += -pen * pdl[c * D + dd + d.cn_max + 1];
+            // ---- breakend adjacency: W[i][j] = prod_m exp(-pen*pd_m[d_m(i,j)]) * exp(-pen*a(i,j)) ----
+            const int tc = meta[(slot * 2 + 0) * 64 + kidx];
+            if (t < 64) {
+                const unsigned dpe = __builtin_amdgcn_readfirstlane(lds_addr(pel));
+                if (t * 2 < MDP) glds16(a.pe_lt + ((size_t)r * a.NBE + bs) * MDP + t * 2, dpe);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            FB_BARRIER();
+            int ca, cb;
+            const int8_t *at;
+            if (RPT > 0) { ca = cb = chain_cls_; }                  // fast chains: one state-table class throughout
+            else { ca = a.be_cls[2 * bs]; cb = a.be_cls[2 * bs + 1]; }
+            if (RPT > 0 && a.amat_lds) at = atl;
+            else at = (dir == 0 ? a.af : a.ab) + (size_t)tc * S * S;
+            // fwd: q = from-state (class ca), o = to-state (class cb); bwd: q = to-state (cb), o = from-state (ca)
+            const int8_t *tq = totl + (size_t)(dir == 0 ? ca : cb) * S * M;
+            const int8_t *to = totl + (size_t)(dir == 0 ? cb : ca) * S * M;
+            const int sgn = dir == 0 ? 1 : -1;
+            if (act) {
+                int to_m[RMX_MAX_CLONES];
+#pragma unroll
+                for (int c = 0; c < RMX_MAX_CLONES; c++) to_m[c] = c < M ? (int)to[(size_t)o * M + c] : 0;
+                for (int rr = 0; rr < QPT; rr++) {
+                    const int q = p * QPT + rr;
+                    if (q < S) {
+                        double wv = wa[(int)at[(size_t)q * S + o]];
+#pragma unroll
+                        for (int c = 0; c < RMX_MAX_CLONES; c++)
+                            if (c < M) { const int dd = sgn * ((int)tq[(size_t)q * M + c] - to_m[c]); wv *= pel[c * D + dd + a.cn_max + 1]; }
+                        acc = fma(vc[q], wv, acc);
                     }
-                    T += -pen * (double)at[(size_t)q * S + o];
-                    acc = fma(vc[q], exp(T), acc);
                 }
             }
         }
-        for (int off = 1; off < PP; off <<= 1) acc += __shfl_xor(acc, off, 64);
-        const double val = acc * inv;
-        const int b = k / BLK, kk = k - b * BLK;
-        const double e = act ? ebuf[((size_t)(b % FB_NBUF) * BLK + kk) * SPAD + o] : 0.;
-        const double outv = (dir == 0) ? val * e : val;
-        const double vecv = val * e;
-        if (act && p == 0) { vec[nxt * SPAD + o] = vecv; outb[(size_t)row * d.SP + o] = outv; }
-        double wm = (act && p == 0) ? vecv : 0.;
-        if (wm != wm) wm = INFINITY;   // propagate a NaN as a detectable value
-        wm = group_max(wm, 64);
-        if ((t & 63) == 0) red[nxt * 16 + (t >> 6)] = wm;
-        if (kk == 0) {   // block boundary: land block b+1, request block b+2
-            if (b + 1 < nblk && b >= 1) commit(b + 1);
-            if (b + 2 < nblk && b >= 1) issue(b + 2);
+        FB_STAMP(2)
+        if (act) part[(size_t)p * SP + o] = acc;
+        FB_BARRIER();
+        FB_STAMP(3)
+        // ============================ phase 2: combine, scale, publish =======================
+        outp += rstep;
+        if ((t >> 6) < npw) {   // wave-uniform
+            double vecv = 0.;
+            if (post) {
+                // the first four partials are requested together (one LDS round trip, not four)
+                const double s0 = part[o];
+                const double s1 = PP > 1 ? part[(size_t)SP + o] : 0.;
+                const double s2 = PP > 2 ? part[(size_t)2 * SP + o] : 0.;
+                const double s3 = PP > 3 ? part[(size_t)3 * SP + o] : 0.;
+                double sum = ((s0 + s1) + s2) + s3;
+                for (int pp = 4; pp < PP; pp++) sum += part[(size_t)pp * SP + o];
+                const double val = sum * inv;
+                vecv = val * e;
+                vec[nxt * SPAD + o] = vecv;
+                gstore8(outp, (dir == 0) ? vecv : val);
+                if (vecv != vecv) vecv = INFINITY;   // propagate a NaN as a detectable value
+            }
+            const double wm = wave_max_nonneg(vecv);
+            if ((t & 63) == 0) lds_max_u64(&red64[rn], (unsigned long long)__double_as_longlong(wm));
         }
-        __syncthreads();
+        mptr += (dir == 0 ? 1 : -1);
+        if (kk == 0 && b >= 1) {
+            // block boundary: block b+1 (requested one block ago) must have landed before its first
+            // reader, BLK barriers from now; then request block b+2 into the slot block b-1 vacated
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (b + 2 < nblk) FB_ISSUE(b + 2)
+        }
+        cur ^= 1; nxt ^= 1; rc = rn;
+        FB_STAMP(4)
+        FB_BARRIER();
+        FB_STAMP(5)
     }
-    if (dir == 0 && t == 0) {
+#ifdef RMX_FB_STAMPS
+    if (a.dbg && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && (t == 0 || t == NT - 64)) for (int i = 0; i < 6; i++) a.dbg[8 + (t == 0 ? 0 : 6) + i] = stamp_acc[i];
+#endif
+    if (a.dbg && t == 0 && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0) { a.dbg[2] = clock64(); a.dbg[3] = wall_clock64(); }
+    if (t == 0) {
         // last row of the chain: its own maximum is not consumed by a later step
-        double m = red[((len - 1) & 1) * 16];
-        for (int i = 1; i < nw; i++) { const double v = red[((len - 1) & 1) * 16 + i]; m = v > m ? v : m; }
-        mrow[ROW(len - 1)] = m;
-        if (!(m > 0.) || m == INFINITY) atomicOr(&d.err[r], RMX_ERR_NAN_AB);
-    }
-    if (dir == 1 && t == 0) {
-        double m = red[((len - 1) & 1) * 16];
-        for (int i = 1; i < nw; i++) { const double v = red[((len - 1) & 1) * 16 + i]; m = v > m ? v : m; }
-        if (!(m > 0.) || m == INFINITY) atomicOr(&d.err[r], RMX_ERR_NAN_AB);
+        const double m = __longlong_as_double((long long)red64[rc]);
+        if (dir == 0) gstore8(mptr, m);
+        if (!(m > 0.) || m == INFINITY) atomicOr(&a.err[r], RMX_ERR_NAN_AB);
     }
 #undef ROW
+#undef FB_ISSUE
 }
 
 // =============================================================================
@@ -392,7 +554,7 @@ __global__ void k_update_allele_swap(Dev d, int r0) {     // bpmodel.pyx:1025-10
 // two outermost slots d = +-(cn_max+1) (buffer of length 2(cn_max+1), :600).
 // grid (NBE, nr), block 64 (>= M*D threads looped)
 // =============================================================================
-__global__ void k_brk_lut(Dev d, int r0, double *dst_base) {
+__global__ void k_brk_lut(Dev d, int r0, double *dst_base, double *exp_base) {
     const int slot = blockIdx.x, r = r0 + blockIdx.y;
     const int n = d.be_n[slot], k = d.brk_idx[n], orient = d.brk_orient[n];
     const double *pb = d.pbrk + ((size_t)r * d.K + k) * d.B;
@@ -409,6 +571,7 @@ __global__ void k_brk_lut(Dev d, int r0, double *dst_base) {
             for (int b = 0; b < d.B; b++) acc += pb[b] * g_transition(d.tmodel, dv - orient * d.brk_states[b * d.M + m]);
         }
         dst[i] = acc;
+        if (exp_base) exp_base[((size_t)r * d.NBE + slot) * ((d.M * d.D + 1) & ~1) + i] = exp(-d.pen * acc);
     }
 }
 
@@ -453,9 +616,8 @@ __global__ void k_pairwise(Dev d, int r0, int mode, const int32_t *list, double 
     const int ca = d.seg_class[n], cb = d.seg_class[n + 1];
     const double *fa = d.fa + rs_off(d, r, n);
     if (mode == 0) {
-        const double *fb = d.fb + rs_off(d, r, n + 1), *fr = d.f + rs_off(d, r, n + 1);
-        const double fm = d.fmax[(size_t)r * d.N + n + 1];
-        for (int j = t; j < S; j += 256) gvec[j] = exp(fr[j] - fm) * fb[j];
+        const double *fb = d.fb + rs_off(d, r, n + 1), *fe = d.fe + rs_off(d, r, n + 1);
+        for (int j = t; j < S; j += 256) gvec[j] = fe[j] * fb[j];
     }
     __syncthreads();
     double z = 0., jt = 0., ja = 0.;
@@ -628,9 +790,18 @@ __global__ void k_elbo_final(Dev d, int r0, const double *partial, int nblk, con
 template <bool GRAD>
 __global__ void k_ell_list(Dev d, int r, const int32_t *list, double *partial) {
     __shared__ double scratch[8];
+    __shared__ double segk[8];
     const int n = list[blockIdx.x];
     const RestartParams &rp = d.rp[r];
-    SegCtx sc; load_seg(d, r, n, sc);
+    SegCtx sc;
+    sc.x = d.x[n]; sc.l = d.l[n]; sc.logl = d.logl[n]; sc.y0 = d.y[2 * (size_t)n]; sc.y1 = d.y[2 * (size_t)n + 1]; sc.ys = sc.y0 + sc.y1;
+    sc.mt = d.mask_t[n]; sc.ma = d.mask_a[n];
+    // the per-segment constants depend on the parameters being optimised: evaluate them here
+    // for this block's segment only (the full [R][8][N] table is rebuilt lazily, not per evaluation)
+    if (threadIdx.x < 8) segk[threadIdx.x] = seg_const_value(rp, sc.x, sc.y0, sc.ys, threadIdx.x);
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; i++) { sc.cnb[i] = segk[i]; sc.cbb[i] = segk[4 + i]; }
     const int cls = d.seg_class[n];
     const size_t rn = (size_t)r * d.N + n;
     const double qt0 = d.qt[rn * 2], qt1 = d.qt[rn * 2 + 1], qa0 = d.qa[rn * 2], qa1 = d.qa[rn * 2 + 1];
@@ -899,12 +1070,11 @@ __global__ void k_materialize_joint(Dev d, int r, int uniform, double *out) {
     if (uniform) { for (int idx = t; idx < S * S; idx += 256) o[idx] = 1.0 / (double)((size_t)S * S); return; }
     const int bs = d.brk_slot[n];
     const double *pd = (bs >= 0) ? d.pd_lt + ((size_t)r * d.NBE + bs) * d.M * d.D : nullptr;
-    const double *fa = d.fa + rs_off(d, r, n), *fb = d.fb + rs_off(d, r, n + 1), *fr = d.f + rs_off(d, r, n + 1);
-    const double fm = d.fmax[(size_t)r * d.N + n + 1];
+    const double *fa = d.fa + rs_off(d, r, n), *fb = d.fb + rs_off(d, r, n + 1), *fe = d.fe + rs_off(d, r, n + 1);
     double z = 0.;
     for (int idx = t; idx < S * S; idx += 256) {
         const int i = idx / S, j = idx - i * S;
-        const double J = fa[i] * exp(trans_value(d, n, i, j, pd)) * (exp(fr[j] - fm) * fb[j]);
+        const double J = fa[i] * exp(trans_value(d, n, i, j, pd)) * (fe[j] * fb[j]);
         o[idx] = J; z += J;
     }
     z = block_sum<256>(z, scratch);

@@ -18,8 +18,10 @@ class RestartSet(object):
     """R restarts of one experiment advancing in lockstep on one device."""
 
     def __init__(self, experiment, init_params, max_copy_number, num_clones=3, device=0, quiet=True,
-                 kernel_module=None, seeds=None, **model_kwargs):
+                 kernel_module=None, seeds=None, strict=False, **model_kwargs):
         self.experiment = experiment
+        self.strict = strict
+        self.error_messages = {}
         self.init_params = list(init_params)
         R = len(self.init_params)
         if R == 0:
@@ -76,9 +78,19 @@ class RestartSet(object):
         """cn_model.py:409-428 for every restart: batched variational sweeps, per-restart
         scipy M-steps, batched ELBO."""
         self.variational_update(num_update_iter)
-        for m in self.models:
+        for r, m in enumerate(self.models):
             if m.do_h_update:
-                m.em_update_h()
+                h_before = np.array(m.model.h, dtype=float)
+                try:
+                    m.em_update_h()
+                except ValueError as err:
+                    # the reference lets a failed L-BFGS-B run kill the whole restart job
+                    # (cn_model.py:510-521); here the restart keeps its previous h and the
+                    # message is reported in stats['error_message']
+                    if self.strict:
+                        raise
+                    m.model.h = h_before
+                    self.error_messages[r] = str(err).splitlines()[0] + ' (h kept)'
             m.em_update_params()
         elbo = self.calculate_elbo()
         for m, e in zip(self.models, elbo):
@@ -97,8 +109,10 @@ class RestartSet(object):
     def results(self):
         """Per-restart result dicts with the keys of analysis/pipeline.py:198-226."""
         out = []
-        for m, p in zip(self.models, self.init_params):
-            out.append(collect_fit_results(m, self.experiment, p))
+        for r, (m, p) in enumerate(zip(self.models, self.init_params)):
+            res = collect_fit_results(m, self.experiment, p)
+            res['stats']['error_message'] = self.error_messages.get(r, '')
+            out.append(res)
         return out
 
 

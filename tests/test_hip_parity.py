@@ -147,3 +147,40 @@ def test_batch_equals_single(hip):
             m.variational_update()
         assert np.isclose(mm.calculate_elbo(), elbo_b[r], rtol=1e-12), (r, mm.calculate_elbo(), elbo_b[r])
         assert np.allclose(mm.posterior_marginals, rs.batch.get_array(r, 'posterior_marginals'), rtol=1e-12, atol=1e-300)
+
+
+def test_s165_matches_oracle(hip, oracle_mod):
+    """BASELINE state grid (3 clones, max_cn=8 -> 165 states): register-stationary FB path vs oracle."""
+    a, h, _ = H.make_model(hip, N=96, M=3, max_cn=8, chains=3, seed=7)
+    b, _, _ = H.make_model(oracle_mod, N=96, M=3, max_cn=8, chains=3, seed=7)
+    ma, mb = H.attach(a, h), H.attach(b, h)
+    assert ma.num_cn_states == 165
+    for it in range(2):
+        a.variational_update(); b.variational_update()
+        H.compare_models(ma, mb, tag='sweep%d' % it)
+        assert np.isclose(ma.calculate_elbo(), mb.calculate_elbo(), rtol=1e-9)
+        assert np.isclose(ma.hmm_log_norm_const, mb.hmm_log_norm_const, rtol=1e-10)
+    cna = np.zeros((ma.num_segments, 3, 2), dtype=int); cnb = cna.copy()
+    ma.infer_cn(cna); mb.infer_cn(cnb)
+    assert np.array_equal(cna, cnb)
+
+
+def test_fb_register_and_generic_paths_agree(hip):
+    """Long chains (prefetch ring wraps many times): the register-stationary kernel and the generic
+    kernel (RMX_FB_GENERIC=1) must produce the same posteriors; repeated runs are bit-identical."""
+    import os
+    outs = []
+    for generic in (False, True, False):
+        if generic:
+            os.environ['RMX_FB_GENERIC'] = '1'
+        else:
+            os.environ.pop('RMX_FB_GENERIC', None)
+        m, h, _ = H.make_model(hip, N=6000, M=3, max_cn=8, chains=5, seed=3)
+        mm = H.attach(m, h)
+        m.variational_update(); m.variational_update()
+        outs.append((mm.posterior_marginals, mm.hmm_log_norm_const, mm.calculate_elbo(), mm.p_breakpoint))
+    os.environ.pop('RMX_FB_GENERIC', None)
+    assert np.allclose(outs[0][0], outs[1][0], rtol=1e-9, atol=1e-13)
+    assert np.isclose(outs[0][1], outs[1][1], rtol=1e-12) and np.isclose(outs[0][2], outs[1][2], rtol=1e-12)
+    assert np.array_equal(outs[0][0], outs[2][0]) and outs[0][1] == outs[2][1] and outs[0][2] == outs[2][2]
+    assert np.array_equal(outs[0][3], outs[2][3])
