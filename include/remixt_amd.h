@@ -150,6 +150,14 @@ int rmx_calculate_variational_entropy(rmx_batch *b, int32_t r0, int32_t r1, doub
  * NULL; when given it receives [M] (:1159-1195). */
 int rmx_expected_log_likelihood(rmx_batch *b, int32_t r, const int64_t *sample, double *ell_out,
                                 double *partial_h_out);
+/* The M-steps of BreakpointModel (cn_model.py:482-569) evaluate the objective hundreds of times on
+ * one fixed sample: rmx_set_sample uploads the mask once; rmx_expected_log_likelihood with
+ * sample == NULL then re-uses it. */
+int rmx_set_sample(rmx_batch *b, int32_t r, const int64_t *sample);
+/* E[ll] on the current sample for G values of one likelihood parameter (the grid stage of
+ * scipy.optimize.brute, cn_model.py:553-558) with one host round trip; G <= 64.  Leaves the
+ * parameter at values[G-1], as G sequential evaluations would. */
+int rmx_expected_ll_param_grid(rmx_batch *b, int32_t r, int32_t param_id, const double *values, int32_t G, double *out);
 /* per-cell values, for tests (:751-776, :809-853): u/v/w in {0,1} */
 int rmx_log_likelihood_total(rmx_batch *b, int32_t r, int32_t n, int32_t s, int32_t u, double *out);
 int rmx_log_likelihood_allele(rmx_batch *b, int32_t r, int32_t n, int32_t s, int32_t v, int32_t w, double *out);

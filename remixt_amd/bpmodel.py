@@ -152,6 +152,7 @@ class RemixtBatch(object):
         self.l = l; self.x = x; self.y = y
         self.cn_max = self.info(0)
         self._transition_model = 0
+        self._samples = {}
 
     # -- lifetime ------------------------------------------------------------
     def close(self):
@@ -278,16 +279,39 @@ class RemixtBatch(object):
     def calculate_variational_entropy(self, r0=None, r1=None):
         return self._scalar_range(self._lib.rmx_calculate_variational_entropy, r0, r1)
 
-    def expected_log_likelihood(self, r, sample, want_grad=False):
-        sample = _i64(sample)
-        if sample.shape != (self.num_segments,):
+    def _use_sample(self, r, sample):
+        """Upload the sample mask unless it is the very array object last uploaded for this restart
+        (the M-steps evaluate hundreds of times on one mask they never modify).  A caller that
+        mutates a mask in place must pass a new array (or call invalidate_sample)."""
+        if self._samples.get(r) is sample:
+            return
+        s64 = _i64(sample)
+        if s64.shape != (self.num_segments,):
             raise ValueError('sample must have length num_segments')
+        self._ck(self._lib.rmx_set_sample(self._handle, r, s64.ctypes.data_as(_ip)))
+        self._samples[r] = sample
+
+    def invalidate_sample(self, r=None):
+        if r is None:
+            self._samples.clear()
+        else:
+            self._samples.pop(r, None)
+
+    def expected_log_likelihood(self, r, sample, want_grad=False):
+        self._use_sample(r, sample)
         ell = C.c_double(0.)
         grad = np.zeros(self.num_clones, dtype=np.float64) if want_grad else None
         self._ck(self._lib.rmx_expected_log_likelihood(
-            self._handle, r, sample.ctypes.data_as(_ip), C.byref(ell),
-            grad.ctypes.data_as(_dp) if want_grad else None))
+            self._handle, r, None, C.byref(ell), grad.ctypes.data_as(_dp) if want_grad else None))
         return float(ell.value), grad
+
+    def expected_log_likelihood_param_grid(self, r, name, values, sample):
+        self._use_sample(r, sample)
+        v = _f64(values).ravel()
+        out = np.zeros(len(v), dtype=np.float64)
+        self._ck(self._lib.rmx_expected_ll_param_grid(self._handle, r, PARAM_IDS[name], v.ctypes.data_as(_dp), len(v),
+                                                      out.ctypes.data_as(_dp)))
+        return out
 
     def infer_cn(self, r):
         cn = np.zeros((self.num_segments, self.num_clones, 2), dtype=np.int64)
@@ -443,6 +467,10 @@ class RemixtModel(object):
 
     def calculate_expected_log_likelihood(self, sample):
         return self._batch.expected_log_likelihood(self._r, sample)[0]
+
+    def calculate_expected_log_likelihood_param_grid(self, name, values, sample):
+        """E[ll] for each value of the likelihood parameter `name` (left at values[-1]), one round trip."""
+        return self._batch.expected_log_likelihood_param_grid(self._r, name, values, sample)
 
     def calculate_expected_log_likelihood_partial_h(self, sample, partial_h):
         _, g = self._batch.expected_log_likelihood(self._r, sample, want_grad=True)

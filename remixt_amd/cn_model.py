@@ -462,9 +462,7 @@ class BreakpointModel(object):
         ell_before = model.calculate_expected_log_likelihood(self._all_segments())
         sample = self._create_sample(weights)
 
-        result = scipy.optimize.brute(nll, ranges=[bounds], full_output=True)
-        assert result[0].shape == (1,)
-        result_value = float(result[0][0])
+        result_value = self._brute_1d(nll, name, bounds, sample)
 
         # quirk kept: the acceptance test looks at the LAST value scipy evaluated, not at the optimum
         ell_after = model.calculate_expected_log_likelihood(self._all_segments())
@@ -473,6 +471,24 @@ class BreakpointModel(object):
             setattr(model, name, value_before)
         else:
             setattr(model, name, result_value)
+
+    def _brute_1d(self, nll, name, bounds, sample, Ns=20):
+        """scipy.optimize.brute(nll, ranges=[bounds], full_output=True)[0] for one parameter, as the
+        reference calls it (cn_model.py:553-561): a 20-point inclusive grid, argmin, then a
+        scipy.optimize.fmin polish started at the best grid point.  Same evaluation sequence as
+        scipy's own brute; the only difference is that a kernel offering
+        calculate_expected_log_likelihood_param_grid evaluates the grid in one device round trip."""
+        grid = np.mgrid[bounds[0]:bounds[1]:complex(Ns)]
+        grid_eval = getattr(self.model, 'calculate_expected_log_likelihood_param_grid', None)
+        if grid_eval is not None:
+            Jout = -np.asarray(grid_eval(name, grid, sample))
+        else:
+            Jout = np.array([nll(np.asarray(x).flatten()) for x in grid])
+        xmin = grid[int(np.argmin(Jout.ravel()))]
+        res = scipy.optimize.fmin(nll, xmin, args=(), full_output=1, disp=False)
+        value = np.asarray(res[0])
+        assert value.shape == (1,)
+        return float(value[0])
 
     # ------------------------------------------------------------------------------
     def optimal_cn(self):

@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstring>
 #include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -59,8 +60,9 @@ struct rmx_batch {
     double *d_ell_partial = nullptr;   // [max(N,ELBO_BLOCKS)][1+MAXC]
     double *d_ell_out = nullptr;       // [1+MAXC]
     double *h_pinned = nullptr;        // pinned staging [max(4R, 16)]
-    int32_t *d_sample = nullptr;       // [N]
-    std::vector<int64_t> sample_cache; int sample_count = -1;
+    int32_t *d_sample = nullptr;       // [R][N] index lists of the current M-step samples
+    std::vector<std::vector<int64_t>> sample_cache; std::vector<int> sample_count;
+    double *d_grid_out = nullptr;      // [64][1+MAXC]
     std::vector<int32_t> plain_list; int32_t *d_plain_list = nullptr; double *d_plain_jt = nullptr;
     // viterbi
     uint16_t *d_bp = nullptr; double *d_final = nullptr; int64_t *d_path = nullptr; double *d_logprob = nullptr;
@@ -80,6 +82,8 @@ struct rmx_batch {
     double prof_ms[KID_COUNT] = {0};
     long long prof_n[KID_COUNT] = {0};
     hipEvent_t tm_a = nullptr, tm_b = nullptr;
+    std::vector<hipEvent_t> done_ev;   // [R] completion marker of a restart's last queued read-back
+    std::mutex mu;                     // guards the profiling lists and launch sequences of concurrent callers
 };
 
 template <typename T> static int dalloc(rmx_batch *b, T **p, size_t count) {
@@ -116,38 +120,49 @@ static void prof_collect(rmx_batch *b) {
 }
 struct ProfScope {
     rmx_batch *b; int id; hipEvent_t a{}, e{};
+    // callers hold b->mu (see LOCK()) whenever profiling may be on
     ProfScope(rmx_batch *b_, int id_) : b(b_), id(id_) {
         if (b->prof) { a = get_event(b); e = get_event(b); hipEventRecord(a, b->stream); }
     }
     ~ProfScope() {
-        if (b->prof) { hipEventRecord(e, b->stream); b->prof_pending.push_back({id, a, e}); if (b->prof_pending.size() > 4096) prof_collect(b); }
+        if (b->prof) { hipEventRecord(e, b->stream); b->prof_pending.push_back({id, a, e}); if (b->prof_pending.size() > 8192) prof_collect(b); }
     }
 };
 
 // ---- error translation -------------------------------------------------------
+static int translate_error(rmx_batch *b, int r, uint32_t v);
 static int check_errors(rmx_batch *b, int r0, int r1) {
     std::vector<uint32_t> e(b->R);
     HIPCHK(hipMemcpyAsync(e.data(), b->d.err, sizeof(uint32_t) * b->R, hipMemcpyDeviceToHost, b->stream));
     HIPCHK(hipStreamSynchronize(b->stream));
     for (int r = r0; r < r1; r++) {
         if (!e[r]) continue;
-        uint32_t v = e[r];
         HIPCHK(hipMemsetAsync(b->d.err + r, 0, sizeof(uint32_t), b->stream));
-        char buf[160];
-        if (v & RMX_ERR_NAN_LL) { snprintf(buf, sizeof buf, "ll is nan (restart %d)", r); return fail(RMX_EVALUE, buf); }
-        if (v & RMX_ERR_TOTAL_DEPTH) { snprintf(buf, sizeof buf, "total_depth <= 0 (restart %d)", r); return fail(RMX_EVALUE, buf); }
-        if (v & RMX_ERR_LOH_P) { snprintf(buf, sizeof buf, "expected p 0 or 1 for loh state (restart %d)", r); return fail(RMX_EVALUE, buf); }
-        if (v & RMX_ERR_BAD_P) { snprintf(buf, sizeof buf, "p <= 0 or (1 - p) <= 0. (restart %d)", r); return fail(RMX_EVALUE, buf); }
-        if (v & RMX_ERR_DIGAMMA) { snprintf(buf, sizeof buf, "x <= 0.0 in digamma (restart %d)", r); return fail(RMX_EVALUE, buf); }
-        if (v & RMX_ERR_NAN_GRAD) { snprintf(buf, sizeof buf, "partial derivative is nan (restart %d)", r); return fail(RMX_EVALUE, buf); }
-        if (v & RMX_ERR_NAN_F) { snprintf(buf, sizeof buf, "nan in framelogprob (restart %d)", r); return fail(RMX_EASSERT, buf); }
-        if (v & RMX_ERR_NAN_AB) { snprintf(buf, sizeof buf, "nan in alphas/betas (restart %d)", r); return fail(RMX_EASSERT, buf); }
-        if (v & RMX_ERR_NAN_POST) { snprintf(buf, sizeof buf, "nan in posterior marginals (restart %d)", r); return fail(RMX_EASSERT, buf); }
-        snprintf(buf, sizeof buf, "device error bits 0x%x (restart %d)", v, r); return fail(RMX_EVALUE, buf);
+        return translate_error(b, r, e[r]);
     }
     return RMX_OK;
 }
+static int translate_error(rmx_batch *b, int r, uint32_t v) {
+    char buf[160];
+    if (v & RMX_ERR_NAN_LL) { snprintf(buf, sizeof buf, "ll is nan (restart %d)", r); return fail(RMX_EVALUE, buf); }
+    if (v & RMX_ERR_TOTAL_DEPTH) { snprintf(buf, sizeof buf, "total_depth <= 0 (restart %d)", r); return fail(RMX_EVALUE, buf); }
+    if (v & RMX_ERR_LOH_P) { snprintf(buf, sizeof buf, "expected p 0 or 1 for loh state (restart %d)", r); return fail(RMX_EVALUE, buf); }
+    if (v & RMX_ERR_BAD_P) { snprintf(buf, sizeof buf, "p <= 0 or (1 - p) <= 0. (restart %d)", r); return fail(RMX_EVALUE, buf); }
+    if (v & RMX_ERR_DIGAMMA) { snprintf(buf, sizeof buf, "x <= 0.0 in digamma (restart %d)", r); return fail(RMX_EVALUE, buf); }
+    if (v & RMX_ERR_NAN_GRAD) { snprintf(buf, sizeof buf, "partial derivative is nan (restart %d)", r); return fail(RMX_EVALUE, buf); }
+    if (v & RMX_ERR_NAN_F) { snprintf(buf, sizeof buf, "nan in framelogprob (restart %d)", r); return fail(RMX_EASSERT, buf); }
+    if (v & RMX_ERR_NAN_AB) { snprintf(buf, sizeof buf, "nan in alphas/betas (restart %d)", r); return fail(RMX_EASSERT, buf); }
+    if (v & RMX_ERR_NAN_POST) { snprintf(buf, sizeof buf, "nan in posterior marginals (restart %d)", r); return fail(RMX_EASSERT, buf); }
+    snprintf(buf, sizeof buf, "device error bits 0x%x (restart %d)", v, r); return fail(RMX_EVALUE, buf);
+}
 
+// Completion + error check for ONE restart that does not wait for other restarts' queued work:
+// the error word travels with the results and the wait is on the restart's own event.
+static int finish_restart(rmx_batch *b, int r, uint32_t *err_host) {
+    HIPCHK(hipMemcpyAsync(err_host, b->d.err + r, sizeof(uint32_t), hipMemcpyDeviceToHost, b->stream));
+    HIPCHK(hipEventRecord(b->done_ev[r], b->stream));
+    return RMX_OK;
+}
 // ---- transition tables ---------------------------------------------------------
 static inline double g_host(int model, int64_t dd) { return model == 0 ? (double)(dd < 0 ? -dd : dd) : (dd == 0 ? 0. : 1.); }
 
@@ -491,10 +506,12 @@ int rmx_batch_create(const rmx_problem *pr, int32_t R, const double *h_init, con
     DA(err, uint32_t, R)
 #undef DA
     if ((rc = dalloc(b, &b->d_lt_valid, R)) || (rc = dalloc(b, &b->d_partial, (size_t)R * ELBO_BLOCKS * 2)) || (rc = dalloc(b, &b->d_out4, (size_t)R * 4)) ||
-        (rc = dalloc(b, &b->d_ell_partial, (size_t)std::max(N, ELBO_BLOCKS) * (1 + RMX_MAX_CLONES))) || (rc = dalloc(b, &b->d_ell_out, 1 + RMX_MAX_CLONES)) ||
-        (rc = dalloc(b, &b->d_sample, N))) { rmx_batch_destroy(b); return rc; }
-    HIPCHK(hipHostMalloc((void **)&b->h_pinned, sizeof(double) * std::max(4 * R, 64)));
+        (rc = dalloc(b, &b->d_ell_partial, (size_t)R * std::max(N, ELBO_BLOCKS) * (1 + RMX_MAX_CLONES))) || (rc = dalloc(b, &b->d_ell_out, (size_t)R * 8)) ||
+        (rc = dalloc(b, &b->d_sample, (size_t)R * N)) || (rc = dalloc(b, &b->d_grid_out, (size_t)R * 64 * (1 + RMX_MAX_CLONES)))) { rmx_batch_destroy(b); return rc; }
+    HIPCHK(hipHostMalloc((void **)&b->h_pinned, sizeof(double) * (size_t)(R + 1) * 64 * (1 + RMX_MAX_CLONES)));
     HIPCHK(hipEventCreate(&b->tm_a)); HIPCHK(hipEventCreate(&b->tm_b));
+    b->done_ev.resize(R);
+    for (int r = 0; r < R; r++) HIPCHK(hipEventCreateWithFlags(&b->done_ev[r], hipEventDisableTiming));
 
     if ((rc = build_transitions(b))) { rmx_batch_destroy(b); return rc; }
     // envelope of the scaled linear-domain recursion: exp(T) must stay a normal double
@@ -509,6 +526,7 @@ int rmx_batch_create(const rmx_problem *pr, int32_t R, const double *h_init, con
     }
 
     // per-restart initial state (bpmodel.pyx:546-597)
+    b->sample_cache.assign(R, std::vector<int64_t>()); b->sample_count.assign(R, -1);
     b->rp.resize(R); b->tables_dirty.assign(R, 1); b->segc_dirty.assign(R, 1); b->ab_dirty.assign(R, 1); b->lt_valid.assign(R, 0); b->logZ.assign(R, 0.);
     for (int r = 0; r < R; r++) {
         RestartParams &p = b->rp[r];
@@ -572,6 +590,7 @@ int rmx_batch_destroy(rmx_batch *b) {
     for (auto e : b->ev_pool) hipEventDestroy(e);
     if (b->tm_a) hipEventDestroy(b->tm_a);
     if (b->tm_b) hipEventDestroy(b->tm_b);
+    for (auto e : b->done_ev) hipEventDestroy(e);
     if (b->own_stream && b->stream) hipStreamDestroy(b->stream);
     delete b;
     return RMX_OK;
@@ -881,41 +900,102 @@ int rmx_calculate_variational_entropy(rmx_batch *b, int32_t r0, int32_t r1, doub
     return RMX_OK;
 }
 
-int rmx_expected_log_likelihood(rmx_batch *b, int32_t r, const int64_t *sample, double *ell_out, double *partial_h_out) {
-    if (!b || r < 0 || r >= b->R || !sample || !ell_out) return fail(RMX_EARG, "bad argument");
+// mask -> index list on the device, cached per restart across the many evaluations of one M-step
+static int set_sample(rmx_batch *b, int r, const int64_t *sample) {
     const Dev &d = b->d;
-    // mask -> index list, cached across the many evaluations of one M-step
-    if ((int)b->sample_cache.size() != d.N || memcmp(b->sample_cache.data(), sample, (size_t)d.N * 8) != 0) {
-        b->sample_cache.assign(sample, sample + d.N);
-        std::vector<int32_t> idx;
-        idx.reserve(256);
-        for (int n = 0; n < d.N; n++) if (sample[n] != 0) idx.push_back(n);
-        b->sample_count = (int)idx.size();
-        if (!idx.empty()) HIPCHK(hipMemcpyAsync(b->d_sample, idx.data(), idx.size() * 4, hipMemcpyHostToDevice, b->stream));
-        HIPCHK(hipStreamSynchronize(b->stream));
-    }
+    std::vector<int64_t> &cache = b->sample_cache[r];
+    if ((int)cache.size() == d.N && memcmp(cache.data(), sample, (size_t)d.N * 8) == 0) return RMX_OK;
+    cache.assign(sample, sample + d.N);
+    std::vector<int32_t> idx;
+    idx.reserve(256);
+    for (int n = 0; n < d.N; n++) if (sample[n] != 0) idx.push_back(n);
+    b->sample_count[r] = (int)idx.size();
+    if (!idx.empty()) HIPCHK(hipMemcpy(b->d_sample + (size_t)r * d.N, idx.data(), idx.size() * 4, hipMemcpyHostToDevice));
+    return RMX_OK;
+}
+// queue one evaluation of E[ll] (and optionally its h-gradient) on restart r's current sample; the
+// (1+MAXC) results land in `dst` (device)
+static int queue_ell(rmx_batch *b, int r, bool grad, double *dst) {
+    const Dev &d = b->d;
     const int W = 1 + RMX_MAX_CLONES;
-    const int cnt = b->sample_count;
+    const int cnt = b->sample_count[r];
+    double *partial = b->d_ell_partial + (size_t)r * std::max(d.N, ELBO_BLOCKS) * W;
+    const int32_t *list = b->d_sample + (size_t)r * d.N;
     int rc;
-    if (cnt == 0) { *ell_out = 0.; if (partial_h_out) for (int m = 0; m < d.M; m++) partial_h_out[m] = 0.; return RMX_OK; }
-    if (cnt == d.N && !partial_h_out) {
+    if (cnt == d.N && !grad) {
         if ((rc = ensure_ab(b, r, r + 1))) return rc;
-        { ProfScope ps(b, KID_ELL_FULL); hipLaunchKernelGGL(k_ell_full, dim3(ELBO_BLOCKS), dim3(256), 0, b->stream, b->d, r, b->d_ell_partial); }
-        { ProfScope ps(b, KID_ELL_FINAL); hipLaunchKernelGGL(k_ell_final, dim3(1), dim3(256), 0, b->stream, b->d_ell_partial, ELBO_BLOCKS, b->d_ell_out); }
+        { ProfScope ps(b, KID_ELL_FULL); hipLaunchKernelGGL(k_ell_full, dim3(ELBO_BLOCKS), dim3(256), 0, b->stream, b->d, r, partial); }
+        { ProfScope ps(b, KID_ELL_FINAL); hipLaunchKernelGGL(k_ell_final, dim3(1), dim3(256), 0, b->stream, (const double *)partial, ELBO_BLOCKS, dst); }
     } else {
         if ((rc = ensure_tables(b, r, r + 1, false))) return rc;
         {
             ProfScope ps(b, KID_ELL_LIST);
-            if (partial_h_out) hipLaunchKernelGGL(k_ell_list<true>, dim3(cnt), dim3(256), 0, b->stream, b->d, r, (const int32_t *)b->d_sample, b->d_ell_partial);
-            else hipLaunchKernelGGL(k_ell_list<false>, dim3(cnt), dim3(256), 0, b->stream, b->d, r, (const int32_t *)b->d_sample, b->d_ell_partial);
+            if (grad) hipLaunchKernelGGL(k_ell_list<true>, dim3(cnt), dim3(256), 0, b->stream, b->d, r, list, partial);
+            else hipLaunchKernelGGL(k_ell_list<false>, dim3(cnt), dim3(256), 0, b->stream, b->d, r, list, partial);
         }
-        { ProfScope ps(b, KID_ELL_FINAL); hipLaunchKernelGGL(k_ell_final, dim3(1), dim3(256), 0, b->stream, b->d_ell_partial, cnt, b->d_ell_out); }
+        { ProfScope ps(b, KID_ELL_FINAL); hipLaunchKernelGGL(k_ell_final, dim3(1), dim3(256), 0, b->stream, (const double *)partial, cnt, dst); }
     }
     HIPCHK(hipGetLastError());
-    HIPCHK(hipMemcpyAsync(b->h_pinned, b->d_ell_out, W * 8, hipMemcpyDeviceToHost, b->stream));
-    if ((rc = check_errors(b, r, r + 1))) return rc;
-    *ell_out = b->h_pinned[0];
-    if (partial_h_out) for (int m = 0; m < d.M; m++) partial_h_out[m] = b->h_pinned[1 + m];
+    return RMX_OK;
+}
+
+int rmx_set_sample(rmx_batch *b, int32_t r, const int64_t *sample) {
+    if (!b || r < 0 || r >= b->R || !sample) return fail(RMX_EARG, "bad argument");
+    return set_sample(b, r, sample);
+}
+
+int rmx_expected_log_likelihood(rmx_batch *b, int32_t r, const int64_t *sample, double *ell_out, double *partial_h_out) {
+    if (!b || r < 0 || r >= b->R || !ell_out) return fail(RMX_EARG, "bad argument");
+    const Dev &d = b->d;
+    int rc;
+    if (sample) { if ((rc = set_sample(b, r, sample))) return rc; }
+    else if (b->sample_count[r] < 0) return fail(RMX_EARG, "no sample set for this restart");
+    const int W = 1 + RMX_MAX_CLONES;
+    if (b->sample_count[r] == 0) { *ell_out = 0.; if (partial_h_out) for (int m = 0; m < d.M; m++) partial_h_out[m] = 0.; return RMX_OK; }
+    double *dst = b->d_ell_out + (size_t)r * 8;
+    const size_t HW = (size_t)64 * W;
+    double *hp = b->h_pinned + (size_t)r * HW;
+    uint32_t *eh = reinterpret_cast<uint32_t *>(b->h_pinned + (size_t)b->R * HW) + r;
+    {
+        std::lock_guard<std::mutex> lk(b->mu);
+        if ((rc = queue_ell(b, r, partial_h_out != nullptr, dst))) return rc;
+        HIPCHK(hipMemcpyAsync(hp, dst, W * 8, hipMemcpyDeviceToHost, b->stream));
+        if ((rc = finish_restart(b, r, eh))) return rc;
+    }
+    HIPCHK(hipEventSynchronize(b->done_ev[r]));
+    if (*eh) { uint32_t v = *eh; std::lock_guard<std::mutex> lk(b->mu); HIPCHK(hipMemsetAsync(b->d.err + r, 0, sizeof(uint32_t), b->stream)); return translate_error(b, r, v); }
+    *ell_out = hp[0];
+    if (partial_h_out) for (int m = 0; m < d.M; m++) partial_h_out[m] = hp[1 + m];
+    return RMX_OK;
+}
+
+// E[ll] on restart r's current sample for a grid of values of one likelihood parameter, evaluated
+// back to back with a single host round trip (the 20-point grid of scipy.optimize.brute in
+// BreakpointModel.update_param, cn_model.py:553-558).  Leaves the parameter at values[G-1], as the
+// sequential evaluation would.
+int rmx_expected_ll_param_grid(rmx_batch *b, int32_t r, int32_t param_id, const double *values, int32_t G, double *out) {
+    if (!b || r < 0 || r >= b->R || !values || !out || G < 1 || G > 64) return fail(RMX_EARG, "bad argument");
+    if (param_id < 0 || param_id >= RMX_P_HMM_LOG_NORM_CONST) return fail(RMX_EARG, "bad param id");
+    if (b->sample_count[r] < 0) return fail(RMX_EARG, "no sample set for this restart");
+    const int W = 1 + RMX_MAX_CLONES;
+    const size_t HW = (size_t)64 * W;
+    double *gout = b->d_grid_out + (size_t)r * HW;
+    double *hp = b->h_pinned + (size_t)r * HW;
+    uint32_t *eh = reinterpret_cast<uint32_t *>(b->h_pinned + (size_t)b->R * HW) + r;
+    int rc;
+    if (b->sample_count[r] == 0) { for (int g = 0; g < G; g++) out[g] = 0.; return rmx_set_param(b, r, param_id, values[G - 1]); }
+    {
+        std::lock_guard<std::mutex> lk(b->mu);
+        for (int g = 0; g < G; g++) {
+            if ((rc = rmx_set_param(b, r, param_id, values[g]))) return rc;
+            if ((rc = queue_ell(b, r, false, gout + (size_t)g * W))) return rc;
+        }
+        HIPCHK(hipMemcpyAsync(hp, gout, (size_t)G * W * 8, hipMemcpyDeviceToHost, b->stream));
+        if ((rc = finish_restart(b, r, eh))) return rc;
+    }
+    HIPCHK(hipEventSynchronize(b->done_ev[r]));
+    if (*eh) { uint32_t v = *eh; std::lock_guard<std::mutex> lk(b->mu); HIPCHK(hipMemsetAsync(b->d.err + r, 0, sizeof(uint32_t), b->stream)); return translate_error(b, r, v); }
+    for (int g = 0; g < G; g++) out[g] = hp[(size_t)g * W];
     return RMX_OK;
 }
 
@@ -923,8 +1003,8 @@ static int cell_probe(rmx_batch *b, int r, int n, int s, double out6[6]) {
     if (r < 0 || r >= b->R || n < 0 || n >= b->d.N || s < 0 || s >= b->d.S) return fail(RMX_EARG, "index out of range");
     int rc = ensure_tables(b, r, r + 1);
     if (rc) return rc;
-    hipLaunchKernelGGL(k_cell_probe, dim3(1), dim3(1), 0, b->stream, b->d, r, n, s, b->d_ell_out);
-    HIPCHK(hipMemcpyAsync(b->h_pinned, b->d_ell_out, 48, hipMemcpyDeviceToHost, b->stream));
+    hipLaunchKernelGGL(k_cell_probe, dim3(1), dim3(1), 0, b->stream, b->d, r, n, s, b->d_ell_out + (size_t)r * 8);
+    HIPCHK(hipMemcpyAsync(b->h_pinned, b->d_ell_out + (size_t)r * 8, 48, hipMemcpyDeviceToHost, b->stream));
     if ((rc = check_errors(b, r, r + 1))) return rc;
     for (int i = 0; i < 6; i++) out6[i] = b->h_pinned[i];
     return RMX_OK;

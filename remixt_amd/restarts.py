@@ -18,9 +18,10 @@ class RestartSet(object):
     """R restarts of one experiment advancing in lockstep on one device."""
 
     def __init__(self, experiment, init_params, max_copy_number, num_clones=3, device=0, quiet=True,
-                 kernel_module=None, seeds=None, strict=False, **model_kwargs):
+                 kernel_module=None, seeds=None, strict=False, mstep_threads=8, **model_kwargs):
         self.experiment = experiment
         self.strict = strict
+        self.mstep_threads = mstep_threads
         self.error_messages = {}
         self.init_params = list(init_params)
         R = len(self.init_params)
@@ -78,7 +79,9 @@ class RestartSet(object):
         """cn_model.py:409-428 for every restart: batched variational sweeps, per-restart
         scipy M-steps, batched ELBO."""
         self.variational_update(num_update_iter)
-        for r, m in enumerate(self.models):
+
+        def mstep(r):
+            m = self.models[r]
             if m.do_h_update:
                 h_before = np.array(m.model.h, dtype=float)
                 try:
@@ -92,6 +95,20 @@ class RestartSet(object):
                     m.model.h = h_before
                     self.error_messages[r] = str(err).splitlines()[0] + ' (h kept)'
             m.em_update_params()
+
+        # The M-steps are host-latency-bound (hundreds of tiny objective evaluations per restart,
+        # each a device round trip): restarts run on host threads so one restart's round trip
+        # overlaps the others' Python.  Needs a private RNG stream per restart (seeds=...); with the
+        # reference's global numpy RNG the restarts run one after the other.
+        threaded = (self.batch is not None and self.mstep_threads > 1 and
+                    all(m.rng is not None for m in self.models))
+        if threaded:
+            from concurrent.futures import ThreadPoolExecutor
+            with ThreadPoolExecutor(max_workers=self.mstep_threads) as pool:
+                list(pool.map(mstep, range(len(self.models))))
+        else:
+            for r in range(len(self.models)):
+                mstep(r)
         elbo = self.calculate_elbo()
         for m, e in zip(self.models, elbo):
             m.record_elbo(float(e), i)
