@@ -1,0 +1,213 @@
+"""Generate tests/golden/*.npz from the REFERENCE itself (build container only).
+
+TEST INFRASTRUCTURE.  Runs the reference's `remixt.cn_model.BreakpointModel`
+(imported in place from /root/reference) over the reference kernel built by
+oracle/build_ref.py and records inputs + outputs of every stage of the hot
+path.  The fixtures are data only (arrays); they pin
+  * the CPU oracle (tests/test_oracle_golden.py, CPU),
+  * the host logic (tests/test_host_golden.py, CPU),
+  * the HIP path (tests/test_hip_golden.py, GPU).
+
+Usage:  python oracle/make_golden.py
+"""
+import contextlib
+import io
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, ROOT)
+
+from oracle import build_ref, refload  # noqa: E402
+from remixt_amd import synthetic  # noqa: E402  (input generator only)
+
+OUT = os.path.join(ROOT, 'tests', 'golden')
+STEPS = ['update_p_allele_swap', 'update_p_cn', 'update_p_breakpoint', 'update_p_outlier_total', 'update_p_outlier_allele']
+STATE = ['framelogprob', 'posterior_marginals', 'p_breakpoint', 'p_outlier_total', 'p_outlier_allele', 'p_allele_swap']
+
+
+def quiet():
+    return contextlib.redirect_stdout(io.StringIO())
+
+
+def adjacency_array(adj):
+    return np.array(sorted(adj), dtype=np.int64).reshape(-1, 2)
+
+
+def breakpoint_array(brk):
+    """dict id -> frozenset{(n,side),(n,side)}  ->  (ids, int array [K][2][2]) in the dict's order,
+    breakends in the frozenset's iteration order (the remap depends on both)."""
+    ids = list(brk.keys())
+    arr = np.array([[list(be) for be in brk[k]] for k in ids], dtype=np.int64)
+    return np.array(ids), arr
+
+
+def state_grids(cm):
+    out = {}
+    for (M, cn) in [(2, 2), (2, 4), (2, 6), (3, 2), (3, 4), (3, 8), (4, 3)]:
+        out['cn_%d_%d' % (M, cn)] = cm.BreakpointModel.create_cn_states(None, M, 2, cn, 1)
+        out['brk_%d_%d' % (M, cn)] = cm.BreakpointModel.create_brk_states(None, M, cn, 1)
+    np.savez_compressed(os.path.join(OUT, 'state_grids.npz'), **out)
+
+
+def remap_cases(cm):
+    """Breakend layouts: interior, at a telomere, two at one boundary, left edge of segment 0."""
+    N = 8
+    x = np.tile(np.array([[60., 40., 1000.]]), (N, 1)); l = np.full(N, 1e5)
+    adj = {(0, 1), (1, 2), (2, 3), (4, 5), (5, 6), (6, 7)}        # telomere between 3 and 4
+    layouts = {
+        'interior': {'a': frozenset([(1, 1), (5, 0)])},
+        'telomere': {'a': frozenset([(3, 1), (6, 1)])},
+        'two_at_one_boundary': {'a': frozenset([(1, 1), (5, 1)]), 'b': frozenset([(2, 0), (6, 0)])},
+        'left_edge': {'a': frozenset([(0, 0), (5, 1)])},
+        'mixed': {'a': frozenset([(0, 0), (7, 1)]), 'b': frozenset([(2, 1), (3, 0)]), 'c': frozenset([(4, 0), (6, 1)])},
+    }
+    out = {'x': x, 'l': l, 'adjacencies': adjacency_array(adj)}
+    for name, brk in layouts.items():
+        with quiet():
+            m = cm.BreakpointModel(x, l, adj, brk, max_copy_number=2, max_depth=1.0, min_segment_length=0.)
+        ids, arr = breakpoint_array(brk)
+        out[name + '/ids'] = ids; out[name + '/breakends'] = arr
+        for a in ['seg_fwd_remap', 'seg_rev_remap', 'seg_is_original', 'is_telomere', 'breakpoint_idx', 'breakpoint_orient', 'x1', 'l1']:
+            out[name + '/' + a] = np.asarray(getattr(m, a))
+        out[name + '/N1'] = np.array(m.N1)
+    np.savez_compressed(os.path.join(OUT, 'remap.npz'), **out)
+
+
+def model_case(cm, name, N, M, max_cn, chains, seed, normal_contamination=True, male_x=False, zero_alleles=(), short=(), fit_seed=7):
+    e = synthetic.make_experiment(N, num_clones=M, max_copy_number=max_cn, num_chains=chains, seed=seed)
+    x = e.x.copy(); l = e.l.copy()
+    for n in zero_alleles:
+        x[n, 0:2] = 0.
+    for n in short:
+        l[n] = 500.
+    p = synthetic.make_init_params(e, 1, max_cn, num_clones=M)[0]
+    h_init = synthetic.h_init_from_params(p, M)
+    normal_copies = np.array([[1, 1]] * N)
+    if male_x:
+        last = np.array([c == str(chains) for c in e.segment_chromosome_id])
+        normal_copies[last] = [1, 0]
+        x[last, 0:2] = 0.
+    kw = dict(max_copy_number=max_cn, divergence_weight=p['divergence_weight'], max_depth=p['max_depth'],
+              normal_contamination=normal_contamination, normal_copies=normal_copies)
+    out = {'x': x, 'l': l, 'adjacencies': adjacency_array(e.adjacencies), 'h_init': h_init, 'num_clones': np.array(M),
+           'max_copy_number': np.array(max_cn), 'divergence_weight': np.array(p['divergence_weight']),
+           'max_depth': np.array(p['max_depth']), 'normal_contamination': np.array(normal_contamination),
+           'normal_copies': normal_copies}
+    out['breakpoint_ids'], out['breakends'] = breakpoint_array(e.breakpoints)
+    with quiet():
+        m = cm.BreakpointModel(x, l, e.adjacencies, e.breakpoints, **kw)
+        m.num_em_iter = 0
+        m.fit(h_init)
+    mod = m.model
+    out['elbo_init'] = np.array(m.prev_elbo)
+    out['total_likelihood_mask'] = np.asarray(mod.total_likelihood_mask); out['allele_likelihood_mask'] = np.asarray(mod.allele_likelihood_mask)
+    out['is_telomere'] = m.is_telomere; out['breakpoint_idx'] = m.breakpoint_idx; out['breakpoint_orient'] = m.breakpoint_orient
+    out['cn_states_seg0'] = np.asarray(mod.cn_states)[0]; out['brk_states'] = np.asarray(mod.brk_states)
+    out['is_hdel'] = np.asarray(mod.is_hdel); out['is_loh'] = np.asarray(mod.is_loh)
+    out['num_alleles_subclonal'] = np.asarray(mod.num_alleles_subclonal)
+    out['cached_log_transmat_init'] = np.asarray(mod.cached_log_transmat).copy()
+    # per-cell likelihoods at the initial parameters
+    S = mod.num_cn_states
+    rng = np.random.RandomState(seed)
+    cells = np.stack([rng.randint(0, m.N1, 24), rng.randint(0, S, 24)], axis=1)
+    cells[:4, 1] = [0, 1, S - 1, S // 2]
+    lt = np.array([[mod.calculate_log_likelihood_total(int(n), int(s), u) for u in range(2)] for n, s in cells])
+    la = np.array([[mod.calculate_log_likelihood_allele(int(n), int(s), v, w) for v in range(2) for w in range(2)] for n, s in cells])
+    out['cells'] = cells; out['cell_ll_total'] = lt; out['cell_ll_allele'] = la
+    with quiet():
+        for sweep in range(2):
+            for step in STEPS:
+                getattr(mod, step)()
+                pre = 's%d/%s/' % (sweep, step)
+                for a in STATE:
+                    out[pre + a] = np.asarray(getattr(mod, a)).copy()
+                out[pre + 'hmm_log_norm_const'] = np.array(mod.hmm_log_norm_const)
+                out[pre + 'elbo'] = np.array(mod.calculate_elbo())
+            if sweep == 0:
+                out['s0/log_transmat'] = np.asarray(mod.log_transmat).copy()
+                out['s0/cached_log_transmat'] = np.asarray(mod.cached_log_transmat).copy()
+                out['s0/joint_posterior_marginals'] = np.asarray(mod.joint_posterior_marginals).copy()
+                out['s0/energy'] = np.array(mod.calculate_variational_energy()); out['s0/entropy'] = np.array(mod.calculate_variational_entropy())
+    sample = (rng.rand(m.N1) < 0.3).astype(np.int64)
+    ones = np.ones(m.N1, dtype=np.int64)
+    out['sample'] = sample
+    out['ell_sample'] = np.array(mod.calculate_expected_log_likelihood(sample)); out['ell_all'] = np.array(mod.calculate_expected_log_likelihood(ones))
+    if normal_contamination or True:
+        g = np.zeros(M); g2 = np.zeros(M)
+        mod.calculate_expected_log_likelihood_partial_h(sample, g); mod.calculate_expected_log_likelihood_partial_h(ones, g2)
+        out['grad_sample'] = g; out['grad_all'] = g2
+    # a parameter change
+    mod.negbin_r_0 = 250.; mod.betabin_M_1 = 25.
+    mod.h = np.asarray(h_init) * 1.07
+    out['ell_all_changed'] = np.array(mod.calculate_expected_log_likelihood(ones)); out['elbo_changed'] = np.array(mod.calculate_elbo())
+    mod.negbin_r_0 = 500.; mod.betabin_M_1 = 10.; mod.h = np.asarray(h_init)
+    cn = np.zeros((m.N1, M, 2), dtype=int)
+    mod.infer_cn(cn)
+    out['infer_cn'] = cn
+    with quiet():
+        cn2, brk_cn = m.optimal_cn()
+    out['optimal_cn'] = cn2; out['brk_cn'] = np.array([brk_cn[k] for k in out['breakpoint_ids']])
+    # seeded full fit.  (On current scipy the reference's own L-BFGS-B step can end with
+    # "ABNORMAL" and raise -- cn_model.py:510-521; such a case is recorded as fit/failed.)
+    out['fit/seed'] = np.array(fit_seed)
+    try:
+        with quiet():
+            m2 = cm.BreakpointModel(x, l, e.adjacencies, e.breakpoints, **kw)
+            m2.num_em_iter = 2; m2.num_update_iter = 2
+            np.random.seed(fit_seed)
+            m2.fit(h_init)
+            cn3, brk3 = m2.optimal_cn()
+        out['fit/failed'] = np.array(0)
+        out['fit/elbo'] = np.array(m2.prev_elbo); out['fit/elbo_diff'] = np.array(m2.prev_elbo_diff); out['fit/h'] = np.asarray(m2.h)
+        pv = m2.get_likelihood_param_values()
+        out['fit/param_names'] = np.array(list(pv.keys())); out['fit/param_values'] = np.array([pv[k] for k in pv])
+        out['fit/cn'] = cn3; out['fit/brk_cn'] = np.array([brk3[k] for k in out['breakpoint_ids']])
+        out['fit/p_outlier_total'] = m2.p_outlier_total; out['fit/p_outlier_allele'] = m2.p_outlier_allele
+    except ValueError as err:
+        out['fit/failed'] = np.array(1)
+        out['fit/elbo'] = np.array(np.nan)
+        out['fit/error'] = np.array(str(err).splitlines()[0])
+    np.savez_compressed(os.path.join(OUT, name + '.npz'), **out)
+    print(name, 'N1', m.N1, 'S', S, 'elbo', float(out['s1/update_p_outlier_allele/elbo']), 'fit elbo', float(out['fit/elbo']), 'failed', int(out['fit/failed']))
+
+
+def chain_kats(bp):
+    out = {}
+    rng = np.random.RandomState(0)
+    f = rng.rand(6, 5); T = -rng.rand(5, 5, 5)
+    a = np.zeros((6, 5)); b = np.zeros((6, 5)); ss = np.zeros(6, dtype=np.int64)
+    bp.sum_product(f, T, a, b); lp = bp.max_product(f, T, ss)
+    out.update(kat3_f=f, kat3_T=T, kat3_alphas=a, kat3_betas=b, kat3_path=ss, kat3_logprob=np.array(lp))
+    for i, (N, S) in enumerate([(40, 9), (25, 47), (12, 97)]):
+        rng = np.random.RandomState(10 + i)
+        f = np.floor(rng.rand(N, S) * 8) - 4.; T = -np.floor(rng.rand(N - 1, S, S) * 4) * 10.     # ties on purpose
+        ss = np.zeros(N, dtype=np.int64); lp = bp.max_product(f, T, ss)
+        out['ties%d_f' % i] = f; out['ties%d_T' % i] = T; out['ties%d_path' % i] = ss; out['ties%d_logprob' % i] = np.array(lp)
+        f = rng.randn(N, S) * 5; T = -rng.rand(N - 1, S, S) * 30
+        a = np.zeros((N, S)); b = np.zeros((N, S)); bp.sum_product(f, T, a, b)
+        ss = np.zeros(N, dtype=np.int64); lp = bp.max_product(f, T, ss)
+        out['rand%d_f' % i] = f; out['rand%d_T' % i] = T; out['rand%d_alphas' % i] = a; out['rand%d_betas' % i] = b
+        out['rand%d_path' % i] = ss; out['rand%d_logprob' % i] = np.array(lp)
+    np.savez_compressed(os.path.join(OUT, 'chains.npz'), **out)
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    build_ref.build()
+    bp = refload.load_ref_bpmodel()
+    cm = refload.load_ref_cn_model()
+    state_grids(cm)
+    remap_cases(cm)
+    chain_kats(bp)
+    model_case(cm, 'model_m2', N=40, M=2, max_cn=4, chains=2, seed=1)
+    model_case(cm, 'model_m3', N=48, M=3, max_cn=3, chains=3, seed=2, zero_alleles=(5, 17), short=(9,))
+    model_case(cm, 'model_nonormal', N=36, M=2, max_cn=3, chains=2, seed=3, normal_contamination=False, zero_alleles=(4,))
+    model_case(cm, 'model_malex', N=36, M=3, max_cn=2, chains=3, seed=4, male_x=True)
+
+
+if __name__ == '__main__':
+    main()

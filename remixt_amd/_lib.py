@@ -80,6 +80,15 @@ def load():
         raise ImportError(
             "remixt_amd: %s not found. Build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950). There is no CPU fallback." % LIB_PATH)
+    # One HIP runtime per process: PyTorch wheels bundle their own libamdhip64 with the same SONAME as
+    # /opt/rocm's.  If this library pulled in the system copy first and torch were imported later
+    # (bench.py, torch.distributed), the process would mix two runtimes and the second one sees no
+    # device.  Importing torch first makes the dynamic linker resolve our dependency to the copy
+    # torch already loaded.  (torch is used for nothing else here.)
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SYMBOLS.items():
         fn = getattr(lib, name)

@@ -53,6 +53,7 @@ struct rmx_batch {
     std::vector<int> lt_valid;
     std::vector<double> plain_T_init;  // [R]
     std::vector<double> logZ;          // last hmm_log_norm_const
+    std::vector<char> logz_dirty;
     int *d_lt_valid = nullptr;
     // scratch
     double *d_partial = nullptr;       // ELBO partials [R][ELBO_BLOCKS][2]
@@ -527,7 +528,7 @@ int rmx_batch_create(const rmx_problem *pr, int32_t R, const double *h_init, con
 
     // per-restart initial state (bpmodel.pyx:546-597)
     b->sample_cache.assign(R, std::vector<int64_t>()); b->sample_count.assign(R, -1);
-    b->rp.resize(R); b->tables_dirty.assign(R, 1); b->segc_dirty.assign(R, 1); b->ab_dirty.assign(R, 1); b->lt_valid.assign(R, 0); b->logZ.assign(R, 0.);
+    b->rp.resize(R); b->tables_dirty.assign(R, 1); b->segc_dirty.assign(R, 1); b->ab_dirty.assign(R, 1); b->lt_valid.assign(R, 0); b->logZ.assign(R, 0.); b->logz_dirty.assign(R, 0);
     for (int r = 0; r < R; r++) {
         RestartParams &p = b->rp[r];
         memset(&p, 0, sizeof p);
@@ -627,6 +628,13 @@ int rmx_set_param(rmx_batch *b, int32_t r, int32_t id, double v) {
 }
 int rmx_get_param(rmx_batch *b, int32_t r, int32_t id, double *v) {
     if (r < 0 || r >= b->R || id < 0 || id >= RMX_P_COUNT) return fail(RMX_EARG, "bad restart / param id");
+    if (id == RMX_P_HMM_LOG_NORM_CONST && b->logz_dirty[r]) {
+        double *dst = b->d_ell_out + (size_t)r * 8;
+        hipLaunchKernelGGL(k_logz, dim3(1), dim3(256), 0, b->stream, b->d, r, dst);
+        HIPCHK(hipMemcpyAsync(&b->logZ[r], dst, 8, hipMemcpyDeviceToHost, b->stream));
+        HIPCHK(hipStreamSynchronize(b->stream));
+        b->logz_dirty[r] = 0;
+    }
     *v = (id == RMX_P_HMM_LOG_NORM_CONST) ? b->logZ[r] : b->rp[r].p[id];
     return RMX_OK;
 }
@@ -787,7 +795,7 @@ static int do_update_p_cn(rmx_batch *b, int r0, int r1) {
         hipLaunchKernelGGL(k_marginals<true>, row_grid(b, r1 - r0), dim3(256), 0, b->stream, b->d, r0, b->G);
         HIPCHK(hipGetLastError());
     }
-    for (int r = r0; r < r1; r++) { b->ab_dirty[r] = 0; if (!b->lt_valid[r]) { b->lt_valid[r] = 1; int one = 1; HIPCHK(hipMemcpyAsync(b->d_lt_valid + r, &one, 4, hipMemcpyHostToDevice, b->stream)); } }
+    for (int r = r0; r < r1; r++) { b->ab_dirty[r] = 0; b->logz_dirty[r] = 1; if (!b->lt_valid[r]) { b->lt_valid[r] = 1; int one = 1; HIPCHK(hipMemcpyAsync(b->d_lt_valid + r, &one, 4, hipMemcpyHostToDevice, b->stream)); } }
     // pairwise reductions at breakend adjacencies (feeds update_p_breakpoint and the ELBO)
     return launch_pairwise_breakends(b, r0, r1, 0);
 }
@@ -872,7 +880,7 @@ static int elbo_parts(rmx_batch *b, int r0, int r1, bool exact_parts, double *ou
     rc = check_errors(b, r0, r1);
     if (d_fp) hipFree(d_fp);
     if (rc) return rc;
-    for (int r = r0; r < r1; r++) if (b->lt_valid[r]) b->logZ[r] = out4[(r - r0) * 4 + 3];
+    for (int r = r0; r < r1; r++) if (b->lt_valid[r]) { b->logZ[r] = out4[(r - r0) * 4 + 3]; b->logz_dirty[r] = 0; }
     return RMX_OK;
 }
 int rmx_calculate_elbo(rmx_batch *b, int32_t r0, int32_t r1, double *out) {

@@ -899,6 +899,15 @@ __global__ void k_ell_full(Dev d, int r, double *partial) {
     if (threadIdx.x == 0) partial[(size_t)blockIdx.x * (1 + RMX_MAX_CLONES)] = acc;
 }
 
+// hmm_log_norm_const = sum of the per-row shares (bpmodel.pyx:946).  grid 1, block 256
+__global__ void k_logz(Dev d, int r, double *out) {
+    __shared__ double scratch[8];
+    double z = 0.;
+    for (int n = threadIdx.x; n < d.N; n += 256) z += d.rowZ[(size_t)r * d.N + n];
+    z = block_sum<256>(z, scratch);
+    if (threadIdx.x == 0) *out = z;
+}
+
 // single cell, for tests
 __global__ void k_cell_probe(Dev d, int r, int n, int s, double *out6) {
     const RestartParams &rp = d.rp[r];

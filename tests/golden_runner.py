@@ -1,0 +1,128 @@
+"""Replay of a tests/golden/model_*.npz fixture (recorded from the reference by
+oracle/make_golden.py) on an arbitrary kernel module, through this project's own
+BreakpointModel host class."""
+import os
+
+import numpy as np
+
+from remixt_amd.cn_model import BreakpointModel
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+STEPS = ['update_p_allele_swap', 'update_p_cn', 'update_p_breakpoint', 'update_p_outlier_total', 'update_p_outlier_allele']
+STATE = ['framelogprob', 'posterior_marginals', 'p_breakpoint', 'p_outlier_total', 'p_outlier_allele', 'p_allele_swap']
+MODEL_CASES = ['model_m2', 'model_m3', 'model_nonormal', 'model_malex']
+
+
+def load(name):
+    return np.load(os.path.join(GOLDEN, name + '.npz'), allow_pickle=False)
+
+
+def inputs(g):
+    adjacencies = set((int(a), int(b)) for a, b in g['adjacencies'])
+    # dict order and the order of the two breakends inside each frozenset are part of the fixture
+    breakpoints = {}
+    for k, be in zip(g['breakpoint_ids'], g['breakends']):
+        breakpoints[str(k)] = frozenset([(int(be[0][0]), int(be[0][1])), (int(be[1][0]), int(be[1][1]))])
+    kw = dict(max_copy_number=int(g['max_copy_number']), divergence_weight=float(g['divergence_weight']),
+              max_depth=float(g['max_depth']), normal_contamination=bool(g['normal_contamination']),
+              normal_copies=g['normal_copies'])
+    return g['x'], g['l'], adjacencies, breakpoints, kw
+
+
+def build(g, kernel):
+    x, l, adj, brk, kw = inputs(g)
+    m = BreakpointModel(x, l, adj, brk, kernel_module=kernel, quiet=True, **kw)
+    return m
+
+
+def check(a, b, rtol, atol, what):
+    a = np.asarray(a, dtype=float); b = np.asarray(b, dtype=float)
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    if not np.allclose(a, b, rtol=rtol, atol=atol):
+        err = np.max(np.abs(a - b) / (atol / max(rtol, 1e-300) + np.maximum(np.abs(a), np.abs(b))))
+        raise AssertionError('%s: max rel err %.3e (rtol %.1e)' % (what, err, rtol))
+
+
+def replay(name, kernel, rtol, atol, dense=True, cells=True):
+    g = load(name)
+    m = build(g, kernel)
+    # host logic against the reference's host class
+    assert np.array_equal(m.is_telomere, g['is_telomere'])
+    assert np.array_equal(m.breakpoint_idx, g['breakpoint_idx']) and np.array_equal(m.breakpoint_orient, g['breakpoint_orient'])
+    m.num_em_iter = 0
+    m.fit(g['h_init'])
+    mod = m.model
+    assert np.array_equal(np.asarray(mod.total_likelihood_mask), g['total_likelihood_mask'])
+    assert np.array_equal(np.asarray(mod.allele_likelihood_mask), g['allele_likelihood_mask'])
+    assert np.array_equal(np.asarray(mod.cn_states)[0], g['cn_states_seg0']) and np.array_equal(np.asarray(mod.brk_states), g['brk_states'])
+    assert np.array_equal(np.asarray(mod.is_hdel), g['is_hdel']) and np.array_equal(np.asarray(mod.is_loh), g['is_loh'])
+    assert np.array_equal(np.asarray(mod.num_alleles_subclonal), g['num_alleles_subclonal'])
+    check(m.prev_elbo, g['elbo_init'], rtol, atol, 'elbo_init')
+    if dense:
+        check(mod.cached_log_transmat, g['cached_log_transmat_init'], 1e-13, 1e-13, 'cached_log_transmat_init')
+    if cells:
+        for (n, s), lt, la in zip(g['cells'], g['cell_ll_total'], g['cell_ll_allele']):
+            for u in range(2):
+                check(mod.calculate_log_likelihood_total(int(n), int(s), u), lt[u], rtol, atol, 'll_total')
+            for v in range(2):
+                for w in range(2):
+                    check(mod.calculate_log_likelihood_allele(int(n), int(s), v, w), la[v * 2 + w], rtol, atol, 'll_allele')
+    for sweep in range(2):
+        for step in STEPS:
+            getattr(mod, step)()
+            pre = 's%d/%s/' % (sweep, step)
+            for a in STATE:
+                check(getattr(mod, a), g[pre + a], rtol, atol, pre + a)
+            check(mod.hmm_log_norm_const, g[pre + 'hmm_log_norm_const'], rtol, atol, pre + 'logZ')
+            check(mod.calculate_elbo(), g[pre + 'elbo'], rtol, atol, pre + 'elbo')
+        if sweep == 0:
+            if dense:
+                check(mod.log_transmat, g['s0/log_transmat'], 1e-12, 1e-12, 'log_transmat')
+                check(mod.cached_log_transmat, g['s0/cached_log_transmat'], 1e-12, 1e-12, 'cached_log_transmat')
+                check(mod.joint_posterior_marginals, g['s0/joint_posterior_marginals'], rtol, atol, 'joint')
+            check(mod.calculate_variational_energy(), g['s0/energy'], rtol, atol, 'energy')
+            check(mod.calculate_variational_entropy(), g['s0/entropy'], rtol, atol, 'entropy')
+    M = int(g['num_clones'])
+    ones = np.ones(m.N1, dtype=np.int64)
+    check(mod.calculate_expected_log_likelihood(g['sample']), g['ell_sample'], rtol, atol, 'ell_sample')
+    check(mod.calculate_expected_log_likelihood(ones), g['ell_all'], rtol, atol, 'ell_all')
+    ga = np.zeros(M); gb = np.zeros(M)
+    mod.calculate_expected_log_likelihood_partial_h(g['sample'], ga); mod.calculate_expected_log_likelihood_partial_h(ones, gb)
+    check(ga, g['grad_sample'], max(rtol, 1e-9), 1e-6, 'grad_sample'); check(gb, g['grad_all'], max(rtol, 1e-9), 1e-6, 'grad_all')
+    mod.negbin_r_0 = 250.; mod.betabin_M_1 = 25.
+    mod.h = np.asarray(g['h_init']) * 1.07
+    check(mod.calculate_expected_log_likelihood(ones), g['ell_all_changed'], rtol, atol, 'ell_all_changed')
+    check(mod.calculate_elbo(), g['elbo_changed'], rtol, atol, 'elbo_changed')
+    mod.negbin_r_0 = 500.; mod.betabin_M_1 = 10.; mod.h = np.asarray(g['h_init'])
+    cn = np.zeros((m.N1, M, 2), dtype=int)
+    mod.infer_cn(cn)
+    assert np.array_equal(cn, g['infer_cn']), 'Viterbi decode differs'
+    cn2, brk = m.optimal_cn()
+    assert np.array_equal(cn2, g['optimal_cn'])
+    assert np.array_equal(np.array([brk[str(k)] for k in g['breakpoint_ids']]), g['brk_cn'])
+    return m
+
+
+def replay_fit(name, kernel, rtol_elbo=1e-6, rtol_h=1e-4, rtol_param=1e-3):
+    """Seeded EM trajectory (global numpy RNG, like the reference)."""
+    g = load(name)
+    m = build(g, kernel)
+    m.num_em_iter = 2; m.num_update_iter = 2
+    np.random.seed(int(g['fit/seed']))
+    if int(g['fit/failed']):
+        try:
+            m.fit(g['h_init'])
+        except ValueError:
+            return None
+        return m   # (optimiser noise decides whether L-BFGS-B reports ABNORMAL; either outcome is accepted)
+    m.fit(g['h_init'])
+    check(m.prev_elbo, g['fit/elbo'], rtol_elbo, 0., 'fit elbo')
+    check(m.h, g['fit/h'], rtol_h, 1e-9, 'fit h')
+    pv = m.get_likelihood_param_values()
+    for k, v in zip(g['fit/param_names'], g['fit/param_values']):
+        check(pv[str(k)], v, rtol_param, 1e-9, 'fit ' + str(k))
+    cn, brk = m.optimal_cn()
+    assert np.array_equal(cn, g['fit/cn'])
+    assert np.array_equal(np.array([brk[str(k)] for k in g['breakpoint_ids']]), g['fit/brk_cn'])
+    check(m.p_outlier_total, g['fit/p_outlier_total'], 1e-4, 1e-7, 'fit p_outlier_total')
+    return m

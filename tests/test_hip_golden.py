@@ -1,0 +1,62 @@
+"""GPU: the HIP path (through the C ABI) against the golden vectors recorded from the reference.
+Tolerance 1e-6 relative (north_star) -- in practice ~1e-10; Viterbi decodes bit-exact."""
+import numpy as np
+import pytest
+
+from tests import golden_runner as GR
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def hip():
+    from remixt_amd import bpmodel
+    return bpmodel
+
+
+@pytest.mark.parametrize('name', GR.MODEL_CASES)
+def test_hip_replays_reference(hip, name):
+    GR.replay(name, hip, rtol=1e-6, atol=1e-9)
+
+
+@pytest.mark.parametrize('name', GR.MODEL_CASES)
+def test_hip_replays_reference_tight(hip, name):
+    """Same replay at a tolerance three orders tighter than required: guards accuracy regressions
+    of the fast lgamma / scaled linear-domain recursion."""
+    GR.replay(name, hip, rtol=1e-9, atol=1e-11, cells=True)
+
+
+@pytest.mark.parametrize('name', ['model_m2', 'model_m3', 'model_malex', 'model_nonormal'])
+def test_hip_full_fit_trajectory(hip, name):
+    GR.replay_fit(name, hip, rtol_elbo=1e-6, rtol_h=1e-4, rtol_param=1e-3)
+
+
+def test_hip_chain_kats(hip):
+    g = GR.load('chains')
+    for i in range(3):
+        f, T = g['ties%d_f' % i], g['ties%d_T' % i]
+        ss = np.zeros(len(f), dtype=np.int64)
+        assert hip.max_product(f, T, ss) == float(g['ties%d_logprob' % i])
+        assert np.array_equal(ss, g['ties%d_path' % i])            # bit-exact, ties included
+        f, T = g['rand%d_f' % i], g['rand%d_T' % i]
+        a = np.zeros_like(f); b = np.zeros_like(f)
+        hip.sum_product(f, T, a, b)
+        assert np.allclose(a, g['rand%d_alphas' % i], rtol=1e-12, atol=1e-10) and np.allclose(b, g['rand%d_betas' % i], rtol=1e-12, atol=1e-10)
+        ss = np.zeros(len(f), dtype=np.int64)
+        assert hip.max_product(f, T, ss) == float(g['rand%d_logprob' % i]) and np.array_equal(ss, g['rand%d_path' % i])
+
+
+def test_error_behaviour(hip):
+    """Reference error sites: shape validation (bpmodel.pyx:509-529) and invalid allele ratio (:335)."""
+    cn = np.ones((3, 2, 2, 2), dtype=np.int64)
+    args = (np.zeros((1, 2), dtype=np.int64), np.array([0.1, 0.1]), np.ones(3) * 1e5, np.ones(3) * 100, np.ones((3, 2)) * 10,
+            np.array([0, 0, 1]), -np.ones(3, dtype=np.int64), np.zeros(3, dtype=np.int64), 10., 1e-6)
+    with pytest.raises(ValueError):
+        hip.RemixtModel(3, 3, 0, True, cn, *args)                       # clone count mismatch
+    with pytest.raises(ValueError):
+        hip.RemixtModel(2, 3, 1, True, cn, *args)                       # num_breakpoints vs breakpoint_idx
+    # a state with allele ratio 1 under normal contamination: p <= 0 or 1-p <= 0 -> ValueError on evaluation
+    cn2 = np.zeros((3, 2, 2, 2), dtype=np.int64); cn2[:, :, :, 0] = 1
+    m = hip.RemixtModel(2, 3, 0, True, cn2, *args)
+    with pytest.raises(ValueError):
+        m.update_p_cn()

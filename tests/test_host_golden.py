@@ -1,0 +1,82 @@
+"""CPU: this project's host logic (state grids, breakend remap, masks, restart selection,
+brute-force search) against golden vectors recorded from the reference's cn_model.py."""
+import numpy as np
+import pytest
+import scipy.optimize
+
+from remixt_amd import cn_model, restarts
+from tests import golden_runner as GR
+
+
+def test_state_grids():
+    g = GR.load('state_grids')
+    for key in g.files:
+        kind, M, cn = key.split('_')
+        if kind == 'cn':
+            mine = cn_model.create_cn_states(int(M), 2, int(cn), 1)
+        else:
+            mine = cn_model.create_brk_states(int(M), int(cn), 1)
+        assert mine.dtype == np.int64 and np.array_equal(mine, g[key]), key
+    # grid sizes quoted in SURVEY.md 0.3
+    assert len(cn_model.create_cn_states(3, 2, 8, 1)) == 165 and len(cn_model.create_brk_states(3, 8, 1)) == 25
+    assert len(cn_model.create_cn_states(3, 2, 12, 1)) == 355
+
+
+@pytest.mark.parametrize('layout', ['interior', 'telomere', 'two_at_one_boundary', 'left_edge', 'mixed'])
+def test_breakend_remap(layout):
+    g = GR.load('remap')
+    adj = set((int(a), int(b)) for a, b in g['adjacencies'])
+    brk = {}
+    for k, be in zip(g[layout + '/ids'], g[layout + '/breakends']):
+        brk[str(k)] = frozenset([(int(be[0][0]), int(be[0][1])), (int(be[1][0]), int(be[1][1]))])
+    m = cn_model.BreakpointModel(g['x'], g['l'], adj, brk, max_copy_number=2, max_depth=1.0, min_segment_length=0., quiet=True)
+    assert m.N1 == int(g[layout + '/N1'])
+    for a in ['seg_fwd_remap', 'seg_rev_remap', 'seg_is_original', 'is_telomere', 'breakpoint_idx', 'breakpoint_orient', 'x1', 'l1']:
+        assert np.array_equal(np.asarray(getattr(m, a)), g[layout + '/' + a]), (layout, a)
+
+
+def test_constructor_errors():
+    x = np.array([[6., 4., 100.]] * 3); l = np.ones(3) * 1e5
+    with pytest.raises(ValueError):
+        cn_model.BreakpointModel(x, l, {(0, 1)}, {'a': frozenset([(0, 1), (2, 0)])})          # max_depth is mandatory
+    with pytest.raises(ValueError):
+        cn_model.BreakpointModel(x, l, {(0, 1)}, {}, max_depth=1.)                            # empty breakpoints (reference quirk)
+    with pytest.raises(AssertionError):
+        cn_model.BreakpointModel(x[:, [1, 0, 2]], l, {(0, 1)}, {'a': frozenset([(0, 1), (2, 0)])}, max_depth=1.)   # minor > major
+
+
+def test_brute_1d_is_scipy_brute():
+    calls = []
+
+    def f(v):
+        assert v.shape == (1,)
+        calls.append(float(v[0]))
+        x = float(v[0])
+        if x < 10 or x > 2000:
+            return np.inf
+        return (np.log(x) - 5.3) ** 2 + 0.01 * np.sin(x / 50.)
+
+    ref = scipy.optimize.brute(f, ranges=[(10., 2000.)], full_output=True)
+    ref_calls = list(calls); calls.clear()
+
+    class Dummy(object):
+        pass
+    bm = cn_model.BreakpointModel.__new__(cn_model.BreakpointModel)
+    bm.model = Dummy()
+    mine = bm._brute_1d(f, 'x', (10., 2000.), None)
+    assert mine == float(ref[0][0]) and calls == ref_calls
+
+
+def test_decode_breakpoints_naive():
+    cn = np.array([[[1, 1], [2, 1]], [[1, 1], [1, 1]], [[1, 1], [1, 1]], [[1, 1], [3, 1]]])
+    adj = [(0, 1), (1, 2), (2, 3)]
+    brk = {'a': frozenset([(0, 1), (3, 0)])}
+    out = cn_model.decode_breakpoints_naive(cn, adj, brk)
+    assert np.array_equal(out['a'], [0, 1])
+
+
+def test_select_optimal():
+    res = {i: {'stats': {'elbo': e, 'proportion_divergent': p}} for i, (e, p) in enumerate([(-10., 0.1), (-5., 0.9), (-7., 0.2), (-7., 0.3)])}
+    assert restarts.select_optimal(res, 0.5) == 2          # best ELBO among the admissible, first on ties
+    assert restarts.select_optimal(res, 0.05) == 1         # nothing admissible: best overall
+    assert restarts.shard_indices(10, 4, 1) == [1, 5, 9]

@@ -1,0 +1,61 @@
+"""CPU, build container only: the oracle against the REFERENCE binary (oracle/_ref, built from
+/root/reference/remixt/bpmodel.pyx) on fresh seeded problems.  Skipped where the reference
+build is absent."""
+import numpy as np
+import pytest
+
+from oracle import refload
+from tests import helpers as H
+
+pytestmark = pytest.mark.skipif(not refload.have_ref_binary(), reason='oracle/_ref not built')
+
+
+@pytest.mark.parametrize('M,max_cn,N,nc', [(2, 5, 60, True), (3, 3, 50, True), (2, 3, 40, False), (3, 2, 30, False)])
+def test_oracle_equals_reference_kernel(oracle_mod, M, max_cn, N, nc):
+    ref = refload.load_ref_bpmodel()
+    a, h, _ = H.make_model(oracle_mod, N=N, M=M, max_cn=max_cn, chains=3, seed=100 + N, normal_contamination=nc)
+    b, _, _ = H.make_model(ref, N=N, M=M, max_cn=max_cn, chains=3, seed=100 + N, normal_contamination=nc)
+    ma, mb = H.attach(a, h), H.attach(b, h)
+    assert ma.calculate_elbo() == pytest.approx(mb.calculate_elbo(), rel=1e-13)
+    for it in range(2):
+        for step in ('update_p_allele_swap', 'update_p_cn', 'update_p_breakpoint', 'update_p_outlier_total', 'update_p_outlier_allele'):
+            getattr(ma, step)(); getattr(mb, step)()
+            for name in H.STATE_ATTRS + H.DENSE_ATTRS:
+                assert np.allclose(np.asarray(getattr(ma, name)), np.asarray(getattr(mb, name)), rtol=1e-12, atol=1e-300), (step, name)
+            assert ma.calculate_elbo() == pytest.approx(mb.calculate_elbo(), rel=1e-12)
+    s = np.ones(ma.num_segments, dtype=np.int64)
+    assert ma.calculate_expected_log_likelihood(s) == pytest.approx(mb.calculate_expected_log_likelihood(s), rel=1e-13)
+    if nc:
+        ga, gb = np.zeros(M), np.zeros(M)
+        ma.calculate_expected_log_likelihood_partial_h(s, ga); mb.calculate_expected_log_likelihood_partial_h(s, gb)
+        assert np.allclose(ga, gb, rtol=1e-12)
+    cna = np.zeros((ma.num_segments, M, 2), dtype=int); cnb = cna.copy()
+    ma.infer_cn(cna); mb.infer_cn(cnb)
+    assert np.array_equal(cna, cnb)
+
+
+def test_host_class_equals_reference_host_class(oracle_mod):
+    """This project's BreakpointModel vs the reference's, both over the reference kernel, seeded fit."""
+    if not refload.have_ref_sources():
+        pytest.skip('reference sources not present')
+    import contextlib, io
+    cm = refload.load_ref_cn_model()
+    ref = refload.load_ref_bpmodel()
+    from remixt_amd import synthetic
+    e = synthetic.make_experiment(70, num_clones=3, max_copy_number=3, num_chains=3, seed=9)
+    p = synthetic.make_init_params(e, 1, 3)[0]
+    h = synthetic.h_init_from_params(p, 3)
+    kw = dict(max_copy_number=3, divergence_weight=p['divergence_weight'], max_depth=p['max_depth'])
+    with contextlib.redirect_stdout(io.StringIO()):
+        r = cm.BreakpointModel(e.x, e.l, e.adjacencies, e.breakpoints, **kw)
+        r.num_em_iter = 2; r.num_update_iter = 2
+        np.random.seed(5); r.fit(h)
+        rcn, rbrk = r.optimal_cn()
+    from remixt_amd.cn_model import BreakpointModel
+    m = BreakpointModel(e.x, e.l, e.adjacencies, e.breakpoints, kernel_module=ref, quiet=True, **kw)
+    m.num_em_iter = 2; m.num_update_iter = 2
+    np.random.seed(5); m.fit(h)
+    cn, brk = m.optimal_cn()
+    assert m.prev_elbo == r.prev_elbo and np.array_equal(m.h, r.h)
+    assert m.get_likelihood_param_values() == r.get_likelihood_param_values()
+    assert np.array_equal(cn, rcn) and all(np.array_equal(brk[k], rbrk[k]) for k in brk)
