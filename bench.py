@@ -46,7 +46,7 @@ def parse():
     ap.add_argument('--restarts', type=int, default=16, help='restarts per GPU')
     ap.add_argument('--update-iters', type=int, default=5)
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--cpu-sample-segments', type=int, default=200)
+    ap.add_argument('--cpu-sample-segments', type=int, default=800)
     ap.add_argument('--no-mstep', action='store_true', help='diagnostic only: variational sweeps without M-steps (NOT the reported metric)')
     return ap.parse_args()
 
@@ -160,18 +160,30 @@ def main():
 
     if rank == 0:
         total_ms = sum(v[0] for v in prof.values())
-        dom = max(prof.items(), key=lambda kv: kv[1][0]) if prof else (None, (0., 0))
+        # dominant kernel of the hot path = the data-parallel (segment x state) kernel with the largest
+        # device time (the M-step's sampled-objective kernels are ~100 us host round trips over
+        # <= 200 segments: latency, not a roofline subject; they are listed under "kernels")
+        hot = [(k, prof[k]) for k in ALG_BYTES_PER_CELL if k in prof]
+        dom = max(hot, key=lambda kv: kv[1][0]) if hot else (None, (0., 0))
         cells_per_launch = float(N1) * S * R
         roof = None
         if dom[0] is not None:
             name, (ms, n) = dom
             avg_ms = ms / max(n, 1)
             alg = ALG_BYTES_PER_CELL.get(name)
-            achieved = (alg * cells_per_launch / (avg_ms * 1e-3) / 1e9) if alg else None
+            achieved = alg * cells_per_launch / (avg_ms * 1e-3) / 1e9
+            traffic = None
+            try:   # PMC traffic of the same kernel on the same workload, measured offline (profiles/)
+                tj = json.load(open(os.path.join(ROOT, 'profiles', 'traffic_r01.json')))
+                w = tj['workload']
+                if (w['segments'], w['states'], w['restarts']) == (args.segments, S, R):
+                    traffic = tj['kernels'][name]['hbm_bytes_per_launch']
+            except Exception:
+                traffic = None
             roof = {'bound': 'hbm', 'kernel': name, 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                    'frac': (achieved / HBM_PEAK_GBS) if achieved else None, 'traffic': None,
-                    'avg_launch_ms': avg_ms, 'launches': n,
-                    'alg_bytes_per_launch': (alg * cells_per_launch) if alg else None}
+                    'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic, 'avg_launch_ms': avg_ms, 'launches': n,
+                    'alg_bytes_per_launch': alg * cells_per_launch,
+                    'note': 'latency/FP64-bound sequential scan, see DESIGN.md 4.4'}
         # whole variational update (all kernels of one sweep) against the 88 B/cell model
         upd = sum(prof.get(k, (0., 0))[0] for k in ('k_framelogprob', 'k_fb', 'k_marginals<true>', 'k_pairwise', 'k_brk_update',
                                                        'k_brk_lut', 'k_update_outlier_total', 'k_update_outlier_allele', 'k_update_allele_swap'))
