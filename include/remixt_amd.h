@@ -158,6 +158,13 @@ int rmx_set_sample(rmx_batch *b, int32_t r, const int64_t *sample);
  * scipy.optimize.brute, cn_model.py:553-558) with one host round trip; G <= 64.  Leaves the
  * parameter at values[G-1], as G sequential evaluations would. */
 int rmx_expected_ll_param_grid(rmx_batch *b, int32_t r, int32_t param_id, const double *values, int32_t G, double *out);
+/* Lock-step M-steps over several restarts (remixt_amd/restarts.py): one candidate value of one
+ * likelihood parameter per listed restart (distinct restarts), each evaluated on its own current
+ * sample; out[i] belongs to restarts[i].  One host round trip for the whole list. */
+int rmx_expected_ll_batch(rmx_batch *b, int32_t nreq, const int32_t *restarts, int32_t param_id, const double *values, double *out);
+/* E[ll] over ALL segments (the reference passes a mask of ones, cn_model.py:497, :524, :549, :563)
+ * for restarts [r0, r1); out: [r1-r0]. */
+int rmx_expected_ll_full(rmx_batch *b, int32_t r0, int32_t r1, double *out);
 /* per-cell values, for tests (:751-776, :809-853): u/v/w in {0,1} */
 int rmx_log_likelihood_total(rmx_batch *b, int32_t r, int32_t n, int32_t s, int32_t u, double *out);
 int rmx_log_likelihood_allele(rmx_batch *b, int32_t r, int32_t n, int32_t s, int32_t v, int32_t w, double *out);

@@ -55,6 +55,8 @@ SYMBOLS = {
     "rmx_expected_log_likelihood": (C.c_int, [C.c_void_p, C.c_int32, _ip, _dp, _dp]),
     "rmx_set_sample": (C.c_int, [C.c_void_p, C.c_int32, _ip]),
     "rmx_expected_ll_param_grid": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, _dp, C.c_int32, _dp]),
+    "rmx_expected_ll_batch": (C.c_int, [C.c_void_p, C.c_int32, _i32p, C.c_int32, _dp, _dp]),
+    "rmx_expected_ll_full": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, _dp]),
     "rmx_log_likelihood_total": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _dp]),
     "rmx_log_likelihood_allele": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _dp]),
     "rmx_infer_cn": (C.c_int, [C.c_void_p, C.c_int32, _ip, _dp]),

@@ -313,6 +313,22 @@ class RemixtBatch(object):
                                                       out.ctypes.data_as(_dp)))
         return out
 
+    def expected_log_likelihood_batch(self, restarts, name, values):
+        """E[ll] on each listed restart's current sample with likelihood parameter `name` set to the
+        matching entry of `values` (and left there): the evaluation round of lock-step optimisers."""
+        rl = np.ascontiguousarray(restarts, dtype=np.int32)
+        v = _f64(values).ravel()
+        if rl.shape != v.shape:
+            raise ValueError('one value per listed restart')
+        out = np.zeros(len(v), dtype=np.float64)
+        self._ck(self._lib.rmx_expected_ll_batch(self._handle, len(v), rl.ctypes.data_as(_i32p), PARAM_IDS[name],
+                                                 v.ctypes.data_as(_dp), out.ctypes.data_as(_dp)))
+        return out
+
+    def expected_log_likelihood_full(self, r0=None, r1=None):
+        """E[ll] over all segments for restarts [r0, r1)."""
+        return self._scalar_range(self._lib.rmx_expected_ll_full, r0, r1)
+
     def infer_cn(self, r):
         cn = np.zeros((self.num_segments, self.num_clones, 2), dtype=np.int64)
         lp = C.c_double(0.)

@@ -63,7 +63,9 @@ struct rmx_batch {
     double *h_pinned = nullptr;        // pinned staging [max(4R, 16)]
     int32_t *d_sample = nullptr;       // [R][N] index lists of the current M-step samples
     std::vector<std::vector<int64_t>> sample_cache; std::vector<int> sample_count;
-    double *d_grid_out = nullptr;      // [64][1+MAXC]
+    double *d_grid_out = nullptr;      // [R][64][1+MAXC]
+    int32_t *d_rlist = nullptr, *d_counts = nullptr; RestartParams *d_rp_stage = nullptr; double *d_batch_out = nullptr;   // [R] each
+    void *h_batch = nullptr;           // pinned staging for the batched objective
     std::vector<int32_t> plain_list; int32_t *d_plain_list = nullptr; double *d_plain_jt = nullptr;
     // viterbi
     uint16_t *d_bp = nullptr; double *d_final = nullptr; int64_t *d_path = nullptr; double *d_logprob = nullptr;
@@ -73,6 +75,7 @@ struct rmx_batch {
     FbLaunch fbG{}; size_t fbG_lds = 0;   // generic kernel configuration
     int n_fast = 0, n_generic = 0, fb_amat_lds = 0;
     unsigned long long *d_dbg = nullptr;
+    int fbv_rpt = 0;   // rows per slice of the multi-vector kernel (0 = not applicable)
     int G = 64;
     // all device allocations (freed on destroy)
     std::vector<void *> allocs;
@@ -244,6 +247,14 @@ static fb_kernel_t fb_kernel_for(int rpt) {
     default: return k_fb<0, 1024>;
     }
 }
+typedef void (*fbv_kernel_t)(FbvArgs);
+static fbv_kernel_t fbv_kernel_for(int rpt, int nv) {
+#define FBV_CASE(R_) \
+    if (rpt == R_) { if (nv == 1) return k_fbv<R_, 1, 768>; if (nv == 2) return k_fbv<R_, 2, 768>; return k_fbv<R_, 4, 768>; }
+    FBV_CASE(2) FBV_CASE(6) FBV_CASE(14) FBV_CASE(22)
+#undef FBV_CASE
+    return nullptr;
+}
 static const size_t kLdsBudget = 150 * 1024;   // of the CU's 160 KiB
 static void fb_layout(rmx_batch *b, int rpt, int P, FbLaunch &L, size_t &lds, int *amat_lds) {
     const int S = b->d.S;
@@ -277,6 +288,8 @@ static void configure_fb(rmx_batch *b) {
     int PG = 1;
     while (S * (PG + 1) <= 1024 && (S + PG) / (PG + 1) >= 1 && PG < 16) PG++;
     if (rpt == 0 || S * P > fb_ntmax(rpt) || getenv("RMX_FB_GENERIC")) rpt = 0;
+    b->fbv_rpt = 0;
+    if (!getenv("RMX_FB_GENERIC") && !getenv("RMX_FB_SINGLE")) { for (int v : {2, 6, 14, 22}) if (8 * v >= S) { b->fbv_rpt = v; break; } }
     b->fb_rpt = rpt;
     if (rpt > 0) fb_layout(b, rpt, P, b->fbL, b->fb_lds, &b->fb_amat_lds);
     fb_layout(b, 0, PG, b->fbG, b->fbG_lds, nullptr);
@@ -346,6 +359,8 @@ static int launch_brk_lut(rmx_batch *b, int r0, int r1, double *dst, double *eds
     HIPCHK(hipGetLastError());
     return RMX_OK;
 }
+
+#define RANGE_CHECK() if (!b || r0 < 0 || r1 > b->R || r0 >= r1) return fail(RMX_EARG, "bad restart range")
 
 // ===========================================================================
 extern "C" {
@@ -508,8 +523,10 @@ int rmx_batch_create(const rmx_problem *pr, int32_t R, const double *h_init, con
 #undef DA
     if ((rc = dalloc(b, &b->d_lt_valid, R)) || (rc = dalloc(b, &b->d_partial, (size_t)R * ELBO_BLOCKS * 2)) || (rc = dalloc(b, &b->d_out4, (size_t)R * 4)) ||
         (rc = dalloc(b, &b->d_ell_partial, (size_t)R * std::max(N, ELBO_BLOCKS) * (1 + RMX_MAX_CLONES))) || (rc = dalloc(b, &b->d_ell_out, (size_t)R * 8)) ||
-        (rc = dalloc(b, &b->d_sample, (size_t)R * N)) || (rc = dalloc(b, &b->d_grid_out, (size_t)R * 64 * (1 + RMX_MAX_CLONES)))) { rmx_batch_destroy(b); return rc; }
+        (rc = dalloc(b, &b->d_sample, (size_t)R * N)) || (rc = dalloc(b, &b->d_grid_out, (size_t)R * 64 * (1 + RMX_MAX_CLONES))) ||
+        (rc = dalloc(b, &b->d_rlist, R)) || (rc = dalloc(b, &b->d_counts, R)) || (rc = dalloc(b, &b->d_rp_stage, R)) || (rc = dalloc(b, &b->d_batch_out, (size_t)R * 8))) { rmx_batch_destroy(b); return rc; }
     HIPCHK(hipHostMalloc((void **)&b->h_pinned, sizeof(double) * (size_t)(R + 1) * 64 * (1 + RMX_MAX_CLONES)));
+    HIPCHK(hipHostMalloc(&b->h_batch, (size_t)R * (sizeof(RestartParams) + 64) + 4096));
     HIPCHK(hipEventCreate(&b->tm_a)); HIPCHK(hipEventCreate(&b->tm_b));
     b->done_ev.resize(R);
     for (int r = 0; r < R; r++) HIPCHK(hipEventCreateWithFlags(&b->done_ev[r], hipEventDisableTiming));
@@ -588,6 +605,7 @@ int rmx_batch_destroy(rmx_batch *b) {
     prof_collect(b);
     for (void *p : b->allocs) hipFree(p);
     if (b->h_pinned) hipHostFree(b->h_pinned);
+    if (b->h_batch) hipHostFree(b->h_batch);
     for (auto e : b->ev_pool) hipEventDestroy(e);
     if (b->tm_a) hipEventDestroy(b->tm_a);
     if (b->tm_b) hipEventDestroy(b->tm_b);
@@ -778,8 +796,47 @@ static int do_update_p_cn(rmx_batch *b, int r0, int r1) {
         a.chain_tc = d.chain_tc; a.chain_cls = d.chain_cls; a.be_cls = d.be_cls; a.amat_lds = 0; a.pad_ = 0;
         a.fe = d.fe; a.Wf = d.Wf; a.Wb = d.Wb; a.pe_lt = d.pe_lt; a.af = d.af; a.ab = d.ab; a.tot = d.tot;
         a.fa = d.fa; a.fb = d.fb; a.mrow = d.mrow; a.err = d.err; a.dbg = b->d_dbg;
-        const bool fast = b->fb_rpt > 0;
-        if (fast && b->n_fast > 0) {
+        bool fast = b->fb_rpt > 0;
+        bool done_fast = false;
+        if (b->fbv_rpt > 0 && b->n_fast > 0) {
+            // multi-vector kernel: NV restarts per workgroup, as few as keep the grid within one wave
+            // of workgroups over the 256 CUs
+            const int nr = r1 - r0;
+            int NV = 1;
+            while (NV < 4 && (long)b->n_fast * 2 * ((nr + NV - 1) / NV) > 256) NV *= 2;
+            FbvArgs v;
+            v.S = d.S; v.SP = d.SP; v.M = d.M; v.D = d.D; v.C = d.C; v.N = d.N; v.NBE = d.NBE; v.cn_max = d.cn_max;
+            v.r0 = r0; v.r1 = r1; v.pen = d.pen; v.pad_ = 0;
+            v.G2 = (d.S + 1) / 2; v.SPW = ((d.S + 63) / 64) * 64;
+            v.chain_start = d.chain_start; v.chain_end = d.chain_end; v.tclass = d.tclass; v.brk_slot = d.brk_slot;
+            v.chain_list = d.chain_list_fast; v.chain_tc = d.chain_tc; v.chain_cls = d.chain_cls;
+            v.fe = d.fe; v.Wf = d.Wf; v.Wb = d.Wb; v.pe_lt = d.pe_lt; v.af = d.af; v.ab = d.ab; v.tot = d.tot;
+            v.fa = d.fa; v.fb = d.fb; v.mrow = d.mrow; v.err = d.err; v.dbg = b->d_dbg;
+            const int rpt = b->fbv_rpt;
+            v.SPAD = ((std::max(d.S, FBV_P * rpt) + 7) / 8) * 8;
+            const int mdp = (d.M * d.D + 1) & ~1;
+            int nt = std::max(((FBV_P * v.G2 + 63) / 64) * 64 + 64, NV * v.SPW);   // + one reducer wave
+            size_t lds = 0; int blk = 8;
+            for (;;) {
+                size_t fixed = ((size_t)NV * 2 * v.SPAD + (size_t)NV * FBV_P * d.SP + NV * 4 + (size_t)NV * mdp + 128) * 8 + (size_t)FB_NBUF * 2 * 64 * 4 +
+                               (((size_t)d.C * d.S * d.M + 15) & ~(size_t)15) + 64;
+                v.amat_lds = (fixed + (size_t)d.S * d.S + (size_t)NV * FB_NBUF * 2 * d.SP * 8 <= kLdsBudget) ? 1 : 0;
+                if (v.amat_lds) fixed += (size_t)d.S * d.S;
+                blk = 8;
+                while (blk > 1 && fixed + (size_t)NV * FB_NBUF * blk * d.SP * 8 > kLdsBudget) blk--;
+                lds = fixed + (size_t)NV * FB_NBUF * blk * d.SP * 8;
+                if (lds <= kLdsBudget || NV == 1) break;
+                NV /= 2; nt = std::max(((FBV_P * v.G2 + 63) / 64) * 64 + 64, NV * v.SPW);
+            }
+            v.BLK = blk;
+            fbv_kernel_t kf = fbv_kernel_for(rpt, NV);
+            if (kf && nt <= 768 && lds <= kLdsBudget) {
+                HIPCHK(hipFuncSetAttribute((const void *)kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                hipLaunchKernelGGL(kf, dim3(b->n_fast, (nr + NV - 1) / NV, 2), dim3(nt), lds, b->stream, v);
+                done_fast = true; fast = true;
+            }
+        }
+        if (!done_fast && fast && b->n_fast > 0) {
             a.P = b->fbL.P; a.BLK = b->fbL.BLK; a.SPAD = b->fbL.SPAD; a.chain_list = d.chain_list_fast; a.amat_lds = b->fb_amat_lds;
             hipLaunchKernelGGL(fb_kernel_for(b->fb_rpt), dim3(b->n_fast, r1 - r0, 2), dim3(b->fbL.NT), b->fb_lds, b->stream, a);
         }
@@ -823,7 +880,6 @@ static int do_indicator(rmx_batch *b, int r0, int r1, int which) {
     HIPCHK(hipGetLastError());
     return RMX_OK;
 }
-#define RANGE_CHECK() if (!b || r0 < 0 || r1 > b->R || r0 >= r1) return fail(RMX_EARG, "bad restart range")
 
 int rmx_update_framelogprob(rmx_batch *b, int32_t r0, int32_t r1) { RANGE_CHECK(); int rc = do_framelogprob(b, r0, r1); return rc ? rc : check_errors(b, r0, r1); }
 int rmx_update_p_cn(rmx_batch *b, int32_t r0, int32_t r1) { RANGE_CHECK(); int rc = do_update_p_cn(b, r0, r1); return rc ? rc : check_errors(b, r0, r1); }
@@ -918,6 +974,7 @@ static int set_sample(rmx_batch *b, int r, const int64_t *sample) {
     idx.reserve(256);
     for (int n = 0; n < d.N; n++) if (sample[n] != 0) idx.push_back(n);
     b->sample_count[r] = (int)idx.size();
+    { int32_t c32 = (int32_t)idx.size(); HIPCHK(hipMemcpy(b->d_counts + r, &c32, 4, hipMemcpyHostToDevice)); }
     if (!idx.empty()) HIPCHK(hipMemcpy(b->d_sample + (size_t)r * d.N, idx.data(), idx.size() * 4, hipMemcpyHostToDevice));
     return RMX_OK;
 }
@@ -1004,6 +1061,68 @@ int rmx_expected_ll_param_grid(rmx_batch *b, int32_t r, int32_t param_id, const 
     HIPCHK(hipEventSynchronize(b->done_ev[r]));
     if (*eh) { uint32_t v = *eh; std::lock_guard<std::mutex> lk(b->mu); HIPCHK(hipMemsetAsync(b->d.err + r, 0, sizeof(uint32_t), b->stream)); return translate_error(b, r, v); }
     for (int g = 0; g < G; g++) out[g] = hp[(size_t)g * W];
+    return RMX_OK;
+}
+
+// One candidate value of one likelihood parameter per listed restart (distinct restarts), each on
+// its restart's current sample: the evaluation round of a lock-step optimiser.  Three launches and
+// one host round trip for the whole list.
+int rmx_expected_ll_batch(rmx_batch *b, int32_t nreq, const int32_t *restarts, int32_t param_id, const double *values, double *out) {
+    if (!b || nreq < 1 || nreq > b->R || !restarts || !values || !out) return fail(RMX_EARG, "bad argument");
+    if (param_id < 0 || param_id >= RMX_P_HMM_LOG_NORM_CONST) return fail(RMX_EARG, "bad param id");
+    const Dev &d = b->d;
+    const int W = 1 + RMX_MAX_CLONES;
+    std::vector<char> seen(b->R, 0);
+    int maxcnt = 0;
+    RestartParams *hs = (RestartParams *)b->h_batch;
+    int32_t *hl = (int32_t *)((char *)b->h_batch + (size_t)b->R * sizeof(RestartParams));
+    for (int i = 0; i < nreq; i++) {
+        const int r = restarts[i];
+        if (r < 0 || r >= b->R || seen[r]) return fail(RMX_EARG, "restart list must hold distinct valid restarts");
+        if (b->sample_count[r] < 0) return fail(RMX_EARG, "no sample set for a listed restart");
+        seen[r] = 1;
+        int rc = rmx_set_param(b, r, param_id, values[i]);
+        if (rc) return rc;
+        fill_logr(b->rp[r]);
+        hs[i] = b->rp[r]; hl[i] = r;
+        maxcnt = std::max(maxcnt, b->sample_count[r]);
+    }
+    {
+        std::lock_guard<std::mutex> lk(b->mu);
+        HIPCHK(hipMemcpyAsync(b->d_rp_stage, hs, (size_t)nreq * sizeof(RestartParams), hipMemcpyHostToDevice, b->stream));
+        HIPCHK(hipMemcpyAsync(b->d_rlist, hl, (size_t)nreq * 4, hipMemcpyHostToDevice, b->stream));
+        { ProfScope ps(b, KID_STATE_TABLES); hipLaunchKernelGGL(k_state_tables_list, dim3(d.C, nreq), dim3(256), 0, b->stream, b->d, (const int32_t *)b->d_rlist, (const RestartParams *)b->d_rp_stage); }
+        const int pstride = std::max(d.N, ELBO_BLOCKS) * W;
+        if (maxcnt > 0) {
+            ProfScope ps(b, KID_ELL_LIST);
+            hipLaunchKernelGGL(k_ell_list_batch, dim3(maxcnt, nreq), dim3(256), 0, b->stream, b->d, (const int32_t *)b->d_rlist, (const RestartParams *)b->d_rp_stage,
+                               (const int32_t *)b->d_sample, (const int32_t *)b->d_counts, b->d_ell_partial, pstride);
+        }
+        { ProfScope ps(b, KID_ELL_FINAL); hipLaunchKernelGGL(k_ell_final_batch, dim3(nreq), dim3(256), 0, b->stream, b->d, (const int32_t *)b->d_rlist, (const int32_t *)b->d_counts,
+                                                             (const double *)b->d_ell_partial, pstride, b->d_batch_out); }
+        HIPCHK(hipGetLastError());
+        for (int i = 0; i < nreq; i++) { b->tables_dirty[restarts[i]] = 0; b->segc_dirty[restarts[i]] = 1; b->ab_dirty[restarts[i]] = 1; }
+        HIPCHK(hipMemcpyAsync(b->h_pinned, b->d_batch_out, (size_t)nreq * 8, hipMemcpyDeviceToHost, b->stream));
+    }
+    int rc = check_errors(b, 0, b->R);
+    if (rc) return rc;
+    for (int i = 0; i < nreq; i++) out[i] = b->h_pinned[i];
+    return RMX_OK;
+}
+
+// Full-data E[ll] (sample of all ones, :1125-1157) for a restart range from the per-segment
+// expectations (refreshed first if h / a parameter changed).
+int rmx_expected_ll_full(rmx_batch *b, int32_t r0, int32_t r1, double *out) {
+    RANGE_CHECK();
+    int rc = ensure_ab(b, r0, r1);
+    if (rc) return rc;
+    const int nr = r1 - r0;
+    { ProfScope ps(b, KID_ELL_FULL); hipLaunchKernelGGL(k_ell_full_batch, dim3(ELBO_BLOCKS, nr), dim3(256), 0, b->stream, b->d, r0, b->d_partial); }
+    { ProfScope ps(b, KID_ELL_FINAL); hipLaunchKernelGGL(k_sum_partials, dim3(nr), dim3(256), 0, b->stream, (const double *)b->d_partial, ELBO_BLOCKS, b->d_out4); }
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(b->h_pinned, b->d_out4, (size_t)nr * 8, hipMemcpyDeviceToHost, b->stream));
+    if ((rc = check_errors(b, r0, r1))) return rc;
+    for (int i = 0; i < nr; i++) out[i] = b->h_pinned[i];
     return RMX_OK;
 }
 

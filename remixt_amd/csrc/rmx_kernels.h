@@ -454,6 +454,290 @@ __global__ __launch_bounds__(NTMAX) void k_fb(FbArgs a) {
 }
 
 // =============================================================================
+// k_fbv: the production forward-backward kernel.  Same recursion as k_fb, but ONE workgroup advances
+// NV restarts of the same (chain, direction) in lock step.  The plain-adjacency weights do not depend
+// on the restart, so they are held in registers once (2 output columns x RPT rows per thread, P = 8
+// row slices) and every LDS vector value feeds two FMAs; the latency chain of a step (two barriers,
+// the partial-sum hand-off, the maximum) is paid once for NV vectors instead of once per vector.
+//   thread t (phase 1):  g = t % G2 (column pair 2g, 2g+1), p = t / G2 (row slice), t < 8*G2
+//   thread t (phase 2):  v = t / SPW (vector), o = t % SPW (state), SPW = ceil(S/64)*64
+// Only chains whose segments share one state-table class come here (chain_tc >= 0).
+// =============================================================================
+#define FBV_P 8
+struct FbvArgs {
+    int S, SP, M, D, C, N, NBE, cn_max, BLK, SPAD, r0, r1, amat_lds, G2, SPW, pad_;
+    double pen;
+    const int32_t *chain_start, *chain_end, *tclass, *brk_slot, *chain_list, *chain_tc, *chain_cls;
+    const double *fe, *Wf, *Wb, *pe_lt;
+    const int8_t *af, *ab, *tot;
+    double *fa, *fb, *mrow;
+    uint32_t *err;
+    unsigned long long *dbg;
+};
+
+template <int RPT, int NV, int NTMAX>
+__global__ __launch_bounds__(NTMAX) void k_fbv(FbvArgs a) {
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    const int chain = a.chain_list[blockIdx.x], dir = blockIdx.z;
+    const int rg0 = a.r0 + blockIdx.y * NV;                 // first restart of this group
+    const int nv = min(NV, a.r1 - rg0);                     // vectors actually present
+    const int S = a.S, M = a.M, D = a.D, SP = a.SP, G2 = a.G2, SPW = a.SPW;
+    const int n0 = a.chain_start[chain], n1 = a.chain_end[chain], len = n1 - n0 + 1;
+    const int t = threadIdx.x, NT = blockDim.x;
+    const int p = t / G2, g = t - p * G2;
+    const int o0 = 2 * g, o1 = 2 * g + 1;
+    const bool act = p < FBV_P;                             // phase-1 worker
+    const int pv = t / SPW, po = t - pv * SPW;              // phase-2 role
+    const bool post = pv < nv && po < S;
+    const bool postwave = pv < nv;                          // wave-uniform (SPW is a multiple of 64)
+    // The maximum of the vector published in step k-1 is only needed in phase 2 of step k: one
+    // otherwise idle wave (the last one) computes it during phase 1 of step k, off everybody's path.
+    const bool reducer = (t >> 6) == (NT >> 6) - 1;
+    const int lane = t & 63;
+    // the reducer's short dependent chain must not queue behind its SIMD neighbours' FMA streams
+    if (__builtin_amdgcn_readfirstlane((int)reducer)) __builtin_amdgcn_s_setprio(3);
+    const int SPAD = a.SPAD, BLK = a.BLK;
+    const int MDP = (M * D + 1) & ~1;
+    // ---- LDS carve-up -----------------------------------------------------------------------
+    double *ebuf = (double *)smem_raw;                          // [NV][NBUF][BLK][SP]  emission rings (LDS-DMA)
+    double *vec = ebuf + (size_t)NV * FB_NBUF * BLK * SP;       // [NV][2][SPAD]
+    double *part = vec + (size_t)NV * 2 * SPAD;                 // [NV][P][SP]
+    double *red = part + (size_t)NV * FBV_P * SP;               // [NV][4]: [v][0] = 1/max of the current vector
+    double *pel = red + NV * 4;                                 // [NV][MDP]
+    double *wa = pel + (size_t)NV * MDP;                        // [128]
+    int *meta = (int *)(wa + 128);                              // [NBUF][2][64]
+    int8_t *totl = (int8_t *)(meta + FB_NBUF * 2 * 64);         // [C][S][M]
+    int8_t *atl = totl + ((a.C * S * M + 15) & ~15);            // [S][S]
+    for (int i = t; i < a.C * S * M; i += NT) totl[i] = a.tot[i];
+    if (a.amat_lds) {
+        const int8_t *src = (dir == 0 ? a.af : a.ab) + (size_t)a.chain_tc[chain] * S * S;
+        for (int i = t; i < S * S; i += NT) atl[i] = src[i];
+    }
+    for (int i = t; i < NV * 2 * SPAD; i += NT) vec[i] = 0.;
+    for (int i = t; i < 128; i += NT) wa[i] = exp(-a.pen * (double)i);
+    for (int i = t; i < FB_NBUF * 2 * 64; i += NT) meta[i] = -1;
+    if (t < NV * 4) red[t] = 0.;
+
+    const double *Wmat = (dir == 0 ? a.Wf : a.Wb) + (size_t)a.chain_tc[chain] * S * S;
+    // ---- stationary weights: 2 columns x RPT rows, consumed before the loop --------------------
+    double w0[RPT], w1[RPT];
+#pragma unroll
+    for (int rr = 0; rr < RPT; rr++) {
+        const int q = p * RPT + rr;
+        w0[rr] = (act && q < S && o0 < S) ? Wmat[(size_t)q * S + o0] : 0.;
+        w1[rr] = (act && q < S && o1 < S) ? Wmat[(size_t)q * S + o1] : 0.;
+    }
+#pragma unroll
+    for (int rr = 0; rr < RPT; rr++) { asm volatile("" ::"v"(w0[rr])); asm volatile("" ::"v"(w1[rr])); }
+    int chain_cls_ = __builtin_amdgcn_readfirstlane(a.chain_cls[chain]);
+    asm volatile("" : "+s"(chain_cls_));
+    __syncthreads();
+
+#define ROW(k) (dir == 0 ? n0 + (k) : n1 - (k))
+    const int nblk = (len + BLK - 1) / BLK;
+    const int elems = BLK * SP / 2;                       // 16-byte elements per block and vector
+    const int wave_base = (t >> 6) << 6;
+    // emission rows of block b_ for all vectors + step metadata, by LDS-DMA
+#define FBV_ISSUE(b_)                                                                                                  \
+    {                                                                                                                  \
+        const int slot_ = (b_) % FB_NBUF;                                                                              \
+        const int rs_ = dir == 0 ? n0 + (b_) * BLK : n1 - (b_) * BLK - (BLK - 1);                                      \
+        for (int v_ = 0; v_ < nv; v_++) {                                                                              \
+            const double *src_ = a.fe + ((size_t)(rg0 + v_) * a.N + rs_) * SP;                                         \
+            for (int i0 = 0; i0 < elems; i0 += NT) {                                                                   \
+                const int idx = i0 + t;                                                                                \
+                const int row_ = rs_ + (idx * 2) / SP;                                                                 \
+                const unsigned dst_ = __builtin_amdgcn_readfirstlane(                                                  \
+                    lds_addr(ebuf + ((size_t)v_ * FB_NBUF + slot_) * BLK * SP + (size_t)(i0 + wave_base) * 2));         \
+                if (idx < elems && row_ >= n0 && row_ <= n1) glds16(src_ + (size_t)idx * 2, dst_);                     \
+            }                                                                                                          \
+        }                                                                                                              \
+        if (t < 64) {                                                                                                  \
+            const int tn_ = (dir == 0 ? n0 + (b_) * BLK - 1 : n1 - (b_) * BLK - (BLK - 1)) + t;                        \
+            const unsigned d0_ = __builtin_amdgcn_readfirstlane(lds_addr(meta + (slot_ * 2 + 0) * 64));                 \
+            const unsigned d1_ = __builtin_amdgcn_readfirstlane(lds_addr(meta + (slot_ * 2 + 1) * 64));                 \
+            if (t < BLK && tn_ >= n0 && tn_ < n1) { glds4(a.tclass + tn_, d0_); glds4(a.brk_slot + tn_, d1_); }        \
+        }                                                                                                              \
+    }
+    FBV_ISSUE(0)
+    if (nblk > 1) FBV_ISSUE(1)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (nblk > 2) FBV_ISSUE(2)
+    FB_BARRIER();
+
+    // ---- step 0 ---------------------------------------------------------------------------------
+    const int rstep = dir == 0 ? SP : -SP;
+    double *outp = (dir == 0 ? a.fa : a.fb) + ((size_t)(rg0 + (postwave ? pv : 0)) * a.N + ROW(0)) * SP + po;
+    if (post) {
+        const double e0 = ebuf[((size_t)pv * FB_NBUF * BLK + (dir == 0 ? 0 : BLK - 1)) * SP + po];
+        vec[(size_t)pv * 2 * SPAD + po] = e0;
+        gstore8(outp, (dir == 0) ? e0 : 1.0);
+    }
+    FB_BARRIER();
+
+    // reducer: maximum of vector v (buffer buf) -> red[v][0] = 1/max, row maximum to mrow (forward)
+    double *mrow_r = a.mrow + (size_t)rg0 * a.N + ROW(0);      // advanced by the reducer lane 0
+#define FBV_REDUCE(buf_)                                                                                   \
+    {                                                                                                      \
+        /* S <= 8*RPT <= 192: three values per lane and vector; all loads first, then NV independent */    \
+        /* cross-lane chains the scheduler can interleave                                            */    \
+        double mx_[NV];                                                                                    \
+        _Pragma("unroll") for (int v_ = 0; v_ < NV; v_++) {                                                \
+            const double *src_ = vec + ((size_t)v_ * 2 + (buf_)) * SPAD;                                   \
+            const double x0_ = src_[lane];                                                                 \
+            const double x1_ = lane + 64 < S ? src_[lane + 64] : 0.;                                       \
+            const double x2_ = lane + 128 < S ? src_[lane + 128] : 0.;                                     \
+            double m_ = (lane < S && x0_ == x0_) ? x0_ : (lane < S ? INFINITY : 0.);                       \
+            m_ = fmax(m_, x1_ == x1_ ? x1_ : INFINITY);                                                    \
+            m_ = fmax(m_, x2_ == x2_ ? x2_ : INFINITY);                                                    \
+            mx_[v_] = m_;                                                                                  \
+        }                                                                                                  \
+        _Pragma("unroll") for (int v_ = 0; v_ < NV; v_++) mx_[v_] = wave_max_nonneg(mx_[v_]);              \
+        _Pragma("unroll") for (int v_ = 0; v_ < NV; v_++)                                                  \
+            if (lane == 0 && v_ < nv) { red[v_ * 4] = fast_rcp(mx_[v_]); red[v_ * 4 + 1] = mx_[v_]; if (dir == 0) gstore8(mrow_r + (size_t)v_ * a.N, mx_[v_]); } \
+    }
+
+    int b = 0, kk = 0, slot = 0, cur = 0, nxt = 1;
+#ifdef RMX_FB_STAMPS
+    unsigned long long stamp_acc[6] = {0, 0, 0, 0, 0, 0}, stamp_last;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_last) :: "memory");
+#endif
+    if (a.dbg && t == 0 && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0) { a.dbg[0] = clock64(); a.dbg[1] = wall_clock64(); a.dbg[4] = len; }
+    for (int k = 1; k < len; k++) {
+        FB_STAMP(0)
+        if (++kk == BLK) { kk = 0; b++; slot = slot + 1 == FB_NBUF ? 0 : slot + 1; }
+        const int kidx = dir == 0 ? kk : BLK - 1 - kk;
+        const int bs = meta[(slot * 2 + 1) * 64 + kidx];
+        // phase-2 operand that is already final: fetched now, latency hidden under phase 1
+        double e = 0.;
+        if (post) e = ebuf[(((size_t)pv * FB_NBUF + slot) * BLK + kidx) * SP + po];
+        FB_STAMP(1)
+        // ============================ phase 1 ============================
+        double acc0[NV], acc1[NV];
+#pragma unroll
+        for (int v = 0; v < NV; v++) { acc0[v] = 0.; acc1[v] = 0.; }
+        if (reducer) {
+            FBV_REDUCE(cur)
+            mrow_r += (dir == 0 ? 1 : -1);
+        }
+        if (bs < 0 && !reducer) {
+            // stages of SW LDS reads (2*SW rows), software-pipelined one stage ahead across rows and
+            // vectors; narrower stages where the weights already fill most of the register budget
+            constexpr int SW = (RPT >= 22) ? 2 : 4;
+            constexpr int NCH = (RPT + 2 * SW - 1) / (2 * SW);      // stages per vector
+            double2 st[2][SW];
+            const double *vbase = vec + (size_t)cur * SPAD + p * RPT;
+#pragma unroll
+            for (int u = 0; u < SW; u++) if (2 * u < RPT) st[0][u] = *reinterpret_cast<const double2 *>(vbase + 2 * u);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int sidx = 0; sidx < NV * NCH; sidx++) {
+                const int v = sidx / NCH, c = sidx % NCH, c0 = c * 2 * SW;
+                if (sidx + 1 < NV * NCH) {
+                    const int v2 = (sidx + 1) / NCH, c2 = ((sidx + 1) % NCH) * 2 * SW;
+                    const double *src = vec + ((size_t)v2 * 2 + cur) * SPAD + p * RPT + c2;
+#pragma unroll
+                    for (int u = 0; u < SW; u++) if (c2 + 2 * u < RPT) st[(sidx + 1) & 1][u] = *reinterpret_cast<const double2 *>(src + 2 * u);
+                }
+#pragma unroll
+                for (int u = 0; u < SW; u++)
+                    if (c0 + 2 * u < RPT) {
+                        const double2 x = st[sidx & 1][u];
+                        acc0[v] = fma(x.x, w0[c0 + 2 * u], acc0[v]); acc1[v] = fma(x.x, w1[c0 + 2 * u], acc1[v]);
+                        acc0[v] = fma(x.y, w0[c0 + 2 * u + 1], acc0[v]); acc1[v] = fma(x.y, w1[c0 + 2 * u + 1], acc1[v]);
+                    }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else if (bs >= 0) {
+            // ---- breakend adjacency: restart-specific weights prod_m pe_m[d_m] * exp(-pen*a) ----
+            const int tc = meta[(slot * 2 + 0) * 64 + kidx];
+            if (t < 64) {
+                for (int v = 0; v < nv; v++) {
+                    const unsigned dpe = __builtin_amdgcn_readfirstlane(lds_addr(pel + (size_t)v * MDP));
+                    if (t * 2 < MDP) glds16(a.pe_lt + ((size_t)(rg0 + v) * a.NBE + bs) * MDP + t * 2, dpe);
+                }
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            FB_BARRIER();
+            const int8_t *at = a.amat_lds ? atl : ((dir == 0 ? a.af : a.ab) + (size_t)tc * S * S);
+            const int8_t *tcl = totl + (size_t)chain_cls_ * S * M;
+            const int sgn = dir == 0 ? 1 : -1;
+            if (act) {
+                for (int rr = 0; rr < RPT; rr++) {
+                    const int q = p * RPT + rr;
+                    if (q >= S) break;
+#pragma unroll
+                    for (int col = 0; col < 2; col++) {
+                        const int o = col == 0 ? o0 : o1;
+                        if (o < S) {
+                            const double wbase = wa[(int)at[(size_t)q * S + o]];
+                            int dd[RMX_MAX_CLONES];
+#pragma unroll
+                            for (int c = 0; c < RMX_MAX_CLONES; c++) dd[c] = c < M ? sgn * ((int)tcl[(size_t)q * M + c] - (int)tcl[(size_t)o * M + c]) + a.cn_max + 1 : 0;
+#pragma unroll
+                            for (int v = 0; v < NV; v++) {
+                                if (v < nv) {
+                                    double wv = wbase;
+#pragma unroll
+                                    for (int c = 0; c < RMX_MAX_CLONES; c++) if (c < M) wv *= pel[(size_t)v * MDP + c * D + dd[c]];
+                                    const double x = vec[((size_t)v * 2 + cur) * SPAD + q];
+                                    if (col == 0) acc0[v] = fma(x, wv, acc0[v]); else acc1[v] = fma(x, wv, acc1[v]);
+                                }
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        FB_STAMP(2)
+        if (act) {
+#pragma unroll
+            for (int v = 0; v < NV; v++) {
+                double2 pr; pr.x = acc0[v]; pr.y = acc1[v];
+                *reinterpret_cast<double2 *>(part + ((size_t)v * FBV_P + p) * SP + o0) = pr;
+            }
+        }
+        FB_BARRIER();
+        FB_STAMP(3)
+        // ============================ phase 2 ============================
+        outp += rstep;
+        if (post) {
+            const double inv = red[pv * 4];
+            const double *pp_ = part + (size_t)pv * FBV_P * SP + po;
+            const double s0 = pp_[0], s1 = pp_[SP], s2 = pp_[2 * SP], s3 = pp_[3 * SP];
+            const double s4 = pp_[4 * SP], s5 = pp_[5 * SP], s6 = pp_[6 * SP], s7 = pp_[7 * SP];
+            const double sum = ((((((s0 + s1) + s2) + s3) + s4) + s5) + s6) + s7;
+            const double val = sum * inv;
+            const double vecv = val * e;
+            vec[((size_t)pv * 2 + nxt) * SPAD + po] = vecv;
+            gstore8(outp, (dir == 0) ? vecv : val);
+        }
+        if (kk == 0 && b >= 1) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (b + 2 < nblk) FBV_ISSUE(b + 2)
+        }
+        cur ^= 1; nxt ^= 1;
+        FB_STAMP(4)
+        FB_BARRIER();
+        FB_STAMP(5)
+    }
+    if (a.dbg && t == 0 && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0) { a.dbg[2] = clock64(); a.dbg[3] = wall_clock64(); }
+#ifdef RMX_FB_STAMPS
+    if (a.dbg && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && (t == 0 || t == NT - 64)) for (int i = 0; i < 6; i++) a.dbg[8 + (t == 0 ? 0 : 6) + i] = stamp_acc[i];
+#endif
+    if (reducer) {
+        // last row of each chain: its maximum is not consumed by a later step, but hmm_log_norm_const
+        // and the vanishing-row check need it
+        FBV_REDUCE(cur)
+        if (lane == 0)
+            for (int v_ = 0; v_ < nv; v_++) { const double m = red[v_ * 4 + 1]; if (!(m > 0.) || m == INFINITY) atomicOr(&a.err[rg0 + v_], RMX_ERR_NAN_AB); }
+    }
+#undef FBV_REDUCE
+#undef ROW
+#undef FBV_ISSUE
+}
+
+// =============================================================================
 // posterior marginals + per-segment likelihood expectations
 //   post[n,s]  = softmax(alpha+beta) (bpmodel.pyx:948-950) == fa*fb / sum
 //   A[n,u]     = sum_s post * LT_u          B[n,vw] = sum_s post * LA_vw
@@ -897,6 +1181,83 @@ __global__ void k_ell_full(Dev d, int r, double *partial) {
     }
     acc = block_sum<256>(acc, scratch);
     if (threadIdx.x == 0) partial[(size_t)blockIdx.x * (1 + RMX_MAX_CLONES)] = acc;
+}
+
+// ---- batched M-step objective: one candidate parameter set per listed restart -------------------
+// (the restarts' optimisers advance in lock step on the host; each round costs three launches for
+// all restarts instead of three per restart)
+// grid (C, nreq): publish the staged parameters of request i to restart rlist[i] and rebuild its tables
+__global__ void k_state_tables_list(Dev d, const int32_t *rlist, const RestartParams *stage) {
+    const int r = rlist[blockIdx.y];
+    const RestartParams rp = stage[blockIdx.y];
+    if (blockIdx.x == 0 && threadIdx.x == 0) d.rp[r] = rp;
+    state_tables_body(d, blockIdx.x, r, rp);
+}
+// grid (maxcount, nreq): block (i, j) evaluates sampled segment i of restart rlist[j]
+__global__ void k_ell_list_batch(Dev d, const int32_t *rlist, const RestartParams *stage, const int32_t *samples, const int32_t *counts,
+                                 double *partial, int pstride) {
+    __shared__ double scratch[8];
+    __shared__ double segk[8];
+    const int r = rlist[blockIdx.y];
+    if ((int)blockIdx.x >= counts[r]) return;
+    const int n = samples[(size_t)r * d.N + blockIdx.x];
+    const RestartParams &rp = stage[blockIdx.y];    // identical to d.rp[r]; read from the stage to stay independent of launch order
+    SegCtx sc;
+    sc.x = d.x[n]; sc.l = d.l[n]; sc.logl = d.logl[n]; sc.y0 = d.y[2 * (size_t)n]; sc.y1 = d.y[2 * (size_t)n + 1]; sc.ys = sc.y0 + sc.y1;
+    sc.mt = d.mask_t[n]; sc.ma = d.mask_a[n];
+    if (threadIdx.x < 8) segk[threadIdx.x] = seg_const_value(rp, sc.x, sc.y0, sc.ys, threadIdx.x);
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; i++) { sc.cnb[i] = segk[i]; sc.cbb[i] = segk[4 + i]; }
+    const int cls = d.seg_class[n];
+    const size_t rn = (size_t)r * d.N + n;
+    const double qt0 = d.qt[rn * 2], qt1 = d.qt[rn * 2 + 1], qa0 = d.qa[rn * 2], qa1 = d.qa[rn * 2 + 1];
+    const double qs0 = d.qs[rn * 2], qs1 = d.qs[rn * 2 + 1];
+    const double *post = d.post + rs_off(d, r, n);
+    unsigned err = 0;
+    double acc = 0.;
+    for (int s = threadIdx.x; s < d.S; s += 256) {
+        double LT[2], LA[4];
+        cell_ll(d, rp, sc, r, cls, s, LT, LA, err);
+        const double ps = post[s];
+        acc += ps * qt0 * LT[0]; acc += ps * qt1 * LT[1];
+        acc += ps * qa0 * qs0 * LA[0]; acc += ps * qa0 * qs1 * LA[1]; acc += ps * qa1 * qs0 * LA[2]; acc += ps * qa1 * qs1 * LA[3];
+    }
+    acc = block_sum<256>(acc, scratch);
+    if (threadIdx.x == 0) partial[(size_t)r * pstride + (size_t)blockIdx.x * (1 + RMX_MAX_CLONES)] = acc;
+    if (err) atomicOr(&d.err[r], err);
+}
+// grid (nreq): deterministic sum of restart rlist[j]'s partials -> out[j]
+__global__ void k_ell_final_batch(Dev d, const int32_t *rlist, const int32_t *counts, const double *partial, int pstride, double *out) {
+    __shared__ double scratch[8];
+    const int r = rlist[blockIdx.x];
+    const int W = 1 + RMX_MAX_CLONES;
+    double a = 0.;
+    for (int i = threadIdx.x; i < counts[r]; i += 256) a += partial[(size_t)r * pstride + (size_t)i * W];
+    a = block_sum<256>(a, scratch);
+    if (threadIdx.x == 0) out[blockIdx.x] = a;
+}
+// full-data E[ll] from (A, B) for a restart range: grid (ELBO_BLOCKS, nr) -> partial[(r-r0)][blk]
+__global__ void k_ell_full_batch(Dev d, int r0, double *partial) {
+    __shared__ double scratch[8];
+    const int r = r0 + blockIdx.y;
+    double acc = 0.;
+    for (int n = blockIdx.x * blockDim.x + threadIdx.x; n < d.N; n += gridDim.x * blockDim.x) {
+        const size_t rn = (size_t)r * d.N + n;
+        const double qt0 = d.qt[rn * 2], qt1 = d.qt[rn * 2 + 1], qa0 = d.qa[rn * 2], qa1 = d.qa[rn * 2 + 1];
+        const double qs0 = d.qs[rn * 2], qs1 = d.qs[rn * 2 + 1];
+        acc += qt0 * d.A[rn * 2] + qt1 * d.A[rn * 2 + 1];
+        acc += qa0 * qs0 * d.Bv[rn * 4] + qa0 * qs1 * d.Bv[rn * 4 + 1] + qa1 * qs0 * d.Bv[rn * 4 + 2] + qa1 * qs1 * d.Bv[rn * 4 + 3];
+    }
+    acc = block_sum<256>(acc, scratch);
+    if (threadIdx.x == 0) partial[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = acc;
+}
+__global__ void k_sum_partials(const double *partial, int n, double *out) {   // grid (nr)
+    __shared__ double scratch[8];
+    double a = 0.;
+    for (int i = threadIdx.x; i < n; i += 256) a += partial[(size_t)blockIdx.x * n + i];
+    a = block_sum<256>(a, scratch);
+    if (threadIdx.x == 0) out[blockIdx.x] = a;
 }
 
 // hmm_log_norm_const = sum of the per-row shares (bpmodel.pyx:946).  grid 1, block 256

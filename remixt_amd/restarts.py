@@ -18,10 +18,11 @@ class RestartSet(object):
     """R restarts of one experiment advancing in lockstep on one device."""
 
     def __init__(self, experiment, init_params, max_copy_number, num_clones=3, device=0, quiet=True,
-                 kernel_module=None, seeds=None, strict=False, mstep_threads=8, **model_kwargs):
+                 kernel_module=None, seeds=None, strict=False, mstep_threads=8, lockstep=True, **model_kwargs):
         self.experiment = experiment
         self.strict = strict
         self.mstep_threads = mstep_threads
+        self.lockstep = lockstep
         self.error_messages = {}
         self.init_params = list(init_params)
         R = len(self.init_params)
@@ -80,6 +81,11 @@ class RestartSet(object):
         scipy M-steps, batched ELBO."""
         self.variational_update(num_update_iter)
 
+        # Lock-step parameter search needs the batched device objective and a private RNG stream per
+        # restart (so that the order in which restarts draw their samples does not matter).
+        lockstep = (self.lockstep and self.batch is not None and hasattr(self.batch, 'expected_log_likelihood_batch') and
+                    all(m.rng is not None for m in self.models))
+
         def mstep(r):
             m = self.models[r]
             if m.do_h_update:
@@ -94,7 +100,8 @@ class RestartSet(object):
                         raise
                     m.model.h = h_before
                     self.error_messages[r] = str(err).splitlines()[0] + ' (h kept)'
-            m.em_update_params()
+            if not lockstep:
+                m.em_update_params()
 
         # The M-steps are host-latency-bound (hundreds of tiny objective evaluations per restart,
         # each a device round trip): restarts run on host threads so one restart's round trip
@@ -109,10 +116,52 @@ class RestartSet(object):
         else:
             for r in range(len(self.models)):
                 mstep(r)
+        if lockstep:
+            self._update_params_lockstep()
         elbo = self.calculate_elbo()
         for m, e in zip(self.models, elbo):
             m.record_elbo(float(e), i)
         return elbo
+
+    def _update_params_lockstep(self):
+        """BreakpointModel.em_update_params (cn_model.py:468-473, 533-569) for all restarts at once:
+        per restart exactly the evaluation sequence of update_param -- full-data E[ll], weighted
+        sample, 20-point grid, Nelder-Mead polish, full-data E[ll], accept / reject -- but every round
+        of evaluations is one batched device call (remixt_amd/lockstep.py)."""
+        from . import lockstep
+        b = self.batch
+        R = len(self.models)
+        ids_all = list(range(R))
+        for name in self.models[0].likelihood_params:
+            lo, hi = self.models[0].likelihood_param_bounds[name]
+            weights = [m.get_param_sample_weight(name) for m in self.models]
+            value_before = [b.get_param(r, name) for r in ids_all]
+            ell_before = b.expected_log_likelihood_full(0, R)
+            for r, m in enumerate(self.models):
+                b._use_sample(r, m._create_sample(weights[r]))
+            grid = np.mgrid[lo:hi:complex(20)]
+            J = np.empty((R, len(grid)))
+            for gi, gv in enumerate(grid):
+                J[:, gi] = -b.expected_log_likelihood_batch(ids_all, name, np.full(R, gv))
+            xmin = grid[np.argmin(J, axis=1)]
+
+            def evaluate(ids, xs):
+                vals = [float(x[0]) for x in xs]
+                out = [np.inf] * len(ids)          # outside the bounds: inf, model untouched (cn_model.py:542-543)
+                sel = [k for k, v in enumerate(vals) if not (v < lo or v > hi)]
+                if sel:
+                    res = b.expected_log_likelihood_batch([ids[k] for k in sel], name, [vals[k] for k in sel])
+                    for k, e in zip(sel, res):
+                        out[k] = -float(e)
+                return out
+            results = lockstep.run_lockstep([lockstep.fmin_1d(xmin[r]) for r in ids_all], evaluate)
+            ell_after = b.expected_log_likelihood_full(0, R)
+            for r, m in enumerate(self.models):
+                if ell_after[r] < ell_before[r]:
+                    m._log('{} rejected, elbo before: {}, after: {}'.format(name, ell_before[r], ell_after[r]))
+                    b.set_param(r, name, value_before[r])
+                else:
+                    b.set_param(r, name, float(results[r][0][0]))
 
     def fit(self, num_em_iter=5, num_update_iter=5):
         elbo0 = self.calculate_elbo()

@@ -184,3 +184,19 @@ def test_fb_register_and_generic_paths_agree(hip):
     assert np.isclose(outs[0][1], outs[1][1], rtol=1e-12) and np.isclose(outs[0][2], outs[1][2], rtol=1e-12)
     assert np.array_equal(outs[0][0], outs[2][0]) and outs[0][1] == outs[2][1] and outs[0][2] == outs[2][2]
     assert np.array_equal(outs[0][3], outs[2][3])
+
+
+def test_lockstep_mstep_equals_per_restart_mstep(hip):
+    """The batched lock-step parameter search gives every restart exactly what its own sequential
+    brute + fmin search gives (same evaluation sequence per restart)."""
+    from remixt_amd import synthetic
+    from remixt_amd.restarts import RestartSet
+    e = synthetic.make_experiment(600, num_clones=3, max_copy_number=3, num_chains=5, seed=6)
+    ps = synthetic.make_init_params(e, 4, 3)
+    out = []
+    for lock in (True, False):
+        rs = RestartSet(e, ps, max_copy_number=3, num_clones=3, quiet=True, seeds=[5, 6, 7, 8], lockstep=lock, mstep_threads=1)
+        rs.fit(num_em_iter=2, num_update_iter=2)
+        out.append([(m.prev_elbo, np.array(m.h), m.get_likelihood_param_values()) for m in rs.models])
+    for (e1, h1, p1), (e2, h2, p2) in zip(*out):
+        assert e1 == e2 and np.array_equal(h1, h2) and p1 == p2
