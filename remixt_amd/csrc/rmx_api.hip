@@ -50,6 +50,7 @@ struct rmx_batch {
     // per-restart host state
     std::vector<RestartParams> rp;
     std::vector<char> tables_dirty, segc_dirty, ab_dirty;
+    std::vector<int> comp_dirty;       // which components of (A, B, PF/PP) are stale: CM_* bits, 16 = PF/PP
     std::vector<int> lt_valid;
     std::vector<double> plain_T_init;  // [R]
     std::vector<double> logZ;          // last hmm_log_norm_const
@@ -327,6 +328,34 @@ static int ensure_tables(rmx_batch *b, int r0, int r1, bool need_segc = true) {
     HIPCHK(hipGetLastError());
     return RMX_OK;
 }
+// ---- strip kernels (S > 32, at most 4 states per lane) --------------------------------------------
+typedef void (*cells_kernel_t)(Dev, int);
+template <int NS> static cells_kernel_t cells_kernel_ns(int mode, int mask) {
+    if (mode == 0) return k_cells<NS, 0, CM_ALL>;
+    if (mode == 1) return k_cells<NS, 1, CM_ALL>;
+    switch (mask) {
+    case 3: return k_cells<NS, 2, 3>; case 4: return k_cells<NS, 2, 4>; case 8: return k_cells<NS, 2, 8>;
+    case 12: return k_cells<NS, 2, 12>; case 15: return k_cells<NS, 2, 15>; default: return k_cells<NS, 2, 31>;
+    }
+}
+static bool use_strip(rmx_batch *b) { return b->d.S > 32 && b->d.S <= 256 && !getenv("RMX_NO_STRIP"); }
+static cells_kernel_t cells_kernel(rmx_batch *b, int mode, int mask) {
+    const int ns = (b->d.S + 63) / 64;
+    switch (ns) { case 1: return cells_kernel_ns<1>(mode, mask); case 2: return cells_kernel_ns<2>(mode, mask);
+                  case 3: return cells_kernel_ns<3>(mode, mask); default: return cells_kernel_ns<4>(mode, mask); }
+}
+static dim3 strip_grid(rmx_batch *b, int nr) { return dim3((b->d.N + 4 * STRIP_RPW - 1) / (4 * STRIP_RPW), nr); }
+// smallest instantiated component mask covering `m`
+static int cover_mask(int m) {
+    if (m & 16) return 31;
+    if ((m & 3) && (m & 12)) return 15;
+    if (m & 3) return 3;
+    if ((m & 12) == 12) return 12;
+    if (m & 4) return 4;
+    if (m & 8) return 8;
+    return 0;
+}
+
 static dim3 row_grid(rmx_batch *b, int nr) { int rows = 256 / b->G; return dim3((b->d.N + rows - 1) / rows, nr); }
 
 static int ensure_ab(rmx_batch *b, int r0, int r1) {
@@ -335,10 +364,16 @@ static int ensure_ab(rmx_batch *b, int r0, int r1) {
     int r = r0;
     while (r < r1) {
         if (!b->ab_dirty[r]) { r++; continue; }
+        // contiguous run of restarts whose stale components are covered by the same kernel
+        const int mask = use_strip(b) ? cover_mask(b->comp_dirty[r]) : 31;
         int e = r;
-        while (e < r1 && b->ab_dirty[e]) e++;
-        { ProfScope ps(b, KID_MARGINALS_AB); hipLaunchKernelGGL(k_marginals<false>, row_grid(b, e - r), dim3(256), 0, b->stream, b->d, r, b->G); }
-        for (int i = r; i < e; i++) b->ab_dirty[i] = 0;
+        while (e < r1 && b->ab_dirty[e] && (use_strip(b) ? cover_mask(b->comp_dirty[e]) : 31) == mask) e++;
+        if (use_strip(b)) {
+            if (mask) { ProfScope ps(b, KID_MARGINALS_AB); hipLaunchKernelGGL(cells_kernel(b, 2, mask), strip_grid(b, e - r), dim3(256), 0, b->stream, b->d, r); }
+        } else {
+            ProfScope ps(b, KID_MARGINALS_AB); hipLaunchKernelGGL(k_marginals<false>, row_grid(b, e - r), dim3(256), 0, b->stream, b->d, r, b->G);
+        }
+        for (int i = r; i < e; i++) { b->ab_dirty[i] = 0; b->comp_dirty[i] = 0; }
         r = e;
     }
     HIPCHK(hipGetLastError());
@@ -545,7 +580,7 @@ int rmx_batch_create(const rmx_problem *pr, int32_t R, const double *h_init, con
 
     // per-restart initial state (bpmodel.pyx:546-597)
     b->sample_cache.assign(R, std::vector<int64_t>()); b->sample_count.assign(R, -1);
-    b->rp.resize(R); b->tables_dirty.assign(R, 1); b->segc_dirty.assign(R, 1); b->ab_dirty.assign(R, 1); b->lt_valid.assign(R, 0); b->logZ.assign(R, 0.); b->logz_dirty.assign(R, 0);
+    b->rp.resize(R); b->tables_dirty.assign(R, 1); b->segc_dirty.assign(R, 1); b->ab_dirty.assign(R, 1); b->comp_dirty.assign(R, 31); b->lt_valid.assign(R, 0); b->logZ.assign(R, 0.); b->logz_dirty.assign(R, 0);
     for (int r = 0; r < R; r++) {
         RestartParams &p = b->rp[r];
         memset(&p, 0, sizeof p);
@@ -642,6 +677,8 @@ int rmx_set_param(rmx_batch *b, int32_t r, int32_t id, double v) {
     if (r < 0 || r >= b->R || id < 0 || id >= RMX_P_HMM_LOG_NORM_CONST) return fail(RMX_EARG, "bad restart / param id");
     if (id == RMX_P_DIVERGENCE_WEIGHT) v = std::fabs(v);
     b->rp[r].p[id] = v; b->tables_dirty[r] = 1; b->ab_dirty[r] = 1;
+    static const int bits[RMX_P_HMM_LOG_NORM_CONST] = {CM_LT0, CM_LT1, CM_LT0 | CM_LT1, CM_LT0, CM_LT1, CM_LA0, CM_LA1, CM_LA0 | CM_LA1, CM_LA0, CM_LA1, 0, 0, 16};
+    b->comp_dirty[r] |= bits[id];
     return RMX_OK;
 }
 int rmx_get_param(rmx_batch *b, int32_t r, int32_t id, double *v) {
@@ -685,7 +722,7 @@ int rmx_set_array(rmx_batch *b, int32_t r, int32_t id, const void *src) {
     switch (id) {
     case RMX_A_H:
         for (int m = 0; m < d.M; m++) b->rp[r].h[m] = ((const double *)src)[m];
-        b->tables_dirty[r] = 1; b->ab_dirty[r] = 1; return RMX_OK;
+        b->tables_dirty[r] = 1; b->ab_dirty[r] = 1; b->comp_dirty[r] = 31; return RMX_OK;
     case RMX_A_P_BREAKPOINT:
         if (d.K) HIPCHK(hipMemcpyAsync(d.pbrk + (size_t)r * d.K * d.B, src, (size_t)d.K * d.B * 8, hipMemcpyHostToDevice, b->stream));
         break;
@@ -694,13 +731,13 @@ int rmx_set_array(rmx_batch *b, int32_t r, int32_t id, const void *src) {
     case RMX_A_P_OUTLIER_ALLELE: HIPCHK(hipMemcpyAsync(d.qa + RN * 2, src, (size_t)d.N * 16, hipMemcpyHostToDevice, b->stream)); break;
     case RMX_A_POSTERIOR_MARGINALS:
         HIPCHK(hipMemcpy2DAsync(d.post + RN * d.SP, (size_t)d.SP * 8, src, (size_t)d.S * 8, (size_t)d.S * 8, d.N, hipMemcpyHostToDevice, b->stream));
-        b->ab_dirty[r] = 1; break;
+        b->ab_dirty[r] = 1; b->comp_dirty[r] = 31; break;
     case RMX_A_TOTAL_LIKELIHOOD_MASK: case RMX_A_ALLELE_LIKELIHOOD_MASK: {
         std::vector<uint8_t> m8(d.N);
         for (int n = 0; n < d.N; n++) m8[n] = ((const int64_t *)src)[n] != 0;
         HIPCHK(hipStreamSynchronize(b->stream));
         HIPCHK(hipMemcpy((void *)(id == RMX_A_TOTAL_LIKELIHOOD_MASK ? d.mask_t : d.mask_a), m8.data(), d.N, hipMemcpyHostToDevice));
-        for (int i = 0; i < b->R; i++) b->ab_dirty[i] = 1;
+        for (int i = 0; i < b->R; i++) { b->ab_dirty[i] = 1; b->comp_dirty[i] = 31; }
         return RMX_OK; }
     default: return fail(RMX_EARG, "array is read-only or unknown");
     }
@@ -777,7 +814,8 @@ static int do_framelogprob(rmx_batch *b, int r0, int r1) {
     int rc = ensure_tables(b, r0, r1);
     if (rc) return rc;
     ProfScope ps(b, KID_FRAMELOGPROB);
-    hipLaunchKernelGGL(k_framelogprob, row_grid(b, r1 - r0), dim3(256), 0, b->stream, b->d, r0, b->G);
+    if (use_strip(b)) hipLaunchKernelGGL(cells_kernel(b, 0, CM_ALL), strip_grid(b, r1 - r0), dim3(256), 0, b->stream, b->d, r0);
+    else hipLaunchKernelGGL(k_framelogprob, row_grid(b, r1 - r0), dim3(256), 0, b->stream, b->d, r0, b->G);
     HIPCHK(hipGetLastError());
     return RMX_OK;
 }
@@ -849,10 +887,11 @@ static int do_update_p_cn(rmx_batch *b, int r0, int r1) {
     }
     {
         ProfScope ps(b, KID_MARGINALS);
-        hipLaunchKernelGGL(k_marginals<true>, row_grid(b, r1 - r0), dim3(256), 0, b->stream, b->d, r0, b->G);
+        if (use_strip(b)) hipLaunchKernelGGL(cells_kernel(b, 1, CM_ALL), strip_grid(b, r1 - r0), dim3(256), 0, b->stream, b->d, r0);
+        else hipLaunchKernelGGL(k_marginals<true>, row_grid(b, r1 - r0), dim3(256), 0, b->stream, b->d, r0, b->G);
         HIPCHK(hipGetLastError());
     }
-    for (int r = r0; r < r1; r++) { b->ab_dirty[r] = 0; b->logz_dirty[r] = 1; if (!b->lt_valid[r]) { b->lt_valid[r] = 1; int one = 1; HIPCHK(hipMemcpyAsync(b->d_lt_valid + r, &one, 4, hipMemcpyHostToDevice, b->stream)); } }
+    for (int r = r0; r < r1; r++) { b->ab_dirty[r] = 0; b->comp_dirty[r] = 0; b->logz_dirty[r] = 1; if (!b->lt_valid[r]) { b->lt_valid[r] = 1; int one = 1; HIPCHK(hipMemcpyAsync(b->d_lt_valid + r, &one, 4, hipMemcpyHostToDevice, b->stream)); } }
     // pairwise reductions at breakend adjacencies (feeds update_p_breakpoint and the ELBO)
     return launch_pairwise_breakends(b, r0, r1, 0);
 }
@@ -1101,7 +1140,7 @@ int rmx_expected_ll_batch(rmx_batch *b, int32_t nreq, const int32_t *restarts, i
         { ProfScope ps(b, KID_ELL_FINAL); hipLaunchKernelGGL(k_ell_final_batch, dim3(nreq), dim3(256), 0, b->stream, b->d, (const int32_t *)b->d_rlist, (const int32_t *)b->d_counts,
                                                              (const double *)b->d_ell_partial, pstride, b->d_batch_out); }
         HIPCHK(hipGetLastError());
-        for (int i = 0; i < nreq; i++) { b->tables_dirty[restarts[i]] = 0; b->segc_dirty[restarts[i]] = 1; b->ab_dirty[restarts[i]] = 1; }
+        for (int i = 0; i < nreq; i++) { b->tables_dirty[restarts[i]] = 0; b->segc_dirty[restarts[i]] = 1; b->ab_dirty[restarts[i]] = 1; }   // comp_dirty: set by rmx_set_param above
         HIPCHK(hipMemcpyAsync(b->h_pinned, b->d_batch_out, (size_t)nreq * 8, hipMemcpyDeviceToHost, b->stream));
     }
     int rc = check_errors(b, 0, b->R);

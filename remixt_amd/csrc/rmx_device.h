@@ -104,6 +104,42 @@ __device__ inline double digamma_as103(double x, unsigned &err) {
     return value;
 }
 
+// reciprocal for scale factors (v_rcp_f64 + one Newton step)
+__device__ __forceinline__ double fast_rcp(double m) {
+    double r = __builtin_amdgcn_rcp(m);
+    const double e = fma(-m, r, 1.0);
+    return fma(r, e, r);
+}
+
+// ---- natural logarithm for positive finite normal arguments -----------------------------------
+// fdlibm's e_log.c scheme (argument reduction to [sqrt(1/2), sqrt(2)), s = f/(2+f), degree-14
+// polynomial in s) with the hardware frexp instructions and a Newton-refined reciprocal: ~30
+// instructions against ~60 for the library routine, < 2 ulp.  Callers guarantee x > 0, finite,
+// not subnormal (counts plus positive dispersions / depths).
+__device__ __forceinline__ double fast_log_pos(double x) {
+    double m = __builtin_amdgcn_frexp_mant(x);      // [0.5, 1)
+    int k = __builtin_amdgcn_frexp_exp(x);
+    const bool lo = m < 0.70710678118654752440;
+    m = lo ? m + m : m;
+    k = lo ? k - 1 : k;
+    const double f = m - 1.0;
+    const double s_ = f * fast_rcp(2.0 + f);
+    const double z = s_ * s_, w = z * z;
+    const double t1 = w * fma(w, fma(w, 1.531383769920937332e-01, 2.222219843214978396e-01), 3.999999999940941908e-01);
+    const double t2 = z * fma(w, fma(w, fma(w, 1.479819860511658591e-01, 1.818357216161805012e-01), 2.857142874366239149e-01), 6.666666666666735130e-01);
+    const double R = t2 + t1;
+    const double hfsq = 0.5 * f * f;
+    const double dk = (double)k;
+    return dk * 6.93147180369123816490e-01 - ((hfsq - (s_ * (hfsq + R) + dk * 1.90821492927058770002e-10)) - f);
+}
+
+// log(1 + t) for t > 0 with the rounding of 1 + t compensated
+__device__ __forceinline__ double fast_log1p_pos(double t) {
+    const double u = 1.0 + t;
+    const double dlt = t - (u - 1.0);
+    return fast_log_pos(u) + dlt * fast_rcp(u);
+}
+
 // ---- fast log-gamma for positive arguments -------------------------------------------
 // Stirling series with 6 correction terms for z >= 16 (truncation error < 1e-17
 // relative), upward recurrence below.  Replaces libm lgamma in the per-cell hot
@@ -114,23 +150,16 @@ __device__ __forceinline__ double lgamma_pos(double z) {
     double shift = 1.;
     bool shifted = false;
     while (z < 16.) { shift *= z; z += 1.; shifted = true; }
-    const double r = 1.0 / z, r2 = r * r;
+    const double r = fast_rcp(z), r2 = r * r;
     double c = 691.0 / 360360.0;
     c = fma(-c, r2, 1.0 / 1188.0);
     c = fma(-c, r2, 1.0 / 1680.0);
     c = fma(-c, r2, 1.0 / 1260.0);
     c = fma(-c, r2, 1.0 / 360.0);
     c = fma(-c, r2, 1.0 / 12.0);
-    double v = fma(z - 0.5, log(z), -z) + 0.91893853320467274178 + c * r;
+    double v = fma(z - 0.5, fast_log_pos(z), -z) + 0.91893853320467274178 + c * r;
     if (shifted) v -= log(shift);
     return v;
-}
-
-// reciprocal for scale factors (v_rcp_f64 + one Newton step)
-__device__ __forceinline__ double fast_rcp(double m) {
-    double r = __builtin_amdgcn_rcp(m);
-    const double e = fma(-m, r, 1.0);
-    return fma(r, e, r);
 }
 
 // ---- per-segment context ----------------------------------------------------------
@@ -156,63 +185,87 @@ __device__ __forceinline__ double nb_state_part(double x, double mu, double r) {
     return x * log(p) + r * log(1 - p);
 }
 
-// The six likelihood values of one (segment,state) cell:
-//   LT[u]      = calculate_log_likelihood_total(n,s,u)      (bpmodel.pyx:751-776)
-//   LA[v*2+w]  = calculate_log_likelihood_allele(n,s,v,w)   (bpmodel.pyx:809-853)
-__device__ inline void cell_ll(const Dev &d, const RestartParams &rp, const SegCtx &sc, int r, int cls, int s,
-                               double LT[2], double LA[4], unsigned &err) {
-    const size_t si = ((size_t)r * d.C + cls) * d.SP + s;
-    const unsigned fl = d.stFlags[si];
-    if (!sc.mt) { LT[0] = 0.; LT[1] = 0.; }
-    else {
+// ---- register-resident variant ---------------------------------------------------------------
+// The strip kernels keep the table entries of the states a lane owns in registers across many
+// segments, and take the per-segment values as wave-uniform scalars.
+struct StateRegs { double D, logD, p, M0, M1, lgA0, lgB0, lgA1, lgB1, nsub; unsigned fl; };
+
+__device__ __forceinline__ void load_state_regs(const Dev &d, int r, int cls, int s, StateRegs &st) {
+    const size_t base = (size_t)r * d.C + cls, cs = d.SP;
+    const size_t si = base * cs + s;
+    st.D = d.stD[si]; st.logD = d.stLogD[si]; st.p = d.stP[si];
+    st.M0 = d.stM[(base * 2 + 0) * cs + s]; st.M1 = d.stM[(base * 2 + 1) * cs + s];
+    st.lgA0 = d.stLg[(base * 4 + 0) * cs + s]; st.lgB0 = d.stLg[(base * 4 + 1) * cs + s];
+    st.lgA1 = d.stLg[(base * 4 + 2) * cs + s]; st.lgB1 = d.stLg[(base * 4 + 3) * cs + s];
+    st.fl = d.stFlags[si];
+    st.nsub = (double)((d.sflags[(size_t)cls * d.S + s] >> 2) & 3);
+}
+
+// component mask of cell_ll_regs: which of the six values the caller needs
+#define CM_LT0 1
+#define CM_LT1 2
+#define CM_LA0 4   // LA[0], LA[1]  (v = 0)
+#define CM_LA1 8   // LA[2], LA[3]  (v = 1)
+#define CM_ALL 15
+
+template <int MASK>
+__device__ __forceinline__ void cell_ll_regs(const RestartParams &rp, const SegCtx &sc, const StateRegs &st,
+                                             double LT[2], double LA[4], unsigned &err) {
+    const unsigned fl = st.fl;
+    LT[0] = LT[1] = 0.;
+    if ((MASK & (CM_LT0 | CM_LT1)) && sc.mt) {
         if (fl & ST_HDEL_NB) {
             const double mu = rp.p[RMX_P_NEGBIN_HDEL_MU];
-            LT[0] = sc.cnb[1] + nb_state_part(sc.x, mu, rp.p[RMX_P_NEGBIN_HDEL_R_0]);
-            LT[1] = sc.cnb[3] + nb_state_part(sc.x, mu, rp.p[RMX_P_NEGBIN_HDEL_R_1]);
+            if (MASK & CM_LT0) LT[0] = sc.cnb[1] + nb_state_part(sc.x, mu, rp.p[RMX_P_NEGBIN_HDEL_R_0]);
+            if (MASK & CM_LT1) LT[1] = sc.cnb[3] + nb_state_part(sc.x, mu, rp.p[RMX_P_NEGBIN_HDEL_R_1]);
         } else {
-            const double mu = d.stD[si] * sc.l;
+            const double mu = st.D * sc.l;
             if (mu > 0.) {
-                // x log p + r log(1-p) with p = mu/(r+mu), t = r/mu:
-                //   log p = -log1p(t)            (no cancellation: keeps the objective smooth in h for L-BFGS-B)
-                //   log(1-p) = log t - log1p(t), log t = log r - log l - log D from the tables
-                // -> one log1p per u instead of two logs
-                const double lmu = sc.logl + d.stLogD[si];
-                const double rmu = 1.0 / mu;
-                const double r0_ = rp.p[RMX_P_NEGBIN_R_0], r1_ = rp.p[RMX_P_NEGBIN_R_1];
-                const double L0 = log1p(r0_ * rmu), L1 = log1p(r1_ * rmu);
-                LT[0] = sc.cnb[0] + (r0_ * ((rp.logr[0] - lmu) - L0) - sc.x * L0);
-                LT[1] = sc.cnb[2] + (r1_ * ((rp.logr[1] - lmu) - L1) - sc.x * L1);
+                const double lmu = sc.logl + st.logD;
+                const double rmu = fast_rcp(mu);
+                if (MASK & CM_LT0) { const double r0_ = rp.p[RMX_P_NEGBIN_R_0]; const double L0 = fast_log1p_pos(r0_ * rmu); LT[0] = sc.cnb[0] + (r0_ * ((rp.logr[0] - lmu) - L0) - sc.x * L0); }
+                if (MASK & CM_LT1) { const double r1_ = rp.p[RMX_P_NEGBIN_R_1]; const double L1 = fast_log1p_pos(r1_ * rmu); LT[1] = sc.cnb[2] + (r1_ * ((rp.logr[1] - lmu) - L1) - sc.x * L1); }
             } else {
-                LT[0] = sc.cnb[0] + nb_state_part(sc.x, mu, rp.p[RMX_P_NEGBIN_R_0]);
-                LT[1] = sc.cnb[2] + nb_state_part(sc.x, mu, rp.p[RMX_P_NEGBIN_R_1]);
+                if (MASK & CM_LT0) LT[0] = sc.cnb[0] + nb_state_part(sc.x, mu, rp.p[RMX_P_NEGBIN_R_0]);
+                if (MASK & CM_LT1) LT[1] = sc.cnb[2] + nb_state_part(sc.x, mu, rp.p[RMX_P_NEGBIN_R_1]);
             }
         }
         if (LT[0] != LT[0] || LT[1] != LT[1]) err |= RMX_ERR_NAN_LL;
     }
-    if (!sc.ma) { LA[0] = LA[1] = LA[2] = LA[3] = 0.; }
-    else {
+    LA[0] = LA[1] = LA[2] = LA[3] = 0.;
+    if ((MASK & (CM_LA0 | CM_LA1)) && sc.ma) {
         if (fl & ST_E_TD) err |= RMX_ERR_TOTAL_DEPTH;
         if (fl & ST_E_LOH) err |= RMX_ERR_LOH_P;
-        if (sc.ys == 0. || (fl & (ST_E_TD | ST_E_LOH))) { LA[0] = LA[1] = LA[2] = LA[3] = 0.; }
-        else if (fl & ST_E_BADP) { err |= RMX_ERR_BAD_P; LA[0] = LA[1] = LA[2] = LA[3] = 0.; }
+        if (sc.ys == 0. || (fl & (ST_E_TD | ST_E_LOH))) {
+        } else if (fl & ST_E_BADP) { err |= RMX_ERR_BAD_P; }
         else {
-            const double p = d.stP[si];
+            const double p = st.p;
             const int var = (fl & ST_LOH_M) ? 1 : 0;
-            const size_t cs = (size_t)d.SP;
-            const double *Mv = d.stM + ((size_t)r * d.C + cls) * 2 * cs + s;
-            const double *lg = d.stLg + ((size_t)r * d.C + cls) * 4 * cs + s;
-#pragma unroll
-            for (int v = 0; v < 2; v++) {
-                const double M = Mv[v * cs];
-                const double a = M * p, b = M * (1 - p);
-                const double base = sc.cbb[v * 2 + var] - lg[(2 * v) * cs] - lg[(2 * v + 1) * cs];
-                // w = 0: k = y0 ; w = 1: k = y1
-                LA[v * 2 + 0] = base + lgamma_pos(sc.y0 + a) + lgamma_pos(sc.ys - sc.y0 + b);
-                LA[v * 2 + 1] = base + lgamma_pos(sc.y1 + a) + lgamma_pos(sc.ys - sc.y1 + b);
+            if (MASK & CM_LA0) {
+                const double a = st.M0 * p, b = st.M0 * (1 - p);
+                const double base = (var ? sc.cbb[1] : sc.cbb[0]) - st.lgA0 - st.lgB0;   // (no runtime-indexed array: that would live in scratch)
+                LA[0] = base + lgamma_pos(sc.y0 + a) + lgamma_pos(sc.ys - sc.y0 + b);
+                LA[1] = base + lgamma_pos(sc.y1 + a) + lgamma_pos(sc.ys - sc.y1 + b);
+            }
+            if (MASK & CM_LA1) {
+                const double a = st.M1 * p, b = st.M1 * (1 - p);
+                const double base = (var ? sc.cbb[3] : sc.cbb[2]) - st.lgA1 - st.lgB1;
+                LA[2] = base + lgamma_pos(sc.y0 + a) + lgamma_pos(sc.ys - sc.y0 + b);
+                LA[3] = base + lgamma_pos(sc.y1 + a) + lgamma_pos(sc.ys - sc.y1 + b);
             }
             if (LA[0] != LA[0] || LA[1] != LA[1] || LA[2] != LA[2] || LA[3] != LA[3]) err |= RMX_ERR_NAN_LL;
         }
     }
+}
+
+// The six likelihood values of one (segment,state) cell, table-driven entry point:
+//   LT[u]      = calculate_log_likelihood_total(n,s,u)      (bpmodel.pyx:751-776)
+//   LA[v*2+w]  = calculate_log_likelihood_allele(n,s,v,w)   (bpmodel.pyx:809-853)
+__device__ inline void cell_ll(const Dev &d, const RestartParams &rp, const SegCtx &sc, int r, int cls, int s,
+                               double LT[2], double LA[4], unsigned &err) {
+    StateRegs st;
+    load_state_regs(d, r, cls, s, st);
+    cell_ll_regs<CM_ALL>(rp, sc, st, LT, LA, err);
 }
 
 // prior of bpmodel.pyx:746-749: -1.0 * num_alleles_subclonal * l * divergence_weight
@@ -234,15 +287,6 @@ __device__ __forceinline__ void exp_normalize2(double lp0, double lp1, double &y
 __device__ __forceinline__ double xlogx(double v) { return v > 0. ? v * log(v) : 0.; }
 
 template <typename T> __device__ __forceinline__ T shfl_xor_t(T v, int off) { return __shfl_xor(v, off, 64); }
-
-__device__ __forceinline__ double group_sum(double v, int G) {
-    for (int off = G >> 1; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-    return v;
-}
-__device__ __forceinline__ double group_max(double v, int G) {
-    for (int off = G >> 1; off > 0; off >>= 1) { double o = __shfl_xor(v, off, 64); v = o > v ? o : v; }
-    return v;
-}
 
 // ---- DPP cross-lane helpers (no LDS round trip, unlike __shfl_xor's ds_bpermute) ----------
 template <int CTRL> __device__ __forceinline__ double dpp_mov_f64(double v) {
@@ -280,6 +324,42 @@ __device__ __forceinline__ double wave_max_nonneg(double v) {
 __device__ __forceinline__ void lds_max_u64(void *lds_ptr, unsigned long long v) {
     const unsigned addr = (unsigned)(size_t)(__attribute__((address_space(3))) void *)lds_ptr;
     asm volatile("ds_max_u64 %0, %1" ::"v"(addr), "v"(v) : "memory");
+}
+
+// sum / max over aligned groups of G lanes (G in {8,16,32,64}); every lane gets its group's result.
+// DPP butterflies inside a row of 16 lanes, v_readlane across rows: fixed evaluation order
+// (deterministic) and no LDS round trips (__shfl_xor lowers to ds_bpermute).
+__device__ __forceinline__ double group_sum(double v, int G) {
+    v += dpp_mov_f64<0xB1>(v);                 // xor 1
+    v += dpp_mov_f64<0x4E>(v);                 // xor 2
+    v += dpp_mov_f64<0x141>(v);                // xor 4 (row_half_mirror on quad-uniform values)
+    if (G >= 16) v += dpp_mov_f64<0x140>(v);   // xor 8 (row_mirror on half-row-uniform values)
+    if (G >= 32) {
+        const int lo = __double2loint(v), hi = __double2hiint(v);
+        const double r0 = __hiloint2double(__builtin_amdgcn_readlane(hi, 0), __builtin_amdgcn_readlane(lo, 0));
+        const double r1 = __hiloint2double(__builtin_amdgcn_readlane(hi, 16), __builtin_amdgcn_readlane(lo, 16));
+        const double r2 = __hiloint2double(__builtin_amdgcn_readlane(hi, 32), __builtin_amdgcn_readlane(lo, 32));
+        const double r3 = __hiloint2double(__builtin_amdgcn_readlane(hi, 48), __builtin_amdgcn_readlane(lo, 48));
+        if (G >= 64) v = ((r0 + r1) + r2) + r3;
+        else v = (threadIdx.x & 32) ? (r2 + r3) : (r0 + r1);
+    }
+    return v;
+}
+__device__ __forceinline__ double group_max(double v, int G) {
+    v = fmax(v, dpp_mov_f64<0xB1>(v));
+    v = fmax(v, dpp_mov_f64<0x4E>(v));
+    v = fmax(v, dpp_mov_f64<0x141>(v));
+    if (G >= 16) v = fmax(v, dpp_mov_f64<0x140>(v));
+    if (G >= 32) {
+        const int lo = __double2loint(v), hi = __double2hiint(v);
+        const double r0 = __hiloint2double(__builtin_amdgcn_readlane(hi, 0), __builtin_amdgcn_readlane(lo, 0));
+        const double r1 = __hiloint2double(__builtin_amdgcn_readlane(hi, 16), __builtin_amdgcn_readlane(lo, 16));
+        const double r2 = __hiloint2double(__builtin_amdgcn_readlane(hi, 32), __builtin_amdgcn_readlane(lo, 32));
+        const double r3 = __hiloint2double(__builtin_amdgcn_readlane(hi, 48), __builtin_amdgcn_readlane(lo, 48));
+        if (G >= 64) v = fmax(fmax(r0, r1), fmax(r2, r3));
+        else v = (threadIdx.x & 32) ? fmax(r2, r3) : fmax(r0, r1);
+    }
+    return v;
 }
 
 // block-wide deterministic sum (fixed tree): all threads must call; result valid in thread 0

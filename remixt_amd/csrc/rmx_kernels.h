@@ -796,6 +796,114 @@ __global__ void k_marginals(Dev d, int r0, int G) {
 }
 
 // =============================================================================
+// Strip kernels for the (segment x state) likelihood passes, S > 32.
+// A wave owns a strip of consecutive segments; lane l owns states l, l+64, ... (NS per lane) and keeps
+// their table entries in registers for the whole strip; everything that depends on the segment only
+// is wave-uniform and arrives through scalar loads (the segment index is made an SGPR).
+//   MODE 0: update_framelogprob (+ row maximum, scaled emissions)          -- k_framelogprob
+//   MODE 1: posterior marginals + (A, B, PF, PP, row share of log Z)        -- k_marginals<true>
+//   MODE 2: refresh of the components of (A, B) selected by MASK            -- k_marginals<false>
+// grid (ceil(N / (4*RPW)), nr), block 256.
+// =============================================================================
+#define STRIP_RPW 8
+template <int NS, int MODE, int MASK>
+__global__ __launch_bounds__(256) void k_cells(Dev d, int r0) {
+    const int r = r0 + blockIdx.y;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int nbeg = (blockIdx.x * 4 + wave) * STRIP_RPW;
+    if (nbeg >= d.N) return;
+    const int nend = min(d.N, nbeg + STRIP_RPW);
+    const RestartParams &rp = d.rp[r];
+    const int S = d.S;
+    StateRegs st[NS];
+    int cur_cls = -1;
+    unsigned err = 0;
+    const double divw = rp.p[RMX_P_DIVERGENCE_WEIGHT];
+    for (int n = nbeg; n < nend; n++) {     // n is wave-uniform (SGPR)
+        const int cls = d.seg_class[n];
+        if (cls != cur_cls) {
+#pragma unroll
+            for (int k = 0; k < NS; k++) { const int s = lane + 64 * k; load_state_regs(d, r, cls, s < S ? s : S - 1, st[k]); }   // clamped: lanes past S are masked at use
+            cur_cls = cls;
+        }
+        SegCtx sc; load_seg(d, r, n, sc);
+        const size_t rn = (size_t)r * d.N + n;
+        const size_t ro = rn * d.SP;
+        if (MODE == 0) {
+            const double qt0 = d.qt[rn * 2], qt1 = d.qt[rn * 2 + 1], qa0 = d.qa[rn * 2], qa1 = d.qa[rn * 2 + 1];
+            const double qs0 = d.qs[rn * 2], qs1 = d.qs[rn * 2 + 1];
+            double fv[NS];
+            double vmax = -INFINITY;
+#pragma unroll
+            for (int k = 0; k < NS; k++) {
+                const int s = lane + 64 * k;
+                fv[k] = -INFINITY;
+                if (s < S) {
+                    double LT[2], LA[4];
+                    cell_ll_regs<CM_ALL>(rp, sc, st[k], LT, LA, err);
+                    double f = 0.;
+                    f += qt0 * LT[0]; f += qt1 * LT[1];
+                    f += qa0 * qs0 * LA[0]; f += qa0 * qs1 * LA[1]; f += qa1 * qs0 * LA[2]; f += qa1 * qs1 * LA[3];
+                    f += -1.0 * st[k].nsub * sc.l * divw;
+                    if (f != f) err |= RMX_ERR_NAN_F;
+                    d.f[ro + s] = f;
+                    fv[k] = f;
+                    vmax = fmax(vmax, f);
+                }
+                __builtin_amdgcn_sched_barrier(0);   // one cell at a time: keeps the register footprint (occupancy) in check
+            }
+            vmax = group_max(vmax, 64);
+            if (lane == 0) d.fmax[rn] = vmax;
+#pragma unroll
+            for (int k = 0; k < NS; k++) { const int s = lane + 64 * k; if (s < d.SP) d.fe[ro + s] = s < S ? exp(fv[k] - vmax) : 0.; }
+        } else {
+            double pv[NS];
+            double sum = 0.;
+            if (MODE == 1) {
+#pragma unroll
+                for (int k = 0; k < NS; k++) { const int s = lane + 64 * k; pv[k] = s < S ? d.fa[ro + s] * d.fb[ro + s] : 0.; sum += pv[k]; }
+                sum = group_sum(sum, 64);
+                if (!(sum > 0.) || sum != sum || sum == INFINITY) err |= RMX_ERR_NAN_POST;
+                double s2 = 0.;
+#pragma unroll
+                for (int k = 0; k < NS; k++) { pv[k] = pv[k] / sum; s2 += pv[k]; }
+                s2 = group_sum(s2, 64);
+#pragma unroll
+                for (int k = 0; k < NS; k++) { const int s = lane + 64 * k; pv[k] = pv[k] / s2; if (s < S) d.post[ro + s] = pv[k]; }   // second renormalisation of _exp_normalize
+            } else {
+#pragma unroll
+                for (int k = 0; k < NS; k++) { const int s = lane + 64 * k; pv[k] = s < S ? d.post[ro + s] : 0.; }
+            }
+            double a0 = 0., a1 = 0., b0 = 0., b1 = 0., b2 = 0., b3 = 0., pf = 0., pp = 0.;
+#pragma unroll
+            for (int k = 0; k < NS; k++) {
+                const int s = lane + 64 * k;
+                if (s < S) {
+                    double LT[2], LA[4];
+                    cell_ll_regs<MASK>(rp, sc, st[k], LT, LA, err);
+                    const double ps = pv[k];
+                    a0 += ps * LT[0]; a1 += ps * LT[1];
+                    b0 += ps * LA[0]; b1 += ps * LA[1]; b2 += ps * LA[2]; b3 += ps * LA[3];
+                    if (MODE == 1 || (MASK & 16)) { pf += ps * d.f[ro + s]; pp += ps * (-1.0 * st[k].nsub * sc.l * divw); }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (MASK & CM_LT0) { a0 = group_sum(a0, 64); if (lane == 0) d.A[rn * 2] = a0; }
+            if (MASK & CM_LT1) { a1 = group_sum(a1, 64); if (lane == 0) d.A[rn * 2 + 1] = a1; }
+            if (MASK & CM_LA0) { b0 = group_sum(b0, 64); b1 = group_sum(b1, 64); if (lane == 0) { d.Bv[rn * 4] = b0; d.Bv[rn * 4 + 1] = b1; } }
+            if (MASK & CM_LA1) { b2 = group_sum(b2, 64); b3 = group_sum(b3, 64); if (lane == 0) { d.Bv[rn * 4 + 2] = b2; d.Bv[rn * 4 + 3] = b3; } }
+            if (MODE == 1 || (MASK & 16)) {
+                pf = group_sum(pf, 64); pp = group_sum(pp, 64);
+                if (lane == 0) { d.rowPF[rn] = pf; d.rowPP[rn] = pp; }
+            }
+            if (MODE == 1 && lane == 0) d.rowZ[rn] = d.fmax[rn] + (d.chain_end_flag[n] ? log(sum) : log(d.mrow[rn]));
+        }
+    }
+    if (err) atomicOr(&d.err[r], err);
+}
+
+// =============================================================================
 // O(N) indicator updates from (A, B)
 // =============================================================================
 __global__ void k_update_outlier_total(Dev d, int r0) {   // bpmodel.pyx:987-1003
