@@ -383,7 +383,15 @@ static int ensure_ab(rmx_batch *b, int r0, int r1) {
 static int launch_pairwise_breakends(rmx_batch *b, int r0, int r1, int mode) {
     if (b->d.NBE == 0) return RMX_OK;
     ProfScope ps(b, KID_PAIRWISE);
-    hipLaunchKernelGGL(k_pairwise, dim3(b->d.NBE, r1 - r0), dim3(256), 0, b->stream, b->d, r0, mode, (const int32_t *)nullptr, (double *)nullptr);
+    const Dev &d = b->d;
+    const int nt = ((d.S + 63) / 64) * 64;
+    const size_t lds = ((size_t)((d.S + 1) & ~1) + ((d.M * d.D + 1) & ~1) + 128 + (size_t)nt * d.M * (d.cn_max + 2)) * 8 + (size_t)d.S * 4 + 64;
+    if (mode == 0 && lds <= 150 * 1024 && !getenv("RMX_PAIRWISE_OLD")) {
+        HIPCHK(hipFuncSetAttribute((const void *)k_pairwise_be, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(k_pairwise_be, dim3(d.NBE, r1 - r0), dim3(nt), lds, b->stream, b->d, r0);
+    } else {
+        hipLaunchKernelGGL(k_pairwise, dim3(d.NBE, r1 - r0), dim3(256), 0, b->stream, b->d, r0, mode, (const int32_t *)nullptr, (double *)nullptr);
+    }
     HIPCHK(hipGetLastError());
     return RMX_OK;
 }

@@ -1058,6 +1058,94 @@ __global__ void k_pairwise(Dev d, int r0, int mode, const int32_t *list, double 
 }
 
 // =============================================================================
+// k_pairwise_be: the production form of k_pairwise for breakend adjacencies (mode 0).
+// Thread i owns row i of the pairwise posterior joint[i][j] = fa[i] * W[i][j] * g[j] and walks j.
+// For a fixed row the histogram key  tot_i,c - tot_j,c  depends on j only through tot_j,c, so each
+// thread accumulates into PRIVATE LDS bins indexed by tot_j,c (no atomics, fixed order); the bins are
+// folded into the per-distance histogram afterwards in thread order.  The weights come from the
+// exponentiated distance tables (no exp per pair) and the expectation of log_transmat is rebuilt from
+// the histogram:  sum joint*T = -pen * ( sum_c sum_d hist_c[d] * pd_c[d] + sum joint*a ).
+// grid (NBE, nr), block NT = ceil(S/64)*64, dynamic LDS.
+// =============================================================================
+__global__ void k_pairwise_be(Dev d, int r0) {
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    __shared__ double scratch[16];
+    __shared__ double zsh, jash;
+    const int r = r0 + blockIdx.y, slot = blockIdx.x;
+    const int n = d.be_n[slot];
+    const int S = d.S, M = d.M, D = d.D, t = threadIdx.x, NT = blockDim.x;
+    const int NB = d.cn_max + 2;                          // totals 0 .. cn_max+1
+    const int tc = d.tclass[n];
+    const int ca = d.seg_class[n], cb = d.seg_class[n + 1];
+    double *gvec = (double *)smem_raw;                    // [S]
+    double *pe = gvec + ((S + 1) & ~1);                   // [M*D] exp(-pen*pd_lt), 1 for a telomere
+    double *wa = pe + ((M * D + 1) & ~1);                 // [128]
+    double *bins = wa + 128;                              // [NT][M][NB]
+    int *totb = (int *)(bins + (size_t)NT * M * NB);      // [S] totals of the j-side states, one byte per clone
+    const double *fb = d.fb + rs_off(d, r, n + 1), *fe = d.fe + rs_off(d, r, n + 1);
+    for (int j = t; j < S; j += NT) {
+        gvec[j] = fe[j] * fb[j];
+        int pk = 0;
+        for (int c = 0; c < M; c++) pk |= ((int)d.tot[((size_t)cb * S + j) * M + c] & 0xff) << (8 * c);
+        totb[j] = pk;
+    }
+    const double *peg = d.pe_lt + ((size_t)r * d.NBE + slot) * ((M * D + 1) & ~1);
+    for (int i = t; i < M * D; i += NT) pe[i] = tc >= 0 ? peg[i] : 1.0;
+    for (int i = t; i < 128; i += NT) wa[i] = tc >= 0 ? exp(-d.pen * (double)i) : 1.0;
+    double *mybins = bins + (size_t)t * M * NB;
+    for (int i = 0; i < M * NB; i++) mybins[i] = 0.;
+    __syncthreads();
+    double z = 0., ja = 0.;
+    if (t < S) {
+        const double fai = d.fa[rs_off(d, r, n) + t];
+        int ta[RMX_MAX_CLONES];
+#pragma unroll
+        for (int c = 0; c < RMX_MAX_CLONES; c++) ta[c] = c < M ? (int)d.tot[((size_t)ca * S + t) * M + c] + d.cn_max + 1 : 0;
+        const int8_t *arow = tc >= 0 ? d.af + ((size_t)tc * S + t) * S : nullptr;
+        for (int j = 0; j < S; j++) {
+            const int a = arow ? (int)arow[j] : 0;
+            const int pk = totb[j];
+            double w = wa[a];
+#pragma unroll
+            for (int c = 0; c < RMX_MAX_CLONES; c++) if (c < M) w *= pe[c * D + ta[c] - ((pk >> (8 * c)) & 0xff)];
+            const double J = fai * w * gvec[j];
+            z += J; ja += J * (double)a;
+#pragma unroll
+            for (int c = 0; c < RMX_MAX_CLONES; c++) if (c < M) unsafeAtomicAdd(&mybins[c * NB + ((pk >> (8 * c)) & 0xff)], J);   // private address: a fire-and-forget ds_add_f64, no read latency
+        }
+    }
+    // deterministic block sums
+    z = group_sum(z, 64); ja = group_sum(ja, 64);
+    if ((t & 63) == 0) { scratch[t >> 6] = z; scratch[8 + (t >> 6)] = ja; }
+    __syncthreads();
+    if (t == 0) { double zz = 0., aa = 0.; for (int w_ = 0; w_ < NT / 64; w_++) { zz += scratch[w_]; aa += scratch[8 + w_]; } zsh = zz; jash = aa; }
+    __syncthreads();
+    const double zz = zsh;
+    // fold the private bins: hist[c][d] = sum_i bins[i][c][tot_i,c - d]
+    double *hist = d.hist + ((size_t)r * d.NBE + slot) * M * D;
+    for (int i = t; i < M * D; i += NT) {
+        const int c = i / D, dv = i % D - (d.cn_max + 1);
+        double acc = 0.;
+        for (int row = 0; row < S; row++) {
+            const int tj = (int)d.tot[((size_t)ca * S + row) * M + c] - dv;
+            if (tj >= 0 && tj < NB) acc += bins[((size_t)row * M + c) * NB + tj];
+        }
+        hist[i] = acc / zz;
+    }
+    __syncthreads();
+    if (t == 0) {
+        d.be_ja[(size_t)r * d.NBE + slot] = jash / zz;
+        double jt = 0.;
+        if (tc >= 0) {
+            const double *pd = d.pd_lt + ((size_t)r * d.NBE + slot) * M * D;
+            for (int i = 0; i < M * D; i++) jt += hist[i] * (-d.pen * pd[i]);
+            jt += -d.pen * (jash / zz);
+        }
+        d.be_jt[(size_t)r * d.NBE + slot] = jt;
+    }
+}
+
+// =============================================================================
 // update_p_breakpoint (bpmodel.pyx:964-985, 618-637) from the breakend histograms
 // grid (K, nr), block 128
 // =============================================================================
