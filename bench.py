@@ -45,8 +45,10 @@ def parse():
     ap.add_argument('--max-cn', type=int, default=8)
     ap.add_argument('--restarts', type=int, default=16, help='restarts per GPU')
     ap.add_argument('--update-iters', type=int, default=5)
+    ap.add_argument('--groups', type=int, default=2, help='restart groups per GPU (own stream + host thread each; results do not depend on it)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-sample-segments', type=int, default=800)
+    ap.add_argument('--profile-all', action='store_true', help='HIP-event every kernel (default: only the variational-sweep kernels; the M-step objective kernels are ~3000 tiny launches per step)')
     ap.add_argument('--no-mstep', action='store_true', help='diagnostic only: variational sweeps without M-steps (NOT the reported metric)')
     return ap.parse_args()
 
@@ -106,45 +108,48 @@ def main():
     torch.cuda.set_device(device)
 
     from remixt_amd import synthetic
-    from remixt_amd.restarts import RestartSet, _pack
+    from remixt_amd.restarts import RestartGroups, _pack
 
     R = args.restarts
     e = synthetic.make_experiment(args.segments, num_clones=args.clones, max_copy_number=args.max_cn, num_chains=23, seed=0)
     all_params = synthetic.make_init_params(e, R * world, args.max_cn, num_clones=args.clones)
     mine = all_params[rank::world]
-    rs = RestartSet(e, mine, args.max_cn, num_clones=args.clones, device=device, quiet=True,
-                    seeds=[1000 + rank + world * i for i in range(R)])
-    b = rs.batch
+    rs = RestartGroups(e, mine, args.max_cn, groups=args.groups, num_clones=args.clones, device=device, quiet=True,
+                       seeds=[1000 + rank + world * i for i in range(R)])
+    b = rs.batches[0]
     N1, S = b.num_segments, b.num_cn_states
     elbo0 = rs.calculate_elbo()
     for m, v in zip(rs.models, elbo0):
         m.prev_elbo = float(v)
 
-    def step(i):
+    def steps(first, count):
+        """`count` EM iterations of every restart on this GPU (restart groups free-run inside)."""
         if args.no_mstep:
-            rs.variational_update(args.update_iters)
+            for _ in range(count):
+                rs.variational_update(args.update_iters)
             return rs.calculate_elbo()
-        return rs.em_iteration(i, args.update_iters)
+        return rs.run(count, first, args.update_iters)
 
-    for i in range(args.warmup):
-        step(i)
+    if args.warmup:
+        steps(0, args.warmup)
 
     def fence():
-        b.synchronize()
+        rs.synchronize()
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
             torch.cuda.synchronize()
 
-    b.profile_reset(); b.profile_enable(True)
+    for b_ in rs.batches:
+        b_.profile_reset(); b_.profile_enable(1 if args.profile_all else 2)
     fence()
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        elbo = step(args.warmup + i)
+    elbo = steps(args.warmup, args.steps)
     fence()
     dt = time.perf_counter() - t0
-    b.profile_enable(False)
-    prof = b.profile()
+    for b_ in rs.batches:
+        b_.profile_enable(0)
+    prof = rs.profile()
     if world > 1:
         tt = torch.tensor([dt], dtype=torch.float64, device='cuda')
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -165,7 +170,8 @@ def main():
         # <= 200 segments: latency, not a roofline subject; they are listed under "kernels")
         hot = [(k, prof[k]) for k in ALG_BYTES_PER_CELL if k in prof]
         dom = max(hot, key=lambda kv: kv[1][0]) if hot else (None, (0., 0))
-        cells_per_launch = float(N1) * S * R
+        cells_total = float(N1) * S * R
+        cells_per_launch = cells_total / len(rs.sets)     # every group launches over its own restarts
         roof = None
         if dom[0] is not None:
             name, (ms, n) = dom
@@ -176,7 +182,7 @@ def main():
             try:   # PMC traffic of the same kernel on the same workload, measured offline (profiles/)
                 tj = json.load(open(os.path.join(ROOT, 'profiles', 'traffic_r01.json')))
                 w = tj['workload']
-                if (w['segments'], w['states'], w['restarts']) == (args.segments, S, R):
+                if (w['segments'], w['states'], w['restarts']) == (args.segments, S, R // len(rs.sets)):
                     traffic = tj['kernels'][name]['hbm_bytes_per_launch']
             except Exception:
                 traffic = None
@@ -196,8 +202,8 @@ def main():
             'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
             'config': {'workload': 'BASELINE configs[2]: %d segments (%d after breakend remap), %d clones, max_cn=%d (%d states), %d restarts/GPU, %d variational sweeps + M-steps per EM iteration'
                                    % (args.segments, N1, args.clones, args.max_cn, S, R, args.update_iters),
-                       'segments': args.segments, 'states': S, 'restarts_per_gpu': R, 'mstep': not args.no_mstep},
-            'seg_state_cells_per_s': cells_per_launch * world * args.update_iters * args.steps / dt,
+                       'segments': args.segments, 'states': S, 'restarts_per_gpu': R, 'restart_groups': len(rs.sets), 'mstep': not args.no_mstep},
+            'seg_state_cells_per_s': cells_total * world * args.update_iters * args.steps / dt,
             'roofline': roof,
             'variational_sweep': {'device_ms_per_sweep_all_restarts': sweep_ms,
                                   'hbm_frac_88B_per_cell': (88.0 * cells_per_launch / (sweep_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if sweep_ms else None},

@@ -162,6 +162,20 @@ int rmx_expected_ll_param_grid(rmx_batch *b, int32_t r, int32_t param_id, const 
  * likelihood parameter per listed restart (distinct restarts), each evaluated on its own current
  * sample; out[i] belongs to restarts[i].  One host round trip for the whole list. */
 int rmx_expected_ll_batch(rmx_batch *b, int32_t nreq, const int32_t *restarts, int32_t param_id, const double *values, double *out);
+/* The whole scipy.optimize.brute search of BreakpointModel.update_param (cn_model.py:553-561) for one
+ * likelihood parameter of every listed restart, in lock step: G grid values (np.mgrid[lo:hi:G*1j]),
+ * first arg-min, then scipy.optimize.fmin (Nelder-Mead) restated as a host state machine; every
+ * round of objective evaluations is one rmx_expected_ll_batch.  nll is +inf outside [lo, hi]
+ * (cn_model.py:542-543).  xopt[i] = the optimiser's result for restarts[i]; the parameter is left at
+ * the value of the restart's last evaluation, as the sequential scipy run leaves it. */
+int rmx_param_search(rmx_batch *b, int32_t nreq, const int32_t *restarts, int32_t param_id, double lo, double hi,
+                     const double *grid, int32_t G, double *xopt);
+/* Lock-step h M-step (BreakpointModel.update_h, cn_model.py:482-531): one candidate haploid-depth
+ * vector h[i][0..M) per listed restart; out[i][0] = E[ll] (calculate_expected_log_likelihood,
+ * bpmodel.pyx:1125-1157) and out[i][1..M] = dE[ll]/dh (calculate_expected_log_likelihood_partial_h,
+ * bpmodel.pyx:1159-1195) on restart i's current sample; out is [nreq][1 + RMX_MAX_CLONES].  Leaves
+ * h[i] set on the restart, as `model.h = h` followed by the two calls would. */
+int rmx_expected_ll_h_batch(rmx_batch *b, int32_t nreq, const int32_t *restarts, const double *h, double *out);
 /* E[ll] over ALL segments (the reference passes a mask of ones, cn_model.py:497, :524, :549, :563)
  * for restarts [r0, r1); out: [r1-r0]. */
 int rmx_expected_ll_full(rmx_batch *b, int32_t r0, int32_t r1, double *out);
@@ -186,7 +200,9 @@ int rmx_max_product(const double *f, const double *T, int64_t *state_sequence, d
 int rmx_timer_start(rmx_batch *b);
 int rmx_timer_stop(rmx_batch *b, double *elapsed_ms);
 /* per-kernel accumulated device time since the last reset (HIP events around
- * each launch; enabled by rmx_profile_enable(b, 1)).  kernel ids: see
+ * each launch).  rmx_profile_enable: 0 = off, 1 = every kernel, 2 = only the kernels of the
+ * variational sweep (the M-step objective kernels are launched thousands of times per EM
+ * iteration; two event records per launch would perturb the host loop).  kernel ids: see
  * rmx_kernel_name(). */
 int rmx_profile_enable(rmx_batch *b, int32_t on);
 int rmx_profile_get(rmx_batch *b, int32_t kernel_id, double *total_ms, int64_t *launches);

@@ -29,6 +29,7 @@ _i32p = C.POINTER(C.c_int32)
 
 RMX_EVALUE, RMX_EASSERT, RMX_EDEVICE, RMX_EUNSUPPORTED, RMX_EARG = 1, 2, 3, 4, 5
 
+MAX_CLONES = 4      # RMX_MAX_CLONES (include/remixt_amd.h)
 PARAM_IDS = {
     'negbin_r_0': 0, 'negbin_r_1': 1, 'negbin_hdel_mu': 2, 'negbin_hdel_r_0': 3, 'negbin_hdel_r_1': 4,
     'betabin_M_0': 5, 'betabin_M_1': 6, 'betabin_loh_p': 7, 'betabin_loh_M_0': 8, 'betabin_loh_M_1': 9,
@@ -325,6 +326,26 @@ class RemixtBatch(object):
                                                  v.ctypes.data_as(_dp), out.ctypes.data_as(_dp)))
         return out
 
+    def param_search(self, restarts, name, lo, hi, grid):
+        """scipy.optimize.brute over `grid` + Nelder-Mead polish of likelihood parameter `name` for all
+        listed restarts in lock step (rmx_param_search); returns the optimum per restart."""
+        rl = np.ascontiguousarray(restarts, dtype=np.int32)
+        g = _f64(grid).ravel()
+        out = np.zeros(len(rl), dtype=np.float64)
+        self._ck(self._lib.rmx_param_search(self._handle, len(rl), rl.ctypes.data_as(_i32p), PARAM_IDS[name], float(lo), float(hi),
+                                            g.ctypes.data_as(_dp), len(g), out.ctypes.data_as(_dp)))
+        return out
+
+    def expected_log_likelihood_h_batch(self, restarts, hs):
+        """(E[ll], dE[ll]/dh) on each listed restart's current sample with h set to the matching row
+        of `hs` (and left there): the evaluation round of the lock-step h M-step."""
+        rl = np.ascontiguousarray(restarts, dtype=np.int32)
+        h = _f64(hs).reshape(len(rl), self.num_clones)
+        out = np.zeros((len(rl), 1 + MAX_CLONES), dtype=np.float64)
+        self._ck(self._lib.rmx_expected_ll_h_batch(self._handle, len(rl), rl.ctypes.data_as(_i32p),
+                                                   h.ctypes.data_as(_dp), out.ctypes.data_as(_dp)))
+        return out[:, 0].copy(), out[:, 1:1 + self.num_clones].copy()
+
     def expected_log_likelihood_full(self, r0=None, r1=None):
         """E[ll] over all segments for restarts [r0, r1)."""
         return self._scalar_range(self._lib.rmx_expected_ll_full, r0, r1)
@@ -345,7 +366,7 @@ class RemixtBatch(object):
         return float(ms.value)
 
     def profile_enable(self, on=True):
-        self._ck(self._lib.rmx_profile_enable(self._handle, int(bool(on))))
+        self._ck(self._lib.rmx_profile_enable(self._handle, int(on)))    # 0 off, 1 all kernels, 2 sweep kernels only
 
     def profile_reset(self):
         self._ck(self._lib.rmx_profile_reset(self._handle))

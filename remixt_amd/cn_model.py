@@ -424,17 +424,7 @@ class BreakpointModel(object):
 
         result = scipy.optimize.minimize(nll, np.array(model.h, dtype=float), method='L-BFGS-B', jac=nll_grad,
                                          bounds=[(1e-8, 10.)] * model.num_clones)
-        if not result.success:
-            message = result.message.decode() if isinstance(result.message, bytes) else str(result.message)
-            if message == 'ABNORMAL_TERMINATION_IN_LNSRCH':
-                # cn_model.py:513-518: the reference cross-checks the gradient numerically and continues
-                # (statsmodels' forward difference there; scipy's here)
-                analytic = nll_grad(result.x)
-                numerical = scipy.optimize.approx_fprime(result.x, nll, 1e-8)
-                if not np.allclose(analytic, numerical, atol=2.):
-                    raise ValueError('gradiant error, analytic: {}, numerical: {}\n'.format(analytic, numerical))
-            else:
-                raise ValueError('optimization failed\n{}'.format(result))
+        self._validate_h_result(result, nll, nll_grad)
 
         model.h = result.x
         ell_after = model.calculate_expected_log_likelihood(self._all_segments())
@@ -443,6 +433,22 @@ class BreakpointModel(object):
             model.h = h_before
         else:
             model.h = result.x
+
+    @staticmethod
+    def _validate_h_result(result, nll, nll_grad):
+        """cn_model.py:510-521: what the reference does with an unsuccessful L-BFGS-B run."""
+        if result.success:
+            return
+        message = result.message.decode() if isinstance(result.message, bytes) else str(result.message)
+        if message == 'ABNORMAL_TERMINATION_IN_LNSRCH':
+            # cn_model.py:513-518: the reference cross-checks the gradient numerically and continues
+            # (statsmodels' forward difference there; scipy's here)
+            analytic = nll_grad(result.x)
+            numerical = scipy.optimize.approx_fprime(result.x, nll, 1e-8)
+            if not np.allclose(analytic, numerical, atol=2.):
+                raise ValueError('gradiant error, analytic: {}, numerical: {}\n'.format(analytic, numerical))
+        else:
+            raise ValueError('optimization failed\n{}'.format(result))
 
     def update_param(self, name):
         """Update one likelihood parameter by brute-force + simplex search (cn_model.py:533-569)."""

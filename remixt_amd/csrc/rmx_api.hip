@@ -50,6 +50,8 @@ struct rmx_batch {
     // per-restart host state
     std::vector<RestartParams> rp;
     std::vector<char> tables_dirty, segc_dirty, ab_dirty;
+    std::vector<int> cache_stale;      // components of the cell cache that are not current (CM_* bits); 15 = nothing cached
+    bool use_cache = false;
     std::vector<int> comp_dirty;       // which components of (A, B, PF/PP) are stale: CM_* bits, 16 = PF/PP
     std::vector<int> lt_valid;
     std::vector<double> plain_T_init;  // [R]
@@ -62,6 +64,7 @@ struct rmx_batch {
     double *d_ell_partial = nullptr;   // [max(N,ELBO_BLOCKS)][1+MAXC]
     double *d_ell_out = nullptr;       // [1+MAXC]
     double *h_pinned = nullptr;        // pinned staging [max(4R, 16)]
+    uint32_t *h_err = nullptr;         // pinned [R]: landing area of check_errors
     int32_t *d_sample = nullptr;       // [R][N] index lists of the current M-step samples
     std::vector<std::vector<int64_t>> sample_cache; std::vector<int> sample_count;
     double *d_grid_out = nullptr;      // [R][64][1+MAXC]
@@ -81,7 +84,7 @@ struct rmx_batch {
     // all device allocations (freed on destroy)
     std::vector<void *> allocs;
     // profiling
-    bool prof = false;
+    int prof = 0;     // 0 off, 1 all kernels, 2 variational-sweep kernels only
     std::vector<ProfRec> prof_pending;
     std::vector<hipEvent_t> ev_pool;
     double prof_ms[KID_COUNT] = {0};
@@ -126,19 +129,28 @@ static void prof_collect(rmx_batch *b) {
 struct ProfScope {
     rmx_batch *b; int id; hipEvent_t a{}, e{};
     // callers hold b->mu (see LOCK()) whenever profiling may be on
+    bool on;
+    // level 1: every kernel; level 2: only the kernels of the variational sweep (a few dozen launches
+    // per EM iteration -- the M-step objective kernels are launched thousands of times and two event
+    // records per launch would slow the host loop being measured)
+    static bool sweep_kernel(int id) {
+        return id == KID_FRAMELOGPROB || id == KID_FB || id == KID_MARGINALS || id == KID_PAIRWISE || id == KID_BRK_LUT ||
+               id == KID_BRK_UPDATE || id == KID_OUTLIER_TOTAL || id == KID_OUTLIER_ALLELE || id == KID_ALLELE_SWAP;
+    }
     ProfScope(rmx_batch *b_, int id_) : b(b_), id(id_) {
-        if (b->prof) { a = get_event(b); e = get_event(b); hipEventRecord(a, b->stream); }
+        on = b->prof == 1 || (b->prof == 2 && sweep_kernel(id));
+        if (on) { a = get_event(b); e = get_event(b); hipEventRecord(a, b->stream); }
     }
     ~ProfScope() {
-        if (b->prof) { hipEventRecord(e, b->stream); b->prof_pending.push_back({id, a, e}); if (b->prof_pending.size() > 8192) prof_collect(b); }
+        if (on) { hipEventRecord(e, b->stream); b->prof_pending.push_back({id, a, e}); if (b->prof_pending.size() > 8192) prof_collect(b); }
     }
 };
 
 // ---- error translation -------------------------------------------------------
 static int translate_error(rmx_batch *b, int r, uint32_t v);
 static int check_errors(rmx_batch *b, int r0, int r1) {
-    std::vector<uint32_t> e(b->R);
-    HIPCHK(hipMemcpyAsync(e.data(), b->d.err, sizeof(uint32_t) * b->R, hipMemcpyDeviceToHost, b->stream));
+    uint32_t *e = b->h_err;      // pinned: the copy is queued behind the caller's own result copy, one wait for both
+    HIPCHK(hipMemcpyAsync(e, b->d.err, sizeof(uint32_t) * b->R, hipMemcpyDeviceToHost, b->stream));
     HIPCHK(hipStreamSynchronize(b->stream));
     for (int r = r0; r < r1; r++) {
         if (!e[r]) continue;
@@ -330,19 +342,27 @@ static int ensure_tables(rmx_batch *b, int r0, int r1, bool need_segc = true) {
 }
 // ---- strip kernels (S > 32, at most 4 states per lane) --------------------------------------------
 typedef void (*cells_kernel_t)(Dev, int);
-template <int NS> static cells_kernel_t cells_kernel_ns(int mode, int mask) {
-    if (mode == 0) return k_cells<NS, 0, CM_ALL>;
-    if (mode == 1) return k_cells<NS, 1, CM_ALL>;
+// cache: 0 none, 1 evaluate + store, 2 read
+template <int NS> static cells_kernel_t cells_kernel_ns(int mode, int mask, int cache) {
+    if (mode == 0) return cache == 2 ? k_cells<NS, 0, CM_ALL, 2> : (cache == 1 ? k_cells<NS, 0, CM_ALL, 1> : k_cells<NS, 0, CM_ALL, 0>);
+    if (mode == 1) return cache == 2 ? k_cells<NS, 1, CM_ALL, 2> : k_cells<NS, 1, CM_ALL, 0>;
+    if (cache == 2) return k_cells<NS, 2, 31, 2>;
+    if (cache == 1) {
+        switch (mask) {
+        case 3: return k_cells<NS, 2, 3, 1>; case 4: return k_cells<NS, 2, 4, 1>; case 8: return k_cells<NS, 2, 8, 1>;
+        case 12: return k_cells<NS, 2, 12, 1>; case 15: return k_cells<NS, 2, 15, 1>; default: return k_cells<NS, 2, 31, 1>;
+        }
+    }
     switch (mask) {
-    case 3: return k_cells<NS, 2, 3>; case 4: return k_cells<NS, 2, 4>; case 8: return k_cells<NS, 2, 8>;
-    case 12: return k_cells<NS, 2, 12>; case 15: return k_cells<NS, 2, 15>; default: return k_cells<NS, 2, 31>;
+    case 3: return k_cells<NS, 2, 3, 0>; case 4: return k_cells<NS, 2, 4, 0>; case 8: return k_cells<NS, 2, 8, 0>;
+    case 12: return k_cells<NS, 2, 12, 0>; case 15: return k_cells<NS, 2, 15, 0>; default: return k_cells<NS, 2, 31, 0>;
     }
 }
 static bool use_strip(rmx_batch *b) { return b->d.S > 32 && b->d.S <= 256 && !getenv("RMX_NO_STRIP"); }
-static cells_kernel_t cells_kernel(rmx_batch *b, int mode, int mask) {
+static cells_kernel_t cells_kernel(rmx_batch *b, int mode, int mask, int cache) {
     const int ns = (b->d.S + 63) / 64;
-    switch (ns) { case 1: return cells_kernel_ns<1>(mode, mask); case 2: return cells_kernel_ns<2>(mode, mask);
-                  case 3: return cells_kernel_ns<3>(mode, mask); default: return cells_kernel_ns<4>(mode, mask); }
+    switch (ns) { case 1: return cells_kernel_ns<1>(mode, mask, cache); case 2: return cells_kernel_ns<2>(mode, mask, cache);
+                  case 3: return cells_kernel_ns<3>(mode, mask, cache); default: return cells_kernel_ns<4>(mode, mask, cache); }
 }
 static dim3 strip_grid(rmx_batch *b, int nr) { return dim3((b->d.N + 4 * STRIP_RPW - 1) / (4 * STRIP_RPW), nr); }
 // smallest instantiated component mask covering `m`
@@ -364,12 +384,25 @@ static int ensure_ab(rmx_batch *b, int r0, int r1) {
     int r = r0;
     while (r < r1) {
         if (!b->ab_dirty[r]) { r++; continue; }
-        // contiguous run of restarts whose stale components are covered by the same kernel
-        const int mask = use_strip(b) ? cover_mask(b->comp_dirty[r]) : 31;
+        // contiguous run of restarts whose stale components are covered by the same kernel; -1 = every
+        // cell value is current in the cell cache, only the (A, B) reductions are redone from it
+        auto variant = [&](int i) {
+            if (!use_strip(b)) return 31;
+            if (b->use_cache && b->cache_stale[i] == 0 && b->comp_dirty[i]) return -1;
+            return cover_mask(b->comp_dirty[i]);
+        };
+        const int mask = variant(r);
         int e = r;
-        while (e < r1 && b->ab_dirty[e] && (use_strip(b) ? cover_mask(b->comp_dirty[e]) : 31) == mask) e++;
+        while (e < r1 && b->ab_dirty[e] && variant(e) == mask) e++;
         if (use_strip(b)) {
-            if (mask) { ProfScope ps(b, KID_MARGINALS_AB); hipLaunchKernelGGL(cells_kernel(b, 2, mask), strip_grid(b, e - r), dim3(256), 0, b->stream, b->d, r); }
+            if (mask == -1) {
+                ProfScope ps(b, KID_MARGINALS_AB);
+                hipLaunchKernelGGL(cells_kernel(b, 2, 31, 2), strip_grid(b, e - r), dim3(256), 0, b->stream, b->d, r);
+            } else if (mask) {
+                ProfScope ps(b, KID_MARGINALS_AB);
+                hipLaunchKernelGGL(cells_kernel(b, 2, mask, b->use_cache ? 1 : 0), strip_grid(b, e - r), dim3(256), 0, b->stream, b->d, r);
+                if (b->use_cache) for (int i = r; i < e; i++) b->cache_stale[i] &= ~(mask & 15);
+            }
         } else {
             ProfScope ps(b, KID_MARGINALS_AB); hipLaunchKernelGGL(k_marginals<false>, row_grid(b, e - r), dim3(256), 0, b->stream, b->d, r, b->G);
         }
@@ -564,11 +597,19 @@ int rmx_batch_create(const rmx_problem *pr, int32_t R, const double *h_init, con
     DA(pd_lt, double, BEW) DA(pe_lt, double, (size_t)R * d.NBE * ((M * d.D + 1) & ~1) + 2) DA(pd_cached, double, BEW) DA(hist, double, BEW) DA(be_jt, double, (size_t)R * d.NBE) DA(be_ja, double, (size_t)R * d.NBE)
     DA(err, uint32_t, R)
 #undef DA
+    d.lc = nullptr;
+    {
+        const size_t bytes = RNS * 6 * 8;
+        const char *env = getenv("RMX_CELL_CACHE");
+        const bool want = env ? atoi(env) != 0 : true;
+        if (want && S > 32 && S <= 256 && bytes <= ((size_t)96 << 30)) { double *p_ = nullptr; if (dalloc(b, &p_, RNS * 6) == RMX_OK) { d.lc = p_; b->use_cache = true; } }
+    }
     if ((rc = dalloc(b, &b->d_lt_valid, R)) || (rc = dalloc(b, &b->d_partial, (size_t)R * ELBO_BLOCKS * 2)) || (rc = dalloc(b, &b->d_out4, (size_t)R * 4)) ||
         (rc = dalloc(b, &b->d_ell_partial, (size_t)R * std::max(N, ELBO_BLOCKS) * (1 + RMX_MAX_CLONES))) || (rc = dalloc(b, &b->d_ell_out, (size_t)R * 8)) ||
         (rc = dalloc(b, &b->d_sample, (size_t)R * N)) || (rc = dalloc(b, &b->d_grid_out, (size_t)R * 64 * (1 + RMX_MAX_CLONES))) ||
         (rc = dalloc(b, &b->d_rlist, R)) || (rc = dalloc(b, &b->d_counts, R)) || (rc = dalloc(b, &b->d_rp_stage, R)) || (rc = dalloc(b, &b->d_batch_out, (size_t)R * 8))) { rmx_batch_destroy(b); return rc; }
     HIPCHK(hipHostMalloc((void **)&b->h_pinned, sizeof(double) * (size_t)(R + 1) * 64 * (1 + RMX_MAX_CLONES)));
+    HIPCHK(hipHostMalloc((void **)&b->h_err, sizeof(uint32_t) * (size_t)R));
     HIPCHK(hipHostMalloc(&b->h_batch, (size_t)R * (sizeof(RestartParams) + 64) + 4096));
     HIPCHK(hipEventCreate(&b->tm_a)); HIPCHK(hipEventCreate(&b->tm_b));
     b->done_ev.resize(R);
@@ -588,7 +629,7 @@ int rmx_batch_create(const rmx_problem *pr, int32_t R, const double *h_init, con
 
     // per-restart initial state (bpmodel.pyx:546-597)
     b->sample_cache.assign(R, std::vector<int64_t>()); b->sample_count.assign(R, -1);
-    b->rp.resize(R); b->tables_dirty.assign(R, 1); b->segc_dirty.assign(R, 1); b->ab_dirty.assign(R, 1); b->comp_dirty.assign(R, 31); b->lt_valid.assign(R, 0); b->logZ.assign(R, 0.); b->logz_dirty.assign(R, 0);
+    b->rp.resize(R); b->tables_dirty.assign(R, 1); b->segc_dirty.assign(R, 1); b->ab_dirty.assign(R, 1); b->comp_dirty.assign(R, 31); b->cache_stale.assign(R, 15); b->lt_valid.assign(R, 0); b->logZ.assign(R, 0.); b->logz_dirty.assign(R, 0);
     for (int r = 0; r < R; r++) {
         RestartParams &p = b->rp[r];
         memset(&p, 0, sizeof p);
@@ -648,6 +689,7 @@ int rmx_batch_destroy(rmx_batch *b) {
     prof_collect(b);
     for (void *p : b->allocs) hipFree(p);
     if (b->h_pinned) hipHostFree(b->h_pinned);
+    if (b->h_err) hipHostFree(b->h_err);
     if (b->h_batch) hipHostFree(b->h_batch);
     for (auto e : b->ev_pool) hipEventDestroy(e);
     if (b->tm_a) hipEventDestroy(b->tm_a);
@@ -687,6 +729,7 @@ int rmx_set_param(rmx_batch *b, int32_t r, int32_t id, double v) {
     b->rp[r].p[id] = v; b->tables_dirty[r] = 1; b->ab_dirty[r] = 1;
     static const int bits[RMX_P_HMM_LOG_NORM_CONST] = {CM_LT0, CM_LT1, CM_LT0 | CM_LT1, CM_LT0, CM_LT1, CM_LA0, CM_LA1, CM_LA0 | CM_LA1, CM_LA0, CM_LA1, 0, 0, 16};
     b->comp_dirty[r] |= bits[id];
+    b->cache_stale[r] |= (bits[id] & 15);
     return RMX_OK;
 }
 int rmx_get_param(rmx_batch *b, int32_t r, int32_t id, double *v) {
@@ -730,7 +773,7 @@ int rmx_set_array(rmx_batch *b, int32_t r, int32_t id, const void *src) {
     switch (id) {
     case RMX_A_H:
         for (int m = 0; m < d.M; m++) b->rp[r].h[m] = ((const double *)src)[m];
-        b->tables_dirty[r] = 1; b->ab_dirty[r] = 1; b->comp_dirty[r] = 31; return RMX_OK;
+        b->tables_dirty[r] = 1; b->ab_dirty[r] = 1; b->comp_dirty[r] = 31; b->cache_stale[r] = 15; return RMX_OK;
     case RMX_A_P_BREAKPOINT:
         if (d.K) HIPCHK(hipMemcpyAsync(d.pbrk + (size_t)r * d.K * d.B, src, (size_t)d.K * d.B * 8, hipMemcpyHostToDevice, b->stream));
         break;
@@ -745,7 +788,7 @@ int rmx_set_array(rmx_batch *b, int32_t r, int32_t id, const void *src) {
         for (int n = 0; n < d.N; n++) m8[n] = ((const int64_t *)src)[n] != 0;
         HIPCHK(hipStreamSynchronize(b->stream));
         HIPCHK(hipMemcpy((void *)(id == RMX_A_TOTAL_LIKELIHOOD_MASK ? d.mask_t : d.mask_a), m8.data(), d.N, hipMemcpyHostToDevice));
-        for (int i = 0; i < b->R; i++) { b->ab_dirty[i] = 1; b->comp_dirty[i] = 31; }
+        for (int i = 0; i < b->R; i++) { b->ab_dirty[i] = 1; b->comp_dirty[i] = 31; b->cache_stale[i] = 15; }
         return RMX_OK; }
     default: return fail(RMX_EARG, "array is read-only or unknown");
     }
@@ -822,7 +865,18 @@ static int do_framelogprob(rmx_batch *b, int r0, int r1) {
     int rc = ensure_tables(b, r0, r1);
     if (rc) return rc;
     ProfScope ps(b, KID_FRAMELOGPROB);
-    if (use_strip(b)) hipLaunchKernelGGL(cells_kernel(b, 0, CM_ALL), strip_grid(b, r1 - r0), dim3(256), 0, b->stream, b->d, r0);
+    if (use_strip(b)) {
+        // per run of restarts: read the cache where it is current, otherwise evaluate (and fill it)
+        int r = r0;
+        while (r < r1) {
+            const bool cur = b->use_cache && b->cache_stale[r] == 0;
+            int e = r;
+            while (e < r1 && (b->use_cache && b->cache_stale[e] == 0) == cur) e++;
+            hipLaunchKernelGGL(cells_kernel(b, 0, CM_ALL, cur ? 2 : (b->use_cache ? 1 : 0)), strip_grid(b, e - r), dim3(256), 0, b->stream, b->d, r);
+            if (b->use_cache) for (int i = r; i < e; i++) b->cache_stale[i] = 0;
+            r = e;
+        }
+    }
     else hipLaunchKernelGGL(k_framelogprob, row_grid(b, r1 - r0), dim3(256), 0, b->stream, b->d, r0, b->G);
     HIPCHK(hipGetLastError());
     return RMX_OK;
@@ -895,7 +949,7 @@ static int do_update_p_cn(rmx_batch *b, int r0, int r1) {
     }
     {
         ProfScope ps(b, KID_MARGINALS);
-        if (use_strip(b)) hipLaunchKernelGGL(cells_kernel(b, 1, CM_ALL), strip_grid(b, r1 - r0), dim3(256), 0, b->stream, b->d, r0);
+        if (use_strip(b)) hipLaunchKernelGGL(cells_kernel(b, 1, CM_ALL, b->use_cache ? 2 : 0), strip_grid(b, r1 - r0), dim3(256), 0, b->stream, b->d, r0);   // the F pass just made the cache current
         else hipLaunchKernelGGL(k_marginals<true>, row_grid(b, r1 - r0), dim3(256), 0, b->stream, b->d, r0, b->G);
         HIPCHK(hipGetLastError());
     }
@@ -1114,22 +1168,17 @@ int rmx_expected_ll_param_grid(rmx_batch *b, int32_t r, int32_t param_id, const 
 // One candidate value of one likelihood parameter per listed restart (distinct restarts), each on
 // its restart's current sample: the evaluation round of a lock-step optimiser.  Three launches and
 // one host round trip for the whole list.
-int rmx_expected_ll_batch(rmx_batch *b, int32_t nreq, const int32_t *restarts, int32_t param_id, const double *values, double *out) {
-    if (!b || nreq < 1 || nreq > b->R || !restarts || !values || !out) return fail(RMX_EARG, "bad argument");
-    if (param_id < 0 || param_id >= RMX_P_HMM_LOG_NORM_CONST) return fail(RMX_EARG, "bad param id");
+// shared tail of the batched objective calls: stage the listed restarts' parameters, rebuild their
+// state tables, evaluate every restart's sample, reduce, copy back nout values per request
+static int run_ell_batch(rmx_batch *b, int nreq, const int32_t *restarts, bool grad, double *out) {
     const Dev &d = b->d;
     const int W = 1 + RMX_MAX_CLONES;
-    std::vector<char> seen(b->R, 0);
+    const int nout = grad ? W : 1;
     int maxcnt = 0;
     RestartParams *hs = (RestartParams *)b->h_batch;
     int32_t *hl = (int32_t *)((char *)b->h_batch + (size_t)b->R * sizeof(RestartParams));
     for (int i = 0; i < nreq; i++) {
         const int r = restarts[i];
-        if (r < 0 || r >= b->R || seen[r]) return fail(RMX_EARG, "restart list must hold distinct valid restarts");
-        if (b->sample_count[r] < 0) return fail(RMX_EARG, "no sample set for a listed restart");
-        seen[r] = 1;
-        int rc = rmx_set_param(b, r, param_id, values[i]);
-        if (rc) return rc;
         fill_logr(b->rp[r]);
         hs[i] = b->rp[r]; hl[i] = r;
         maxcnt = std::max(maxcnt, b->sample_count[r]);
@@ -1142,19 +1191,180 @@ int rmx_expected_ll_batch(rmx_batch *b, int32_t nreq, const int32_t *restarts, i
         const int pstride = std::max(d.N, ELBO_BLOCKS) * W;
         if (maxcnt > 0) {
             ProfScope ps(b, KID_ELL_LIST);
-            hipLaunchKernelGGL(k_ell_list_batch, dim3(maxcnt, nreq), dim3(256), 0, b->stream, b->d, (const int32_t *)b->d_rlist, (const RestartParams *)b->d_rp_stage,
-                               (const int32_t *)b->d_sample, (const int32_t *)b->d_counts, b->d_ell_partial, pstride);
+            if (grad) hipLaunchKernelGGL(k_ell_list_batch<true>, dim3(maxcnt, nreq), dim3(256), 0, b->stream, b->d, (const int32_t *)b->d_rlist, (const RestartParams *)b->d_rp_stage,
+                                         (const int32_t *)b->d_sample, (const int32_t *)b->d_counts, b->d_ell_partial, pstride);
+            else hipLaunchKernelGGL(k_ell_list_batch<false>, dim3(maxcnt, nreq), dim3(256), 0, b->stream, b->d, (const int32_t *)b->d_rlist, (const RestartParams *)b->d_rp_stage,
+                                    (const int32_t *)b->d_sample, (const int32_t *)b->d_counts, b->d_ell_partial, pstride);
         }
         { ProfScope ps(b, KID_ELL_FINAL); hipLaunchKernelGGL(k_ell_final_batch, dim3(nreq), dim3(256), 0, b->stream, b->d, (const int32_t *)b->d_rlist, (const int32_t *)b->d_counts,
-                                                             (const double *)b->d_ell_partial, pstride, b->d_batch_out); }
+                                                             (const double *)b->d_ell_partial, pstride, b->d_batch_out, nout); }
         HIPCHK(hipGetLastError());
-        for (int i = 0; i < nreq; i++) { b->tables_dirty[restarts[i]] = 0; b->segc_dirty[restarts[i]] = 1; b->ab_dirty[restarts[i]] = 1; }   // comp_dirty: set by rmx_set_param above
-        HIPCHK(hipMemcpyAsync(b->h_pinned, b->d_batch_out, (size_t)nreq * 8, hipMemcpyDeviceToHost, b->stream));
+        for (int i = 0; i < nreq; i++) { b->tables_dirty[restarts[i]] = 0; b->segc_dirty[restarts[i]] = 1; b->ab_dirty[restarts[i]] = 1; }   // comp_dirty / cache_stale: set by the callers' setters
+        HIPCHK(hipMemcpyAsync(b->h_pinned, b->d_batch_out, (size_t)nreq * nout * 8, hipMemcpyDeviceToHost, b->stream));
     }
     int rc = check_errors(b, 0, b->R);
     if (rc) return rc;
-    for (int i = 0; i < nreq; i++) out[i] = b->h_pinned[i];
+    for (int i = 0; i < nreq * nout; i++) out[i] = b->h_pinned[i];
     return RMX_OK;
+}
+static int check_request_list(rmx_batch *b, int nreq, const int32_t *restarts) {
+    std::vector<char> seen(b->R, 0);
+    for (int i = 0; i < nreq; i++) {
+        const int r = restarts[i];
+        if (r < 0 || r >= b->R || seen[r]) return fail(RMX_EARG, "restart list must hold distinct valid restarts");
+        if (b->sample_count[r] < 0) return fail(RMX_EARG, "no sample set for a listed restart");
+        seen[r] = 1;
+    }
+    return RMX_OK;
+}
+int rmx_expected_ll_batch(rmx_batch *b, int32_t nreq, const int32_t *restarts, int32_t param_id, const double *values, double *out) {
+    if (!b || nreq < 1 || nreq > b->R || !restarts || !values || !out) return fail(RMX_EARG, "bad argument");
+    if (param_id < 0 || param_id >= RMX_P_HMM_LOG_NORM_CONST) return fail(RMX_EARG, "bad param id");
+    int rc = check_request_list(b, nreq, restarts);
+    if (rc) return rc;
+    for (int i = 0; i < nreq; i++)
+        if ((rc = rmx_set_param(b, restarts[i], param_id, values[i]))) return rc;
+    return run_ell_batch(b, nreq, restarts, false, out);
+}
+
+// ---- lock-step 1-D parameter search ------------------------------------------------------------
+// scipy.optimize.fmin (Nelder-Mead, one variable, xatol = fatol = 1e-4, maxiter = maxfun = 200) as a
+// resumable state machine: same floating-point operations in the same order as scipy's
+// _minimize_neldermead (python twin: remixt_amd/lockstep.py fmin_1d; tests compare the two).
+namespace {
+struct Nm1 {
+    enum { START, W_INIT0, W_INIT1, W_XR, W_XE, W_XC, W_XCC, W_SHRINK, DONE };
+    double s0 = 0, s1 = 0, f0 = INFINITY, f1 = INFINITY, xbar = 0, xr = 0, fxr = 0, xe = 0, xc = 0, xcc = 0, req = 0, last = 0;
+    int fcalls = 0, iters = 0, state = START;
+    static constexpr int maxfun = 200, maxiter = 200;
+    static constexpr double xatol = 1e-4, fatol = 1e-4;
+    bool request(double x, int next) { if (fcalls >= maxfun) return false; fcalls++; req = x; last = x; state = next; return true; }
+    void sort() { if (f1 < f0) { std::swap(f0, f1); std::swap(s0, s1); } }
+    // feed the value of the last request (ignored on the first call); true = `req` holds the next point
+    bool advance(double x0, double f) {
+#pragma clang fp contract(off)
+        switch (state) {
+        case START:
+            s0 = x0; s1 = x0 != 0. ? (1 + 0.05) * x0 : 0.00025;
+            if (request(s0, W_INIT0)) return true;
+            goto init_done;
+        case W_INIT0:
+            f0 = f;
+            if (request(s1, W_INIT1)) return true;
+            goto init_done;
+        case W_INIT1:
+            f1 = f;
+            goto init_done;
+        case W_XR:
+            fxr = f;
+            if (fxr < f0) {
+                xe = 3. * xbar - 2. * s1;
+                if (request(xe, W_XE)) return true;
+                goto maxfun_exit;
+            }
+            // N = 1: fsim[-2] is fsim[0], so "fxr < fsim[-2]" cannot hold here
+            if (fxr < f1) {
+                xc = 1.5 * xbar - 0.5 * s1;
+                if (request(xc, W_XC)) return true;
+                goto maxfun_exit;
+            }
+            xcc = 0.5 * xbar + 0.5 * s1;
+            if (request(xcc, W_XCC)) return true;
+            goto maxfun_exit;
+        case W_XE:
+            if (f < fxr) { s1 = xe; f1 = f; } else { s1 = xr; f1 = fxr; }
+            goto iter_done;
+        case W_XC:
+            if (f <= fxr) { s1 = xc; f1 = f; goto iter_done; }
+            goto shrink;
+        case W_XCC:
+            if (f < f1) { s1 = xcc; f1 = f; goto iter_done; }
+            goto shrink;
+        case W_SHRINK:
+            f1 = f;
+            goto iter_done;
+        default:
+            return false;
+        }
+    shrink:
+        s1 = s0 + 0.5 * (s1 - s0);
+        if (request(s1, W_SHRINK)) return true;
+        goto maxfun_exit;
+    init_done:
+        sort();
+        iters = 1;
+        goto loop_top;
+    iter_done:
+        iters++;
+    maxfun_exit:
+        sort();
+    loop_top:
+        if (fcalls < maxfun && iters < maxiter) {
+            if (!(fabs(s1 - s0) <= xatol && fabs(f0 - f1) <= fatol)) {
+                xbar = s0 / 1;
+                xr = 2. * xbar - 1. * s1;
+                if (request(xr, W_XR)) return true;
+                goto maxfun_exit;      // cannot happen (fcalls < maxfun was just checked); mirrors the python flow
+            }
+        }
+        state = DONE;
+        return false;
+    }
+    double xopt() const { return s0; }
+};
+}  // namespace
+
+// scipy.optimize.brute(nll, ranges=[(lo, hi)], Ns=G, full_output=True)[0] for one likelihood parameter
+// of every listed restart in lock step (BreakpointModel.update_param, cn_model.py:553-561): grid of G
+// values (np.mgrid[lo:hi:complex(G)], passed in), first arg-min, Nelder-Mead polish from the best grid
+// point; nll(v) = -E[ll] on the restart's current sample, +inf outside [lo, hi] without touching the
+// model (cn_model.py:542-543).  Each round of evaluations is one rmx_expected_ll_batch call.  The
+// parameter is left at the last value evaluated for the restart (the reference's acceptance test
+// looks at exactly that state); xopt[i] receives the optimiser's result for restarts[i].
+int rmx_param_search(rmx_batch *b, int32_t nreq, const int32_t *restarts, int32_t param_id, double lo, double hi,
+                     const double *grid, int32_t G, double *xopt) {
+    if (!b || nreq < 1 || nreq > b->R || !restarts || !grid || G < 1 || !xopt) return fail(RMX_EARG, "bad argument");
+    int rc;
+    std::vector<double> vals(nreq), out(nreq), best(nreq, INFINITY), x0(nreq);
+    for (int g = 0; g < G; g++) {
+        for (int i = 0; i < nreq; i++) vals[i] = grid[g];
+        if ((rc = rmx_expected_ll_batch(b, nreq, restarts, param_id, vals.data(), out.data()))) return rc;
+        for (int i = 0; i < nreq; i++) { const double J = -out[i]; if (g == 0 || J < best[i]) { best[i] = J; x0[i] = grid[g]; } }   // np.argmin: first minimum
+    }
+    std::vector<Nm1> nm(nreq);
+    std::vector<int> want;          // requests waiting for a device evaluation
+    std::vector<int32_t> rl(nreq);
+    auto pump = [&](int i, double f) {
+        // advance optimiser i until it needs a device evaluation or finishes; out-of-bounds points are +inf at once
+        while (nm[i].advance(x0[i], f)) {
+            const double v = nm[i].req;
+            if (v < lo || v > hi) { f = INFINITY; continue; }
+            want.push_back(i);
+            return;
+        }
+    };
+    for (int i = 0; i < nreq; i++) pump(i, 0.);
+    while (!want.empty()) {
+        std::vector<int> cur;
+        cur.swap(want);
+        for (size_t k = 0; k < cur.size(); k++) { rl[k] = restarts[cur[k]]; vals[k] = nm[cur[k]].req; }
+        if ((rc = rmx_expected_ll_batch(b, (int)cur.size(), rl.data(), param_id, vals.data(), out.data()))) return rc;
+        for (size_t k = 0; k < cur.size(); k++) pump(cur[k], -out[k]);
+    }
+    for (int i = 0; i < nreq; i++) xopt[i] = nm[i].xopt();
+    return RMX_OK;
+}
+
+// One candidate haploid-depth vector per listed restart: E[ll] and dE[ll]/dh on each restart's
+// current sample (the objective / gradient pair of BreakpointModel.update_h, cn_model.py:484-498),
+// the evaluation round of a lock-step L-BFGS-B.  h [nreq][M]; out [nreq][1 + RMX_MAX_CLONES].
+int rmx_expected_ll_h_batch(rmx_batch *b, int32_t nreq, const int32_t *restarts, const double *h, double *out) {
+    if (!b || nreq < 1 || nreq > b->R || !restarts || !h || !out) return fail(RMX_EARG, "bad argument");
+    int rc = check_request_list(b, nreq, restarts);
+    if (rc) return rc;
+    for (int i = 0; i < nreq; i++)
+        if ((rc = rmx_set_array(b, restarts[i], RMX_A_H, h + (size_t)i * b->d.M))) return rc;
+    return run_ell_batch(b, nreq, restarts, true, out);
 }
 
 // Full-data E[ll] (sample of all ones, :1125-1157) for a restart range from the per-segment
@@ -1276,7 +1486,7 @@ int rmx_timer_stop(rmx_batch *b, double *ms) {
     HIPCHK(hipEventRecord(b->tm_b, b->stream)); HIPCHK(hipEventSynchronize(b->tm_b));
     float f = 0; HIPCHK(hipEventElapsedTime(&f, b->tm_a, b->tm_b)); *ms = f; return RMX_OK;
 }
-int rmx_profile_enable(rmx_batch *b, int32_t on) { prof_collect(b); b->prof = on != 0; return RMX_OK; }
+int rmx_profile_enable(rmx_batch *b, int32_t on) { prof_collect(b); b->prof = on < 0 ? 0 : (on > 2 ? 1 : on); return RMX_OK; }
 int rmx_profile_get(rmx_batch *b, int32_t id, double *ms, int64_t *n) {
     if (id < 0 || id >= KID_COUNT) return fail(RMX_EARG, "bad kernel id");
     HIPCHK(hipStreamSynchronize(b->stream));

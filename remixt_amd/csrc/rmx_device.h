@@ -73,6 +73,7 @@ struct Dev {
     double *qt, *qa, *qs;                // [R][N][2]
     double *pbrk;                        // [R][K][B]
     double *f, *fe, *fa, *fb, *post;     // [R][N][SP]; fe = exp(f - rowmax)
+    double *lc;                          // [R][6][N][SP] cached cell likelihoods (LT0, LT1, LA00, LA01, LA10, LA11) or null
     double *fmax, *mrow;                 // [R][N]
     double *A, *Bv;                      // [R][N][2], [R][N][4]
     double *rowPF, *rowPP, *rowZ;        // [R][N]

@@ -806,7 +806,11 @@ __global__ void k_marginals(Dev d, int r0, int G) {
 // grid (ceil(N / (4*RPW)), nr), block 256.
 // =============================================================================
 #define STRIP_RPW 8
-template <int NS, int MODE, int MASK>
+// CACHE: 0 = evaluate the cells, 1 = evaluate and store the evaluated components in the cell cache
+// d.lc, 2 = take all six values from the cache (no transcendental at all).  The six values depend on
+// (h, likelihood parameters, masks) only, i.e. they are constant across the variational sweeps of one
+// EM iteration; the host tracks per restart which components of the cache are current.
+template <int NS, int MODE, int MASK, int CACHE>
 __global__ __launch_bounds__(256) void k_cells(Dev d, int r0) {
     const int r = r0 + blockIdx.y;
     const int lane = threadIdx.x & 63;
@@ -818,11 +822,29 @@ __global__ __launch_bounds__(256) void k_cells(Dev d, int r0) {
     const int S = d.S;
     StateRegs st[NS];
     int cur_cls = -1;
+    auto nsub_of = [&](int cls_, int s_) { return (double)((d.sflags[(size_t)cls_ * d.S + s_] >> 2) & 3); };
     unsigned err = 0;
     const double divw = rp.p[RMX_P_DIVERGENCE_WEIGHT];
+    const size_t plane = (size_t)d.N * d.SP;
+    double *lcr = d.lc ? d.lc + (size_t)r * 6 * plane : nullptr;
+    // one cell through the cache policy
+    auto cell = [&](const SegCtx &sc, const StateRegs &stx, size_t off, double LT[2], double LA[4]) {
+        if (CACHE == 2) {
+            LT[0] = lcr[off]; LT[1] = lcr[plane + off];
+            LA[0] = lcr[2 * plane + off]; LA[1] = lcr[3 * plane + off]; LA[2] = lcr[4 * plane + off]; LA[3] = lcr[5 * plane + off];
+        } else {
+            cell_ll_regs<MASK & CM_ALL>(rp, sc, stx, LT, LA, err);
+            if (CACHE == 1) {
+                if (MASK & CM_LT0) lcr[off] = LT[0];
+                if (MASK & CM_LT1) lcr[plane + off] = LT[1];
+                if (MASK & CM_LA0) { lcr[2 * plane + off] = LA[0]; lcr[3 * plane + off] = LA[1]; }
+                if (MASK & CM_LA1) { lcr[4 * plane + off] = LA[2]; lcr[5 * plane + off] = LA[3]; }
+            }
+        }
+    };
     for (int n = nbeg; n < nend; n++) {     // n is wave-uniform (SGPR)
         const int cls = d.seg_class[n];
-        if (cls != cur_cls) {
+        if (CACHE != 2 && cls != cur_cls) {
 #pragma unroll
             for (int k = 0; k < NS; k++) { const int s = lane + 64 * k; load_state_regs(d, r, cls, s < S ? s : S - 1, st[k]); }   // clamped: lanes past S are masked at use
             cur_cls = cls;
@@ -841,11 +863,11 @@ __global__ __launch_bounds__(256) void k_cells(Dev d, int r0) {
                 fv[k] = -INFINITY;
                 if (s < S) {
                     double LT[2], LA[4];
-                    cell_ll_regs<CM_ALL>(rp, sc, st[k], LT, LA, err);
+                    cell(sc, st[k], (size_t)n * d.SP + s, LT, LA);
                     double f = 0.;
                     f += qt0 * LT[0]; f += qt1 * LT[1];
                     f += qa0 * qs0 * LA[0]; f += qa0 * qs1 * LA[1]; f += qa1 * qs0 * LA[2]; f += qa1 * qs1 * LA[3];
-                    f += -1.0 * st[k].nsub * sc.l * divw;
+                    f += -1.0 * (CACHE == 2 ? nsub_of(cls, s) : st[k].nsub) * sc.l * divw;
                     if (f != f) err |= RMX_ERR_NAN_F;
                     d.f[ro + s] = f;
                     fv[k] = f;
@@ -881,11 +903,11 @@ __global__ __launch_bounds__(256) void k_cells(Dev d, int r0) {
                 const int s = lane + 64 * k;
                 if (s < S) {
                     double LT[2], LA[4];
-                    cell_ll_regs<MASK>(rp, sc, st[k], LT, LA, err);
+                    cell(sc, st[k], (size_t)n * d.SP + s, LT, LA);
                     const double ps = pv[k];
                     a0 += ps * LT[0]; a1 += ps * LT[1];
                     b0 += ps * LA[0]; b1 += ps * LA[1]; b2 += ps * LA[2]; b3 += ps * LA[3];
-                    if (MODE == 1 || (MASK & 16)) { pf += ps * d.f[ro + s]; pp += ps * (-1.0 * st[k].nsub * sc.l * divw); }
+                    if (MODE == 1 || (MASK & 16)) { pf += ps * d.f[ro + s]; pp += ps * (-1.0 * (CACHE == 2 ? nsub_of(cls, s) : st[k].nsub) * sc.l * divw); }
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -1267,12 +1289,11 @@ __global__ void k_elbo_final(Dev d, int r0, const double *partial, int nblk, con
 // M-step objectives on a list of segments (bpmodel.pyx:1125-1195)
 // grid (nlist), block 256: one segment per block; partial [nlist][1+M]
 // =============================================================================
+// one sampled segment per block: E[ll] (and d/dh when GRAD) of segment n under parameters rp -> prow[1+MAXC]
 template <bool GRAD>
-__global__ void k_ell_list(Dev d, int r, const int32_t *list, double *partial) {
+__device__ __forceinline__ void ell_segment(const Dev &d, const RestartParams &rp, int r, int n, double *prow) {
     __shared__ double scratch[8];
     __shared__ double segk[8];
-    const int n = list[blockIdx.x];
-    const RestartParams &rp = d.rp[r];
     SegCtx sc;
     sc.x = d.x[n]; sc.l = d.l[n]; sc.logl = d.logl[n]; sc.y0 = d.y[2 * (size_t)n]; sc.y1 = d.y[2 * (size_t)n + 1]; sc.ys = sc.y0 + sc.y1;
     sc.mt = d.mask_t[n]; sc.ma = d.mask_a[n];
@@ -1343,15 +1364,18 @@ __global__ void k_ell_list(Dev d, int r, const int32_t *list, double *partial) {
             }
         }
     }
-    const int W = 1 + RMX_MAX_CLONES;
     acc = block_sum<256>(acc, scratch);
-    if (threadIdx.x == 0) partial[(size_t)blockIdx.x * W] = acc;
+    if (threadIdx.x == 0) prow[0] = acc;
     if (GRAD)
         for (int m = 0; m < RMX_MAX_CLONES; m++) {
             const double gm = block_sum<256>(g[m], scratch);
-            if (threadIdx.x == 0) partial[(size_t)blockIdx.x * W + 1 + m] = gm;
+            if (threadIdx.x == 0) prow[1 + m] = gm;
         }
     if (err) atomicOr(&d.err[r], err);
+}
+template <bool GRAD>
+__global__ void k_ell_list(Dev d, int r, const int32_t *list, double *partial) {
+    ell_segment<GRAD>(d, d.rp[r], r, list[blockIdx.x], partial + (size_t)blockIdx.x * (1 + RMX_MAX_CLONES));
 }
 // deterministic final sum over nlist partials -> out[1+MAXC].  grid 1, block 256
 __global__ void k_ell_final(const double *partial, int nlist, double *out) {
@@ -1390,48 +1414,26 @@ __global__ void k_state_tables_list(Dev d, const int32_t *rlist, const RestartPa
     state_tables_body(d, blockIdx.x, r, rp);
 }
 // grid (maxcount, nreq): block (i, j) evaluates sampled segment i of restart rlist[j]
+template <bool GRAD>
 __global__ void k_ell_list_batch(Dev d, const int32_t *rlist, const RestartParams *stage, const int32_t *samples, const int32_t *counts,
                                  double *partial, int pstride) {
-    __shared__ double scratch[8];
-    __shared__ double segk[8];
     const int r = rlist[blockIdx.y];
     if ((int)blockIdx.x >= counts[r]) return;
     const int n = samples[(size_t)r * d.N + blockIdx.x];
-    const RestartParams &rp = stage[blockIdx.y];    // identical to d.rp[r]; read from the stage to stay independent of launch order
-    SegCtx sc;
-    sc.x = d.x[n]; sc.l = d.l[n]; sc.logl = d.logl[n]; sc.y0 = d.y[2 * (size_t)n]; sc.y1 = d.y[2 * (size_t)n + 1]; sc.ys = sc.y0 + sc.y1;
-    sc.mt = d.mask_t[n]; sc.ma = d.mask_a[n];
-    if (threadIdx.x < 8) segk[threadIdx.x] = seg_const_value(rp, sc.x, sc.y0, sc.ys, threadIdx.x);
-    __syncthreads();
-#pragma unroll
-    for (int i = 0; i < 4; i++) { sc.cnb[i] = segk[i]; sc.cbb[i] = segk[4 + i]; }
-    const int cls = d.seg_class[n];
-    const size_t rn = (size_t)r * d.N + n;
-    const double qt0 = d.qt[rn * 2], qt1 = d.qt[rn * 2 + 1], qa0 = d.qa[rn * 2], qa1 = d.qa[rn * 2 + 1];
-    const double qs0 = d.qs[rn * 2], qs1 = d.qs[rn * 2 + 1];
-    const double *post = d.post + rs_off(d, r, n);
-    unsigned err = 0;
-    double acc = 0.;
-    for (int s = threadIdx.x; s < d.S; s += 256) {
-        double LT[2], LA[4];
-        cell_ll(d, rp, sc, r, cls, s, LT, LA, err);
-        const double ps = post[s];
-        acc += ps * qt0 * LT[0]; acc += ps * qt1 * LT[1];
-        acc += ps * qa0 * qs0 * LA[0]; acc += ps * qa0 * qs1 * LA[1]; acc += ps * qa1 * qs0 * LA[2]; acc += ps * qa1 * qs1 * LA[3];
-    }
-    acc = block_sum<256>(acc, scratch);
-    if (threadIdx.x == 0) partial[(size_t)r * pstride + (size_t)blockIdx.x * (1 + RMX_MAX_CLONES)] = acc;
-    if (err) atomicOr(&d.err[r], err);
+    // stage[j] is identical to d.rp[r]; read from the stage to stay independent of launch order
+    ell_segment<GRAD>(d, stage[blockIdx.y], r, n, partial + (size_t)r * pstride + (size_t)blockIdx.x * (1 + RMX_MAX_CLONES));
 }
-// grid (nreq): deterministic sum of restart rlist[j]'s partials -> out[j]
-__global__ void k_ell_final_batch(Dev d, const int32_t *rlist, const int32_t *counts, const double *partial, int pstride, double *out) {
+// grid (nreq): deterministic sum of restart rlist[j]'s partials -> out[j * nout + c], c < nout (1 = value only, 1+MAXC = value and d/dh)
+__global__ void k_ell_final_batch(Dev d, const int32_t *rlist, const int32_t *counts, const double *partial, int pstride, double *out, int nout) {
     __shared__ double scratch[8];
     const int r = rlist[blockIdx.x];
     const int W = 1 + RMX_MAX_CLONES;
-    double a = 0.;
-    for (int i = threadIdx.x; i < counts[r]; i += 256) a += partial[(size_t)r * pstride + (size_t)i * W];
-    a = block_sum<256>(a, scratch);
-    if (threadIdx.x == 0) out[blockIdx.x] = a;
+    for (int c = 0; c < nout; c++) {
+        double a = 0.;
+        for (int i = threadIdx.x; i < counts[r]; i += 256) a += partial[(size_t)r * pstride + (size_t)i * W + c];
+        a = block_sum<256>(a, scratch);
+        if (threadIdx.x == 0) out[(size_t)blockIdx.x * nout + c] = a;
+    }
 }
 // full-data E[ll] from (A, B) for a restart range: grid (ELBO_BLOCKS, nr) -> partial[(r-r0)][blk]
 __global__ void k_ell_full_batch(Dev d, int r0, double *partial) {

@@ -158,3 +158,91 @@ def run_lockstep(generators, evaluate):
                 results[i] = stop.value
         pending = nxt
     return results
+
+
+class LbfgsbResult(object):
+    """The fields of scipy's OptimizeResult that BreakpointModel.update_h looks at."""
+
+    def __init__(self, x, fun, jac, nfev, nit, status, message, success):
+        self.x, self.fun, self.jac, self.nfev, self.njev, self.nit = x, fun, jac, nfev, nfev, nit
+        self.status, self.message, self.success = status, message, success
+
+    def __str__(self):
+        return ' message: {}\n success: {}\n  status: {}\n     fun: {}\n       x: {}\n     nit: {}\n     jac: {}\n    nfev: {}'.format(
+            self.message, self.success, self.status, self.fun, self.x, self.nit, self.jac, self.nfev)
+
+
+def lbfgsb_available():
+    """The reverse-communication L-BFGS-B driver below calls scipy's private `_lbfgsb.setulb` with the
+    argument list of scipy 1.15; other layouts make callers fall back to scipy.optimize.minimize."""
+    try:
+        import scipy
+        from scipy.optimize import _lbfgsb, _lbfgsb_py   # noqa: F401
+        major, minor = [int(v) for v in scipy.__version__.split('.')[:2]]
+        return (major, minor) == (1, 15) and hasattr(_lbfgsb_py, 'status_messages') and hasattr(_lbfgsb_py, 'task_messages')
+    except Exception:
+        return False
+
+
+def lbfgsb_gen(x0, bounds, maxcor=10, ftol=2.2204460492503131e-09, gtol=1e-5, maxfun=15000, maxiter=15000, maxls=20):
+    """Generator form of scipy.optimize.minimize(fun, x0, method='L-BFGS-B', jac=grad, bounds=bounds)
+    (scipy 1.15 `_minimize_lbfgsb`): yields the point at which it wants (f, g), receives the pair.
+
+    Same sequence as scipy: ScalarFunction evaluates (f, g) at the clipped x0 when it is built and
+    serves the first request from that cache; afterwards one (f, g) evaluation per `task == FG`.
+    StopIteration.value is an LbfgsbResult."""
+    from scipy.optimize import _lbfgsb
+    from scipy.optimize._lbfgsb_py import status_messages, task_messages
+    m = maxcor
+    factr = ftol / np.finfo(float).eps
+    x0 = np.asarray(x0, dtype=np.float64).ravel()
+    n = x0.shape[0]
+    lo = np.array([b[0] for b in bounds], dtype=np.float64)
+    hi = np.array([b[1] for b in bounds], dtype=np.float64)
+    x0 = np.clip(x0, lo, hi)
+    nbd = np.full(n, 2, dtype=np.int32)       # finite lower and upper bounds on every variable
+    low_bnd = lo.copy(); upper_bnd = hi.copy()
+
+    x = np.array(x0, dtype=np.float64)
+    f = np.array(0.0, dtype=np.int32)
+    g = np.zeros((n,), dtype=np.int32)
+    wa = np.zeros(2 * m * n + 5 * n + 11 * m * m + 8 * m, np.float64)
+    iwa = np.zeros(3 * n, dtype=np.int32)
+    task = np.zeros(2, dtype=np.int32)
+    ln_task = np.zeros(2, dtype=np.int32)
+    lsave = np.zeros(4, dtype=np.int32)
+    isave = np.zeros(44, dtype=np.int32)
+    dsave = np.zeros(29, dtype=np.float64)
+
+    # ScalarFunction.__init__: f and g at x0
+    cx = np.copy(x0)
+    cf, cg = yield np.copy(cx)
+    cg = np.atleast_1d(np.asarray(cg, dtype=np.float64))
+    nfev = 1
+    n_iterations = 0
+    while True:
+        g = g.astype(np.float64)
+        _lbfgsb.setulb(m, x, low_bnd, upper_bnd, nbd, f, g, factr, gtol, wa, iwa, task, lsave, isave, dsave, maxls, ln_task)
+        if task[0] == 3:
+            if not np.array_equal(x, cx):
+                cx = np.copy(x)
+                cf, cg = yield np.copy(cx)
+                cg = np.atleast_1d(np.asarray(cg, dtype=np.float64))
+                nfev += 1
+            f, g = cf, cg
+        elif task[0] == 1:
+            n_iterations += 1
+            if n_iterations >= maxiter:
+                task[0] = 5; task[1] = 504
+            elif nfev > maxfun:
+                task[0] = 5; task[1] = 502
+        else:
+            break
+    if task[0] == 4:
+        warnflag = 0
+    elif nfev > maxfun or n_iterations >= maxiter:
+        warnflag = 1
+    else:
+        warnflag = 2
+    msg = status_messages[task[0]] + ": " + task_messages[task[1]]
+    return LbfgsbResult(x, f, g, nfev, n_iterations, warnflag, msg, warnflag == 0)

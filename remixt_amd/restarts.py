@@ -18,8 +18,9 @@ class RestartSet(object):
     """R restarts of one experiment advancing in lockstep on one device."""
 
     def __init__(self, experiment, init_params, max_copy_number, num_clones=3, device=0, quiet=True,
-                 kernel_module=None, seeds=None, strict=False, mstep_threads=8, lockstep=True, **model_kwargs):
+                 kernel_module=None, seeds=None, strict=False, mstep_threads=8, lockstep=True, native_search=True, **model_kwargs):
         self.experiment = experiment
+        self.native_search = native_search
         self.strict = strict
         self.mstep_threads = mstep_threads
         self.lockstep = lockstep
@@ -79,16 +80,19 @@ class RestartSet(object):
     def em_iteration(self, i=0, num_update_iter=5):
         """cn_model.py:409-428 for every restart: batched variational sweeps, per-restart
         scipy M-steps, batched ELBO."""
+        import time
+        t_ = [time.perf_counter()]
         self.variational_update(num_update_iter)
+        t_.append(time.perf_counter())
 
         # Lock-step parameter search needs the batched device objective and a private RNG stream per
         # restart (so that the order in which restarts draw their samples does not matter).
         lockstep = (self.lockstep and self.batch is not None and hasattr(self.batch, 'expected_log_likelihood_batch') and
-                    all(m.rng is not None for m in self.models))
+                    all(m.rng is not None for m in self.models) and not any(m.check_elbo for m in self.models))
 
-        def mstep(r):
+        def mstep(r, with_h=True):
             m = self.models[r]
-            if m.do_h_update:
+            if with_h and m.do_h_update:
                 h_before = np.array(m.model.h, dtype=float)
                 try:
                     m.em_update_h()
@@ -104,24 +108,113 @@ class RestartSet(object):
                 m.em_update_params()
 
         # The M-steps are host-latency-bound (hundreds of tiny objective evaluations per restart,
-        # each a device round trip): restarts run on host threads so one restart's round trip
-        # overlaps the others' Python.  Needs a private RNG stream per restart (seeds=...); with the
-        # reference's global numpy RNG the restarts run one after the other.
+        # each a device round trip).  Preferred: every optimiser of every restart advances in lock
+        # step and each round of evaluations is one batched device call.  Otherwise restarts run on
+        # host threads so one restart's round trip overlaps the others' Python.  Both need a private
+        # RNG stream per restart (seeds=...); with the reference's global numpy RNG the restarts run
+        # one after the other.
+        from . import lockstep as _ls
+        h_done = False
+        if lockstep and hasattr(self.batch, 'expected_log_likelihood_h_batch') and _ls.lbfgsb_available():
+            h_done = self._update_h_lockstep()
         threaded = (self.batch is not None and self.mstep_threads > 1 and
                     all(m.rng is not None for m in self.models))
-        if threaded:
-            from concurrent.futures import ThreadPoolExecutor
-            with ThreadPoolExecutor(max_workers=self.mstep_threads) as pool:
-                list(pool.map(mstep, range(len(self.models))))
+        if h_done and lockstep:
+            pass
+        elif threaded:
+            list(self._threads().map(lambda r: mstep(r, not h_done), range(len(self.models))))
         else:
             for r in range(len(self.models)):
-                mstep(r)
+                mstep(r, not h_done)
+        t_.append(time.perf_counter())
         if lockstep:
             self._update_params_lockstep()
+        t_.append(time.perf_counter())
         elbo = self.calculate_elbo()
+        t_.append(time.perf_counter())
+        self.phase_times = t_      # [start, after sweeps, after h M-step, after parameter M-steps, after ELBO]
         for m, e in zip(self.models, elbo):
             m.record_elbo(float(e), i)
         return elbo
+
+    def _threads(self):
+        if getattr(self, '_pool', None) is None:
+            from concurrent.futures import ThreadPoolExecutor
+            self._pool = ThreadPoolExecutor(max_workers=max(1, self.mstep_threads))
+        return self._pool
+
+    def _samples(self, weights=None):
+        """One M-step sample per restart (BreakpointModel._create_sample).  Every restart draws from
+        its own RNG stream, so the draws run on host threads (numpy's cumsum / searchsorted /
+        permutation release the GIL)."""
+        def draw(r):
+            return self.models[r]._create_sample(None if weights is None else weights[r])
+        R = len(self.models)
+        if self.mstep_threads > 1 and R > 1:
+            return list(self._threads().map(draw, range(R)))
+        return [draw(r) for r in range(R)]
+
+    def _update_h_lockstep(self):
+        """BreakpointModel.update_h (cn_model.py:482-531) for all restarts at once: per restart the
+        evaluation sequence of scipy's L-BFGS-B driver (remixt_amd/lockstep.py lbfgsb_gen), every
+        round of (objective, gradient) evaluations one batched device call.  Returns False (state
+        restored) when the batched path hit a device-side error, so that the caller can run the
+        per-restart path, whose error handling is per restart."""
+        from . import lockstep
+        b = self.batch
+        R = len(self.models)
+        active = [r for r, m in enumerate(self.models) if m.do_h_update]
+        if not active:
+            return True
+        h_before = [np.array(m.model.h, dtype=float) for m in self.models]
+        rng_state = [m.rng.get_state() for m in self.models]
+        try:
+            ell_before = b.expected_log_likelihood_full(0, R)
+            samples = self._samples()
+            for r in active:
+                b._use_sample(r, samples[r])
+            bounds = [(1e-8, 10.)] * b.num_clones
+
+            def evaluate(ids, xs):
+                f, g = b.expected_log_likelihood_h_batch([active[i] for i in ids], np.stack(xs))
+                return [(-float(f[k]), -g[k]) for k in range(len(ids))]
+            results = lockstep.run_lockstep([lockstep.lbfgsb_gen(h_before[r], bounds) for r in active], evaluate)
+        except ValueError:
+            for r, m in enumerate(self.models):
+                m.model.h = h_before[r]
+                m.rng.set_state(rng_state[r])
+            return False
+        failed = set()
+        for r, res in zip(active, results):
+            m = self.models[r]
+            try:
+                if not res.success:
+                    def nll(h, m=m, r=r):
+                        m.model.h = h
+                        return -m.model.calculate_expected_log_likelihood(samples[r])
+
+                    def nll_grad(h, m=m, r=r):
+                        m.model.h = h
+                        out = np.zeros((b.num_clones,))
+                        m.model.calculate_expected_log_likelihood_partial_h(samples[r], out)
+                        return -out
+                    m._validate_h_result(res, nll, nll_grad)
+                m.model.h = res.x
+            except ValueError as err:
+                if self.strict:
+                    raise
+                m.model.h = h_before[r]
+                failed.add(r)
+                self.error_messages[r] = str(err).splitlines()[0] + ' (h kept)'
+        ell_after = b.expected_log_likelihood_full(0, R)
+        for r in active:
+            if r in failed:
+                continue
+            m = self.models[r]
+            if ell_after[r] < ell_before[r]:
+                m._log('h rejected, elbo before: {}, after: {}'.format(ell_before[r], ell_after[r]))
+                m.model.h = h_before[r]
+        return True
 
     def _update_params_lockstep(self):
         """BreakpointModel.em_update_params (cn_model.py:468-473, 533-569) for all restarts at once:
@@ -137,31 +230,43 @@ class RestartSet(object):
             weights = [m.get_param_sample_weight(name) for m in self.models]
             value_before = [b.get_param(r, name) for r in ids_all]
             ell_before = b.expected_log_likelihood_full(0, R)
-            for r, m in enumerate(self.models):
-                b._use_sample(r, m._create_sample(weights[r]))
+            for r, smp in enumerate(self._samples(weights)):
+                b._use_sample(r, smp)
             grid = np.mgrid[lo:hi:complex(20)]
-            J = np.empty((R, len(grid)))
-            for gi, gv in enumerate(grid):
-                J[:, gi] = -b.expected_log_likelihood_batch(ids_all, name, np.full(R, gv))
-            xmin = grid[np.argmin(J, axis=1)]
-
-            def evaluate(ids, xs):
-                vals = [float(x[0]) for x in xs]
-                out = [np.inf] * len(ids)          # outside the bounds: inf, model untouched (cn_model.py:542-543)
-                sel = [k for k, v in enumerate(vals) if not (v < lo or v > hi)]
-                if sel:
-                    res = b.expected_log_likelihood_batch([ids[k] for k in sel], name, [vals[k] for k in sel])
-                    for k, e in zip(sel, res):
-                        out[k] = -float(e)
-                return out
-            results = lockstep.run_lockstep([lockstep.fmin_1d(xmin[r]) for r in ids_all], evaluate)
+            if self.native_search and hasattr(b, 'param_search'):
+                xopt = b.param_search(ids_all, name, lo, hi, grid)       # the same search, host loop in C++
+            else:
+                xopt = self._param_search_python(name, lo, hi, grid)
             ell_after = b.expected_log_likelihood_full(0, R)
             for r, m in enumerate(self.models):
                 if ell_after[r] < ell_before[r]:
                     m._log('{} rejected, elbo before: {}, after: {}'.format(name, ell_before[r], ell_after[r]))
                     b.set_param(r, name, value_before[r])
                 else:
-                    b.set_param(r, name, float(results[r][0][0]))
+                    b.set_param(r, name, float(xopt[r]))
+
+    def _param_search_python(self, name, lo, hi, grid):
+        """The search of rmx_param_search driven from Python generators (remixt_amd/lockstep.py)."""
+        from . import lockstep
+        b = self.batch
+        R = len(self.models)
+        ids_all = list(range(R))
+        J = np.empty((R, len(grid)))
+        for gi, gv in enumerate(grid):
+            J[:, gi] = -b.expected_log_likelihood_batch(ids_all, name, np.full(R, gv))
+        xmin = grid[np.argmin(J, axis=1)]
+
+        def evaluate(ids, xs):
+            vals = [float(x[0]) for x in xs]
+            out = [np.inf] * len(ids)          # outside the bounds: inf, model untouched (cn_model.py:542-543)
+            sel = [k for k, v in enumerate(vals) if not (v < lo or v > hi)]
+            if sel:
+                res = b.expected_log_likelihood_batch([ids[k] for k in sel], name, [vals[k] for k in sel])
+                for k, e in zip(sel, res):
+                    out[k] = -float(e)
+            return out
+        results = lockstep.run_lockstep([lockstep.fmin_1d(xmin[r]) for r in ids_all], evaluate)
+        return np.array([float(res[0][0]) for res in results])
 
     def fit(self, num_em_iter=5, num_update_iter=5):
         elbo0 = self.calculate_elbo()
@@ -179,6 +284,89 @@ class RestartSet(object):
             res = collect_fit_results(m, self.experiment, p)
             res['stats']['error_message'] = self.error_messages.get(r, '')
             out.append(res)
+        return out
+
+
+class RestartGroups(object):
+    """The restarts of one GPU split into `groups` RestartSets, each with its own device batch
+    (own HIP stream) and its own host thread.
+
+    One EM iteration alternates a device-bound phase (variational sweeps) with a host-latency-bound
+    phase (scipy / Nelder-Mead M-steps whose objective evaluations are ~100 us device round trips).
+    With two or more groups the phases of different groups overlap: while one group's host thread
+    drives its M-step, the other group's sweeps keep the CUs busy, and kernels of different groups
+    run concurrently on the device (a 184-workgroup forward-backward launch leaves CUs idle).
+    Restarts are independent (reference remixt/workflow.py:329-340) and every restart owns its RNG
+    stream, so the results do not depend on the grouping."""
+
+    def __init__(self, experiment, init_params, max_copy_number, groups=2, seeds=None, **kwargs):
+        init_params = list(init_params)
+        R = len(init_params)
+        groups = max(1, min(int(groups), R))
+        if seeds is None and groups > 1:
+            raise ValueError('grouped restarts need one RNG seed per restart')
+        bounds = [(R * g) // groups for g in range(groups + 1)]
+        self.slices = [slice(bounds[g], bounds[g + 1]) for g in range(groups)]
+        self.sets = [RestartSet(experiment, init_params[sl], max_copy_number,
+                                seeds=(list(seeds)[sl] if seeds is not None else None), **kwargs) for sl in self.slices]
+        self.models = [m for rs in self.sets for m in rs.models]
+        self.init_params = init_params
+        self.experiment = experiment
+        self._pool = None
+
+    @property
+    def num_restarts(self):
+        return len(self.models)
+
+    @property
+    def batches(self):
+        return [rs.batch for rs in self.sets]
+
+    def _map(self, fn):
+        if len(self.sets) == 1:
+            return [fn(self.sets[0])]
+        if self._pool is None:
+            from concurrent.futures import ThreadPoolExecutor
+            self._pool = ThreadPoolExecutor(max_workers=len(self.sets))
+        return list(self._pool.map(fn, self.sets))
+
+    def calculate_elbo(self):
+        return np.concatenate(self._map(lambda rs: np.asarray(rs.calculate_elbo())))
+
+    def variational_update(self, iters=1):
+        self._map(lambda rs: rs.variational_update(iters))
+
+    def em_iteration(self, i=0, num_update_iter=5):
+        return np.concatenate(self._map(lambda rs: np.asarray(rs.em_iteration(i, num_update_iter))))
+
+    def fit(self, num_em_iter=5, num_update_iter=5):
+        return np.concatenate(self._map(lambda rs: np.asarray(rs.fit(num_em_iter, num_update_iter))))
+
+    def run(self, num_em_iter, start=0, num_update_iter=5):
+        """`num_em_iter` EM iterations of every restart.  The groups free-run (no join between
+        iterations), which is what lets one group's sweeps overlap another group's M-step."""
+        def go(rs):
+            elbo = None
+            for i in range(num_em_iter):
+                elbo = rs.em_iteration(start + i, num_update_iter)
+            return np.asarray(elbo)
+        return np.concatenate(self._map(go))
+
+    def synchronize(self):
+        for rs in self.sets:
+            if rs.batch is not None:
+                rs.batch.synchronize()
+
+    def results(self):
+        return [r for rs in self.sets for r in rs.results()]
+
+    def profile(self):
+        """{kernel: (ms, launches)} summed over the groups' batches."""
+        out = {}
+        for rs in self.sets:
+            for k, (ms, n) in rs.batch.profile().items():
+                a = out.get(k, (0., 0))
+                out[k] = (a[0] + ms, a[1] + n)
         return out
 
 
@@ -261,7 +449,7 @@ def _unpack(f, i8, N, M, K, nparams, brk_ids, param_names, init_params):
 
 
 def fit_restarts_distributed(experiment, init_params, max_copy_number, num_clones=3, num_em_iter=5, num_update_iter=5,
-                             device=None, kernel_module=None, seeds=None, quiet=True, **model_kwargs):
+                             device=None, kernel_module=None, seeds=None, quiet=True, groups=2, **model_kwargs):
     """Fit all restarts across the ranks of the default torch.distributed group.
 
     Every rank holds the (small, read-only) experiment; rank g fits restarts
@@ -282,9 +470,10 @@ def fit_restarts_distributed(experiment, init_params, max_copy_number, num_clone
     local = []
     param_names = None
     if mine:
-        rs = RestartSet(experiment, [init_params[i] for i in mine], max_copy_number, num_clones=num_clones, device=device,
-                        quiet=quiet, kernel_module=kernel_module, seeds=[seeds[i] for i in mine] if seeds is not None else None,
-                        **model_kwargs)
+        my_seeds = [seeds[i] for i in mine] if seeds is not None else None
+        rs = RestartGroups(experiment, [init_params[i] for i in mine], max_copy_number, groups=(groups if my_seeds is not None else 1),
+                           num_clones=num_clones, device=device, quiet=quiet, kernel_module=kernel_module, seeds=my_seeds,
+                           **model_kwargs)
         rs.fit(num_em_iter, num_update_iter)
         local = rs.results()
         param_names = list(rs.models[0].likelihood_params)

@@ -194,9 +194,32 @@ def test_lockstep_mstep_equals_per_restart_mstep(hip):
     e = synthetic.make_experiment(600, num_clones=3, max_copy_number=3, num_chains=5, seed=6)
     ps = synthetic.make_init_params(e, 4, 3)
     out = []
-    for lock in (True, False):
-        rs = RestartSet(e, ps, max_copy_number=3, num_clones=3, quiet=True, seeds=[5, 6, 7, 8], lockstep=lock, mstep_threads=1)
+    for lock, native in ((True, True), (True, False), (False, False)):
+        rs = RestartSet(e, ps, max_copy_number=3, num_clones=3, quiet=True, seeds=[5, 6, 7, 8], lockstep=lock,
+                        native_search=native, mstep_threads=1)
         rs.fit(num_em_iter=2, num_update_iter=2)
         out.append([(m.prev_elbo, np.array(m.h), m.get_likelihood_param_values()) for m in rs.models])
-    for (e1, h1, p1), (e2, h2, p2) in zip(*out):
-        assert e1 == e2 and np.array_equal(h1, h2) and p1 == p2
+    for other in out[1:]:
+        for (e1, h1, p1), (e2, h2, p2) in zip(out[0], other):
+            assert e1 == e2 and np.array_equal(h1, h2) and p1 == p2
+
+
+def test_restart_groups_do_not_change_results(hip):
+    """Restarts split into groups (own batch, stream and host thread each) give every restart the
+    same fit as one batch of all restarts."""
+    from remixt_amd import synthetic
+    from remixt_amd.restarts import RestartGroups
+    e = synthetic.make_experiment(500, num_clones=3, max_copy_number=3, num_chains=4, seed=9)
+    ps = synthetic.make_init_params(e, 4, 3)
+    out = []
+    for groups in (1, 2):
+        rs = RestartGroups(e, ps, 3, groups=groups, num_clones=3, quiet=True, seeds=[1, 2, 3, 4])
+        el = rs.calculate_elbo()
+        for m, v in zip(rs.models, el):
+            m.prev_elbo = float(v)
+        elbo = rs.run(2, 0, 2)
+        out.append((elbo, [np.array(m.h) for m in rs.models], [m.get_likelihood_param_values() for m in rs.models]))
+    assert np.array_equal(out[0][0], out[1][0])
+    for h1, h2 in zip(out[0][1], out[1][1]):
+        assert np.array_equal(h1, h2)
+    assert out[0][2] == out[1][2]
