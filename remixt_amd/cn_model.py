@@ -76,6 +76,36 @@ def create_brk_states(num_clones, cn_max, cn_diff_max):
     return np.concatenate([np.zeros((len(grids), 1), dtype=grids.dtype), grids], axis=1).astype(np.int64)
 
 
+def _sample_without_replacement(rng, n, size, p=None):
+    """`size` distinct indices from range(n), successively with probability proportional to p
+    (uniform if None): the distribution of numpy's choice(n, size, replace=False, p=p).  numpy
+    re-normalises and re-accumulates p after every batch of draws and permutes all n items in the
+    uniform case; drawing WITH replacement from the one cumulative distribution and keeping first
+    occurrences is the same process (a repeat is exactly a draw the renormalised distribution would
+    not have produced) and needs one cumsum / no permutation."""
+    if size > n:
+        raise ValueError("Cannot take a larger sample than population when 'replace=False'")
+    cdf = None
+    if p is not None:
+        if np.count_nonzero(p > 0) < size:
+            raise ValueError("Fewer non-zero entries in p than size")
+        cdf = np.cumsum(p)
+        cdf /= cdf[-1]
+    found = np.empty(0, dtype=np.int64)
+    while found.size < size:
+        k = size - found.size
+        k += k // 2 + 8
+        if cdf is None:
+            new = rng.randint(0, n, size=k).astype(np.int64)
+        else:
+            new = np.minimum(cdf.searchsorted(rng.rand(k), side='right'), n - 1).astype(np.int64)
+        cand = np.concatenate([found, new])
+        _, first = np.unique(cand, return_index=True)
+        first.sort()
+        found = cand.take(first)
+    return found[:size]
+
+
 class BreakpointModel(object):
 
     def __init__(self, x, l, adjacencies, breakpoints, **kwargs):
@@ -395,8 +425,11 @@ class BreakpointModel(object):
     def _create_sample(self, weights=None):
         """Random subset of segments for the stochastic M-steps (cn_model.py:475-480; global numpy RNG)."""
         sample_size = int(min(200, self.model.num_segments / 10))
-        chooser = self.rng if self.rng is not None else np.random
-        sample_idxs = chooser.choice(self.model.num_segments, size=sample_size, replace=False, p=weights)
+        if self.rng is not None:
+            # private stream (RestartSet): the same distribution, drawn with one cumulative sum
+            sample_idxs = _sample_without_replacement(self.rng, self.model.num_segments, sample_size, weights)
+        else:
+            sample_idxs = np.random.choice(self.model.num_segments, size=sample_size, replace=False, p=weights)
         sample = np.zeros((self.model.num_segments,), dtype=int)
         sample[sample_idxs] = 1
         return sample
