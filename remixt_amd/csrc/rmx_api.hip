@@ -84,6 +84,9 @@ struct rmx_batch {
     // all device allocations (freed on destroy)
     std::vector<void *> allocs;
     // profiling
+    int pe2p = 0;     // padded row length of pe2_lt (0: no product table)
+    int max_adist = 0; // largest allele distance in af / ab
+    int be_cap = 4;   // LDS ints for a chain's breakend adjacency list (largest chain + pad)
     int prof = 0;     // 0 off, 1 all kernels, 2 variational-sweep kernels only
     std::vector<ProfRec> prof_pending;
     std::vector<hipEvent_t> ev_pool;
@@ -220,6 +223,7 @@ static int build_transitions(rmx_batch *b) {
                 Wf[tc * SS + (size_t)i * S + j] = std::exp(T);
                 Wb[tc * SS + (size_t)j * S + i] = std::exp(T);
                 af[tc * SS + (size_t)i * S + j] = (int8_t)amin;
+                b->max_adist = std::max(b->max_adist, (int)amin);
                 ab[tc * SS + (size_t)j * S + i] = (int8_t)amin;
                 tsum += T;
             }
@@ -261,9 +265,16 @@ static fb_kernel_t fb_kernel_for(int rpt) {
     }
 }
 typedef void (*fbv_kernel_t)(FbvArgs);
-static fbv_kernel_t fbv_kernel_for(int rpt, int nv) {
+static fbv_kernel_t fbv_kernel_for(int rpt, int nv, int blk) {
+    // two or more vectors per workgroup: the lock-step kernel, or with RMX_FB_PIPELINED=1 the
+    // phase-pipelined one (same bits; measured slower so far)
+    // (the pipelined kernel's split block-boundary protocol needs blocks of at least two rows)
+    (void)blk;
+    const bool lockstep = getenv("RMX_FB_PIPELINED") == nullptr;
 #define FBV_CASE(R_) \
-    if (rpt == R_) { if (nv == 1) return k_fbv<R_, 1, 768>; if (nv == 2) return k_fbv<R_, 2, 768>; return k_fbv<R_, 4, 768>; }
+    if (rpt == R_) { if (nv == 1) return k_fbv<R_, 1, 768>; \
+                     if (nv == 2) return lockstep ? k_fbv<R_, 2, 768> : k_fbs<R_, 1, 768>; \
+                     return lockstep ? k_fbv<R_, 4, 768> : k_fbs<R_, 2, 768>; }
     FBV_CASE(2) FBV_CASE(6) FBV_CASE(14) FBV_CASE(22)
 #undef FBV_CASE
     return nullptr;
@@ -431,7 +442,7 @@ static int launch_pairwise_breakends(rmx_batch *b, int r0, int r1, int mode) {
 static int launch_brk_lut(rmx_batch *b, int r0, int r1, double *dst, double *edst) {
     if (b->d.NBE == 0) return RMX_OK;
     ProfScope ps(b, KID_BRK_LUT);
-    hipLaunchKernelGGL(k_brk_lut, dim3(b->d.NBE, r1 - r0), dim3(64), 0, b->stream, b->d, r0, dst, edst);
+    hipLaunchKernelGGL(k_brk_lut, dim3(b->d.NBE, r1 - r0), dim3(64), 0, b->stream, b->d, r0, dst, edst, edst ? b->d.pe2_lt : (double *)nullptr, b->pe2p);
     HIPCHK(hipGetLastError());
     return RMX_OK;
 }
@@ -562,6 +573,14 @@ int rmx_batch_create(const rmx_problem *pr, int32_t R, const double *h_init, con
         chain_tc[c] = tc0;
         (tc0 >= 0 ? list_fast : list_gen).push_back(c);
     }
+    // be_n ascends with the slot, so the breakend adjacencies of a chain are a slot interval
+    std::vector<int32_t> chain_be(2 * (size_t)d.NC);
+    for (int c = 0; c < d.NC; c++) {
+        chain_be[2 * c] = (int32_t)(std::lower_bound(b->be_n.begin(), b->be_n.end(), cstart[c]) - b->be_n.begin());
+        chain_be[2 * c + 1] = (int32_t)(std::lower_bound(b->be_n.begin(), b->be_n.end(), cend[c]) - b->be_n.begin());
+    }
+    b->be_cap = 4;
+    for (int c = 0; c < d.NC; c++) b->be_cap = std::max(b->be_cap, (int)(chain_be[2 * c + 1] - chain_be[2 * c]) + 4);
     for (int s_ = 0; s_ < d.NBE; s_++) { be_cls[2 * s_] = b->seg_class[b->be_n[s_]]; be_cls[2 * s_ + 1] = b->seg_class[b->be_n[s_] + 1]; }
     b->n_fast = (int)list_fast.size(); b->n_generic = (int)list_gen.size();
     if (d.TC > 4096) { delete b; return fail(RMX_EUNSUPPORTED, "too many transition classes"); }
@@ -583,7 +602,7 @@ int rmx_batch_create(const rmx_problem *pr, int32_t R, const double *h_init, con
     UP(brk_slot, b->brk_slot) UP(brk_idx, b->brk_idx) UP(brk_orient, b->brk_orient) UP(be_n, b->be_n) UP(chain_start, cstart)
     UP(chain_end, cend) UP(chain_end_flag, cendflag) UP(cn, cn8) UP(tot, tot8) UP(sflags, sflags) UP(brk_states, brkst)
     UP(bk_ptr, bk_ptr) UP(bk_slots, bk_slots) UP(chain_tc, chain_tc) UP(chain_cls, chain_cls) UP(chain_list_fast, list_fast) UP(chain_list_generic, list_gen)
-    UP(chain_list_all, list_all) UP(be_cls, be_cls)
+    UP(chain_list_all, list_all) UP(be_cls, be_cls) UP(chain_be, chain_be)
 #undef UP
     const size_t SS = (size_t)S * S;
 #define DA(field, type, count) { type *p_ = nullptr; if ((rc = dalloc(b, &p_, (size_t)(count)))) { rmx_batch_destroy(b); return rc; } d.field = p_; }
@@ -594,7 +613,14 @@ int rmx_batch_create(const rmx_problem *pr, int32_t R, const double *h_init, con
     DA(f, double, RNS) DA(fe, double, RNS) DA(fa, double, RNS) DA(fb, double, RNS) DA(post, double, RNS) DA(fmax, double, RN) DA(mrow, double, RN)
     DA(A, double, RN * 2) DA(Bv, double, RN * 4) DA(rowPF, double, RN) DA(rowPP, double, RN) DA(rowZ, double, RN)
     const size_t BEW = (size_t)R * d.NBE * M * d.D;
-    DA(pd_lt, double, BEW) DA(pe_lt, double, (size_t)R * d.NBE * ((M * d.D + 1) & ~1) + 2) DA(pd_cached, double, BEW) DA(hist, double, BEW) DA(be_jt, double, (size_t)R * d.NBE) DA(be_ja, double, (size_t)R * d.NBE)
+    DA(pd_lt, double, BEW) DA(pe_lt, double, (size_t)R * d.NBE * ((M * d.D + 1) & ~1) + 2)
+    d.pe2_lt = nullptr; b->pe2p = 0;
+    if (M >= 2 && M <= 3 && d.D <= 31 && d.NBE > 0) {
+        int n2 = M == 2 ? d.D : d.D * d.D;
+        b->pe2p = (n2 + 1) & ~1;
+        DA(pe2_lt, double, (size_t)R * d.NBE * b->pe2p + 2)
+    }
+    DA(pd_cached, double, BEW) DA(hist, double, BEW) DA(be_jt, double, (size_t)R * d.NBE) DA(be_ja, double, (size_t)R * d.NBE)
     DA(err, uint32_t, R)
 #undef DA
     d.lc = nullptr;
@@ -716,6 +742,7 @@ int rmx_info(rmx_batch *b, int32_t what, int64_t *out) {
     case 4: *out = b->d.SP; break; case 5: *out = b->fb_rpt; break; case 6: *out = b->fbL.P; break; case 7: *out = b->fbL.NT; break;
     case 8: *out = b->fbL.BLK; break; case 9: *out = (int64_t)b->fb_lds; break; case 10: *out = b->n_fast; break; case 11: *out = b->n_generic; break;
     case 20: case 21: case 22: case 23: case 24: case 25: case 26: case 27: case 28: case 29: case 30: case 31: case 32: case 33: case 34: case 35: case 36: case 37: case 38: case 39:
+    case 40: case 41: case 42: case 43: case 44: case 45: case 46: case 47: case 48: case 49: case 50: case 51:
         { if (!b->d_dbg) { *out = 0; break; } unsigned long long v[32]; HIPCHK(hipStreamSynchronize(b->stream)); HIPCHK(hipMemcpy(v, b->d_dbg, 256, hipMemcpyDeviceToHost)); *out = (int64_t)v[what - 20]; break; }
     default: return fail(RMX_EARG, "bad info id");
     }
@@ -907,29 +934,38 @@ static int do_update_p_cn(rmx_batch *b, int r0, int r1) {
             FbvArgs v;
             v.S = d.S; v.SP = d.SP; v.M = d.M; v.D = d.D; v.C = d.C; v.N = d.N; v.NBE = d.NBE; v.cn_max = d.cn_max;
             v.r0 = r0; v.r1 = r1; v.pen = d.pen; v.pad_ = 0;
-            v.G2 = (d.S + 1) / 2; v.SPW = ((d.S + 63) / 64) * 64;
+            v.G2 = (((d.S + 1) / 2 + 15) / 16) * 16;   // column pairs per row slice, whole DPP rows
+            v.SPW = ((d.S + 63) / 64) * 64;
             v.chain_start = d.chain_start; v.chain_end = d.chain_end; v.tclass = d.tclass; v.brk_slot = d.brk_slot;
-            v.chain_list = d.chain_list_fast; v.chain_tc = d.chain_tc; v.chain_cls = d.chain_cls;
+            v.chain_list = d.chain_list_fast; v.chain_tc = d.chain_tc; v.chain_cls = d.chain_cls; v.be_n = d.be_n; v.chain_be = d.chain_be; v.pe2_lt = d.pe2_lt; v.PE2P = b->pe2p; v.SPC = d.SP; v.pad2_ = 0; v.code_lds = 0;
             v.fe = d.fe; v.Wf = d.Wf; v.Wb = d.Wb; v.pe_lt = d.pe_lt; v.af = d.af; v.ab = d.ab; v.tot = d.tot;
             v.fa = d.fa; v.fb = d.fb; v.mrow = d.mrow; v.err = d.err; v.dbg = b->d_dbg;
             const int rpt = b->fbv_rpt;
             v.SPAD = ((std::max(d.S, FBV_P * rpt) + 7) / 8) * 8;
             const int mdp = (d.M * d.D + 1) & ~1;
-            int nt = std::max(((FBV_P * v.G2 + 63) / 64) * 64 + 64, NV * v.SPW);   // + one reducer wave
-            size_t lds = 0; int blk = 8;
+            int nt = std::max(FBV_P * v.G2, NV * v.SPW);
+            size_t lds = 0; const int blk = 0;      // no emission ring: publishing lanes load their emission value directly
             for (;;) {
-                size_t fixed = ((size_t)NV * 2 * v.SPAD + (size_t)NV * FBV_P * d.SP + NV * 4 + (size_t)NV * mdp + 128) * 8 + (size_t)FB_NBUF * 2 * 64 * 4 +
-                               (((size_t)d.C * d.S * d.M + 15) & ~(size_t)15) + 64;
-                v.amat_lds = (fixed + (size_t)d.S * d.S + (size_t)NV * FB_NBUF * 2 * d.SP * 8 <= kLdsBudget) ? 1 : 0;
-                if (v.amat_lds) fixed += (size_t)d.S * d.S;
-                blk = 8;
-                while (blk > 1 && fixed + (size_t)NV * FB_NBUF * blk * d.SP * 8 > kLdsBudget) blk--;
-                lds = fixed + (size_t)NV * FB_NBUF * blk * d.SP * 8;
+                // breakend fast path: product tables + pair codes in LDS (the allele-distance matrix is then
+                // not needed there)
+                const size_t code_bytes = (size_t)FBV_P * rpt * d.SP * 2;
+                const bool want_code = d.pe2_lt != nullptr && b->max_adist < 64 && (d.SP & 1) == 0 && !getenv("RMX_FB_NO_CODE");
+                size_t base_ = ((size_t)NV * 2 * v.SPAD + (size_t)NV * FBV_P * d.SP + NV * 4 + 128) * 8 +
+                               (((size_t)d.C * d.S * d.M + 15) & ~(size_t)15) + 64 + (size_t)b->be_cap * 4;
+                size_t fixed;
+                v.code_lds = (want_code && base_ + (size_t)NV * b->pe2p * 8 + code_bytes <= kLdsBudget) ? 1 : 0;
+                if (v.code_lds) { fixed = base_ + (size_t)NV * b->pe2p * 8 + code_bytes; v.amat_lds = 0; }
+                else {
+                    fixed = base_ + (size_t)NV * mdp * 8;
+                    v.amat_lds = (fixed + (size_t)d.S * d.S + 16 <= kLdsBudget) ? 1 : 0;
+                    if (v.amat_lds) fixed += (((size_t)d.S * d.S + 15) & ~(size_t)15);
+                }
+                lds = fixed;
                 if (lds <= kLdsBudget || NV == 1) break;
-                NV /= 2; nt = std::max(((FBV_P * v.G2 + 63) / 64) * 64 + 64, NV * v.SPW);
+                NV /= 2; nt = std::max(FBV_P * v.G2, NV * v.SPW);
             }
             v.BLK = blk;
-            fbv_kernel_t kf = fbv_kernel_for(rpt, NV);
+            fbv_kernel_t kf = fbv_kernel_for(rpt, NV, blk);
             if (kf && nt <= 768 && lds <= kLdsBudget) {
                 HIPCHK(hipFuncSetAttribute((const void *)kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
                 hipLaunchKernelGGL(kf, dim3(b->n_fast, (nr + NV - 1) / NV, 2), dim3(nt), lds, b->stream, v);

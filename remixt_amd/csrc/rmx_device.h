@@ -50,7 +50,8 @@ struct Dev {
     const int32_t *tclass;               // [N] transition class of (n,n+1); -1: telomere / last
     const int32_t *brk_slot;             // [N] breakend slot of (n,n+1) or -1
     const int32_t *brk_idx, *brk_orient; // [N]
-    const int32_t *be_n;                 // [NBE] slot -> n
+    const int32_t *be_n;                 // [NBE] slot -> n (ascending)
+    const int32_t *chain_be;             // [NC][2] slots lo, hi: the breakend adjacencies inside chain c are slots [lo, hi)
     const int32_t *be_cls;               // [NBE][2] state-table class of segments n, n+1
     const int32_t *chain_tc;             // [NC] transition class of a chain whose segments share one state-table class, or -1
     const int32_t *chain_cls;            // [NC] that state-table class
@@ -79,6 +80,7 @@ struct Dev {
     double *rowPF, *rowPP, *rowZ;        // [R][N]
     double *pd_lt, *pd_cached;           // [R][NBE][M][D]
     double *pe_lt;                       // [R][NBE][MDP] exp(-pen * pd_lt), rows padded to 16 bytes
+    double *pe2_lt;                      // [R][NBE][PE2P] product of pe_lt over the clones by tumour-clone differences (M <= 3), or null
     double *hist;                        // [R][NBE][M][D]
     double *be_jt, *be_ja;               // [R][NBE]
     uint32_t *err;                       // [R]
@@ -320,6 +322,31 @@ __device__ __forceinline__ double wave_max_nonneg(double v) {
     for (int row = 0; row < 4; row++)
         r = fmax(r, __hiloint2double(__builtin_amdgcn_readlane(hi, row * 16), __builtin_amdgcn_readlane(lo, row * 16)));
     return r;
+}
+// Row scaling of the forward / backward vectors.  Any positive per-row factor is legal (posteriors are
+// self-normalised and hmm_log_norm_const adds log(factor) per row, see rowZ); the factor used is the
+// power of two 2^e <= max < 2^(e+1): multiplying by 2^-e is exact, needs no reciprocal, and the
+// reduction only has to find the largest HIGH DWORD of the (non-negative) values -- a 32-bit integer
+// maximum, single-instruction DPP steps instead of a 64-bit floating-point butterfly.
+__device__ __forceinline__ void pow2_scale(unsigned hi, double &scale, double &inv) {
+    const unsigned ef = (hi >> 20) & 0x7ffu;
+    if (ef == 0x7ffu) { scale = INFINITY; inv = 0.; }        // inf / nan in the vector (a nan's sign bit only raises the key)
+    else if (ef == 0u) { scale = 0.; inv = 0.; }             // zero or denormal maximum: the row vanished
+    else { scale = __hiloint2double((int)(ef << 20), 0); inv = __hiloint2double((int)((2046u - ef) << 20), 0); }
+}
+// maximum over the 64 lanes of a wave of unsigned keys (wave-uniform result)
+__device__ __forceinline__ unsigned wave_max_u32(unsigned v) {
+    v = max(v, (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x121, 0xf, 0xf, false));   // row_ror:1
+    v = max(v, (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x122, 0xf, 0xf, false));   // row_ror:2
+    v = max(v, (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x124, 0xf, 0xf, false));   // row_ror:4
+    v = max(v, (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x128, 0xf, 0xf, false));   // row_ror:8
+    const unsigned a = __builtin_amdgcn_readlane((int)v, 0), b = __builtin_amdgcn_readlane((int)v, 16);
+    const unsigned c = __builtin_amdgcn_readlane((int)v, 32), d = __builtin_amdgcn_readlane((int)v, 48);
+    return max(max(a, b), max(c, d));
+}
+__device__ __forceinline__ void lds_max_u32(void *lds_ptr, unsigned v) {
+    const unsigned addr = (unsigned)(size_t)(__attribute__((address_space(3))) void *)lds_ptr;
+    asm volatile("ds_max_u32 %0, %1" ::"v"(addr), "v"(v) : "memory");
 }
 // LDS 64-bit unsigned atomic max, one instruction (atomicMax() makes hipcc emit a per-lane scalar loop)
 __device__ __forceinline__ void lds_max_u64(void *lds_ptr, unsigned long long v) {

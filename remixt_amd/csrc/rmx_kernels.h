@@ -186,6 +186,14 @@ __device__ __forceinline__ void glds4(const void *gsrc, unsigned lds_dst_uniform
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(gsrc), "s"(lds_dst_uniform) : "memory");
 }
+// 8-byte global load whose completion the COMPILER does not track: no s_waitcnt is inserted for it
+// anywhere (a tracked load pending over the step loop makes hipcc drain vmcnt(0) -- i.e. also the result
+// stores' HBM round trip -- at the loop head).  The value is valid only after gwait8() on the same
+// variable; nothing may read (or copy) it in between.
+__device__ __forceinline__ void gload8(double &dst, const double *src) {
+    asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(dst) : "v"(src) : "memory");
+}
+__device__ __forceinline__ void gwait8(double &v) { asm volatile("s_waitcnt vmcnt(0)" : "+v"(v) :: "memory"); }
 __device__ __forceinline__ void gstore8(double *dst, double v) {
     asm volatile("global_store_dwordx2 %0, %1, off\n\ts_nop 1" ::"v"(dst), "v"(v) : "memory");
 }
@@ -331,9 +339,9 @@ __global__ __launch_bounds__(NTMAX) void k_fb(FbArgs a) {
         const int rn = rc + 1 == 3 ? 0 : rc + 1, rz = rn + 1 == 3 ? 0 : rn + 1;
         double inv = 0., e = 0.;
         if ((t >> 6) < npw) {
-            const double m = __longlong_as_double((long long)red64[rc]);
+            double m;
+            pow2_scale((unsigned)(red64[rc] >> 32), m, inv);
             if (post) e = ebuf[((size_t)slot * BLK + kidx) * SP + o];
-            inv = fast_rcp(m);
             if (t == 0) { if (dir == 0) gstore8(mptr, m); red64[rz] = 0ull; }
         }
         FB_STAMP(1)
@@ -445,7 +453,8 @@ __global__ __launch_bounds__(NTMAX) void k_fb(FbArgs a) {
     if (a.dbg && t == 0 && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0) { a.dbg[2] = clock64(); a.dbg[3] = wall_clock64(); }
     if (t == 0) {
         // last row of the chain: its own maximum is not consumed by a later step
-        const double m = __longlong_as_double((long long)red64[rc]);
+        double m, inv_;
+        pow2_scale((unsigned)(red64[rc] >> 32), m, inv_);
         if (dir == 0) gstore8(mptr, m);
         if (!(m > 0.) || m == INFINITY) atomicOr(&a.err[r], RMX_ERR_NAN_AB);
     }
@@ -457,18 +466,66 @@ __global__ __launch_bounds__(NTMAX) void k_fb(FbArgs a) {
 // k_fbv: the production forward-backward kernel.  Same recursion as k_fb, but ONE workgroup advances
 // NV restarts of the same (chain, direction) in lock step.  The plain-adjacency weights do not depend
 // on the restart, so they are held in registers once (2 output columns x RPT rows per thread, P = 8
-// row slices) and every LDS vector value feeds two FMAs; the latency chain of a step (two barriers,
-// the partial-sum hand-off, the maximum) is paid once for NV vectors instead of once per vector.
-//   thread t (phase 1):  g = t % G2 (column pair 2g, 2g+1), p = t / G2 (row slice), t < 8*G2
+// row slices); the latency chain of a step (two barriers, the partial-sum hand-off, the maximum) is
+// paid once for NV vectors instead of once per vector.
+// The vector operand of the S x S product never comes from LDS broadcasts: the 16 lanes of a DPP row
+// share one row slice p, lane n of the row loads a[p*RPT + n] (and a[p*RPT + 16 + n]) ONCE per step
+// and vector, and every product term is `v_fmac_f64_dpp acc, a, w row_newbcast:n` -- the multiplier
+// is lane n's register, broadcast inside the row by the DPP network.  Per step and wave that is
+// 2*NV 8-byte LDS reads instead of RPT*NV/2 16-byte broadcast reads (11x less LDS traffic at S = 165),
+// which leaves phase 1 bound by the FP64 FMA rate.
+//   thread t (phase 1):  g = t % G2 (column pair 2g, 2g+1; G2 a multiple of 16), p = t / G2 (row slice), t < 8*G2
 //   thread t (phase 2):  v = t / SPW (vector), o = t % SPW (state), SPW = ceil(S/64)*64
 // Only chains whose segments share one state-table class come here (chain_tc >= 0).
 // =============================================================================
+// acc0[v] += a_v[row] * w0[row], acc1[v] += a_v[row] * w1[row] for row = RR..RPT-1 and every vector v, the
+// multiplier taken from lane (row % 16) of the DPP row (register av[v][row / 16]).  gfx90a+ VOP2 DPP
+// on 64-bit operands supports exactly this control (row_newbcast).  Rows ascend per accumulator (the
+// summation order of the LDS-broadcast formulation) and the 2*NV accumulators give the FMA pipe
+// independent chains.
+template <int RPT, int NV, int NA, int RR>
+__device__ __forceinline__ void fbv_row_fma(const double (&av)[NV][NA], const double (&w0)[RPT], const double (&w1)[RPT],
+                                            double (&acc0)[NV], double (&acc1)[NV]) {
+    if constexpr (RR < RPT) {
+#pragma unroll
+        for (int v = 0; v < NV; v++) {
+            asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc0[v]) : "v"(av[v][RR / 16]), "v"(w0[RR]), "n"(RR % 16));
+            asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc1[v]) : "v"(av[v][RR / 16]), "v"(w1[RR]), "n"(RR % 16));
+        }
+        fbv_row_fma<RPT, NV, NA, RR + 1>(av, w0, w1, acc0, acc1);
+    }
+}
+
+// breakend-step counterpart of fbv_row_fma: the weight of (row, column) is wa[a] * tab_v[idx] with
+// (idx | a << 10) the pair's 16-bit code (two adjacent columns = one 32-bit LDS read)
+template <int RPT, int NV, int NA, int RR>
+__device__ __forceinline__ void fbv_row_fma_be(const double (&av)[NV][NA], const unsigned short *crow, int SPC, const double *wa,
+                                               const double *tab, int tabw, double (&acc0)[NV], double (&acc1)[NV]) {
+    if constexpr (RR < RPT) {
+        const unsigned cc = *reinterpret_cast<const unsigned *>(crow + (size_t)RR * SPC);
+        const unsigned c0 = cc & 0xffffu, c1 = cc >> 16;
+        const double wa0 = wa[c0 >> 10], wa1 = wa[c1 >> 10];
+#pragma unroll
+        for (int v = 0; v < NV; v++) {
+            const double x0 = wa0 * tab[(size_t)v * tabw + (c0 & 1023u)], x1 = wa1 * tab[(size_t)v * tabw + (c1 & 1023u)];
+            asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc0[v]) : "v"(av[v][RR / 16]), "v"(x0), "n"(RR % 16));
+            asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc1[v]) : "v"(av[v][RR / 16]), "v"(x1), "n"(RR % 16));
+        }
+        if (RR % 2 == 1) __builtin_amdgcn_sched_barrier(0);      // bound the look-ahead of the LDS reads (register budget)
+        fbv_row_fma_be<RPT, NV, NA, RR + 1>(av, crow, SPC, wa, tab, tabw, acc0, acc1);
+    }
+}
+
 #define FBV_P 8
+#ifndef FBV_DEPTH
+#define FBV_DEPTH 4
+#endif
 struct FbvArgs {
     int S, SP, M, D, C, N, NBE, cn_max, BLK, SPAD, r0, r1, amat_lds, G2, SPW, pad_;
+    int code_lds, PE2P, SPC, pad2_;     // breakend fast path: code table in LDS, padded row length of pe2_lt, row stride of the code table
     double pen;
-    const int32_t *chain_start, *chain_end, *tclass, *brk_slot, *chain_list, *chain_tc, *chain_cls;
-    const double *fe, *Wf, *Wb, *pe_lt;
+    const int32_t *chain_start, *chain_end, *tclass, *brk_slot, *chain_list, *chain_tc, *chain_cls, *be_n, *chain_be;
+    const double *fe, *Wf, *Wb, *pe_lt, *pe2_lt;
     const int8_t *af, *ab, *tot;
     double *fa, *fb, *mrow;
     uint32_t *err;
@@ -490,32 +547,50 @@ __global__ __launch_bounds__(NTMAX) void k_fbv(FbvArgs a) {
     const int pv = t / SPW, po = t - pv * SPW;              // phase-2 role
     const bool post = pv < nv && po < S;
     const bool postwave = pv < nv;                          // wave-uniform (SPW is a multiple of 64)
-    // The maximum of the vector published in step k-1 is only needed in phase 2 of step k: one
-    // otherwise idle wave (the last one) computes it during phase 1 of step k, off everybody's path.
-    const bool reducer = (t >> 6) == (NT >> 6) - 1;
     const int lane = t & 63;
-    // the reducer's short dependent chain must not queue behind its SIMD neighbours' FMA streams
-    if (__builtin_amdgcn_readfirstlane((int)reducer)) __builtin_amdgcn_s_setprio(3);
-    const int SPAD = a.SPAD, BLK = a.BLK;
+    const int SPAD = a.SPAD;
     const int MDP = (M * D + 1) & ~1;
     // ---- LDS carve-up -----------------------------------------------------------------------
-    double *ebuf = (double *)smem_raw;                          // [NV][NBUF][BLK][SP]  emission rings (LDS-DMA)
-    double *vec = ebuf + (size_t)NV * FB_NBUF * BLK * SP;       // [NV][2][SPAD]
-    double *part = vec + (size_t)NV * 2 * SPAD;                 // [NV][P][SP]
-    double *red = part + (size_t)NV * FBV_P * SP;               // [NV][4]: [v][0] = 1/max of the current vector
-    double *pel = red + NV * 4;                                 // [NV][MDP]
-    double *wa = pel + (size_t)NV * MDP;                        // [128]
-    int *meta = (int *)(wa + 128);                              // [NBUF][2][64]
-    int8_t *totl = (int8_t *)(meta + FB_NBUF * 2 * 64);         // [C][S][M]
-    int8_t *atl = totl + ((a.C * S * M + 15) & ~15);            // [S][S]
+    double *vec = (double *)smem_raw;                           // [NV][2][SPAD]  the vectors, double-buffered by step parity
+    double *part = vec + (size_t)NV * 2 * SPAD;                 // [NV][P][SP]    partial sums of phase 1
+    double *red = part + (size_t)NV * FBV_P * SP;               // [NV][4]: [v][0] = 1/scale of the current vector, [v][1] = scale, [v][2 + buf] = largest high dword of vec[v][buf] (u32 in the slot's low half)
+    unsigned *red32 = (unsigned *)red;
+    // breakend steps: per-vector weight table(s) of the current breakend -- with code_lds the product over
+    // the clones, indexed by the code of a state pair (PE2P doubles per vector), else one table per clone
+    const int PELW = a.code_lds ? a.PE2P : MDP;
+    double *pel = red + NV * 4;                                 // [NV][PELW]
+    double *wa = pel + (size_t)NV * PELW;                       // [128]
+    int8_t *totl = (int8_t *)(wa + 128);                        // [C][S][M]
+    int8_t *atl = totl + ((a.C * S * M + 15) & ~15);            // [S][S] (amat_lds)
+    unsigned short *codel = (unsigned short *)(atl + (a.amat_lds ? ((S * S + 15) & ~15) : 0));   // [8*RPT][SPC] (code_lds)
+    int *bel = (int *)(codel + (a.code_lds ? (size_t)FBV_P * RPT * a.SPC : 0));                   // adjacencies of this chain's breakends
     for (int i = t; i < a.C * S * M; i += NT) totl[i] = a.tot[i];
     if (a.amat_lds) {
         const int8_t *src = (dir == 0 ? a.af : a.ab) + (size_t)a.chain_tc[chain] * S * S;
         for (int i = t; i < S * S; i += NT) atl[i] = src[i];
     }
+    if (a.code_lds) {
+        // code of the pair (row q -> column o) at a breakend adjacency of this chain and direction: the
+        // index of the clone-product weight (differences of the tumour clones' totals; the normal clone's
+        // is 0 inside a class) in the low 10 bits, the allele distance (< 64) above.  Rows / columns past S: 0.
+        const int8_t *src = (dir == 0 ? a.af : a.ab) + (size_t)a.chain_tc[chain] * S * S;
+        const int8_t *tg = a.tot + (size_t)a.chain_cls[chain] * S * M;
+        const int off_ = a.cn_max + 1, sg_ = dir == 0 ? 1 : -1;
+        for (int i = t; i < FBV_P * RPT * a.SPC; i += NT) {
+            const int q = i / a.SPC, o = i - q * a.SPC;
+            unsigned c_ = 0;
+            if (q < S && o < S) {
+                int idx = 0;
+                for (int c = 1; c < M; c++) idx = idx * D + sg_ * ((int)tg[q * M + c] - (int)tg[o * M + c]) + off_;
+                c_ = (unsigned)idx | ((unsigned)src[(size_t)q * S + o] << 10);
+            }
+            codel[i] = (unsigned short)c_;
+        }
+    }
+    const int be_lo = a.chain_be[2 * chain], be_hi = a.chain_be[2 * chain + 1];
+    for (int i = t; i < be_hi - be_lo; i += NT) bel[i] = a.be_n[be_lo + i];
     for (int i = t; i < NV * 2 * SPAD; i += NT) vec[i] = 0.;
     for (int i = t; i < 128; i += NT) wa[i] = exp(-a.pen * (double)i);
-    for (int i = t; i < FB_NBUF * 2 * 64; i += NT) meta[i] = -1;
     if (t < NV * 4) red[t] = 0.;
 
     const double *Wmat = (dir == 0 ? a.Wf : a.Wb) + (size_t)a.chain_tc[chain] * S * S;
@@ -534,154 +609,144 @@ __global__ __launch_bounds__(NTMAX) void k_fbv(FbvArgs a) {
     __syncthreads();
 
 #define ROW(k) (dir == 0 ? n0 + (k) : n1 - (k))
-    const int nblk = (len + BLK - 1) / BLK;
-    const int elems = BLK * SP / 2;                       // 16-byte elements per block and vector
-    const int wave_base = (t >> 6) << 6;
-    // emission rows of block b_ for all vectors + step metadata, by LDS-DMA
-#define FBV_ISSUE(b_)                                                                                                  \
-    {                                                                                                                  \
-        const int slot_ = (b_) % FB_NBUF;                                                                              \
-        const int rs_ = dir == 0 ? n0 + (b_) * BLK : n1 - (b_) * BLK - (BLK - 1);                                      \
-        for (int v_ = 0; v_ < nv; v_++) {                                                                              \
-            const double *src_ = a.fe + ((size_t)(rg0 + v_) * a.N + rs_) * SP;                                         \
-            for (int i0 = 0; i0 < elems; i0 += NT) {                                                                   \
-                const int idx = i0 + t;                                                                                \
-                const int row_ = rs_ + (idx * 2) / SP;                                                                 \
-                const unsigned dst_ = __builtin_amdgcn_readfirstlane(                                                  \
-                    lds_addr(ebuf + ((size_t)v_ * FB_NBUF + slot_) * BLK * SP + (size_t)(i0 + wave_base) * 2));         \
-                if (idx < elems && row_ >= n0 && row_ <= n1) glds16(src_ + (size_t)idx * 2, dst_);                     \
-            }                                                                                                          \
-        }                                                                                                              \
-        if (t < 64) {                                                                                                  \
-            const int tn_ = (dir == 0 ? n0 + (b_) * BLK - 1 : n1 - (b_) * BLK - (BLK - 1)) + t;                        \
-            const unsigned d0_ = __builtin_amdgcn_readfirstlane(lds_addr(meta + (slot_ * 2 + 0) * 64));                 \
-            const unsigned d1_ = __builtin_amdgcn_readfirstlane(lds_addr(meta + (slot_ * 2 + 1) * 64));                 \
-            if (t < BLK && tn_ >= n0 && tn_ < n1) { glds4(a.tclass + tn_, d0_); glds4(a.brk_slot + tn_, d1_); }        \
-        }                                                                                                              \
+    // Adjacency crossed by step k (between rows ROW(k-1) and ROW(k)): n0 + k - 1 forward, n1 - k backward.
+    // Every adjacency of such a chain has transition class chain_tc; the breakend ones are the slot
+    // interval chain_be[chain] of be_n (ascending, copied to LDS above), walked in step order, so a plain
+    // step pays one scalar compare and nothing is fetched per step.
+#define ADJ(k) (dir == 0 ? n0 + (k) - 1 : n1 - (k))
+    const int tc = a.chain_tc[chain];
+    const int be_step = dir == 0 ? 1 : -1;
+    int be_i = dir == 0 ? be_lo : be_hi - 1;                                   // slot of the next breakend step
+    int be_adj = (be_i >= be_lo && be_i < be_hi) ? __builtin_amdgcn_readfirstlane(bel[be_i - be_lo]) : -2;   // its adjacency
+    // breakend slot of step k_ (-1: plain adjacency), advancing the walk past it
+#define BE_SLOT(k_, bs_)                                                                                   \
+    int bs_ = -1;                                                                                          \
+    if (ADJ(k_) == be_adj) {                                                                               \
+        bs_ = be_i; be_i += be_step;                                                                       \
+        be_adj = (be_i >= be_lo && be_i < be_hi) ? __builtin_amdgcn_readfirstlane(bel[be_i - be_lo]) : -2; \
     }
-    FBV_ISSUE(0)
-    if (nblk > 1) FBV_ISSUE(1)
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (nblk > 2) FBV_ISSUE(2)
-    FB_BARRIER();
-
     // ---- step 0 ---------------------------------------------------------------------------------
+    // The emission value a publishing lane needs in step k is one 8-byte global load (coalesced over
+    // the wave), requested a whole step ahead of its use.
     const int rstep = dir == 0 ? SP : -SP;
-    double *outp = (dir == 0 ? a.fa : a.fb) + ((size_t)(rg0 + (postwave ? pv : 0)) * a.N + ROW(0)) * SP + po;
-    if (post) {
-        const double e0 = ebuf[((size_t)pv * FB_NBUF * BLK + (dir == 0 ? 0 : BLK - 1)) * SP + po];
-        vec[(size_t)pv * 2 * SPAD + po] = e0;
-        gstore8(outp, (dir == 0) ? e0 : 1.0);
+    // (lanes without a publishing role get a valid in-range address: their loads are issued too, unused)
+    const size_t lane_off = ((size_t)(rg0 + (postwave ? pv : 0)) * a.N + ROW(0)) * SP + (po < S ? po : S - 1);
+    double *outp = (dir == 0 ? a.fa : a.fb) + lane_off;
+    const double *eptr = a.fe + lane_off;
+    if (postwave) {      // wave-uniform
+        double e0 = 0.;
+        if (post) {
+            e0 = *eptr;
+            vec[(size_t)pv * 2 * SPAD + po] = e0;
+            gstore8(outp, (dir == 0) ? e0 : 1.0);
+        }
+        const unsigned wm = wave_max_u32((unsigned)__double2hiint(e0));
+        if (lane == 0) lds_max_u32(&red32[(pv * 4 + 2) * 2], wm);
     }
+    eptr += rstep;
+    const int8_t *tcl = totl + (size_t)chain_cls_ * S * M;
+    const int sgn = dir == 0 ? 1 : -1;
     FB_BARRIER();
 
-    // reducer: maximum of vector v (buffer buf) -> red[v][0] = 1/max, row maximum to mrow (forward)
-    double *mrow_r = a.mrow + (size_t)rg0 * a.N + ROW(0);      // advanced by the reducer lane 0
-#define FBV_REDUCE(buf_)                                                                                   \
-    {                                                                                                      \
-        /* S <= 8*RPT <= 192: three values per lane and vector; all loads first, then NV independent */    \
-        /* cross-lane chains the scheduler can interleave                                            */    \
-        double mx_[NV];                                                                                    \
-        _Pragma("unroll") for (int v_ = 0; v_ < NV; v_++) {                                                \
-            const double *src_ = vec + ((size_t)v_ * 2 + (buf_)) * SPAD;                                   \
-            const double x0_ = src_[lane];                                                                 \
-            const double x1_ = lane + 64 < S ? src_[lane + 64] : 0.;                                       \
-            const double x2_ = lane + 128 < S ? src_[lane + 128] : 0.;                                     \
-            double m_ = (lane < S && x0_ == x0_) ? x0_ : (lane < S ? INFINITY : 0.);                       \
-            m_ = fmax(m_, x1_ == x1_ ? x1_ : INFINITY);                                                    \
-            m_ = fmax(m_, x2_ == x2_ ? x2_ : INFINITY);                                                    \
-            mx_[v_] = m_;                                                                                  \
-        }                                                                                                  \
-        _Pragma("unroll") for (int v_ = 0; v_ < NV; v_++) mx_[v_] = wave_max_nonneg(mx_[v_]);              \
-        _Pragma("unroll") for (int v_ = 0; v_ < NV; v_++)                                                  \
-            if (lane == 0 && v_ < nv) { red[v_ * 4] = fast_rcp(mx_[v_]); red[v_ * 4 + 1] = mx_[v_]; if (dir == 0) gstore8(mrow_r + (size_t)v_ * a.N, mx_[v_]); } \
+    // lanes 0..NV-1: scale of the vector in buffer buf_ (complete since the last barrier) and its exact
+    // reciprocal, the scale to mrow (forward), the other buffer's accumulator cleared for this step
+#define FBV_SCALE(buf_, row_)                                                                              \
+    if (t < NV) {                                                                                          \
+        double m_, i_;                                                                                     \
+        pow2_scale(red32[(t * 4 + 2 + (buf_)) * 2], m_, i_);                                               \
+        red[t * 4] = i_; red[t * 4 + 1] = m_;                                                              \
+        red32[(t * 4 + 2 + ((buf_) ^ 1)) * 2] = 0u;                                                        \
+        if (dir == 0 && t < nv) gstore8(a.mrow + (size_t)(rg0 + t) * a.N + (row_), m_);                    \
     }
 
-    int b = 0, kk = 0, slot = 0, cur = 0, nxt = 1;
 #ifdef RMX_FB_STAMPS
-    unsigned long long stamp_acc[6] = {0, 0, 0, 0, 0, 0}, stamp_last;
+    unsigned long long stamp_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, stamp_last;
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_last) :: "memory");
 #endif
     if (a.dbg && t == 0 && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0) { a.dbg[0] = clock64(); a.dbg[1] = wall_clock64(); a.dbg[4] = len; }
+    constexpr int NVX = NV;
+    const int vX = 0;
     for (int k = 1; k < len; k++) {
         FB_STAMP(0)
-        if (++kk == BLK) { kk = 0; b++; slot = slot + 1 == FB_NBUF ? 0 : slot + 1; }
-        const int kidx = dir == 0 ? kk : BLK - 1 - kk;
-        const int bs = meta[(slot * 2 + 1) * 64 + kidx];
-        // phase-2 operand that is already final: fetched now, latency hidden under phase 1
-        double e = 0.;
-        if (post) e = ebuf[(((size_t)pv * FB_NBUF + slot) * BLK + kidx) * SP + po];
+        BE_SLOT(k, bs)
+        const int cb = (k - 1) & 1, nb = k & 1;       // buffers of the vectors of steps k-1 and k
+        // phase-2 operand that is already final: requested now, latency hidden under phase 1
+        double e;
+        gload8(e, eptr);
+        eptr += rstep;
         FB_STAMP(1)
         // ============================ phase 1 ============================
         double acc0[NV], acc1[NV];
 #pragma unroll
         for (int v = 0; v < NV; v++) { acc0[v] = 0.; acc1[v] = 0.; }
-        if (reducer) {
-            FBV_REDUCE(cur)
-            mrow_r += (dir == 0 ? 1 : -1);
-        }
-        if (bs < 0 && !reducer) {
-            // stages of SW LDS reads (2*SW rows), software-pipelined one stage ahead across rows and
-            // vectors; narrower stages where the weights already fill most of the register budget
-            constexpr int SW = (RPT >= 22) ? 2 : 4;
-            constexpr int NCH = (RPT + 2 * SW - 1) / (2 * SW);      // stages per vector
-            double2 st[2][SW];
-            const double *vbase = vec + (size_t)cur * SPAD + p * RPT;
+        FBV_SCALE(cb, ROW(k - 1))
+        if (bs < 0) {
+            if (act) {      // wave-uniform: 8*G2 is a multiple of 128
+                constexpr int NA = (RPT + 15) / 16;
+                double av[NV][NA];
+                const double *vb0 = vec + (size_t)cb * SPAD + p * RPT + (lane & 15);
 #pragma unroll
-            for (int u = 0; u < SW; u++) if (2 * u < RPT) st[0][u] = *reinterpret_cast<const double2 *>(vbase + 2 * u);
-            __builtin_amdgcn_sched_barrier(0);
+                for (int v = 0; v < NV; v++)
 #pragma unroll
-            for (int sidx = 0; sidx < NV * NCH; sidx++) {
-                const int v = sidx / NCH, c = sidx % NCH, c0 = c * 2 * SW;
-                if (sidx + 1 < NV * NCH) {
-                    const int v2 = (sidx + 1) / NCH, c2 = ((sidx + 1) % NCH) * 2 * SW;
-                    const double *src = vec + ((size_t)v2 * 2 + cur) * SPAD + p * RPT + c2;
-#pragma unroll
-                    for (int u = 0; u < SW; u++) if (c2 + 2 * u < RPT) st[(sidx + 1) & 1][u] = *reinterpret_cast<const double2 *>(src + 2 * u);
-                }
-#pragma unroll
-                for (int u = 0; u < SW; u++)
-                    if (c0 + 2 * u < RPT) {
-                        const double2 x = st[sidx & 1][u];
-                        acc0[v] = fma(x.x, w0[c0 + 2 * u], acc0[v]); acc1[v] = fma(x.x, w1[c0 + 2 * u], acc1[v]);
-                        acc0[v] = fma(x.y, w0[c0 + 2 * u + 1], acc0[v]); acc1[v] = fma(x.y, w1[c0 + 2 * u + 1], acc1[v]);
-                    }
-                __builtin_amdgcn_sched_barrier(0);
+                    for (int h = 0; h < NA; h++) av[v][h] = vb0[(size_t)v * 2 * SPAD + 16 * h];
+                fbv_row_fma<RPT, NV, NA, 0>(av, w0, w1, acc0, acc1);
             }
-        } else if (bs >= 0) {
+        } else {
             // ---- breakend adjacency: restart-specific weights prod_m pe_m[d_m] * exp(-pen*a) ----
-            const int tc = meta[(slot * 2 + 0) * 64 + kidx];
-            if (t < 64) {
-                for (int v = 0; v < nv; v++) {
-                    const unsigned dpe = __builtin_amdgcn_readfirstlane(lds_addr(pel + (size_t)v * MDP));
-                    if (t * 2 < MDP) glds16(a.pe_lt + ((size_t)(rg0 + v) * a.NBE + bs) * MDP + t * 2, dpe);
+            if (a.code_lds) {
+                // fast path: the clone product comes as one table per vector (k_brk_lut), the pair's table index
+                // and allele distance as one 16-bit code from LDS; the vector operand is broadcast inside the DPP
+                // row exactly as on a plain step
+                if (t < (a.PE2P + 1) / 2) {          // (waves 0..2 at most: wave-granular s_waitcnt below)
+                    for (int v = 0; v < NVX; v++) {
+                        const unsigned dpe = __builtin_amdgcn_readfirstlane(lds_addr(pel + (size_t)(vX + v) * PELW) + (unsigned)(((t >> 6) << 6) * 16));
+                        if (vX + v < nv && t * 2 < a.PE2P) glds16(a.pe2_lt + ((size_t)(rg0 + vX + v) * a.NBE + bs) * a.PE2P + t * 2, dpe);
+                    }
                 }
-            }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            FB_BARRIER();
-            const int8_t *at = a.amat_lds ? atl : ((dir == 0 ? a.af : a.ab) + (size_t)tc * S * S);
-            const int8_t *tcl = totl + (size_t)chain_cls_ * S * M;
-            const int sgn = dir == 0 ? 1 : -1;
-            if (act) {
-                for (int rr = 0; rr < RPT; rr++) {
-                    const int q = p * RPT + rr;
-                    if (q >= S) break;
+                if (t < 256) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                FB_BARRIER();
+                if (act) {
+                    constexpr int NA = (RPT + 15) / 16;
+                    double av[NVX][NA];
+                    const double *vb0 = vec + ((size_t)vX * 2 + cb) * SPAD + p * RPT + (lane & 15);
 #pragma unroll
-                    for (int col = 0; col < 2; col++) {
-                        const int o = col == 0 ? o0 : o1;
-                        if (o < S) {
-                            const double wbase = wa[(int)at[(size_t)q * S + o]];
-                            int dd[RMX_MAX_CLONES];
+                    for (int v = 0; v < NVX; v++)
 #pragma unroll
-                            for (int c = 0; c < RMX_MAX_CLONES; c++) dd[c] = c < M ? sgn * ((int)tcl[(size_t)q * M + c] - (int)tcl[(size_t)o * M + c]) + a.cn_max + 1 : 0;
+                        for (int h = 0; h < NA; h++) av[v][h] = vb0[(size_t)v * 2 * SPAD + 16 * h];
+                    const unsigned short *crow = codel + (size_t)(p * RPT) * a.SPC + (o0 < a.SPC ? o0 : a.SPC - 2);
+                    fbv_row_fma_be<RPT, NVX, NA, 0>(av, crow, a.SPC, wa, pel + (size_t)vX * PELW, PELW, acc0, acc1);
+                }
+            } else {
+                if (t < 64) {
+                    for (int v = 0; v < NVX; v++) {
+                        const unsigned dpe = __builtin_amdgcn_readfirstlane(lds_addr(pel + (size_t)(vX + v) * MDP));
+                        if (vX + v < nv && t * 2 < MDP) glds16(a.pe_lt + ((size_t)(rg0 + vX + v) * a.NBE + bs) * MDP + t * 2, dpe);
+                    }
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
+                FB_BARRIER();
+                const int8_t *at = a.amat_lds ? atl : ((dir == 0 ? a.af : a.ab) + (size_t)tc * S * S);
+                if (act) {
+                    for (int rr = 0; rr < RPT; rr++) {
+                        const int q = p * RPT + rr;
+                        if (q >= S) break;
 #pragma unroll
-                            for (int v = 0; v < NV; v++) {
-                                if (v < nv) {
-                                    double wv = wbase;
+                        for (int col = 0; col < 2; col++) {
+                            const int o = col == 0 ? o0 : o1;
+                            if (o < S) {
+                                const double wbase = wa[(int)at[(size_t)q * S + o]];
+                                int dd[RMX_MAX_CLONES];
 #pragma unroll
-                                    for (int c = 0; c < RMX_MAX_CLONES; c++) if (c < M) wv *= pel[(size_t)v * MDP + c * D + dd[c]];
-                                    const double x = vec[((size_t)v * 2 + cur) * SPAD + q];
-                                    if (col == 0) acc0[v] = fma(x, wv, acc0[v]); else acc1[v] = fma(x, wv, acc1[v]);
+                                for (int c = 0; c < RMX_MAX_CLONES; c++) dd[c] = c < M ? sgn * ((int)tcl[(size_t)q * M + c] - (int)tcl[(size_t)o * M + c]) + a.cn_max + 1 : 0;
+#pragma unroll
+                                for (int v = 0; v < NVX; v++) {
+                                    if (vX + v < nv) {
+                                        double wv = wbase;
+#pragma unroll
+                                        for (int c = 0; c < RMX_MAX_CLONES; c++) if (c < M) wv *= pel[(size_t)(vX + v) * MDP + c * D + dd[c]];
+                                        const double x = vec[((size_t)(vX + v) * 2 + cb) * SPAD + q];
+                                        if (col == 0) acc0[v] = fma(x, wv, acc0[v]); else acc1[v] = fma(x, wv, acc1[v]);
+                                    }
                                 }
                             }
                         }
@@ -690,7 +755,7 @@ __global__ __launch_bounds__(NTMAX) void k_fbv(FbvArgs a) {
             }
         }
         FB_STAMP(2)
-        if (act) {
+        if (act && o0 < SP) {
 #pragma unroll
             for (int v = 0; v < NV; v++) {
                 double2 pr; pr.x = acc0[v]; pr.y = acc1[v];
@@ -701,40 +766,339 @@ __global__ __launch_bounds__(NTMAX) void k_fbv(FbvArgs a) {
         FB_STAMP(3)
         // ============================ phase 2 ============================
         outp += rstep;
+        unsigned vmax_in = 0u;
+        gwait8(e);        // a step old by now, like this wave's previous result store
         if (post) {
             const double inv = red[pv * 4];
             const double *pp_ = part + (size_t)pv * FBV_P * SP + po;
             const double s0 = pp_[0], s1 = pp_[SP], s2 = pp_[2 * SP], s3 = pp_[3 * SP];
             const double s4 = pp_[4 * SP], s5 = pp_[5 * SP], s6 = pp_[6 * SP], s7 = pp_[7 * SP];
             const double sum = ((((((s0 + s1) + s2) + s3) + s4) + s5) + s6) + s7;
+            FB_STAMP(6)
             const double val = sum * inv;
             const double vecv = val * e;
-            vec[((size_t)pv * 2 + nxt) * SPAD + po] = vecv;
+            vec[((size_t)pv * 2 + nb) * SPAD + po] = vecv;
             gstore8(outp, (dir == 0) ? vecv : val);
+            vmax_in = (unsigned)__double2hiint(vecv);
         }
-        if (kk == 0 && b >= 1) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if (b + 2 < nblk) FBV_ISSUE(b + 2)
+        FB_STAMP(7)
+        if (postwave) {
+            const unsigned wm = wave_max_u32(vmax_in);
+            if (lane == 0) lds_max_u32(&red32[(pv * 4 + 2 + nb) * 2], wm);
         }
-        cur ^= 1; nxt ^= 1;
-        FB_STAMP(4)
+        FB_STAMP(8)
         FB_BARRIER();
         FB_STAMP(5)
     }
     if (a.dbg && t == 0 && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0) { a.dbg[2] = clock64(); a.dbg[3] = wall_clock64(); }
 #ifdef RMX_FB_STAMPS
-    if (a.dbg && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && (t == 0 || t == NT - 64)) for (int i = 0; i < 6; i++) a.dbg[8 + (t == 0 ? 0 : 6) + i] = stamp_acc[i];
+    if (a.dbg && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && (t == 0 || t == NT - 64)) for (int i = 0; i < 10; i++) a.dbg[8 + (t == 0 ? 0 : 10) + i] = stamp_acc[i];
 #endif
-    if (reducer) {
-        // last row of each chain: its maximum is not consumed by a later step, but hmm_log_norm_const
-        // and the vanishing-row check need it
-        FBV_REDUCE(cur)
-        if (lane == 0)
-            for (int v_ = 0; v_ < nv; v_++) { const double m = red[v_ * 4 + 1]; if (!(m > 0.) || m == INFINITY) atomicOr(&a.err[rg0 + v_], RMX_ERR_NAN_AB); }
-    }
-#undef FBV_REDUCE
+    // last row of each chain: its scale is not consumed by a later step, but hmm_log_norm_const and
+    // the vanishing-row check need it
+    FBV_SCALE((len - 1) & 1, ROW(len - 1))
+    if (t < nv) { const double m = red[t * 4 + 1]; if (!(m > 0.) || m == INFINITY) atomicOr(&a.err[rg0 + t], RMX_ERR_NAN_AB); }
+#undef FBV_SCALE
 #undef ROW
-#undef FBV_ISSUE
+#undef ADJ
+#undef BE_SLOT
+}
+
+// =============================================================================
+// k_fbs: k_fbv with the two phases of a step software-pipelined across two half-groups of vectors.
+// Phase 2 of k_fbv (partial sums -> scale -> publish -> maximum) is a pure latency chain of LDS round
+// trips during which the FP64 pipes idle, and both barriers of a step sit on that chain.  Here the
+// NV = 2*NVH vectors of a workgroup form groups A (vectors 0..NVH-1) and B (NVH..NV-1), B half a step
+// behind A.  One barrier interval ("tick") holds phase 1 of one group and phase 2 of the other:
+//     tick 2j   : phase 1 of A at step j+1   |  phase 2 of B at step j
+//     tick 2j+1 : phase 1 of B at step j+1   |  phase 2 of A at step j+1
+// The two touch disjoint LDS regions (vec / part / red are per vector), so one barrier per tick is
+// enough.  Same arithmetic per vector as k_fbv (bit-identical results).
+// =============================================================================
+template <int RPT, int NVH, int NTMAX>
+__global__ __launch_bounds__(NTMAX) void k_fbs(FbvArgs a) {
+    constexpr int NV = 2 * NVH;
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    const int chain = a.chain_list[blockIdx.x], dir = blockIdx.z;
+    const int rg0 = a.r0 + blockIdx.y * NV;                 // first restart of this group
+    const int nv = min(NV, a.r1 - rg0);                     // vectors actually present
+    const int S = a.S, M = a.M, D = a.D, SP = a.SP, G2 = a.G2, SPW = a.SPW;
+    const int n0 = a.chain_start[chain], n1 = a.chain_end[chain], len = n1 - n0 + 1;
+    const int t = threadIdx.x, NT = blockDim.x;
+    const int p = t / G2, g = t - p * G2;
+    const int o0 = 2 * g, o1 = 2 * g + 1;
+    const bool act = p < FBV_P;                             // phase-1 worker
+    const int pv = t / SPW, po = t - pv * SPW;              // phase-2 role
+    const bool post = pv < nv && po < S;
+    const bool postwave = pv < nv;                          // wave-uniform (SPW is a multiple of 64)
+    const int lane = t & 63;
+    const int SPAD = a.SPAD;
+    const int MDP = (M * D + 1) & ~1;
+    // ---- LDS carve-up -----------------------------------------------------------------------
+    double *vec = (double *)smem_raw;                           // [NV][2][SPAD]  the vectors, double-buffered by step parity
+    double *part = vec + (size_t)NV * 2 * SPAD;                 // [NV][P][SP]    partial sums of phase 1
+    double *red = part + (size_t)NV * FBV_P * SP;               // [NV][4]: [v][0] = 1/scale of the current vector, [v][1] = scale, [v][2 + buf] = largest high dword of vec[v][buf] (u32 in the slot's low half)
+    unsigned *red32 = (unsigned *)red;
+    // breakend steps: per-vector weight table(s) of the current breakend -- with code_lds the product over
+    // the clones, indexed by the code of a state pair (PE2P doubles per vector), else one table per clone
+    const int PELW = a.code_lds ? a.PE2P : MDP;
+    double *pel = red + NV * 4;                                 // [NV][PELW]
+    double *wa = pel + (size_t)NV * PELW;                       // [128]
+    int8_t *totl = (int8_t *)(wa + 128);                        // [C][S][M]
+    int8_t *atl = totl + ((a.C * S * M + 15) & ~15);            // [S][S] (amat_lds)
+    unsigned short *codel = (unsigned short *)(atl + (a.amat_lds ? ((S * S + 15) & ~15) : 0));   // [8*RPT][SPC] (code_lds)
+    int *bel = (int *)(codel + (a.code_lds ? (size_t)FBV_P * RPT * a.SPC : 0));                   // adjacencies of this chain's breakends
+    for (int i = t; i < a.C * S * M; i += NT) totl[i] = a.tot[i];
+    if (a.amat_lds) {
+        const int8_t *src = (dir == 0 ? a.af : a.ab) + (size_t)a.chain_tc[chain] * S * S;
+        for (int i = t; i < S * S; i += NT) atl[i] = src[i];
+    }
+    if (a.code_lds) {
+        // code of the pair (row q -> column o) at a breakend adjacency of this chain and direction: the
+        // index of the clone-product weight (differences of the tumour clones' totals; the normal clone's
+        // is 0 inside a class) in the low 10 bits, the allele distance (< 64) above.  Rows / columns past S: 0.
+        const int8_t *src = (dir == 0 ? a.af : a.ab) + (size_t)a.chain_tc[chain] * S * S;
+        const int8_t *tg = a.tot + (size_t)a.chain_cls[chain] * S * M;
+        const int off_ = a.cn_max + 1, sg_ = dir == 0 ? 1 : -1;
+        for (int i = t; i < FBV_P * RPT * a.SPC; i += NT) {
+            const int q = i / a.SPC, o = i - q * a.SPC;
+            unsigned c_ = 0;
+            if (q < S && o < S) {
+                int idx = 0;
+                for (int c = 1; c < M; c++) idx = idx * D + sg_ * ((int)tg[q * M + c] - (int)tg[o * M + c]) + off_;
+                c_ = (unsigned)idx | ((unsigned)src[(size_t)q * S + o] << 10);
+            }
+            codel[i] = (unsigned short)c_;
+        }
+    }
+    const int be_lo = a.chain_be[2 * chain], be_hi = a.chain_be[2 * chain + 1];
+    for (int i = t; i < be_hi - be_lo; i += NT) bel[i] = a.be_n[be_lo + i];
+    for (int i = t; i < NV * 2 * SPAD; i += NT) vec[i] = 0.;
+    for (int i = t; i < 128; i += NT) wa[i] = exp(-a.pen * (double)i);
+    if (t < NV * 4) red[t] = 0.;
+
+    const double *Wmat = (dir == 0 ? a.Wf : a.Wb) + (size_t)a.chain_tc[chain] * S * S;
+    // ---- stationary weights: 2 columns x RPT rows, consumed before the loop --------------------
+    double w0[RPT], w1[RPT];
+#pragma unroll
+    for (int rr = 0; rr < RPT; rr++) {
+        const int q = p * RPT + rr;
+        w0[rr] = (act && q < S && o0 < S) ? Wmat[(size_t)q * S + o0] : 0.;
+        w1[rr] = (act && q < S && o1 < S) ? Wmat[(size_t)q * S + o1] : 0.;
+    }
+#pragma unroll
+    for (int rr = 0; rr < RPT; rr++) { asm volatile("" ::"v"(w0[rr])); asm volatile("" ::"v"(w1[rr])); }
+    int chain_cls_ = __builtin_amdgcn_readfirstlane(a.chain_cls[chain]);
+    asm volatile("" : "+s"(chain_cls_));
+    __syncthreads();
+
+#define ROW(k) (dir == 0 ? n0 + (k) : n1 - (k))
+    // Adjacency crossed by step k (between rows ROW(k-1) and ROW(k)): n0 + k - 1 forward, n1 - k backward.
+    // Every adjacency of such a chain has transition class chain_tc; the breakend ones are the slot
+    // interval chain_be[chain] of be_n (ascending, copied to LDS above), walked in step order, so a plain
+    // step pays one scalar compare and nothing is fetched per step.
+#define ADJ(k) (dir == 0 ? n0 + (k) - 1 : n1 - (k))
+    const int tc = a.chain_tc[chain];
+    const int be_step = dir == 0 ? 1 : -1;
+    int be_i = dir == 0 ? be_lo : be_hi - 1;                                   // slot of the next breakend step
+    int be_adj = (be_i >= be_lo && be_i < be_hi) ? __builtin_amdgcn_readfirstlane(bel[be_i - be_lo]) : -2;   // its adjacency
+    // breakend slot of step k_ (-1: plain adjacency), advancing the walk past it
+#define BE_SLOT(k_, bs_)                                                                                   \
+    int bs_ = -1;                                                                                          \
+    if (ADJ(k_) == be_adj) {                                                                               \
+        bs_ = be_i; be_i += be_step;                                                                       \
+        be_adj = (be_i >= be_lo && be_i < be_hi) ? __builtin_amdgcn_readfirstlane(bel[be_i - be_lo]) : -2; \
+    }
+    // ---- step 0 ---------------------------------------------------------------------------------
+    // The emission value a publishing lane needs in step k is one 8-byte global load (coalesced over
+    // the wave), requested a whole step ahead of its use.
+    const int rstep = dir == 0 ? SP : -SP;
+    // (lanes without a publishing role get a valid in-range address: their loads are issued too, unused)
+    const size_t lane_off = ((size_t)(rg0 + (postwave ? pv : 0)) * a.N + ROW(0)) * SP + (po < S ? po : S - 1);
+    double *outp = (dir == 0 ? a.fa : a.fb) + lane_off;
+    const double *eptr = a.fe + lane_off;
+    if (postwave) {      // wave-uniform
+        double e0 = 0.;
+        if (post) {
+            e0 = *eptr;
+            vec[(size_t)pv * 2 * SPAD + po] = e0;
+            gstore8(outp, (dir == 0) ? e0 : 1.0);
+        }
+        const unsigned wm = wave_max_u32((unsigned)__double2hiint(e0));
+        if (lane == 0) lds_max_u32(&red32[(pv * 4 + 2) * 2], wm);
+    }
+    eptr += rstep;
+    const int8_t *tcl = totl + (size_t)chain_cls_ * S * M;
+    const int sgn = dir == 0 ? 1 : -1;
+    FB_BARRIER();
+
+    // lanes 0..NVH-1 of wave 0, group X at the tick of its phase 1 of step k_: scale of the vector of
+    // step k_-1 (complete since the last barrier) and its exact reciprocal, the scale to mrow (forward),
+    // the accumulator of this step's buffer cleared
+#define FBS_SCALE(v0_, k_)                                                                                 \
+    if (t < NVH) {                                                                                         \
+        const int v_ = (v0_) + t, pb_ = ((k_) - 1) & 1;                                                    \
+        double m_, i_;                                                                                     \
+        pow2_scale(red32[(v_ * 4 + 2 + pb_) * 2], m_, i_);                                                 \
+        red[v_ * 4] = i_; red[v_ * 4 + 1] = m_;                                                            \
+        red32[(v_ * 4 + 2 + (pb_ ^ 1)) * 2] = 0u;                                                          \
+        if (dir == 0 && v_ < nv) gstore8(a.mrow + (size_t)(rg0 + v_) * a.N + ROW((k_) - 1), m_);           \
+    }
+    const int mygroup = pv / NVH;                            // phase-2 role: group of this lane's vector
+    constexpr int NVX = NVH;
+    // emission value of this lane's next phase 2 (step 1 first), always requested a whole step ahead
+    double e_cur = 0.;
+    if (len > 1) gload8(e_cur, eptr);
+    eptr += rstep;
+
+    // one tick: phase 1 of group X at step kX if doP1 (bs / tc: that step's breakend slot and transition
+    // class), phase 2 of the other group at step kY if doP2
+    auto tick = [&](const int X, const bool doP1, const int kX, const int bs, const int tc, const bool doP2, const int kY) __attribute__((always_inline)) {
+        const int vX = X * NVH;
+        const bool myP2 = doP2 && postwave && mygroup == (X ^ 1);        // wave-uniform
+        // ---- phase 2 of the other group: every operand is final since the last barrier.  The waves that
+        // own it run it first (a chain of LDS round trips); the FP64 pipes are kept busy meanwhile by the
+        // waves that have no phase-2 role in this tick and go straight to the FMAs below ----
+        if (myP2) {
+            outp += rstep;
+            unsigned vmax_in = 0u;
+            gwait8(e_cur);        // requested a whole step ago, like this wave's previous result store
+            const double e_use = e_cur;
+            if (kY + 1 < len) gload8(e_cur, eptr);      // for this lane's next phase 2
+            eptr += rstep;
+            if (post) {
+                const double *pp_ = part + (size_t)pv * FBV_P * SP + po;
+                const double s0 = pp_[0], s1 = pp_[SP], s2 = pp_[2 * SP], s3 = pp_[3 * SP];
+                const double s4 = pp_[4 * SP], s5 = pp_[5 * SP], s6 = pp_[6 * SP], s7 = pp_[7 * SP];
+                const double inv = red[pv * 4];
+                const double sum = ((((((s0 + s1) + s2) + s3) + s4) + s5) + s6) + s7;
+                const double val = sum * inv;
+                const double vecv = val * e_use;
+                vec[((size_t)pv * 2 + (kY & 1)) * SPAD + po] = vecv;
+                gstore8(outp, (dir == 0) ? vecv : val);
+                vmax_in = (unsigned)__double2hiint(vecv);
+            }
+            const unsigned wm = wave_max_u32(vmax_in);
+            if (lane == 0) lds_max_u32(&red32[(pv * 4 + 2 + (kY & 1)) * 2], wm);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- phase 1 of group X ----
+        double acc0[NVH], acc1[NVH];
+#pragma unroll
+        for (int v = 0; v < NVH; v++) { acc0[v] = 0.; acc1[v] = 0.; }
+        if (doP1) {
+            FBS_SCALE(vX, kX)
+            const int cb = (kX - 1) & 1;       // buffer holding the vectors of step kX-1
+            if (bs < 0) {
+                if (act) {      // wave-uniform: 8*G2 is a multiple of 128
+                    constexpr int NA = (RPT + 15) / 16;
+                    double av[NVH][NA];
+                    const double *vb0 = vec + ((size_t)vX * 2 + cb) * SPAD + p * RPT + (lane & 15);
+#pragma unroll
+                    for (int v = 0; v < NVH; v++)
+#pragma unroll
+                        for (int h = 0; h < NA; h++) av[v][h] = vb0[(size_t)v * 2 * SPAD + 16 * h];
+                    fbv_row_fma<RPT, NVH, NA, 0>(av, w0, w1, acc0, acc1);
+                }
+            } else {
+                // ---- breakend adjacency: restart-specific weights prod_m pe_m[d_m] * exp(-pen*a) ----
+                if (a.code_lds) {
+                    // fast path: the clone product comes as one table per vector (k_brk_lut), the pair's table index
+                    // and allele distance as one 16-bit code from LDS; the vector operand is broadcast inside the DPP
+                    // row exactly as on a plain step
+                    if (t < (a.PE2P + 1) / 2) {          // (waves 0..2 at most: wave-granular s_waitcnt below)
+                        for (int v = 0; v < NVX; v++) {
+                            const unsigned dpe = __builtin_amdgcn_readfirstlane(lds_addr(pel + (size_t)(vX + v) * PELW) + (unsigned)(((t >> 6) << 6) * 16));
+                            if (vX + v < nv && t * 2 < a.PE2P) glds16(a.pe2_lt + ((size_t)(rg0 + vX + v) * a.NBE + bs) * a.PE2P + t * 2, dpe);
+                        }
+                    }
+                    if (t < 256) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    FB_BARRIER();
+                    if (act) {
+                        constexpr int NA = (RPT + 15) / 16;
+                        double av[NVX][NA];
+                        const double *vb0 = vec + ((size_t)vX * 2 + cb) * SPAD + p * RPT + (lane & 15);
+#pragma unroll
+                        for (int v = 0; v < NVX; v++)
+#pragma unroll
+                            for (int h = 0; h < NA; h++) av[v][h] = vb0[(size_t)v * 2 * SPAD + 16 * h];
+                        const unsigned short *crow = codel + (size_t)(p * RPT) * a.SPC + (o0 < a.SPC ? o0 : a.SPC - 2);
+                        fbv_row_fma_be<RPT, NVX, NA, 0>(av, crow, a.SPC, wa, pel + (size_t)vX * PELW, PELW, acc0, acc1);
+                    }
+                } else {
+                    if (t < 64) {
+                        for (int v = 0; v < NVX; v++) {
+                            const unsigned dpe = __builtin_amdgcn_readfirstlane(lds_addr(pel + (size_t)(vX + v) * MDP));
+                            if (vX + v < nv && t * 2 < MDP) glds16(a.pe_lt + ((size_t)(rg0 + vX + v) * a.NBE + bs) * MDP + t * 2, dpe);
+                        }
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    }
+                    FB_BARRIER();
+                    const int8_t *at = a.amat_lds ? atl : ((dir == 0 ? a.af : a.ab) + (size_t)tc * S * S);
+                    if (act) {
+                        for (int rr = 0; rr < RPT; rr++) {
+                            const int q = p * RPT + rr;
+                            if (q >= S) break;
+#pragma unroll
+                            for (int col = 0; col < 2; col++) {
+                                const int o = col == 0 ? o0 : o1;
+                                if (o < S) {
+                                    const double wbase = wa[(int)at[(size_t)q * S + o]];
+                                    int dd[RMX_MAX_CLONES];
+#pragma unroll
+                                    for (int c = 0; c < RMX_MAX_CLONES; c++) dd[c] = c < M ? sgn * ((int)tcl[(size_t)q * M + c] - (int)tcl[(size_t)o * M + c]) + a.cn_max + 1 : 0;
+#pragma unroll
+                                    for (int v = 0; v < NVX; v++) {
+                                        if (vX + v < nv) {
+                                            double wv = wbase;
+#pragma unroll
+                                            for (int c = 0; c < RMX_MAX_CLONES; c++) if (c < M) wv *= pel[(size_t)(vX + v) * MDP + c * D + dd[c]];
+                                            const double x = vec[((size_t)(vX + v) * 2 + cb) * SPAD + q];
+                                            if (col == 0) acc0[v] = fma(x, wv, acc0[v]); else acc1[v] = fma(x, wv, acc1[v]);
+                                        }
+                                    }
+                                }
+                            }
+                        }
+                    }
+                }
+            }
+            // ---- hand the partial sums of group X over ----
+            if (act && o0 < SP) {
+#pragma unroll
+                for (int v = 0; v < NVH; v++) {
+                    double2 pr; pr.x = acc0[v]; pr.y = acc1[v];
+                    *reinterpret_cast<double2 *>(part + ((size_t)(vX + v) * FBV_P + p) * SP + o0) = pr;
+                }
+            }
+        }
+    };
+
+    if (a.dbg && t == 0 && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0) { a.dbg[0] = clock64(); a.dbg[1] = wall_clock64(); a.dbg[4] = len; }
+    for (int j = 0; j < len; j++) {
+        const bool more = j + 1 < len;
+        BE_SLOT(j + 1, bs)                                // step j+1 (ADJ(len) is past the chain and never matches)
+        // even tick: phase 1 of A at step j+1, phase 2 of B at step j
+        tick(0, more, j + 1, bs, tc, j >= 1, j);
+        FB_BARRIER();
+        if (!more) break;
+        // odd tick: phase 1 of B at step j+1, phase 2 of A at step j+1
+        tick(1, true, j + 1, bs, tc, true, j + 1);
+        FB_BARRIER();
+    }
+    if (a.dbg && t == 0 && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0) { a.dbg[2] = clock64(); a.dbg[3] = wall_clock64(); }
+    // last row of each chain: its scale is not consumed by a later step, but hmm_log_norm_const and
+    // the vanishing-row check need it
+    if (t < NV) {
+        double m, i_;
+        pow2_scale(red32[(t * 4 + 2 + ((len - 1) & 1)) * 2], m, i_);
+        if (dir == 0 && t < nv) gstore8(a.mrow + (size_t)(rg0 + t) * a.N + ROW(len - 1), m);
+        if (t < nv && (!(m > 0.) || m == INFINITY)) atomicOr(&a.err[rg0 + t], RMX_ERR_NAN_AB);
+    }
+#undef FBS_SCALE
+#undef ROW
+#undef ADJ
+#undef BE_SLOT
 }
 
 // =============================================================================
@@ -968,7 +1332,8 @@ __global__ void k_update_allele_swap(Dev d, int r0) {     // bpmodel.pyx:1025-10
 // two outermost slots d = +-(cn_max+1) (buffer of length 2(cn_max+1), :600).
 // grid (NBE, nr), block 64 (>= M*D threads looped)
 // =============================================================================
-__global__ void k_brk_lut(Dev d, int r0, double *dst_base, double *exp_base) {
+__global__ void k_brk_lut(Dev d, int r0, double *dst_base, double *exp_base, double *prod_base, int PE2P) {
+    __shared__ double pes[RMX_MAX_CLONES * 64];
     const int slot = blockIdx.x, r = r0 + blockIdx.y;
     const int n = d.be_n[slot], k = d.brk_idx[n], orient = d.brk_orient[n];
     const double *pb = d.pbrk + ((size_t)r * d.K + k) * d.B;
@@ -985,7 +1350,21 @@ __global__ void k_brk_lut(Dev d, int r0, double *dst_base, double *exp_base) {
             for (int b = 0; b < d.B; b++) acc += pb[b] * g_transition(d.tmodel, dv - orient * d.brk_states[b * d.M + m]);
         }
         dst[i] = acc;
-        if (exp_base) exp_base[((size_t)r * d.NBE + slot) * ((d.M * d.D + 1) & ~1) + i] = exp(-d.pen * acc);
+        if (exp_base) { const double ev = exp(-d.pen * acc); exp_base[((size_t)r * d.NBE + slot) * ((d.M * d.D + 1) & ~1) + i] = ev; if (prod_base && d.D <= 64) pes[m * 64 + dd] = ev; }
+    }
+    if (exp_base && prod_base && d.D <= 64) {
+        // product over the clones for the forward-backward kernels' breakend steps (M <= 3): entry
+        // (d_1 [, d_2]) = pe_0[0 difference] * pe_1[d_1] [* pe_2[d_2]]; the normal clone's totals agree
+        // inside a state-table class
+        __syncthreads();
+        double *pr = prod_base + ((size_t)r * d.NBE + slot) * PE2P;
+        const double p0 = pes[d.cn_max + 1];
+        const int n2 = d.M == 2 ? d.D : d.D * d.D;
+        for (int i = threadIdx.x; i < PE2P; i += blockDim.x) {
+            double v = 0.;
+            if (i < n2) v = d.M == 2 ? p0 * pes[64 + i] : (p0 * pes[64 + i / d.D]) * pes[128 + i % d.D];
+            pr[i] = v;
+        }
     }
 }
 

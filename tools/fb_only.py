@@ -24,5 +24,5 @@ import os
 if os.environ.get('RMX_FB_DEBUG'):
     c0, w0, c1, w1, ln = [b.info(i) for i in (20, 21, 22, 23, 24)]
     print('debug: steps', ln, 'shader cycles/step', (c1 - c0) / max(ln - 1, 1), 'wall us/step', (w1 - w0) / 100.0 / max(ln - 1, 1), 'clock GHz', (c1 - c0) / ((w1 - w0) * 10.0))
-    print('stamps wave0 :', [round(b.info(28 + i) / max(ln - 1, 1)) for i in range(6)])
-    print('stamps waveN :', [round(b.info(34 + i) / max(ln - 1, 1)) for i in range(6)])
+    print('stamps wave0 :', [round(b.info(28 + i) / max(ln - 1, 1)) for i in range(10)])
+    print('stamps waveN :', [round(b.info(38 + i) / max(ln - 1, 1)) for i in range(10)])
