@@ -360,11 +360,13 @@ template <int NS> static cells_kernel_t cells_kernel_ns(int mode, int mask, int 
     if (cache == 2) return k_cells<NS, 2, 31, 2>;
     if (cache == 1) {
         switch (mask) {
+        case 1: return k_cells<NS, 2, 1, 1>; case 2: return k_cells<NS, 2, 2, 1>;
         case 3: return k_cells<NS, 2, 3, 1>; case 4: return k_cells<NS, 2, 4, 1>; case 8: return k_cells<NS, 2, 8, 1>;
         case 12: return k_cells<NS, 2, 12, 1>; case 15: return k_cells<NS, 2, 15, 1>; default: return k_cells<NS, 2, 31, 1>;
         }
     }
     switch (mask) {
+    case 1: return k_cells<NS, 2, 1, 0>; case 2: return k_cells<NS, 2, 2, 0>;
     case 3: return k_cells<NS, 2, 3, 0>; case 4: return k_cells<NS, 2, 4, 0>; case 8: return k_cells<NS, 2, 8, 0>;
     case 12: return k_cells<NS, 2, 12, 0>; case 15: return k_cells<NS, 2, 15, 0>; default: return k_cells<NS, 2, 31, 0>;
     }
@@ -380,7 +382,9 @@ static dim3 strip_grid(rmx_batch *b, int nr) { return dim3((b->d.N + 4 * STRIP_R
 static int cover_mask(int m) {
     if (m & 16) return 31;
     if ((m & 3) && (m & 12)) return 15;
-    if (m & 3) return 3;
+    if ((m & 3) == 3) return 3;
+    if (m & 1) return 1;
+    if (m & 2) return 2;
     if ((m & 12) == 12) return 12;
     if (m & 4) return 4;
     if (m & 8) return 8;
@@ -1062,11 +1066,14 @@ static int elbo_parts(rmx_batch *b, int r0, int r1, bool exact_parts, double *ou
         full_plain = d_fp;
     }
     { ProfScope ps(b, KID_ELBO_SEG); hipLaunchKernelGGL(k_elbo_seg, dim3(ELBO_BLOCKS, nr), dim3(256), 0, b->stream, b->d, r0, b->d_partial); }
-    // plain_T_init may differ per restart only in exotic call orders; launch per distinct value
-    for (int r = r0; r < r1; r++) {
+    // plain_T_init may differ per restart only in exotic call orders: one launch per run of equal values
+    for (int r = r0; r < r1;) {
+        int e = r + 1;
+        while (e < r1 && b->plain_T_init[e] == b->plain_T_init[r]) e++;
         ProfScope ps(b, KID_ELBO_FINAL);
-        hipLaunchKernelGGL(k_elbo_final, dim3(1), dim3(256), 0, b->stream, b->d, r, b->d_partial + (size_t)(r - r0) * ELBO_BLOCKS * 2, ELBO_BLOCKS,
+        hipLaunchKernelGGL(k_elbo_final, dim3(e - r), dim3(256), 0, b->stream, b->d, r, b->d_partial + (size_t)(r - r0) * ELBO_BLOCKS * 2, ELBO_BLOCKS,
                            (const int *)b->d_lt_valid, b->plain_T_init[r], full_plain ? full_plain + (r - r0) : nullptr, b->d_out4 + (size_t)(r - r0) * 4);
+        r = e;
     }
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(out4, b->d_out4, (size_t)nr * 32, hipMemcpyDeviceToHost, b->stream));
@@ -1206,7 +1213,7 @@ int rmx_expected_ll_param_grid(rmx_batch *b, int32_t r, int32_t param_id, const 
 // one host round trip for the whole list.
 // shared tail of the batched objective calls: stage the listed restarts' parameters, rebuild their
 // state tables, evaluate every restart's sample, reduce, copy back nout values per request
-static int run_ell_batch(rmx_batch *b, int nreq, const int32_t *restarts, bool grad, double *out) {
+static int run_ell_batch(rmx_batch *b, int nreq, const int32_t *restarts, bool grad, double *out, int mask = CM_ALL) {
     const Dev &d = b->d;
     const int W = 1 + RMX_MAX_CLONES;
     const int nout = grad ? W : 1;
@@ -1229,8 +1236,17 @@ static int run_ell_batch(rmx_batch *b, int nreq, const int32_t *restarts, bool g
             ProfScope ps(b, KID_ELL_LIST);
             if (grad) hipLaunchKernelGGL(k_ell_list_batch<true>, dim3(maxcnt, nreq), dim3(256), 0, b->stream, b->d, (const int32_t *)b->d_rlist, (const RestartParams *)b->d_rp_stage,
                                          (const int32_t *)b->d_sample, (const int32_t *)b->d_counts, b->d_ell_partial, pstride);
-            else hipLaunchKernelGGL(k_ell_list_batch<false>, dim3(maxcnt, nreq), dim3(256), 0, b->stream, b->d, (const int32_t *)b->d_rlist, (const RestartParams *)b->d_rp_stage,
-                                    (const int32_t *)b->d_sample, (const int32_t *)b->d_counts, b->d_ell_partial, pstride);
+            else {
+                void (*kf)(Dev, const int32_t *, const RestartParams *, const int32_t *, const int32_t *, double *, int) = k_ell_list_batch<false, CM_ALL>;
+                switch (mask) {
+                case 1: kf = k_ell_list_batch<false, 1>; break; case 2: kf = k_ell_list_batch<false, 2>; break;
+                case 3: kf = k_ell_list_batch<false, 3>; break; case 4: kf = k_ell_list_batch<false, 4>; break;
+                case 8: kf = k_ell_list_batch<false, 8>; break; case 12: kf = k_ell_list_batch<false, 12>; break;
+                default: break;
+                }
+                hipLaunchKernelGGL(kf, dim3(maxcnt, nreq), dim3(256), 0, b->stream, b->d, (const int32_t *)b->d_rlist, (const RestartParams *)b->d_rp_stage,
+                                   (const int32_t *)b->d_sample, (const int32_t *)b->d_counts, b->d_ell_partial, pstride);
+            }
         }
         { ProfScope ps(b, KID_ELL_FINAL); hipLaunchKernelGGL(k_ell_final_batch, dim3(nreq), dim3(256), 0, b->stream, b->d, (const int32_t *)b->d_rlist, (const int32_t *)b->d_counts,
                                                              (const double *)b->d_ell_partial, pstride, b->d_batch_out, nout); }
@@ -1361,10 +1377,35 @@ int rmx_param_search(rmx_batch *b, int32_t nreq, const int32_t *restarts, int32_
                      const double *grid, int32_t G, double *xopt) {
     if (!b || nreq < 1 || nreq > b->R || !restarts || !grid || G < 1 || !xopt) return fail(RMX_EARG, "bad argument");
     int rc;
-    std::vector<double> vals(nreq), out(nreq), best(nreq, INFINITY), x0(nreq);
+    if ((rc = check_request_list(b, nreq, restarts))) return rc;
+    // One likelihood parameter moves one or two of the four likelihood components (negbin_r_0: the
+    // non-outlier total-count term, ...).  The rest of E[ll] is constant over the search: it is taken
+    // once from a full evaluation at the first grid value, and every later evaluation computes only the
+    // moving part.  (Differs from the full sum by rounding only; RMX_SEARCH_FULL=1 evaluates everything.)
+    static const int comp_bits[RMX_P_HMM_LOG_NORM_CONST] = {CM_LT0, CM_LT1, CM_LT0 | CM_LT1, CM_LT0, CM_LT1, CM_LA0, CM_LA1, CM_LA0 | CM_LA1, CM_LA0, CM_LA1, 0, 0, 0};
+    int mask = comp_bits[param_id] & CM_ALL;
+    if (mask == 0 || getenv("RMX_SEARCH_FULL")) mask = CM_ALL;
+    std::vector<double> vals(nreq), out(nreq), best(nreq, INFINITY), x0(nreq), cst(nreq, 0.);
+    auto eval = [&](int n_, const int32_t *rl_, const double *v_, double *o_, const int *who) -> int {
+        for (int i = 0; i < n_; i++)
+            if (int e_ = rmx_set_param(b, rl_[i], param_id, v_[i])) return e_;
+        int e_ = run_ell_batch(b, n_, rl_, false, o_, mask);
+        if (e_) return e_;
+        if (mask != CM_ALL) for (int i = 0; i < n_; i++) o_[i] += cst[who ? who[i] : i];
+        return RMX_OK;
+    };
+    if (mask != CM_ALL) {
+        std::vector<double> full(nreq), part(nreq);
+        for (int i = 0; i < nreq; i++) vals[i] = grid[0];
+        for (int i = 0; i < nreq; i++)
+            if ((rc = rmx_set_param(b, restarts[i], param_id, vals[i]))) return rc;
+        if ((rc = run_ell_batch(b, nreq, restarts, false, full.data(), CM_ALL))) return rc;
+        if ((rc = run_ell_batch(b, nreq, restarts, false, part.data(), mask))) return rc;
+        for (int i = 0; i < nreq; i++) cst[i] = full[i] - part[i];
+    }
     for (int g = 0; g < G; g++) {
         for (int i = 0; i < nreq; i++) vals[i] = grid[g];
-        if ((rc = rmx_expected_ll_batch(b, nreq, restarts, param_id, vals.data(), out.data()))) return rc;
+        if ((rc = eval(nreq, restarts, vals.data(), out.data(), nullptr))) return rc;
         for (int i = 0; i < nreq; i++) { const double J = -out[i]; if (g == 0 || J < best[i]) { best[i] = J; x0[i] = grid[g]; } }   // np.argmin: first minimum
     }
     std::vector<Nm1> nm(nreq);
@@ -1384,7 +1425,7 @@ int rmx_param_search(rmx_batch *b, int32_t nreq, const int32_t *restarts, int32_
         std::vector<int> cur;
         cur.swap(want);
         for (size_t k = 0; k < cur.size(); k++) { rl[k] = restarts[cur[k]]; vals[k] = nm[cur[k]].req; }
-        if ((rc = rmx_expected_ll_batch(b, (int)cur.size(), rl.data(), param_id, vals.data(), out.data()))) return rc;
+        if ((rc = eval((int)cur.size(), rl.data(), vals.data(), out.data(), cur.data()))) return rc;
         for (size_t k = 0; k < cur.size(); k++) pump(cur[k], -out[k]);
     }
     for (int i = 0; i < nreq; i++) xopt[i] = nm[i].xopt();

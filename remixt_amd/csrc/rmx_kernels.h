@@ -1669,7 +1669,9 @@ __global__ void k_elbo_final(Dev d, int r0, const double *partial, int nblk, con
 // grid (nlist), block 256: one segment per block; partial [nlist][1+M]
 // =============================================================================
 // one sampled segment per block: E[ll] (and d/dh when GRAD) of segment n under parameters rp -> prow[1+MAXC]
-template <bool GRAD>
+// MASK (CM_* bits, GRAD == false only): restrict the sum to those likelihood components -- the part of
+// the objective that moves during the search over one likelihood parameter
+template <bool GRAD, int MASK = CM_ALL>
 __device__ __forceinline__ void ell_segment(const Dev &d, const RestartParams &rp, int r, int n, double *prow) {
     __shared__ double scratch[8];
     __shared__ double segk[8];
@@ -1691,10 +1693,13 @@ __device__ __forceinline__ void ell_segment(const Dev &d, const RestartParams &r
     double acc = 0., g[RMX_MAX_CLONES] = {0., 0., 0., 0.};
     for (int s = threadIdx.x; s < d.S; s += 256) {
         double LT[2], LA[4];
-        cell_ll(d, rp, sc, r, cls, s, LT, LA, err);
+        if (MASK == CM_ALL) cell_ll(d, rp, sc, r, cls, s, LT, LA, err);
+        else { StateRegs st_; load_state_regs(d, r, cls, s, st_); cell_ll_regs<MASK>(rp, sc, st_, LT, LA, err); }
         const double ps = post[s];
-        acc += ps * qt0 * LT[0]; acc += ps * qt1 * LT[1];
-        acc += ps * qa0 * qs0 * LA[0]; acc += ps * qa0 * qs1 * LA[1]; acc += ps * qa1 * qs0 * LA[2]; acc += ps * qa1 * qs1 * LA[3];
+        if (MASK & CM_LT0) acc += ps * qt0 * LT[0];
+        if (MASK & CM_LT1) acc += ps * qt1 * LT[1];
+        if (MASK & CM_LA0) { acc += ps * qa0 * qs0 * LA[0]; acc += ps * qa0 * qs1 * LA[1]; }
+        if (MASK & CM_LA1) { acc += ps * qa1 * qs0 * LA[2]; acc += ps * qa1 * qs1 * LA[3]; }
         if (GRAD) {
             const size_t si = ((size_t)r * d.C + cls) * d.SP + s;
             const unsigned fl = d.stFlags[si];
@@ -1793,14 +1798,14 @@ __global__ void k_state_tables_list(Dev d, const int32_t *rlist, const RestartPa
     state_tables_body(d, blockIdx.x, r, rp);
 }
 // grid (maxcount, nreq): block (i, j) evaluates sampled segment i of restart rlist[j]
-template <bool GRAD>
+template <bool GRAD, int MASK = CM_ALL>
 __global__ void k_ell_list_batch(Dev d, const int32_t *rlist, const RestartParams *stage, const int32_t *samples, const int32_t *counts,
                                  double *partial, int pstride) {
     const int r = rlist[blockIdx.y];
     if ((int)blockIdx.x >= counts[r]) return;
     const int n = samples[(size_t)r * d.N + blockIdx.x];
     // stage[j] is identical to d.rp[r]; read from the stage to stay independent of launch order
-    ell_segment<GRAD>(d, stage[blockIdx.y], r, n, partial + (size_t)r * pstride + (size_t)blockIdx.x * (1 + RMX_MAX_CLONES));
+    ell_segment<GRAD, MASK>(d, stage[blockIdx.y], r, n, partial + (size_t)r * pstride + (size_t)blockIdx.x * (1 + RMX_MAX_CLONES));
 }
 // grid (nreq): deterministic sum of restart rlist[j]'s partials -> out[j * nout + c], c < nout (1 = value only, 1+MAXC = value and d/dh)
 __global__ void k_ell_final_batch(Dev d, const int32_t *rlist, const int32_t *counts, const double *partial, int pstride, double *out, int nout) {
