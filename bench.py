@@ -26,13 +26,20 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8.0 TB/s spec
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8.0 TB/s spec
+FP64_PEAK_TFLOPS = 78.6    # dense FP64 rate of MI355X (vector = matrix on gfx950): 256 CUs x 4 SIMDs x 16 FMA lanes x 2.4 GHz
 # algorithmic HBM bytes per (segment,state) cell per variational update, split by kernel
 ALG_BYTES_PER_CELL = {
-    'k_framelogprob': 8.0,       # write f
-    'k_fb': 32.0,                # read f (fwd) + write alpha + read f (bwd) + write beta
-    'k_marginals<true>': 48.0,   # read alpha, beta + write posterior + the 3 indicator updates' posterior re-reads it replaces
+    'k_framelogprob': 64.0,      # read the 6 cached likelihood components, write f and exp(f - rowmax)
+    'k_fb': 32.0,                # read exp(f - rowmax) (fwd) + write alpha + read it again (bwd) + write beta
+    'k_marginals<true>': 72.0,   # read alpha, beta and the 6 cached components, write the posterior
 }
+
+
+def alg_flops_per_cell(name, S):
+    """FP64 flops per (segment, state) cell: the forward and the backward recursion are S x S
+    matrix-vector products per segment, i.e. S FMAs per cell and direction."""
+    return 4.0 * S if name == 'k_fb' else None
 
 
 def parse():
@@ -177,19 +184,30 @@ def main():
             name, (ms, n) = dom
             avg_ms = ms / max(n, 1)
             alg = ALG_BYTES_PER_CELL.get(name)
-            achieved = alg * cells_per_launch / (avg_ms * 1e-3) / 1e9
+            hbm_gbs = alg * cells_per_launch / (avg_ms * 1e-3) / 1e9
             traffic = None
-            try:   # PMC traffic of the same kernel on the same workload, measured offline (profiles/)
+            try:   # PMC traffic of the same kernel on the same launch shape, measured offline (profiles/)
                 tj = json.load(open(os.path.join(ROOT, 'profiles', 'traffic_r01.json')))
                 w = tj['workload']
                 if (w['segments'], w['states'], w['restarts']) == (args.segments, S, R // len(rs.sets)):
                     traffic = tj['kernels'][name]['hbm_bytes_per_launch']
             except Exception:
                 traffic = None
-            roof = {'bound': 'hbm', 'kernel': name, 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                    'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic, 'avg_launch_ms': avg_ms, 'launches': n,
-                    'alg_bytes_per_launch': alg * cells_per_launch,
-                    'note': 'latency/FP64-bound sequential scan, see DESIGN.md 4.4'}
+            fl = alg_flops_per_cell(name, S)
+            if fl is not None:
+                # the forward-backward recursion: S^2 FP64 FMAs per segment, direction and restart on vector
+                # v_fmac_f64 (no MFMA: matrix x vector with a sequential dependency between segments)
+                achieved = fl * cells_per_launch / (avg_ms * 1e-3) / 1e12
+                roof = {'bound': 'mfma', 'kernel': name, 'achieved': achieved, 'peak': FP64_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                        'frac': achieved / FP64_PEAK_TFLOPS, 'traffic': traffic, 'avg_launch_ms': avg_ms, 'launches': n,
+                        'alg_flops_per_launch': fl * cells_per_launch, 'alg_bytes_per_launch': alg * cells_per_launch,
+                        'hbm_gbs_at_alg_bytes': hbm_gbs,
+                        'note': 'FP64 vector FMA bound (v_fmac_f64 with DPP row broadcast), peak = dense FP64 rate; '
+                                'restart groups launch concurrently on separate streams, so avg_launch_ms includes time shared with the other group\'s kernels'}
+            else:
+                roof = {'bound': 'hbm', 'kernel': name, 'achieved': hbm_gbs, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                        'frac': hbm_gbs / HBM_PEAK_GBS, 'traffic': traffic, 'avg_launch_ms': avg_ms, 'launches': n,
+                        'alg_bytes_per_launch': alg * cells_per_launch}
         # whole variational update (all kernels of one sweep) against the 88 B/cell model
         upd = sum(prof.get(k, (0., 0))[0] for k in ('k_framelogprob', 'k_fb', 'k_marginals<true>', 'k_pairwise', 'k_brk_update',
                                                        'k_brk_lut', 'k_update_outlier_total', 'k_update_outlier_allele', 'k_update_allele_swap'))
@@ -206,7 +224,7 @@ def main():
             'seg_state_cells_per_s': cells_total * world * args.update_iters * args.steps / dt,
             'roofline': roof,
             'variational_sweep': {'device_ms_per_sweep_all_restarts': sweep_ms,
-                                  'hbm_frac_88B_per_cell': (88.0 * cells_per_launch / (sweep_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if sweep_ms else None},
+                                  'hbm_frac_168B_per_cell': (168.0 * cells_per_launch / (sweep_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if sweep_ms else None},
             'device_ms_total': total_ms,
             'kernels': dict((k, {'ms': round(v[0], 3), 'n': v[1]}) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])),
             'elbo_best': float(np.max(elbo)),

@@ -1218,19 +1218,32 @@ static int run_ell_batch(rmx_batch *b, int nreq, const int32_t *restarts, bool g
     const int W = 1 + RMX_MAX_CLONES;
     const int nout = grad ? W : 1;
     int maxcnt = 0;
-    RestartParams *hs = (RestartParams *)b->h_batch;
-    int32_t *hl = (int32_t *)((char *)b->h_batch + (size_t)b->R * sizeof(RestartParams));
+    // up to 16 requests travel in the kernel arguments and the results come back through host-pinned
+    // memory the kernel writes directly: three launches and one stream wait per round, no copy kernels
+    const bool by_value = nreq <= 16;
+    StageArgs sa;
+    RestartParams *hs = by_value ? sa.rp : (RestartParams *)b->h_batch;
+    int32_t *hl = by_value ? sa.rlist : (int32_t *)((char *)b->h_batch + (size_t)b->R * sizeof(RestartParams));
     for (int i = 0; i < nreq; i++) {
         const int r = restarts[i];
         fill_logr(b->rp[r]);
         hs[i] = b->rp[r]; hl[i] = r;
         maxcnt = std::max(maxcnt, b->sample_count[r]);
     }
+    for (int i = nreq; by_value && i < 16; i++) { hs[i] = hs[0]; hl[i] = hl[0]; }
+    double *res = by_value ? b->h_pinned : b->d_batch_out;          // host-pinned memory is device-accessible
+    uint32_t *eres = by_value ? b->h_err : nullptr;
     {
         std::lock_guard<std::mutex> lk(b->mu);
-        HIPCHK(hipMemcpyAsync(b->d_rp_stage, hs, (size_t)nreq * sizeof(RestartParams), hipMemcpyHostToDevice, b->stream));
-        HIPCHK(hipMemcpyAsync(b->d_rlist, hl, (size_t)nreq * 4, hipMemcpyHostToDevice, b->stream));
-        { ProfScope ps(b, KID_STATE_TABLES); hipLaunchKernelGGL(k_state_tables_list, dim3(d.C, nreq), dim3(256), 0, b->stream, b->d, (const int32_t *)b->d_rlist, (const RestartParams *)b->d_rp_stage); }
+        if (by_value) {
+            ProfScope ps(b, KID_STATE_TABLES);
+            hipLaunchKernelGGL(k_state_tables_list_v, dim3(d.C, nreq), dim3(256), 0, b->stream, b->d, sa, b->d_rlist, b->d_rp_stage);
+        } else {
+            HIPCHK(hipMemcpyAsync(b->d_rp_stage, hs, (size_t)nreq * sizeof(RestartParams), hipMemcpyHostToDevice, b->stream));
+            HIPCHK(hipMemcpyAsync(b->d_rlist, hl, (size_t)nreq * 4, hipMemcpyHostToDevice, b->stream));
+            ProfScope ps(b, KID_STATE_TABLES);
+            hipLaunchKernelGGL(k_state_tables_list, dim3(d.C, nreq), dim3(256), 0, b->stream, b->d, (const int32_t *)b->d_rlist, (const RestartParams *)b->d_rp_stage);
+        }
         const int pstride = std::max(d.N, ELBO_BLOCKS) * W;
         if (maxcnt > 0) {
             ProfScope ps(b, KID_ELL_LIST);
@@ -1249,13 +1262,23 @@ static int run_ell_batch(rmx_batch *b, int nreq, const int32_t *restarts, bool g
             }
         }
         { ProfScope ps(b, KID_ELL_FINAL); hipLaunchKernelGGL(k_ell_final_batch, dim3(nreq), dim3(256), 0, b->stream, b->d, (const int32_t *)b->d_rlist, (const int32_t *)b->d_counts,
-                                                             (const double *)b->d_ell_partial, pstride, b->d_batch_out, nout); }
+                                                             (const double *)b->d_ell_partial, pstride, res, nout, eres); }
         HIPCHK(hipGetLastError());
         for (int i = 0; i < nreq; i++) { b->tables_dirty[restarts[i]] = 0; b->segc_dirty[restarts[i]] = 1; b->ab_dirty[restarts[i]] = 1; }   // comp_dirty / cache_stale: set by the callers' setters
-        HIPCHK(hipMemcpyAsync(b->h_pinned, b->d_batch_out, (size_t)nreq * nout * 8, hipMemcpyDeviceToHost, b->stream));
+        if (!by_value) HIPCHK(hipMemcpyAsync(b->h_pinned, b->d_batch_out, (size_t)nreq * nout * 8, hipMemcpyDeviceToHost, b->stream));
     }
-    int rc = check_errors(b, 0, b->R);
-    if (rc) return rc;
+    if (by_value) {
+        HIPCHK(hipStreamSynchronize(b->stream));
+        for (int i = 0; i < nreq; i++) {
+            if (!eres[i]) continue;
+            const uint32_t v = eres[i];
+            HIPCHK(hipMemsetAsync(b->d.err + restarts[i], 0, sizeof(uint32_t), b->stream));
+            return translate_error(b, restarts[i], v);
+        }
+    } else {
+        int rc = check_errors(b, 0, b->R);
+        if (rc) return rc;
+    }
     for (int i = 0; i < nreq * nout; i++) out[i] = b->h_pinned[i];
     return RMX_OK;
 }

@@ -1797,6 +1797,17 @@ __global__ void k_state_tables_list(Dev d, const int32_t *rlist, const RestartPa
     if (blockIdx.x == 0 && threadIdx.x == 0) d.rp[r] = rp;
     state_tables_body(d, blockIdx.x, r, rp);
 }
+// The same with the request list and the candidate parameters passed BY VALUE in the kernel arguments
+// (<= 16 requests: 2.5 KB of the 4 KB argument segment): no host-to-device staging copies -- each one
+// is a copy kernel serialised on the stream -- in front of every evaluation round.  The list is also
+// written to the device staging buffers for the kernels that follow on the stream.
+struct StageArgs { int32_t rlist[16]; RestartParams rp[16]; };
+__global__ void k_state_tables_list_v(Dev d, StageArgs sa, int32_t *rlist_dev, RestartParams *stage_dev) {
+    const int r = sa.rlist[blockIdx.y];
+    const RestartParams rp = sa.rp[blockIdx.y];
+    if (blockIdx.x == 0 && threadIdx.x == 0) { d.rp[r] = rp; rlist_dev[blockIdx.y] = r; stage_dev[blockIdx.y] = rp; }
+    state_tables_body(d, blockIdx.x, r, rp);
+}
 // grid (maxcount, nreq): block (i, j) evaluates sampled segment i of restart rlist[j]
 template <bool GRAD, int MASK = CM_ALL>
 __global__ void k_ell_list_batch(Dev d, const int32_t *rlist, const RestartParams *stage, const int32_t *samples, const int32_t *counts,
@@ -1808,9 +1819,12 @@ __global__ void k_ell_list_batch(Dev d, const int32_t *rlist, const RestartParam
     ell_segment<GRAD, MASK>(d, stage[blockIdx.y], r, n, partial + (size_t)r * pstride + (size_t)blockIdx.x * (1 + RMX_MAX_CLONES));
 }
 // grid (nreq): deterministic sum of restart rlist[j]'s partials -> out[j * nout + c], c < nout (1 = value only, 1+MAXC = value and d/dh)
-__global__ void k_ell_final_batch(Dev d, const int32_t *rlist, const int32_t *counts, const double *partial, int pstride, double *out, int nout) {
+// err_out (optional, host-visible): the restart's error word, so that the host needs no separate copy
+__global__ void k_ell_final_batch(Dev d, const int32_t *rlist, const int32_t *counts, const double *partial, int pstride, double *out, int nout,
+                                  uint32_t *err_out) {
     __shared__ double scratch[8];
     const int r = rlist[blockIdx.x];
+    if (err_out && threadIdx.x == 0) err_out[blockIdx.x] = d.err[r];
     const int W = 1 + RMX_MAX_CLONES;
     for (int c = 0; c < nout; c++) {
         double a = 0.;
