@@ -266,15 +266,9 @@ static fb_kernel_t fb_kernel_for(int rpt) {
 }
 typedef void (*fbv_kernel_t)(FbvArgs);
 static fbv_kernel_t fbv_kernel_for(int rpt, int nv, int blk) {
-    // two or more vectors per workgroup: the lock-step kernel, or with RMX_FB_PIPELINED=1 the
-    // phase-pipelined one (same bits; measured slower so far)
-    // (the pipelined kernel's split block-boundary protocol needs blocks of at least two rows)
     (void)blk;
-    const bool lockstep = getenv("RMX_FB_PIPELINED") == nullptr;
 #define FBV_CASE(R_) \
-    if (rpt == R_) { if (nv == 1) return k_fbv<R_, 1, 768>; \
-                     if (nv == 2) return lockstep ? k_fbv<R_, 2, 768> : k_fbs<R_, 1, 768>; \
-                     return lockstep ? k_fbv<R_, 4, 768> : k_fbs<R_, 2, 768>; }
+    if (rpt == R_) { if (nv == 1) return k_fbv<R_, 1, 768>; if (nv == 2) return k_fbv<R_, 2, 768>; return k_fbv<R_, 4, 768>; }
     FBV_CASE(2) FBV_CASE(6) FBV_CASE(14) FBV_CASE(22)
 #undef FBV_CASE
     return nullptr;
@@ -935,6 +929,7 @@ static int do_update_p_cn(rmx_batch *b, int r0, int r1) {
             const int nr = r1 - r0;
             int NV = 1;
             while (NV < 4 && (long)b->n_fast * 2 * ((nr + NV - 1) / NV) > 256) NV *= 2;
+            if (const char *env = getenv("RMX_FB_NV")) { const int want = atoi(env); if (want == 1 || want == 2 || want == 4) NV = std::min(want, std::max(1, nr)); if (NV == 3) NV = 2; }
             FbvArgs v;
             v.S = d.S; v.SP = d.SP; v.M = d.M; v.D = d.D; v.C = d.C; v.N = d.N; v.NBE = d.NBE; v.cn_max = d.cn_max;
             v.r0 = r0; v.r1 = r1; v.pen = d.pen; v.pad_ = 0;

@@ -805,303 +805,6 @@ __global__ __launch_bounds__(NTMAX) void k_fbv(FbvArgs a) {
 }
 
 // =============================================================================
-// k_fbs: k_fbv with the two phases of a step software-pipelined across two half-groups of vectors.
-// Phase 2 of k_fbv (partial sums -> scale -> publish -> maximum) is a pure latency chain of LDS round
-// trips during which the FP64 pipes idle, and both barriers of a step sit on that chain.  Here the
-// NV = 2*NVH vectors of a workgroup form groups A (vectors 0..NVH-1) and B (NVH..NV-1), B half a step
-// behind A.  One barrier interval ("tick") holds phase 1 of one group and phase 2 of the other:
-//     tick 2j   : phase 1 of A at step j+1   |  phase 2 of B at step j
-//     tick 2j+1 : phase 1 of B at step j+1   |  phase 2 of A at step j+1
-// The two touch disjoint LDS regions (vec / part / red are per vector), so one barrier per tick is
-// enough.  Same arithmetic per vector as k_fbv (bit-identical results).
-// =============================================================================
-template <int RPT, int NVH, int NTMAX>
-__global__ __launch_bounds__(NTMAX) void k_fbs(FbvArgs a) {
-    constexpr int NV = 2 * NVH;
-    extern __shared__ __align__(16) unsigned char smem_raw[];
-    const int chain = a.chain_list[blockIdx.x], dir = blockIdx.z;
-    const int rg0 = a.r0 + blockIdx.y * NV;                 // first restart of this group
-    const int nv = min(NV, a.r1 - rg0);                     // vectors actually present
-    const int S = a.S, M = a.M, D = a.D, SP = a.SP, G2 = a.G2, SPW = a.SPW;
-    const int n0 = a.chain_start[chain], n1 = a.chain_end[chain], len = n1 - n0 + 1;
-    const int t = threadIdx.x, NT = blockDim.x;
-    const int p = t / G2, g = t - p * G2;
-    const int o0 = 2 * g, o1 = 2 * g + 1;
-    const bool act = p < FBV_P;                             // phase-1 worker
-    const int pv = t / SPW, po = t - pv * SPW;              // phase-2 role
-    const bool post = pv < nv && po < S;
-    const bool postwave = pv < nv;                          // wave-uniform (SPW is a multiple of 64)
-    const int lane = t & 63;
-    const int SPAD = a.SPAD;
-    const int MDP = (M * D + 1) & ~1;
-    // ---- LDS carve-up -----------------------------------------------------------------------
-    double *vec = (double *)smem_raw;                           // [NV][2][SPAD]  the vectors, double-buffered by step parity
-    double *part = vec + (size_t)NV * 2 * SPAD;                 // [NV][P][SP]    partial sums of phase 1
-    double *red = part + (size_t)NV * FBV_P * SP;               // [NV][4]: [v][0] = 1/scale of the current vector, [v][1] = scale, [v][2 + buf] = largest high dword of vec[v][buf] (u32 in the slot's low half)
-    unsigned *red32 = (unsigned *)red;
-    // breakend steps: per-vector weight table(s) of the current breakend -- with code_lds the product over
-    // the clones, indexed by the code of a state pair (PE2P doubles per vector), else one table per clone
-    const int PELW = a.code_lds ? a.PE2P : MDP;
-    double *pel = red + NV * 4;                                 // [NV][PELW]
-    double *wa = pel + (size_t)NV * PELW;                       // [128]
-    int8_t *totl = (int8_t *)(wa + 128);                        // [C][S][M]
-    int8_t *atl = totl + ((a.C * S * M + 15) & ~15);            // [S][S] (amat_lds)
-    unsigned short *codel = (unsigned short *)(atl + (a.amat_lds ? ((S * S + 15) & ~15) : 0));   // [8*RPT][SPC] (code_lds)
-    int *bel = (int *)(codel + (a.code_lds ? (size_t)FBV_P * RPT * a.SPC : 0));                   // adjacencies of this chain's breakends
-    for (int i = t; i < a.C * S * M; i += NT) totl[i] = a.tot[i];
-    if (a.amat_lds) {
-        const int8_t *src = (dir == 0 ? a.af : a.ab) + (size_t)a.chain_tc[chain] * S * S;
-        for (int i = t; i < S * S; i += NT) atl[i] = src[i];
-    }
-    if (a.code_lds) {
-        // code of the pair (row q -> column o) at a breakend adjacency of this chain and direction: the
-        // index of the clone-product weight (differences of the tumour clones' totals; the normal clone's
-        // is 0 inside a class) in the low 10 bits, the allele distance (< 64) above.  Rows / columns past S: 0.
-        const int8_t *src = (dir == 0 ? a.af : a.ab) + (size_t)a.chain_tc[chain] * S * S;
-        const int8_t *tg = a.tot + (size_t)a.chain_cls[chain] * S * M;
-        const int off_ = a.cn_max + 1, sg_ = dir == 0 ? 1 : -1;
-        for (int i = t; i < FBV_P * RPT * a.SPC; i += NT) {
-            const int q = i / a.SPC, o = i - q * a.SPC;
-            unsigned c_ = 0;
-            if (q < S && o < S) {
-                int idx = 0;
-                for (int c = 1; c < M; c++) idx = idx * D + sg_ * ((int)tg[q * M + c] - (int)tg[o * M + c]) + off_;
-                c_ = (unsigned)idx | ((unsigned)src[(size_t)q * S + o] << 10);
-            }
-            codel[i] = (unsigned short)c_;
-        }
-    }
-    const int be_lo = a.chain_be[2 * chain], be_hi = a.chain_be[2 * chain + 1];
-    for (int i = t; i < be_hi - be_lo; i += NT) bel[i] = a.be_n[be_lo + i];
-    for (int i = t; i < NV * 2 * SPAD; i += NT) vec[i] = 0.;
-    for (int i = t; i < 128; i += NT) wa[i] = exp(-a.pen * (double)i);
-    if (t < NV * 4) red[t] = 0.;
-
-    const double *Wmat = (dir == 0 ? a.Wf : a.Wb) + (size_t)a.chain_tc[chain] * S * S;
-    // ---- stationary weights: 2 columns x RPT rows, consumed before the loop --------------------
-    double w0[RPT], w1[RPT];
-#pragma unroll
-    for (int rr = 0; rr < RPT; rr++) {
-        const int q = p * RPT + rr;
-        w0[rr] = (act && q < S && o0 < S) ? Wmat[(size_t)q * S + o0] : 0.;
-        w1[rr] = (act && q < S && o1 < S) ? Wmat[(size_t)q * S + o1] : 0.;
-    }
-#pragma unroll
-    for (int rr = 0; rr < RPT; rr++) { asm volatile("" ::"v"(w0[rr])); asm volatile("" ::"v"(w1[rr])); }
-    int chain_cls_ = __builtin_amdgcn_readfirstlane(a.chain_cls[chain]);
-    asm volatile("" : "+s"(chain_cls_));
-    __syncthreads();
-
-#define ROW(k) (dir == 0 ? n0 + (k) : n1 - (k))
-    // Adjacency crossed by step k (between rows ROW(k-1) and ROW(k)): n0 + k - 1 forward, n1 - k backward.
-    // Every adjacency of such a chain has transition class chain_tc; the breakend ones are the slot
-    // interval chain_be[chain] of be_n (ascending, copied to LDS above), walked in step order, so a plain
-    // step pays one scalar compare and nothing is fetched per step.
-#define ADJ(k) (dir == 0 ? n0 + (k) - 1 : n1 - (k))
-    const int tc = a.chain_tc[chain];
-    const int be_step = dir == 0 ? 1 : -1;
-    int be_i = dir == 0 ? be_lo : be_hi - 1;                                   // slot of the next breakend step
-    int be_adj = (be_i >= be_lo && be_i < be_hi) ? __builtin_amdgcn_readfirstlane(bel[be_i - be_lo]) : -2;   // its adjacency
-    // breakend slot of step k_ (-1: plain adjacency), advancing the walk past it
-#define BE_SLOT(k_, bs_)                                                                                   \
-    int bs_ = -1;                                                                                          \
-    if (ADJ(k_) == be_adj) {                                                                               \
-        bs_ = be_i; be_i += be_step;                                                                       \
-        be_adj = (be_i >= be_lo && be_i < be_hi) ? __builtin_amdgcn_readfirstlane(bel[be_i - be_lo]) : -2; \
-    }
-    // ---- step 0 ---------------------------------------------------------------------------------
-    // The emission value a publishing lane needs in step k is one 8-byte global load (coalesced over
-    // the wave), requested a whole step ahead of its use.
-    const int rstep = dir == 0 ? SP : -SP;
-    // (lanes without a publishing role get a valid in-range address: their loads are issued too, unused)
-    const size_t lane_off = ((size_t)(rg0 + (postwave ? pv : 0)) * a.N + ROW(0)) * SP + (po < S ? po : S - 1);
-    double *outp = (dir == 0 ? a.fa : a.fb) + lane_off;
-    const double *eptr = a.fe + lane_off;
-    if (postwave) {      // wave-uniform
-        double e0 = 0.;
-        if (post) {
-            e0 = *eptr;
-            vec[(size_t)pv * 2 * SPAD + po] = e0;
-            gstore8(outp, (dir == 0) ? e0 : 1.0);
-        }
-        const unsigned wm = wave_max_u32((unsigned)__double2hiint(e0));
-        if (lane == 0) lds_max_u32(&red32[(pv * 4 + 2) * 2], wm);
-    }
-    eptr += rstep;
-    const int8_t *tcl = totl + (size_t)chain_cls_ * S * M;
-    const int sgn = dir == 0 ? 1 : -1;
-    FB_BARRIER();
-
-    // lanes 0..NVH-1 of wave 0, group X at the tick of its phase 1 of step k_: scale of the vector of
-    // step k_-1 (complete since the last barrier) and its exact reciprocal, the scale to mrow (forward),
-    // the accumulator of this step's buffer cleared
-#define FBS_SCALE(v0_, k_)                                                                                 \
-    if (t < NVH) {                                                                                         \
-        const int v_ = (v0_) + t, pb_ = ((k_) - 1) & 1;                                                    \
-        double m_, i_;                                                                                     \
-        pow2_scale(red32[(v_ * 4 + 2 + pb_) * 2], m_, i_);                                                 \
-        red[v_ * 4] = i_; red[v_ * 4 + 1] = m_;                                                            \
-        red32[(v_ * 4 + 2 + (pb_ ^ 1)) * 2] = 0u;                                                          \
-        if (dir == 0 && v_ < nv) gstore8(a.mrow + (size_t)(rg0 + v_) * a.N + ROW((k_) - 1), m_);           \
-    }
-    const int mygroup = pv / NVH;                            // phase-2 role: group of this lane's vector
-    constexpr int NVX = NVH;
-    // emission value of this lane's next phase 2 (step 1 first), always requested a whole step ahead
-    double e_cur = 0.;
-    if (len > 1) gload8(e_cur, eptr);
-    eptr += rstep;
-
-    // one tick: phase 1 of group X at step kX if doP1 (bs / tc: that step's breakend slot and transition
-    // class), phase 2 of the other group at step kY if doP2
-    auto tick = [&](const int X, const bool doP1, const int kX, const int bs, const int tc, const bool doP2, const int kY) __attribute__((always_inline)) {
-        const int vX = X * NVH;
-        const bool myP2 = doP2 && postwave && mygroup == (X ^ 1);        // wave-uniform
-        // ---- phase 2 of the other group: every operand is final since the last barrier.  The waves that
-        // own it run it first (a chain of LDS round trips); the FP64 pipes are kept busy meanwhile by the
-        // waves that have no phase-2 role in this tick and go straight to the FMAs below ----
-        if (myP2) {
-            outp += rstep;
-            unsigned vmax_in = 0u;
-            gwait8(e_cur);        // requested a whole step ago, like this wave's previous result store
-            const double e_use = e_cur;
-            if (kY + 1 < len) gload8(e_cur, eptr);      // for this lane's next phase 2
-            eptr += rstep;
-            if (post) {
-                const double *pp_ = part + (size_t)pv * FBV_P * SP + po;
-                const double s0 = pp_[0], s1 = pp_[SP], s2 = pp_[2 * SP], s3 = pp_[3 * SP];
-                const double s4 = pp_[4 * SP], s5 = pp_[5 * SP], s6 = pp_[6 * SP], s7 = pp_[7 * SP];
-                const double inv = red[pv * 4];
-                const double sum = ((((((s0 + s1) + s2) + s3) + s4) + s5) + s6) + s7;
-                const double val = sum * inv;
-                const double vecv = val * e_use;
-                vec[((size_t)pv * 2 + (kY & 1)) * SPAD + po] = vecv;
-                gstore8(outp, (dir == 0) ? vecv : val);
-                vmax_in = (unsigned)__double2hiint(vecv);
-            }
-            const unsigned wm = wave_max_u32(vmax_in);
-            if (lane == 0) lds_max_u32(&red32[(pv * 4 + 2 + (kY & 1)) * 2], wm);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        // ---- phase 1 of group X ----
-        double acc0[NVH], acc1[NVH];
-#pragma unroll
-        for (int v = 0; v < NVH; v++) { acc0[v] = 0.; acc1[v] = 0.; }
-        if (doP1) {
-            FBS_SCALE(vX, kX)
-            const int cb = (kX - 1) & 1;       // buffer holding the vectors of step kX-1
-            if (bs < 0) {
-                if (act) {      // wave-uniform: 8*G2 is a multiple of 128
-                    constexpr int NA = (RPT + 15) / 16;
-                    double av[NVH][NA];
-                    const double *vb0 = vec + ((size_t)vX * 2 + cb) * SPAD + p * RPT + (lane & 15);
-#pragma unroll
-                    for (int v = 0; v < NVH; v++)
-#pragma unroll
-                        for (int h = 0; h < NA; h++) av[v][h] = vb0[(size_t)v * 2 * SPAD + 16 * h];
-                    fbv_row_fma<RPT, NVH, NA, 0>(av, w0, w1, acc0, acc1);
-                }
-            } else {
-                // ---- breakend adjacency: restart-specific weights prod_m pe_m[d_m] * exp(-pen*a) ----
-                if (a.code_lds) {
-                    // fast path: the clone product comes as one table per vector (k_brk_lut), the pair's table index
-                    // and allele distance as one 16-bit code from LDS; the vector operand is broadcast inside the DPP
-                    // row exactly as on a plain step
-                    if (t < (a.PE2P + 1) / 2) {          // (waves 0..2 at most: wave-granular s_waitcnt below)
-                        for (int v = 0; v < NVX; v++) {
-                            const unsigned dpe = __builtin_amdgcn_readfirstlane(lds_addr(pel + (size_t)(vX + v) * PELW) + (unsigned)(((t >> 6) << 6) * 16));
-                            if (vX + v < nv && t * 2 < a.PE2P) glds16(a.pe2_lt + ((size_t)(rg0 + vX + v) * a.NBE + bs) * a.PE2P + t * 2, dpe);
-                        }
-                    }
-                    if (t < 256) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    FB_BARRIER();
-                    if (act) {
-                        constexpr int NA = (RPT + 15) / 16;
-                        double av[NVX][NA];
-                        const double *vb0 = vec + ((size_t)vX * 2 + cb) * SPAD + p * RPT + (lane & 15);
-#pragma unroll
-                        for (int v = 0; v < NVX; v++)
-#pragma unroll
-                            for (int h = 0; h < NA; h++) av[v][h] = vb0[(size_t)v * 2 * SPAD + 16 * h];
-                        const unsigned short *crow = codel + (size_t)(p * RPT) * a.SPC + (o0 < a.SPC ? o0 : a.SPC - 2);
-                        fbv_row_fma_be<RPT, NVX, NA, 0>(av, crow, a.SPC, wa, pel + (size_t)vX * PELW, PELW, acc0, acc1);
-                    }
-                } else {
-                    if (t < 64) {
-                        for (int v = 0; v < NVX; v++) {
-                            const unsigned dpe = __builtin_amdgcn_readfirstlane(lds_addr(pel + (size_t)(vX + v) * MDP));
-                            if (vX + v < nv && t * 2 < MDP) glds16(a.pe_lt + ((size_t)(rg0 + vX + v) * a.NBE + bs) * MDP + t * 2, dpe);
-                        }
-                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    }
-                    FB_BARRIER();
-                    const int8_t *at = a.amat_lds ? atl : ((dir == 0 ? a.af : a.ab) + (size_t)tc * S * S);
-                    if (act) {
-                        for (int rr = 0; rr < RPT; rr++) {
-                            const int q = p * RPT + rr;
-                            if (q >= S) break;
-#pragma unroll
-                            for (int col = 0; col < 2; col++) {
-                                const int o = col == 0 ? o0 : o1;
-                                if (o < S) {
-                                    const double wbase = wa[(int)at[(size_t)q * S + o]];
-                                    int dd[RMX_MAX_CLONES];
-#pragma unroll
-                                    for (int c = 0; c < RMX_MAX_CLONES; c++) dd[c] = c < M ? sgn * ((int)tcl[(size_t)q * M + c] - (int)tcl[(size_t)o * M + c]) + a.cn_max + 1 : 0;
-#pragma unroll
-                                    for (int v = 0; v < NVX; v++) {
-                                        if (vX + v < nv) {
-                                            double wv = wbase;
-#pragma unroll
-                                            for (int c = 0; c < RMX_MAX_CLONES; c++) if (c < M) wv *= pel[(size_t)(vX + v) * MDP + c * D + dd[c]];
-                                            const double x = vec[((size_t)(vX + v) * 2 + cb) * SPAD + q];
-                                            if (col == 0) acc0[v] = fma(x, wv, acc0[v]); else acc1[v] = fma(x, wv, acc1[v]);
-                                        }
-                                    }
-                                }
-                            }
-                        }
-                    }
-                }
-            }
-            // ---- hand the partial sums of group X over ----
-            if (act && o0 < SP) {
-#pragma unroll
-                for (int v = 0; v < NVH; v++) {
-                    double2 pr; pr.x = acc0[v]; pr.y = acc1[v];
-                    *reinterpret_cast<double2 *>(part + ((size_t)(vX + v) * FBV_P + p) * SP + o0) = pr;
-                }
-            }
-        }
-    };
-
-    if (a.dbg && t == 0 && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0) { a.dbg[0] = clock64(); a.dbg[1] = wall_clock64(); a.dbg[4] = len; }
-    for (int j = 0; j < len; j++) {
-        const bool more = j + 1 < len;
-        BE_SLOT(j + 1, bs)                                // step j+1 (ADJ(len) is past the chain and never matches)
-        // even tick: phase 1 of A at step j+1, phase 2 of B at step j
-        tick(0, more, j + 1, bs, tc, j >= 1, j);
-        FB_BARRIER();
-        if (!more) break;
-        // odd tick: phase 1 of B at step j+1, phase 2 of A at step j+1
-        tick(1, true, j + 1, bs, tc, true, j + 1);
-        FB_BARRIER();
-    }
-    if (a.dbg && t == 0 && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0) { a.dbg[2] = clock64(); a.dbg[3] = wall_clock64(); }
-    // last row of each chain: its scale is not consumed by a later step, but hmm_log_norm_const and
-    // the vanishing-row check need it
-    if (t < NV) {
-        double m, i_;
-        pow2_scale(red32[(t * 4 + 2 + ((len - 1) & 1)) * 2], m, i_);
-        if (dir == 0 && t < nv) gstore8(a.mrow + (size_t)(rg0 + t) * a.N + ROW(len - 1), m);
-        if (t < nv && (!(m > 0.) || m == INFINITY)) atomicOr(&a.err[rg0 + t], RMX_ERR_NAN_AB);
-    }
-#undef FBS_SCALE
-#undef ROW
-#undef ADJ
-#undef BE_SLOT
-}
-
-// =============================================================================
 // posterior marginals + per-segment likelihood expectations
 //   post[n,s]  = softmax(alpha+beta) (bpmodel.pyx:948-950) == fa*fb / sum
 //   A[n,u]     = sum_s post * LT_u          B[n,vw] = sum_s post * LA_vw
