@@ -351,6 +351,7 @@ typedef void (*cells_kernel_t)(Dev, int);
 template <int NS> static cells_kernel_t cells_kernel_ns(int mode, int mask, int cache) {
     if (mode == 0) return cache == 2 ? k_cells<NS, 0, CM_ALL, 2> : (cache == 1 ? k_cells<NS, 0, CM_ALL, 1> : k_cells<NS, 0, CM_ALL, 0>);
     if (mode == 1) return cache == 2 ? k_cells<NS, 1, CM_ALL, 2> : k_cells<NS, 1, CM_ALL, 0>;
+    if (mode == 3) return k_cells<NS, 3, CM_ALL, 2>;
     if (cache == 2) return k_cells<NS, 2, 31, 2>;
     if (cache == 1) {
         switch (mask) {
@@ -906,8 +907,11 @@ static int do_framelogprob(rmx_batch *b, int r0, int r1) {
     HIPCHK(hipGetLastError());
     return RMX_OK;
 }
-static int do_update_p_cn(rmx_batch *b, int r0, int r1) {
-    int rc = do_framelogprob(b, r0, r1);
+// skip_frame: the frame log-probabilities of this sweep were already written by the fused pass of the
+// previous sweep; fuse_next: the marginal pass also does the outlier / allele-swap updates and the next
+// sweep's frame pass (k_cells MODE 3)
+static int do_update_p_cn(rmx_batch *b, int r0, int r1, bool skip_frame = false, bool fuse_next = false) {
+    int rc = skip_frame ? ensure_tables(b, r0, r1) : do_framelogprob(b, r0, r1);
     if (rc) return rc;
     // log_transmat snapshot := T(current p_breakpoint)   (bpmodel.pyx:939)
     if ((rc = launch_brk_lut(b, r0, r1, b->d.pd_lt, b->d.pe_lt))) return rc;
@@ -982,15 +986,18 @@ static int do_update_p_cn(rmx_batch *b, int r0, int r1) {
         }
         HIPCHK(hipGetLastError());
     }
+    for (int r = r0; r < r1; r++) { if (!b->lt_valid[r]) { b->lt_valid[r] = 1; int one = 1; HIPCHK(hipMemcpyAsync(b->d_lt_valid + r, &one, 4, hipMemcpyHostToDevice, b->stream)); } }
+    // pairwise reductions at breakend adjacencies (feeds update_p_breakpoint and the ELBO): they read this
+    // sweep's fa / fb / fe, so they run before a fused marginal pass overwrites fe with the next sweep's
+    if ((rc = launch_pairwise_breakends(b, r0, r1, 0))) return rc;
     {
         ProfScope ps(b, KID_MARGINALS);
-        if (use_strip(b)) hipLaunchKernelGGL(cells_kernel(b, 1, CM_ALL, b->use_cache ? 2 : 0), strip_grid(b, r1 - r0), dim3(256), 0, b->stream, b->d, r0);   // the F pass just made the cache current
+        if (use_strip(b)) hipLaunchKernelGGL(cells_kernel(b, fuse_next ? 3 : 1, CM_ALL, b->use_cache ? 2 : 0), strip_grid(b, r1 - r0), dim3(256), 0, b->stream, b->d, r0);   // the F pass made the cache current
         else hipLaunchKernelGGL(k_marginals<true>, row_grid(b, r1 - r0), dim3(256), 0, b->stream, b->d, r0, b->G);
         HIPCHK(hipGetLastError());
     }
-    for (int r = r0; r < r1; r++) { b->ab_dirty[r] = 0; b->comp_dirty[r] = 0; b->logz_dirty[r] = 1; if (!b->lt_valid[r]) { b->lt_valid[r] = 1; int one = 1; HIPCHK(hipMemcpyAsync(b->d_lt_valid + r, &one, 4, hipMemcpyHostToDevice, b->stream)); } }
-    // pairwise reductions at breakend adjacencies (feeds update_p_breakpoint and the ELBO)
-    return launch_pairwise_breakends(b, r0, r1, 0);
+    for (int r = r0; r < r1; r++) { b->ab_dirty[r] = 0; b->comp_dirty[r] = 0; b->logz_dirty[r] = 1; }
+    return RMX_OK;
 }
 static int do_update_p_breakpoint(rmx_batch *b, int r0, int r1) {
     const Dev &d = b->d;
@@ -1026,10 +1033,16 @@ int rmx_update_p_allele_swap(rmx_batch *b, int32_t r0, int32_t r1) { RANGE_CHECK
 
 int rmx_variational_update(rmx_batch *b, int32_t r0, int32_t r1, int32_t iters) {
     RANGE_CHECK();
+    // Between two sweeps of this call everything from the marginals of sweep i to the frame
+    // log-probabilities of sweep i+1 is local to a segment: one fused pass (k_cells MODE 3) instead of
+    // marginals + update_p_outlier_total + update_p_outlier_allele + update_p_allele_swap + frame pass.
+    const bool fusable = use_strip(b) && b->use_cache && !getenv("RMX_NO_FUSE");
     for (int it = 0; it < iters; it++) {
         int rc;
-        if ((rc = do_indicator(b, r0, r1, 2)) || (rc = do_update_p_cn(b, r0, r1)) || (rc = do_update_p_breakpoint(b, r0, r1)) ||
-            (rc = do_indicator(b, r0, r1, 0)) || (rc = do_indicator(b, r0, r1, 1))) return rc;
+        const bool fused_in = fusable && it > 0, fuse_out = fusable && it + 1 < iters;
+        if (!fused_in && (rc = do_indicator(b, r0, r1, 2))) return rc;
+        if ((rc = do_update_p_cn(b, r0, r1, fused_in, fuse_out)) || (rc = do_update_p_breakpoint(b, r0, r1))) return rc;
+        if (!fuse_out && ((rc = do_indicator(b, r0, r1, 0)) || (rc = do_indicator(b, r0, r1, 1)))) return rc;
     }
     return check_errors(b, r0, r1);
 }

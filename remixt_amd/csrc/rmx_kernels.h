@@ -870,6 +870,10 @@ __global__ void k_marginals(Dev d, int r0, int G) {
 //   MODE 0: update_framelogprob (+ row maximum, scaled emissions)          -- k_framelogprob
 //   MODE 1: posterior marginals + (A, B, PF, PP, row share of log Z)        -- k_marginals<true>
 //   MODE 2: refresh of the components of (A, B) selected by MASK            -- k_marginals<false>
+//   MODE 3: MODE 1, then -- everything below is local to the segment -- update_p_outlier_total,
+//           update_p_outlier_allele, the NEXT sweep's update_p_allele_swap and update_framelogprob from
+//           the cell values already in registers (CACHE 2 only): between two sweeps of one
+//           rmx_variational_update call the six cached planes are streamed once instead of twice
 // grid (ceil(N / (4*RPW)), nr), block 256.
 // =============================================================================
 #define STRIP_RPW 8
@@ -909,6 +913,11 @@ __global__ __launch_bounds__(256) void k_cells(Dev d, int r0) {
             }
         }
     };
+    double lp_prior[4] = {0., 0., 0., 0.};
+    if (MODE == 3) {
+        const double pt_ = rp.p[RMX_P_PRIOR_OUTLIER_TOTAL], pa_ = rp.p[RMX_P_PRIOR_OUTLIER_ALLELE];
+        lp_prior[0] = log(1. - pt_); lp_prior[1] = log(pt_); lp_prior[2] = log(1. - pa_); lp_prior[3] = log(pa_);
+    }
     for (int n = nbeg; n < nend; n++) {     // n is wave-uniform (SGPR)
         const int cls = d.seg_class[n];
         if (CACHE != 2 && cls != cur_cls) {
@@ -947,9 +956,11 @@ __global__ __launch_bounds__(256) void k_cells(Dev d, int r0) {
 #pragma unroll
             for (int k = 0; k < NS; k++) { const int s = lane + 64 * k; if (s < d.SP) d.fe[ro + s] = s < S ? exp(fv[k] - vmax) : 0.; }
         } else {
+            constexpr bool M1 = MODE == 1 || MODE == 3;
             double pv[NS];
+            double L6[MODE == 3 ? NS : 1][6];
             double sum = 0.;
-            if (MODE == 1) {
+            if (M1) {
 #pragma unroll
                 for (int k = 0; k < NS; k++) { const int s = lane + 64 * k; pv[k] = s < S ? d.fa[ro + s] * d.fb[ro + s] : 0.; sum += pv[k]; }
                 sum = group_sum(sum, 64);
@@ -972,9 +983,10 @@ __global__ __launch_bounds__(256) void k_cells(Dev d, int r0) {
                     double LT[2], LA[4];
                     cell(sc, st[k], (size_t)n * d.SP + s, LT, LA);
                     const double ps = pv[k];
+                    if (MODE == 3) { L6[k][0] = LT[0]; L6[k][1] = LT[1]; L6[k][2] = LA[0]; L6[k][3] = LA[1]; L6[k][4] = LA[2]; L6[k][5] = LA[3]; }
                     a0 += ps * LT[0]; a1 += ps * LT[1];
                     b0 += ps * LA[0]; b1 += ps * LA[1]; b2 += ps * LA[2]; b3 += ps * LA[3];
-                    if (MODE == 1 || (MASK & 16)) { pf += ps * d.f[ro + s]; pp += ps * (-1.0 * (CACHE == 2 ? nsub_of(cls, s) : st[k].nsub) * sc.l * divw); }
+                    if (M1 || (MASK & 16)) { pf += ps * d.f[ro + s]; pp += ps * (-1.0 * (CACHE == 2 ? nsub_of(cls, s) : st[k].nsub) * sc.l * divw); }
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -982,11 +994,79 @@ __global__ __launch_bounds__(256) void k_cells(Dev d, int r0) {
             if (MASK & CM_LT1) { a1 = group_sum(a1, 64); if (lane == 0) d.A[rn * 2 + 1] = a1; }
             if (MASK & CM_LA0) { b0 = group_sum(b0, 64); b1 = group_sum(b1, 64); if (lane == 0) { d.Bv[rn * 4] = b0; d.Bv[rn * 4 + 1] = b1; } }
             if (MASK & CM_LA1) { b2 = group_sum(b2, 64); b3 = group_sum(b3, 64); if (lane == 0) { d.Bv[rn * 4 + 2] = b2; d.Bv[rn * 4 + 3] = b3; } }
-            if (MODE == 1 || (MASK & 16)) {
+            if (M1 || (MASK & 16)) {
                 pf = group_sum(pf, 64); pp = group_sum(pp, 64);
                 if (lane == 0) { d.rowPF[rn] = pf; d.rowPP[rn] = pp; }
             }
-            if (MODE == 1 && lane == 0) d.rowZ[rn] = d.fmax[rn] + (d.chain_end_flag[n] ? log(sum) : log(d.mrow[rn]));
+            if (M1 && lane == 0) d.rowZ[rn] = d.fmax[rn] + (d.chain_end_flag[n] ? log(sum) : log(d.mrow[rn]));
+            if (MODE == 3) {
+                // lane 0's sums are the ones the stand-alone kernels would read back from (A, B)
+                auto b0_ = [](double v) { return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v))); };
+                a0 = b0_(a0); a1 = b0_(a1); b0 = b0_(b0); b1 = b0_(b1); b2 = b0_(b2); b3 = b0_(b3);
+                // The three updates are two-element _exp_normalize's (bpmodel.pyx:120-128): exp, exp, log, exp,
+                // exp each.  Evaluated one after the other in every lane they would be a serial chain of ~15
+                // transcendentals per segment; here independent evaluations sit in different lanes of ONE
+                // call (lanes 0,1: outlier-total, lanes 2,3: outlier-allele) and are gathered with
+                // v_readlane -- same functions on the same arguments, hence the same bits.
+                auto lane_of = [&](double v, int l_) { return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l_), __builtin_amdgcn_readlane(__double2loint(v), l_)); };
+                // update_p_outlier_total (bpmodel.pyx:987-1003)
+                double lpt0 = lp_prior[0], lpt1 = lp_prior[1];
+                lpt0 += a0; lpt1 += a1;
+                // update_p_outlier_allele (:1005-1023), with this sweep's allele-swap indicator
+                const double qs0o = d.qs[rn * 2], qs1o = d.qs[rn * 2 + 1];
+                double lpa0 = lp_prior[2], lpa1 = lp_prior[3];
+                lpa0 += qs0o * b0; lpa0 += qs1o * b1;
+                lpa1 += qs0o * b2; lpa1 += qs1o * b3;
+                const double vmt = lpt0 > lpt1 ? lpt0 : lpt1, vma = lpa0 > lpa1 ? lpa0 : lpa1;       // _max: strict > from -inf
+                const double lp_l = lane == 0 ? lpt0 : (lane == 1 ? lpt1 : (lane == 2 ? lpa0 : lpa1));
+                const double vm_l = lane < 2 ? vmt : vma;
+                const double ex = exp(lp_l - vm_l);
+                double pst = 0.; pst += lane_of(ex, 0); pst += lane_of(ex, 1);
+                double psa = 0.; psa += lane_of(ex, 2); psa += lane_of(ex, 3);
+                const double lg = log(lane < 2 ? pst : psa);
+                const double norm_l = lg + vm_l;
+                const double y_l = exp(lp_l - norm_l);
+                double qt0 = lane_of(y_l, 0), qt1 = lane_of(y_l, 1), qa0 = lane_of(y_l, 2), qa1 = lane_of(y_l, 3);
+                { const double st_ = qt0 + qt1; qt0 /= st_; qt1 /= st_; const double sa_ = qa0 + qa1; qa0 /= sa_; qa1 /= sa_; }
+                // the next sweep's update_p_allele_swap (:1025-1042)
+                double lps0 = 0., lps1 = 0.;
+                lps0 += qa0 * b0; lps1 += qa0 * b1;
+                lps0 += qa1 * b2; lps1 += qa1 * b3;
+                const double vms = lps0 > lps1 ? lps0 : lps1;
+                const double lps_l = (lane & 1) ? lps1 : lps0;
+                const double exs = exp(lps_l - vms);
+                double pss = 0.; pss += lane_of(exs, 0); pss += lane_of(exs, 1);
+                const double norms = log(pss) + vms;
+                const double ys_l = exp(lps_l - norms);
+                double qs0 = lane_of(ys_l, 0), qs1 = lane_of(ys_l, 1);
+                { const double ss_ = qs0 + qs1; qs0 /= ss_; qs1 /= ss_; }
+                if (lane == 0) {
+                    d.qt[rn * 2] = qt0; d.qt[rn * 2 + 1] = qt1; d.qa[rn * 2] = qa0; d.qa[rn * 2 + 1] = qa1;
+                    d.qs[rn * 2] = qs0; d.qs[rn * 2 + 1] = qs1;
+                }
+                // the next sweep's update_framelogprob (:898-919) -- MODE 0 on the values in registers
+                double fv[NS];
+                double vmax = -INFINITY;
+#pragma unroll
+                for (int k = 0; k < NS; k++) {
+                    const int s = lane + 64 * k;
+                    fv[k] = -INFINITY;
+                    if (s < S) {
+                        double f = 0.;
+                        f += qt0 * L6[k][0]; f += qt1 * L6[k][1];
+                        f += qa0 * qs0 * L6[k][2]; f += qa0 * qs1 * L6[k][3]; f += qa1 * qs0 * L6[k][4]; f += qa1 * qs1 * L6[k][5];
+                        f += -1.0 * nsub_of(cls, s) * sc.l * divw;
+                        if (f != f) err |= RMX_ERR_NAN_F;
+                        d.f[ro + s] = f;
+                        fv[k] = f;
+                        vmax = fmax(vmax, f);
+                    }
+                }
+                vmax = group_max(vmax, 64);
+                if (lane == 0) d.fmax[rn] = vmax;
+#pragma unroll
+                for (int k = 0; k < NS; k++) { const int s = lane + 64 * k; if (s < d.SP) d.fe[ro + s] = s < S ? exp(fv[k] - vmax) : 0.; }
+            }
         }
     }
     if (err) atomicOr(&d.err[r], err);

@@ -186,6 +186,35 @@ def test_fb_register_and_generic_paths_agree(hip):
     assert np.array_equal(outs[0][3], outs[2][3])
 
 
+def test_fused_sweeps_equal_separate_updates(hip):
+    """rmx_variational_update fuses marginals + outlier / allele-swap updates + the next sweep's frame
+    pass into one kernel between sweeps; the result must equal the separate coordinate updates bit
+    for bit (S = 165: strip kernels with the cell cache)."""
+    import os
+    from remixt_amd import synthetic
+    from remixt_amd.restarts import RestartSet
+    e = synthetic.make_experiment(700, num_clones=3, max_copy_number=8, num_chains=4, seed=11)
+    ps = synthetic.make_init_params(e, 3, 8)
+    outs = []
+    for fuse in (True, False):
+        if fuse:
+            os.environ.pop('RMX_NO_FUSE', None)
+        else:
+            os.environ['RMX_NO_FUSE'] = '1'
+        rs = RestartSet(e, ps, max_copy_number=8, num_clones=3, quiet=True)
+        assert rs.batch.num_cn_states == 165
+        rs.batch.variational_update(3)
+        el = rs.batch.calculate_elbo()
+        outs.append((el, [rs.batch.get_array(r, 'posterior_marginals') for r in range(3)],
+                     [rs.batch.get_array(r, 'p_outlier_total') for r in range(3)], [rs.batch.get_array(r, 'p_outlier_allele') for r in range(3)],
+                     [rs.batch.get_array(r, 'p_allele_swap') for r in range(3)], [rs.batch.get_array(r, 'p_breakpoint') for r in range(3)]))
+    os.environ.pop('RMX_NO_FUSE', None)
+    assert np.array_equal(outs[0][0], outs[1][0])
+    for k in range(1, 6):
+        for x, y in zip(outs[0][k], outs[1][k]):
+            assert np.array_equal(x, y), k
+
+
 def test_lockstep_mstep_equals_per_restart_mstep(hip):
     """The batched lock-step parameter search gives every restart exactly what its own sequential
     brute + fmin search gives (same evaluation sequence per restart)."""
