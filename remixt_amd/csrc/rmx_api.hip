@@ -85,6 +85,8 @@ struct rmx_batch {
     std::vector<void *> allocs;
     // profiling
     int pe2p = 0;     // padded row length of pe2_lt (0: no product table)
+    int spc = 0;      // row stride of the pair-code table
+    bool pcode_ok = false;
     int max_adist = 0; // largest allele distance in af / ab
     int be_cap = 4;   // LDS ints for a chain's breakend adjacency list (largest chain + pad)
     int prof = 0;     // 0 off, 1 all kernels, 2 variational-sweep kernels only
@@ -228,6 +230,49 @@ static int build_transitions(rmx_batch *b) {
                 tsum += T;
             }
         b->Tsum[tc] = tsum;
+    }
+    // pair codes + column order for k_pairwise_be2 (M in {2, 3}; index < 1024, allele distance < 64)
+    b->pcode_ok = false;
+    if (TC > 0 && b->d.pcode && (M == 2 || M == 3) && b->max_adist < 64 && (M == 2 ? b->d.D : b->d.D * b->d.D) <= 1024) {
+        const int C = b->d.C, D = b->d.D, off = b->d.cn_max + 1, SPC = b->spc;
+        auto tot_of = [&](int cls, int s_, int c) { const int64_t *t_ = b->cn_classes.data() + ((size_t)cls * S + s_) * M * 2 + (size_t)c * 2; return (int)(t_[0] + t_[1]); };
+        std::vector<int32_t> jord((size_t)C * S), jmeta((size_t)C * S);
+        for (int cls = 0; cls < C; cls++) {
+            std::vector<int> ord(S);
+            for (int j = 0; j < S; j++) ord[j] = j;
+            std::stable_sort(ord.begin(), ord.end(), [&](int x, int y) {
+                const int x1 = tot_of(cls, x, 1), y1 = tot_of(cls, y, 1);
+                if (x1 != y1) return x1 < y1;
+                return M == 3 && tot_of(cls, x, 2) < tot_of(cls, y, 2);
+            });
+            for (int jj = 0; jj < S; jj++) {
+                const int j = ord[jj], t1 = tot_of(cls, j, 1), t2 = M == 3 ? tot_of(cls, j, 2) : 0;
+                const bool last = jj + 1 == S;
+                const int n1 = last ? -1 : tot_of(cls, ord[jj + 1], 1), n2 = last || M < 3 ? -1 : tot_of(cls, ord[jj + 1], 2);
+                int fl = 0;
+                if (last || n1 != t1 || (M == 3 && n2 != t2)) fl |= 1;
+                if (last || n1 != t1) fl |= 2;
+                jord[(size_t)cls * S + jj] = j;
+                jmeta[(size_t)cls * S + jj] = t1 | (t2 << 8) | (fl << 16);
+            }
+        }
+        const int S8 = (S + 7) & ~7;
+        std::vector<uint16_t> pcode((size_t)TC * S8 * SPC, 0);
+        for (int tc = 0; tc < TC; tc++) {
+            const int ca = b->tc_pairs[tc].first, cb = b->tc_pairs[tc].second;
+            for (int jj = 0; jj < S; jj++) {
+                const int j = jord[(size_t)cb * S + jj];
+                for (int i = 0; i < S; i++) {
+                    int idx = 0;
+                    for (int c = 1; c < M; c++) idx = idx * D + (tot_of(ca, i, c) - tot_of(cb, j, c) + off);
+                    pcode[((size_t)tc * S8 + jj) * SPC + i] = (uint16_t)(idx | ((int)af[tc * SS + (size_t)i * S + j] << 10));
+                }
+            }
+        }
+        HIPCHK(hipMemcpy((void *)b->d.pcode, pcode.data(), pcode.size() * 2, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy((void *)b->d.jord, jord.data(), jord.size() * 4, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy((void *)b->d.jmeta, jmeta.data(), jmeta.size() * 4, hipMemcpyHostToDevice));
+        b->pcode_ok = true;
     }
     if (TC > 0) {
         HIPCHK(hipMemcpy((void *)b->d.Tval, Tval.data(), Tval.size() * 8, hipMemcpyHostToDevice));
@@ -429,7 +474,11 @@ static int launch_pairwise_breakends(rmx_batch *b, int r0, int r1, int mode) {
     const Dev &d = b->d;
     const int nt = ((d.S + 63) / 64) * 64;
     const size_t lds = ((size_t)((d.S + 1) & ~1) + ((d.M * d.D + 1) & ~1) + 128 + (size_t)nt * d.M * (d.cn_max + 2)) * 8 + (size_t)d.S * 4 + 64;
-    if (mode == 0 && lds <= 150 * 1024 && !getenv("RMX_PAIRWISE_OLD")) {
+    const size_t lds2 = ((size_t)((d.S + 7) & ~7) + b->pe2p + 128 + (size_t)nt * (d.M - 1) * (d.cn_max + 2) + nt) * 8 + (size_t)((d.S + 7) & ~7) * 4 + 64;
+    if (mode == 0 && b->pcode_ok && lds2 <= 150 * 1024 && !getenv("RMX_PAIRWISE_OLD") && !getenv("RMX_PAIRWISE_V1")) {
+        HIPCHK(hipFuncSetAttribute((const void *)k_pairwise_be2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
+        hipLaunchKernelGGL(k_pairwise_be2, dim3(d.NBE, r1 - r0), dim3(nt), lds2, b->stream, b->d, r0, b->pe2p, b->spc);
+    } else if (mode == 0 && lds <= 150 * 1024 && !getenv("RMX_PAIRWISE_OLD")) {
         HIPCHK(hipFuncSetAttribute((const void *)k_pairwise_be, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(k_pairwise_be, dim3(d.NBE, r1 - r0), dim3(nt), lds, b->stream, b->d, r0);
     } else {
@@ -618,7 +667,9 @@ int rmx_batch_create(const rmx_problem *pr, int32_t R, const double *h_init, con
         int n2 = M == 2 ? d.D : d.D * d.D;
         b->pe2p = (n2 + 1) & ~1;
         DA(pe2_lt, double, (size_t)R * d.NBE * b->pe2p + 2)
-    }
+        b->spc = ((S + 63) / 64) * 64;
+        DA(pcode, uint16_t, (size_t)std::max(d.TC, 1) * ((S + 7) & ~7) * b->spc) DA(jord, int32_t, (size_t)C * S) DA(jmeta, int32_t, (size_t)C * S)
+    } else { d.pcode = nullptr; d.jord = nullptr; d.jmeta = nullptr; }
     DA(pd_cached, double, BEW) DA(hist, double, BEW) DA(be_jt, double, (size_t)R * d.NBE) DA(be_ja, double, (size_t)R * d.NBE)
     DA(err, uint32_t, R)
 #undef DA

@@ -65,6 +65,8 @@ struct Dev {
     const int32_t *bk_ptr, *bk_slots;    // CSR breakpoint -> slots (ascending n)
     const double *Tval, *Wf, *Wb;        // [TC][S][S]: log T (reference order), exp(T) (q=i,o=j), exp(T)^T
     const int8_t *af, *ab;               // [TC][S][S] allele-flip term (q=i,o=j) and its transpose
+    const uint16_t *pcode;               // [TC][S][SPC] pair codes for k_pairwise_be2, columns in jord order: (index into pe2_lt) | allele distance << 10; or null
+    const int32_t *jord, *jmeta;         // [C][S] columns sorted by the tumour clones' totals; totals t1 | t2 << 8 | run-end flags << 16
     // ---- per restart ----------------------------------------------------------
     RestartParams *rp;                   // [R]
     double *stD, *stP, *stM, *stLg;      // [R][C][SP]; stM [R][C][2][SP]; stLg [R][C][4][SP]

@@ -1137,11 +1137,12 @@ __global__ void k_brk_lut(Dev d, int r0, double *dst_base, double *exp_base, dou
     }
     if (exp_base && prod_base && d.D <= 64) {
         // product over the clones for the forward-backward kernels' breakend steps (M <= 3): entry
-        // (d_1 [, d_2]) = pe_0[0 difference] * pe_1[d_1] [* pe_2[d_2]]; the normal clone's totals agree
-        // inside a state-table class
+        // (d_1 [, d_2]) = pe_0[normal-clone difference of the two classes] * pe_1[d_1] [* pe_2[d_2]]
         __syncthreads();
         double *pr = prod_base + ((size_t)r * d.NBE + slot) * PE2P;
-        const double p0 = pes[d.cn_max + 1];
+        // (normal clone: every state of a class has the same total, so its difference is a property of the adjacency)
+        const int d0 = (int)d.tot[(size_t)d.be_cls[2 * slot] * d.S * d.M] - (int)d.tot[(size_t)d.be_cls[2 * slot + 1] * d.S * d.M];
+        const double p0 = pes[d0 + d.cn_max + 1];
         const int n2 = d.M == 2 ? d.D : d.D * d.D;
         for (int i = threadIdx.x; i < PE2P; i += blockDim.x) {
             double v = 0.;
@@ -1313,6 +1314,115 @@ __global__ void k_pairwise_be(Dev d, int r0) {
         for (int row = 0; row < S; row++) {
             const int tj = (int)d.tot[((size_t)ca * S + row) * M + c] - dv;
             if (tj >= 0 && tj < NB) acc += bins[((size_t)row * M + c) * NB + tj];
+        }
+        hist[i] = acc / zz;
+    }
+    __syncthreads();
+    if (t == 0) {
+        d.be_ja[(size_t)r * d.NBE + slot] = jash / zz;
+        double jt = 0.;
+        if (tc >= 0) {
+            const double *pd = d.pd_lt + ((size_t)r * d.NBE + slot) * M * D;
+            for (int i = 0; i < M * D; i++) jt += hist[i] * (-d.pen * pd[i]);
+            jt += -d.pen * (jash / zz);
+        }
+        d.be_jt[(size_t)r * d.NBE + slot] = jt;
+    }
+}
+
+// =============================================================================
+// k_pairwise_be2: k_pairwise_be with the weight of a state pair taken from the per-breakend clone-product
+// table (k_brk_lut) through a precomputed 16-bit pair code, and with the columns walked in the order of
+// their tumour-clone totals (t1, t2): the histogram contribution of a whole run of equal totals is
+// flushed to the thread's private bins once per run (about S/3 + 9 LDS adds per row at M = 3 instead
+// of 3 S).  M in {2, 3}; same reductions downstream as k_pairwise_be.
+// grid (NBE, nr), block NT = ceil(S/64)*64, dynamic LDS.
+// =============================================================================
+__global__ void k_pairwise_be2(Dev d, int r0, int PE2P, int SPC) {
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    __shared__ double scratch[16];
+    __shared__ double zsh, jash;
+    const int r = r0 + blockIdx.y, slot = blockIdx.x;
+    const int n = d.be_n[slot];
+    const int S = d.S, M = d.M, D = d.D, t = threadIdx.x, NT = blockDim.x;
+    const int NB = d.cn_max + 2;                          // totals 0 .. cn_max+1
+    const int tc = d.tclass[n];
+    const int ca = d.seg_class[n], cb = d.seg_class[n + 1];
+    double *gvec = (double *)smem_raw;                    // [S8] fe*fb of segment n+1, in jord order, zero-padded
+    double *tab = gvec + ((S + 7) & ~7);                  // [PE2P] clone-product weights of this breakend (1 for a telomere)
+    double *wa = tab + PE2P;                              // [128]
+    double *bins = wa + 128;                              // [NT][M-1][NB] tumour clones; [NT] row sums behind them (the normal clone's single bin)
+    double *zrow = bins + (size_t)NT * (M - 1) * NB;
+    int *jm = (int *)(zrow + NT);                         // [S8] jmeta of class cb, zero-padded
+    const double *fb = d.fb + rs_off(d, r, n + 1), *fe = d.fe + rs_off(d, r, n + 1);
+    for (int jj = t; jj < ((S + 7) & ~7); jj += NT) {
+        if (jj < S) { const int j = d.jord[(size_t)cb * S + jj]; gvec[jj] = fe[j] * fb[j]; jm[jj] = d.jmeta[(size_t)cb * S + jj]; }
+        else { gvec[jj] = 0.; jm[jj] = 0; }
+    }
+    const double *tg = d.pe2_lt + ((size_t)r * d.NBE + slot) * PE2P;
+    for (int i = t; i < PE2P; i += NT) tab[i] = tc >= 0 ? tg[i] : 1.0;
+    for (int i = t; i < 128; i += NT) wa[i] = tc >= 0 ? exp(-d.pen * (double)i) : 1.0;
+    double *mybins = bins + (size_t)t * (M - 1) * NB;     // plane c-1 for tumour clone c
+    for (int i = 0; i < (M - 1) * NB; i++) mybins[i] = 0.;
+    zrow[t] = 0.;
+    __syncthreads();
+    double z = 0., ja = 0.;
+    if (t < S) {
+        const double fai = d.fa[rs_off(d, r, n) + t];
+        const int S8 = (S + 7) & ~7;                       // code rows / gvec / jm are padded to a multiple of 8 columns (zeros)
+        const uint16_t *crow = d.pcode + (size_t)(tc >= 0 ? tc : 0) * S8 * SPC + t;
+        double acc1 = 0., acc2 = 0.;
+        // chunks of 8 columns, the next chunk's codes requested before the current one is consumed
+        unsigned cn_[8], cc_[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) cn_[u] = tc >= 0 ? (unsigned)crow[(size_t)u * SPC] : 0u;
+        for (int j0 = 0; j0 < S8; j0 += 8) {
+#pragma unroll
+            for (int u = 0; u < 8; u++) cc_[u] = cn_[u];
+            if (j0 + 8 < S8) {
+#pragma unroll
+                for (int u = 0; u < 8; u++) cn_[u] = tc >= 0 ? (unsigned)crow[(size_t)(j0 + 8 + u) * SPC] : 0u;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int jj = j0 + u;
+                const unsigned c_ = cc_[u];
+                const int a = (int)(c_ >> 10);
+                const double w = wa[a] * tab[c_ & 1023u];
+                const double J = fai * w * gvec[jj];
+                z += J; ja += J * (double)a;
+                acc2 += J;
+                const int m_ = jm[jj];                         // wave-uniform
+                if (m_ & 0x10000) {                            // last column of a (t1, t2) run
+                    if (M == 3) unsafeAtomicAdd(&mybins[1 * NB + ((m_ >> 8) & 0xff)], acc2);   // private address: fire-and-forget ds_add_f64
+                    acc1 += acc2; acc2 = 0.;
+                    if (m_ & 0x20000) { unsafeAtomicAdd(&mybins[0 * NB + (m_ & 0xff)], acc1); acc1 = 0.; }   // last column of a t1 run
+                }
+            }
+        }
+        // normal clone: one total for every column, the whole row lands in one bin
+        zrow[t] = z;
+    }
+    // deterministic block sums
+    z = group_sum(z, 64); ja = group_sum(ja, 64);
+    if ((t & 63) == 0) { scratch[t >> 6] = z; scratch[8 + (t >> 6)] = ja; }
+    __syncthreads();
+    if (t == 0) { double zz = 0., aa = 0.; for (int w_ = 0; w_ < NT / 64; w_++) { zz += scratch[w_]; aa += scratch[8 + w_]; } zsh = zz; jash = aa; }
+    __syncthreads();
+    const double zz = zsh;
+    // fold the private bins: hist[c][d] = sum_i bins[i][c][tot_i,c - d]
+    double *hist = d.hist + ((size_t)r * d.NBE + slot) * M * D;
+    for (int i = t; i < M * D; i += NT) {
+        const int c = i / D, dv = i % D - (d.cn_max + 1);
+        double acc = 0.;
+        if (c == 0) {
+            const int t0b = (int)d.tot[(size_t)cb * S * M];
+            for (int row = 0; row < S; row++) if ((int)d.tot[((size_t)ca * S + row) * M] - dv == t0b) acc += zrow[row];
+        } else {
+            for (int row = 0; row < S; row++) {
+                const int tj = (int)d.tot[((size_t)ca * S + row) * M + c] - dv;
+                if (tj >= 0 && tj < NB) acc += bins[((size_t)row * (M - 1) + (c - 1)) * NB + tj];
+            }
         }
         hist[i] = acc / zz;
     }
