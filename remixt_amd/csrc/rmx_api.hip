@@ -1485,6 +1485,52 @@ int rmx_param_search(rmx_batch *b, int32_t nreq, const int32_t *restarts, int32_
         if ((rc = run_ell_batch(b, nreq, restarts, false, part.data(), mask))) return rc;
         for (int i = 0; i < nreq; i++) cst[i] = full[i] - part[i];
     }
+    // Table-free evaluation for the four standard parameters: candidates are evaluated against the
+    // restart's device parameters and state tables with only the searched parameter (and the table
+    // entries it feeds) overridden in registers -- no table rebuild, no host mirror update per candidate,
+    // and the whole grid in ONE launch.
+    const bool table_free = (mask == CM_LT0 || mask == CM_LT1 || mask == CM_LA0 || mask == CM_LA1) && nreq <= 16 && G <= 32 &&
+                            (param_id == RMX_P_NEGBIN_R_0 || param_id == RMX_P_NEGBIN_R_1 || param_id == RMX_P_BETABIN_M_0 || param_id == RMX_P_BETABIN_M_1) &&
+                            !getenv("RMX_SEARCH_TABLES");
+    std::vector<double> lastval(nreq, grid[0]);
+    auto search_eval = [&](int n_, const int *who, const double *v_, int Gz, bool per_request, double *o_) -> int {
+        // who: indices into restarts[] (nullptr: all, in order); v_: Gz grid values or n_ per-request values
+        const Dev &d = b->d;
+        SearchVals sv;
+        sv.per_request = per_request ? 1 : 0; sv.Gz = Gz; sv.pad0 = sv.pad1 = 0;
+        const int nv_ = per_request ? n_ : Gz;
+        for (int i = 0; i < 32; i++) { sv.v[i] = i < nv_ ? v_[i] : v_[0]; sv.lv[i] = std::log(sv.v[i]); }
+        int maxcnt = 0;
+        for (int i = 0; i < 16; i++) { const int r_ = restarts[who ? who[i < n_ ? i : 0] : (i < n_ ? i : 0)]; sv.rlist[i] = r_; if (i < n_) maxcnt = std::max(maxcnt, b->sample_count[r_]); }
+        {
+            std::lock_guard<std::mutex> lk(b->mu);
+            if (maxcnt > 0) {
+                ProfScope ps(b, KID_ELL_LIST);
+                void (*kf)(Dev, SearchVals, const int32_t *, const int32_t *, double *, int) =
+                    mask == CM_LT0 ? k_ell_search<CM_LT0> : (mask == CM_LT1 ? k_ell_search<CM_LT1> : (mask == CM_LA0 ? k_ell_search<CM_LA0> : k_ell_search<CM_LA1>));
+                hipLaunchKernelGGL(kf, dim3(maxcnt, n_, Gz), dim3(256), 0, b->stream, b->d, sv, (const int32_t *)b->d_sample, (const int32_t *)b->d_counts, b->d_ell_partial, std::max(maxcnt, 1));
+            }
+            { ProfScope ps(b, KID_ELL_FINAL); hipLaunchKernelGGL(k_ell_search_final, dim3(n_ * Gz), dim3(256), 0, b->stream, b->d, sv, (const int32_t *)b->d_counts, (const double *)b->d_ell_partial, std::max(maxcnt, 1), b->h_pinned, b->h_err); }
+            HIPCHK(hipGetLastError());
+        }
+        HIPCHK(hipStreamSynchronize(b->stream));
+        for (int i = 0; i < n_; i++) {
+            if (!b->h_err[i]) continue;
+            const uint32_t ev = b->h_err[i];
+            HIPCHK(hipMemsetAsync(b->d.err + sv.rlist[i], 0, sizeof(uint32_t), b->stream));
+            return translate_error(b, sv.rlist[i], ev);
+        }
+        for (int i = 0; i < n_; i++)
+            for (int g = 0; g < Gz; g++) o_[i * Gz + g] = b->h_pinned[i * Gz + g] + cst[who ? who[i] : i];
+        return RMX_OK;
+    };
+    if (table_free) {
+        std::vector<double> og((size_t)nreq * G);
+        if ((rc = search_eval(nreq, nullptr, grid, G, false, og.data()))) return rc;
+        for (int g = 0; g < G; g++)
+            for (int i = 0; i < nreq; i++) { const double J = -og[(size_t)i * G + g]; if (g == 0 || J < best[i]) { best[i] = J; x0[i] = grid[g]; } }
+        for (int i = 0; i < nreq; i++) lastval[i] = grid[G - 1];
+    } else
     for (int g = 0; g < G; g++) {
         for (int i = 0; i < nreq; i++) vals[i] = grid[g];
         if ((rc = eval(nreq, restarts, vals.data(), out.data(), nullptr))) return rc;
@@ -1506,10 +1552,14 @@ int rmx_param_search(rmx_batch *b, int32_t nreq, const int32_t *restarts, int32_
     while (!want.empty()) {
         std::vector<int> cur;
         cur.swap(want);
-        for (size_t k = 0; k < cur.size(); k++) { rl[k] = restarts[cur[k]]; vals[k] = nm[cur[k]].req; }
-        if ((rc = eval((int)cur.size(), rl.data(), vals.data(), out.data(), cur.data()))) return rc;
+        for (size_t k = 0; k < cur.size(); k++) { rl[k] = restarts[cur[k]]; vals[k] = nm[cur[k]].req; lastval[cur[k]] = vals[k]; }
+        if (table_free) { if ((rc = search_eval((int)cur.size(), cur.data(), vals.data(), 1, true, out.data()))) return rc; }
+        else if ((rc = eval((int)cur.size(), rl.data(), vals.data(), out.data(), cur.data()))) return rc;
         for (size_t k = 0; k < cur.size(); k++) pump(cur[k], -out[k]);
     }
+    // the table-free evaluations did not touch the model: leave the parameter at the value of the restart's
+    // last evaluation, as the sequential scipy run (and the table-rebuilding path) does
+    if (table_free) for (int i = 0; i < nreq; i++) if ((rc = rmx_set_param(b, restarts[i], param_id, lastval[i]))) return rc;
     for (int i = 0; i < nreq; i++) xopt[i] = nm[i].xopt();
     return RMX_OK;
 }

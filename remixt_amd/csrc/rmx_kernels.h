@@ -55,10 +55,10 @@ __device__ __forceinline__ void state_tables_body(const Dev &d, int cls, int r, 
         d.stM[(base * 2 + 0) * d.SP + s] = M0;
         d.stM[(base * 2 + 1) * d.SP + s] = M1;
         const bool ok = !(fl & (ST_E_BADP | ST_E_TD | ST_E_LOH));
-        d.stLg[(base * 4 + 0) * d.SP + s] = ok ? lgamma(M0 * p) : 0.;
-        d.stLg[(base * 4 + 1) * d.SP + s] = ok ? lgamma(M0 * (1 - p)) : 0.;
-        d.stLg[(base * 4 + 2) * d.SP + s] = ok ? lgamma(M1 * p) : 0.;
-        d.stLg[(base * 4 + 3) * d.SP + s] = ok ? lgamma(M1 * (1 - p)) : 0.;
+        d.stLg[(base * 4 + 0) * d.SP + s] = ok ? lgamma_pos(M0 * p) : 0.;
+        d.stLg[(base * 4 + 1) * d.SP + s] = ok ? lgamma_pos(M0 * (1 - p)) : 0.;
+        d.stLg[(base * 4 + 2) * d.SP + s] = ok ? lgamma_pos(M1 * p) : 0.;
+        d.stLg[(base * 4 + 3) * d.SP + s] = ok ? lgamma_pos(M1 * (1 - p)) : 0.;
         d.stFlags[si] = fl;
     }
 }
@@ -1564,7 +1564,10 @@ __global__ void k_elbo_final(Dev d, int r0, const double *partial, int nblk, con
 // one sampled segment per block: E[ll] (and d/dh when GRAD) of segment n under parameters rp -> prow[1+MAXC]
 // MASK (CM_* bits, GRAD == false only): restrict the sum to those likelihood components -- the part of
 // the objective that moves during the search over one likelihood parameter
-template <bool GRAD, int MASK = CM_ALL>
+// OVR: the state-table entries that depend on the searched beta-binomial precision (M, lgamma(M p),
+// lgamma(M (1-p))) are recomputed from rp here instead of being read from the restart's tables, which
+// therefore need no rebuild per candidate value
+template <bool GRAD, int MASK = CM_ALL, bool OVR = false>
 __device__ __forceinline__ void ell_segment(const Dev &d, const RestartParams &rp, int r, int n, double *prow) {
     __shared__ double scratch[8];
     __shared__ double segk[8];
@@ -1587,7 +1590,15 @@ __device__ __forceinline__ void ell_segment(const Dev &d, const RestartParams &r
     for (int s = threadIdx.x; s < d.S; s += 256) {
         double LT[2], LA[4];
         if (MASK == CM_ALL) cell_ll(d, rp, sc, r, cls, s, LT, LA, err);
-        else { StateRegs st_; load_state_regs(d, r, cls, s, st_); cell_ll_regs<MASK>(rp, sc, st_, LT, LA, err); }
+        else {
+            StateRegs st_; load_state_regs(d, r, cls, s, st_);
+            if (OVR && (MASK & (CM_LA0 | CM_LA1)) && !(st_.fl & ST_LOH_M)) {
+                const bool ok_ = !(st_.fl & (ST_E_BADP | ST_E_TD | ST_E_LOH));      // as state_tables_body
+                if (MASK & CM_LA0) { const double M_ = rp.p[RMX_P_BETABIN_M_0]; st_.M0 = M_; st_.lgA0 = ok_ ? lgamma_pos(M_ * st_.p) : 0.; st_.lgB0 = ok_ ? lgamma_pos(M_ * (1 - st_.p)) : 0.; }
+                if (MASK & CM_LA1) { const double M_ = rp.p[RMX_P_BETABIN_M_1]; st_.M1 = M_; st_.lgA1 = ok_ ? lgamma_pos(M_ * st_.p) : 0.; st_.lgB1 = ok_ ? lgamma_pos(M_ * (1 - st_.p)) : 0.; }
+            }
+            cell_ll_regs<MASK>(rp, sc, st_, LT, LA, err);
+        }
         const double ps = post[s];
         if (MASK & CM_LT0) acc += ps * qt0 * LT[0];
         if (MASK & CM_LT1) acc += ps * qt1 * LT[1];
@@ -1725,6 +1736,38 @@ __global__ void k_ell_final_batch(Dev d, const int32_t *rlist, const int32_t *co
         a = block_sum<256>(a, scratch);
         if (threadIdx.x == 0) out[(size_t)blockIdx.x * nout + c] = a;
     }
+}
+// ---- parameter search without table rebuilds ------------------------------------------------------
+// Candidate values of ONE of negbin_r_0 / negbin_r_1 / betabin_M_0 / betabin_M_1 (MASK = the likelihood
+// component it moves: 1 / 2 / 4 / 8) for the listed restarts: block (i, j, g) evaluates sampled segment i
+// of restart rlist[j] with the parameter set to v[g] (grid stage: the same Gz values for every restart)
+// or v[j] (per_request: one value per restart, Gz = 1).  Everything else comes from d.rp[r] and the
+// restart's state tables; nothing is written back, so a whole grid is ONE launch.
+struct SearchVals { double v[32], lv[32]; int32_t rlist[16]; int32_t per_request, Gz, pad0, pad1; };
+template <int MASK>
+__global__ void k_ell_search(Dev d, SearchVals sv, const int32_t *samples, const int32_t *counts, double *partial, int maxcnt) {
+    const int req = blockIdx.y, gz = blockIdx.z;
+    const int r = sv.rlist[req];
+    if ((int)blockIdx.x >= counts[r]) return;
+    const int n = samples[(size_t)r * d.N + blockIdx.x];
+    RestartParams rp = d.rp[r];
+    const int vi = sv.per_request ? req : gz;
+    if (MASK == CM_LT0) { rp.p[RMX_P_NEGBIN_R_0] = sv.v[vi]; rp.logr[0] = sv.lv[vi]; }
+    if (MASK == CM_LT1) { rp.p[RMX_P_NEGBIN_R_1] = sv.v[vi]; rp.logr[1] = sv.lv[vi]; }
+    if (MASK == CM_LA0) rp.p[RMX_P_BETABIN_M_0] = sv.v[vi];
+    if (MASK == CM_LA1) rp.p[RMX_P_BETABIN_M_1] = sv.v[vi];
+    ell_segment<false, MASK, true>(d, rp, r, n, partial + ((size_t)(req * sv.Gz + gz) * maxcnt + blockIdx.x));
+}
+// grid (nreq * Gz): the sum of k_ell_final_batch over the partials of (request, candidate)
+__global__ void k_ell_search_final(Dev d, SearchVals sv, const int32_t *counts, const double *partial, int maxcnt, double *out, uint32_t *err_out) {
+    __shared__ double scratch[8];
+    const int req = blockIdx.x / sv.Gz;
+    const int r = sv.rlist[req];
+    if (err_out && threadIdx.x == 0 && blockIdx.x % sv.Gz == 0) err_out[req] = d.err[r];
+    double a = 0.;
+    for (int i = threadIdx.x; i < counts[r]; i += 256) a += partial[(size_t)blockIdx.x * maxcnt + i];
+    a = block_sum<256>(a, scratch);
+    if (threadIdx.x == 0) out[blockIdx.x] = a;
 }
 // full-data E[ll] from (A, B) for a restart range: grid (ELBO_BLOCKS, nr) -> partial[(r-r0)][blk]
 __global__ void k_ell_full_batch(Dev d, int r0, double *partial) {
