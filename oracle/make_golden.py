@@ -195,6 +195,60 @@ def chain_kats(bp):
     np.savez_compressed(os.path.join(OUT, 'chains.npz'), **out)
 
 
+def pipeline_case(name, N, seed, max_cn=8, **config):
+    """Read-depth initialisation and result tables: the reference's readdepth /
+    likelihood / experiment-table functions and its `init` on a synthetic experiment.  `init` reads a
+    pickled experiment and ends by writing two tables into a pandas.HDFStore (PyTables is not in this
+    image): the store is replaced by a no-op for the call -- the returned init_params do not depend on it."""
+    import pickle
+    import tempfile
+    from unittest import mock
+    lk, ex, rd, pl = refload.load_ref_analysis()
+    e = synthetic.make_experiment(N, num_clones=3, max_copy_number=max_cn, num_chains=23, seed=seed)
+    out = {'in/x': e.x, 'in/l': e.l, 'in/chromosome': np.array(e.segment_chromosome_id), 'in/start': e.segment_start, 'in/end': e.segment_end,
+           'in/major_is_allele_a': e.segment_major_is_allele_a, 'in/seed': np.array(seed), 'in/max_cn': np.array(max_cn)}
+    for k, v in config.items():
+        out['config/' + k] = np.array(v)
+    config = dict(config, max_copy_number=max_cn)
+    phi = lk.estimate_phi(e.x)
+    out['phi'] = phi
+    out['expected_read_count'] = lk.expected_read_count(e.l, e.cn, e.h, phi)
+    out['in/cn'] = e.cn; out['in/h'] = e.h
+    seg = ex.create_segment_table(e)
+    for c in ('allele_ratio', 'major_depth', 'minor_depth', 'total_depth'):
+        out['segment_table/' + c] = seg[c].values
+    cnt = ex.create_cn_table(e, e.cn, e.h)
+    for c in cnt.columns:
+        if c not in ('chromosome',):
+            out['cn_table/' + c] = cnt[c].values
+    read_depth = rd.calculate_depth(e)
+    out['read_depth/index'] = read_depth.index.values
+    for c in ('length', 'major', 'minor', 'total', 'high_quality'):
+        out['read_depth/' + c] = read_depth[c].values
+    np.random.seed(config.get('random_seed', 1234))
+    modes = rd.calculate_minor_modes(read_depth)
+    out['minor_modes'] = modes
+    h_mono = rd.calculate_candidate_h_monoclonal(modes)
+    out['h_mono'] = np.array(h_mono)
+    out['ploidy'] = np.array([rd.estimate_ploidy(h, e) for h in h_mono])
+    with tempfile.TemporaryDirectory() as tmp:
+        with open(os.path.join(tmp, 'experiment.pickle'), 'wb') as f:
+            pickle.dump(e, f)
+        ip = None
+        with mock.patch('pandas.HDFStore', mock.MagicMock()):
+            try:
+                ip = pl.init(os.path.join(tmp, 'init.h5'), os.path.join(tmp, 'experiment.pickle'), config)
+            except ValueError as err:      # "Unable to model ... of the genome" (:93-94): recorded, the build must raise too
+                out['init_error'] = np.array(str(err))
+    keys = ['mode_idx', 'h_normal', 'h_tumour', 'mix_frac', 'divergence_weight', 'max_depth']
+    if ip is not None:
+        out['init_params'] = np.array([[float(ip[i][k]) for k in keys] for i in range(len(ip))])
+    else:
+        ip = {}
+    np.savez_compressed(os.path.join(OUT, name + '.npz'), **out)
+    print(name, 'modes', len(modes), 'init params', len(ip))
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     build_ref.build()
@@ -207,6 +261,9 @@ def main():
     model_case(cm, 'model_m3', N=48, M=3, max_cn=3, chains=3, seed=2, zero_alleles=(5, 17), short=(9,))
     model_case(cm, 'model_nonormal', N=36, M=2, max_cn=3, chains=2, seed=3, normal_contamination=False, zero_alleles=(4,))
     model_case(cm, 'model_malex', N=36, M=3, max_cn=2, chains=3, seed=4, male_x=True)
+    pipeline_case('pipeline_init', N=1200, seed=5)
+    pipeline_case('pipeline_init_strict', N=900, seed=6, min_ploidy=7.5, max_ploidy=8.0, random_seed=99)
+    pipeline_case('pipeline_init_closest', N=900, seed=7, min_ploidy=2.95, max_ploidy=3.0, random_seed=7)
 
 
 if __name__ == '__main__':

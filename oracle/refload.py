@@ -67,3 +67,16 @@ def load_ref_cn_model():
         if name not in sys.modules:
             sys.modules[name] = types.ModuleType(name)
     return importlib.import_module("remixt.cn_model")
+
+
+def load_ref_analysis():
+    """The reference's read-depth initialisation / result-table modules, imported in place:
+    (likelihood, analysis.experiment, analysis.readdepth, analysis.pipeline).  `pypeliner` is imported
+    by remixt/utils.py:10 and unused on this path; it is absent from this image, so an empty placeholder
+    module is registered for the import to succeed."""
+    load_ref_cn_model()
+    for name in ("pypeliner", "pypeliner.commandline"):
+        if name not in sys.modules:
+            sys.modules[name] = types.ModuleType(name)
+    return tuple(importlib.import_module(m) for m in
+                 ("remixt.likelihood", "remixt.analysis.experiment", "remixt.analysis.readdepth", "remixt.analysis.pipeline"))

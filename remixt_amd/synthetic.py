@@ -32,6 +32,20 @@ class SyntheticExperiment(object):
         self.segment_chromosome_id = segment_chromosome_id
         self.h = h
         self.cn = cn
+        # the remaining read-only properties of the reference Experiment that the tables either side of
+        # the hot path use (analysis/experiment.py:284-310): coordinates laid end to end per chromosome
+        import pandas as pd
+        l_int = np.maximum(1, np.round(np.asarray(l)).astype(np.int64))
+        start = np.zeros(len(l_int), dtype=np.int64)
+        chrom = np.asarray(segment_chromosome_id)
+        for c in pd.unique(chrom):
+            idx = np.nonzero(chrom == c)[0]
+            ends = np.cumsum(l_int[idx])
+            start[idx] = np.concatenate([[0], ends[:-1]]) + 1
+        self.segment_start = start
+        self.segment_end = start + l_int - 1
+        self.segment_major_is_allele_a = np.ones(len(l_int), dtype=np.int64)
+        self.breakpoint_segment_data = pd.DataFrame({'prediction_id': list(breakpoints.keys())})
 
 
 def _true_copy_number(rng, N, M, max_cn, chain_of):

@@ -268,3 +268,20 @@ def test_restart_groups_do_not_change_results(hip):
     for h1, h2 in zip(out[0][1], out[1][1]):
         assert np.array_equal(h1, h2)
     assert out[0][2] == out[1][2]
+
+
+def test_pipeline_run_experiment_to_best_solution(hip, tmp_path):
+    """init grid -> all restarts in one device batch -> collation / best-ELBO selection (the reference's
+    init / fit_task / collate chain, workflow.py:307-354) on one GPU."""
+    from remixt_amd import synthetic
+    from remixt_amd.analysis import pipeline
+    e = synthetic.make_experiment(800, num_clones=3, max_copy_number=4, num_chains=6, seed=12)
+    config = {'max_copy_number': 4, 'tumour_mix_fractions': [0.45, 0.3, 0.2], 'divergence_weights': [1e-6, 1e-7], 'num_em_iter': 1, 'num_update_iter': 2,
+              'min_ploidy': None, 'max_ploidy': None, 'h_normal': 0.04, 'h_tumour': 0.06}
+    init_params, results, best = pipeline.run(e, config)
+    assert sorted(results) == sorted(init_params) and best in results
+    elig = [i for i in results if results[i]['stats']['proportion_divergent'] < 0.5] or list(results)
+    assert results[best]['stats']['elbo'] == max(results[i]['stats']['elbo'] for i in elig)
+    with pipeline._Store(str(tmp_path / 'collated.store'), 'w') as st:
+        assert pipeline.collate_results(st, e, results, config) == best
+        assert len(st['/cn']) == 800 and 'major_2' in st['/cn'].columns
