@@ -214,7 +214,7 @@ def main():
         nupd = prof.get('k_fb', (0., 1))[1]
         sweep_ms = upd / max(nupd, 1)
         line = {
-            'metric': 'EM iterations/sec (50k seg x 165 states x 16 restarts/GPU)',
+            'metric': 'EM iterations/sec (%dk seg x %d states x %d restarts/GPU)' % (args.segments // 1000, S, R),
             'value': (R * world * args.steps) / dt, 'unit': 'EM iterations/s', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',

@@ -84,6 +84,8 @@ struct rmx_batch {
     // all device allocations (freed on destroy)
     std::vector<void *> allocs;
     // profiling
+    bool fbk_ok = false;   // k_fbk usable: log-weights of every uniform class equal -pen * min(SAD, SAD swapped)
+    uint32_t *d_cnpack = nullptr, *d_totpack = nullptr; double *d_wk = nullptr;   // [C][S], [C][S], [TC][64]
     int pe2p = 0;     // padded row length of pe2_lt (0: no product table)
     int spc = 0;      // row stride of the pair-code table
     bool pcode_ok = false;
@@ -274,6 +276,46 @@ static int build_transitions(rmx_batch *b) {
         HIPCHK(hipMemcpy((void *)b->d.jmeta, jmeta.data(), jmeta.size() * 4, hipMemcpyHostToDevice));
         b->pcode_ok = true;
     }
+    // k_fbk (state grids too large for register-resident weights): byte-packed allele copies / totals of the
+    // tumour clones per class, exp(-pen*k) per transition class, and the check that the closed form
+    // -pen * min(SAD(cn_q, cn_o), SAD(cn_q, swap(cn_o))) reproduces the tabulated log-weights exactly
+    b->fbk_ok = false;
+    if (TC > 0 && (M == 2 || M == 3) && model == 0 && b->d.cn_max <= 15 && b->d_cnpack) {
+        const int C = b->d.C;
+        std::vector<uint32_t> cnp((size_t)C * S), ttp((size_t)C * S);
+        for (int cls = 0; cls < C; cls++)
+            for (int s_ = 0; s_ < S; s_++) {
+                const int64_t *t_ = b->cn_classes.data() + ((size_t)cls * S + s_) * M * 2;
+                uint32_t cp = 0, tp = 0;
+                for (int c = 1; c < M; c++) {
+                    cp |= ((uint32_t)t_[c * 2] & 0xff) << (16 * (c - 1)); cp |= ((uint32_t)t_[c * 2 + 1] & 0xff) << (16 * (c - 1) + 8);
+                    tp |= ((uint32_t)(t_[c * 2] + t_[c * 2 + 1]) & 0xff) << (8 * (c - 1));
+                }
+                cnp[(size_t)cls * S + s_] = cp; ttp[(size_t)cls * S + s_] = tp;
+            }
+        auto sad = [](uint32_t x, uint32_t y) { int r_ = 0; for (int i = 0; i < 4; i++) r_ += std::abs((int)((x >> (8 * i)) & 0xff) - (int)((y >> (8 * i)) & 0xff)); return r_; };
+        auto swp = [](uint32_t x) { return ((x & 0x00ff00ffu) << 8) | ((x >> 8) & 0x00ff00ffu); };
+        bool ok = true;
+        std::vector<double> wk((size_t)TC * 64, 0.);
+        for (int tc = 0; tc < TC && ok; tc++) {
+            for (int k = 0; k < 64; k++) wk[(size_t)tc * 64 + k] = std::exp(-pen * (double)k);
+            const int ca = b->tc_pairs[tc].first, cb = b->tc_pairs[tc].second;
+            if (ca != cb) continue;      // only chains of one class use the kernel
+            for (int i = 0; i < S && ok; i++)
+                for (int j = 0; j < S; j++) {
+                    const int k = std::min(sad(cnp[(size_t)ca * S + i], cnp[(size_t)cb * S + j]), sad(cnp[(size_t)ca * S + i], swp(cnp[(size_t)cb * S + j])));
+                    const int kt = sad(ttp[(size_t)ca * S + i], ttp[(size_t)cb * S + j]);
+                    if (k >= 64 || Tval[tc * SS + (size_t)i * S + j] != -pen * (double)k || (int)af[tc * SS + (size_t)i * S + j] != k - kt ||
+                        Wf[tc * SS + (size_t)i * S + j] != wk[(size_t)tc * 64 + k]) { ok = false; break; }
+                }
+        }
+        if (ok) {
+            HIPCHK(hipMemcpy(b->d_cnpack, cnp.data(), cnp.size() * 4, hipMemcpyHostToDevice));
+            HIPCHK(hipMemcpy(b->d_totpack, ttp.data(), ttp.size() * 4, hipMemcpyHostToDevice));
+            HIPCHK(hipMemcpy(b->d_wk, wk.data(), wk.size() * 8, hipMemcpyHostToDevice));
+            b->fbk_ok = true;
+        }
+    }
     if (TC > 0) {
         HIPCHK(hipMemcpy((void *)b->d.Tval, Tval.data(), Tval.size() * 8, hipMemcpyHostToDevice));
         HIPCHK(hipMemcpy((void *)b->d.Wf, Wf.data(), Wf.size() * 8, hipMemcpyHostToDevice));
@@ -411,11 +453,12 @@ template <int NS> static cells_kernel_t cells_kernel_ns(int mode, int mask, int 
     case 12: return k_cells<NS, 2, 12, 0>; case 15: return k_cells<NS, 2, 15, 0>; default: return k_cells<NS, 2, 31, 0>;
     }
 }
-static bool use_strip(rmx_batch *b) { return b->d.S > 32 && b->d.S <= 256 && !getenv("RMX_NO_STRIP"); }
+static bool use_strip(rmx_batch *b) { return b->d.S > 32 && b->d.S <= 384 && !getenv("RMX_NO_STRIP"); }
 static cells_kernel_t cells_kernel(rmx_batch *b, int mode, int mask, int cache) {
     const int ns = (b->d.S + 63) / 64;
     switch (ns) { case 1: return cells_kernel_ns<1>(mode, mask, cache); case 2: return cells_kernel_ns<2>(mode, mask, cache);
-                  case 3: return cells_kernel_ns<3>(mode, mask, cache); default: return cells_kernel_ns<4>(mode, mask, cache); }
+                  case 3: return cells_kernel_ns<3>(mode, mask, cache); case 4: return cells_kernel_ns<4>(mode, mask, cache);
+                  case 5: return cells_kernel_ns<5>(mode, mask, cache); default: return cells_kernel_ns<6>(mode, mask, cache); }
 }
 static dim3 strip_grid(rmx_batch *b, int nr) { return dim3((b->d.N + 4 * STRIP_RPW - 1) / (4 * STRIP_RPW), nr); }
 // smallest instantiated component mask covering `m`
@@ -670,6 +713,7 @@ int rmx_batch_create(const rmx_problem *pr, int32_t R, const double *h_init, con
         b->spc = ((S + 63) / 64) * 64;
         DA(pcode, uint16_t, (size_t)std::max(d.TC, 1) * ((S + 7) & ~7) * b->spc) DA(jord, int32_t, (size_t)C * S) DA(jmeta, int32_t, (size_t)C * S)
     } else { d.pcode = nullptr; d.jord = nullptr; d.jmeta = nullptr; }
+    if ((rc = dalloc(b, &b->d_cnpack, (size_t)C * S)) || (rc = dalloc(b, &b->d_totpack, (size_t)C * S)) || (rc = dalloc(b, &b->d_wk, (size_t)std::max(d.TC, 1) * 64))) { rmx_batch_destroy(b); return rc; }
     DA(pd_cached, double, BEW) DA(hist, double, BEW) DA(be_jt, double, (size_t)R * d.NBE) DA(be_ja, double, (size_t)R * d.NBE)
     DA(err, uint32_t, R)
 #undef DA
@@ -678,7 +722,7 @@ int rmx_batch_create(const rmx_problem *pr, int32_t R, const double *h_init, con
         const size_t bytes = RNS * 6 * 8;
         const char *env = getenv("RMX_CELL_CACHE");
         const bool want = env ? atoi(env) != 0 : true;
-        if (want && S > 32 && S <= 256 && bytes <= ((size_t)96 << 30)) { double *p_ = nullptr; if (dalloc(b, &p_, RNS * 6) == RMX_OK) { d.lc = p_; b->use_cache = true; } }
+        if (want && S > 32 && S <= 384 && bytes <= ((size_t)96 << 30)) { double *p_ = nullptr; if (dalloc(b, &p_, RNS * 6) == RMX_OK) { d.lc = p_; b->use_cache = true; } }
     }
     if ((rc = dalloc(b, &b->d_lt_valid, R)) || (rc = dalloc(b, &b->d_partial, (size_t)R * ELBO_BLOCKS * 2)) || (rc = dalloc(b, &b->d_out4, (size_t)R * 4)) ||
         (rc = dalloc(b, &b->d_ell_partial, (size_t)R * std::max(N, ELBO_BLOCKS) * (1 + RMX_MAX_CLONES))) || (rc = dalloc(b, &b->d_ell_out, (size_t)R * 8)) ||
@@ -1023,6 +1067,34 @@ static int do_update_p_cn(rmx_batch *b, int r0, int r1, bool skip_frame = false,
             if (kf && nt <= 768 && lds <= kLdsBudget) {
                 HIPCHK(hipFuncSetAttribute((const void *)kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
                 hipLaunchKernelGGL(kf, dim3(b->n_fast, (nr + NV - 1) / NV, 2), dim3(nt), lds, b->stream, v);
+                done_fast = true; fast = true;
+            }
+        }
+        if (!done_fast && b->fbv_rpt == 0 && b->fbk_ok && d.pe2_lt && b->n_fast > 0 && !getenv("RMX_FB_GENERIC") && !getenv("RMX_FB_NO_FBK")) {
+            // state grid too large for register-resident weights: weights from packed copy numbers on the fly
+            const int nr = r1 - r0;
+            int NV = 1;
+            while (NV < 4 && (long)b->n_fast * 2 * ((nr + NV - 1) / NV) > 256) NV *= 2;
+            if (const char *env = getenv("RMX_FB_NV")) { const int want = atoi(env); if (want == 1 || want == 2 || want == 4) NV = want; }
+            FbvArgs v;
+            memset(&v, 0, sizeof v);
+            v.S = d.S; v.SP = d.SP; v.M = d.M; v.D = d.D; v.C = d.C; v.N = d.N; v.NBE = d.NBE; v.cn_max = d.cn_max;
+            v.r0 = r0; v.r1 = r1; v.pen = d.pen;
+            v.G2 = (((d.S + 1) / 2 + 15) / 16) * 16; v.SPW = ((d.S + 63) / 64) * 64;
+            const int nch = (d.S + FBK_P * 16 - 1) / (FBK_P * 16);
+            v.SPAD = FBK_P * 16 * nch;
+            v.PE2P = b->pe2p;
+            v.chain_start = d.chain_start; v.chain_end = d.chain_end; v.tclass = d.tclass; v.brk_slot = d.brk_slot;
+            v.chain_list = d.chain_list_fast; v.chain_tc = d.chain_tc; v.chain_cls = d.chain_cls; v.be_n = d.be_n; v.chain_be = d.chain_be; v.pe2_lt = d.pe2_lt;
+            v.fe = d.fe; v.Wf = d.Wf; v.Wb = d.Wb; v.pe_lt = d.pe_lt; v.af = d.af; v.ab = d.ab; v.tot = d.tot;
+            v.fa = d.fa; v.fb = d.fb; v.mrow = d.mrow; v.err = d.err; v.dbg = b->d_dbg;
+            int nt = ((FBK_P * v.G2 + v.SPW - 1) / v.SPW) * v.SPW;
+            const size_t lds = ((size_t)NV * 2 * v.SPAD + (size_t)NV * FBK_P * d.SP + NV * 4 + (size_t)NV * b->pe2p + 64) * 8 + (size_t)2 * v.SPAD * 4 + (size_t)b->be_cap * 4 + 64;
+            const int vpp = nt / v.SPW;
+            if (nt <= 768 && lds <= kLdsBudget && (NV + vpp - 1) / vpp <= 2 && ((b->pe2p + 1) / 2) <= 384) {
+                void (*kf)(FbvArgs, const double *, const uint32_t *, const uint32_t *) = NV == 1 ? k_fbk<1, 768> : (NV == 2 ? k_fbk<2, 768> : k_fbk<4, 768>);
+                HIPCHK(hipFuncSetAttribute((const void *)kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                hipLaunchKernelGGL(kf, dim3(b->n_fast, (nr + NV - 1) / NV, 2), dim3(nt), lds, b->stream, v, (const double *)b->d_wk, (const uint32_t *)b->d_cnpack, (const uint32_t *)b->d_totpack);
                 done_fast = true; fast = true;
             }
         }

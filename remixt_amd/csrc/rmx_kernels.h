@@ -805,6 +805,213 @@ __global__ __launch_bounds__(NTMAX) void k_fbv(FbvArgs a) {
 }
 
 // =============================================================================
+// k_fbk: forward-backward for state grids whose S x S weight matrix does not fit the register file
+// (S > 176, e.g. 355 states at max_cn = 12).  Same step structure, vector operand broadcast (DPP
+// row_newbcast), scaling, emission loads and breakend walk as k_fbv, but the plain-adjacency weight
+// is never stored: with the default transition model (|d|) the log-weight of (q -> o) is
+//     -pen * min( SAD(cn_q, cn_o), SAD(cn_q, swap_alleles(cn_o)) )
+// (bpmodel.pyx:648-684: the total-copy terms cancel against the allele term's correction), the copies
+// of the tumour clones' alleles packed one byte each -- two v_sad_u8 and a v_min per pair, then one
+// LDS lookup exp(-pen*k) (<= 64 entries).  M <= 3; the host verifies the identity against the
+// tabulated log-weights of the class before it selects this kernel.
+//   thread t (phase 1):  g = t % G2 (column pair), p = t / G2 (row slice, FBK_P slices of 16*NCH rows)
+//   thread t (phase 2):  vector t / SPW + pass * (NT / SPW), state t % SPW
+// =============================================================================
+#define FBK_P 4
+template <int NV, int NTMAX>
+__global__ __launch_bounds__(NTMAX) void k_fbk(FbvArgs a, const double *wk, const uint32_t *cnpack, const uint32_t *totpack) {
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    const int chain = a.chain_list[blockIdx.x], dir = blockIdx.z;
+    const int rg0 = a.r0 + blockIdx.y * NV;
+    const int nv = min(NV, a.r1 - rg0);
+    const int S = a.S, M = a.M, D = a.D, SP = a.SP, G2 = a.G2, SPW = a.SPW;
+    const int n0 = a.chain_start[chain], n1 = a.chain_end[chain], len = n1 - n0 + 1;
+    const int t = threadIdx.x, NT = blockDim.x;
+    const int p = t / G2, g = t - p * G2;
+    const int o0 = 2 * g, o1 = 2 * g + 1;
+    const bool act = p < FBK_P;
+    const int VPP = NT / SPW;                               // vectors published per pass of phase 2
+    const int NPASS = (NV + VPP - 1) / VPP;
+    const int pv0 = t / SPW, po = t - pv0 * SPW;
+    const int lane = t & 63;
+    const int SPAD = a.SPAD;                                // = FBK_P * 16 * NCH (rows padded per slice)
+    const int NCH = SPAD / (FBK_P * 16);                    // 16-row chunks per slice
+    const int cls = a.chain_cls[chain];
+    // ---- LDS carve-up -----------------------------------------------------------------------
+    double *vec = (double *)smem_raw;                           // [NV][2][SPAD]
+    double *part = vec + (size_t)NV * 2 * SPAD;                 // [NV][FBK_P][SP]
+    double *red = part + (size_t)NV * FBK_P * SP;               // [NV][4]
+    unsigned *red32 = (unsigned *)red;
+    double *pel = red + NV * 4;                                 // [NV][PE2P]  clone-product weights of the current breakend
+    double *wtab = pel + (size_t)NV * a.PE2P;                   // [64] exp(-pen * k)
+    uint32_t *cnl = (uint32_t *)(wtab + 64);                    // [SPAD] packed allele copies of the row states (0 past S)
+    uint32_t *tpl = cnl + SPAD;                                 // [SPAD] packed totals
+    int *bel = (int *)(tpl + SPAD);                             // adjacencies of this chain's breakends
+    for (int i = t; i < SPAD; i += NT) { cnl[i] = i < S ? cnpack[(size_t)cls * S + i] : 0u; tpl[i] = i < S ? totpack[(size_t)cls * S + i] : 0u; }
+    const int be_lo = a.chain_be[2 * chain], be_hi = a.chain_be[2 * chain + 1];
+    for (int i = t; i < be_hi - be_lo; i += NT) bel[i] = a.be_n[be_lo + i];
+    for (int i = t; i < NV * 2 * SPAD; i += NT) vec[i] = 0.;
+    for (int i = t; i < 64; i += NT) wtab[i] = wk[(size_t)a.chain_tc[chain] * 64 + i];
+    if (t < NV * 4) red[t] = 0.;
+    // this thread's two columns: allele copies as they are and with the alleles swapped, totals
+    auto swap_alleles = [](uint32_t x) { return ((x & 0x00ff00ffu) << 8) | ((x >> 8) & 0x00ff00ffu); };
+    const uint32_t co0 = o0 < S ? cnpack[(size_t)cls * S + o0] : 0u, co1 = o1 < S ? cnpack[(size_t)cls * S + o1] : 0u;
+    const uint32_t co0s = swap_alleles(co0), co1s = swap_alleles(co1);
+    const uint32_t to0 = o0 < S ? totpack[(size_t)cls * S + o0] : 0u, to1 = o1 < S ? totpack[(size_t)cls * S + o1] : 0u;
+    __syncthreads();
+
+#define ROW(k) (dir == 0 ? n0 + (k) : n1 - (k))
+#define ADJ(k) (dir == 0 ? n0 + (k) - 1 : n1 - (k))
+    const int be_step = dir == 0 ? 1 : -1;
+    int be_i = dir == 0 ? be_lo : be_hi - 1;
+    int be_adj = (be_i >= be_lo && be_i < be_hi) ? __builtin_amdgcn_readfirstlane(bel[be_i - be_lo]) : -2;
+#define BE_SLOT(k_, bs_)                                                                                   \
+    int bs_ = -1;                                                                                          \
+    if (ADJ(k_) == be_adj) {                                                                               \
+        bs_ = be_i; be_i += be_step;                                                                       \
+        be_adj = (be_i >= be_lo && be_i < be_hi) ? __builtin_amdgcn_readfirstlane(bel[be_i - be_lo]) : -2; \
+    }
+    // ---- step 0 ---------------------------------------------------------------------------------
+    const int rstep = dir == 0 ? SP : -SP;
+    const size_t vstride = (size_t)VPP * a.N * SP;          // between the vectors of consecutive passes
+    const bool pubwave = pv0 < VPP;                         // (always true for NT == VPP * SPW)
+    const size_t lane_off = ((size_t)(rg0 + (pv0 < nv ? pv0 : 0)) * a.N + ROW(0)) * SP + (po < S ? po : S - 1);
+    double *outp = (dir == 0 ? a.fa : a.fb) + lane_off;
+    const double *eptr = a.fe + lane_off;
+    for (int ps = 0; ps < NPASS; ps++) {
+        const int pv = pv0 + ps * VPP;
+        if (pv < NV && pubwave) {      // wave-uniform
+            double e0 = 0.;
+            if (pv < nv && po < S) {
+                e0 = eptr[(size_t)ps * vstride];
+                vec[(size_t)pv * 2 * SPAD + po] = e0;
+                gstore8(outp + (size_t)ps * vstride, (dir == 0) ? e0 : 1.0);
+            }
+            const unsigned wm = wave_max_u32((unsigned)__double2hiint(e0));
+            if (lane == 0) lds_max_u32(&red32[(pv * 4 + 2) * 2], wm);
+        }
+    }
+    eptr += rstep;
+    const int sgn = dir == 0 ? 1 : -1, off = a.cn_max + 1;
+    FB_BARRIER();
+
+#define FBV_SCALE(buf_, row_)                                                                              \
+    if (t < NV) {                                                                                          \
+        double m_, i_;                                                                                     \
+        pow2_scale(red32[(t * 4 + 2 + (buf_)) * 2], m_, i_);                                               \
+        red[t * 4] = i_; red[t * 4 + 1] = m_;                                                              \
+        red32[(t * 4 + 2 + ((buf_) ^ 1)) * 2] = 0u;                                                        \
+        if (dir == 0 && t < nv) gstore8(a.mrow + (size_t)(rg0 + t) * a.N + (row_), m_);                    \
+    }
+    // one 16-row chunk of phase 1: rows q0 .. q0+15 of this thread's slice against its two columns;
+    // BE: breakend step (weight = exp(-pen * allele distance) * clone-product table entry)
+#define FBK_ROW(rr_, BE_)                                                                                  \
+    {                                                                                                      \
+        const uint32_t cq_ = cnl[q0 + (rr_)];                                                              \
+        const unsigned k0_ = min(__builtin_amdgcn_sad_u8(cq_, co0, 0u), __builtin_amdgcn_sad_u8(cq_, co0s, 0u)); \
+        const unsigned k1_ = min(__builtin_amdgcn_sad_u8(cq_, co1, 0u), __builtin_amdgcn_sad_u8(cq_, co1s, 0u)); \
+        double w0_, w1_;                                                                                   \
+        if (!(BE_)) { w0_ = wtab[k0_]; w1_ = wtab[k1_]; }                                                  \
+        else {                                                                                             \
+            const uint32_t tq_ = tpl[q0 + (rr_)];                                                          \
+            const unsigned a0_ = k0_ - __builtin_amdgcn_sad_u8(tq_, to0, 0u), a1_ = k1_ - __builtin_amdgcn_sad_u8(tq_, to1, 0u); \
+            int i0_ = sgn * ((int)(tq_ & 0xff) - (int)(to0 & 0xff)) + off, i1_ = sgn * ((int)(tq_ & 0xff) - (int)(to1 & 0xff)) + off; \
+            if (M == 3) { i0_ = i0_ * D + sgn * ((int)((tq_ >> 8) & 0xff) - (int)((to0 >> 8) & 0xff)) + off;  \
+                          i1_ = i1_ * D + sgn * ((int)((tq_ >> 8) & 0xff) - (int)((to1 >> 8) & 0xff)) + off; } \
+            w0_ = wtab[a0_]; w1_ = wtab[a1_];                                                              \
+            _Pragma("unroll") for (int v = 0; v < NV; v++) { wbe0[v] = w0_ * pel[(size_t)v * a.PE2P + i0_]; wbe1[v] = w1_ * pel[(size_t)v * a.PE2P + i1_]; } \
+        }                                                                                                  \
+        _Pragma("unroll") for (int v = 0; v < NV; v++) {                                                   \
+            const double x0_ = (BE_) ? wbe0[v] : w0_, x1_ = (BE_) ? wbe1[v] : w1_;                         \
+            asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:" #rr_ " row_mask:0xf bank_mask:0xf" : "+v"(acc0[v]) : "v"(av[v]), "v"(x0_)); \
+            asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:" #rr_ " row_mask:0xf bank_mask:0xf" : "+v"(acc1[v]) : "v"(av[v]), "v"(x1_)); \
+        }                                                                                                  \
+    }
+#define FBK_CHUNK(BE_)                                                                                     \
+    FBK_ROW(0, BE_) FBK_ROW(1, BE_) FBK_ROW(2, BE_) FBK_ROW(3, BE_) FBK_ROW(4, BE_) FBK_ROW(5, BE_) FBK_ROW(6, BE_) FBK_ROW(7, BE_) \
+    FBK_ROW(8, BE_) FBK_ROW(9, BE_) FBK_ROW(10, BE_) FBK_ROW(11, BE_) FBK_ROW(12, BE_) FBK_ROW(13, BE_) FBK_ROW(14, BE_) FBK_ROW(15, BE_)
+
+    if (a.dbg && t == 0 && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0) { a.dbg[0] = clock64(); a.dbg[1] = wall_clock64(); a.dbg[4] = len; }
+    for (int k = 1; k < len; k++) {
+        BE_SLOT(k, bs)
+        const int cb = (k - 1) & 1, nb = k & 1;
+        double e[2] = {0., 0.};                                 // NPASS <= 2
+        gload8(e[0], eptr);
+        if (NPASS > 1) gload8(e[1], eptr + vstride);
+        eptr += rstep;
+        // ============================ phase 1 ============================
+        double acc0[NV], acc1[NV];
+#pragma unroll
+        for (int v = 0; v < NV; v++) { acc0[v] = 0.; acc1[v] = 0.; }
+        FBV_SCALE(cb, ROW(k - 1))
+        if (bs >= 0) {
+            // clone-product tables of this breakend, one per vector (k_brk_lut), by LDS-DMA
+            if (t < (a.PE2P + 1) / 2) {
+                for (int v = 0; v < NV; v++) {
+                    const unsigned dpe = __builtin_amdgcn_readfirstlane(lds_addr(pel + (size_t)v * a.PE2P) + (unsigned)(((t >> 6) << 6) * 16));
+                    if (v < nv && t * 2 < a.PE2P) glds16(a.pe2_lt + ((size_t)(rg0 + v) * a.NBE + bs) * a.PE2P + t * 2, dpe);
+                }
+            }
+            if (t < 384) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            FB_BARRIER();
+        }
+        if (act) {      // wave-uniform: FBK_P * G2 is a multiple of 64
+            double wbe0[NV], wbe1[NV];
+            for (int h = 0; h < NCH; h++) {
+                const int q0 = (p * NCH + h) * 16;
+                double av[NV];
+#pragma unroll
+                for (int v = 0; v < NV; v++) av[v] = vec[((size_t)v * 2 + cb) * SPAD + q0 + (lane & 15)];
+                if (bs < 0) { FBK_CHUNK(false) } else { FBK_CHUNK(true) }
+            }
+        }
+        if (act && o0 < SP) {
+#pragma unroll
+            for (int v = 0; v < NV; v++) {
+                double2 pr; pr.x = acc0[v]; pr.y = acc1[v];
+                *reinterpret_cast<double2 *>(part + ((size_t)v * FBK_P + p) * SP + o0) = pr;
+            }
+        }
+        FB_BARRIER();
+        // ============================ phase 2 ============================
+        outp += rstep;
+        gwait8(e[0]);
+        if (NPASS > 1) gwait8(e[1]);
+#pragma unroll
+        for (int ps = 0; ps < 2; ps++) {
+            if (ps >= NPASS) break;
+            const int pv = pv0 + ps * VPP;
+            if (pv < NV) {           // wave-uniform
+                unsigned vmax_in = 0u;
+                if (pv < nv && po < S) {
+                    const double inv = red[pv * 4];
+                    const double *pp_ = part + (size_t)pv * FBK_P * SP + po;
+                    const double s0 = pp_[0], s1 = pp_[SP], s2 = pp_[2 * SP], s3 = pp_[3 * SP];
+                    const double sum = ((s0 + s1) + s2) + s3;
+                    const double val = sum * inv;
+                    const double vecv = val * e[ps];
+                    vec[((size_t)pv * 2 + nb) * SPAD + po] = vecv;
+                    gstore8(outp + (size_t)ps * vstride, (dir == 0) ? vecv : val);
+                    vmax_in = (unsigned)__double2hiint(vecv);
+                }
+                const unsigned wm = wave_max_u32(vmax_in);
+                if (lane == 0) lds_max_u32(&red32[(pv * 4 + 2 + nb) * 2], wm);
+            }
+        }
+        FB_BARRIER();
+    }
+    if (a.dbg && t == 0 && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0) { a.dbg[2] = clock64(); a.dbg[3] = wall_clock64(); }
+    FBV_SCALE((len - 1) & 1, ROW(len - 1))
+    if (t < nv) { const double m = red[t * 4 + 1]; if (!(m > 0.) || m == INFINITY) atomicOr(&a.err[rg0 + t], RMX_ERR_NAN_AB); }
+#undef FBK_CHUNK
+#undef FBK_ROW
+#undef FBV_SCALE
+#undef ROW
+#undef ADJ
+#undef BE_SLOT
+}
+
+// =============================================================================
 // posterior marginals + per-segment likelihood expectations
 //   post[n,s]  = softmax(alpha+beta) (bpmodel.pyx:948-950) == fa*fb / sum
 //   A[n,u]     = sum_s post * LT_u          B[n,vw] = sum_s post * LA_vw

@@ -186,6 +186,29 @@ def test_fb_register_and_generic_paths_agree(hip):
     assert np.array_equal(outs[0][3], outs[2][3])
 
 
+def test_s355_on_the_fly_weights_match_tabulated(hip):
+    """max_cn = 12 (355 states): the S x S weights do not fit the register file; k_fbk rebuilds them from
+    byte-packed copy numbers (two SADs and a min per pair).  Must agree with the generic kernel that reads
+    the tabulated weights (RMX_FB_NO_FBK=1), breakend steps included, and be repeatable bit for bit."""
+    import os
+    outs = []
+    for mode in ('fbk', 'generic', 'fbk'):
+        if mode == 'generic':
+            os.environ['RMX_FB_NO_FBK'] = '1'
+        else:
+            os.environ.pop('RMX_FB_NO_FBK', None)
+        m, h, _ = H.make_model(hip, N=1500, M=3, max_cn=12, chains=4, seed=13)
+        mm = H.attach(m, h)
+        assert mm.num_cn_states == 355
+        m.variational_update(); m.variational_update()
+        outs.append((mm.posterior_marginals, mm.hmm_log_norm_const, mm.calculate_elbo(), mm.p_breakpoint))
+    os.environ.pop('RMX_FB_NO_FBK', None)
+    assert np.allclose(outs[0][0], outs[1][0], rtol=1e-9, atol=1e-13)
+    assert np.isclose(outs[0][1], outs[1][1], rtol=1e-12) and np.isclose(outs[0][2], outs[1][2], rtol=1e-12)
+    assert np.allclose(outs[0][3], outs[1][3], rtol=1e-9, atol=1e-13)
+    assert np.array_equal(outs[0][0], outs[2][0]) and outs[0][1] == outs[2][1] and outs[0][2] == outs[2][2]
+
+
 def test_fused_sweeps_equal_separate_updates(hip):
     """rmx_variational_update fuses marginals + outlier / allele-swap updates + the next sweep's frame
     pass into one kernel between sweeps; the result must equal the separate coordinate updates bit
