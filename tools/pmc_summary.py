@@ -14,10 +14,11 @@ def fold(name):
         if key in name:
             return out
     if 'k_cells' in name:
-        # k_cells<NS, MODE, MASK, CACHE>: MODE 0 = frame log-probabilities, 1 = marginals, 2 = refresh
+        # k_cells<NS, MODE, MASK, CACHE>: MODE 0 = frame log-probabilities, 1 = marginals, 2 = refresh,
+        # 3 = marginals fused with the next sweep's frame pass (counted with the marginals, as in bench.py)
         args = name[name.index('<') + 1:name.index('>')].split(',')
         mode = int(args[1])
-        return {0: 'k_framelogprob', 1: 'k_marginals<true>', 2: 'k_marginals<false>'}[mode]
+        return {0: 'k_framelogprob', 1: 'k_marginals<true>', 2: 'k_marginals<false>', 3: 'k_marginals<true>'}[mode]
     return None
 
 
