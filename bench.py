@@ -139,8 +139,15 @@ def main():
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if world > 1:
+        # RCCL over xGMI; BENCH_DIST_BACKEND=gloo rehearses the multi-rank control flow where ranks share a GPU
+        backend = os.environ.get('BENCH_DIST_BACKEND', 'nccl')
+        if backend != 'nccl':
+            local_rank = local_rank % max(1, torch.cuda.device_count())
         torch.cuda.set_device(local_rank)
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+        if backend == 'nccl':
+            dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+        else:
+            dist.init_process_group(backend)
     device = local_rank if world > 1 else 0
     torch.cuda.set_device(device)
 
@@ -188,7 +195,8 @@ def main():
         b_.profile_enable(0)
     prof = rs.profile()
     if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device='cuda')
+        cdev = 'cuda' if dist.get_backend() == 'nccl' else 'cpu'
+        tt = torch.tensor([dt], dtype=torch.float64, device=cdev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
         # final gather of the per-restart results (outside the timed region: it happens once per fit)
@@ -196,7 +204,7 @@ def main():
         names = list(rs.models[0].likelihood_params)
         ids = list(e.breakpoints.keys())
         packs = [_pack(r_, len(e.x), args.clones, len(ids), len(names), ids, names) for r_ in res]
-        ft = torch.from_numpy(np.stack([p_[0] for p_ in packs])).cuda()
+        ft = torch.from_numpy(np.stack([p_[0] for p_ in packs])).to(cdev)
         out = [torch.empty_like(ft) for _ in range(world)]
         dist.all_gather(out, ft)
 

@@ -1,5 +1,6 @@
 """CPU: the generator restatement of scipy's 1-D Nelder-Mead is scipy's, evaluation by evaluation."""
 import numpy as np
+import pytest
 import scipy.optimize
 
 from remixt_amd import lockstep
@@ -60,3 +61,71 @@ def test_run_lockstep_batches_rounds():
         ref = scipy.optimize.fmin(f, x0, full_output=1, disp=False)
         assert r[0][0] == ref[0][0] and r[3] == ref[3]
     assert rounds[0] == 12 and max(rounds) == 12 and len(rounds) == max(r[3] for r in res)
+
+
+def test_lbfgsb_gen_reproduces_scipy_minimize():
+    """The reverse-communication L-BFGS-B generator visits the points of scipy.optimize.minimize(method=
+    'L-BFGS-B', jac=..., bounds=...) in the same order and returns the same result, bit for bit (the h
+    M-step of BreakpointModel.update_h, cn_model.py:500-508, for all restarts in lock step)."""
+    import scipy.optimize
+    from remixt_amd import lockstep
+    if not lockstep.lbfgsb_available():
+        pytest.skip('scipy layout other than 1.15: RestartSet falls back to scipy.optimize.minimize per restart')
+    rng = np.random.RandomState(3)
+    for trial in range(6):
+        n = 3
+        A = rng.randn(n, n); A = A @ A.T + np.eye(n)
+        c = rng.randn(n) * (trial + 1)
+        fun = lambda x: float(0.5 * x @ A @ x - c @ x + np.sum(np.log1p(x * x)))
+        grad = lambda x: A @ x - c + 2 * x / (1 + x * x)
+        seen = []
+
+        def f_rec(x):
+            seen.append(np.array(x)); return fun(x)
+        x0 = rng.rand(n) * 12.0          # partly outside the upper bound: scipy clips
+        bounds = [(1e-8, 10.)] * n
+        ref = scipy.optimize.minimize(f_rec, x0, method='L-BFGS-B', jac=grad, bounds=bounds)
+        gen = lockstep.lbfgsb_gen(x0, bounds)
+        pts = []
+        try:
+            x = next(gen)
+            while True:
+                pts.append(np.array(x))
+                x = gen.send((fun(x), grad(x)))
+        except StopIteration as stop:
+            res = stop.value
+        assert len(pts) == len(seen) and all(np.array_equal(a, b) for a, b in zip(pts, seen))
+        assert np.array_equal(res.x, ref.x) and res.fun == ref.fun and res.nfev == ref.nfev and res.nit == ref.nit
+        assert res.success == ref.success and res.message == ref.message
+
+
+def test_lockstep_runs_generators_together():
+    from remixt_amd import lockstep
+    calls = []
+
+    def evaluate(ids, xs):
+        calls.append(list(ids))
+        return [float((x[0] - 3.0 - i) ** 2) for i, x in zip(ids, xs)]
+    out = lockstep.run_lockstep([lockstep.fmin_1d(1.0), lockstep.fmin_1d(2.0), lockstep.fmin_1d(10.0)], evaluate)
+    assert [abs(o[0][0] - (3.0 + i)) < 1e-3 for i, o in enumerate(out)] == [True] * 3
+    assert calls[0] == [0, 1, 2] and len(calls) < sum(o[3] for o in out)      # rounds are shared
+
+
+def test_sample_without_replacement_matches_numpy_distribution():
+    """Seeded restarts draw their M-step samples with one cumulative sum; the draws must follow the
+    distribution of numpy's choice(replace=False, p=...) (successive sampling)."""
+    from collections import Counter
+    from remixt_amd.cn_model import _sample_without_replacement as draw
+    p = np.array([.4, .3, .15, .1, .04, .01])
+    r1, r2 = np.random.RandomState(1), np.random.RandomState(2)
+    c1, c2 = Counter(), Counter()
+    for _ in range(20000):
+        c1[tuple(draw(r1, 6, 2, p))] += 1
+        c2[tuple(r2.choice(6, 2, replace=False, p=p))] += 1
+    for k in c2:
+        if c2[k] > 400:
+            assert abs(c1[k] - c2[k]) < 6 * np.sqrt(c2[k]), (k, c1[k], c2[k])
+    s = draw(np.random.RandomState(0), 5000, 200)
+    assert len(set(s.tolist())) == 200 and s.min() >= 0 and s.max() < 5000
+    with pytest.raises(ValueError):
+        draw(np.random.RandomState(0), 6, 3, np.array([.5, .5, 0, 0, 0, 0]))
