@@ -179,6 +179,16 @@ int rmx_expected_ll_h_batch(rmx_batch *b, int32_t nreq, const int32_t *restarts,
 /* E[ll] over ALL segments (the reference passes a mask of ones, cn_model.py:497, :524, :549, :563)
  * for restarts [r0, r1); out: [r1-r0]. */
 int rmx_expected_ll_full(rmx_batch *b, int32_t r0, int32_t r1, double *out);
+/* The M-step's accept test (`ell_after < ell_before`, cn_model.py:497-505, 563-569) without committing the
+ * tried values: full-data E[ll] at the current (changed) h / parameters, evaluated into scratch
+ * per-segment expectations -- same numbers as rmx_expected_ll_full -- leaving the restart's own
+ * expectations, cell cache and staleness flags untouched.  rmx_trial_rollback then puts the previous
+ * value back (param_id >= 0: likelihood parameter, values[0]; param_id < 0: h, values[0..M)) and declares
+ * the untouched expectations current again, so a rejected update costs no second pass over the cells.
+ * Valid only in the sequence rmx_expected_ll_full -> sampled evaluations -> rmx_expected_ll_full_trial ->
+ * accept (set the new value) | rmx_trial_rollback. */
+int rmx_expected_ll_full_trial(rmx_batch *b, int32_t r0, int32_t r1, double *out);
+int rmx_trial_rollback(rmx_batch *b, int32_t r, int32_t param_id, const double *values);
 /* per-cell values, for tests (:751-776, :809-853): u/v/w in {0,1} */
 int rmx_log_likelihood_total(rmx_batch *b, int32_t r, int32_t n, int32_t s, int32_t u, double *out);
 int rmx_log_likelihood_allele(rmx_batch *b, int32_t r, int32_t n, int32_t s, int32_t v, int32_t w, double *out);

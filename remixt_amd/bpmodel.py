@@ -350,6 +350,22 @@ class RemixtBatch(object):
         """E[ll] over all segments for restarts [r0, r1)."""
         return self._scalar_range(self._lib.rmx_expected_ll_full, r0, r1)
 
+    def expected_log_likelihood_full_trial(self, r0=None, r1=None):
+        """E[ll] over all segments at h / parameter values that are on trial (rmx_expected_ll_full_trial):
+        nothing of the restarts' committed state changes; follow with set_param / set h (accept) or
+        rollback_param / rollback_h (reject)."""
+        return self._scalar_range(self._lib.rmx_expected_ll_full_trial, r0, r1)
+
+    def rollback_param(self, r, name, value):
+        v = _f64([value])
+        self._ck(self._lib.rmx_trial_rollback(self._handle, int(r), PARAM_IDS[name], v.ctypes.data_as(_dp)))
+
+    def rollback_h(self, r, h):
+        v = _f64(h).ravel()
+        if len(v) != self.num_clones:
+            raise ValueError('h must have one entry per clone')
+        self._ck(self._lib.rmx_trial_rollback(self._handle, int(r), -1, v.ctypes.data_as(_dp)))
+
     def infer_cn(self, r):
         cn = np.zeros((self.num_segments, self.num_clones, 2), dtype=np.int64)
         lp = C.c_double(0.)

@@ -85,6 +85,7 @@ struct rmx_batch {
     std::vector<void *> allocs;
     // profiling
     bool fbk_ok = false;   // k_fbk usable: log-weights of every uniform class equal -pen * min(SAD, SAD swapped)
+    double *d_A2 = nullptr, *d_Bv2 = nullptr;   // [R][N][2], [R][N][4]: (A, B) of a trial parameter value (rmx_expected_ll_full_trial)
     uint32_t *d_cnpack = nullptr, *d_totpack = nullptr; double *d_wk = nullptr;   // [C][S], [C][S], [TC][64]
     int pe2p = 0;     // padded row length of pe2_lt (0: no product table)
     int spc = 0;      // row stride of the pair-code table
@@ -713,6 +714,7 @@ int rmx_batch_create(const rmx_problem *pr, int32_t R, const double *h_init, con
         b->spc = ((S + 63) / 64) * 64;
         DA(pcode, uint16_t, (size_t)std::max(d.TC, 1) * ((S + 7) & ~7) * b->spc) DA(jord, int32_t, (size_t)C * S) DA(jmeta, int32_t, (size_t)C * S)
     } else { d.pcode = nullptr; d.jord = nullptr; d.jmeta = nullptr; }
+    if ((rc = dalloc(b, &b->d_A2, RN * 2)) || (rc = dalloc(b, &b->d_Bv2, RN * 4))) { rmx_batch_destroy(b); return rc; }
     if ((rc = dalloc(b, &b->d_cnpack, (size_t)C * S)) || (rc = dalloc(b, &b->d_totpack, (size_t)C * S)) || (rc = dalloc(b, &b->d_wk, (size_t)std::max(d.TC, 1) * 64))) { rmx_batch_destroy(b); return rc; }
     DA(pd_cached, double, BEW) DA(hist, double, BEW) DA(be_jt, double, (size_t)R * d.NBE) DA(be_ja, double, (size_t)R * d.NBE)
     DA(err, uint32_t, R)
@@ -1661,6 +1663,56 @@ int rmx_expected_ll_full(rmx_batch *b, int32_t r0, int32_t r1, double *out) {
     HIPCHK(hipMemcpyAsync(b->h_pinned, b->d_out4, (size_t)nr * 8, hipMemcpyDeviceToHost, b->stream));
     if ((rc = check_errors(b, r0, r1))) return rc;
     for (int i = 0; i < nr; i++) out[i] = b->h_pinned[i];
+    return RMX_OK;
+}
+
+// Full-data E[ll] at parameter values that are on TRIAL: h / likelihood parameters were changed (the
+// M-step's accept test `ell_after < ell_before`, cn_model.py:497-505, 563-569) but may be rolled back.
+// The stale components of (A, B) are evaluated into a scratch copy -- the same values, reduced in the
+// same order, as a refresh would produce -- while the restart's own (A, B), its cell cache and its
+// staleness flags stay as they are.  A rejected value then costs no second pass over the cells:
+// rmx_trial_rollback puts the old value back and declares (A, B) / cache current again.
+int rmx_expected_ll_full_trial(rmx_batch *b, int32_t r0, int32_t r1, double *out) {
+    RANGE_CHECK();
+    int rc = ensure_tables(b, r0, r1);
+    if (rc) return rc;
+    const Dev &d = b->d;
+    const int nr = r1 - r0;
+    const size_t RN0 = (size_t)r0 * d.N, cnt = (size_t)nr * d.N;
+    HIPCHK(hipMemcpyAsync(b->d_A2 + RN0 * 2, d.A + RN0 * 2, cnt * 16, hipMemcpyDeviceToDevice, b->stream));
+    HIPCHK(hipMemcpyAsync(b->d_Bv2 + RN0 * 4, d.Bv + RN0 * 4, cnt * 32, hipMemcpyDeviceToDevice, b->stream));
+    Dev d2 = b->d;
+    d2.A = b->d_A2; d2.Bv = b->d_Bv2; d2.lc = nullptr;
+    for (int r = r0; r < r1;) {
+        const int mask = use_strip(b) ? cover_mask(b->comp_dirty[r] & 15) : (b->comp_dirty[r] ? 15 : 0);
+        int e = r + 1;
+        while (e < r1 && (use_strip(b) ? cover_mask(b->comp_dirty[e] & 15) : (b->comp_dirty[e] ? 15 : 0)) == mask) e++;
+        if (mask) {
+            ProfScope ps(b, KID_MARGINALS_AB);
+            if (use_strip(b)) hipLaunchKernelGGL(cells_kernel(b, 2, mask, 0), strip_grid(b, e - r), dim3(256), 0, b->stream, d2, r);
+            else hipLaunchKernelGGL(k_marginals<false>, row_grid(b, e - r), dim3(256), 0, b->stream, d2, r, b->G);
+        }
+        r = e;
+    }
+    { ProfScope ps(b, KID_ELL_FULL); hipLaunchKernelGGL(k_ell_full_batch, dim3(ELBO_BLOCKS, nr), dim3(256), 0, b->stream, d2, r0, b->d_partial); }
+    { ProfScope ps(b, KID_ELL_FINAL); hipLaunchKernelGGL(k_sum_partials, dim3(nr), dim3(256), 0, b->stream, (const double *)b->d_partial, ELBO_BLOCKS, b->d_out4); }
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(b->h_pinned, b->d_out4, (size_t)nr * 8, hipMemcpyDeviceToHost, b->stream));
+    if ((rc = check_errors(b, r0, r1))) return rc;
+    for (int i = 0; i < nr; i++) out[i] = b->h_pinned[i];
+    return RMX_OK;
+}
+// Undo a trial: param_id >= 0 puts likelihood parameter param_id of restart r back to values[0];
+// param_id < 0 puts h back to values[0..M).  Only valid when (A, B) and the cell cache were current for
+// exactly these values before the trial and nothing refreshed them since (no coordinate update, ELBO or
+// rmx_expected_ll_full in between) -- which is the M-step's sequence: full E[ll], search on samples,
+// rmx_expected_ll_full_trial, then accept (set the new value) or this.
+int rmx_trial_rollback(rmx_batch *b, int32_t r, int32_t param_id, const double *values) {
+    if (!b || r < 0 || r >= b->R || !values || param_id >= RMX_P_HMM_LOG_NORM_CONST) return fail(RMX_EARG, "bad argument");
+    if (param_id >= 0) b->rp[r].p[param_id] = param_id == RMX_P_DIVERGENCE_WEIGHT ? std::fabs(values[0]) : values[0];
+    else for (int m = 0; m < b->d.M; m++) b->rp[r].h[m] = values[m];
+    b->tables_dirty[r] = 1; b->segc_dirty[r] = 1;      // the device tables hold the trial values
+    b->ab_dirty[r] = 0; b->comp_dirty[r] = 0; b->cache_stale[r] = 0;
     return RMX_OK;
 }
 

@@ -185,6 +185,7 @@ class RestartSet(object):
                 m.rng.set_state(rng_state[r])
             return False
         failed = set()
+        trial = hasattr(b, 'expected_log_likelihood_full_trial')
         for r, res in zip(active, results):
             m = self.models[r]
             try:
@@ -203,17 +204,28 @@ class RestartSet(object):
             except ValueError as err:
                 if self.strict:
                     raise
-                m.model.h = h_before[r]
                 failed.add(r)
                 self.error_messages[r] = str(err).splitlines()[0] + ' (h kept)'
-        ell_after = b.expected_log_likelihood_full(0, R)
+        # accept test on trial values; a restart that keeps its h is rolled back without a second pass
+        # over the cells (its expectations and cell cache still belong to h_before)
+        ell_after = b.expected_log_likelihood_full_trial(0, R) if trial else None
+        for r in failed:
+            if trial:
+                b.rollback_h(r, h_before[r])
+            else:
+                self.models[r].model.h = h_before[r]
+        if not trial:
+            ell_after = b.expected_log_likelihood_full(0, R)
         for r in active:
             if r in failed:
                 continue
             m = self.models[r]
             if ell_after[r] < ell_before[r]:
                 m._log('h rejected, elbo before: {}, after: {}'.format(ell_before[r], ell_after[r]))
-                m.model.h = h_before[r]
+                if trial:
+                    b.rollback_h(r, h_before[r])
+                else:
+                    m.model.h = h_before[r]
         return True
 
     def _update_params_lockstep(self):
@@ -237,11 +249,17 @@ class RestartSet(object):
                 xopt = b.param_search(ids_all, name, lo, hi, grid)       # the same search, host loop in C++
             else:
                 xopt = self._param_search_python(name, lo, hi, grid)
-            ell_after = b.expected_log_likelihood_full(0, R)
+            # the accept test on trial values: a rejected value is rolled back without a second pass over
+            # the cells (the restart's expectations and cell cache still belong to value_before)
+            trial = hasattr(b, 'expected_log_likelihood_full_trial')
+            ell_after = b.expected_log_likelihood_full_trial(0, R) if trial else b.expected_log_likelihood_full(0, R)
             for r, m in enumerate(self.models):
                 if ell_after[r] < ell_before[r]:
                     m._log('{} rejected, elbo before: {}, after: {}'.format(name, ell_before[r], ell_after[r]))
-                    b.set_param(r, name, value_before[r])
+                    if trial:
+                        b.rollback_param(r, name, value_before[r])
+                    else:
+                        b.set_param(r, name, value_before[r])
                 else:
                     b.set_param(r, name, float(xopt[r]))
 
