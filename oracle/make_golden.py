@@ -195,6 +195,71 @@ def chain_kats(bp):
     np.savez_compressed(os.path.join(OUT, 'chains.npz'), **out)
 
 
+def experiment_tables(N, seed, chains=6):
+    """Count and breakpoint tables in the reference's TSV layout (analysis/experiment.py:228-241) built
+    from the synthetic generator, with the awkward breakpoints the mapping has to handle: exact hits,
+    near misses inside and beyond max_brk_dist, wild-type-looking events, loop-backs, a chromosome without
+    counts, gaps above max_seg_gap."""
+    import pandas as pd
+    rng = np.random.RandomState(seed)
+    e = synthetic.make_experiment(N, num_clones=3, max_copy_number=6, num_chains=chains, seed=seed)
+    start = e.segment_start.copy(); end = e.segment_end.copy()
+    # a 5 Mb hole inside chromosome 2 (above the 3 Mb max_seg_gap) and small gaps elsewhere
+    chrom = np.asarray(e.segment_chromosome_id)
+    idx2 = np.nonzero(chrom == '2')[0]
+    if len(idx2) > 4:
+        start[idx2[len(idx2) // 2]:idx2[-1] + 1] += 5000000; end[idx2[len(idx2) // 2]:idx2[-1] + 1] += 5000000
+    counts = pd.DataFrame({'chromosome': chrom, 'start': start, 'end': end, 'length': np.asarray(e.l),
+                           'major_readcount': e.x[:, 0].astype(int), 'minor_readcount': e.x[:, 1].astype(int), 'readcount': e.x[:, 2].astype(int),
+                           'major_is_allele_a': rng.randint(0, 2, size=N)})
+    rows = []
+    def end_of(n, side):
+        return (chrom[n], '+' if side == 1 else '-', int(end[n] if side == 1 else start[n]))
+    pid = 0
+    for k in range(40):
+        n1, n2 = int(rng.randint(0, N)), int(rng.randint(0, N))
+        s1, s2 = int(rng.randint(0, 2)), int(rng.randint(0, 2))
+        c1, st1, p1 = end_of(n1, s1); c2, st2, p2 = end_of(n2, s2)
+        jitter = [0, 0, 150, -300, 900, 1500, 2500][k % 7]
+        rows.append((pid, c1, st1, p1 + jitter, c2, st2, p2 - jitter // 2)); pid += 1
+    for n in (3, 10, 11):                       # wild-type-looking: end of n joined to start of n+1
+        if chrom[n] == chrom[n + 1]:
+            rows.append((pid, chrom[n], '+', int(end[n]), chrom[n + 1], '-', int(start[n + 1]))); pid += 1
+    rows.append((pid, chrom[5], '+', int(end[5]), chrom[5], '+', int(end[5]) + 3)); pid += 1      # loop-back on one extremity
+    rows.append((pid, 'Y', '+', 12345, chrom[7], '-', int(start[7]))); pid += 1                   # chromosome without counts
+    rows.append((pid, chrom[8], '-', int(start[8]), chrom[20 % N], '+', int(end[20 % N]))); pid += 1
+    perm = rng.permutation(len(rows))
+    brk = pd.DataFrame([rows[i] for i in perm], columns=['prediction_id', 'chromosome_1', 'strand_1', 'position_1', 'chromosome_2', 'strand_2', 'position_2'])
+    return counts, brk
+
+
+def experiment_case(name, N, seed):
+    """Experiment construction: the reference's Experiment on count / breakpoint
+    tables; records the tables and what the hot path reads from the object."""
+    lk, ex, rd, pl = refload.load_ref_analysis()
+    counts, brk = experiment_tables(N, seed)
+    e = ex.Experiment(counts.copy(), brk.copy())
+    out = {}
+    for c in counts.columns:
+        out['counts/' + c] = counts[c].values if counts[c].dtype != object else counts[c].values.astype(str)
+    for c in brk.columns:
+        out['brk/' + c] = brk[c].values if brk[c].dtype != object else brk[c].values.astype(str)
+    out['adjacencies'] = adjacency_array(e.adjacencies)
+    bsd = e.breakpoint_segment_data
+    for c in ('prediction_id', 'n_1', 'side_1', 'n_2', 'side_2'):
+        out['bsd/' + c] = bsd[c].values.astype(np.int64)
+    out['chains'] = np.array(list(e.chains), dtype=np.int64)
+    out['x'] = e.x; out['l'] = e.l
+    closest = ex.find_closest_segment_end(e.count_data, e.breakpoint_data).sort_values(['prediction_id', 'prediction_side'])
+    for c in ('prediction_id', 'prediction_side', 'dist', 'segment_idx', 'segment_side'):
+        out['closest/' + c] = closest[c].values.astype(np.int64)
+    a = np.sort(np.random.RandomState(seed).randint(0, 1000, size=50)); v = np.random.RandomState(seed + 1).randint(-50, 1100, size=80)
+    i_, d_ = ex.find_closest(a, v)
+    out['fc/a'] = a; out['fc/v'] = v; out['fc/idx'] = i_; out['fc/dist'] = d_
+    np.savez_compressed(os.path.join(OUT, name + '.npz'), **out)
+    print(name, 'breakpoints kept', len(bsd), 'of', len(brk), 'adjacencies', len(e.adjacencies))
+
+
 def pipeline_case(name, N, seed, max_cn=8, **config):
     """Read-depth initialisation and result tables: the reference's readdepth /
     likelihood / experiment-table functions and its `init` on a synthetic experiment.  `init` reads a
@@ -262,6 +327,7 @@ def main():
     model_case(cm, 'model_nonormal', N=36, M=2, max_cn=3, chains=2, seed=3, normal_contamination=False, zero_alleles=(4,))
     model_case(cm, 'model_malex', N=36, M=3, max_cn=2, chains=3, seed=4, male_x=True)
     pipeline_case('pipeline_init', N=1200, seed=5)
+    experiment_case('experiment_tables', N=240, seed=8)
     pipeline_case('pipeline_init_strict', N=900, seed=6, min_ploidy=7.5, max_ploidy=8.0, random_seed=99)
     pipeline_case('pipeline_init_closest', N=900, seed=7, min_ploidy=2.95, max_ploidy=3.0, random_seed=7)
 
