@@ -1079,7 +1079,7 @@ __global__ void k_marginals(Dev d, int r0, int G) {
 //   MODE 2: refresh of the components of (A, B) selected by MASK            -- k_marginals<false>
 //   MODE 3: MODE 1, then -- everything below is local to the segment -- update_p_outlier_total,
 //           update_p_outlier_allele, the NEXT sweep's update_p_allele_swap and update_framelogprob from
-//           the cell values already in registers (CACHE 2 only): between two sweeps of one
+//           the cached cell values (CACHE 2 only; their second read hits L2): between two sweeps of one
 //           rmx_variational_update call the six cached planes are streamed once instead of twice
 // grid (ceil(N / (4*RPW)), nr), block 256.
 // =============================================================================
@@ -1165,7 +1165,6 @@ __global__ __launch_bounds__(256) void k_cells(Dev d, int r0) {
         } else {
             constexpr bool M1 = MODE == 1 || MODE == 3;
             double pv[NS];
-            double L6[MODE == 3 ? NS : 1][6];
             double sum = 0.;
             if (M1) {
 #pragma unroll
@@ -1190,7 +1189,6 @@ __global__ __launch_bounds__(256) void k_cells(Dev d, int r0) {
                     double LT[2], LA[4];
                     cell(sc, st[k], (size_t)n * d.SP + s, LT, LA);
                     const double ps = pv[k];
-                    if (MODE == 3) { L6[k][0] = LT[0]; L6[k][1] = LT[1]; L6[k][2] = LA[0]; L6[k][3] = LA[1]; L6[k][4] = LA[2]; L6[k][5] = LA[3]; }
                     a0 += ps * LT[0]; a1 += ps * LT[1];
                     b0 += ps * LA[0]; b1 += ps * LA[1]; b2 += ps * LA[2]; b3 += ps * LA[3];
                     if (M1 || (MASK & 16)) { pf += ps * d.f[ro + s]; pp += ps * (-1.0 * (CACHE == 2 ? nsub_of(cls, s) : st[k].nsub) * sc.l * divw); }
@@ -1259,9 +1257,13 @@ __global__ __launch_bounds__(256) void k_cells(Dev d, int r0) {
                     const int s = lane + 64 * k;
                     fv[k] = -INFINITY;
                     if (s < S) {
+                        // (the six values were streamed a moment ago for the expectations: this second read
+                        // hits L2; keeping 6 x NS doubles live instead costs a wave per SIMD of occupancy)
+                        double LT[2], LA[4];
+                        cell(sc, st[k], (size_t)n * d.SP + s, LT, LA);
                         double f = 0.;
-                        f += qt0 * L6[k][0]; f += qt1 * L6[k][1];
-                        f += qa0 * qs0 * L6[k][2]; f += qa0 * qs1 * L6[k][3]; f += qa1 * qs0 * L6[k][4]; f += qa1 * qs1 * L6[k][5];
+                        f += qt0 * LT[0]; f += qt1 * LT[1];
+                        f += qa0 * qs0 * LA[0]; f += qa0 * qs1 * LA[1]; f += qa1 * qs0 * LA[2]; f += qa1 * qs1 * LA[3];
                         f += -1.0 * nsub_of(cls, s) * sc.l * divw;
                         if (f != f) err |= RMX_ERR_NAN_F;
                         d.f[ro + s] = f;
