@@ -339,19 +339,7 @@ static double plain_T_mean_sum(rmx_batch *b) {
 
 // ---- FB configuration -----------------------------------------------------------
 typedef void (*fb_kernel_t)(FbArgs);
-static fb_kernel_t fb_kernel_for(int rpt) {
-    switch (rpt) {
-    case 2: return k_fb<2, 1024>;
-    case 4: return k_fb<4, 1024>;
-    case 8: return k_fb<8, 1024>;
-    case 16: return k_fb<16, 1024>;
-    case 24: return k_fb<24, 1024>;
-    case 32: return k_fb<32, 768>;
-    case 42: return k_fb<42, 704>;
-    case 44: return k_fb<44, 704>;
-    default: return k_fb<0, 1024>;
-    }
-}
+static fb_kernel_t fb_kernel_for(int) { return k_fb<1024>; }
 typedef void (*fbv_kernel_t)(FbvArgs);
 static fbv_kernel_t fbv_kernel_for(int rpt, int nv, int blk) {
     (void)blk;
@@ -380,27 +368,17 @@ static void fb_layout(rmx_batch *b, int rpt, int P, FbLaunch &L, size_t &lds, in
     L.BLK = std::max(1, blk);
     lds = fixed + (size_t)FB_NBUF * L.BLK * b->d.SP * 8;
 }
-static const int kRpts[] = {2, 4, 8, 16, 24, 32, 42, 44};
-static int fb_ntmax(int rpt) { return rpt >= 42 ? 704 : (rpt >= 32 ? 768 : 1024); }
 static void configure_fb(rmx_batch *b) {
     const int S = b->d.S;
-    // slices of the reduction index: as few as keep the per-thread weight slice in registers, but
-    // enough threads to give every SIMD of the CU work
-    int P = 1;
-    while ((S + P - 1) / P > 44) P++;
-    while (S * (P + 1) <= 512 && (S + P) / (P + 1) >= 2) P++;
-    int need = (S + P - 1) / P, rpt = 0;
-    for (int v : kRpts) if (v >= need) { rpt = v; break; }
+    // general single-vector kernel: as many slices of the reduction index as fit 1024 threads
     int PG = 1;
     while (S * (PG + 1) <= 1024 && (S + PG) / (PG + 1) >= 1 && PG < 16) PG++;
-    if (rpt == 0 || S * P > fb_ntmax(rpt) || getenv("RMX_FB_GENERIC")) rpt = 0;
+    // multi-vector register kernel (chains of one state-table class): rows per slice for 8 slices
     b->fbv_rpt = 0;
-    if (!getenv("RMX_FB_GENERIC") && !getenv("RMX_FB_SINGLE")) { for (int v : {2, 6, 14, 22}) if (8 * v >= S) { b->fbv_rpt = v; break; } }
-    b->fb_rpt = rpt;
-    if (rpt > 0) fb_layout(b, rpt, P, b->fbL, b->fb_lds, &b->fb_amat_lds);
+    if (!getenv("RMX_FB_GENERIC")) { for (int v : {2, 6, 14, 22}) if (8 * v >= S) { b->fbv_rpt = v; break; } }
+    b->fb_rpt = 0;
     fb_layout(b, 0, PG, b->fbG, b->fbG_lds, nullptr);
     // more than 64 KiB of dynamic LDS needs an explicit opt-in per kernel
-    if (rpt > 0) hipFuncSetAttribute((const void *)fb_kernel_for(rpt), hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->fb_lds);
     hipFuncSetAttribute((const void *)fb_kernel_for(0), hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->fbG_lds);
 }
 

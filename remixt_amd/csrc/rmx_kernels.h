@@ -142,10 +142,9 @@ __global__ void k_framelogprob(Dev d, int r0, int G) {
 // scales themselves (row maxima, fmax) are kept to rebuild hmm_log_norm_const.
 //
 // One workgroup per (chain, restart, direction).  Thread (o, p): output state o,
-// slice p of the reduction index q.  With RPT > 0 the plain-adjacency transition
-// weights W[q][o] of the thread's slice live in registers for the whole chain
-// (they only change with the transition class); breakend adjacencies build their
-// weights on the fly from the per-breakend distance tables (bpmodel.pyx:658-668).
+// slice p of the reduction index q.  Plain-adjacency weights W[q][o] come from the
+// transition class's table; breakend adjacencies build their weights on the fly from
+// the per-breakend distance tables (bpmodel.pyx:658-668).
 // One barrier per step: the unnormalised vector and the per-wave maxima are
 // published together and the division by the maximum is applied by the consumer.
 // =============================================================================
@@ -199,8 +198,9 @@ __device__ __forceinline__ void gstore8(double *dst, double v) {
 }
 __device__ __forceinline__ unsigned lds_addr(const void *p) { return (unsigned)(size_t)(lptr_t)p; }
 
-// RPT > 0: register-stationary weights, only for chains whose segments all share one state-table
-// class (chain_tc[chain] >= 0; the host routes the other chains to the RPT == 0 kernel).
+// k_fb is the general single-vector kernel: any chain (segments of different state-table classes, any S up
+// to 1024), weights read from the tabulated S x S matrices in L2.  Chains of one class go to k_fbv /
+// k_fbk below, which is where the time is spent.
 //
 // Thread t = p * S + o: slice p of the reduction index for output state o (slices are packed
 // back to back, so a wave may straddle two slices).  A step is
@@ -214,7 +214,7 @@ __device__ __forceinline__ unsigned lds_addr(const void *p) { return (unsigned)(
 #else
 #define FB_STAMP(i_)
 #endif
-template <int RPT, int NTMAX>
+template <int NTMAX>
 __global__ __launch_bounds__(NTMAX) void k_fb(FbArgs a) {
     extern __shared__ __align__(16) unsigned char smem_raw[];
     const int chain = a.chain_list[blockIdx.x], r = a.r0 + blockIdx.y, dir = blockIdx.z;
@@ -225,7 +225,7 @@ __global__ __launch_bounds__(NTMAX) void k_fb(FbArgs a) {
     const int p = t / S, o = t - p * S;
     const bool act = p < PP;                            // thread takes part in phase 1
     const bool post = t < S;                            // thread takes part in phase 2
-    const int QPT = (RPT > 0) ? RPT : (S + PP - 1) / PP;
+    const int QPT = (S + PP - 1) / PP;
     const int SPAD = a.SPAD, BLK = a.BLK;
     const int MDP = (M * D + 1) & ~1;                   // breakend table row, padded to 16 bytes
     // LDS carve-up (one array: see cdna_hip_programming.md 5, trap 4a)
@@ -237,12 +237,7 @@ __global__ __launch_bounds__(NTMAX) void k_fb(FbArgs a) {
     double *wa = pel + MDP;                             // [128] exp(-pen*a) for the allele-flip term
     int *meta = (int *)(wa + 128);                      // [NBUF][2][64]  tclass / brk_slot per step (LDS-DMA)
     int8_t *totl = (int8_t *)(meta + FB_NBUF * 2 * 64); // [C][S][M]
-    int8_t *atl = totl + ((a.C * S * M + 15) & ~15);    // [S][S] allele-flip term of the chain's class (RPT > 0, if it fits)
     for (int i = t; i < a.C * S * M; i += NT) totl[i] = a.tot[i];
-    if (RPT > 0 && a.amat_lds) {
-        const int8_t *src = (dir == 0 ? a.af : a.ab) + (size_t)a.chain_tc[chain] * S * S;
-        for (int i = t; i < S * S; i += NT) atl[i] = src[i];
-    }
     for (int i = t; i < 2 * SPAD; i += NT) vec[i] = 0.;   // tails [S, SPAD) stay zero: padded slices read them
     for (int i = t; i < 128; i += NT) wa[i] = exp(-a.pen * (double)i);
     for (int i = t; i < FB_NBUF * 2 * 64; i += NT) meta[i] = -1;
@@ -255,20 +250,6 @@ __global__ __launch_bounds__(NTMAX) void k_fb(FbArgs a) {
     double *mrow = a.mrow + rbase;
     const double *Wmat = dir == 0 ? a.Wf : a.Wb;
 
-    // ---- stationary weights: loaded once, consumed before the loop --------------------
-    double w[RPT > 0 ? RPT : 1];
-    if constexpr (RPT > 0) {
-        const double *Wt = Wmat + (size_t)a.chain_tc[chain] * S * S;
-#pragma unroll
-        for (int rr = 0; rr < RPT; rr++) { const int q = p * RPT + rr; w[rr] = (act && q < S) ? Wt[(size_t)q * S + o] : 0.; }
-        // consume the loads here: a load hipcc believes may still be pending at the loop's first FMA
-        // costs an s_waitcnt vmcnt(0) in EVERY step, which also waits for the result stores
-#pragma unroll
-        for (int rr = 0; rr < RPT; rr++) asm volatile("" ::"v"(w[rr]));
-    }
-    // the chain's state-table class, fetched once (same reason)
-    int chain_cls_ = RPT > 0 ? __builtin_amdgcn_readfirstlane(a.chain_cls[chain]) : 0;
-    asm volatile("" : "+s"(chain_cls_));
     __syncthreads();   // LDS initialisation done
 
 #define ROW(k) (dir == 0 ? n0 + (k) : n1 - (k))
@@ -348,33 +329,8 @@ __global__ __launch_bounds__(NTMAX) void k_fb(FbArgs a) {
         // ============================ phase 1: partial products ============================
         double acc = 0.;
         if (bs < 0) {
-            if constexpr (RPT > 0) {
-                // 8 rows (4 LDS reads) per stage, software-pipelined one stage ahead; two accumulators
-                // halve the dependent-FMA chain.  sched_barrier pins the stage order so the staged
-                // vector values never occupy more than two stages of registers.
-                double acc2 = 0.;
-                const double *vp = vc + p * RPT;
-                constexpr int NST = (RPT + 7) / 8;
-                double2 st[2][4];
-#pragma unroll
-                for (int u = 0; u < 4; u++) if (2 * u < RPT) st[0][u] = *reinterpret_cast<const double2 *>(vp + 2 * u);
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int c = 0; c < NST; c++) {
-                    const int c0 = c * 8, n0_ = c0 + 8;
-                    if (c + 1 < NST) {
-#pragma unroll
-                        for (int u = 0; u < 4; u++) if (n0_ + 2 * u < RPT) st[(c + 1) & 1][u] = *reinterpret_cast<const double2 *>(vp + n0_ + 2 * u);
-                    }
-#pragma unroll
-                    for (int u = 0; u < 4; u++) if (c0 + 2 * u < RPT) { acc = fma(st[c & 1][u].x, w[c0 + 2 * u], acc); acc2 = fma(st[c & 1][u].y, w[c0 + 2 * u + 1], acc2); }
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-                acc += acc2;
-            } else {
-                const double *Wt = Wmat + (size_t)meta[(slot * 2 + 0) * 64 + kidx] * S * S;
-                if (act) for (int rr = 0; rr < QPT; rr++) { const int q = p * QPT + rr; if (q < S) acc = fma(vc[q], Wt[(size_t)q * S + o], acc); }
-            }
+            const double *Wt = Wmat + (size_t)meta[(slot * 2 + 0) * 64 + kidx] * S * S;
+            if (act) for (int rr = 0; rr < QPT; rr++) { const int q = p * QPT + rr; if (q < S) acc = fma(vc[q], Wt[(size_t)q * S + o], acc); }
         } else {
             // ---- breakend adjacency: W[i][j] = prod_m exp(-pen*pd_m[d_m(i,j)]) * exp(-pen*a(i,j)) ----
             const int tc = meta[(slot * 2 + 0) * 64 + kidx];
@@ -386,10 +342,8 @@ __global__ __launch_bounds__(NTMAX) void k_fb(FbArgs a) {
             FB_BARRIER();
             int ca, cb;
             const int8_t *at;
-            if (RPT > 0) { ca = cb = chain_cls_; }                  // fast chains: one state-table class throughout
-            else { ca = a.be_cls[2 * bs]; cb = a.be_cls[2 * bs + 1]; }
-            if (RPT > 0 && a.amat_lds) at = atl;
-            else at = (dir == 0 ? a.af : a.ab) + (size_t)tc * S * S;
+            ca = a.be_cls[2 * bs]; cb = a.be_cls[2 * bs + 1];
+            at = (dir == 0 ? a.af : a.ab) + (size_t)tc * S * S;
             // fwd: q = from-state (class ca), o = to-state (class cb); bwd: q = to-state (cb), o = from-state (ca)
             const int8_t *tq = totl + (size_t)(dir == 0 ? ca : cb) * S * M;
             const int8_t *to = totl + (size_t)(dir == 0 ? cb : ca) * S * M;
