@@ -439,6 +439,8 @@ static cells_kernel_t cells_kernel(rmx_batch *b, int mode, int mask, int cache) 
                   case 3: return cells_kernel_ns<3>(mode, mask, cache); case 4: return cells_kernel_ns<4>(mode, mask, cache);
                   case 5: return cells_kernel_ns<5>(mode, mask, cache); default: return cells_kernel_ns<6>(mode, mask, cache); }
 }
+// block size of the sampled-objective kernels: one lane per state, whole waves, at most 256
+static dim3 ell_block(rmx_batch *b) { return dim3(std::min(256, ((b->d.S + 63) / 64) * 64)); }
 static dim3 strip_grid(rmx_batch *b, int nr) { return dim3((b->d.N + 4 * STRIP_RPW - 1) / (4 * STRIP_RPW), nr); }
 // smallest instantiated component mask covering `m`
 static int cover_mask(int m) {
@@ -1250,8 +1252,8 @@ static int queue_ell(rmx_batch *b, int r, bool grad, double *dst) {
         if ((rc = ensure_tables(b, r, r + 1, false))) return rc;
         {
             ProfScope ps(b, KID_ELL_LIST);
-            if (grad) hipLaunchKernelGGL(k_ell_list<true>, dim3(cnt), dim3(256), 0, b->stream, b->d, r, list, partial);
-            else hipLaunchKernelGGL(k_ell_list<false>, dim3(cnt), dim3(256), 0, b->stream, b->d, r, list, partial);
+            if (grad) hipLaunchKernelGGL(k_ell_list<true>, dim3(cnt), ell_block(b), 0, b->stream, b->d, r, list, partial);
+            else hipLaunchKernelGGL(k_ell_list<false>, dim3(cnt), ell_block(b), 0, b->stream, b->d, r, list, partial);
         }
         { ProfScope ps(b, KID_ELL_FINAL); hipLaunchKernelGGL(k_ell_final, dim3(1), dim3(256), 0, b->stream, (const double *)partial, cnt, dst); }
     }
@@ -1358,7 +1360,7 @@ static int run_ell_batch(rmx_batch *b, int nreq, const int32_t *restarts, bool g
         const int pstride = std::max(d.N, ELBO_BLOCKS) * W;
         if (maxcnt > 0) {
             ProfScope ps(b, KID_ELL_LIST);
-            if (grad) hipLaunchKernelGGL(k_ell_list_batch<true>, dim3(maxcnt, nreq), dim3(256), 0, b->stream, b->d, (const int32_t *)b->d_rlist, (const RestartParams *)b->d_rp_stage,
+            if (grad) hipLaunchKernelGGL(k_ell_list_batch<true>, dim3(maxcnt, nreq), ell_block(b), 0, b->stream, b->d, (const int32_t *)b->d_rlist, (const RestartParams *)b->d_rp_stage,
                                          (const int32_t *)b->d_sample, (const int32_t *)b->d_counts, b->d_ell_partial, pstride);
             else {
                 void (*kf)(Dev, const int32_t *, const RestartParams *, const int32_t *, const int32_t *, double *, int) = k_ell_list_batch<false, CM_ALL>;
@@ -1368,7 +1370,7 @@ static int run_ell_batch(rmx_batch *b, int nreq, const int32_t *restarts, bool g
                 case 8: kf = k_ell_list_batch<false, 8>; break; case 12: kf = k_ell_list_batch<false, 12>; break;
                 default: break;
                 }
-                hipLaunchKernelGGL(kf, dim3(maxcnt, nreq), dim3(256), 0, b->stream, b->d, (const int32_t *)b->d_rlist, (const RestartParams *)b->d_rp_stage,
+                hipLaunchKernelGGL(kf, dim3(maxcnt, nreq), ell_block(b), 0, b->stream, b->d, (const int32_t *)b->d_rlist, (const RestartParams *)b->d_rp_stage,
                                    (const int32_t *)b->d_sample, (const int32_t *)b->d_counts, b->d_ell_partial, pstride);
             }
         }
@@ -1560,7 +1562,7 @@ int rmx_param_search(rmx_batch *b, int32_t nreq, const int32_t *restarts, int32_
                 ProfScope ps(b, KID_ELL_LIST);
                 void (*kf)(Dev, SearchVals, const int32_t *, const int32_t *, double *, int) =
                     mask == CM_LT0 ? k_ell_search<CM_LT0> : (mask == CM_LT1 ? k_ell_search<CM_LT1> : (mask == CM_LA0 ? k_ell_search<CM_LA0> : k_ell_search<CM_LA1>));
-                hipLaunchKernelGGL(kf, dim3(maxcnt, n_, Gz), dim3(256), 0, b->stream, b->d, sv, (const int32_t *)b->d_sample, (const int32_t *)b->d_counts, b->d_ell_partial, std::max(maxcnt, 1));
+                hipLaunchKernelGGL(kf, dim3(maxcnt, n_, Gz), ell_block(b), 0, b->stream, b->d, sv, (const int32_t *)b->d_sample, (const int32_t *)b->d_counts, b->d_ell_partial, std::max(maxcnt, 1));
             }
             { ProfScope ps(b, KID_ELL_FINAL); hipLaunchKernelGGL(k_ell_search_final, dim3(n_ * Gz), dim3(256), 0, b->stream, b->d, sv, (const int32_t *)b->d_counts, (const double *)b->d_ell_partial, std::max(maxcnt, 1), b->h_pinned, b->h_err); }
             HIPCHK(hipGetLastError());

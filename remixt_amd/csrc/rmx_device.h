@@ -392,6 +392,19 @@ __device__ __forceinline__ double group_max(double v, int G) {
     return v;
 }
 
+// the same with the number of waves taken from the launch (blocks of 64 * k threads): the per-wave sums are
+// added in wave order, so a block of fewer waves whose dropped lanes would have contributed zeros gives the
+// same bits
+__device__ inline double block_sum_rt(double v, double *scratch /* >= blockDim.x/64 */) {
+    v = group_sum(v, 64);
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    __syncthreads();
+    if (lane == 0) scratch[w] = v;
+    __syncthreads();
+    double t = 0.;
+    if (threadIdx.x == 0) for (int i = 0; i < (int)(blockDim.x >> 6); i++) t += scratch[i];
+    return t;
+}
 // block-wide deterministic sum (fixed tree): all threads must call; result valid in thread 0
 template <int NT> __device__ inline double block_sum(double v, double *scratch /* >= NT/64 */) {
     v = group_sum(v, 64);

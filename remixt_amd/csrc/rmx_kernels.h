@@ -1750,7 +1750,7 @@ __device__ __forceinline__ void ell_segment(const Dev &d, const RestartParams &r
     const double *post = d.post + rs_off(d, r, n);
     unsigned err = 0;
     double acc = 0., g[RMX_MAX_CLONES] = {0., 0., 0., 0.};
-    for (int s = threadIdx.x; s < d.S; s += 256) {
+    for (int s = threadIdx.x; s < d.S; s += blockDim.x) {      // blocks of min(256, 64 * ceil(S / 64)) threads
         double LT[2], LA[4];
         if (MASK == CM_ALL) cell_ll(d, rp, sc, r, cls, s, LT, LA, err);
         else {
@@ -1815,11 +1815,11 @@ __device__ __forceinline__ void ell_segment(const Dev &d, const RestartParams &r
             }
         }
     }
-    acc = block_sum<256>(acc, scratch);
+    acc = block_sum_rt(acc, scratch);
     if (threadIdx.x == 0) prow[0] = acc;
     if (GRAD)
         for (int m = 0; m < RMX_MAX_CLONES; m++) {
-            const double gm = block_sum<256>(g[m], scratch);
+            const double gm = block_sum_rt(g[m], scratch);
             if (threadIdx.x == 0) prow[1 + m] = gm;
         }
     if (err) atomicOr(&d.err[r], err);
