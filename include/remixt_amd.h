@@ -128,6 +128,9 @@ int rmx_get_array(rmx_batch *b, int32_t r, int32_t array_id, void *host_dst);
 /* read-only derived state tables, (N,S[,M]) int64 like the reference attributes
  * cn_states_total / num_alleles_subclonal / is_hdel / is_loh (bpmodel.pyx:497-507):
  * which = 0..3 in that order */
+/* calculate_log_transmat(out) (bpmodel.pyx:639-684): dense (N-1) x S x S log transition array for the CURRENT
+ * p_breakpoint of restart r into a host array of 8 (N-1) S^2 bytes; no model state changes. */
+int rmx_calculate_log_transmat(rmx_batch *b, int32_t r, double *dst);
 int rmx_get_state_table(rmx_batch *b, int32_t which, int64_t *host_dst);
 
 /* -- coordinate updates (bpmodel.pyx cpdef methods), restarts [r0,r1) ------ */

@@ -530,10 +530,14 @@ class RemixtModel(object):
         partial_h[:] = g
 
     def calculate_log_transmat(self, log_transmat):
-        """bpmodel.pyx:639-684 with the *current* p_breakpoint, into the caller's array."""
+        """bpmodel.pyx:639-684 with the *current* p_breakpoint, into the caller's (N-1, S, S) array."""
         b = self._batch
-        # materialise through the cached snapshot slot without disturbing it: use a scratch restart-free path
-        raise NotImplementedError('calculate_log_transmat(out): read model.log_transmat / model.cached_log_transmat instead')
+        out = np.ascontiguousarray(log_transmat, dtype=np.float64)
+        if out.shape != (b.num_segments - 1, b.num_cn_states, b.num_cn_states):
+            raise ValueError('log_transmat must have shape (num_segments - 1, num_cn_states, num_cn_states)')
+        b._ck(b._lib.rmx_calculate_log_transmat(b._handle, self._r, out.ctypes.data_as(_dp)))
+        if out is not log_transmat:
+            np.asarray(log_transmat)[...] = out
 
     def calculate_log_likelihood_total(self, n, s, u):
         out = C.c_double(0.)

@@ -943,6 +943,28 @@ int rmx_get_array(rmx_batch *b, int32_t r, int32_t id, void *dst) {
     return RMX_OK;
 }
 
+// calculate_log_transmat(out) (bpmodel.pyx:639-684): the dense (N-1) x S x S log transition array for the
+// CURRENT p_breakpoint of restart r, into the caller's host array.  Neither the log_transmat snapshot of
+// the last update_p_cn nor cached_log_transmat is touched.  Size warning: 8 (N-1) S^2 bytes.
+int rmx_calculate_log_transmat(rmx_batch *b, int32_t r, double *dst) {
+    if (!b || r < 0 || r >= b->R || !dst) return fail(RMX_EARG, "bad argument");
+    const Dev &d = b->d;
+    if (d.N < 2) return RMX_OK;
+    const size_t cnt = (size_t)(d.N - 1) * d.S * d.S;
+    double *tmp = nullptr, *pd = nullptr;
+    HIPCHK(hipMalloc((void **)&tmp, cnt * 8));
+    if (hipMalloc((void **)&pd, std::max<size_t>((size_t)b->R * d.NBE * d.M * d.D, 1) * 8) != hipSuccess) { hipFree(tmp); return fail(RMX_EDEVICE, "out of device memory"); }
+    if (d.NBE > 0) hipLaunchKernelGGL(k_brk_lut, dim3(d.NBE, 1), dim3(64), 0, b->stream, b->d, r, pd, (double *)nullptr, (double *)nullptr, 0);
+    Dev d2 = b->d;
+    d2.pd_lt = pd;
+    hipLaunchKernelGGL(k_materialize_T, dim3(d.N - 1), dim3(256), 0, b->stream, d2, r, 0, 0, tmp);
+    hipError_t e = hipMemcpyAsync(dst, tmp, cnt * 8, hipMemcpyDeviceToHost, b->stream);
+    hipStreamSynchronize(b->stream);
+    hipFree(tmp); hipFree(pd);
+    if (e != hipSuccess) return fail(RMX_EDEVICE, hipGetErrorString(e));
+    return RMX_OK;
+}
+
 int rmx_get_state_table(rmx_batch *b, int32_t which, int64_t *dst) {
     const Dev &d = b->d;
     const int S = d.S, M = d.M;

@@ -86,6 +86,26 @@ def test_coordinate_updates_match_oracle(hip, oracle_mod, M, max_cn, N, chains, 
     assert np.array_equal(cna, cnb)
 
 
+def test_calculate_log_transmat_into_caller_buffer(hip, oracle_mod):
+    """calculate_log_transmat(out) (bpmodel.pyx:639-684): dense transitions for the CURRENT p_breakpoint,
+    neither snapshot touched."""
+    a, h, _ = H.make_model(hip, N=60, M=3, max_cn=3, chains=3, seed=5)
+    b, _, _ = H.make_model(oracle_mod, N=60, M=3, max_cn=3, chains=3, seed=5)
+    ma, mb = H.attach(a, h), H.attach(b, h)
+    a.variational_update(); b.variational_update()
+    for m in (ma, mb):
+        pb = np.asarray(m.p_breakpoint).copy()
+        pb[:] = np.linspace(1., 2., pb.shape[1])[None, :]
+        pb /= pb.sum(axis=1)[:, None]
+        m.p_breakpoint = pb
+    N, S = ma.num_segments, ma.num_cn_states
+    ta, tb = np.full((N - 1, S, S), np.nan), np.full((N - 1, S, S), np.nan)
+    snap = np.asarray(ma.log_transmat).copy()
+    ma.calculate_log_transmat(ta); mb.calculate_log_transmat(tb)
+    assert np.allclose(ta, tb, rtol=1e-12, atol=1e-12)
+    assert np.array_equal(np.asarray(ma.log_transmat), snap) and not np.array_equal(ta, snap)
+
+
 def test_module_sum_product_max_product(hip, oracle_mod):
     rng = np.random.RandomState(0)
     f = rng.rand(6, 5); T = -rng.rand(5, 5, 5)
