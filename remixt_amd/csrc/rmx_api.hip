@@ -75,9 +75,8 @@ struct rmx_batch {
     uint16_t *d_bp = nullptr; double *d_final = nullptr; int64_t *d_path = nullptr; double *d_logprob = nullptr;
     std::vector<int64_t> last_path;
     // FB launch configuration
-    int fb_rpt = 0; FbLaunch fbL{}; size_t fb_lds = 0;
     FbLaunch fbG{}; size_t fbG_lds = 0;   // generic kernel configuration
-    int n_fast = 0, n_generic = 0, fb_amat_lds = 0;
+    int n_fast = 0, n_generic = 0;
     unsigned long long *d_dbg = nullptr;
     int fbv_rpt = 0;   // rows per slice of the multi-vector kernel (0 = not applicable)
     int G = 64;
@@ -376,7 +375,6 @@ static void configure_fb(rmx_batch *b) {
     // multi-vector register kernel (chains of one state-table class): rows per slice for 8 slices
     b->fbv_rpt = 0;
     if (!getenv("RMX_FB_GENERIC")) { for (int v : {2, 6, 14, 22}) if (8 * v >= S) { b->fbv_rpt = v; break; } }
-    b->fb_rpt = 0;
     fb_layout(b, 0, PG, b->fbG, b->fbG_lds, nullptr);
     // more than 64 KiB of dynamic LDS needs an explicit opt-in per kernel
     hipFuncSetAttribute((const void *)fb_kernel_for(0), hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->fbG_lds);
@@ -773,7 +771,7 @@ int rmx_batch_create(const rmx_problem *pr, int32_t R, const double *h_init, con
     if (getenv("RMX_FB_DEBUG")) { if ((rc = dalloc(b, &b->d_dbg, 32))) { rmx_batch_destroy(b); return rc; } HIPCHK(hipMemset(b->d_dbg, 0, 256)); }
     b->G = S > 32 ? 64 : (S > 16 ? 32 : (S > 8 ? 16 : 8));
     configure_fb(b);
-    if (b->fb_lds > 160 * 1024 || b->fbG_lds > 160 * 1024) { rmx_batch_destroy(b); return fail(RMX_EUNSUPPORTED, "LDS budget exceeded"); }
+    if (b->fbG_lds > 160 * 1024) { rmx_batch_destroy(b); return fail(RMX_EUNSUPPORTED, "LDS budget exceeded"); }
     // cached_log_transmat of the constructor (:604) + pairwise reductions of the uniform joint
     if ((rc = launch_brk_lut(b, 0, R, d.pd_cached, nullptr)) || (rc = launch_pairwise_breakends(b, 0, R, 1))) { rmx_batch_destroy(b); return rc; }
     b->plain_T_init.assign(R, plain_T_mean_sum(b));
@@ -815,8 +813,8 @@ int rmx_synchronize(rmx_batch *b) { HIPCHK(hipStreamSynchronize(b->stream)); ret
 int rmx_info(rmx_batch *b, int32_t what, int64_t *out) {
     switch (what) {
     case 0: *out = b->d.cn_max; break; case 1: *out = b->d.NC; break; case 2: *out = b->d.TC; break; case 3: *out = b->d.NBE; break;
-    case 4: *out = b->d.SP; break; case 5: *out = b->fb_rpt; break; case 6: *out = b->fbL.P; break; case 7: *out = b->fbL.NT; break;
-    case 8: *out = b->fbL.BLK; break; case 9: *out = (int64_t)b->fb_lds; break; case 10: *out = b->n_fast; break; case 11: *out = b->n_generic; break;
+    case 4: *out = b->d.SP; break; case 5: *out = b->fbv_rpt; break; case 6: *out = b->fbG.P; break; case 7: *out = b->fbG.NT; break;
+    case 8: *out = b->fbG.BLK; break; case 9: *out = (int64_t)b->fbG_lds; break; case 10: *out = b->n_fast; break; case 11: *out = b->n_generic; break;
     case 20: case 21: case 22: case 23: case 24: case 25: case 26: case 27: case 28: case 29: case 30: case 31: case 32: case 33: case 34: case 35: case 36: case 37: case 38: case 39:
     case 40: case 41: case 42: case 43: case 44: case 45: case 46: case 47: case 48: case 49: case 50: case 51:
         { if (!b->d_dbg) { *out = 0; break; } unsigned long long v[32]; HIPCHK(hipStreamSynchronize(b->stream)); HIPCHK(hipMemcpy(v, b->d_dbg, 256, hipMemcpyDeviceToHost)); *out = (int64_t)v[what - 20]; break; }
@@ -1024,7 +1022,7 @@ static int do_update_p_cn(rmx_batch *b, int r0, int r1, bool skip_frame = false,
         a.chain_tc = d.chain_tc; a.chain_cls = d.chain_cls; a.be_cls = d.be_cls; a.amat_lds = 0; a.pad_ = 0;
         a.fe = d.fe; a.Wf = d.Wf; a.Wb = d.Wb; a.pe_lt = d.pe_lt; a.af = d.af; a.ab = d.ab; a.tot = d.tot;
         a.fa = d.fa; a.fb = d.fb; a.mrow = d.mrow; a.err = d.err; a.dbg = b->d_dbg;
-        bool fast = b->fb_rpt > 0;
+        bool fast = false;
         bool done_fast = false;
         if (b->fbv_rpt > 0 && b->n_fast > 0) {
             // multi-vector kernel: NV restarts per workgroup, as few as keep the grid within one wave
@@ -1101,10 +1099,6 @@ static int do_update_p_cn(rmx_batch *b, int r0, int r1, bool skip_frame = false,
                 hipLaunchKernelGGL(kf, dim3(b->n_fast, (nr + NV - 1) / NV, 2), dim3(nt), lds, b->stream, v, (const double *)b->d_wk, (const uint32_t *)b->d_cnpack, (const uint32_t *)b->d_totpack);
                 done_fast = true; fast = true;
             }
-        }
-        if (!done_fast && fast && b->n_fast > 0) {
-            a.P = b->fbL.P; a.BLK = b->fbL.BLK; a.SPAD = b->fbL.SPAD; a.chain_list = d.chain_list_fast; a.amat_lds = b->fb_amat_lds;
-            hipLaunchKernelGGL(fb_kernel_for(b->fb_rpt), dim3(b->n_fast, r1 - r0, 2), dim3(b->fbL.NT), b->fb_lds, b->stream, a);
         }
         const int ngen = fast ? b->n_generic : d.NC;
         if (ngen > 0) {
