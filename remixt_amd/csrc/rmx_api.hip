@@ -496,7 +496,7 @@ static int launch_pairwise_breakends(rmx_batch *b, int r0, int r1, int mode) {
     const Dev &d = b->d;
     const int nt = ((d.S + 63) / 64) * 64;
     const size_t lds = ((size_t)((d.S + 1) & ~1) + ((d.M * d.D + 1) & ~1) + 128 + (size_t)nt * d.M * (d.cn_max + 2)) * 8 + (size_t)d.S * 4 + 64;
-    const size_t lds2 = ((size_t)((d.S + 7) & ~7) + b->pe2p + 128 + (size_t)nt * (d.M - 1) * (d.cn_max + 2) + nt) * 8 + (size_t)((d.S + 7) & ~7) * 4 + 64;
+    const size_t lds2 = ((size_t)((d.S + 7) & ~7) + b->pe2p + 128 + (size_t)nt * (d.M - 1) * (d.cn_max + 2) + nt + 3 * d.M * d.D) * 8 + (size_t)((d.S + 7) & ~7) * 4 + (size_t)d.S * 4 + 64;
     if (mode == 0 && b->pcode_ok && lds2 <= 150 * 1024 && !getenv("RMX_PAIRWISE_OLD") && !getenv("RMX_PAIRWISE_V1")) {
         HIPCHK(hipFuncSetAttribute((const void *)k_pairwise_be2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
         hipLaunchKernelGGL(k_pairwise_be2, dim3(d.NBE, r1 - r0), dim3(nt), lds2, b->stream, b->d, r0, b->pe2p, b->spc);

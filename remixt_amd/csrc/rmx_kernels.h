@@ -1516,11 +1516,18 @@ __global__ void k_pairwise_be2(Dev d, int r0, int PE2P, int SPC) {
     double *wa = tab + PE2P;                              // [128]
     double *bins = wa + 128;                              // [NT][M-1][NB] tumour clones; [NT] row sums behind them (the normal clone's single bin)
     double *zrow = bins + (size_t)NT * (M - 1) * NB;
-    int *jm = (int *)(zrow + NT);                         // [S8] jmeta of class cb, zero-padded
+    double *fold = zrow + NT;                             // [3][M*D] partial sums of the fold
+    int *jm = (int *)(fold + 3 * M * D);                  // [S8] jmeta of class cb, zero-padded
+    int *toti = jm + ((S + 7) & ~7);                      // [S] totals of the row states (class ca), one byte per clone
     const double *fb = d.fb + rs_off(d, r, n + 1), *fe = d.fe + rs_off(d, r, n + 1);
     for (int jj = t; jj < ((S + 7) & ~7); jj += NT) {
         if (jj < S) { const int j = d.jord[(size_t)cb * S + jj]; gvec[jj] = fe[j] * fb[j]; jm[jj] = d.jmeta[(size_t)cb * S + jj]; }
         else { gvec[jj] = 0.; jm[jj] = 0; }
+    }
+    for (int i = t; i < S; i += NT) {
+        int pk = 0;
+        for (int c = 0; c < M; c++) pk |= ((int)d.tot[((size_t)ca * S + i) * M + c] & 0xff) << (8 * c);
+        toti[i] = pk;
     }
     const double *tg = d.pe2_lt + ((size_t)r * d.NBE + slot) * PE2P;
     for (int i = t; i < PE2P; i += NT) tab[i] = tc >= 0 ? tg[i] : 1.0;
@@ -1573,32 +1580,42 @@ __global__ void k_pairwise_be2(Dev d, int r0, int PE2P, int SPC) {
     if (t == 0) { double zz = 0., aa = 0.; for (int w_ = 0; w_ < NT / 64; w_++) { zz += scratch[w_]; aa += scratch[8 + w_]; } zsh = zz; jash = aa; }
     __syncthreads();
     const double zz = zsh;
-    // fold the private bins: hist[c][d] = sum_i bins[i][c][tot_i,c - d]
+    // fold the private bins: hist[c][d] = sum_i bins[i][c][tot_i,c - d].  Three threads per (c, d), each over
+    // every third row, combined in fixed order; row totals come from LDS
     double *hist = d.hist + ((size_t)r * d.NBE + slot) * M * D;
-    for (int i = t; i < M * D; i += NT) {
+    const int t0b = (int)d.tot[(size_t)cb * S * M];
+    for (int tt = t; tt < 3 * M * D; tt += NT) {
+        const int i = tt / 3, part_ = tt - i * 3;
         const int c = i / D, dv = i % D - (d.cn_max + 1);
         double acc = 0.;
-        if (c == 0) {
-            const int t0b = (int)d.tot[(size_t)cb * S * M];
-            for (int row = 0; row < S; row++) if ((int)d.tot[((size_t)ca * S + row) * M] - dv == t0b) acc += zrow[row];
-        } else {
-            for (int row = 0; row < S; row++) {
-                const int tj = (int)d.tot[((size_t)ca * S + row) * M + c] - dv;
-                if (tj >= 0 && tj < NB) acc += bins[((size_t)row * (M - 1) + (c - 1)) * NB + tj];
-            }
+        for (int row = part_; row < S; row += 3) {
+            const int tj = ((toti[row] >> (8 * c)) & 0xff) - dv;
+            if (c == 0) { if (tj == t0b) acc += zrow[row]; }
+            else if (tj >= 0 && tj < NB) acc += bins[((size_t)row * (M - 1) + (c - 1)) * NB + tj];
         }
-        hist[i] = acc / zz;
+        fold[part_ * M * D + i] = acc;
     }
     __syncthreads();
-    if (t == 0) {
-        d.be_ja[(size_t)r * d.NBE + slot] = jash / zz;
+    double *hl = fold;                                      // fold[0][i] becomes hist[i]
+    for (int i = t; i < M * D; i += NT) {       // (entry i of the three partial rows is touched by this thread only)
+        const double v = ((fold[i] + fold[M * D + i]) + fold[2 * M * D + i]) / zz;
+        hl[i] = v;
+        hist[i] = v;
+    }
+    __syncthreads();
+    if (t < 64) {
+        // sum joint*T = -pen * (sum_c sum_d hist_c[d] * pd_c[d] + sum joint*a)
         double jt = 0.;
         if (tc >= 0) {
             const double *pd = d.pd_lt + ((size_t)r * d.NBE + slot) * M * D;
-            for (int i = 0; i < M * D; i++) jt += hist[i] * (-d.pen * pd[i]);
-            jt += -d.pen * (jash / zz);
+            for (int i = t; i < M * D; i += 64) jt += hl[i] * (-d.pen * pd[i]);
         }
-        d.be_jt[(size_t)r * d.NBE + slot] = jt;
+        jt = group_sum(jt, 64);
+        if (t == 0) {
+            d.be_ja[(size_t)r * d.NBE + slot] = jash / zz;
+            if (tc >= 0) jt += -d.pen * (jash / zz);
+            d.be_jt[(size_t)r * d.NBE + slot] = jt;
+        }
     }
 }
 
