@@ -1118,6 +1118,8 @@ __global__ __launch_bounds__(256) void k_cells(Dev d, int r0) {
             for (int k = 0; k < NS; k++) { const int s = lane + 64 * k; if (s < d.SP) d.fe[ro + s] = s < S ? exp(fv[k] - vmax) : 0.; }
         } else {
             constexpr bool M1 = MODE == 1 || MODE == 3;
+            constexpr bool STASH = MODE == 3 && NS <= 3;
+            __shared__ double lsm[STASH ? 4 : 1][STASH ? NS * 6 * 64 : 1];
             double pv[NS];
             double sum = 0.;
             if (M1) {
@@ -1130,7 +1132,8 @@ __global__ __launch_bounds__(256) void k_cells(Dev d, int r0) {
                 for (int k = 0; k < NS; k++) { pv[k] = pv[k] / sum; s2 += pv[k]; }
                 s2 = group_sum(s2, 64);
 #pragma unroll
-                for (int k = 0; k < NS; k++) { const int s = lane + 64 * k; pv[k] = pv[k] / s2; if (s < S) d.post[ro + s] = pv[k]; }   // second renormalisation of _exp_normalize
+                // (a fused pass keeps the posterior in registers: nothing reads d.post before the last, unfused, sweep of the call writes it)
+                for (int k = 0; k < NS; k++) { const int s = lane + 64 * k; pv[k] = pv[k] / s2; if (MODE != 3 && s < S) d.post[ro + s] = pv[k]; }   // second renormalisation of _exp_normalize
             } else {
 #pragma unroll
                 for (int k = 0; k < NS; k++) { const int s = lane + 64 * k; pv[k] = s < S ? d.post[ro + s] : 0.; }
@@ -1143,6 +1146,12 @@ __global__ __launch_bounds__(256) void k_cells(Dev d, int r0) {
                     double LT[2], LA[4];
                     cell(sc, st[k], (size_t)n * d.SP + s, LT, LA);
                     const double ps = pv[k];
+                    if (STASH) {
+#pragma unroll
+                        for (int q_ = 0; q_ < 2; q_++) lsm[wave][(k * 6 + q_) * 64 + lane] = LT[q_];
+#pragma unroll
+                        for (int q_ = 0; q_ < 4; q_++) lsm[wave][(k * 6 + 2 + q_) * 64 + lane] = LA[q_];
+                    }
                     a0 += ps * LT[0]; a1 += ps * LT[1];
                     b0 += ps * LA[0]; b1 += ps * LA[1]; b2 += ps * LA[2]; b3 += ps * LA[3];
                     if (M1 || (MASK & 16)) { pf += ps * d.f[ro + s]; pp += ps * (-1.0 * (CACHE == 2 ? nsub_of(cls, s) : st[k].nsub) * sc.l * divw); }
@@ -1211,10 +1220,16 @@ __global__ __launch_bounds__(256) void k_cells(Dev d, int r0) {
                     const int s = lane + 64 * k;
                     fv[k] = -INFINITY;
                     if (s < S) {
-                        // (the six values were streamed a moment ago for the expectations: this second read
-                        // hits L2; keeping 6 x NS doubles live instead costs a wave per SIMD of occupancy)
+                        // the six values were streamed a moment ago for the expectations: up to 192 states they
+                        // wait in a wave-private LDS stash (36 KB per block); beyond, they are read again (L2 /
+                        // MALL).  Keeping 6 x NS doubles live in registers would cost a wave per SIMD of occupancy.
                         double LT[2], LA[4];
-                        cell(sc, st[k], (size_t)n * d.SP + s, LT, LA);
+                        if (STASH) {
+#pragma unroll
+                            for (int q_ = 0; q_ < 2; q_++) LT[q_] = lsm[wave][(k * 6 + q_) * 64 + lane];
+#pragma unroll
+                            for (int q_ = 0; q_ < 4; q_++) LA[q_] = lsm[wave][(k * 6 + 2 + q_) * 64 + lane];
+                        } else cell(sc, st[k], (size_t)n * d.SP + s, LT, LA);
                         double f = 0.;
                         f += qt0 * LT[0]; f += qt1 * LT[1];
                         f += qa0 * qs0 * LA[0]; f += qa0 * qs1 * LA[1]; f += qa1 * qs0 * LA[2]; f += qa1 * qs1 * LA[3];
