@@ -206,6 +206,12 @@ __device__ __forceinline__ void load_state_regs(const Dev &d, int r, int cls, in
     st.nsub = (double)((d.sflags[(size_t)cls * d.S + s] >> 2) & 3);
 }
 
+// Posterior mass below which a state's term post * ll is dropped from an expectation when ALL 64 states
+// of a wave are below it: |ll| < 1e7, so such a group adds less than 64 * 1e-23 to sums of magnitude
+// >= 1 -- far under half an ulp, the rounded sum is the same.  (Posteriors concentrate on a few
+// neighbouring states; whole 64-state groups are skipped on most segments.)
+#define RMX_POST_EPS 1e-30
+
 // component mask of cell_ll_regs: which of the six values the caller needs
 #define CM_LT0 1
 #define CM_LT1 2

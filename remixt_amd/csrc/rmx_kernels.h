@@ -1142,6 +1142,8 @@ __global__ __launch_bounds__(256) void k_cells(Dev d, int r0) {
 #pragma unroll
             for (int k = 0; k < NS; k++) {
                 const int s = lane + 64 * k;
+                // (trial passes -- expectations only, nothing cached: a group of 64 states without posterior mass adds nothing)
+                if (MODE == 2 && CACHE == 0 && !(MASK & 16) && !__any(pv[k] >= RMX_POST_EPS)) continue;
                 if (s < S) {
                     double LT[2], LA[4];
                     cell(sc, st[k], (size_t)n * d.SP + s, LT, LA);
@@ -1782,7 +1784,11 @@ __device__ __forceinline__ void ell_segment(const Dev &d, const RestartParams &r
     const double *post = d.post + rs_off(d, r, n);
     unsigned err = 0;
     double acc = 0., g[RMX_MAX_CLONES] = {0., 0., 0., 0.};
-    for (int s = threadIdx.x; s < d.S; s += blockDim.x) {      // blocks of min(256, 64 * ceil(S / 64)) threads
+    for (int s0 = 0; s0 < d.S; s0 += blockDim.x) {      // blocks of min(256, 64 * ceil(S / 64)) threads
+        const int s = s0 + threadIdx.x;
+        const double ps_ = s < d.S ? post[s] : 0.;
+        if (!GRAD && !__any(ps_ >= RMX_POST_EPS)) continue;      // wave-uniform: no posterior mass in this group of 64 states
+        if (s >= d.S) continue;
         double LT[2], LA[4];
         if (MASK == CM_ALL) cell_ll(d, rp, sc, r, cls, s, LT, LA, err);
         else {
@@ -1794,7 +1800,7 @@ __device__ __forceinline__ void ell_segment(const Dev &d, const RestartParams &r
             }
             cell_ll_regs<MASK>(rp, sc, st_, LT, LA, err);
         }
-        const double ps = post[s];
+        const double ps = ps_;
         if (MASK & CM_LT0) acc += ps * qt0 * LT[0];
         if (MASK & CM_LT1) acc += ps * qt1 * LT[1];
         if (MASK & CM_LA0) { acc += ps * qa0 * qs0 * LA[0]; acc += ps * qa0 * qs1 * LA[1]; }
