@@ -269,6 +269,19 @@ __device__ __forceinline__ void cell_ll_regs(const RestartParams &rp, const SegC
     }
 }
 
+// The part of cell_ll_regs' error reporting that does not need the cell evaluated: the state-table
+// flags of invalid states raise for every segment that looks at the allele likelihood, whatever the
+// state's posterior mass -- kernels that skip states without posterior mass call this for them, so
+// that the reference's ValueErrors (bpmodel.pyx:717-733, 823-853) are raised in the same situations.
+template <int MASK>
+__device__ __forceinline__ void cell_static_errors(const SegCtx &sc, unsigned fl, unsigned &err) {
+    if ((MASK & (CM_LA0 | CM_LA1)) && sc.ma) {
+        if (fl & ST_E_TD) err |= RMX_ERR_TOTAL_DEPTH;
+        if (fl & ST_E_LOH) err |= RMX_ERR_LOH_P;
+        if (!(sc.ys == 0. || (fl & (ST_E_TD | ST_E_LOH))) && (fl & ST_E_BADP)) err |= RMX_ERR_BAD_P;
+    }
+}
+
 // The six likelihood values of one (segment,state) cell, table-driven entry point:
 //   LT[u]      = calculate_log_likelihood_total(n,s,u)      (bpmodel.pyx:751-776)
 //   LA[v*2+w]  = calculate_log_likelihood_allele(n,s,v,w)   (bpmodel.pyx:809-853)

@@ -1143,7 +1143,7 @@ __global__ __launch_bounds__(256) void k_cells(Dev d, int r0) {
             for (int k = 0; k < NS; k++) {
                 const int s = lane + 64 * k;
                 // (trial passes -- expectations only, nothing cached: a group of 64 states without posterior mass adds nothing)
-                if (MODE == 2 && CACHE == 0 && !(MASK & 16) && !__any(pv[k] >= RMX_POST_EPS)) continue;
+                if (MODE == 2 && CACHE == 0 && !(MASK & 16) && !__any(pv[k] >= RMX_POST_EPS)) { if (s < S) cell_static_errors<MASK & CM_ALL>(sc, st[k].fl, err); continue; }
                 if (s < S) {
                     double LT[2], LA[4];
                     cell(sc, st[k], (size_t)n * d.SP + s, LT, LA);
@@ -1787,7 +1787,10 @@ __device__ __forceinline__ void ell_segment(const Dev &d, const RestartParams &r
     for (int s0 = 0; s0 < d.S; s0 += blockDim.x) {      // blocks of min(256, 64 * ceil(S / 64)) threads
         const int s = s0 + threadIdx.x;
         const double ps_ = s < d.S ? post[s] : 0.;
-        if (!GRAD && !__any(ps_ >= RMX_POST_EPS)) continue;      // wave-uniform: no posterior mass in this group of 64 states
+        if (!GRAD && !__any(ps_ >= RMX_POST_EPS)) {      // wave-uniform: no posterior mass in this group of 64 states
+            if (s < d.S) cell_static_errors<MASK>(sc, d.stFlags[((size_t)r * d.C + cls) * d.SP + s], err);      // (its state-table errors still count)
+            continue;
+        }
         if (s >= d.S) continue;
         double LT[2], LA[4];
         if (MASK == CM_ALL) cell_ll(d, rp, sc, r, cls, s, LT, LA, err);
