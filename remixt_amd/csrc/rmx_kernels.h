@@ -78,10 +78,10 @@ __device__ __forceinline__ double seg_const_value(const RestartParams &rp, doubl
     // i in 0..3: NB constants [u*2+var]; i in 4..7: BB constants [v*2+var]
     if (i < 4) {
         const double rr = rp.p[i == 0 ? RMX_P_NEGBIN_R_0 : (i == 1 ? RMX_P_NEGBIN_HDEL_R_0 : (i == 2 ? RMX_P_NEGBIN_R_1 : RMX_P_NEGBIN_HDEL_R_1))];
-        return lgamma(x + rr) - lgamma(x + 1) - lgamma(rr);
+        return lgamma_pos(x + rr) - lgamma_pos(x + 1) - lgamma_pos(rr);
     }
     const double MM = rp.p[i == 4 ? RMX_P_BETABIN_M_0 : (i == 5 ? RMX_P_BETABIN_LOH_M_0 : (i == 6 ? RMX_P_BETABIN_M_1 : RMX_P_BETABIN_LOH_M_1))];
-    return (lgamma(ys + 1) - lgamma(y0 + 1) - lgamma(ys - y0 + 1)) - lgamma(ys + MM) + lgamma(MM);
+    return (lgamma_pos(ys + 1) - lgamma_pos(y0 + 1) - lgamma_pos(ys - y0 + 1)) - lgamma_pos(ys + MM) + lgamma_pos(MM);
 }
 __global__ void k_seg_const(Dev d, int r0) {
     const int n = blockIdx.x * blockDim.x + threadIdx.x, r = r0 + blockIdx.y;
