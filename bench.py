@@ -274,7 +274,7 @@ def main():
                 line['states_355'] = extra_states(args, rs, device)
             except Exception as err:      # never let the extra measurement hide the headline number
                 line['states_355'] = {'error': str(err)}
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:      # reported baseline, rank 0 at N = 1 only
             line['cpu_baseline'] = cpu_baseline(args)
         print(json.dumps(line))
     if world > 1:
