@@ -48,7 +48,7 @@ def test_kat4_known_answers(hip):
     assert np.array_equal(brk['b0'], [0, 0])
 
 
-@pytest.mark.parametrize('M,max_cn,N,chains,nc', [(2, 4, 150, 3, True), (3, 3, 120, 4, True), (3, 4, 90, 1, True),
+@pytest.mark.parametrize('M,max_cn,N,chains,nc', [(2, 4, 150, 3, True), (2, 6, 400, 4, True), (3, 3, 120, 4, True), (3, 4, 90, 1, True),
                                                  (2, 3, 100, 5, False), (3, 2, 80, 2, False)])
 def test_coordinate_updates_match_oracle(hip, oracle_mod, M, max_cn, N, chains, nc):
     a, h, _ = H.make_model(hip, N=N, M=M, max_cn=max_cn, chains=chains, seed=M * 10 + max_cn, normal_contamination=nc)
