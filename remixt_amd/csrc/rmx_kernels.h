@@ -1156,7 +1156,7 @@ __global__ __launch_bounds__(256) void k_cells(Dev d, int r0) {
                     }
                     a0 += ps * LT[0]; a1 += ps * LT[1];
                     b0 += ps * LA[0]; b1 += ps * LA[1]; b2 += ps * LA[2]; b3 += ps * LA[3];
-                    if (M1 || (MASK & 16)) { pf += ps * d.f[ro + s]; pp += ps * (-1.0 * (CACHE == 2 ? nsub_of(cls, s) : st[k].nsub) * sc.l * divw); }
+                    if (MODE == 1 || (MODE == 2 && (MASK & 16))) { pf += ps * d.f[ro + s]; pp += ps * (-1.0 * (CACHE == 2 ? nsub_of(cls, s) : st[k].nsub) * sc.l * divw); }
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -1164,11 +1164,12 @@ __global__ __launch_bounds__(256) void k_cells(Dev d, int r0) {
             if (MASK & CM_LT1) { a1 = group_sum(a1, 64); if (lane == 0) d.A[rn * 2 + 1] = a1; }
             if (MASK & CM_LA0) { b0 = group_sum(b0, 64); b1 = group_sum(b1, 64); if (lane == 0) { d.Bv[rn * 4] = b0; d.Bv[rn * 4 + 1] = b1; } }
             if (MASK & CM_LA1) { b2 = group_sum(b2, 64); b3 = group_sum(b3, 64); if (lane == 0) { d.Bv[rn * 4 + 2] = b2; d.Bv[rn * 4 + 3] = b3; } }
-            if (M1 || (MASK & 16)) {
+            // (a fused pass is never the last of its call: the ELBO terms PF, PP, Z of its sweep are not read by anyone)
+            if (MODE == 1 || (MODE == 2 && (MASK & 16))) {
                 pf = group_sum(pf, 64); pp = group_sum(pp, 64);
                 if (lane == 0) { d.rowPF[rn] = pf; d.rowPP[rn] = pp; }
             }
-            if (M1 && lane == 0) d.rowZ[rn] = d.fmax[rn] + (d.chain_end_flag[n] ? log(sum) : log(d.mrow[rn]));
+            if (MODE == 1 && lane == 0) d.rowZ[rn] = d.fmax[rn] + (d.chain_end_flag[n] ? log(sum) : log(d.mrow[rn]));
             if (MODE == 3) {
                 // lane 0's sums are the ones the stand-alone kernels would read back from (A, B)
                 auto b0_ = [](double v) { return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v))); };
