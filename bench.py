@@ -45,8 +45,8 @@ def alg_flops_per_cell(name, S):
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=2)
-    ap.add_argument('--warmup', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=6)
+    ap.add_argument('--warmup', type=int, default=2)
     ap.add_argument('--segments', type=int, default=50000)
     ap.add_argument('--clones', type=int, default=3)
     ap.add_argument('--max-cn', type=int, default=8)
