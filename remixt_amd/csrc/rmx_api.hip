@@ -50,6 +50,7 @@ struct rmx_batch {
     // per-restart host state
     std::vector<RestartParams> rp;
     std::vector<char> tables_dirty, segc_dirty, ab_dirty;
+    std::vector<char> sig_valid;       // per restart: the lists of states with posterior mass belong to the current posterior
     std::vector<int> cache_stale;      // components of the cell cache that are not current (CM_* bits); 15 = nothing cached
     bool use_cache = false;
     std::vector<int> comp_dirty;       // which components of (A, B, PF/PP) are stale: CM_* bits, 16 = PF/PP
@@ -697,7 +698,11 @@ int rmx_batch_create(const rmx_problem *pr, int32_t R, const double *h_init, con
     DA(pd_cached, double, BEW) DA(hist, double, BEW) DA(be_jt, double, (size_t)R * d.NBE) DA(be_ja, double, (size_t)R * d.NBE)
     DA(err, uint32_t, R)
 #undef DA
-    d.lc = nullptr;
+    d.lc = nullptr; d.sig_idx = nullptr; d.sig_cnt = nullptr;
+    if (S > 32 && S <= 384 && !getenv("RMX_NO_SPARSE_TRIAL")) {
+        uint16_t *pi_ = nullptr; uint8_t *pc_ = nullptr;
+        if (dalloc(b, &pi_, RN * RMX_SIGK) == RMX_OK && dalloc(b, &pc_, RN) == RMX_OK) { d.sig_idx = pi_; d.sig_cnt = pc_; }
+    }
     {
         const size_t bytes = RNS * 6 * 8;
         const char *env = getenv("RMX_CELL_CACHE");
@@ -729,7 +734,7 @@ int rmx_batch_create(const rmx_problem *pr, int32_t R, const double *h_init, con
 
     // per-restart initial state (bpmodel.pyx:546-597)
     b->sample_cache.assign(R, std::vector<int64_t>()); b->sample_count.assign(R, -1);
-    b->rp.resize(R); b->tables_dirty.assign(R, 1); b->segc_dirty.assign(R, 1); b->ab_dirty.assign(R, 1); b->comp_dirty.assign(R, 31); b->cache_stale.assign(R, 15); b->lt_valid.assign(R, 0); b->logZ.assign(R, 0.); b->logz_dirty.assign(R, 0);
+    b->rp.resize(R); b->tables_dirty.assign(R, 1); b->segc_dirty.assign(R, 1); b->ab_dirty.assign(R, 1); b->comp_dirty.assign(R, 31); b->cache_stale.assign(R, 15); b->sig_valid.assign(R, 0); b->lt_valid.assign(R, 0); b->logZ.assign(R, 0.); b->logz_dirty.assign(R, 0);
     for (int r = 0; r < R; r++) {
         RestartParams &p = b->rp[r];
         memset(&p, 0, sizeof p);
@@ -883,7 +888,7 @@ int rmx_set_array(rmx_batch *b, int32_t r, int32_t id, const void *src) {
     case RMX_A_P_OUTLIER_ALLELE: HIPCHK(hipMemcpyAsync(d.qa + RN * 2, src, (size_t)d.N * 16, hipMemcpyHostToDevice, b->stream)); break;
     case RMX_A_POSTERIOR_MARGINALS:
         HIPCHK(hipMemcpy2DAsync(d.post + RN * d.SP, (size_t)d.SP * 8, src, (size_t)d.S * 8, (size_t)d.S * 8, d.N, hipMemcpyHostToDevice, b->stream));
-        b->ab_dirty[r] = 1; b->comp_dirty[r] = 31; break;
+        b->ab_dirty[r] = 1; b->comp_dirty[r] = 31; b->sig_valid[r] = 0; break;
     case RMX_A_TOTAL_LIKELIHOOD_MASK: case RMX_A_ALLELE_LIKELIHOOD_MASK: {
         std::vector<uint8_t> m8(d.N);
         for (int n = 0; n < d.N; n++) m8[n] = ((const int64_t *)src)[n] != 0;
@@ -1117,7 +1122,7 @@ static int do_update_p_cn(rmx_batch *b, int r0, int r1, bool skip_frame = false,
         else hipLaunchKernelGGL(k_marginals<true>, row_grid(b, r1 - r0), dim3(256), 0, b->stream, b->d, r0, b->G);
         HIPCHK(hipGetLastError());
     }
-    for (int r = r0; r < r1; r++) { b->ab_dirty[r] = 0; b->comp_dirty[r] = 0; b->logz_dirty[r] = 1; }
+    for (int r = r0; r < r1; r++) { b->ab_dirty[r] = 0; b->comp_dirty[r] = 0; b->logz_dirty[r] = 1; b->sig_valid[r] = (!fuse_next && use_strip(b) && b->d.sig_cnt) ? 1 : 0; }
     return RMX_OK;
 }
 static int do_update_p_breakpoint(rmx_batch *b, int r0, int r1) {
@@ -1685,7 +1690,18 @@ int rmx_expected_ll_full_trial(rmx_batch *b, int32_t r0, int32_t r1, double *out
         while (e < r1 && (use_strip(b) ? cover_mask(b->comp_dirty[e] & 15) : (b->comp_dirty[e] ? 15 : 0)) == mask) e++;
         if (mask) {
             ProfScope ps(b, KID_MARGINALS_AB);
-            if (use_strip(b)) hipLaunchKernelGGL(cells_kernel(b, 2, mask, 0), strip_grid(b, e - r), dim3(256), 0, b->stream, d2, r);
+            bool sparse = use_strip(b) && d.sig_cnt != nullptr;
+            for (int i = r; i < e; i++) if (!b->sig_valid[i]) sparse = false;
+            if (sparse) {
+                void (*kf)(Dev, int) = nullptr;
+                switch (mask) {
+                case 1: kf = k_trial_sparse<1>; break; case 2: kf = k_trial_sparse<2>; break; case 3: kf = k_trial_sparse<3>; break;
+                case 4: kf = k_trial_sparse<4>; break; case 8: kf = k_trial_sparse<8>; break; case 12: kf = k_trial_sparse<12>; break;
+                default: kf = k_trial_sparse<15>; break;
+                }
+                hipLaunchKernelGGL(kf, dim3((d.N + 7) / 8, e - r), dim3(256), 0, b->stream, d2, r);
+            }
+            else if (use_strip(b)) hipLaunchKernelGGL(cells_kernel(b, 2, mask, 0), strip_grid(b, e - r), dim3(256), 0, b->stream, d2, r);
             else hipLaunchKernelGGL(k_marginals<false>, row_grid(b, e - r), dim3(256), 0, b->stream, d2, r, b->G);
         }
         r = e;

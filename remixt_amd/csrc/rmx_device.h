@@ -76,6 +76,7 @@ struct Dev {
     double *qt, *qa, *qs;                // [R][N][2]
     double *pbrk;                        // [R][K][B]
     double *f, *fe, *fa, *fb, *post;     // [R][N][SP]; fe = exp(f - rowmax)
+    uint16_t *sig_idx; uint8_t *sig_cnt; // [R][N][RMX_SIGK], [R][N]: states with posterior mass >= RMX_POST_EPS per segment (count 255: more than RMX_SIGK, use all states), or null
     double *lc;                          // [R][6][N][SP] cached cell likelihoods (LT0, LT1, LA00, LA01, LA10, LA11) or null
     double *fmax, *mrow;                 // [R][N]
     double *A, *Bv;                      // [R][N][2], [R][N][4]
@@ -211,6 +212,7 @@ __device__ __forceinline__ void load_state_regs(const Dev &d, int r, int cls, in
 // >= 1 -- far under half an ulp, the rounded sum is the same.  (Posteriors concentrate on a few
 // neighbouring states; whole 64-state groups are skipped on most segments.)
 #define RMX_POST_EPS 1e-30
+#define RMX_SIGK 32        // capacity of the per-segment list of states with posterior mass
 
 // component mask of cell_ll_regs: which of the six values the caller needs
 #define CM_LT0 1

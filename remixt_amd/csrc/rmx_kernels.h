@@ -1134,6 +1134,20 @@ __global__ __launch_bounds__(256) void k_cells(Dev d, int r0) {
 #pragma unroll
                 // (a fused pass keeps the posterior in registers: nothing reads d.post before the last, unfused, sweep of the call writes it)
                 for (int k = 0; k < NS; k++) { const int s = lane + 64 * k; pv[k] = pv[k] / s2; if (MODE != 3 && s < S) d.post[ro + s] = pv[k]; }   // second renormalisation of _exp_normalize
+                if (MODE == 1 && d.sig_cnt) {
+                    // states with posterior mass, in state order, for the sparse trial passes of the M-step
+                    int base_ = 0;
+#pragma unroll
+                    for (int k = 0; k < NS; k++) {
+                        const int s = lane + 64 * k;
+                        const bool sg_ = s < S && pv[k] >= RMX_POST_EPS;
+                        const unsigned long long bal_ = __ballot(sg_);
+                        const int pos_ = base_ + __popcll(bal_ & ((1ull << lane) - 1ull));
+                        if (sg_ && pos_ < RMX_SIGK) d.sig_idx[rn * RMX_SIGK + pos_] = (uint16_t)s;
+                        base_ += __popcll(bal_);
+                    }
+                    if (lane == 0) d.sig_cnt[rn] = base_ <= RMX_SIGK ? (uint8_t)base_ : (uint8_t)255;
+                }
             } else {
 #pragma unroll
                 for (int k = 0; k < NS; k++) { const int s = lane + 64 * k; pv[k] = s < S ? d.post[ro + s] : 0.; }
@@ -1250,6 +1264,47 @@ __global__ __launch_bounds__(256) void k_cells(Dev d, int r0) {
             }
         }
     }
+    if (err) atomicOr(&d.err[r], err);
+}
+
+// =============================================================================
+// k_trial_sparse: the (A, B) expectations of the components in MASK at the restarts' CURRENT parameters
+// into d.A / d.Bv (the caller passes a Dev whose A / Bv point at scratch), from the per-segment lists of
+// states with posterior mass (built by the last marginal pass): ~13 of 165 states per segment carry all
+// of the posterior, the others cannot move the rounded sums (RMX_POST_EPS).  Half a wave per segment;
+// segments whose list overflowed (count 255) walk all states.  State-table error flags are reported for
+// every state.  grid (ceil(N / 8), nr), block 256.
+// =============================================================================
+template <int MASK>
+__global__ __launch_bounds__(256) void k_trial_sparse(Dev d, int r0) {
+    const int r = r0 + blockIdx.y;
+    const int n = blockIdx.x * 8 + (threadIdx.x >> 5), j = threadIdx.x & 31;
+    if (n >= d.N) return;
+    const RestartParams &rp = d.rp[r];
+    SegCtx sc; load_seg(d, r, n, sc);
+    const int cls = d.seg_class[n];
+    const size_t rn = (size_t)r * d.N + n;
+    const double *post = d.post + rn * d.SP;
+    const int cnt = d.sig_cnt[rn];
+    unsigned err = 0;
+    double a0 = 0., a1 = 0., b0 = 0., b1 = 0., b2 = 0., b3 = 0.;
+    auto one = [&](int s) {
+        StateRegs st; load_state_regs(d, r, cls, s, st);
+        double LT[2], LA[4];
+        cell_ll_regs<MASK>(rp, sc, st, LT, LA, err);
+        const double ps = post[s];
+        a0 += ps * LT[0]; a1 += ps * LT[1];
+        b0 += ps * LA[0]; b1 += ps * LA[1]; b2 += ps * LA[2]; b3 += ps * LA[3];
+    };
+    if (cnt == 255) { for (int s = j; s < d.S; s += 32) one(s); }
+    else {
+        if (j < cnt) one((int)d.sig_idx[rn * RMX_SIGK + j]);
+        if (MASK & (CM_LA0 | CM_LA1)) for (int s = j; s < d.S; s += 32) cell_static_errors<MASK>(sc, d.stFlags[((size_t)r * d.C + cls) * d.SP + s], err);
+    }
+    if (MASK & CM_LT0) { a0 = group_sum(a0, 32); if (j == 0) d.A[rn * 2] = a0; }
+    if (MASK & CM_LT1) { a1 = group_sum(a1, 32); if (j == 0) d.A[rn * 2 + 1] = a1; }
+    if (MASK & CM_LA0) { b0 = group_sum(b0, 32); b1 = group_sum(b1, 32); if (j == 0) { d.Bv[rn * 4] = b0; d.Bv[rn * 4 + 1] = b1; } }
+    if (MASK & CM_LA1) { b2 = group_sum(b2, 32); b3 = group_sum(b3, 32); if (j == 0) { d.Bv[rn * 4 + 2] = b2; d.Bv[rn * 4 + 3] = b3; } }
     if (err) atomicOr(&d.err[r], err);
 }
 
