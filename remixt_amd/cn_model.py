@@ -286,10 +286,14 @@ class BreakpointModel(object):
     def get_param_sample_weight(self, name):
         """Segment weights for the stochastic M-step of one parameter (cn_model.py:323-352)."""
         m = self.model
+        # (RestartSet passes the outlier indicators it fetched once for the whole M-step: they do not change in it)
+        cache = getattr(self, '_mstep_indicator_cache', None) or {}
         if name in ('negbin_r_0', 'negbin_r_1'):
-            weights = np.asarray(m.p_outlier_total)[:, int(name[-1])]
+            q = cache.get('p_outlier_total')
+            weights = (np.asarray(m.p_outlier_total) if q is None else q)[:, int(name[-1])]
         elif name in ('betabin_M_0', 'betabin_M_1'):
-            weights = np.asarray(m.p_outlier_allele)[:, int(name[-1])]
+            q = cache.get('p_outlier_allele')
+            weights = (np.asarray(m.p_outlier_allele) if q is None else q)[:, int(name[-1])]
         elif name == 'negbin_hdel_mu':
             weights = self._get_hdel_weights()
         elif name in ('negbin_hdel_r_0', 'negbin_hdel_r_1'):

@@ -237,6 +237,17 @@ class RestartSet(object):
         b = self.batch
         R = len(self.models)
         ids_all = list(range(R))
+        # the outlier indicators feed the sample weights of several parameters and do not change during the
+        # M-step: one device-to-host copy per restart and array instead of one per parameter
+        for m in self.models:
+            m._mstep_indicator_cache = {'p_outlier_total': np.asarray(m.model.p_outlier_total), 'p_outlier_allele': np.asarray(m.model.p_outlier_allele)}
+        try:
+            self._params_lockstep_body(b, R, ids_all)
+        finally:
+            for m in self.models:
+                m._mstep_indicator_cache = None
+
+    def _params_lockstep_body(self, b, R, ids_all):
         for name in self.models[0].likelihood_params:
             lo, hi = self.models[0].likelihood_param_bounds[name]
             weights = [m.get_param_sample_weight(name) for m in self.models]
