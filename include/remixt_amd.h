@@ -131,6 +131,10 @@ int rmx_get_array(rmx_batch *b, int32_t r, int32_t array_id, void *host_dst);
 /* calculate_log_transmat(out) (bpmodel.pyx:639-684): dense (N-1) x S x S log transition array for the CURRENT
  * p_breakpoint of restart r into a host array of 8 (N-1) S^2 bytes; no model state changes. */
 int rmx_calculate_log_transmat(rmx_batch *b, int32_t r, double *dst);
+/* Host-only helper of the weighted M-step sampling (cn_model.py:475-480 with p = weights): the index every
+ * uniform draw u[j] selects from cumsum(p) / sum -- numpy's cumsum / searchsorted(side='right') with the same
+ * accumulation order; *positive = count_nonzero(p > 0).  Runs without the GIL, no device involved. */
+int rmx_weighted_search(const double *p, int64_t n, const double *u, int32_t k, int64_t *out, int64_t *positive);
 int rmx_get_state_table(rmx_batch *b, int32_t which, int64_t *host_dst);
 
 /* -- coordinate updates (bpmodel.pyx cpdef methods), restarts [r0,r1) ------ */

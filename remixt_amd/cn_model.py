@@ -76,6 +76,35 @@ def create_brk_states(num_clones, cn_max, cn_diff_max):
     return np.concatenate([np.zeros((len(grids), 1), dtype=grids.dtype), grids], axis=1).astype(np.int64)
 
 
+_NATIVE_SEARCH = [False, None]
+
+
+def _native_weighted_search():
+    """rmx_weighted_search of the HIP library if it is loadable (it is host code), else None: the numpy
+    formulation gives the same indices."""
+    if _NATIVE_SEARCH[0]:
+        return _NATIVE_SEARCH[1]
+    _NATIVE_SEARCH[0] = True
+    try:
+        import ctypes as C
+        from . import _lib
+        lib = _lib.load()
+        dp, ip = C.POINTER(C.c_double), C.POINTER(C.c_int64)
+
+        def search(p, u):
+            u = np.ascontiguousarray(u, dtype=np.float64)
+            out = np.empty(len(u), dtype=np.int64)
+            pos = C.c_int64(0)
+            rc = lib.rmx_weighted_search(p.ctypes.data_as(dp), len(p), u.ctypes.data_as(dp), len(u), out.ctypes.data_as(ip), C.byref(pos))
+            if rc != 0:
+                raise RuntimeError('rmx_weighted_search failed')
+            return out, int(pos.value)
+        _NATIVE_SEARCH[1] = search
+    except Exception:
+        _NATIVE_SEARCH[1] = None
+    return _NATIVE_SEARCH[1]
+
+
 def _sample_without_replacement(rng, n, size, p=None):
     """`size` distinct indices from range(n), successively with probability proportional to p
     (uniform if None): the distribution of numpy's choice(n, size, replace=False, p=p).  numpy
@@ -86,17 +115,26 @@ def _sample_without_replacement(rng, n, size, p=None):
     if size > n:
         raise ValueError("Cannot take a larger sample than population when 'replace=False'")
     cdf = None
-    if p is not None:
+    native = _native_weighted_search() if p is not None else None
+    if p is not None and native is None:
         if np.count_nonzero(p > 0) < size:
             raise ValueError("Fewer non-zero entries in p than size")
         cdf = np.cumsum(p)
         cdf /= cdf[-1]
+    if native is not None:
+        p = np.ascontiguousarray(p, dtype=np.float64)
     found = np.empty(0, dtype=np.int64)
     while found.size < size:
         k = size - found.size
         k += k // 2 + 8
-        if cdf is None:
+        if p is None:
             new = rng.randint(0, n, size=k).astype(np.int64)
+        elif native is not None:
+            # the same cumulative sum and binary search in C++ (rmx_weighted_search): no GIL, so the
+            # restarts' draws really run side by side on the host threads
+            new, positive = native(p, rng.rand(k))
+            if positive < size:
+                raise ValueError("Fewer non-zero entries in p than size")
         else:
             new = np.minimum(cdf.searchsorted(rng.rand(k), side='right'), n - 1).astype(np.int64)
         cand = np.concatenate([found, new])

@@ -968,6 +968,27 @@ int rmx_calculate_log_transmat(rmx_batch *b, int32_t r, double *dst) {
     return RMX_OK;
 }
 
+// Host-only helper of the M-step's weighted segment sampling (BreakpointModel._create_sample with a private
+// RNG stream): for k uniform draws u, the index each one selects from the cumulative distribution of p --
+// numpy's  cdf = cumsum(p); cdf /= cdf[-1]; minimum(cdf.searchsorted(u, side='right'), n - 1)  with the same
+// sequential accumulation, hence the same indices.  *positive receives count_nonzero(p > 0).  No device work,
+// no Python objects: host threads run it concurrently.
+int rmx_weighted_search(const double *p, int64_t n, const double *u, int32_t k, int64_t *out, int64_t *positive) {
+    if (!p || n < 1 || (k > 0 && (!u || !out))) return fail(RMX_EARG, "bad argument");
+    std::vector<double> cdf((size_t)n);
+    double acc = 0.;
+    int64_t pos = 0;
+    for (int64_t i = 0; i < n; i++) { acc += p[i]; cdf[(size_t)i] = acc; pos += p[i] > 0.; }
+    const double last = cdf[(size_t)n - 1];
+    for (int64_t i = 0; i < n; i++) cdf[(size_t)i] /= last;
+    for (int32_t j = 0; j < k; j++) {
+        const int64_t idx = (int64_t)(std::upper_bound(cdf.begin(), cdf.end(), u[j]) - cdf.begin());
+        out[j] = std::min<int64_t>(idx, n - 1);
+    }
+    if (positive) *positive = pos;
+    return RMX_OK;
+}
+
 int rmx_get_state_table(rmx_batch *b, int32_t which, int64_t *dst) {
     const Dev &d = b->d;
     const int S = d.S, M = d.M;
