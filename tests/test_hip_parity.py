@@ -86,6 +86,37 @@ def test_coordinate_updates_match_oracle(hip, oracle_mod, M, max_cn, N, chains, 
     assert np.array_equal(cna, cnb)
 
 
+def _random_configs():
+    rng = np.random.RandomState(2024)
+    out = []
+    for i in range(10):
+        M = int(rng.choice([2, 3]))
+        max_cn = int(rng.randint(2, 6 if M == 3 else 8))
+        out.append((M, max_cn, int(rng.randint(30, 260)), int(rng.randint(1, 7)), bool(rng.rand() < 0.7), 500 + i))
+    # three clones with grids past 32 states: strip kernels, cell cache, fused sweeps, register forward-backward
+    out += [(3, 5, 150, 3, True, 601), (3, 6, 120, 2, True, 602), (3, 6, 90, 4, False, 603), (3, 5, 200, 5, False, 604)]
+    return out
+
+
+@pytest.mark.parametrize('M,max_cn,N,chains,nc,seed', _random_configs())
+def test_randomized_configurations_match_oracle(hip, oracle_mod, M, max_cn, N, chains, nc, seed):
+    """Seeded random problem shapes (clones, state grid, segments, chains, contamination mode): two full
+    sweeps, ELBO, log Z, sampled E[ll] and the Viterbi decode against the CPU oracle."""
+    a, h, _ = H.make_model(hip, N=N, M=M, max_cn=max_cn, chains=chains, seed=seed, normal_contamination=nc)
+    b, _, _ = H.make_model(oracle_mod, N=N, M=M, max_cn=max_cn, chains=chains, seed=seed, normal_contamination=nc)
+    ma, mb = H.attach(a, h), H.attach(b, h)
+    for it in range(2):
+        a.variational_update(); b.variational_update()
+        H.compare_models(ma, mb, tag='sweep%d' % it)
+        assert np.isclose(ma.calculate_elbo(), mb.calculate_elbo(), rtol=1e-8)
+        assert np.isclose(ma.hmm_log_norm_const, mb.hmm_log_norm_const, rtol=1e-9)
+    sample = (np.random.RandomState(seed).rand(ma.num_segments) < 0.3).astype(int)
+    assert np.isclose(ma.calculate_expected_log_likelihood(sample), mb.calculate_expected_log_likelihood(sample), rtol=1e-9)
+    cna = np.zeros((ma.num_segments, M, 2), dtype=int); cnb = cna.copy()
+    ma.infer_cn(cna); mb.infer_cn(cnb)
+    assert np.array_equal(cna, cnb)
+
+
 def test_calculate_log_transmat_into_caller_buffer(hip, oracle_mod):
     """calculate_log_transmat(out) (bpmodel.pyx:639-684): dense transitions for the CURRENT p_breakpoint,
     neither snapshot touched."""
