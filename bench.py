@@ -247,6 +247,14 @@ def main():
                 roof = {'bound': 'hbm', 'kernel': name, 'achieved': hbm_gbs, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                         'frac': hbm_gbs / HBM_PEAK_GBS, 'traffic': traffic, 'avg_launch_ms': avg_ms, 'launches': n,
                         'alg_bytes_per_launch': alg * cells_per_launch}
+        # the HBM-streaming passes of the sweep, same construction (algorithmic bytes / HIP-event launch time)
+        others = []
+        for name in ('k_framelogprob', 'k_marginals<true>'):
+            if name in prof and prof[name][1]:
+                avg = prof[name][0] / prof[name][1]
+                gbs = ALG_BYTES_PER_CELL[name] * cells_per_launch / (avg * 1e-3) / 1e9
+                others.append({'kernel': name, 'bound': 'hbm', 'achieved': gbs, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': gbs / HBM_PEAK_GBS,
+                               'avg_launch_ms': avg, 'launches': prof[name][1]})
         # whole variational update (all kernels of one sweep) against the 88 B/cell model
         upd = sum(prof.get(k, (0., 0))[0] for k in ('k_framelogprob', 'k_fb', 'k_marginals<true>', 'k_pairwise', 'k_brk_update',
                                                        'k_brk_lut', 'k_update_outlier_total', 'k_update_outlier_allele', 'k_update_allele_swap'))
@@ -262,6 +270,7 @@ def main():
                        'segments': args.segments, 'states': S, 'restarts_per_gpu': R, 'restart_groups': len(rs.sets), 'mstep': not args.no_mstep},
             'seg_state_cells_per_s': cells_total * world * args.update_iters * args.steps / dt,
             'roofline': roof,
+            'roofline_other': others,
             'variational_sweep': {'device_ms_per_sweep_all_restarts': sweep_ms,
                                   'hbm_frac_168B_per_cell': (168.0 * cells_per_launch / (sweep_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if sweep_ms else None},
             'device_ms_total': total_ms,
