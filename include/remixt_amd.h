@@ -204,6 +204,9 @@ int rmx_log_likelihood_allele(rmx_batch *b, int32_t r, int32_t n, int32_t s, int
 /* infer_cn (:1197-1210): Viterbi over the framelogprob / log_transmat of the last
  * update_p_cn; cn_out int64 [N][M][2]; logprob_out may be NULL */
 int rmx_infer_cn(rmx_batch *b, int32_t r, int64_t *cn_out, double *logprob_out);
+/* the same for restarts r0 .. r0+nr-1 with their lattices running side by side: cn_out int64
+ * [nr][N][M][2], logprob_out [nr] or NULL (the per-restart decode of analysis/pipeline.py:196-206) */
+int rmx_infer_cn_batch(rmx_batch *b, int32_t r0, int32_t nr, int64_t *cn_out, double *logprob_out);
 
 /* -- module-level functions on caller-supplied dense inputs ----------------- */
 /* sum_product (:1213-1246): f [N][S], T [N-1][S][S] -> alphas, betas [N][S] */

@@ -66,6 +66,7 @@ SYMBOLS = {
     "rmx_log_likelihood_total": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _dp]),
     "rmx_log_likelihood_allele": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _dp]),
     "rmx_infer_cn": (C.c_int, [C.c_void_p, C.c_int32, _ip, _dp]),
+    "rmx_infer_cn_batch": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, _ip, _dp]),
     "rmx_sum_product": (C.c_int, [_dp, _dp, _dp, _dp, C.c_int32, C.c_int32, C.c_int32]),
     "rmx_max_product": (C.c_int, [_dp, _dp, _ip, _dp, C.c_int32, C.c_int32, C.c_int32]),
     "rmx_timer_start": (C.c_int, [C.c_void_p]),

@@ -372,6 +372,13 @@ class RemixtBatch(object):
         self._ck(self._lib.rmx_infer_cn(self._handle, r, cn.ctypes.data_as(_ip), C.byref(lp)))
         return cn, float(lp.value)
 
+    def infer_cn_batch(self, r0, nr):
+        """Viterbi decode of restarts r0 .. r0+nr-1 in one call: (cn [nr][N][M][2], logprob [nr])."""
+        cn = np.zeros((nr, self.num_segments, self.num_clones, 2), dtype=np.int64)
+        lp = np.zeros(nr)
+        self._ck(self._lib.rmx_infer_cn_batch(self._handle, int(r0), int(nr), cn.ctypes.data_as(_ip), lp.ctypes.data_as(_dp)))
+        return cn, lp
+
     # -- measurement ------------------------------------------------------------
     def timer_start(self):
         self._ck(self._lib.rmx_timer_start(self._handle))

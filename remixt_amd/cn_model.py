@@ -572,25 +572,31 @@ class BreakpointModel(object):
         return float(value[0])
 
     # ------------------------------------------------------------------------------
-    def optimal_cn(self):
-        """Viterbi decode + per-breakpoint argmax (cn_model.py:571-598)."""
+    def optimal_cn(self, cn=None):
+        """Viterbi decode + per-breakpoint argmax (cn_model.py:571-598).  `cn` = an already decoded
+        path of this model ([N][M][2], model segment order), e.g. from a batched infer_cn."""
         m = self.model
-        cn = np.zeros((m.num_segments, m.num_clones, m.num_alleles), dtype=int)
-        m.infer_cn(cn)
+        if cn is None:
+            cn = np.zeros((m.num_segments, m.num_clones, m.num_alleles), dtype=int)
+            m.infer_cn(cn)
 
         brk_states = np.asarray(m.brk_states)
         bidx = np.asarray(m.breakpoint_idx); borient = np.asarray(m.breakpoint_orient)
         log_breakpoint_p = np.zeros((m.num_breakpoints, m.num_brk_states))
         tot = cn.sum(axis=-1)
+        # the reference's loops over (n, clone, brk state): every entry accumulates its terms in the
+        # same (n, clone) order here, the brk-state axis is the vector
+        pen = m.transition_penalty
         for n in np.nonzero(bidx[:-1] >= 0)[0]:
+            row = log_breakpoint_p[bidx[n]]
             for c in range(m.num_clones):
                 d = tot[n, c] - tot[n + 1, c]
-                for s_b in range(m.num_brk_states):
-                    log_breakpoint_p[bidx[n], s_b] += (-m.transition_penalty * abs(d - borient[n] * brk_states[s_b, c]))
+                row += (-pen * np.abs(d - borient[n] * brk_states[:, c]))
 
         brk_cn = dict()
+        best = log_breakpoint_p.argmax(axis=1) if m.num_breakpoints else []
         for k in range(m.num_breakpoints):
-            brk_cn[self.breakpoint_ids[k]] = brk_states[log_breakpoint_p[k, :].argmax()]
+            brk_cn[self.breakpoint_ids[k]] = brk_states[best[k]]
 
         return cn[self.seg_fwd_remap], brk_cn
 

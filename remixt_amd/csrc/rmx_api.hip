@@ -74,7 +74,7 @@ struct rmx_batch {
     std::vector<int32_t> plain_list; int32_t *d_plain_list = nullptr; double *d_plain_jt = nullptr;
     // viterbi
     uint16_t *d_bp = nullptr; double *d_final = nullptr; int64_t *d_path = nullptr; double *d_logprob = nullptr;
-    std::vector<int64_t> last_path;
+    std::vector<int64_t> last_path; int vit_cap = 0;
     // FB launch configuration
     FbLaunch fbG{}; size_t fbG_lds = 0;   // generic kernel configuration
     int n_fast = 0, n_generic = 0;
@@ -110,6 +110,12 @@ template <typename T> static int dalloc(rmx_batch *b, T **p, size_t count) {
     b->allocs.push_back(q);
     *p = (T *)q;
     return RMX_OK;
+}
+static void dfree(rmx_batch *b, void *q) {
+    if (!q) return;
+    auto it = std::find(b->allocs.begin(), b->allocs.end(), q);
+    if (it != b->allocs.end()) b->allocs.erase(it);
+    hipFree(q);
 }
 template <typename T> static int dupload(rmx_batch *b, const T **p, const std::vector<T> &v) {
     T *q = nullptr;
@@ -1768,39 +1774,74 @@ int rmx_log_likelihood_allele(rmx_batch *b, int32_t r, int32_t n, int32_t s, int
 
 // ---- decoding -----------------------------------------------------------------------------
 static int viterbi_P(int S) { int P = 1; while (S * P * 2 <= 1024 && P < 64) P *= 2; return P; }
+static int viterbi_reg_P(int S) { int P = 1; while (S * P * 2 <= 768 && P < 64) P *= 2; return P; }
 
-int rmx_infer_cn(rmx_batch *b, int32_t r, int64_t *cn_out, double *logprob_out) {
-    if (!b || r < 0 || r >= b->R || !cn_out) return fail(RMX_EARG, "bad argument");
+// Viterbi paths of restarts r0 .. r0+nr-1: forward lattices side by side (one workgroup each), then the trace-backs
+static int viterbi_paths(rmx_batch *b, int r0, int nr, std::vector<int64_t> &paths, std::vector<double> &lps) {
     const Dev &d = b->d;
     const int N = d.N, S = d.S, M = d.M;
-    b->last_path.assign(N, 0);
-    double lp = 0.;
-    if (!b->lt_valid[r]) {
-        // framelogprob == 1 and log_transmat == 0 (bpmodel.pyx:557-558): every comparison ties, first index wins
-        lp = (double)N;
-    } else {
-        int rc;
-        if (!b->d_bp) { if ((rc = dalloc(b, &b->d_bp, (size_t)N * S)) || (rc = dalloc(b, &b->d_final, S)) || (rc = dalloc(b, &b->d_path, N)) || (rc = dalloc(b, &b->d_logprob, 1))) return rc; }
-        const int P = viterbi_P(S);
-        const int NT = ((S * P + 63) / 64) * 64;
-        { ProfScope ps(b, KID_VITERBI);
-          hipLaunchKernelGGL(k_viterbi, dim3(1), dim3(NT), (size_t)(2 * S + M * d.D) * 8, b->stream, b->d, r, P, b->d_bp, b->d_final); }
-        int rows = std::max(1, std::min(256, (48 * 1024) / (2 * S)));
-        { ProfScope ps(b, KID_BACKTRACE);
-          hipLaunchKernelGGL(k_backtrace, dim3(1), dim3(256), (size_t)rows * S * 2, b->stream, b->d, (const uint16_t *)b->d_bp, (const double *)b->d_final, b->d_path, b->d_logprob, rows); }
-        HIPCHK(hipGetLastError());
-        HIPCHK(hipMemcpyAsync(b->last_path.data(), b->d_path, (size_t)N * 8, hipMemcpyDeviceToHost, b->stream));
-        HIPCHK(hipMemcpyAsync(b->h_pinned, b->d_logprob, 8, hipMemcpyDeviceToHost, b->stream));
-        HIPCHK(hipStreamSynchronize(b->stream));
-        lp = b->h_pinned[0];
+    int rc;
+    if (b->vit_cap < nr) {
+        dfree(b, b->d_bp); dfree(b, b->d_final); dfree(b, b->d_path); dfree(b, b->d_logprob);
+        b->d_bp = nullptr; b->d_final = nullptr; b->d_path = nullptr; b->d_logprob = nullptr; b->vit_cap = 0;
+        if ((rc = dalloc(b, &b->d_bp, (size_t)nr * N * S)) || (rc = dalloc(b, &b->d_final, (size_t)nr * S)) || (rc = dalloc(b, &b->d_path, (size_t)nr * N)) || (rc = dalloc(b, &b->d_logprob, nr))) return rc;
+        b->vit_cap = nr;
     }
-    if (logprob_out) *logprob_out = lp;
+    const int Pr = viterbi_reg_P(S), QPT = (S + Pr - 1) / Pr;
+    const bool reg = QPT <= 44 && !getenv("RMX_VITERBI_PLAIN");
+    { ProfScope ps(b, KID_VITERBI);
+      if (reg) {
+          const int NT = ((S * Pr + 63) / 64) * 64;
+#define VREG(Q) hipLaunchKernelGGL(k_viterbi_reg<Q>, dim3(nr), dim3(NT), (size_t)(2 * (Pr * QPT + Q) + M * d.D) * 8, b->stream, b->d, r0, Pr, b->d_bp, b->d_final)
+          if (QPT <= 8) VREG(8); else if (QPT <= 16) VREG(16); else if (QPT <= 24) VREG(24); else if (QPT <= 32) VREG(32);
+          else if (QPT <= 36) VREG(36); else if (QPT <= 40) VREG(40); else VREG(44);
+#undef VREG
+      } else {
+          const int P = viterbi_P(S), NT = ((S * P + 63) / 64) * 64;
+          for (int i = 0; i < nr; i++)
+              hipLaunchKernelGGL(k_viterbi, dim3(1), dim3(NT), (size_t)(2 * S + M * d.D) * 8, b->stream, b->d, r0 + i, P, b->d_bp + (size_t)i * N * S, b->d_final + (size_t)i * S);
+      } }
+    int rows = std::max(1, std::min(256, (48 * 1024) / (2 * S)));
+    { ProfScope ps(b, KID_BACKTRACE);
+      hipLaunchKernelGGL(k_backtrace, dim3(nr), dim3(256), (size_t)rows * S * 2, b->stream, b->d, (const uint16_t *)b->d_bp, (const double *)b->d_final, b->d_path, b->d_logprob, rows); }
+    HIPCHK(hipGetLastError());
+    paths.resize((size_t)nr * N); lps.resize(nr);
+    HIPCHK(hipMemcpyAsync(paths.data(), b->d_path, (size_t)nr * N * 8, hipMemcpyDeviceToHost, b->stream));
+    HIPCHK(hipMemcpyAsync(lps.data(), b->d_logprob, (size_t)nr * 8, hipMemcpyDeviceToHost, b->stream));
+    HIPCHK(hipStreamSynchronize(b->stream));
+    return RMX_OK;
+}
+
+int rmx_infer_cn_batch(rmx_batch *b, int32_t r0, int32_t nr, int64_t *cn_out, double *logprob_out) {
+    if (!b || r0 < 0 || nr < 1 || r0 + nr > b->R || !cn_out) return fail(RMX_EARG, "bad argument");
+    const Dev &d = b->d;
+    const int N = d.N, S = d.S, M = d.M;
+    std::vector<int64_t> paths; std::vector<double> lps;
+    // maximal runs of restarts with a lattice; the others have framelogprob == 1 and log_transmat == 0
+    // (bpmodel.pyx:557-558): every comparison ties, the first index wins
+    std::vector<int64_t> all((size_t)nr * N, 0); std::vector<double> lp(nr, (double)N);
+    for (int i = 0; i < nr;) {
+        if (!b->lt_valid[r0 + i]) { i++; continue; }
+        int j = i; while (j < nr && b->lt_valid[r0 + j]) j++;
+        int rc = viterbi_paths(b, r0 + i, j - i, paths, lps); if (rc) return rc;
+        memcpy(all.data() + (size_t)i * N, paths.data(), (size_t)(j - i) * N * 8);
+        for (int k = i; k < j; k++) lp[k] = lps[k - i];
+        i = j;
+    }
+    b->last_path.assign(all.end() - N, all.end());
     // bpmodel.pyx:1205-1210 (the allele "swap" there re-uses the flipped index on both sides: a plain gather)
-    for (int n = 0; n < N; n++) {
-        const int64_t *t = b->cn_classes.data() + ((size_t)b->seg_class[n] * S + b->last_path[n]) * M * 2;
-        for (int i = 0; i < M * 2; i++) cn_out[(size_t)n * M * 2 + i] = t[i];
+    for (int i = 0; i < nr; i++) {
+        if (logprob_out) logprob_out[i] = lp[i];
+        for (int n = 0; n < N; n++) {
+            const int64_t *t = b->cn_classes.data() + ((size_t)b->seg_class[n] * S + all[(size_t)i * N + n]) * M * 2;
+            for (int k = 0; k < M * 2; k++) cn_out[((size_t)i * N + n) * M * 2 + k] = t[k];
+        }
     }
     return RMX_OK;
+}
+int rmx_infer_cn(rmx_batch *b, int32_t r, int64_t *cn_out, double *logprob_out) {
+    if (!b || r < 0 || r >= b->R || !cn_out) return fail(RMX_EARG, "bad argument");
+    return rmx_infer_cn_batch(b, r, 1, cn_out, logprob_out);
 }
 
 // ---- module-level functions -------------------------------------------------------------------

@@ -2121,12 +2121,88 @@ __global__ __launch_bounds__(1024) void k_viterbi(Dev d, int r, int P, uint16_t 
     }
     if (t < S) final_row[t] = V[((d.N - 1) & 1) * S + t];
 }
-// trace-back: one workgroup; chunks of back-pointer rows staged through LDS
-__global__ void k_backtrace(Dev d, const uint16_t *bp, const double *final_row, int64_t *path, double *logprob, int ROWS) {
+// Same lattice, one workgroup per restart (grid nr), with the transition values of class 0 held
+// in registers: thread (o, p) keeps T(i, o) for its QPT source states i, which never change along
+// the genome while the adjacency is a plain one of class 0 (every adjacency of an experiment
+// without masked segments).  A step is then QPT LDS reads of V, adds and compares per thread and
+// one barrier; breakend, telomere and other-class adjacencies take the expression of k_viterbi.
+// Values, comparison order and tie rule are those of k_viterbi, so the paths are identical.
+template <int QMAX>
+__global__ __launch_bounds__(768) void k_viterbi_reg(Dev d, int r0, int P, uint16_t *bp_all /* [nr][N][S] */, double *final_all /* [nr][S] */) {
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    const int S = d.S, M = d.M, D = d.D, t = threadIdx.x, NT = blockDim.x, r = r0 + blockIdx.x;
+    const int QPT = (S + P - 1) / P;
+    const int SV = P * QPT + QMAX;         // padded row: reads past S see 0 and are paired with T = -inf
+    double *V = (double *)smem_raw;        // [2][SV]
+    double *pdl = V + 2 * SV;              // [M*D]
+    uint16_t *bp = bp_all + (size_t)blockIdx.x * d.N * S;
+    const int o = t / P, p = t % P;
+    const bool act = o < S;
+    const int i0 = p * QPT;
+    const double *f = d.f + rs_off(d, r, 0);
+    double Treg[QMAX];
+#pragma unroll
+    for (int rr = 0; rr < QMAX; rr++) {
+        const int i = i0 + rr;
+        Treg[rr] = (act && rr < QPT && i < S && d.TC > 0) ? d.Tval[(size_t)i * S + o] : -INFINITY;
+    }
+    for (int i = t; i < 2 * SV; i += NT) V[i] = 0.;
+    __syncthreads();
+    if (t < S) V[t] = f[t];
+    __syncthreads();
+    int tc = d.N > 1 ? d.tclass[0] : -1, bs = d.N > 1 ? d.brk_slot[0] : -1;
+    for (int n = 1; n < d.N; n++) {
+        const int cur = (n - 1) & 1, nxt = n & 1, tn = n - 1;
+        const int tc_n = n + 1 < d.N ? d.tclass[n] : -1, bs_n = n + 1 < d.N ? d.brk_slot[n] : -1;
+        const double fn = act ? f[(size_t)n * d.SP + o] : 0.;
+        double best = -INFINITY; int bi = 0;
+        if (tc == 0 && bs < 0) {
+            const double *Vc = V + cur * SV + i0;
+#pragma unroll
+            for (int rr = 0; rr < QMAX; rr++) {
+                const double v = Vc[rr] + Treg[rr];
+                if (v > best) { best = v; bi = i0 + rr; }
+            }
+        } else {
+            const double *pd = nullptr;
+            if (tc >= 0 && bs >= 0) {
+                const double *pdg = d.pd_lt + ((size_t)r * d.NBE + bs) * M * D;
+                for (int i = t; i < M * D; i += NT) pdl[i] = pdg[i];
+                __syncthreads();
+                pd = pdl;
+            }
+            if (act) for (int rr = 0; rr < QPT; rr++) {
+                const int i = i0 + rr;
+                if (i < S) {
+                    const double T = (tc < 0) ? 0. : trans_value(d, tn, i, o, pd);
+                    const double v = V[cur * SV + i] + T;
+                    if (v > best) { best = v; bi = i; }
+                }
+            }
+        }
+        for (int off = 1; off < P; off <<= 1) {
+            const double ob = __shfl_xor(best, off, 64); const int oi = __shfl_xor(bi, off, 64);
+            if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+        }
+        if (act && p == 0) {
+            V[nxt * SV + o] = best + fn;
+            bp[(size_t)n * S + o] = (uint16_t)bi;
+        }
+        tc = tc_n; bs = bs_n;
+        __syncthreads();
+    }
+    if (t < S) final_all[(size_t)blockIdx.x * S + t] = V[((d.N - 1) & 1) * SV + t];
+}
+// trace-back: one workgroup per restart; chunks of back-pointer rows staged through LDS
+__global__ void k_backtrace(Dev d, const uint16_t *bp_all, const double *final_all, int64_t *path_all, double *logprob_all, int ROWS) {
     extern __shared__ __align__(16) unsigned char smem_raw[];
     uint16_t *chunk = (uint16_t *)smem_raw;
     __shared__ int cur_state;
     const int S = d.S, t = threadIdx.x, NT = blockDim.x;
+    const uint16_t *bp = bp_all + (size_t)blockIdx.x * d.N * S;
+    const double *final_row = final_all + (size_t)blockIdx.x * S;
+    int64_t *path = path_all + (size_t)blockIdx.x * d.N;
+    double *logprob = logprob_all + blockIdx.x;
     if (t == 0) {
         int mp = 0; double vm = final_row[0];
         for (int i = 1; i < S; i++) if (final_row[i] > vm) { vm = final_row[i]; mp = i; }

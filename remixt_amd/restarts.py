@@ -309,8 +309,11 @@ class RestartSet(object):
     def results(self):
         """Per-restart result dicts with the keys of analysis/pipeline.py:198-226."""
         out = []
+        cn_all = None
+        if self.batch is not None and len(self.models) > 0:
+            cn_all, _ = self.batch.infer_cn_batch(0, len(self.models))     # all lattices side by side
         for r, (m, p) in enumerate(zip(self.models, self.init_params)):
-            res = collect_fit_results(m, self.experiment, p)
+            res = collect_fit_results(m, self.experiment, p, cn=None if cn_all is None else cn_all[r])
             res['stats']['error_message'] = self.error_messages.get(r, '')
             out.append(res)
         return out
@@ -387,7 +390,7 @@ class RestartGroups(object):
                 rs.batch.synchronize()
 
     def results(self):
-        return [r for rs in self.sets for r in rs.results()]
+        return [r for part in self._map(lambda rs: rs.results()) for r in part]
 
     def profile(self):
         """{kernel: (ms, launches)} summed over the groups' batches."""
@@ -399,10 +402,11 @@ class RestartGroups(object):
         return out
 
 
-def collect_fit_results(model, experiment, init_params):
-    """fit_results of analysis/pipeline.py:196-226 from a fitted BreakpointModel."""
+def collect_fit_results(model, experiment, init_params, cn=None):
+    """fit_results of analysis/pipeline.py:196-226 from a fitted BreakpointModel (`cn`: its Viterbi
+    path if a batched decode already produced it)."""
     from .cn_model import decode_breakpoints_naive
-    cn, brk_cn = model.optimal_cn()
+    cn, brk_cn = model.optimal_cn(cn) if cn is not None else model.optimal_cn()
     if model.disable_breakpoints:
         brk_cn = decode_breakpoints_naive(cn, experiment.adjacencies, experiment.breakpoints)
     res = dict()

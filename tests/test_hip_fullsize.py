@@ -72,6 +72,24 @@ def test_viterbi_path_is_a_valid_decode_and_repeatable(fullsize):
     assert dominant_ok > 0.9
 
 
+def test_batched_decode_equals_the_per_restart_lattice(fullsize, monkeypatch):
+    """rmx_infer_cn_batch (transition values in registers, restarts side by side) against the plain
+    one-restart kernel (RMX_VITERBI_PLAIN): same paths and path log-probabilities, bit for bit."""
+    e, rs = fullsize
+    b = rs.batch
+    cn_all, lp_all = b.infer_cn_batch(0, 3)
+    monkeypatch.setenv('RMX_VITERBI_PLAIN', '1')
+    for r in range(3):
+        cn, lp = b.infer_cn(r)
+        assert np.array_equal(cn, cn_all[r]) and lp == lp_all[r]
+    monkeypatch.delenv('RMX_VITERBI_PLAIN')
+    res = rs.results()
+    for r in range(3):
+        cn_r, brk_r = rs.models[r].optimal_cn()
+        assert np.array_equal(res[r]['cn'], cn_r)
+        assert all(np.array_equal(res[r]['brk_cn'][k], brk_r[k]) for k in brk_r)
+
+
 def test_sweeps_are_deterministic(fullsize):
     e, rs = fullsize
     from remixt_amd.restarts import RestartSet
