@@ -191,7 +191,18 @@ class BreakpointModel(object):
         if not self.normal_contamination:
             self.normal_copies = self.normal_copies * 0
 
-        self._remap_segments(adjacencies)
+        # restarts of one experiment share the segment remap (same adjacencies and breakpoints):
+        # the first model of a RestartSet computes it, the others copy the arrays
+        remap_cache = kwargs.get('remap_cache', None)
+        names = ('N1', 'seg_fwd_remap', 'seg_is_original', 'seg_rev_remap', 'num_breakpoints',
+                 'is_telomere', 'breakpoint_idx', 'breakpoint_orient')
+        if remap_cache is not None and 'remap' in remap_cache:
+            for name, value in zip(names, remap_cache['remap']):
+                setattr(self, name, value.copy() if isinstance(value, np.ndarray) else value)
+        else:
+            self._remap_segments(adjacencies)
+            if remap_cache is not None:
+                remap_cache['remap'] = tuple(getattr(self, name) for name in names)
 
         self.x1 = np.zeros((self.N1, x.shape[1]), dtype=float)
         self.l1 = np.zeros((self.N1,), dtype=float)
@@ -584,14 +595,22 @@ class BreakpointModel(object):
         bidx = np.asarray(m.breakpoint_idx); borient = np.asarray(m.breakpoint_orient)
         log_breakpoint_p = np.zeros((m.num_breakpoints, m.num_brk_states))
         tot = cn.sum(axis=-1)
-        # the reference's loops over (n, clone, brk state): every entry accumulates its terms in the
-        # same (n, clone) order here, the brk-state axis is the vector
+        # the reference's loops over (n, clone, brk state): every entry of log_breakpoint_p accumulates
+        # its terms in the same (n, clone) order here -- the j-th breakend (in n order) of all
+        # breakpoints at once, clone by clone
         pen = m.transition_penalty
-        for n in np.nonzero(bidx[:-1] >= 0)[0]:
-            row = log_breakpoint_p[bidx[n]]
-            for c in range(m.num_clones):
-                d = tot[n, c] - tot[n + 1, c]
-                row += (-pen * np.abs(d - borient[n] * brk_states[:, c]))
+        ns = np.nonzero(bidx[:-1] >= 0)[0]
+        if len(ns) > 0:
+            order = np.argsort(bidx[ns], kind='stable')
+            ns = ns[order]; ks = bidx[ns]
+            starts = np.nonzero(np.r_[True, ks[1:] != ks[:-1]])[0]
+            rank = np.arange(len(ks)) - np.repeat(starts, np.diff(np.r_[starts, len(ks)]))
+            for j in range(int(rank.max()) + 1):
+                sel = rank == j
+                n_j = ns[sel]; k_j = ks[sel]
+                for c in range(m.num_clones):
+                    d = tot[n_j, c] - tot[n_j + 1, c]
+                    log_breakpoint_p[k_j] += (-pen * np.abs(d[:, None] - borient[n_j][:, None] * brk_states[None, :, c]))
 
         brk_cn = dict()
         best = log_breakpoint_p.argmax(axis=1) if m.num_breakpoints else []

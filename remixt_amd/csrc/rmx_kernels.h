@@ -2127,6 +2127,50 @@ __global__ __launch_bounds__(1024) void k_viterbi(Dev d, int r, int P, uint16_t 
 // without masked segments).  A step is then QPT LDS reads of V, adds and compares per thread and
 // one barrier; breakend, telomere and other-class adjacencies take the expression of k_viterbi.
 // Values, comparison order and tie rule are those of k_viterbi, so the paths are identical.
+// Vector-memory traffic of the step loop goes through untracked inline asm (see gload8): the row of
+// f and the adjacency's class / breakend slot for step n+1 are requested at the end of step n and
+// retired by ONE vmcnt(0) after the compares of step n+1, when they and the back-pointer store of
+// step n are a step old.
+__device__ __forceinline__ void gload4(int &dst, const int *src) {
+    asm volatile("global_load_dword %0, %1, off" : "=v"(dst) : "v"(src) : "memory");
+}
+__device__ __forceinline__ void gwait_all(double &a, int &b, int &c) { asm volatile("s_waitcnt vmcnt(0)" : "+v"(a), "+v"(b), "+v"(c) :: "memory"); }
+__device__ __forceinline__ void gstore2(uint16_t *dst, int v) {
+    asm volatile("global_store_short %0, %1, off\n\ts_nop 1" ::"v"(dst), "v"(v) : "memory");
+}
+// The QMAX LDS reads of a step as an explicit pipeline (hipcc serialises them: read, wait, compare):
+// pairs of values by ds_read2_b64 through untracked asm, DEPTH pairs in flight, each retired by a
+// counted lgkmcnt wait right before its two compares.  LDS returns in order, and the block issues
+// no other LDS traffic between the first read and the last wait.
+typedef double vit_d2 __attribute__((ext_vector_type(2)));
+template <int K> __device__ __forceinline__ void vit_rd2(vit_d2 &dst, unsigned addr) {
+    asm volatile("ds_read2_b64 %0, %1 offset0:%2 offset1:%3" : "=v"(dst) : "v"(addr), "n"(2 * K), "n"(2 * K + 1) : "memory");
+}
+template <int CNT> __device__ __forceinline__ void vit_wait(vit_d2 &x) { asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(x) : "n"(CNT) : "memory"); }
+template <int G, int NG, int DEPTH> struct vit_pipe {
+    template <int QMAX>
+    static __device__ __forceinline__ void step(vit_d2 (&buf)[DEPTH], const double (&T)[QMAX], unsigned addr, double &best, int &bi, int i0) {
+        constexpr int younger = (NG - 1 - G) < (DEPTH - 1) ? (NG - 1 - G) : (DEPTH - 1);
+        vit_wait<younger>(buf[G % DEPTH]);
+        const vit_d2 x = buf[G % DEPTH];
+        if constexpr (G + DEPTH < NG) vit_rd2<G + DEPTH>(buf[G % DEPTH], addr);
+        const double v0 = x.x + T[2 * G], v1 = x.y + T[2 * G + 1];
+        if (v0 > best) { best = v0; bi = i0 + 2 * G; }
+        if (v1 > best) { best = v1; bi = i0 + 2 * G + 1; }
+        if constexpr (G + 1 < NG) vit_pipe<G + 1, NG, DEPTH>::step(buf, T, addr, best, bi, i0);
+    }
+    template <int QMAX>
+    static __device__ __forceinline__ void run(const double (&T)[QMAX], unsigned addr, double &best, int &bi, int i0) {
+        static_assert(G == 0 && 2 * NG == QMAX && DEPTH <= NG && 2 * NG + 1 < 256, "pipeline shape");
+        vit_d2 buf[DEPTH];
+        fill<0>(buf, addr);
+        step(buf, T, addr, best, bi, i0);
+    }
+    template <int I> static __device__ __forceinline__ void fill(vit_d2 (&buf)[DEPTH], unsigned addr) {
+        vit_rd2<I>(buf[I], addr);
+        if constexpr (I + 1 < DEPTH) fill<I + 1>(buf, addr);
+    }
+};
 template <int QMAX>
 __global__ __launch_bounds__(768) void k_viterbi_reg(Dev d, int r0, int P, uint16_t *bp_all /* [nr][N][S] */, double *final_all /* [nr][S] */) {
     extern __shared__ __align__(16) unsigned char smem_raw[];
@@ -2138,6 +2182,7 @@ __global__ __launch_bounds__(768) void k_viterbi_reg(Dev d, int r0, int P, uint1
     uint16_t *bp = bp_all + (size_t)blockIdx.x * d.N * S;
     const int o = t / P, p = t % P;
     const bool act = o < S;
+    const int oc = act ? o : S - 1;
     const int i0 = p * QPT;
     const double *f = d.f + rs_off(d, r, 0);
     double Treg[QMAX];
@@ -2146,50 +2191,59 @@ __global__ __launch_bounds__(768) void k_viterbi_reg(Dev d, int r0, int P, uint1
         const int i = i0 + rr;
         Treg[rr] = (act && rr < QPT && i < S && d.TC > 0) ? d.Tval[(size_t)i * S + o] : -INFINITY;
     }
+    // a use of every value: their loads retire here, not at a vmcnt(0) inside the step loop
+#pragma unroll
+    for (int rr = 0; rr < QMAX; rr++) asm volatile("" : "+v"(Treg[rr]));
     for (int i = t; i < 2 * SV; i += NT) V[i] = 0.;
     __syncthreads();
     if (t < S) V[t] = f[t];
     __syncthreads();
-    int tc = d.N > 1 ? d.tclass[0] : -1, bs = d.N > 1 ? d.brk_slot[0] : -1;
-    for (int n = 1; n < d.N; n++) {
-        const int cur = (n - 1) & 1, nxt = n & 1, tn = n - 1;
-        const int tc_n = n + 1 < d.N ? d.tclass[n] : -1, bs_n = n + 1 < d.N ? d.brk_slot[n] : -1;
-        const double fn = act ? f[(size_t)n * d.SP + o] : 0.;
-        double best = -INFINITY; int bi = 0;
-        if (tc == 0 && bs < 0) {
-            const double *Vc = V + cur * SV + i0;
-#pragma unroll
-            for (int rr = 0; rr < QMAX; rr++) {
-                const double v = Vc[rr] + Treg[rr];
-                if (v > best) { best = v; bi = i0 + rr; }
+    if (d.N > 1) {
+        double fn; int tcv, bsv;
+        gload8(fn, f + (size_t)1 * d.SP + oc); gload4(tcv, d.tclass); gload4(bsv, d.brk_slot);
+        gwait_all(fn, tcv, bsv);
+        for (int n = 1; n < d.N; n++) {
+            const int cur = (n - 1) & 1, nxt = n & 1, tn = n - 1;
+            const int tc = __builtin_amdgcn_readfirstlane(tcv), bs = __builtin_amdgcn_readfirstlane(bsv);
+            const double fcur = fn;
+            {   // requests for step n+1 (the last step re-reads its own row)
+                const int nn = n + 1 < d.N ? n + 1 : n;
+                gload8(fn, f + (size_t)nn * d.SP + oc); gload4(tcv, d.tclass + (nn - 1)); gload4(bsv, d.brk_slot + (nn - 1));
             }
-        } else {
-            const double *pd = nullptr;
-            if (tc >= 0 && bs >= 0) {
-                const double *pdg = d.pd_lt + ((size_t)r * d.NBE + bs) * M * D;
-                for (int i = t; i < M * D; i += NT) pdl[i] = pdg[i];
-                __syncthreads();
-                pd = pdl;
-            }
-            if (act) for (int rr = 0; rr < QPT; rr++) {
-                const int i = i0 + rr;
-                if (i < S) {
-                    const double T = (tc < 0) ? 0. : trans_value(d, tn, i, o, pd);
-                    const double v = V[cur * SV + i] + T;
-                    if (v > best) { best = v; bi = i; }
+            double best = -INFINITY; int bi = 0;
+            if (tc == 0 && bs < 0) {
+                const double *Vc = V + cur * SV + i0;
+                vit_pipe<0, QMAX / 2, (QMAX / 2 < 6 ? QMAX / 2 : 6)>::run(Treg, lds_addr(Vc), best, bi, i0);
+            } else {
+                const double *pd = nullptr;
+                if (tc >= 0 && bs >= 0) {
+                    const double *pdg = d.pd_lt + ((size_t)r * d.NBE + bs) * M * D;
+                    for (int i = t; i < M * D; i += NT) pdl[i] = pdg[i];
+                    __syncthreads();
+                    pd = pdl;
+                }
+                if (act) for (int rr = 0; rr < QPT; rr++) {
+                    const int i = i0 + rr;
+                    if (i < S) {
+                        const double T = (tc < 0) ? 0. : trans_value(d, tn, i, o, pd);
+                        const double v = V[cur * SV + i] + T;
+                        if (v > best) { best = v; bi = i; }
+                    }
                 }
             }
+            for (int off = 1; off < P; off <<= 1) {
+                const double ob = __shfl_xor(best, off, 64); const int oi = __shfl_xor(bi, off, 64);
+                if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+            }
+            // retires the requests made at the top of this step and the store of the previous one;
+            // this step's store stays in flight over the next step's compares
+            gwait_all(fn, tcv, bsv);
+            if (act && p == 0) {
+                V[nxt * SV + o] = best + fcur;
+                gstore2(bp + (size_t)n * S + o, bi);
+            }
+            __syncthreads();
         }
-        for (int off = 1; off < P; off <<= 1) {
-            const double ob = __shfl_xor(best, off, 64); const int oi = __shfl_xor(bi, off, 64);
-            if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
-        }
-        if (act && p == 0) {
-            V[nxt * SV + o] = best + fn;
-            bp[(size_t)n * S + o] = (uint16_t)bi;
-        }
-        tc = tc_n; bs = bs_n;
-        __syncthreads();
     }
     if (t < S) final_all[(size_t)blockIdx.x * S + t] = V[((d.N - 1) & 1) * SV + t];
 }

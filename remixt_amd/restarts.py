@@ -35,12 +35,15 @@ class RestartSet(object):
             raise ValueError('all restarts must share max_depth')
         self.num_clones = num_clones
         self.models = []
+        remap_cache = model_kwargs.pop('remap_cache', None)
+        if remap_cache is None:
+            remap_cache = dict()
         for i, p in enumerate(self.init_params):
             rng = np.random.RandomState(seeds[i]) if seeds is not None else None
             self.models.append(BreakpointModel(
                 experiment.x, experiment.l, experiment.adjacencies, experiment.breakpoints,
                 max_copy_number=max_copy_number, divergence_weight=p['divergence_weight'], max_depth=p['max_depth'],
-                kernel_module=kernel_module, device=device, quiet=quiet, rng=rng, **model_kwargs))
+                kernel_module=kernel_module, device=device, quiet=quiet, rng=rng, remap_cache=remap_cache, **model_kwargs))
         self.h_init = np.array([synthetic.h_init_from_params(p, num_clones) for p in self.init_params])
         m0 = self.models[0]
         kern = m0._kernel_module()
@@ -339,7 +342,8 @@ class RestartGroups(object):
             raise ValueError('grouped restarts need one RNG seed per restart')
         bounds = [(R * g) // groups for g in range(groups + 1)]
         self.slices = [slice(bounds[g], bounds[g + 1]) for g in range(groups)]
-        self.sets = [RestartSet(experiment, init_params[sl], max_copy_number,
+        remap_cache = dict()
+        self.sets = [RestartSet(experiment, init_params[sl], max_copy_number, remap_cache=remap_cache,
                                 seeds=(list(seeds)[sl] if seeds is not None else None), **kwargs) for sl in self.slices]
         self.models = [m for rs in self.sets for m in rs.models]
         self.init_params = init_params

@@ -60,6 +60,7 @@ def test_posteriors_are_distributions_and_chains_are_consistent(fullsize):
 def test_viterbi_path_is_a_valid_decode_and_repeatable(fullsize):
     e, rs = fullsize
     b = rs.batch
+    b.variational_update(1)      # a lattice exists whichever tests ran before
     m = rs.models[0]
     cn1, brk1 = m.optimal_cn()
     cn2, brk2 = m.optimal_cn()
@@ -77,6 +78,7 @@ def test_batched_decode_equals_the_per_restart_lattice(fullsize, monkeypatch):
     one-restart kernel (RMX_VITERBI_PLAIN): same paths and path log-probabilities, bit for bit."""
     e, rs = fullsize
     b = rs.batch
+    b.variational_update(1)
     cn_all, lp_all = b.infer_cn_batch(0, 3)
     monkeypatch.setenv('RMX_VITERBI_PLAIN', '1')
     for r in range(3):

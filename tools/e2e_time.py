@@ -1,0 +1,38 @@
+"""Wall-clock of the whole restart fan-out at BASELINE's size, phase by phase:
+construct (host tables + uploads) -> initial ELBO -> EM iterations -> results (decode + stats)."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from remixt_amd import synthetic
+from remixt_amd.restarts import RestartGroups
+
+R = int(os.environ.get('RST', 16)); ITERS = int(os.environ.get('ITERS', 3))
+t = time.time()
+e = synthetic.make_experiment(int(os.environ.get('SEG', 50000)), num_clones=3, max_copy_number=8, num_chains=23, seed=0)
+ps = synthetic.make_init_params(e, R, 8, num_clones=3)
+print('synthetic experiment   %.2f s' % (time.time() - t)); t = time.time()
+rs = RestartGroups(e, ps, 8, groups=2, num_clones=3, device=0, quiet=True, seeds=list(range(R)))
+rs.synchronize()
+print('construct              %.2f s' % (time.time() - t)); t = time.time()
+el = rs.calculate_elbo()
+for m, v in zip(rs.models, el): m.prev_elbo = float(v)
+print('initial elbo           %.2f s' % (time.time() - t)); t = time.time()
+rs.run(ITERS, 0, 5)
+print('%d EM iterations        %.2f s' % (ITERS, time.time() - t)); t = time.time()
+res = rs.results()
+print('results                %.2f s' % (time.time() - t))
+if os.environ.get('E2E_PROFILE'):
+    import cProfile, pstats
+    t = time.time()
+    pr = cProfile.Profile(); pr.enable()
+    rs2 = RestartGroups(e, ps, 8, groups=2, num_clones=3, device=0, quiet=True, seeds=list(range(R)))
+    rs2.synchronize()
+    pr.disable()
+    print('second construct       %.2f s' % (time.time() - t))
+    pstats.Stats(pr).sort_stats('cumulative').print_stats(25)
+    t = time.time(); res = rs.results(); print('second results         %.2f s' % (time.time() - t))
+if os.environ.get('E2E_PROFILE'):
+    for s_ in rs.sets: s_.batch.profile_enable(1)
+    t = time.time(); res = rs.results(); print('profiled results       %.2f s' % (time.time() - t))
+    for k, (ms, n) in sorted(rs.profile().items(), key=lambda kv: -kv[1][0])[:6]:
+        print('   %-22s %8.2f ms  %d launches' % (k, ms, n))
