@@ -314,6 +314,54 @@ def pipeline_case(name, N, seed, max_cn=8, **config):
     print(name, 'modes', len(modes), 'init params', len(ip))
 
 
+SAMPLER_CASES = [
+    # name, mixture-sampler params, experiment-sampler params, attributes set on the sampler instance
+    ('default', {}, {}, {}),
+    ('custom', {'frac_normal': 0.3, 'frac_clone_1': 0.5, 'num_false_breakpoints': 7, 'proportion_breakpoints_detected': 0.5},
+     {'h_total': 0.05, 'negbin_r_0': 300., 'negbin_mix': 0.1, 'betabin_M_0': 500., 'betabin_mix': 0.2, 'frac_beta_noise_stddev': 0.05}, {}),
+    ('poisson', {'num_false_breakpoints': 3}, {'emission_model': 'poisson'}, {}),
+    ('full', {'num_false_breakpoints': 3}, {'emission_model': 'full'}, {}),
+    ('negbin', {'num_false_breakpoints': 3}, {'emission_model': 'negbin'}, {'negbin_r': 200.}),
+    ('normal', {'num_false_breakpoints': 3}, {'emission_model': 'normal'}, {'noise_prior': None}),
+    ('normal_noise', {'num_false_breakpoints': 3}, {'emission_model': 'normal'}, {'noise_prior': 0.05}),
+]
+
+
+def sampler_cases(name, N, seed):
+    """Genome-mixture and read-count samplers: the reference's GenomeMixtureSampler
+    and ExperimentSampler (simulations/experiment.py:1066-1399) on one clone-genome collection, numpy's
+    global generator seeded per case.  Records the collection, and per case the mixture (fractions,
+    detected breakpoints) and the experiment (x, h, phi, h_pred, flags)."""
+    ref = refload.load_ref_simulations()
+    gc = synthetic.collection(N, num_clones=3, max_copy_number=6, num_chains=5, seed=seed)
+    true_bps = np.array(sorted(tuple(sorted(b)) for b in gc.breakpoints), dtype=np.int64)        # [K][2][2]
+    # the set is rebuilt from this array by tests (same insertion sequence -> same iteration order)
+    gc.breakpoints = set(frozenset((tuple(r[0]), tuple(r[1]))) for r in true_bps.tolist())
+    out = {'l': gc.l, 'cn': gc.cn, 'adjacencies': adjacency_array(gc.adjacencies), 'true_breakpoints': true_bps,
+           'chromosome': np.array(gc.segment_chromosome_id), 'segment_start': gc.segment_start, 'segment_end': gc.segment_end,
+           'case_names': np.array([c[0] for c in SAMPLER_CASES])}
+    for i, (cname, mp, ep, attrs) in enumerate(SAMPLER_CASES):
+        np.random.seed(1000 + i)
+        gm = ref.GenomeMixtureSampler(mp).sample_genome_mixture(gc)
+        sampler = ref.ExperimentSampler(ep)
+        for k, v in attrs.items():
+            setattr(sampler, k, v)
+        e = sampler.sample_experiment(gm)
+        out[cname + '_frac'] = gm.frac
+        out[cname + '_detected'] = np.array([[list(be) for be in sorted(gm.detected_breakpoints[k])] for k in sorted(gm.detected_breakpoints)], dtype=np.int64)
+        out[cname + '_x'] = np.asarray(e.x, dtype=float); out[cname + '_h'] = e.h; out[cname + '_phi'] = e.phi; out[cname + '_h_pred'] = e.h_pred
+        out[cname + '_major_is_a'] = np.asarray(e.segment_major_is_allele_a)
+        out[cname + '_chains'] = np.array(list(e.chains), dtype=np.int64)
+        for k in ('is_outlier_total', 'is_outlier_allele'):
+            if hasattr(e, k):
+                out[cname + '_' + k] = np.asarray(getattr(e, k))
+        bsd = gm.breakpoint_segment_data
+        out[cname + '_bsd_position'] = bsd[['position_1', 'position_2']].values.astype(np.int64)
+        out[cname + '_bsd_strand'] = np.array(bsd[['strand_1', 'strand_2']].values.tolist())
+    np.savez_compressed(os.path.join(OUT, name + '.npz'), **out)
+    print(name, 'cases', len(SAMPLER_CASES))
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     build_ref.build()
@@ -330,6 +378,7 @@ def main():
     experiment_case('experiment_tables', N=240, seed=8)
     pipeline_case('pipeline_init_strict', N=900, seed=6, min_ploidy=7.5, max_ploidy=8.0, random_seed=99)
     pipeline_case('pipeline_init_closest', N=900, seed=7, min_ploidy=2.95, max_ploidy=3.0, random_seed=7)
+    sampler_cases('simulations', N=300, seed=3)
 
 
 if __name__ == '__main__':

@@ -21,6 +21,10 @@ import os
 import sys
 import types
 
+# importing the reference's .py files in place must not leave __pycache__ files in /root/reference
+# (the tree is not ours to write to)
+sys.dont_write_bytecode = True
+
 HERE = os.path.dirname(os.path.abspath(__file__))
 REF = os.environ.get("REMIXT_REFERENCE", "/root/reference")
 REF_BIN = os.path.join(HERE, "_ref", "remixt")
@@ -80,3 +84,17 @@ def load_ref_analysis():
             sys.modules[name] = types.ModuleType(name)
     return tuple(importlib.import_module(m) for m in
                  ("remixt.likelihood", "remixt.analysis.experiment", "remixt.analysis.readdepth", "remixt.analysis.pipeline"))
+
+
+def load_ref_simulations():
+    """The reference's simulation module (`remixt/simulations/experiment.py`), imported in place, for the
+    genome-mixture and read-count samplers (:965-1399).  `remixt/simulations/balanced.py` imports
+    `networkx` and `blossomv.blossomv` at module level; both are absent from this image and only used
+    by `collapsed_balanced_breakpoints`, so empty placeholder modules are registered for the import to
+    succeed.  The rearrangement-history sampler in the same file calls `scipy.misc.logsumexp`
+    (:698), which no longer exists: that part is not usable here and no vectors come from it."""
+    load_ref_analysis()
+    for name in ("networkx", "blossomv", "blossomv.blossomv"):
+        if name not in sys.modules:
+            sys.modules[name] = types.ModuleType(name)
+    return importlib.import_module("remixt.simulations.experiment")

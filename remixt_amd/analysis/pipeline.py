@@ -59,12 +59,20 @@ def fit(experiment, init_params, config, device=0, quiet=False):
     return collect_fit_results(model, experiment, init_params)
 
 
-def fit_restarts(experiment, init_params_by_id, config, device=0, quiet=True, seeds=None):
+def fit_restarts(experiment, init_params_by_id, config, device=0, quiet=True, seeds=None, groups=2):
     """All restarts of one GPU in lockstep; returns {init_id: fit_results} like one
-    `fit_task` per init_id (workflow.py:329-340)."""
+    `fit_task` per init_id (workflow.py:329-340).  With per-restart seeds the restarts run as
+    `groups` RestartSets on their own streams and host threads (same per-restart results)."""
     ids = sorted(init_params_by_id)
-    rs = RestartSet(experiment, [init_params_by_id[i] for i in ids], defaults.get_param(config, 'max_copy_number'),
-                    num_clones=3, device=device, quiet=quiet, seeds=seeds, **_model_kwargs(experiment, config))
+    params = [init_params_by_id[i] for i in ids]
+    max_cn = defaults.get_param(config, 'max_copy_number')
+    if seeds is not None and groups > 1 and len(ids) >= 2 * groups:
+        from ..restarts import RestartGroups
+        rs = RestartGroups(experiment, params, max_cn, groups=groups, num_clones=3, device=device, quiet=quiet,
+                           seeds=seeds, **_model_kwargs(experiment, config))
+    else:
+        rs = RestartSet(experiment, params, max_cn, num_clones=3, device=device, quiet=quiet, seeds=seeds,
+                        **_model_kwargs(experiment, config))
     rs.fit(defaults.get_param(config, 'num_em_iter'), defaults.get_param(config, 'num_update_iter'))
     return dict(zip(ids, rs.results()))
 

@@ -162,3 +162,36 @@ def h_init_from_params(p, num_clones=3):
     if num_clones == 2:
         return np.array([p['h_normal'], p['h_tumour']])
     return np.array([p['h_normal'], p['h_tumour'] * p['mix_frac'], p['h_tumour'] * (1. - p['mix_frac'])])
+
+
+class GenomeCollection(object):
+    """Clone genomes in the shape remixt_amd.simulations' samplers read (the reference's
+    GenomeCollection, simulations/experiment.py:776-866, without its rearrangement history): segment
+    lengths and coordinates, per-clone copy number, reference adjacencies and the set of true
+    breakpoints."""
+
+    def __init__(self, l, cn, adjacencies, breakpoints, segment_chromosome_id, segment_start, segment_end):
+        self.l = np.asarray(l)
+        self.cn = np.asarray(cn)
+        self.adjacencies = adjacencies
+        self.breakpoints = breakpoints
+        self.segment_chromosome_id = segment_chromosome_id
+        self.segment_start = segment_start
+        self.segment_end = segment_end
+
+    @property
+    def N(self):
+        return self.cn.shape[0]
+
+    @property
+    def M(self):
+        return self.cn.shape[1]
+
+
+def collection(num_segments, num_clones=3, max_copy_number=8, num_chains=23, seed=0, num_breakpoints=None):
+    """A GenomeCollection with make_experiment's piecewise-constant clone copy number and change-point
+    breakpoints: the input of simulations.GenomeMixtureSampler / ExperimentSampler."""
+    e = make_experiment(num_segments, num_clones=num_clones, max_copy_number=max_copy_number, num_chains=num_chains,
+                        seed=seed, num_breakpoints=num_breakpoints)
+    return GenomeCollection(e.l, e.cn, e.adjacencies, set(e.breakpoints.values()), e.segment_chromosome_id,
+                            e.segment_start, e.segment_end)

@@ -120,3 +120,27 @@ def test_fit_recovers_the_simulated_mixture(hip):
     ev = evaluate.evaluate_cn(e.cn, results[best]['cn'], e.l, h_true=e.h, h_pred=results[best]['h'], allow_swap=True)
     assert ev['proportion_dom_cn_correct'] > 0.8, ev
     assert abs(ev['pred_ploidy'] - ev['true_ploidy']) < 0.35, ev
+
+
+def test_fit_recovers_a_sampled_experiment(hip):
+    """The same accuracy regression on an experiment drawn by the reference's samplers as restated in
+    remixt_amd/simulations.py (GenomeMixtureSampler -> ExperimentSampler, negbin/betabin mixtures with 1 %
+    outliers, detected + false breakpoints), through analysis.pipeline.run: read-depth initialisation
+    grid -> all restarts on the device -> best solution."""
+    from remixt_amd import evaluate, simulations, synthetic
+    from remixt_amd.analysis import pipeline
+    gc = synthetic.collection(6000, num_clones=3, max_copy_number=6, num_chains=23, seed=31)
+    np.random.seed(77)
+    gm = simulations.GenomeMixtureSampler({'frac_normal': 0.4, 'frac_clone_1': 0.4, 'num_false_breakpoints': 10}).sample_genome_mixture(gc)
+    e = simulations.ExperimentSampler({}).sample_experiment(gm)
+    config = {'max_copy_number': 6, 'num_em_iter': 3, 'num_update_iter': 5, 'min_ploidy': None, 'max_ploidy': None,
+              'h_normal': float(e.h[0]), 'h_tumour': float(e.h[1:].sum())}
+    init_params, results, best = pipeline.run(e, config)
+    ev = evaluate.evaluate_cn(e.cn, results[best]['cn'], e.l, h_true=e.h, h_pred=results[best]['h'], allow_swap=True)
+    assert ev['proportion_dom_cn_correct'] > 0.8, ev
+    assert abs(ev['pred_ploidy'] - ev['true_ploidy']) < 0.35, ev
+    # outlier calls: the sampler's flagged total-count outliers get more outlier posterior than the rest
+    q = results[best]['p_outlier_total'][:, 1]
+    flagged = np.asarray(e.is_outlier_total)
+    if flagged.sum() >= 5:
+        assert q[flagged].mean() > q[~flagged].mean()

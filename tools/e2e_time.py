@@ -36,3 +36,15 @@ if os.environ.get('E2E_PROFILE'):
     t = time.time(); res = rs.results(); print('profiled results       %.2f s' % (time.time() - t))
     for k, (ms, n) in sorted(rs.profile().items(), key=lambda kv: -kv[1][0])[:6]:
         print('   %-22s %8.2f ms  %d launches' % (k, ms, n))
+if os.environ.get('E2E_PIPELINE'):
+    # the reference's init -> fit_task x grid -> collate chain on the same experiment, default grid
+    from remixt_amd.analysis import pipeline
+    config = {'max_copy_number': 8, 'num_em_iter': 5, 'num_update_iter': 5, 'min_ploidy': None, 'max_ploidy': None,
+              'h_normal': float(e.h[0]), 'h_tumour': float(np.sum(e.h[1:]))}
+    import cProfile, pstats
+    pr = cProfile.Profile(); pr.enable()
+    t = time.time()
+    init_params, results, best = pipeline.run(e, config)
+    pr.disable()
+    print('pipeline.run: %d restarts, 5 EM iterations  %.2f s   (best init_id %d)' % (len(init_params), time.time() - t, best))
+    pstats.Stats(pr).sort_stats('cumulative').print_stats(22)
