@@ -446,6 +446,14 @@ static cells_kernel_t cells_kernel(rmx_batch *b, int mode, int mask, int cache) 
 }
 // block size of the sampled-objective kernels: one lane per state, whole waves, at most 256
 static dim3 ell_block(rmx_batch *b) { return dim3(std::min(256, ((b->d.S + 63) / 64) * 64)); }
+// single-component sampled objectives can run from the lists of states with posterior mass when every
+// listed restart's lists belong to its current posterior (both evaluation paths of rmx_param_search ask
+// this same question, so they sum the same terms in the same order)
+static bool ell_sparse_ok(rmx_batch *b, int n, const int32_t *restarts) {
+    if (!b->d.sig_cnt || getenv("RMX_ELL_DENSE")) return false;
+    for (int i = 0; i < n; i++) if (!b->sig_valid[restarts[i]]) return false;
+    return true;
+}
 static dim3 strip_grid(rmx_batch *b, int nr) { return dim3((b->d.N + 4 * STRIP_RPW - 1) / (4 * STRIP_RPW), nr); }
 // smallest instantiated component mask covering `m`
 static int cover_mask(int m) {
@@ -1412,13 +1420,18 @@ static int run_ell_batch(rmx_batch *b, int nreq, const int32_t *restarts, bool g
                                          (const int32_t *)b->d_sample, (const int32_t *)b->d_counts, b->d_ell_partial, pstride);
             else {
                 void (*kf)(Dev, const int32_t *, const RestartParams *, const int32_t *, const int32_t *, double *, int) = k_ell_list_batch<false, CM_ALL>;
+                const bool sparse = (mask == 1 || mask == 2 || mask == 4 || mask == 8) && ell_sparse_ok(b, nreq, restarts);
                 switch (mask) {
-                case 1: kf = k_ell_list_batch<false, 1>; break; case 2: kf = k_ell_list_batch<false, 2>; break;
-                case 3: kf = k_ell_list_batch<false, 3>; break; case 4: kf = k_ell_list_batch<false, 4>; break;
-                case 8: kf = k_ell_list_batch<false, 8>; break; case 12: kf = k_ell_list_batch<false, 12>; break;
+                case 1: kf = sparse ? k_ell_list_batch_sparse<1> : k_ell_list_batch<false, 1>; break;
+                case 2: kf = sparse ? k_ell_list_batch_sparse<2> : k_ell_list_batch<false, 2>; break;
+                case 3: kf = k_ell_list_batch<false, 3>; break;
+                case 4: kf = sparse ? k_ell_list_batch_sparse<4> : k_ell_list_batch<false, 4>; break;
+                case 8: kf = sparse ? k_ell_list_batch_sparse<8> : k_ell_list_batch<false, 8>; break;
+                case 12: kf = k_ell_list_batch<false, 12>; break;
                 default: break;
                 }
-                hipLaunchKernelGGL(kf, dim3(maxcnt, nreq), ell_block(b), 0, b->stream, b->d, (const int32_t *)b->d_rlist, (const RestartParams *)b->d_rp_stage,
+                hipLaunchKernelGGL(kf, sparse ? dim3((maxcnt + 3) / 4, nreq) : dim3(maxcnt, nreq), sparse ? dim3(256) : ell_block(b), 0, b->stream, b->d,
+                                   (const int32_t *)b->d_rlist, (const RestartParams *)b->d_rp_stage,
                                    (const int32_t *)b->d_sample, (const int32_t *)b->d_counts, b->d_ell_partial, pstride);
             }
         }
@@ -1547,6 +1560,15 @@ struct Nm1 {
         return false;
     }
     double xopt() const { return s0; }
+    // the points the NEXT call of advance() can request, whatever value the pending request gets (same
+    // expressions as above): after the first initial point the second one; after a reflection the
+    // expansion, the outside and the inside contraction
+    int lookahead(double out[3]) const {
+#pragma clang fp contract(off)
+        if (state == W_INIT0) { out[0] = s1; return 1; }
+        if (state == W_XR) { out[0] = 3. * xbar - 2. * s1; out[1] = 1.5 * xbar - 0.5 * s1; out[2] = 0.5 * xbar + 0.5 * s1; return 3; }
+        return 0;
+    }
 };
 }  // namespace
 
@@ -1595,13 +1617,15 @@ int rmx_param_search(rmx_batch *b, int32_t nreq, const int32_t *restarts, int32_
                             (param_id == RMX_P_NEGBIN_R_0 || param_id == RMX_P_NEGBIN_R_1 || param_id == RMX_P_BETABIN_M_0 || param_id == RMX_P_BETABIN_M_1) &&
                             !getenv("RMX_SEARCH_TABLES");
     std::vector<double> lastval(nreq, grid[0]);
+    const bool sparse_search = ell_sparse_ok(b, nreq, restarts);
     auto search_eval = [&](int n_, const int *who, const double *v_, int Gz, bool per_request, double *o_) -> int {
         // who: indices into restarts[] (nullptr: all, in order); v_: Gz grid values or n_ per-request values
         const Dev &d = b->d;
         SearchVals sv;
         sv.per_request = per_request ? 1 : 0; sv.Gz = Gz; sv.pad0 = sv.pad1 = 0;
-        const int nv_ = per_request ? n_ : Gz;
-        for (int i = 0; i < 32; i++) { sv.v[i] = i < nv_ ? v_[i] : v_[0]; sv.lv[i] = std::log(sv.v[i]); }
+        const int nv_ = per_request ? n_ * Gz : Gz;
+        if (per_request && Gz > 1) sv.per_request = 2;
+        for (int i = 0; i < 64; i++) { sv.v[i] = i < nv_ ? v_[i] : v_[0]; sv.lv[i] = std::log(sv.v[i]); }
         int maxcnt = 0;
         for (int i = 0; i < 16; i++) { const int r_ = restarts[who ? who[i < n_ ? i : 0] : (i < n_ ? i : 0)]; sv.rlist[i] = r_; if (i < n_) maxcnt = std::max(maxcnt, b->sample_count[r_]); }
         {
@@ -1609,8 +1633,10 @@ int rmx_param_search(rmx_batch *b, int32_t nreq, const int32_t *restarts, int32_
             if (maxcnt > 0) {
                 ProfScope ps(b, KID_ELL_LIST);
                 void (*kf)(Dev, SearchVals, const int32_t *, const int32_t *, double *, int) =
-                    mask == CM_LT0 ? k_ell_search<CM_LT0> : (mask == CM_LT1 ? k_ell_search<CM_LT1> : (mask == CM_LA0 ? k_ell_search<CM_LA0> : k_ell_search<CM_LA1>));
-                hipLaunchKernelGGL(kf, dim3(maxcnt, n_, Gz), ell_block(b), 0, b->stream, b->d, sv, (const int32_t *)b->d_sample, (const int32_t *)b->d_counts, b->d_ell_partial, std::max(maxcnt, 1));
+                    sparse_search ? (mask == CM_LT0 ? k_ell_search_sparse<CM_LT0> : (mask == CM_LT1 ? k_ell_search_sparse<CM_LT1> : (mask == CM_LA0 ? k_ell_search_sparse<CM_LA0> : k_ell_search_sparse<CM_LA1>)))
+                                  : (mask == CM_LT0 ? k_ell_search<CM_LT0> : (mask == CM_LT1 ? k_ell_search<CM_LT1> : (mask == CM_LA0 ? k_ell_search<CM_LA0> : k_ell_search<CM_LA1>)));
+                hipLaunchKernelGGL(kf, sparse_search ? dim3((maxcnt + 3) / 4, n_, Gz) : dim3(maxcnt, n_, Gz), sparse_search ? dim3(256) : ell_block(b), 0, b->stream, b->d, sv,
+                                   (const int32_t *)b->d_sample, (const int32_t *)b->d_counts, b->d_ell_partial, std::max(maxcnt, 1));
             }
             { ProfScope ps(b, KID_ELL_FINAL); hipLaunchKernelGGL(k_ell_search_final, dim3(n_ * Gz), dim3(256), 0, b->stream, b->d, sv, (const int32_t *)b->d_counts, (const double *)b->d_ell_partial, std::max(maxcnt, 1), b->h_pinned, b->h_err); }
             HIPCHK(hipGetLastError());
@@ -1641,21 +1667,52 @@ int rmx_param_search(rmx_batch *b, int32_t nreq, const int32_t *restarts, int32_
     std::vector<Nm1> nm(nreq);
     std::vector<int> want;          // requests waiting for a device evaluation
     std::vector<int32_t> rl(nreq);
+    // RMX_SEARCH_LOOKAHEAD=1: table-free rounds also evaluate, in the same launch, the points each
+    // optimiser may ask for next (Nm1::lookahead); when the next request is one of them its value is
+    // already here and the round trip is saved.  A value is a function of the point only, so the sequence
+    // of (point, value) pairs every optimiser sees -- and with it the result and the restart's last
+    // evaluated point -- is unchanged.  Off by default: the evaluation kernel is bound by FP64
+    // transcendental throughput, not by launch latency, so 4 candidates per request cost more device time
+    // (taken from the other restart group's sweeps) than the halved round count returns (measured on
+    // MI355X at the benchmark shape: 69.3 ms per step with, 66.2 ms without).
+    constexpr int LOOK = 4;
+    const bool lookahead = table_free && getenv("RMX_SEARCH_LOOKAHEAD");
+    struct Seen { double x[LOOK], f[LOOK]; int n = 0; };
+    std::vector<Seen> seen(nreq);
     auto pump = [&](int i, double f) {
         // advance optimiser i until it needs a device evaluation or finishes; out-of-bounds points are +inf at once
         while (nm[i].advance(x0[i], f)) {
             const double v = nm[i].req;
             if (v < lo || v > hi) { f = INFINITY; continue; }
+            bool hit = false;
+            for (int c = 0; c < seen[i].n && !hit; c++) if (seen[i].x[c] == v) { f = seen[i].f[c]; hit = true; }
+            if (hit) { lastval[i] = v; continue; }
             want.push_back(i);
             return;
         }
     };
     for (int i = 0; i < nreq; i++) pump(i, 0.);
+    std::vector<double> cand((size_t)nreq * LOOK), oc((size_t)nreq * LOOK);
     while (!want.empty()) {
         std::vector<int> cur;
         cur.swap(want);
         for (size_t k = 0; k < cur.size(); k++) { rl[k] = restarts[cur[k]]; vals[k] = nm[cur[k]].req; lastval[cur[k]] = vals[k]; }
-        if (table_free) { if ((rc = search_eval((int)cur.size(), cur.data(), vals.data(), 1, true, out.data()))) return rc; }
+        if (lookahead) {
+            for (size_t k = 0; k < cur.size(); k++) {
+                double la[3];
+                const int nl = nm[cur[k]].lookahead(la);
+                for (int c = 0; c < LOOK; c++) cand[k * LOOK + c] = vals[k];                       // unused slots repeat the pending point
+                for (int c = 0; c < nl; c++) if (la[c] >= lo && la[c] <= hi) cand[k * LOOK + 1 + c] = la[c];
+            }
+            if ((rc = search_eval((int)cur.size(), cur.data(), cand.data(), LOOK, true, oc.data()))) return rc;
+            for (size_t k = 0; k < cur.size(); k++) {
+                Seen &sn = seen[cur[k]];
+                sn.n = LOOK;
+                for (int c = 0; c < LOOK; c++) { sn.x[c] = cand[k * LOOK + c]; sn.f[c] = -oc[k * LOOK + c]; }
+                out[k] = oc[k * LOOK];
+            }
+        }
+        else if (table_free) { if ((rc = search_eval((int)cur.size(), cur.data(), vals.data(), 1, true, out.data()))) return rc; }
         else if ((rc = eval((int)cur.size(), rl.data(), vals.data(), out.data(), cur.data()))) return rc;
         for (size_t k = 0; k < cur.size(); k++) pump(cur[k], -out[k]);
     }
@@ -1798,8 +1855,7 @@ static int viterbi_paths(rmx_batch *b, int r0, int nr, std::vector<int64_t> &pat
 #undef VREG
       } else {
           const int P = viterbi_P(S), NT = ((S * P + 63) / 64) * 64;
-          for (int i = 0; i < nr; i++)
-              hipLaunchKernelGGL(k_viterbi, dim3(1), dim3(NT), (size_t)(2 * S + M * d.D) * 8, b->stream, b->d, r0 + i, P, b->d_bp + (size_t)i * N * S, b->d_final + (size_t)i * S);
+          hipLaunchKernelGGL(k_viterbi, dim3(nr), dim3(NT), (size_t)(2 * S + M * d.D) * 8, b->stream, b->d, r0, P, b->d_bp, b->d_final);
       } }
     int rows = std::max(1, std::min(256, (48 * 1024) / (2 * S)));
     { ProfScope ps(b, KID_BACKTRACE);

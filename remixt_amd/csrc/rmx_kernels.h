@@ -1921,6 +1921,53 @@ __device__ __forceinline__ void ell_segment(const Dev &d, const RestartParams &r
         }
     if (err) atomicOr(&d.err[r], err);
 }
+// The same objective for ONE likelihood component from the segment's list of states with posterior mass
+// (d.sig_idx / d.sig_cnt, built by the last marginal pass; ~13 of 165 states): one WAVE per sampled
+// segment instead of one block, a lane per listed state; the states off the list cannot move the
+// rounded sum (RMX_POST_EPS) and only report their state-table error flags.  A segment whose list
+// overflowed (count 255) walks all states.  No block-level synchronisation: waves of a block work on
+// different segments.
+template <int MASK, bool OVR>
+__device__ __forceinline__ void ell_segment_sparse(const Dev &d, const RestartParams &rp, int r, int n, double *prow) {
+    const int lane = threadIdx.x & 63;
+    SegCtx sc;
+    sc.x = d.x[n]; sc.l = d.l[n]; sc.logl = d.logl[n]; sc.y0 = d.y[2 * (size_t)n]; sc.y1 = d.y[2 * (size_t)n + 1]; sc.ys = sc.y0 + sc.y1;
+    sc.mt = d.mask_t[n]; sc.ma = d.mask_a[n];
+    const double k_ = seg_const_value(rp, sc.x, sc.y0, sc.ys, lane & 7);      // lanes 0..7 hold the eight per-segment constants
+#pragma unroll
+    for (int i = 0; i < 4; i++) { sc.cnb[i] = __shfl(k_, i, 64); sc.cbb[i] = __shfl(k_, 4 + i, 64); }
+    const int cls = d.seg_class[n];
+    const size_t rn = (size_t)r * d.N + n;
+    const double qt0 = d.qt[rn * 2], qt1 = d.qt[rn * 2 + 1], qa0 = d.qa[rn * 2], qa1 = d.qa[rn * 2 + 1];
+    const double qs0 = d.qs[rn * 2], qs1 = d.qs[rn * 2 + 1];
+    const double *post = d.post + rs_off(d, r, n);
+    unsigned err = 0;
+    double acc = 0.;
+    auto one = [&](int s) {
+        StateRegs st_; load_state_regs(d, r, cls, s, st_);
+        if (OVR && (MASK & (CM_LA0 | CM_LA1)) && !(st_.fl & ST_LOH_M)) {
+            const bool ok_ = !(st_.fl & (ST_E_BADP | ST_E_TD | ST_E_LOH));      // as state_tables_body
+            if (MASK & CM_LA0) { const double M_ = rp.p[RMX_P_BETABIN_M_0]; st_.M0 = M_; st_.lgA0 = ok_ ? lgamma_pos(M_ * st_.p) : 0.; st_.lgB0 = ok_ ? lgamma_pos(M_ * (1 - st_.p)) : 0.; }
+            if (MASK & CM_LA1) { const double M_ = rp.p[RMX_P_BETABIN_M_1]; st_.M1 = M_; st_.lgA1 = ok_ ? lgamma_pos(M_ * st_.p) : 0.; st_.lgB1 = ok_ ? lgamma_pos(M_ * (1 - st_.p)) : 0.; }
+        }
+        double LT[2], LA[4];
+        cell_ll_regs<MASK>(rp, sc, st_, LT, LA, err);
+        const double ps = post[s];
+        if (MASK & CM_LT0) acc += ps * qt0 * LT[0];
+        if (MASK & CM_LT1) acc += ps * qt1 * LT[1];
+        if (MASK & CM_LA0) { acc += ps * qa0 * qs0 * LA[0]; acc += ps * qa0 * qs1 * LA[1]; }
+        if (MASK & CM_LA1) { acc += ps * qa1 * qs0 * LA[2]; acc += ps * qa1 * qs1 * LA[3]; }
+    };
+    const int cnt = d.sig_cnt[rn];
+    if (cnt == 255) { for (int s = lane; s < d.S; s += 64) one(s); }
+    else {
+        if (lane < cnt) one((int)d.sig_idx[rn * RMX_SIGK + lane]);
+        for (int s = lane; s < d.S; s += 64) cell_static_errors<MASK>(sc, d.stFlags[((size_t)r * d.C + cls) * d.SP + s], err);
+    }
+    acc = group_sum(acc, 64);
+    if (lane == 0) prow[0] = acc;
+    if (err) atomicOr(&d.err[r], err);
+}
 template <bool GRAD>
 __global__ void k_ell_list(Dev d, int r, const int32_t *list, double *partial) {
     ell_segment<GRAD>(d, d.rp[r], r, list[blockIdx.x], partial + (size_t)blockIdx.x * (1 + RMX_MAX_CLONES));
@@ -1982,6 +2029,16 @@ __global__ void k_ell_list_batch(Dev d, const int32_t *rlist, const RestartParam
     // stage[j] is identical to d.rp[r]; read from the stage to stay independent of launch order
     ell_segment<GRAD, MASK>(d, stage[blockIdx.y], r, n, partial + (size_t)r * pstride + (size_t)blockIdx.x * (1 + RMX_MAX_CLONES));
 }
+// grid (ceil(maxcount / 4), nreq), block 256: wave w of block (i, j) evaluates sampled segment 4 i + w of restart rlist[j]
+template <int MASK>
+__global__ __launch_bounds__(256) void k_ell_list_batch_sparse(Dev d, const int32_t *rlist, const RestartParams *stage, const int32_t *samples, const int32_t *counts,
+                                                               double *partial, int pstride) {
+    const int r = rlist[blockIdx.y];
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= counts[r]) return;
+    const int n = samples[(size_t)r * d.N + i];
+    ell_segment_sparse<MASK, false>(d, stage[blockIdx.y], r, n, partial + (size_t)r * pstride + (size_t)i * (1 + RMX_MAX_CLONES));
+}
 // grid (nreq): deterministic sum of restart rlist[j]'s partials -> out[j * nout + c], c < nout (1 = value only, 1+MAXC = value and d/dh)
 // err_out (optional, host-visible): the restart's error word, so that the host needs no separate copy
 __global__ void k_ell_final_batch(Dev d, const int32_t *rlist, const int32_t *counts, const double *partial, int pstride, double *out, int nout,
@@ -2003,7 +2060,10 @@ __global__ void k_ell_final_batch(Dev d, const int32_t *rlist, const int32_t *co
 // of restart rlist[j] with the parameter set to v[g] (grid stage: the same Gz values for every restart)
 // or v[j] (per_request: one value per restart, Gz = 1).  Everything else comes from d.rp[r] and the
 // restart's state tables; nothing is written back, so a whole grid is ONE launch.
-struct SearchVals { double v[32], lv[32]; int32_t rlist[16]; int32_t per_request, Gz, pad0, pad1; };
+// per_request: 0 = v[] is a grid of Gz values shared by all requests; 1 = one value per request (Gz = 1);
+// 2 = Gz values per request, v[req * Gz + gz] (a request's pending point and the points its optimiser may ask
+// for next, evaluated in the same launch)
+struct SearchVals { double v[64], lv[64]; int32_t rlist[16]; int32_t per_request, Gz, pad0, pad1; };
 template <int MASK>
 __global__ void k_ell_search(Dev d, SearchVals sv, const int32_t *samples, const int32_t *counts, double *partial, int maxcnt) {
     const int req = blockIdx.y, gz = blockIdx.z;
@@ -2011,12 +2071,28 @@ __global__ void k_ell_search(Dev d, SearchVals sv, const int32_t *samples, const
     if ((int)blockIdx.x >= counts[r]) return;
     const int n = samples[(size_t)r * d.N + blockIdx.x];
     RestartParams rp = d.rp[r];
-    const int vi = sv.per_request ? req : gz;
+    const int vi = sv.per_request == 2 ? req * sv.Gz + gz : (sv.per_request ? req : gz);
     if (MASK == CM_LT0) { rp.p[RMX_P_NEGBIN_R_0] = sv.v[vi]; rp.logr[0] = sv.lv[vi]; }
     if (MASK == CM_LT1) { rp.p[RMX_P_NEGBIN_R_1] = sv.v[vi]; rp.logr[1] = sv.lv[vi]; }
     if (MASK == CM_LA0) rp.p[RMX_P_BETABIN_M_0] = sv.v[vi];
     if (MASK == CM_LA1) rp.p[RMX_P_BETABIN_M_1] = sv.v[vi];
     ell_segment<false, MASK, true>(d, rp, r, n, partial + ((size_t)(req * sv.Gz + gz) * maxcnt + blockIdx.x));
+}
+// grid (ceil(maxcount / 4), nreq, Gz), block 256: a wave per sampled segment (ell_segment_sparse)
+template <int MASK>
+__global__ __launch_bounds__(256) void k_ell_search_sparse(Dev d, SearchVals sv, const int32_t *samples, const int32_t *counts, double *partial, int maxcnt) {
+    const int req = blockIdx.y, gz = blockIdx.z;
+    const int r = sv.rlist[req];
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= counts[r]) return;
+    const int n = samples[(size_t)r * d.N + i];
+    RestartParams rp = d.rp[r];
+    const int vi = sv.per_request == 2 ? req * sv.Gz + gz : (sv.per_request ? req : gz);
+    if (MASK == CM_LT0) { rp.p[RMX_P_NEGBIN_R_0] = sv.v[vi]; rp.logr[0] = sv.lv[vi]; }
+    if (MASK == CM_LT1) { rp.p[RMX_P_NEGBIN_R_1] = sv.v[vi]; rp.logr[1] = sv.lv[vi]; }
+    if (MASK == CM_LA0) rp.p[RMX_P_BETABIN_M_0] = sv.v[vi];
+    if (MASK == CM_LA1) rp.p[RMX_P_BETABIN_M_1] = sv.v[vi];
+    ell_segment_sparse<MASK, true>(d, rp, r, n, partial + ((size_t)(req * sv.Gz + gz) * maxcnt + i));
 }
 // grid (nreq * Gz): the sum of k_ell_final_batch over the partials of (request, candidate)
 __global__ void k_ell_search_final(Dev d, SearchVals sv, const int32_t *counts, const double *partial, int maxcnt, double *out, uint32_t *err_out) {
@@ -2075,13 +2151,15 @@ __global__ void k_cell_probe(Dev d, int r, int n, int s, double *out6) {
 // Viterbi (max_product, bpmodel.pyx:1296-1333), bit-exact: the lattice is carried
 // through telomeres exactly like the reference (no per-chain re-basing, which
 // would change float rounding), additions and comparisons only.
-// Forward: one workgroup per restart; thread (o,p); back-pointers (first maximum)
+// Forward: one workgroup per restart (grid nr); thread (o,p); back-pointers (first maximum)
 // are recorded so the trace-back is pointer chasing; identical to the reference's
 // recomputed argmax (:1327-1331) because it is the same expression and tie rule.
 // =============================================================================
-__global__ __launch_bounds__(1024) void k_viterbi(Dev d, int r, int P, uint16_t *bp /* [N][S] */, double *final_row /* [S] */) {
+__global__ __launch_bounds__(1024) void k_viterbi(Dev d, int r0, int P, uint16_t *bp_all /* [nr][N][S] */, double *final_all /* [nr][S] */) {
     extern __shared__ __align__(16) unsigned char smem_raw[];
-    const int S = d.S, M = d.M, D = d.D, t = threadIdx.x, NT = blockDim.x;
+    const int S = d.S, M = d.M, D = d.D, t = threadIdx.x, NT = blockDim.x, r = r0 + blockIdx.x;
+    uint16_t *bp = bp_all + (size_t)blockIdx.x * d.N * S;
+    double *final_row = final_all + (size_t)blockIdx.x * S;
     double *V = (double *)smem_raw;        // [2][S]
     double *pdl = V + 2 * S;               // [M*D]
     const int o = t / P, p = t % P;

@@ -84,6 +84,8 @@ def test_batched_decode_equals_the_per_restart_lattice(fullsize, monkeypatch):
     for r in range(3):
         cn, lp = b.infer_cn(r)
         assert np.array_equal(cn, cn_all[r]) and lp == lp_all[r]
+    cn_plain, lp_plain = b.infer_cn_batch(1, 2)          # the plain kernel's own multi-restart launch
+    assert np.array_equal(cn_plain, cn_all[1:3]) and np.array_equal(lp_plain, lp_all[1:3])
     monkeypatch.delenv('RMX_VITERBI_PLAIN')
     res = rs.results()
     for r in range(3):

@@ -298,18 +298,22 @@ def test_lockstep_mstep_equals_per_restart_mstep(hip):
     ps = synthetic.make_init_params(e, 4, 3)
     import os
     out = []
-    for lock, native, tables in ((True, True, False), (True, False, False), (False, False, False), (True, True, True)):
-        if tables:
+    for lock, native, tables in ((True, True, False), (True, False, False), (False, False, False), (True, True, True), (True, True, 'plain')):
+        os.environ.pop('RMX_SEARCH_TABLES', None)
+        os.environ.pop('RMX_SEARCH_LOOKAHEAD', None)
+        if tables == 'plain':
+            os.environ['RMX_SEARCH_LOOKAHEAD'] = '1'      # rounds that also evaluate the optimisers' possible next points
+        elif tables:
             os.environ['RMX_SEARCH_TABLES'] = '1'      # candidate values through the table-rebuilding evaluation rounds
-        else:
-            os.environ.pop('RMX_SEARCH_TABLES', None)
         rs = RestartSet(e, ps, max_copy_number=3, num_clones=3, quiet=True, seeds=[5, 6, 7, 8], lockstep=lock,
                         native_search=native, mstep_threads=1)
         rs.fit(num_em_iter=2, num_update_iter=2)
         out.append([(m.prev_elbo, np.array(m.h), m.get_likelihood_param_values()) for m in rs.models])
     os.environ.pop('RMX_SEARCH_TABLES', None)
-    # the table-free search kernel evaluates exactly what the table-rebuilding rounds evaluate
-    for (e1, h1, p1), (e2, h2, p2) in zip(out[0], out[3]):
+    os.environ.pop('RMX_SEARCH_LOOKAHEAD', None)
+    # the table-free search kernel evaluates exactly what the table-rebuilding rounds evaluate, and the
+    # optional look-ahead evaluations change nothing any optimiser sees
+    for (e1, h1, p1), (e2, h2, p2) in list(zip(out[0], out[3])) + list(zip(out[0], out[4])):
         assert e1 == e2 and np.array_equal(h1, h2) and p1 == p2
     # python lock-step == per-restart scipy path, bit for bit
     for (e1, h1, p1), (e2, h2, p2) in zip(out[1], out[2]):
