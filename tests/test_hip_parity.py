@@ -200,6 +200,36 @@ def test_batch_equals_single(hip):
         assert np.allclose(mm.posterior_marginals, rs.batch.get_array(r, 'posterior_marginals'), rtol=1e-12, atol=1e-300)
 
 
+@pytest.mark.parametrize('M,max_cn', [(2, 4), (3, 3), (3, 6), (3, 8)])
+def test_batched_decode_matches_oracle_paths(hip, oracle_mod, M, max_cn):
+    """rmx_infer_cn_batch on grids of 9 / 20 / 84 / 165 states (different register-tile widths of the
+    lattice kernel): every restart's path equals the oracle's Viterbi path of the same model, bit for bit;
+    before the first update_p_cn every comparison ties and the first state wins (bpmodel.pyx:557-558)."""
+    from remixt_amd import synthetic
+    from remixt_amd.restarts import RestartSet
+    e = synthetic.make_experiment(260, num_clones=M, max_copy_number=max_cn, num_chains=4, seed=17)
+    ps = synthetic.make_init_params(e, 3, max_cn, num_clones=M)
+    sets = [RestartSet(e, ps, max_copy_number=max_cn, num_clones=M, quiet=True, kernel_module=k) for k in (None, oracle_mod)]
+    b = sets[0].batch
+    cn0, lp0 = b.infer_cn_batch(0, 3)
+    for r in range(3):
+        ref = np.zeros((b.num_segments, M, 2), dtype=int); sets[1].models[r].model.infer_cn(ref)
+        assert np.array_equal(cn0[r], ref)
+    for rs in sets:
+        rs.variational_update(2)
+    cn, lp = b.infer_cn_batch(0, 3)
+    for r in range(3):
+        ref = np.zeros((b.num_segments, M, 2), dtype=int); sets[1].models[r].model.infer_cn(ref)
+        assert np.array_equal(cn[r], ref), r
+        one, lp1 = b.infer_cn(r)
+        assert np.array_equal(one, cn[r]) and lp1 == lp[r]
+    cn12, _ = b.infer_cn_batch(1, 2)
+    assert np.array_equal(cn12, cn[1:3])
+    for r0, nr in ((0, 4), (-1, 1), (2, 0), (3, 1)):
+        with pytest.raises(ValueError):
+            b.infer_cn_batch(r0, nr)
+
+
 def test_s165_matches_oracle(hip, oracle_mod):
     """BASELINE state grid (3 clones, max_cn=8 -> 165 states): register-stationary FB path vs oracle."""
     a, h, _ = H.make_model(hip, N=96, M=3, max_cn=8, chains=3, seed=7)
