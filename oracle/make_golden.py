@@ -362,6 +362,97 @@ def sampler_cases(name, N, seed):
     print(name, 'cases', len(SAMPLER_CASES))
 
 
+def _prediction_tables(rng, gm, merge_every, cn_noise, total_only, single_clone):
+    """A predicted copy-number table on a coarser segmentation than the truth (every `merge_every`-th
+    boundary inside a chromosome removed), truth copy number with a fraction `cn_noise` of rows perturbed,
+    and a predicted breakpoint table for most of the detected breakpoints."""
+    import pandas as pd
+    chrom = np.asarray(gm.segment_chromosome_id); start = np.asarray(gm.segment_start); end = np.asarray(gm.segment_end)
+    cn = np.asarray(gm.cn)
+    rows = []
+    n = 0
+    while n < gm.N:
+        m = n
+        if n % merge_every == 0 and n + 1 < gm.N and chrom[n + 1] == chrom[n]:
+            m = n + 1
+        c = cn[n, 1:, :].copy()
+        if rng.random() < cn_noise:
+            c[rng.integers(0, c.shape[0]), rng.integers(0, 2)] += 1
+        rows.append((chrom[n], start[n], end[m], c))
+        n = m + 1
+    tab = pd.DataFrame({'chromosome': [r[0] for r in rows], 'start': [r[1] for r in rows], 'end': [r[2] for r in rows]})
+    for k in range(1 if single_clone else 2):
+        major = np.array([max(r[3][k]) for r in rows]); minor = np.array([min(r[3][k]) for r in rows])
+        if total_only:
+            tab['total_%d' % (k + 1)] = major + minor
+        else:
+            tab['major_%d' % (k + 1)] = major; tab['minor_%d' % (k + 1)] = minor
+    truth = gm.genome_collection.collapsed_minimal_breakpoint_copy_number()
+    brows = []
+    for pid, bp in gm.detected_breakpoints.items():
+        if rng.random() < 0.15:
+            continue                                   # not predicted at all
+        c = np.array(truth[bp][1:]) if bp in truth else np.zeros(gm.M - 1, dtype=int)
+        if rng.random() < 0.2:
+            c = c.copy(); c[rng.integers(0, len(c))] += 1
+        brows.append([pid] + [int(v) for v in c[:1 if single_clone else len(c)]])
+    btab = pd.DataFrame(brows, columns=['prediction_id'] + ['cn_%d' % (k + 1) for k in range(1 if single_clone else gm.M - 1)])
+    return tab, btab
+
+
+EVALUATION_CASES = [
+    # name, frac_clone_1, merge_every, cn_noise, total_only, single_clone, mix_pred
+    ('alleles', 0.45, 3, 0.2, False, False, [0.35, 0.2, 0.45]),
+    ('swap', 0.32, 4, 0.1, False, False, [0.4, 0.31, 0.29]),
+    ('totals', 0.45, 2, 0.3, True, False, [0.4, 0.4, 0.2]),
+    ('one_clone', 0.45, 5, 0.2, False, True, [0.4, 0.6]),
+]
+
+
+def evaluation_case(name, N, seed):
+    """Accuracy statistics: the reference's `evaluate_results`
+    (simulations/pipeline.py:575-647, with evaluate_cn_results / evaluate_brk_cn_results and
+    segalg.reindex_segments under it) on a sampled mixture and perturbed predictions.  Records the inputs
+    (collection, truth breakpoint copies, prediction tables) and every returned statistic."""
+    ref = refload.load_ref_evaluation()
+    rsim = refload.load_ref_simulations()
+    gc = synthetic.collection(N, num_clones=3, max_copy_number=6, num_chains=5, seed=seed, num_breakpoints=40)
+    true_bps = np.array(sorted(tuple(sorted(b)) for b in gc.breakpoints), dtype=np.int64)
+    order = [frozenset((tuple(r[0]), tuple(r[1]))) for r in true_bps.tolist()]
+    gc.breakpoints = set(order)
+    full = gc.collapsed_breakpoint_copy_number()
+    rng = np.random.default_rng(seed)
+    brk_cn = np.array([full[b] for b in order]); min_brk_cn = np.minimum(brk_cn, rng.integers(1, 3, size=brk_cn.shape))
+    balanced = np.array([i for i in range(len(order)) if i % 9 == 4], dtype=np.int64)
+    gc = synthetic.GenomeCollection(gc.l, gc.cn, gc.adjacencies, gc.breakpoints, gc.segment_chromosome_id, gc.segment_start, gc.segment_end,
+                                    breakpoint_copy_number=dict(zip(order, brk_cn)), minimal_breakpoint_copy_number=dict(zip(order, min_brk_cn)),
+                                    balanced_breakpoints=set(order[i] for i in balanced))
+    out = {'l': gc.l, 'cn': gc.cn, 'adjacencies': adjacency_array(gc.adjacencies), 'true_breakpoints': true_bps, 'brk_cn': brk_cn,
+           'min_brk_cn': min_brk_cn, 'balanced': balanced, 'chromosome': np.array(gc.segment_chromosome_id),
+           'segment_start': gc.segment_start, 'segment_end': gc.segment_end, 'case_names': np.array([c[0] for c in EVALUATION_CASES])}
+    for i, (cname, frac_1, merge_every, noise, total_only, single, mix_pred) in enumerate(EVALUATION_CASES):
+        np.random.seed(2000 + i)
+        gm = rsim.GenomeMixtureSampler({'frac_normal': 0.4, 'frac_clone_1': frac_1, 'num_false_breakpoints': 6}).sample_genome_mixture(gc)
+        tab, btab = _prediction_tables(np.random.default_rng(seed + i), gm, merge_every, noise, total_only, single)
+        res = ref.evaluate_results(gm, tab, btab, np.array(mix_pred))
+        out[cname + '_frac_clone_1'] = np.array(frac_1); out[cname + '_mix_pred'] = np.array(mix_pred)
+        out[cname + '_cn_chromosome'] = np.array(tab['chromosome'].values.tolist())
+        out[cname + '_cn_columns'] = np.array([c for c in tab.columns if c != 'chromosome'])
+        out[cname + '_cn_values'] = tab[[c for c in tab.columns if c != 'chromosome']].values.astype(np.int64)
+        out[cname + '_brk_columns'] = np.array(list(btab.columns)); out[cname + '_brk_values'] = btab.values.astype(np.int64)
+        for key in ('cn_evaluation', 'brk_cn_evaluation', 'mix_results'):
+            out[cname + '_' + key + '_keys'] = np.array(list(res[key].index)); out[cname + '_' + key + '_values'] = res[key].values.astype(float)
+        bt = res['brk_cn_table']
+        cols = ['prediction_id', 'cn_correct', 'true_present', 'pred_present', 'true_subclonal', 'pred_subclonal']
+        out[cname + '_brk_table'] = bt[cols].values.astype(np.int64)
+    reseg = ref.remixt.segalg.reindex_segments(
+        __import__('pandas').DataFrame({'chromosome': out['chromosome'], 'start': out['segment_start'], 'end': out['segment_end']}), tab)
+    out['reindex_last'] = reseg[['start', 'end', 'idx_1', 'idx_2']].values.astype(np.int64)
+    out['reindex_last_chromosome'] = np.array(reseg['chromosome'].values.tolist())
+    np.savez_compressed(os.path.join(OUT, name + '.npz'), **out)
+    print(name, 'cases', len(EVALUATION_CASES))
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     build_ref.build()
@@ -379,6 +470,7 @@ def main():
     pipeline_case('pipeline_init_strict', N=900, seed=6, min_ploidy=7.5, max_ploidy=8.0, random_seed=99)
     pipeline_case('pipeline_init_closest', N=900, seed=7, min_ploidy=2.95, max_ploidy=3.0, random_seed=7)
     sampler_cases('simulations', N=300, seed=3)
+    evaluation_case('evaluation', N=400, seed=9)
 
 
 if __name__ == '__main__':

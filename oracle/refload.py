@@ -30,6 +30,17 @@ REF = os.environ.get("REMIXT_REFERENCE", "/root/reference")
 REF_BIN = os.path.join(HERE, "_ref", "remixt")
 
 
+def _placeholder_if_absent(names):
+    """Register an empty module for every name that cannot be imported (never shadows a real package)."""
+    for name in names:
+        if name in sys.modules:
+            continue
+        try:
+            importlib.import_module(name)
+        except Exception:
+            sys.modules[name] = types.ModuleType(name)
+
+
 def _ensure_pkg(with_sources):
     pkg = sys.modules.get("remixt")
     if pkg is None or not getattr(pkg, "_oracle_synthetic", False):
@@ -67,9 +78,7 @@ def load_ref_cn_model():
         raise ImportError("reference sources not present")
     load_ref_bpmodel()
     _ensure_pkg(with_sources=True)
-    for name in ("statsmodels", "statsmodels.tools", "statsmodels.tools.numdiff"):
-        if name not in sys.modules:
-            sys.modules[name] = types.ModuleType(name)
+    _placeholder_if_absent(("statsmodels", "statsmodels.tools", "statsmodels.tools.numdiff"))
     return importlib.import_module("remixt.cn_model")
 
 
@@ -79,9 +88,7 @@ def load_ref_analysis():
     by remixt/utils.py:10 and unused on this path; it is absent from this image, so an empty placeholder
     module is registered for the import to succeed."""
     load_ref_cn_model()
-    for name in ("pypeliner", "pypeliner.commandline"):
-        if name not in sys.modules:
-            sys.modules[name] = types.ModuleType(name)
+    _placeholder_if_absent(("pypeliner", "pypeliner.commandline"))
     return tuple(importlib.import_module(m) for m in
                  ("remixt.likelihood", "remixt.analysis.experiment", "remixt.analysis.readdepth", "remixt.analysis.pipeline"))
 
@@ -89,12 +96,21 @@ def load_ref_analysis():
 def load_ref_simulations():
     """The reference's simulation module (`remixt/simulations/experiment.py`), imported in place, for the
     genome-mixture and read-count samplers (:965-1399).  `remixt/simulations/balanced.py` imports
-    `networkx` and `blossomv.blossomv` at module level; both are absent from this image and only used
-    by `collapsed_balanced_breakpoints`, so empty placeholder modules are registered for the import to
-    succeed.  The rearrangement-history sampler in the same file calls `scipy.misc.logsumexp`
+    `networkx` and `blossomv.blossomv` at module level, only used by `collapsed_balanced_breakpoints`;
+    `blossomv` is absent from this image, so an empty placeholder module is registered for the import to
+    succeed (a package that is importable is never shadowed).  The rearrangement-history sampler in the same file calls `scipy.misc.logsumexp`
     (:698), which no longer exists: that part is not usable here and no vectors come from it."""
     load_ref_analysis()
-    for name in ("networkx", "blossomv", "blossomv.blossomv"):
-        if name not in sys.modules:
-            sys.modules[name] = types.ModuleType(name)
+    _placeholder_if_absent(("networkx", "blossomv", "blossomv.blossomv"))
     return importlib.import_module("remixt.simulations.experiment")
+
+
+def load_ref_evaluation():
+    """The reference's accuracy statistics (`remixt/simulations/pipeline.py:343-647`, `evaluate_results`
+    and the two functions under it; `remixt/segalg.py:260-336` `reindex_segments`), imported in place.
+    The module also imports the read simulator, whose `remixt/seqdataio.py` needs the reference's compiled
+    `remixt.bamreader` (htslib sources, not buildable here) -- unused by the evaluation functions, so an
+    empty placeholder module is registered for that import."""
+    load_ref_simulations()
+    _placeholder_if_absent(("remixt.bamreader",))
+    return importlib.import_module("remixt.simulations.pipeline")

@@ -170,7 +170,8 @@ class GenomeCollection(object):
     lengths and coordinates, per-clone copy number, reference adjacencies and the set of true
     breakpoints."""
 
-    def __init__(self, l, cn, adjacencies, breakpoints, segment_chromosome_id, segment_start, segment_end):
+    def __init__(self, l, cn, adjacencies, breakpoints, segment_chromosome_id, segment_start, segment_end,
+                 breakpoint_copy_number=None, minimal_breakpoint_copy_number=None, balanced_breakpoints=None):
         self.l = np.asarray(l)
         self.cn = np.asarray(cn)
         self.adjacencies = adjacencies
@@ -178,6 +179,29 @@ class GenomeCollection(object):
         self.segment_chromosome_id = segment_chromosome_id
         self.segment_start = segment_start
         self.segment_end = segment_end
+        # truth for remixt_amd.evaluate.evaluate_brk_cn_results: breakpoint -> copies per clone (normal first)
+        self._brk_cn = breakpoint_copy_number
+        self._min_brk_cn = minimal_breakpoint_copy_number if minimal_breakpoint_copy_number is not None else breakpoint_copy_number
+        self._balanced = balanced_breakpoints if balanced_breakpoints is not None else set()
+
+    def collapsed_breakpoint_copy_number(self):
+        """Per-clone copies of every true breakpoint (simulations/experiment.py:856-857).  Without a
+        recorded history the copies are the copy-number steps at the breakends (decode_breakpoints_naive)."""
+        if self._brk_cn is None:
+            from .cn_model import decode_breakpoints_naive
+            self._brk_cn = decode_breakpoints_naive(self.cn, self.adjacencies, dict((b, b) for b in self.breakpoints))
+            if self._min_brk_cn is None:
+                self._min_brk_cn = self._brk_cn
+        return self._brk_cn
+
+    def collapsed_minimal_breakpoint_copy_number(self):
+        """simulations/experiment.py:859-862 (here: the same table unless one was given)."""
+        self.collapsed_breakpoint_copy_number()
+        return self._min_brk_cn
+
+    def collapsed_balanced_breakpoints(self):
+        """simulations/experiment.py:864-865 (here: the set given at construction, empty by default)."""
+        return self._balanced
 
     @property
     def N(self):

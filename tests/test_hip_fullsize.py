@@ -141,6 +141,14 @@ def test_fit_recovers_a_sampled_experiment(hip):
     ev = evaluate.evaluate_cn(e.cn, results[best]['cn'], e.l, h_true=e.h, h_pred=results[best]['h'], allow_swap=True)
     assert ev['proportion_dom_cn_correct'] > 0.8, ev
     assert abs(ev['pred_ploidy'] - ev['true_ploidy']) < 0.35, ev
+    # the reference's own scoring of the same solution, through the result tables (analysis/experiment.py
+    # create_cn_table / create_brk_cn_table -> simulations/pipeline.py evaluate_results)
+    from remixt_amd.analysis import experiment as ex
+    cn_table = ex.create_cn_table(e, results[best]['cn'], results[best]['h'])
+    brk_table = ex.create_brk_cn_table(results[best]['brk_cn'], e.breakpoint_segment_data)
+    scored = evaluate.evaluate_results(gm, cn_table, brk_table, results[best]['h'] / results[best]['h'].sum())
+    assert scored['cn_evaluation']['proportion_dom_cn_correct'] > 0.8, scored['cn_evaluation']
+    assert scored['brk_cn_evaluation']['brk_cn_correct_proportion'] > 0.5, scored['brk_cn_evaluation']
     # outlier calls: the sampler's flagged total-count outliers get more outlier posterior than the rest
     q = results[best]['p_outlier_total'][:, 1]
     flagged = np.asarray(e.is_outlier_total)
