@@ -177,6 +177,16 @@ int rmx_expected_ll_batch(rmx_batch *b, int32_t nreq, const int32_t *restarts, i
  * the value of the restart's last evaluation, as the sequential scipy run leaves it. */
 int rmx_param_search(rmx_batch *b, int32_t nreq, const int32_t *restarts, int32_t param_id, double lo, double hi,
                      const double *grid, int32_t G, double *xopt);
+/* The four standard searches of every listed restart in the same evaluation rounds (they move disjoint
+ * likelihood components and do not write to the model while searching, cn_model.py:533-561 x 4):
+ * param_ids [nparams] a subset of negbin_r_0/1, betabin_M_0/1; slot j = position in param_ids, its
+ * samples given by rmx_set_sample_slot; lo / hi [nparams]; grids [nparams][G]; xopt / lastval
+ * [nparams][nreq] = optimiser result and last evaluated point (the state the acceptance test of
+ * cn_model.py:563-569 looks at).  The model is not modified.  RMX_EUNSUPPORTED: use rmx_param_search. */
+int rmx_set_sample_slot(rmx_batch *b, int32_t r, int32_t slot, const int64_t *sample);
+int rmx_param_search_multi(rmx_batch *b, int32_t nreq, const int32_t *restarts, int32_t nparams,
+                           const int32_t *param_ids, const double *lo, const double *hi,
+                           const double *grids, int32_t G, double *xopt, double *lastval);
 /* Lock-step h M-step (BreakpointModel.update_h, cn_model.py:482-531): one candidate haploid-depth
  * vector h[i][0..M) per listed restart; out[i][0] = E[ll] (calculate_expected_log_likelihood,
  * bpmodel.pyx:1125-1157) and out[i][1..M] = dE[ll]/dh (calculate_expected_log_likelihood_partial_h,

@@ -336,6 +336,30 @@ class RemixtBatch(object):
                                             g.ctypes.data_as(_dp), len(g), out.ctypes.data_as(_dp)))
         return out
 
+    def set_sample_slot(self, r, slot, sample):
+        """The M-step sample of restart r for parameter slot `slot` of param_search_multi."""
+        s64 = _i64(sample)
+        if s64.shape != (self.num_segments,):
+            raise ValueError('sample must have length num_segments')
+        self._ck(self._lib.rmx_set_sample_slot(self._handle, int(r), int(slot), s64.ctypes.data_as(_ip)))
+
+    def param_search_multi(self, restarts, names, los, his, grids):
+        """The searches of param_search for several of the four standard likelihood parameters at once
+        (rmx_param_search_multi; samples from set_sample_slot, slot = position in `names`).  Returns
+        (xopt, lastval), each [len(names)][len(restarts)]; the model is not modified.  Raises
+        NotImplementedError when the request does not qualify -- fall back to param_search."""
+        rl = np.ascontiguousarray(restarts, dtype=np.int32)
+        ids = np.ascontiguousarray([PARAM_IDS[n] for n in names], dtype=np.int32)
+        lo = _f64(los).ravel(); hi = _f64(his).ravel()
+        g = _f64(grids)
+        if g.ndim != 2 or g.shape[0] != len(ids) or len(lo) != len(ids) or len(hi) != len(ids):
+            raise ValueError('one grid, lower and upper bound per parameter')
+        xopt = np.zeros((len(ids), len(rl))); last = np.zeros((len(ids), len(rl)))
+        self._ck(self._lib.rmx_param_search_multi(self._handle, len(rl), rl.ctypes.data_as(_i32p), len(ids), ids.ctypes.data_as(_i32p),
+                                                  lo.ctypes.data_as(_dp), hi.ctypes.data_as(_dp), g.ctypes.data_as(_dp), g.shape[1],
+                                                  xopt.ctypes.data_as(_dp), last.ctypes.data_as(_dp)))
+        return xopt, last
+
     def expected_log_likelihood_h_batch(self, restarts, hs):
         """(E[ll], dE[ll]/dh) on each listed restart's current sample with h set to the matching row
         of `hs` (and left there): the evaluation round of the lock-step h M-step."""

@@ -65,8 +65,11 @@ struct rmx_batch {
     double *d_ell_partial = nullptr;   // [max(N,ELBO_BLOCKS)][1+MAXC]
     double *d_ell_out = nullptr;       // [1+MAXC]
     double *h_pinned = nullptr;        // pinned staging [max(4R, 16)]
-    uint32_t *h_err = nullptr;         // pinned [R]: landing area of check_errors
+    uint32_t *h_err = nullptr;         // pinned [4R+64]: landing area of check_errors / per-request error words
     int32_t *d_sample = nullptr;       // [R][N] index lists of the current M-step samples
+    int32_t *d_msample = nullptr, *d_mcounts = nullptr;   // [4][R][N], [4][R]: per parameter slot, for rmx_param_search_multi
+    std::vector<int> msample_count;    // [4][R], -1 = not set
+    double *d_mpartial = nullptr; size_t mpartial_cap = 0;
     std::vector<std::vector<int64_t>> sample_cache; std::vector<int> sample_count;
     double *d_grid_out = nullptr;      // [R][64][1+MAXC]
     int32_t *d_rlist = nullptr, *d_counts = nullptr; RestartParams *d_rp_stage = nullptr; double *d_batch_out = nullptr;   // [R] each
@@ -728,7 +731,7 @@ int rmx_batch_create(const rmx_problem *pr, int32_t R, const double *h_init, con
         (rc = dalloc(b, &b->d_sample, (size_t)R * N)) || (rc = dalloc(b, &b->d_grid_out, (size_t)R * 64 * (1 + RMX_MAX_CLONES))) ||
         (rc = dalloc(b, &b->d_rlist, R)) || (rc = dalloc(b, &b->d_counts, R)) || (rc = dalloc(b, &b->d_rp_stage, R)) || (rc = dalloc(b, &b->d_batch_out, (size_t)R * 8))) { rmx_batch_destroy(b); return rc; }
     HIPCHK(hipHostMalloc((void **)&b->h_pinned, sizeof(double) * (size_t)(R + 1) * 64 * (1 + RMX_MAX_CLONES)));
-    HIPCHK(hipHostMalloc((void **)&b->h_err, sizeof(uint32_t) * (size_t)R));
+    HIPCHK(hipHostMalloc((void **)&b->h_err, sizeof(uint32_t) * ((size_t)R * 4 + 64)));      // one word per request of a round (<= 4R in rmx_param_search_multi)
     HIPCHK(hipHostMalloc(&b->h_batch, (size_t)R * (sizeof(RestartParams) + 64) + 4096));
     HIPCHK(hipEventCreate(&b->tm_a)); HIPCHK(hipEventCreate(&b->tm_b));
     b->done_ev.resize(R);
@@ -1720,6 +1723,145 @@ int rmx_param_search(rmx_batch *b, int32_t nreq, const int32_t *restarts, int32_
     // last evaluation, as the sequential scipy run (and the table-rebuilding path) does
     if (table_free) for (int i = 0; i < nreq; i++) if ((rc = rmx_set_param(b, restarts[i], param_id, lastval[i]))) return rc;
     for (int i = 0; i < nreq; i++) xopt[i] = nm[i].xopt();
+    return RMX_OK;
+}
+
+// The sample of restart r for parameter slot `slot` (0..3) of rmx_param_search_multi
+int rmx_set_sample_slot(rmx_batch *b, int32_t r, int32_t slot, const int64_t *sample) {
+    if (!b || r < 0 || r >= b->R || slot < 0 || slot > 3 || !sample) return fail(RMX_EARG, "bad argument");
+    const Dev &d = b->d;
+    int rc;
+    if (!b->d_msample) {
+        if ((rc = dalloc(b, &b->d_msample, (size_t)4 * b->R * d.N)) || (rc = dalloc(b, &b->d_mcounts, (size_t)4 * b->R))) return rc;
+        b->msample_count.assign((size_t)4 * b->R, -1);
+    }
+    std::vector<int32_t> idx;
+    idx.reserve(256);
+    for (int n = 0; n < d.N; n++) if (sample[n] != 0) idx.push_back(n);
+    const size_t q = (size_t)slot * b->R + r;
+    b->msample_count[q] = (int)idx.size();
+    { int32_t c32 = (int32_t)idx.size(); HIPCHK(hipMemcpy(b->d_mcounts + q, &c32, 4, hipMemcpyHostToDevice)); }
+    if (!idx.empty()) HIPCHK(hipMemcpy(b->d_msample + q * d.N, idx.data(), idx.size() * 4, hipMemcpyHostToDevice));
+    return RMX_OK;
+}
+
+// rmx_param_search for up to four of the standard likelihood parameters (negbin_r_0/1, betabin_M_0/1, each
+// at most once) of every listed restart AT ONCE: the searches of one restart are independent -- each
+// evaluates only the likelihood component its parameter moves, on its own sample (rmx_set_sample_slot, slot
+// = position in param_ids), against a model nothing writes to -- so all of them share their evaluation
+// rounds: one launch pair and one stream wait per round for nparams x nreq optimisers instead of nreq.
+// The objective of a search is its component's part of -E[ll] alone (the full-sum form differs by a
+// constant, i.e. by rounding only).  Nothing is written to the model: xopt / lastval [nparams][nreq]
+// return the optimisers' results and the last point each one evaluated (what the reference's acceptance
+// test looks at); the caller sets parameters.  RMX_EUNSUPPORTED when the request does not qualify (other
+// parameters, lists of states with posterior mass not current, more than 64 optimisers, G > 20, ...):
+// the caller falls back to rmx_param_search per parameter.
+int rmx_param_search_multi(rmx_batch *b, int32_t nreq, const int32_t *restarts, int32_t nparams, const int32_t *param_ids,
+                           const double *lo, const double *hi, const double *grids, int32_t G, double *xopt, double *lastval) {
+    if (!b || nreq < 1 || nreq > b->R || !restarts || nparams < 1 || nparams > 4 || !param_ids || !lo || !hi || !grids || G < 1 || !xopt || !lastval)
+        return fail(RMX_EARG, "bad argument");
+    int rc;
+    if ((rc = check_request_list(b, nreq, restarts))) return rc;
+    const Dev &d = b->d;
+    const int Q = nreq * nparams;
+    MultiVals mv;
+    memset(&mv, 0, sizeof(mv));
+    int used = 0;
+    for (int j = 0; j < nparams; j++) {
+        int bit = 0;
+        switch (param_ids[j]) {
+        case RMX_P_NEGBIN_R_0: bit = CM_LT0; break; case RMX_P_NEGBIN_R_1: bit = CM_LT1; break;
+        case RMX_P_BETABIN_M_0: bit = CM_LA0; break; case RMX_P_BETABIN_M_1: bit = CM_LA1; break;
+        default: return fail(RMX_EUNSUPPORTED, "rmx_param_search_multi: not one of the four standard parameters");
+        }
+        if (used & bit) return fail(RMX_EUNSUPPORTED, "rmx_param_search_multi: parameter listed twice");
+        used |= bit; mv.maskbit[j] = bit;
+        if (!(lo[j] > 0.)) return fail(RMX_EUNSUPPORTED, "rmx_param_search_multi: lower bound must be positive");
+    }
+    if (Q > 64 || G > RMX_MULTI_G || !ell_sparse_ok(b, nreq, restarts) || !b->d_msample)
+        return fail(RMX_EUNSUPPORTED, "rmx_param_search_multi: request does not qualify");
+    int maxcnt = 0;
+    for (int j = 0; j < nparams; j++)
+        for (int i = 0; i < nreq; i++) {
+            const int c = b->msample_count[(size_t)j * b->R + restarts[i]];
+            if (c < 0) return fail(RMX_EARG, "no sample set for a listed restart and parameter slot");
+            maxcnt = std::max(maxcnt, c);
+            mv.rlist[j * nreq + i] = (int16_t)restarts[i]; mv.slot[j * nreq + i] = (int8_t)j;
+        }
+    if ((size_t)Q * G > (size_t)(b->R + 1) * 64 * (1 + RMX_MAX_CLONES) || b->R > 32767)
+        return fail(RMX_EUNSUPPORTED, "rmx_param_search_multi: staging too small for this request");
+    const size_t need = (size_t)Q * G * std::max(maxcnt, 1);      // partial sums [request][candidate][sampled segment]
+    if (b->mpartial_cap < need) {
+        dfree(b, b->d_mpartial); b->d_mpartial = nullptr; b->mpartial_cap = 0;
+        if ((rc = dalloc(b, &b->d_mpartial, need))) return rc;
+        b->mpartial_cap = need;
+    }
+    for (int j = 0; j < nparams; j++)
+        for (int g = 0; g < G; g++) { mv.gv[j][g] = grids[(size_t)j * G + g]; mv.glv[j][g] = std::log(mv.gv[j][g]); }
+    // one round: requests cur[0..n) (indices q = j * nreq + i), their values vals[] (ignored in the grid stage)
+    std::vector<double> out((size_t)Q * G);
+    auto round = [&](int n_, const int *cur, const double *vals, bool grid_stage) -> int {
+        MultiVals m2 = mv;
+        m2.grid_stage = grid_stage ? 1 : 0; m2.Gz = grid_stage ? G : 1;
+        int mc = 0;
+        for (int k = 0; k < n_; k++) {
+            const int q = cur[k];
+            m2.rlist[k] = mv.rlist[q]; m2.slot[k] = mv.slot[q];
+            m2.v[k] = grid_stage ? 1. : vals[k]; m2.lv[k] = std::log(m2.v[k]);
+            mc = std::max(mc, b->msample_count[(size_t)mv.slot[q] * b->R + mv.rlist[q]]);
+        }
+        for (int k = n_; k < 64; k++) { m2.rlist[k] = m2.rlist[0]; m2.slot[k] = m2.slot[0]; m2.v[k] = m2.v[0]; m2.lv[k] = m2.lv[0]; }
+        {
+            std::lock_guard<std::mutex> lk(b->mu);
+            if (mc > 0) {
+                ProfScope ps(b, KID_ELL_LIST);
+                hipLaunchKernelGGL(k_ell_search_multi, dim3((mc + 3) / 4, n_, m2.Gz), dim3(256), 0, b->stream, b->d, m2, (const int32_t *)b->d_msample,
+                                   (const int32_t *)b->d_mcounts, b->d_mpartial, std::max(mc, 1));
+            }
+            { ProfScope ps(b, KID_ELL_FINAL); hipLaunchKernelGGL(k_ell_multi_final, dim3(n_ * m2.Gz), dim3(256), 0, b->stream, b->d, m2, (const int32_t *)b->d_mcounts,
+                                                                 (const double *)b->d_mpartial, std::max(mc, 1), b->h_pinned, b->h_err); }
+            HIPCHK(hipGetLastError());
+        }
+        HIPCHK(hipStreamSynchronize(b->stream));
+        for (int k = 0; k < n_; k++) {
+            if (!b->h_err[k]) continue;
+            const uint32_t ev = b->h_err[k];
+            HIPCHK(hipMemsetAsync(b->d.err + m2.rlist[k], 0, sizeof(uint32_t), b->stream));
+            return translate_error(b, m2.rlist[k], ev);
+        }
+        for (int k = 0; k < n_ * m2.Gz; k++) out[k] = b->h_pinned[k];
+        return RMX_OK;
+    };
+    std::vector<int> all(Q);
+    for (int q = 0; q < Q; q++) all[q] = q;
+    if ((rc = round(Q, all.data(), nullptr, true))) return rc;
+    std::vector<double> x0(Q), best(Q, INFINITY);
+    for (int q = 0; q < Q; q++) {
+        const int j = q / nreq;
+        for (int g = 0; g < G; g++) { const double J = -out[(size_t)q * G + g]; if (g == 0 || J < best[q]) { best[q] = J; x0[q] = grids[(size_t)j * G + g]; } }   // np.argmin: first minimum
+        lastval[q] = grids[(size_t)j * G + (G - 1)];
+    }
+    std::vector<Nm1> nm(Q);
+    std::vector<int> want;
+    auto pump = [&](int q, double f) {
+        const int j = q / nreq;
+        while (nm[q].advance(x0[q], f)) {
+            const double v = nm[q].req;
+            if (v < lo[j] || v > hi[j]) { f = INFINITY; continue; }      // +inf outside the bounds, nothing evaluated (cn_model.py:542-543)
+            want.push_back(q);
+            return;
+        }
+    };
+    for (int q = 0; q < Q; q++) pump(q, 0.);
+    std::vector<double> vals(Q);
+    while (!want.empty()) {
+        std::vector<int> cur;
+        cur.swap(want);
+        for (size_t k = 0; k < cur.size(); k++) { vals[k] = nm[cur[k]].req; lastval[cur[k]] = vals[k]; }
+        if ((rc = round((int)cur.size(), cur.data(), vals.data(), false))) return rc;
+        for (size_t k = 0; k < cur.size(); k++) pump(cur[k], -out[k]);
+    }
+    for (int q = 0; q < Q; q++) xopt[q] = nm[q].xopt();
     return RMX_OK;
 }
 

@@ -2094,6 +2094,50 @@ __global__ __launch_bounds__(256) void k_ell_search_sparse(Dev d, SearchVals sv,
     if (MASK == CM_LA1) rp.p[RMX_P_BETABIN_M_1] = sv.v[vi];
     ell_segment_sparse<MASK, true>(d, rp, r, n, partial + ((size_t)(req * sv.Gz + gz) * maxcnt + i));
 }
+// ---- all four standard parameter searches of a restart group in the same rounds -------------------------
+// The four likelihood parameters move disjoint components of E[ll] (negbin_r_0: LT0, negbin_r_1: LT1,
+// betabin_M_0: LA0, betabin_M_1: LA1), each search evaluates only its own component, and the restart's
+// model is not touched while candidates are evaluated: the four searches of a restart are independent of
+// each other and advance together.  A request is a (restart, parameter slot) pair; slot j has its own
+// sample per restart (samples [4][R][N], counts [4][R]).  grid_stage: candidate gz of every request is
+// gv[slot][gz]; otherwise request q evaluates v[q] (Gz = 1).
+#define RMX_MULTI_G 20
+struct MultiVals {
+    double v[64], lv[64];
+    double gv[4][RMX_MULTI_G], glv[4][RMX_MULTI_G];
+    int16_t rlist[64];
+    int8_t slot[64];
+    int32_t maskbit[4];
+    int32_t grid_stage, Gz, pad0, pad1;
+};
+// grid (ceil(maxcount / 4), nreq, Gz), block 256: a wave per sampled segment
+__global__ __launch_bounds__(256) void k_ell_search_multi(Dev d, MultiVals mv, const int32_t *samples, const int32_t *counts, double *partial, int maxcnt) {
+    const int req = blockIdx.y, gz = blockIdx.z;
+    const int r = mv.rlist[req], sl = mv.slot[req];
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= counts[sl * d.R + r]) return;
+    const int n = samples[((size_t)sl * d.R + r) * d.N + i];
+    RestartParams rp = d.rp[r];
+    const double v = mv.grid_stage ? mv.gv[sl][gz] : mv.v[req], lv = mv.grid_stage ? mv.glv[sl][gz] : mv.lv[req];
+    double *prow = partial + ((size_t)(req * mv.Gz + gz) * maxcnt + i);
+    switch (mv.maskbit[sl]) {
+    case CM_LT0: rp.p[RMX_P_NEGBIN_R_0] = v; rp.logr[0] = lv; ell_segment_sparse<CM_LT0, true>(d, rp, r, n, prow); break;
+    case CM_LT1: rp.p[RMX_P_NEGBIN_R_1] = v; rp.logr[1] = lv; ell_segment_sparse<CM_LT1, true>(d, rp, r, n, prow); break;
+    case CM_LA0: rp.p[RMX_P_BETABIN_M_0] = v; ell_segment_sparse<CM_LA0, true>(d, rp, r, n, prow); break;
+    default:     rp.p[RMX_P_BETABIN_M_1] = v; ell_segment_sparse<CM_LA1, true>(d, rp, r, n, prow); break;
+    }
+}
+// grid (nreq * Gz): fixed-order sum of the partials of (request, candidate), as k_ell_search_final
+__global__ void k_ell_multi_final(Dev d, MultiVals mv, const int32_t *counts, const double *partial, int maxcnt, double *out, uint32_t *err_out) {
+    __shared__ double scratch[8];
+    const int req = blockIdx.x / mv.Gz;
+    const int r = mv.rlist[req], cnt = counts[mv.slot[req] * d.R + r];
+    if (err_out && threadIdx.x == 0 && blockIdx.x % mv.Gz == 0) err_out[req] = d.err[r];
+    double a = 0.;
+    for (int i = threadIdx.x; i < cnt; i += 256) a += partial[(size_t)blockIdx.x * maxcnt + i];
+    a = block_sum<256>(a, scratch);
+    if (threadIdx.x == 0) out[blockIdx.x] = a;
+}
 // grid (nreq * Gz): the sum of k_ell_final_batch over the partials of (request, candidate)
 __global__ void k_ell_search_final(Dev d, SearchVals sv, const int32_t *counts, const double *partial, int maxcnt, double *out, uint32_t *err_out) {
     __shared__ double scratch[8];

@@ -250,19 +250,61 @@ class RestartSet(object):
             for m in self.models:
                 m._mstep_indicator_cache = None
 
-    def _params_lockstep_body(self, b, R, ids_all):
-        for name in self.models[0].likelihood_params:
-            lo, hi = self.models[0].likelihood_param_bounds[name]
+    _MULTI_PARAMS = ('negbin_r_0', 'negbin_r_1', 'betabin_M_0', 'betabin_M_1')
+
+    def _search_standard_params_together(self, b, R, ids_all, names):
+        """The searches of the leading standard parameters in shared evaluation rounds
+        (rmx_param_search_multi): {name: (xopt, lastval)} or {} when the batch cannot.  The samples are
+        drawn here, parameter by parameter in the reference's order, so every restart's RNG stream is
+        consumed exactly as by the sequential loop (weights depend on the outlier indicators only)."""
+        import os
+        first = []
+        for name in names:
+            if name not in self._MULTI_PARAMS or len(first) == 4:
+                break
+            first.append(name)
+        sequential = any(os.environ.get(k) for k in ('RMX_SEARCH_SEQUENTIAL', 'RMX_SEARCH_TABLES', 'RMX_SEARCH_FULL', 'RMX_SEARCH_LOOKAHEAD'))
+        if not (first and self.native_search and hasattr(b, 'param_search_multi')) or sequential:
+            return {}, {}
+        bounds = [self.models[0].likelihood_param_bounds[name] for name in first]
+        samples = {}
+        for j, name in enumerate(first):
             weights = [m.get_param_sample_weight(name) for m in self.models]
+            samples[name] = self._samples(weights)
+            for r, smp in enumerate(samples[name]):
+                b.set_sample_slot(r, j, smp)
+        grids = np.array([np.mgrid[lo:hi:complex(20)] for lo, hi in bounds])
+        try:
+            xopt, last = b.param_search_multi(ids_all, first, [lo for lo, hi in bounds], [hi for lo, hi in bounds], grids)
+        except NotImplementedError:
+            return {}, samples           # the samples are drawn: the sequential searches below use them
+        return dict((name, (xopt[j], last[j])) for j, name in enumerate(first)), samples
+
+    def _params_lockstep_body(self, b, R, ids_all):
+        names = list(self.models[0].likelihood_params)
+        together, drawn = self._search_standard_params_together(b, R, ids_all, names)
+        for name in names:
+            lo, hi = self.models[0].likelihood_param_bounds[name]
             value_before = [b.get_param(r, name) for r in ids_all]
             ell_before = b.expected_log_likelihood_full(0, R)
-            for r, smp in enumerate(self._samples(weights)):
-                b._use_sample(r, smp)
-            grid = np.mgrid[lo:hi:complex(20)]
-            if self.native_search and hasattr(b, 'param_search'):
-                xopt = b.param_search(ids_all, name, lo, hi, grid)       # the same search, host loop in C++
+            if name in together:
+                # searched already, model untouched: put the parameter where the sequential search leaves it
+                # (the last point the optimiser evaluated, cn_model.py:563-569)
+                xopt, last = together[name]
+                for r in ids_all:
+                    b.set_param(r, name, float(last[r]))
             else:
-                xopt = self._param_search_python(name, lo, hi, grid)
+                if name in drawn:
+                    smps = drawn[name]
+                else:
+                    smps = self._samples([m.get_param_sample_weight(name) for m in self.models])
+                for r, smp in enumerate(smps):
+                    b._use_sample(r, smp)
+                grid = np.mgrid[lo:hi:complex(20)]
+                if self.native_search and hasattr(b, 'param_search'):
+                    xopt = b.param_search(ids_all, name, lo, hi, grid)       # the same search, host loop in C++
+                else:
+                    xopt = self._param_search_python(name, lo, hi, grid)
             # the accept test on trial values: a rejected value is rolled back without a second pass over
             # the cells (the restart's expectations and cell cache still belong to value_before)
             trial = hasattr(b, 'expected_log_likelihood_full_trial')

@@ -327,34 +327,42 @@ def test_lockstep_mstep_equals_per_restart_mstep(hip):
     e = synthetic.make_experiment(600, num_clones=3, max_copy_number=3, num_chains=5, seed=6)
     ps = synthetic.make_init_params(e, 4, 3)
     import os
+    knobs = ('RMX_SEARCH_TABLES', 'RMX_SEARCH_LOOKAHEAD', 'RMX_SEARCH_SEQUENTIAL')
+    configs = [
+        (True, True, ()),                          # 0: native, the four standard searches in shared rounds
+        (True, False, ()),                         # 1: python lock-step
+        (False, False, ()),                        # 2: per-restart scipy
+        (True, True, ('RMX_SEARCH_TABLES',)),      # 3: native, one parameter at a time, table-rebuilding evaluation rounds
+        (True, True, ('RMX_SEARCH_LOOKAHEAD',)),   # 4: native, one at a time, rounds that also evaluate the optimisers' possible next points
+        (True, True, ('RMX_SEARCH_SEQUENTIAL',)),  # 5: native, one at a time, table-free rounds
+    ]
     out = []
-    for lock, native, tables in ((True, True, False), (True, False, False), (False, False, False), (True, True, True), (True, True, 'plain')):
-        os.environ.pop('RMX_SEARCH_TABLES', None)
-        os.environ.pop('RMX_SEARCH_LOOKAHEAD', None)
-        if tables == 'plain':
-            os.environ['RMX_SEARCH_LOOKAHEAD'] = '1'      # rounds that also evaluate the optimisers' possible next points
-        elif tables:
-            os.environ['RMX_SEARCH_TABLES'] = '1'      # candidate values through the table-rebuilding evaluation rounds
+    for lock, native, env in configs:
+        for k in knobs:
+            os.environ.pop(k, None)
+        for k in env:
+            os.environ[k] = '1'
         rs = RestartSet(e, ps, max_copy_number=3, num_clones=3, quiet=True, seeds=[5, 6, 7, 8], lockstep=lock,
                         native_search=native, mstep_threads=1)
         rs.fit(num_em_iter=2, num_update_iter=2)
         out.append([(m.prev_elbo, np.array(m.h), m.get_likelihood_param_values()) for m in rs.models])
-    os.environ.pop('RMX_SEARCH_TABLES', None)
-    os.environ.pop('RMX_SEARCH_LOOKAHEAD', None)
+    for k in knobs:
+        os.environ.pop(k, None)
     # the table-free search kernel evaluates exactly what the table-rebuilding rounds evaluate, and the
     # optional look-ahead evaluations change nothing any optimiser sees
-    for (e1, h1, p1), (e2, h2, p2) in list(zip(out[0], out[3])) + list(zip(out[0], out[4])):
+    for (e1, h1, p1), (e2, h2, p2) in list(zip(out[5], out[3])) + list(zip(out[5], out[4])):
         assert e1 == e2 and np.array_equal(h1, h2) and p1 == p2
     # python lock-step == per-restart scipy path, bit for bit
     for (e1, h1, p1), (e2, h2, p2) in zip(out[1], out[2]):
         assert e1 == e2 and np.array_equal(h1, h2) and p1 == p2
-    # the native search evaluates only the likelihood component the parameter moves and adds the rest as
-    # a constant taken from one full evaluation: same objective up to rounding
-    for (e1, h1, p1), (e2, h2, p2) in zip(out[0], out[1]):
-        assert abs(e1 - e2) <= 1e-8 * abs(e2)
-        np.testing.assert_allclose(h1, h2, rtol=1e-6)
-        for k in p1:
-            assert abs(p1[k] - p2[k]) <= 1e-3 + 1e-5 * abs(p2[k]), k
+    # the native searches evaluate only the likelihood component the parameter moves (plus, one at a time, the
+    # rest as a constant from one full evaluation; none in the shared rounds): same objective up to rounding
+    for a_, b_ in ((0, 1), (5, 1), (0, 5)):
+        for (e1, h1, p1), (e2, h2, p2) in zip(out[a_], out[b_]):
+            assert abs(e1 - e2) <= 1e-8 * abs(e2)
+            np.testing.assert_allclose(h1, h2, rtol=1e-6)
+            for k in p1:
+                assert abs(p1[k] - p2[k]) <= 1e-3 + 1e-5 * abs(p2[k]), k
 
 
 def test_restart_groups_do_not_change_results(hip):
