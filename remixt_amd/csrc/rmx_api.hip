@@ -38,6 +38,8 @@ struct ProfRec { int id; hipEvent_t a, b; };
 struct rmx_batch {
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t stream2 = nullptr;     // breakend branch of a sweep (pairwise reductions, p_breakpoint) next to the marginal pass
+    hipEvent_t ev_fb = nullptr, ev_brk = nullptr;
     bool own_stream = false;
     Dev d{};
     int R = 0;
@@ -698,7 +700,7 @@ int rmx_batch_create(const rmx_problem *pr, int32_t R, const double *h_init, con
     const size_t RN = (size_t)R * N, RNS = RN * d.SP, RCS = (size_t)R * C * d.SP;
     DA(rp, RestartParams, R) DA(stLogD, double, RCS) DA(stD, double, RCS) DA(stP, double, RCS) DA(stM, double, RCS * 2) DA(stLg, double, RCS * 4) DA(stFlags, uint32_t, RCS)
     DA(segc, double, RN * 8) DA(qt, double, RN * 2) DA(qa, double, RN * 2) DA(qs, double, RN * 2) DA(pbrk, double, (size_t)R * K * B)
-    DA(f, double, RNS) DA(fe, double, RNS) DA(fa, double, RNS) DA(fb, double, RNS) DA(post, double, RNS) DA(fmax, double, RN) DA(mrow, double, RN)
+    DA(f, double, RNS) DA(fe, double, RNS) DA(fe_alt, double, RNS) DA(fa, double, RNS) DA(fb, double, RNS) DA(post, double, RNS) DA(fmax, double, RN) DA(mrow, double, RN)
     DA(A, double, RN * 2) DA(Bv, double, RN * 4) DA(rowPF, double, RN) DA(rowPP, double, RN) DA(rowZ, double, RN)
     const size_t BEW = (size_t)R * d.NBE * M * d.D;
     DA(pd_lt, double, BEW) DA(pe_lt, double, (size_t)R * d.NBE * ((M * d.D + 1) & ~1) + 2)
@@ -785,7 +787,7 @@ int rmx_batch_create(const rmx_problem *pr, int32_t R, const double *h_init, con
         for (auto &x_ : row) x_ = 1.0 / (double)S;
         for (int r = 0; r < R; r++) HIPCHK(hipMemcpy(d.post + (size_t)r * N * d.SP, row.data(), row.size() * 8, hipMemcpyHostToDevice));
         HIPCHK(hipMemset(d.rowZ, 0, RN * 8)); HIPCHK(hipMemset(d.fmax, 0, RN * 8)); HIPCHK(hipMemset(d.mrow, 0, RN * 8));
-        HIPCHK(hipMemset(d.fa, 0, RNS * 8)); HIPCHK(hipMemset(d.fb, 0, RNS * 8)); HIPCHK(hipMemset(d.fe, 0, RNS * 8));
+        HIPCHK(hipMemset(d.fa, 0, RNS * 8)); HIPCHK(hipMemset(d.fb, 0, RNS * 8)); HIPCHK(hipMemset(d.fe, 0, RNS * 8)); HIPCHK(hipMemset(d.fe_alt, 0, RNS * 8));
         HIPCHK(hipMemset(d.err, 0, R * 4)); HIPCHK(hipMemset(b->d_lt_valid, 0, R * 4));
         HIPCHK(hipMemset(d.hist, 0, BEW * 8)); HIPCHK(hipMemset(d.be_jt, 0, (size_t)R * d.NBE * 8)); HIPCHK(hipMemset(d.be_ja, 0, (size_t)R * d.NBE * 8));
         HIPCHK(hipMemset(d.pd_lt, 0, BEW * 8));
@@ -817,6 +819,7 @@ int rmx_batch_destroy(rmx_batch *b) {
     if (b->tm_a) hipEventDestroy(b->tm_a);
     if (b->tm_b) hipEventDestroy(b->tm_b);
     for (auto e : b->done_ev) hipEventDestroy(e);
+    if (b->stream2) { hipStreamSynchronize(b->stream2); hipStreamDestroy(b->stream2); hipEventDestroy(b->ev_fb); hipEventDestroy(b->ev_brk); }
     if (b->own_stream && b->stream) hipStreamDestroy(b->stream);
     delete b;
     return RMX_OK;
@@ -1050,11 +1053,16 @@ static int do_framelogprob(rmx_batch *b, int r0, int r1) {
 // skip_frame: the frame log-probabilities of this sweep were already written by the fused pass of the
 // previous sweep; fuse_next: the marginal pass also does the outlier / allele-swap updates and the next
 // sweep's frame pass (k_cells MODE 3)
-static int do_update_p_cn(rmx_batch *b, int r0, int r1, bool skip_frame = false, bool fuse_next = false) {
+// update_p_cn in three parts: (1) frame pass, transition snapshot, forward-backward; (2) pairwise reductions at
+// the breakend adjacencies; (3) marginals.  (2) and (3) only read what (1) wrote and write disjoint arrays
+// (a fused marginal pass puts the next sweep's fe into the second buffer), so rmx_variational_update runs
+// (2) -- and update_p_breakpoint behind it -- on a second stream next to (3).
+static int p_cn_front(rmx_batch *b, int r0, int r1, bool skip_frame, bool snapshot_done = false) {
     int rc = skip_frame ? ensure_tables(b, r0, r1) : do_framelogprob(b, r0, r1);
     if (rc) return rc;
-    // log_transmat snapshot := T(current p_breakpoint)   (bpmodel.pyx:939)
-    if ((rc = launch_brk_lut(b, r0, r1, b->d.pd_lt, b->d.pe_lt))) return rc;
+    // log_transmat snapshot := T(current p_breakpoint)   (bpmodel.pyx:939); snapshot_done: the previous sweep of the
+    // same call already built it behind its update_p_breakpoint
+    if (!snapshot_done && (rc = launch_brk_lut(b, r0, r1, b->d.pd_lt, b->d.pe_lt))) return rc;
     {
         ProfScope ps(b, KID_FB);
         const Dev &d = b->d;
@@ -1151,17 +1159,24 @@ static int do_update_p_cn(rmx_batch *b, int r0, int r1, bool skip_frame = false,
         HIPCHK(hipGetLastError());
     }
     for (int r = r0; r < r1; r++) { if (!b->lt_valid[r]) { b->lt_valid[r] = 1; int one = 1; HIPCHK(hipMemcpyAsync(b->d_lt_valid + r, &one, 4, hipMemcpyHostToDevice, b->stream)); } }
-    // pairwise reductions at breakend adjacencies (feeds update_p_breakpoint and the ELBO): they read this
-    // sweep's fa / fb / fe, so they run before a fused marginal pass overwrites fe with the next sweep's
-    if ((rc = launch_pairwise_breakends(b, r0, r1, 0))) return rc;
+    return RMX_OK;
+}
+static int p_cn_marginals(rmx_batch *b, int r0, int r1, bool fuse_next) {
     {
         ProfScope ps(b, KID_MARGINALS);
         if (use_strip(b)) hipLaunchKernelGGL(cells_kernel(b, fuse_next ? 3 : 1, CM_ALL, b->use_cache ? 2 : 0), strip_grid(b, r1 - r0), dim3(256), 0, b->stream, b->d, r0);   // the F pass made the cache current
         else hipLaunchKernelGGL(k_marginals<true>, row_grid(b, r1 - r0), dim3(256), 0, b->stream, b->d, r0, b->G);
         HIPCHK(hipGetLastError());
     }
+    if (fuse_next && use_strip(b)) std::swap(b->d.fe, b->d.fe_alt);      // the fused pass left the next sweep's scaled emissions in the second buffer
     for (int r = r0; r < r1; r++) { b->ab_dirty[r] = 0; b->comp_dirty[r] = 0; b->logz_dirty[r] = 1; b->sig_valid[r] = (!fuse_next && use_strip(b) && b->d.sig_cnt) ? 1 : 0; }
     return RMX_OK;
+}
+static int do_update_p_cn(rmx_batch *b, int r0, int r1, bool skip_frame = false, bool fuse_next = false) {
+    int rc;
+    // pairwise reductions at breakend adjacencies (feed update_p_breakpoint and the ELBO) read this sweep's fa / fb / fe
+    if ((rc = p_cn_front(b, r0, r1, skip_frame)) || (rc = launch_pairwise_breakends(b, r0, r1, 0))) return rc;
+    return p_cn_marginals(b, r0, r1, fuse_next);
 }
 static int do_update_p_breakpoint(rmx_batch *b, int r0, int r1) {
     const Dev &d = b->d;
@@ -1201,11 +1216,36 @@ int rmx_variational_update(rmx_batch *b, int32_t r0, int32_t r1, int32_t iters) 
     // log-probabilities of sweep i+1 is local to a segment: one fused pass (k_cells MODE 3) instead of
     // marginals + update_p_outlier_total + update_p_outlier_allele + update_p_allele_swap + frame pass.
     const bool fusable = use_strip(b) && b->use_cache && !getenv("RMX_NO_FUSE");
+    // the breakend branch of a sweep (pairwise reductions, update_p_breakpoint) next to its marginal pass
+    const bool two_streams = use_strip(b) && b->d.NBE > 0 && !getenv("RMX_ONE_STREAM");
+    if (two_streams && !b->stream2) {
+        HIPCHK(hipStreamCreateWithFlags(&b->stream2, hipStreamNonBlocking));
+        HIPCHK(hipEventCreateWithFlags(&b->ev_fb, hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&b->ev_brk, hipEventDisableTiming));
+    }
+    bool snapshot_done = false;
     for (int it = 0; it < iters; it++) {
         int rc;
         const bool fused_in = fusable && it > 0, fuse_out = fusable && it + 1 < iters;
         if (!fused_in && (rc = do_indicator(b, r0, r1, 2))) return rc;
-        if ((rc = do_update_p_cn(b, r0, r1, fused_in, fuse_out)) || (rc = do_update_p_breakpoint(b, r0, r1))) return rc;
+        if (two_streams) {
+            if ((rc = p_cn_front(b, r0, r1, fused_in, snapshot_done))) return rc;
+            // breakend branch on the second stream: pairwise reductions -> p_breakpoint -> cached transition tables
+            hipStream_t main_stream = b->stream;
+            HIPCHK(hipEventRecord(b->ev_fb, main_stream));
+            HIPCHK(hipStreamWaitEvent(b->stream2, b->ev_fb, 0));
+            b->stream = b->stream2;
+            rc = launch_pairwise_breakends(b, r0, r1, 0);
+            if (!rc) rc = do_update_p_breakpoint(b, r0, r1);
+            // the next sweep's transition snapshot is T(the p_breakpoint just computed): build it here, off the main stream
+            snapshot_done = false;
+            if (!rc && it + 1 < iters) { rc = launch_brk_lut(b, r0, r1, b->d.pd_lt, b->d.pe_lt); snapshot_done = true; }
+            b->stream = main_stream;
+            if (rc) return rc;
+            HIPCHK(hipEventRecord(b->ev_brk, b->stream2));
+            if ((rc = p_cn_marginals(b, r0, r1, fuse_out))) return rc;
+            HIPCHK(hipStreamWaitEvent(main_stream, b->ev_brk, 0));
+        } else if ((rc = do_update_p_cn(b, r0, r1, fused_in, fuse_out)) || (rc = do_update_p_breakpoint(b, r0, r1))) return rc;
         if (!fuse_out && ((rc = do_indicator(b, r0, r1, 0)) || (rc = do_indicator(b, r0, r1, 1)))) return rc;
     }
     return check_errors(b, r0, r1);

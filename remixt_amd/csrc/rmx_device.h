@@ -76,6 +76,8 @@ struct Dev {
     double *qt, *qa, *qs;                // [R][N][2]
     double *pbrk;                        // [R][K][B]
     double *f, *fe, *fa, *fb, *post;     // [R][N][SP]; fe = exp(f - rowmax)
+    double *fe_alt;                      // [R][N][SP] second fe buffer: a fused marginal pass writes the NEXT sweep's scaled
+                                         // emissions here while this sweep's breakend reductions still read fe (the host swaps)
     uint16_t *sig_idx; uint8_t *sig_cnt; // [R][N][RMX_SIGK], [R][N]: states with posterior mass >= RMX_POST_EPS per segment (count 255: more than RMX_SIGK, use all states), or null
     double *lc;                          // [R][6][N][SP] cached cell likelihoods (LT0, LT1, LA00, LA01, LA10, LA11) or null
     double *fmax, *mrow;                 // [R][N]

@@ -1260,7 +1260,7 @@ __global__ __launch_bounds__(256) void k_cells(Dev d, int r0) {
                 vmax = group_max(vmax, 64);
                 if (lane == 0) d.fmax[rn] = vmax;
 #pragma unroll
-                for (int k = 0; k < NS; k++) { const int s = lane + 64 * k; if (s < d.SP) d.fe[ro + s] = s < S ? exp(fv[k] - vmax) : 0.; }
+                for (int k = 0; k < NS; k++) { const int s = lane + 64 * k; if (s < d.SP) d.fe_alt[ro + s] = s < S ? exp(fv[k] - vmax) : 0.; }
             }
         }
     }
