@@ -157,6 +157,54 @@ class RestartSet(object):
             return list(self._threads().map(draw, range(R)))
         return [draw(r) for r in range(R)]
 
+    _MULTI_PARAMS = ('negbin_r_0', 'negbin_r_1', 'betabin_M_0', 'betabin_M_1')
+
+    def _multi_param_names(self):
+        """The leading standard likelihood parameters, whose searches can share their rounds."""
+        import os
+        b = self.batch
+        first = []
+        for name in self.models[0].likelihood_params:
+            if name not in self._MULTI_PARAMS or len(first) == 4:
+                break
+            first.append(name)
+        sequential = any(os.environ.get(k) for k in ('RMX_SEARCH_SEQUENTIAL', 'RMX_SEARCH_TABLES', 'RMX_SEARCH_FULL', 'RMX_SEARCH_LOOKAHEAD'))
+        if not (first and self.native_search and b is not None and hasattr(b, 'param_search_multi')) or sequential:
+            return []
+        return first
+
+    def _draw_param_samples(self, names):
+        """Weighted samples of the listed parameters, parameter by parameter in the reference's order, and
+        the outlier indicators they were weighted with: (samples {name: [per restart]}, indicators)."""
+        ind = [{'p_outlier_total': np.asarray(m.model.p_outlier_total), 'p_outlier_allele': np.asarray(m.model.p_outlier_allele)} for m in self.models]
+        samples = {}
+        for name in names:
+            weights = []
+            for m, c in zip(self.models, ind):
+                m._mstep_indicator_cache = c
+                weights.append(m.get_param_sample_weight(name))
+            samples[name] = self._samples(weights)
+        return samples, ind
+
+    def _start_param_sample_prep(self):
+        import os
+        self._param_prep = None
+        names = self._multi_param_names()
+        if not names or os.environ.get('RMX_NO_SAMPLE_PREP'):
+            return
+        if getattr(self, '_prep_pool', None) is None:
+            from concurrent.futures import ThreadPoolExecutor
+            self._prep_pool = ThreadPoolExecutor(max_workers=1)
+        self._param_prep = (names, self._prep_pool.submit(self._draw_param_samples, names))
+
+    def _drop_param_sample_prep(self):
+        prep, self._param_prep = getattr(self, '_param_prep', None), None
+        if prep is not None:
+            try:
+                prep[1].result()
+            except Exception:
+                pass
+
     def _update_h_lockstep(self):
         """BreakpointModel.update_h (cn_model.py:482-531) for all restarts at once: per restart the
         evaluation sequence of scipy's L-BFGS-B driver (remixt_amd/lockstep.py lbfgsb_gen), every
@@ -174,6 +222,9 @@ class RestartSet(object):
         try:
             ell_before = b.expected_log_likelihood_full(0, R)
             samples = self._samples()
+            # the parameter M-steps' samples come next in every restart's RNG stream and depend on the outlier
+            # indicators only: they are drawn on a helper thread while this thread waits on the h rounds
+            self._start_param_sample_prep()
             for r in active:
                 b._use_sample(r, samples[r])
             bounds = [(1e-8, 10.)] * b.num_clones
@@ -183,6 +234,7 @@ class RestartSet(object):
                 return [(-float(f[k]), -g[k]) for k in range(len(ids))]
             results = lockstep.run_lockstep([lockstep.lbfgsb_gen(h_before[r], bounds) for r in active], evaluate)
         except ValueError:
+            self._drop_param_sample_prep()
             for r, m in enumerate(self.models):
                 m.model.h = h_before[r]
                 m.rng.set_state(rng_state[r])
@@ -241,36 +293,42 @@ class RestartSet(object):
         R = len(self.models)
         ids_all = list(range(R))
         # the outlier indicators feed the sample weights of several parameters and do not change during the
-        # M-step: one device-to-host copy per restart and array instead of one per parameter
-        for m in self.models:
-            m._mstep_indicator_cache = {'p_outlier_total': np.asarray(m.model.p_outlier_total), 'p_outlier_allele': np.asarray(m.model.p_outlier_allele)}
+        # M-step: one device-to-host copy per restart and array instead of one per parameter (already made,
+        # with the samples of the standard parameters, if the h M-step started the preparation)
+        prep, self._param_prep = getattr(self, '_param_prep', None), None
+        self._prepared = None
+        if prep is not None:
+            samples, ind = prep[1].result()
+            self._prepared = (prep[0], samples)
+            for m, c in zip(self.models, ind):
+                m._mstep_indicator_cache = c
+        else:
+            for m in self.models:
+                m._mstep_indicator_cache = {'p_outlier_total': np.asarray(m.model.p_outlier_total), 'p_outlier_allele': np.asarray(m.model.p_outlier_allele)}
         try:
             self._params_lockstep_body(b, R, ids_all)
         finally:
+            self._prepared = None
             for m in self.models:
                 m._mstep_indicator_cache = None
-
-    _MULTI_PARAMS = ('negbin_r_0', 'negbin_r_1', 'betabin_M_0', 'betabin_M_1')
 
     def _search_standard_params_together(self, b, R, ids_all, names):
         """The searches of the leading standard parameters in shared evaluation rounds
         (rmx_param_search_multi): {name: (xopt, lastval)} or {} when the batch cannot.  The samples are
         drawn here, parameter by parameter in the reference's order, so every restart's RNG stream is
         consumed exactly as by the sequential loop (weights depend on the outlier indicators only)."""
-        import os
-        first = []
-        for name in names:
-            if name not in self._MULTI_PARAMS or len(first) == 4:
-                break
-            first.append(name)
-        sequential = any(os.environ.get(k) for k in ('RMX_SEARCH_SEQUENTIAL', 'RMX_SEARCH_TABLES', 'RMX_SEARCH_FULL', 'RMX_SEARCH_LOOKAHEAD'))
-        if not (first and self.native_search and hasattr(b, 'param_search_multi')) or sequential:
+        first = self._multi_param_names()
+        if not first:
             return {}, {}
         bounds = [self.models[0].likelihood_param_bounds[name] for name in first]
-        samples = {}
+        prepared = getattr(self, '_prepared', None)
+        if prepared is not None and prepared[0] == first:
+            samples = prepared[1]                  # drawn during the h M-step
+        else:
+            samples = {}
+            for name in first:
+                samples[name] = self._samples([m.get_param_sample_weight(name) for m in self.models])
         for j, name in enumerate(first):
-            weights = [m.get_param_sample_weight(name) for m in self.models]
-            samples[name] = self._samples(weights)
             for r, smp in enumerate(samples[name]):
                 b.set_sample_slot(r, j, smp)
         grids = np.array([np.mgrid[lo:hi:complex(20)] for lo, hi in bounds])
