@@ -1473,7 +1473,7 @@ static int run_ell_batch(rmx_batch *b, int nreq, const int32_t *restarts, bool g
                 case 12: kf = k_ell_list_batch<false, 12>; break;
                 default: break;
                 }
-                hipLaunchKernelGGL(kf, sparse ? dim3((maxcnt + 3) / 4, nreq) : dim3(maxcnt, nreq), sparse ? dim3(256) : ell_block(b), 0, b->stream, b->d,
+                hipLaunchKernelGGL(kf, sparse ? dim3((maxcnt + 7) / 8, nreq) : dim3(maxcnt, nreq), sparse ? dim3(256) : ell_block(b), 0, b->stream, b->d,
                                    (const int32_t *)b->d_rlist, (const RestartParams *)b->d_rp_stage,
                                    (const int32_t *)b->d_sample, (const int32_t *)b->d_counts, b->d_ell_partial, pstride);
             }
@@ -1678,7 +1678,7 @@ int rmx_param_search(rmx_batch *b, int32_t nreq, const int32_t *restarts, int32_
                 void (*kf)(Dev, SearchVals, const int32_t *, const int32_t *, double *, int) =
                     sparse_search ? (mask == CM_LT0 ? k_ell_search_sparse<CM_LT0> : (mask == CM_LT1 ? k_ell_search_sparse<CM_LT1> : (mask == CM_LA0 ? k_ell_search_sparse<CM_LA0> : k_ell_search_sparse<CM_LA1>)))
                                   : (mask == CM_LT0 ? k_ell_search<CM_LT0> : (mask == CM_LT1 ? k_ell_search<CM_LT1> : (mask == CM_LA0 ? k_ell_search<CM_LA0> : k_ell_search<CM_LA1>)));
-                hipLaunchKernelGGL(kf, sparse_search ? dim3((maxcnt + 3) / 4, n_, Gz) : dim3(maxcnt, n_, Gz), sparse_search ? dim3(256) : ell_block(b), 0, b->stream, b->d, sv,
+                hipLaunchKernelGGL(kf, sparse_search ? dim3((maxcnt + 7) / 8, n_, Gz) : dim3(maxcnt, n_, Gz), sparse_search ? dim3(256) : ell_block(b), 0, b->stream, b->d, sv,
                                    (const int32_t *)b->d_sample, (const int32_t *)b->d_counts, b->d_ell_partial, std::max(maxcnt, 1));
             }
             { ProfScope ps(b, KID_ELL_FINAL); hipLaunchKernelGGL(k_ell_search_final, dim3(n_ * Gz), dim3(256), 0, b->stream, b->d, sv, (const int32_t *)b->d_counts, (const double *)b->d_ell_partial, std::max(maxcnt, 1), b->h_pinned, b->h_err); }
@@ -1855,7 +1855,7 @@ int rmx_param_search_multi(rmx_batch *b, int32_t nreq, const int32_t *restarts, 
             std::lock_guard<std::mutex> lk(b->mu);
             if (mc > 0) {
                 ProfScope ps(b, KID_ELL_LIST);
-                hipLaunchKernelGGL(k_ell_search_multi, dim3((mc + 3) / 4, n_, m2.Gz), dim3(256), 0, b->stream, b->d, m2, (const int32_t *)b->d_msample,
+                hipLaunchKernelGGL(k_ell_search_multi, dim3((mc + 7) / 8, n_, m2.Gz), dim3(256), 0, b->stream, b->d, m2, (const int32_t *)b->d_msample,
                                    (const int32_t *)b->d_mcounts, b->d_mpartial, std::max(mc, 1));
             }
             { ProfScope ps(b, KID_ELL_FINAL); hipLaunchKernelGGL(k_ell_multi_final, dim3(n_ * m2.Gz), dim3(256), 0, b->stream, b->d, m2, (const int32_t *)b->d_mcounts,

@@ -1922,20 +1922,20 @@ __device__ __forceinline__ void ell_segment(const Dev &d, const RestartParams &r
     if (err) atomicOr(&d.err[r], err);
 }
 // The same objective for ONE likelihood component from the segment's list of states with posterior mass
-// (d.sig_idx / d.sig_cnt, built by the last marginal pass; ~13 of 165 states): one WAVE per sampled
-// segment instead of one block, a lane per listed state; the states off the list cannot move the
+// (d.sig_idx / d.sig_cnt, built by the last marginal pass; ~13 of 165 states, at most RMX_SIGK = 32): HALF A
+// WAVE per sampled segment instead of one block, a lane per listed state; the states off the list cannot move the
 // rounded sum (RMX_POST_EPS) and only report their state-table error flags.  A segment whose list
-// overflowed (count 255) walks all states.  No block-level synchronisation: waves of a block work on
-// different segments.
+// overflowed (count 255) walks all states.  No block-level synchronisation: the half-waves of a block work
+// on different segments.
 template <int MASK, bool OVR>
 __device__ __forceinline__ void ell_segment_sparse(const Dev &d, const RestartParams &rp, int r, int n, double *prow) {
-    const int lane = threadIdx.x & 63;
+    const int lane = threadIdx.x & 31;      // half a wave per segment
     SegCtx sc;
     sc.x = d.x[n]; sc.l = d.l[n]; sc.logl = d.logl[n]; sc.y0 = d.y[2 * (size_t)n]; sc.y1 = d.y[2 * (size_t)n + 1]; sc.ys = sc.y0 + sc.y1;
     sc.mt = d.mask_t[n]; sc.ma = d.mask_a[n];
     const double k_ = seg_const_value(rp, sc.x, sc.y0, sc.ys, lane & 7);      // lanes 0..7 hold the eight per-segment constants
 #pragma unroll
-    for (int i = 0; i < 4; i++) { sc.cnb[i] = __shfl(k_, i, 64); sc.cbb[i] = __shfl(k_, 4 + i, 64); }
+    for (int i = 0; i < 4; i++) { sc.cnb[i] = __shfl(k_, i, 32); sc.cbb[i] = __shfl(k_, 4 + i, 32); }
     const int cls = d.seg_class[n];
     const size_t rn = (size_t)r * d.N + n;
     const double qt0 = d.qt[rn * 2], qt1 = d.qt[rn * 2 + 1], qa0 = d.qa[rn * 2], qa1 = d.qa[rn * 2 + 1];
@@ -1959,12 +1959,12 @@ __device__ __forceinline__ void ell_segment_sparse(const Dev &d, const RestartPa
         if (MASK & CM_LA1) { acc += ps * qa1 * qs0 * LA[2]; acc += ps * qa1 * qs1 * LA[3]; }
     };
     const int cnt = d.sig_cnt[rn];
-    if (cnt == 255) { for (int s = lane; s < d.S; s += 64) one(s); }
+    if (cnt == 255) { for (int s = lane; s < d.S; s += 32) one(s); }
     else {
         if (lane < cnt) one((int)d.sig_idx[rn * RMX_SIGK + lane]);
-        for (int s = lane; s < d.S; s += 64) cell_static_errors<MASK>(sc, d.stFlags[((size_t)r * d.C + cls) * d.SP + s], err);
+        for (int s = lane; s < d.S; s += 32) cell_static_errors<MASK>(sc, d.stFlags[((size_t)r * d.C + cls) * d.SP + s], err);
     }
-    acc = group_sum(acc, 64);
+    acc = group_sum(acc, 32);
     if (lane == 0) prow[0] = acc;
     if (err) atomicOr(&d.err[r], err);
 }
@@ -2029,12 +2029,12 @@ __global__ void k_ell_list_batch(Dev d, const int32_t *rlist, const RestartParam
     // stage[j] is identical to d.rp[r]; read from the stage to stay independent of launch order
     ell_segment<GRAD, MASK>(d, stage[blockIdx.y], r, n, partial + (size_t)r * pstride + (size_t)blockIdx.x * (1 + RMX_MAX_CLONES));
 }
-// grid (ceil(maxcount / 4), nreq), block 256: wave w of block (i, j) evaluates sampled segment 4 i + w of restart rlist[j]
+// grid (ceil(maxcount / 8), nreq), block 256: half-wave w of block (i, j) evaluates sampled segment 8 i + w of restart rlist[j]
 template <int MASK>
 __global__ __launch_bounds__(256) void k_ell_list_batch_sparse(Dev d, const int32_t *rlist, const RestartParams *stage, const int32_t *samples, const int32_t *counts,
                                                                double *partial, int pstride) {
     const int r = rlist[blockIdx.y];
-    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int i = blockIdx.x * 8 + (threadIdx.x >> 5);
     if (i >= counts[r]) return;
     const int n = samples[(size_t)r * d.N + i];
     ell_segment_sparse<MASK, false>(d, stage[blockIdx.y], r, n, partial + (size_t)r * pstride + (size_t)i * (1 + RMX_MAX_CLONES));
@@ -2078,12 +2078,12 @@ __global__ void k_ell_search(Dev d, SearchVals sv, const int32_t *samples, const
     if (MASK == CM_LA1) rp.p[RMX_P_BETABIN_M_1] = sv.v[vi];
     ell_segment<false, MASK, true>(d, rp, r, n, partial + ((size_t)(req * sv.Gz + gz) * maxcnt + blockIdx.x));
 }
-// grid (ceil(maxcount / 4), nreq, Gz), block 256: a wave per sampled segment (ell_segment_sparse)
+// grid (ceil(maxcount / 8), nreq, Gz), block 256: half a wave per sampled segment (ell_segment_sparse)
 template <int MASK>
 __global__ __launch_bounds__(256) void k_ell_search_sparse(Dev d, SearchVals sv, const int32_t *samples, const int32_t *counts, double *partial, int maxcnt) {
     const int req = blockIdx.y, gz = blockIdx.z;
     const int r = sv.rlist[req];
-    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int i = blockIdx.x * 8 + (threadIdx.x >> 5);
     if (i >= counts[r]) return;
     const int n = samples[(size_t)r * d.N + i];
     RestartParams rp = d.rp[r];
@@ -2110,11 +2110,11 @@ struct MultiVals {
     int32_t maskbit[4];
     int32_t grid_stage, Gz, pad0, pad1;
 };
-// grid (ceil(maxcount / 4), nreq, Gz), block 256: a wave per sampled segment
+// grid (ceil(maxcount / 8), nreq, Gz), block 256: half a wave per sampled segment
 __global__ __launch_bounds__(256) void k_ell_search_multi(Dev d, MultiVals mv, const int32_t *samples, const int32_t *counts, double *partial, int maxcnt) {
     const int req = blockIdx.y, gz = blockIdx.z;
     const int r = mv.rlist[req], sl = mv.slot[req];
-    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int i = blockIdx.x * 8 + (threadIdx.x >> 5);
     if (i >= counts[sl * d.R + r]) return;
     const int n = samples[((size_t)sl * d.R + r) * d.N + i];
     RestartParams rp = d.rp[r];
