@@ -538,7 +538,15 @@ static int launch_brk_lut(rmx_batch *b, int r0, int r1, double *dst, double *eds
 }
 
 #define RANGE_CHECK() if (!b || r0 < 0 || r1 > b->R || r0 >= r1) return fail(RMX_EARG, "bad restart range")
+// HIP's current device is per host thread and starts at 0: every entry point binds the calling thread to the
+// batch's device first (restart groups, M-step helpers and result collection call from their own threads;
+// allocations and events made there must belong to the batch's GPU, not to GPU 0)
+static inline void bind_device(const rmx_batch *b);
+#define BIND(b) do { if (b) bind_device(b); } while (0)
 
+static inline void bind_device(const rmx_batch *b) {
+    (void)hipSetDevice(b->device);      // thread-local and cheap; not cached: other libraries may change the thread's device
+}
 // ===========================================================================
 extern "C" {
 
@@ -806,7 +814,7 @@ int rmx_batch_create(const rmx_problem *pr, int32_t R, const double *h_init, con
     return RMX_OK;
 }
 
-int rmx_batch_destroy(rmx_batch *b) {
+int rmx_batch_destroy(rmx_batch *b) { BIND(b);
     if (!b) return RMX_OK;
     hipSetDevice(b->device);
     if (b->stream) hipStreamSynchronize(b->stream);
@@ -825,7 +833,7 @@ int rmx_batch_destroy(rmx_batch *b) {
     return RMX_OK;
 }
 
-int rmx_set_stream(rmx_batch *b, void *s) {
+int rmx_set_stream(rmx_batch *b, void *s) { BIND(b);
     if (!b) return fail(RMX_EARG, "null batch");
     HIPCHK(hipStreamSynchronize(b->stream));
     if (b->own_stream) { hipStreamDestroy(b->stream); b->own_stream = false; }
@@ -833,9 +841,9 @@ int rmx_set_stream(rmx_batch *b, void *s) {
     else { HIPCHK(hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking)); b->own_stream = true; }
     return RMX_OK;
 }
-int rmx_synchronize(rmx_batch *b) { HIPCHK(hipStreamSynchronize(b->stream)); return RMX_OK; }
+int rmx_synchronize(rmx_batch *b) { BIND(b); HIPCHK(hipStreamSynchronize(b->stream)); return RMX_OK; }
 
-int rmx_info(rmx_batch *b, int32_t what, int64_t *out) {
+int rmx_info(rmx_batch *b, int32_t what, int64_t *out) { BIND(b);
     switch (what) {
     case 0: *out = b->d.cn_max; break; case 1: *out = b->d.NC; break; case 2: *out = b->d.TC; break; case 3: *out = b->d.NBE; break;
     case 4: *out = b->d.SP; break; case 5: *out = b->fbv_rpt; break; case 6: *out = b->fbG.P; break; case 7: *out = b->fbG.NT; break;
@@ -849,7 +857,7 @@ int rmx_info(rmx_batch *b, int32_t what, int64_t *out) {
 }
 
 // ---- attributes -----------------------------------------------------------------
-int rmx_set_param(rmx_batch *b, int32_t r, int32_t id, double v) {
+int rmx_set_param(rmx_batch *b, int32_t r, int32_t id, double v) { BIND(b);
     if (r < 0 || r >= b->R || id < 0 || id >= RMX_P_HMM_LOG_NORM_CONST) return fail(RMX_EARG, "bad restart / param id");
     if (id == RMX_P_DIVERGENCE_WEIGHT) v = std::fabs(v);
     b->rp[r].p[id] = v; b->tables_dirty[r] = 1; b->ab_dirty[r] = 1;
@@ -858,7 +866,7 @@ int rmx_set_param(rmx_batch *b, int32_t r, int32_t id, double v) {
     b->cache_stale[r] |= (bits[id] & 15);
     return RMX_OK;
 }
-int rmx_get_param(rmx_batch *b, int32_t r, int32_t id, double *v) {
+int rmx_get_param(rmx_batch *b, int32_t r, int32_t id, double *v) { BIND(b);
     if (r < 0 || r >= b->R || id < 0 || id >= RMX_P_COUNT) return fail(RMX_EARG, "bad restart / param id");
     if (id == RMX_P_HMM_LOG_NORM_CONST && b->logz_dirty[r]) {
         double *dst = b->d_ell_out + (size_t)r * 8;
@@ -870,7 +878,7 @@ int rmx_get_param(rmx_batch *b, int32_t r, int32_t id, double *v) {
     *v = (id == RMX_P_HMM_LOG_NORM_CONST) ? b->logZ[r] : b->rp[r].p[id];
     return RMX_OK;
 }
-int rmx_set_transition_model(rmx_batch *b, int32_t model) {
+int rmx_set_transition_model(rmx_batch *b, int32_t model) { BIND(b);
     if (model != 0 && model != 1) return fail(RMX_EUNSUPPORTED, "transition_model must be 0 or 1");
     if (model == b->d.tmodel) return RMX_OK;
     HIPCHK(hipStreamSynchronize(b->stream));
@@ -892,7 +900,7 @@ static int array_shape(rmx_batch *b, int id, size_t *count, bool *is_int) {
     return RMX_OK;
 }
 
-int rmx_set_array(rmx_batch *b, int32_t r, int32_t id, const void *src) {
+int rmx_set_array(rmx_batch *b, int32_t r, int32_t id, const void *src) { BIND(b);
     if (r < 0 || r >= b->R || !src) return fail(RMX_EARG, "bad restart / null source");
     Dev &d = b->d;
     const size_t RN = (size_t)r * d.N;
@@ -922,7 +930,7 @@ int rmx_set_array(rmx_batch *b, int32_t r, int32_t id, const void *src) {
     return RMX_OK;
 }
 
-int rmx_get_array(rmx_batch *b, int32_t r, int32_t id, void *dst) {
+int rmx_get_array(rmx_batch *b, int32_t r, int32_t id, void *dst) { BIND(b);
     if (r < 0 || r >= b->R || !dst) return fail(RMX_EARG, "bad restart / null destination");
     Dev &d = b->d;
     const size_t RN = (size_t)r * d.N;
@@ -969,7 +977,7 @@ int rmx_get_array(rmx_batch *b, int32_t r, int32_t id, void *dst) {
 // calculate_log_transmat(out) (bpmodel.pyx:639-684): the dense (N-1) x S x S log transition array for the
 // CURRENT p_breakpoint of restart r, into the caller's host array.  Neither the log_transmat snapshot of
 // the last update_p_cn nor cached_log_transmat is touched.  Size warning: 8 (N-1) S^2 bytes.
-int rmx_calculate_log_transmat(rmx_batch *b, int32_t r, double *dst) {
+int rmx_calculate_log_transmat(rmx_batch *b, int32_t r, double *dst) { BIND(b);
     if (!b || r < 0 || r >= b->R || !dst) return fail(RMX_EARG, "bad argument");
     const Dev &d = b->d;
     if (d.N < 2) return RMX_OK;
@@ -1009,7 +1017,7 @@ int rmx_weighted_search(const double *p, int64_t n, const double *u, int32_t k, 
     return RMX_OK;
 }
 
-int rmx_get_state_table(rmx_batch *b, int32_t which, int64_t *dst) {
+int rmx_get_state_table(rmx_batch *b, int32_t which, int64_t *dst) { BIND(b);
     const Dev &d = b->d;
     const int S = d.S, M = d.M;
     for (int n = 0; n < d.N; n++) {
@@ -1203,14 +1211,14 @@ static int do_indicator(rmx_batch *b, int r0, int r1, int which) {
     return RMX_OK;
 }
 
-int rmx_update_framelogprob(rmx_batch *b, int32_t r0, int32_t r1) { RANGE_CHECK(); int rc = do_framelogprob(b, r0, r1); return rc ? rc : check_errors(b, r0, r1); }
-int rmx_update_p_cn(rmx_batch *b, int32_t r0, int32_t r1) { RANGE_CHECK(); int rc = do_update_p_cn(b, r0, r1); return rc ? rc : check_errors(b, r0, r1); }
-int rmx_update_p_breakpoint(rmx_batch *b, int32_t r0, int32_t r1) { RANGE_CHECK(); int rc = do_update_p_breakpoint(b, r0, r1); return rc ? rc : check_errors(b, r0, r1); }
-int rmx_update_p_outlier_total(rmx_batch *b, int32_t r0, int32_t r1) { RANGE_CHECK(); int rc = do_indicator(b, r0, r1, 0); return rc ? rc : check_errors(b, r0, r1); }
-int rmx_update_p_outlier_allele(rmx_batch *b, int32_t r0, int32_t r1) { RANGE_CHECK(); int rc = do_indicator(b, r0, r1, 1); return rc ? rc : check_errors(b, r0, r1); }
-int rmx_update_p_allele_swap(rmx_batch *b, int32_t r0, int32_t r1) { RANGE_CHECK(); int rc = do_indicator(b, r0, r1, 2); return rc ? rc : check_errors(b, r0, r1); }
+int rmx_update_framelogprob(rmx_batch *b, int32_t r0, int32_t r1) { BIND(b); RANGE_CHECK(); int rc = do_framelogprob(b, r0, r1); return rc ? rc : check_errors(b, r0, r1); }
+int rmx_update_p_cn(rmx_batch *b, int32_t r0, int32_t r1) { BIND(b); RANGE_CHECK(); int rc = do_update_p_cn(b, r0, r1); return rc ? rc : check_errors(b, r0, r1); }
+int rmx_update_p_breakpoint(rmx_batch *b, int32_t r0, int32_t r1) { BIND(b); RANGE_CHECK(); int rc = do_update_p_breakpoint(b, r0, r1); return rc ? rc : check_errors(b, r0, r1); }
+int rmx_update_p_outlier_total(rmx_batch *b, int32_t r0, int32_t r1) { BIND(b); RANGE_CHECK(); int rc = do_indicator(b, r0, r1, 0); return rc ? rc : check_errors(b, r0, r1); }
+int rmx_update_p_outlier_allele(rmx_batch *b, int32_t r0, int32_t r1) { BIND(b); RANGE_CHECK(); int rc = do_indicator(b, r0, r1, 1); return rc ? rc : check_errors(b, r0, r1); }
+int rmx_update_p_allele_swap(rmx_batch *b, int32_t r0, int32_t r1) { BIND(b); RANGE_CHECK(); int rc = do_indicator(b, r0, r1, 2); return rc ? rc : check_errors(b, r0, r1); }
 
-int rmx_variational_update(rmx_batch *b, int32_t r0, int32_t r1, int32_t iters) {
+int rmx_variational_update(rmx_batch *b, int32_t r0, int32_t r1, int32_t iters) { BIND(b);
     RANGE_CHECK();
     // Between two sweeps of this call everything from the marginals of sweep i to the frame
     // log-probabilities of sweep i+1 is local to a segment: one fused pass (k_cells MODE 3) instead of
@@ -1295,7 +1303,7 @@ static int elbo_parts(rmx_batch *b, int r0, int r1, bool exact_parts, double *ou
     for (int r = r0; r < r1; r++) if (b->lt_valid[r]) { b->logZ[r] = out4[(r - r0) * 4 + 3]; b->logz_dirty[r] = 0; }
     return RMX_OK;
 }
-int rmx_calculate_elbo(rmx_batch *b, int32_t r0, int32_t r1, double *out) {
+int rmx_calculate_elbo(rmx_batch *b, int32_t r0, int32_t r1, double *out) { BIND(b);
     RANGE_CHECK();
     std::vector<double> o4((size_t)(r1 - r0) * 4);
     int rc = elbo_parts(b, r0, r1, false, o4.data());
@@ -1303,7 +1311,7 @@ int rmx_calculate_elbo(rmx_batch *b, int32_t r0, int32_t r1, double *out) {
     for (int i = 0; i < r1 - r0; i++) out[i] = o4[i * 4 + 2];
     return RMX_OK;
 }
-int rmx_calculate_variational_energy(rmx_batch *b, int32_t r0, int32_t r1, double *out) {
+int rmx_calculate_variational_energy(rmx_batch *b, int32_t r0, int32_t r1, double *out) { BIND(b);
     RANGE_CHECK();
     std::vector<double> o4((size_t)(r1 - r0) * 4);
     int rc = elbo_parts(b, r0, r1, true, o4.data());
@@ -1311,7 +1319,7 @@ int rmx_calculate_variational_energy(rmx_batch *b, int32_t r0, int32_t r1, doubl
     for (int i = 0; i < r1 - r0; i++) out[i] = o4[i * 4 + 0];
     return RMX_OK;
 }
-int rmx_calculate_variational_entropy(rmx_batch *b, int32_t r0, int32_t r1, double *out) {
+int rmx_calculate_variational_entropy(rmx_batch *b, int32_t r0, int32_t r1, double *out) { BIND(b);
     RANGE_CHECK();
     std::vector<double> o4((size_t)(r1 - r0) * 4);
     int rc = elbo_parts(b, r0, r1, true, o4.data());
@@ -1360,12 +1368,12 @@ static int queue_ell(rmx_batch *b, int r, bool grad, double *dst) {
     return RMX_OK;
 }
 
-int rmx_set_sample(rmx_batch *b, int32_t r, const int64_t *sample) {
+int rmx_set_sample(rmx_batch *b, int32_t r, const int64_t *sample) { BIND(b);
     if (!b || r < 0 || r >= b->R || !sample) return fail(RMX_EARG, "bad argument");
     return set_sample(b, r, sample);
 }
 
-int rmx_expected_log_likelihood(rmx_batch *b, int32_t r, const int64_t *sample, double *ell_out, double *partial_h_out) {
+int rmx_expected_log_likelihood(rmx_batch *b, int32_t r, const int64_t *sample, double *ell_out, double *partial_h_out) { BIND(b);
     if (!b || r < 0 || r >= b->R || !ell_out) return fail(RMX_EARG, "bad argument");
     const Dev &d = b->d;
     int rc;
@@ -1394,7 +1402,7 @@ int rmx_expected_log_likelihood(rmx_batch *b, int32_t r, const int64_t *sample, 
 // back to back with a single host round trip (the 20-point grid of scipy.optimize.brute in
 // BreakpointModel.update_param, cn_model.py:553-558).  Leaves the parameter at values[G-1], as the
 // sequential evaluation would.
-int rmx_expected_ll_param_grid(rmx_batch *b, int32_t r, int32_t param_id, const double *values, int32_t G, double *out) {
+int rmx_expected_ll_param_grid(rmx_batch *b, int32_t r, int32_t param_id, const double *values, int32_t G, double *out) { BIND(b);
     if (!b || r < 0 || r >= b->R || !values || !out || G < 1 || G > 64) return fail(RMX_EARG, "bad argument");
     if (param_id < 0 || param_id >= RMX_P_HMM_LOG_NORM_CONST) return fail(RMX_EARG, "bad param id");
     if (b->sample_count[r] < 0) return fail(RMX_EARG, "no sample set for this restart");
@@ -1509,7 +1517,7 @@ static int check_request_list(rmx_batch *b, int nreq, const int32_t *restarts) {
     }
     return RMX_OK;
 }
-int rmx_expected_ll_batch(rmx_batch *b, int32_t nreq, const int32_t *restarts, int32_t param_id, const double *values, double *out) {
+int rmx_expected_ll_batch(rmx_batch *b, int32_t nreq, const int32_t *restarts, int32_t param_id, const double *values, double *out) { BIND(b);
     if (!b || nreq < 1 || nreq > b->R || !restarts || !values || !out) return fail(RMX_EARG, "bad argument");
     if (param_id < 0 || param_id >= RMX_P_HMM_LOG_NORM_CONST) return fail(RMX_EARG, "bad param id");
     int rc = check_request_list(b, nreq, restarts);
@@ -1623,7 +1631,7 @@ struct Nm1 {
 // parameter is left at the last value evaluated for the restart (the reference's acceptance test
 // looks at exactly that state); xopt[i] receives the optimiser's result for restarts[i].
 int rmx_param_search(rmx_batch *b, int32_t nreq, const int32_t *restarts, int32_t param_id, double lo, double hi,
-                     const double *grid, int32_t G, double *xopt) {
+                     const double *grid, int32_t G, double *xopt) { BIND(b);
     if (!b || nreq < 1 || nreq > b->R || !restarts || !grid || G < 1 || !xopt) return fail(RMX_EARG, "bad argument");
     int rc;
     if ((rc = check_request_list(b, nreq, restarts))) return rc;
@@ -1767,7 +1775,7 @@ int rmx_param_search(rmx_batch *b, int32_t nreq, const int32_t *restarts, int32_
 }
 
 // The sample of restart r for parameter slot `slot` (0..3) of rmx_param_search_multi
-int rmx_set_sample_slot(rmx_batch *b, int32_t r, int32_t slot, const int64_t *sample) {
+int rmx_set_sample_slot(rmx_batch *b, int32_t r, int32_t slot, const int64_t *sample) { BIND(b);
     if (!b || r < 0 || r >= b->R || slot < 0 || slot > 3 || !sample) return fail(RMX_EARG, "bad argument");
     const Dev &d = b->d;
     int rc;
@@ -1797,7 +1805,7 @@ int rmx_set_sample_slot(rmx_batch *b, int32_t r, int32_t slot, const int64_t *sa
 // parameters, lists of states with posterior mass not current, more than 64 optimisers, G > 20, ...):
 // the caller falls back to rmx_param_search per parameter.
 int rmx_param_search_multi(rmx_batch *b, int32_t nreq, const int32_t *restarts, int32_t nparams, const int32_t *param_ids,
-                           const double *lo, const double *hi, const double *grids, int32_t G, double *xopt, double *lastval) {
+                           const double *lo, const double *hi, const double *grids, int32_t G, double *xopt, double *lastval) { BIND(b);
     if (!b || nreq < 1 || nreq > b->R || !restarts || nparams < 1 || nparams > 4 || !param_ids || !lo || !hi || !grids || G < 1 || !xopt || !lastval)
         return fail(RMX_EARG, "bad argument");
     int rc;
@@ -1908,7 +1916,7 @@ int rmx_param_search_multi(rmx_batch *b, int32_t nreq, const int32_t *restarts, 
 // One candidate haploid-depth vector per listed restart: E[ll] and dE[ll]/dh on each restart's
 // current sample (the objective / gradient pair of BreakpointModel.update_h, cn_model.py:484-498),
 // the evaluation round of a lock-step L-BFGS-B.  h [nreq][M]; out [nreq][1 + RMX_MAX_CLONES].
-int rmx_expected_ll_h_batch(rmx_batch *b, int32_t nreq, const int32_t *restarts, const double *h, double *out) {
+int rmx_expected_ll_h_batch(rmx_batch *b, int32_t nreq, const int32_t *restarts, const double *h, double *out) { BIND(b);
     if (!b || nreq < 1 || nreq > b->R || !restarts || !h || !out) return fail(RMX_EARG, "bad argument");
     int rc = check_request_list(b, nreq, restarts);
     if (rc) return rc;
@@ -1919,7 +1927,7 @@ int rmx_expected_ll_h_batch(rmx_batch *b, int32_t nreq, const int32_t *restarts,
 
 // Full-data E[ll] (sample of all ones, :1125-1157) for a restart range from the per-segment
 // expectations (refreshed first if h / a parameter changed).
-int rmx_expected_ll_full(rmx_batch *b, int32_t r0, int32_t r1, double *out) {
+int rmx_expected_ll_full(rmx_batch *b, int32_t r0, int32_t r1, double *out) { BIND(b);
     RANGE_CHECK();
     int rc = ensure_ab(b, r0, r1);
     if (rc) return rc;
@@ -1939,7 +1947,7 @@ int rmx_expected_ll_full(rmx_batch *b, int32_t r0, int32_t r1, double *out) {
 // same order, as a refresh would produce -- while the restart's own (A, B), its cell cache and its
 // staleness flags stay as they are.  A rejected value then costs no second pass over the cells:
 // rmx_trial_rollback puts the old value back and declares (A, B) / cache current again.
-int rmx_expected_ll_full_trial(rmx_batch *b, int32_t r0, int32_t r1, double *out) {
+int rmx_expected_ll_full_trial(rmx_batch *b, int32_t r0, int32_t r1, double *out) { BIND(b);
     RANGE_CHECK();
     int rc = ensure_tables(b, r0, r1);
     if (rc) return rc;
@@ -1985,7 +1993,7 @@ int rmx_expected_ll_full_trial(rmx_batch *b, int32_t r0, int32_t r1, double *out
 // exactly these values before the trial and nothing refreshed them since (no coordinate update, ELBO or
 // rmx_expected_ll_full in between) -- which is the M-step's sequence: full E[ll], search on samples,
 // rmx_expected_ll_full_trial, then accept (set the new value) or this.
-int rmx_trial_rollback(rmx_batch *b, int32_t r, int32_t param_id, const double *values) {
+int rmx_trial_rollback(rmx_batch *b, int32_t r, int32_t param_id, const double *values) { BIND(b);
     if (!b || r < 0 || r >= b->R || !values || param_id >= RMX_P_HMM_LOG_NORM_CONST) return fail(RMX_EARG, "bad argument");
     if (param_id >= 0) b->rp[r].p[param_id] = param_id == RMX_P_DIVERGENCE_WEIGHT ? std::fabs(values[0]) : values[0];
     else for (int m = 0; m < b->d.M; m++) b->rp[r].h[m] = values[m];
@@ -2004,10 +2012,10 @@ static int cell_probe(rmx_batch *b, int r, int n, int s, double out6[6]) {
     for (int i = 0; i < 6; i++) out6[i] = b->h_pinned[i];
     return RMX_OK;
 }
-int rmx_log_likelihood_total(rmx_batch *b, int32_t r, int32_t n, int32_t s, int32_t u, double *out) {
+int rmx_log_likelihood_total(rmx_batch *b, int32_t r, int32_t n, int32_t s, int32_t u, double *out) { BIND(b);
     double o[6]; int rc = cell_probe(b, r, n, s, o); if (rc) return rc; *out = o[u ? 1 : 0]; return RMX_OK;
 }
-int rmx_log_likelihood_allele(rmx_batch *b, int32_t r, int32_t n, int32_t s, int32_t v, int32_t w, double *out) {
+int rmx_log_likelihood_allele(rmx_batch *b, int32_t r, int32_t n, int32_t s, int32_t v, int32_t w, double *out) { BIND(b);
     double o[6]; int rc = cell_probe(b, r, n, s, o); if (rc) return rc; *out = o[2 + (v ? 2 : 0) + (w ? 1 : 0)]; return RMX_OK;
 }
 
@@ -2050,7 +2058,7 @@ static int viterbi_paths(rmx_batch *b, int r0, int nr, std::vector<int64_t> &pat
     return RMX_OK;
 }
 
-int rmx_infer_cn_batch(rmx_batch *b, int32_t r0, int32_t nr, int64_t *cn_out, double *logprob_out) {
+int rmx_infer_cn_batch(rmx_batch *b, int32_t r0, int32_t nr, int64_t *cn_out, double *logprob_out) { BIND(b);
     if (!b || r0 < 0 || nr < 1 || r0 + nr > b->R || !cn_out) return fail(RMX_EARG, "bad argument");
     const Dev &d = b->d;
     const int N = d.N, S = d.S, M = d.M;
@@ -2077,7 +2085,7 @@ int rmx_infer_cn_batch(rmx_batch *b, int32_t r0, int32_t nr, int64_t *cn_out, do
     }
     return RMX_OK;
 }
-int rmx_infer_cn(rmx_batch *b, int32_t r, int64_t *cn_out, double *logprob_out) {
+int rmx_infer_cn(rmx_batch *b, int32_t r, int64_t *cn_out, double *logprob_out) { BIND(b);
     if (!b || r < 0 || r >= b->R || !cn_out) return fail(RMX_EARG, "bad argument");
     return rmx_infer_cn_batch(b, r, 1, cn_out, logprob_out);
 }
@@ -2126,20 +2134,20 @@ int rmx_max_product(const double *f, const double *T, int64_t *ss, double *logpr
 }
 
 // ---- measurement --------------------------------------------------------------------------------
-int rmx_timer_start(rmx_batch *b) { HIPCHK(hipEventRecord(b->tm_a, b->stream)); return RMX_OK; }
-int rmx_timer_stop(rmx_batch *b, double *ms) {
+int rmx_timer_start(rmx_batch *b) { BIND(b); HIPCHK(hipEventRecord(b->tm_a, b->stream)); return RMX_OK; }
+int rmx_timer_stop(rmx_batch *b, double *ms) { BIND(b);
     HIPCHK(hipEventRecord(b->tm_b, b->stream)); HIPCHK(hipEventSynchronize(b->tm_b));
     float f = 0; HIPCHK(hipEventElapsedTime(&f, b->tm_a, b->tm_b)); *ms = f; return RMX_OK;
 }
-int rmx_profile_enable(rmx_batch *b, int32_t on) { prof_collect(b); b->prof = on < 0 ? 0 : (on > 2 ? 1 : on); return RMX_OK; }
-int rmx_profile_get(rmx_batch *b, int32_t id, double *ms, int64_t *n) {
+int rmx_profile_enable(rmx_batch *b, int32_t on) { BIND(b); prof_collect(b); b->prof = on < 0 ? 0 : (on > 2 ? 1 : on); return RMX_OK; }
+int rmx_profile_get(rmx_batch *b, int32_t id, double *ms, int64_t *n) { BIND(b);
     if (id < 0 || id >= KID_COUNT) return fail(RMX_EARG, "bad kernel id");
     HIPCHK(hipStreamSynchronize(b->stream));
     prof_collect(b);
     *ms = b->prof_ms[id]; *n = b->prof_n[id];
     return RMX_OK;
 }
-int rmx_profile_reset(rmx_batch *b) { prof_collect(b); for (int i = 0; i < KID_COUNT; i++) { b->prof_ms[i] = 0; b->prof_n[i] = 0; } return RMX_OK; }
+int rmx_profile_reset(rmx_batch *b) { BIND(b); prof_collect(b); for (int i = 0; i < KID_COUNT; i++) { b->prof_ms[i] = 0; b->prof_n[i] = 0; } return RMX_OK; }
 const char *rmx_kernel_name(int32_t id) { return (id >= 0 && id < KID_COUNT) ? kKernelNames[id] : ""; }
 int rmx_num_kernels(void) { return KID_COUNT; }
 
