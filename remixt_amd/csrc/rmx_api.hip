@@ -80,6 +80,7 @@ struct rmx_batch {
     // viterbi
     uint16_t *d_bp = nullptr; double *d_final = nullptr; int64_t *d_path = nullptr; double *d_logprob = nullptr;
     std::vector<int64_t> last_path; int vit_cap = 0;
+    uint8_t *d_vit_code = nullptr; double *d_vit_val = nullptr; bool vit_code_ok = false;   // 8-bit codes of T(i, o) of class 0 + their values (k_viterbi_code)
     // FB launch configuration
     FbLaunch fbG{}; size_t fbG_lds = 0;   // generic kernel configuration
     int n_fast = 0, n_generic = 0;
@@ -326,6 +327,31 @@ static int build_transitions(rmx_batch *b) {
             HIPCHK(hipMemcpy(b->d_totpack, ttp.data(), ttp.size() * 4, hipMemcpyHostToDevice));
             HIPCHK(hipMemcpy(b->d_wk, wk.data(), wk.size() * 8, hipMemcpyHostToDevice));
             b->fbk_ok = true;
+        }
+    }
+    // Viterbi lattice for grids beyond the register-resident kernel: codes of the distinct values of class 0
+    b->vit_code_ok = false;
+    if (TC > 0 && S > 176 && S <= 384) {
+        std::map<double, int> ids;
+        std::vector<uint8_t> code(SS);
+        std::vector<double> vals(256, 0.);
+        bool ok = true;
+        for (int i = 0; i < S && ok; i++)
+            for (int j = 0; j < S; j++) {
+                const double T = Tval[(size_t)i * S + j];
+                auto it = ids.find(T);
+                int id;
+                if (it == ids.end()) { id = (int)ids.size(); if (id >= 255) { ok = false; break; } ids[T] = id; vals[id] = T; }
+                else id = it->second;
+                code[(size_t)j * S + i] = (uint8_t)id;       // transposed: row = target state o, column = source state i
+            }
+        if (ok) {
+            vals[255] = -INFINITY;
+            int rc2;
+            if (!b->d_vit_code && ((rc2 = dalloc(b, &b->d_vit_code, SS)) || (rc2 = dalloc(b, &b->d_vit_val, 256)))) return rc2;
+            HIPCHK(hipMemcpy(b->d_vit_code, code.data(), SS, hipMemcpyHostToDevice));
+            HIPCHK(hipMemcpy(b->d_vit_val, vals.data(), 256 * 8, hipMemcpyHostToDevice));
+            b->vit_code_ok = true;
         }
     }
     if (TC > 0) {
@@ -2036,6 +2062,9 @@ static int viterbi_paths(rmx_batch *b, int r0, int nr, std::vector<int64_t> &pat
     }
     const int Pr = viterbi_reg_P(S), QPT = (S + Pr - 1) / Pr;
     const bool reg = QPT <= 44 && !getenv("RMX_VITERBI_PLAIN");
+    // code-table lattice (k_viterbi_code): V rows, breakend table, value table, S rows of P * QPT4 codes
+    const int QPT4 = ((QPT + 3) / 4) * 4;
+    const size_t code_lds = b->vit_code_ok ? (size_t)(2 * (Pr * QPT4 + 4) + ((M * d.D + 1) & ~1) + 256) * 8 + (size_t)S * Pr * QPT4 : (size_t)1 << 30;
     { ProfScope ps(b, KID_VITERBI);
       if (reg) {
           const int NT = ((S * Pr + 63) / 64) * 64;
@@ -2043,6 +2072,11 @@ static int viterbi_paths(rmx_batch *b, int r0, int nr, std::vector<int64_t> &pat
           if (QPT <= 8) VREG(8); else if (QPT <= 16) VREG(16); else if (QPT <= 24) VREG(24); else if (QPT <= 32) VREG(32);
           else if (QPT <= 36) VREG(36); else if (QPT <= 40) VREG(40); else VREG(44);
 #undef VREG
+      } else if (code_lds <= kLdsBudget && !getenv("RMX_VITERBI_PLAIN")) {
+          const int NT = ((S * Pr + 63) / 64) * 64;
+          HIPCHK(hipFuncSetAttribute((const void *)k_viterbi_code, hipFuncAttributeMaxDynamicSharedMemorySize, (int)code_lds));
+          hipLaunchKernelGGL(k_viterbi_code, dim3(nr), dim3(NT), code_lds, b->stream, b->d, r0, Pr, QPT4,
+                             (const uint8_t *)b->d_vit_code, (const double *)b->d_vit_val, b->d_bp, b->d_final);
       } else {
           const int P = viterbi_P(S), NT = ((S * P + 63) / 64) * 64;
           hipLaunchKernelGGL(k_viterbi, dim3(nr), dim3(NT), (size_t)(2 * S + M * d.D) * 8, b->stream, b->d, r0, P, b->d_bp, b->d_final);

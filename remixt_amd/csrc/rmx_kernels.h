@@ -2369,6 +2369,93 @@ __global__ __launch_bounds__(768) void k_viterbi_reg(Dev d, int r0, int P, uint1
     }
     if (t < S) final_all[(size_t)blockIdx.x * S + t] = V[((d.N - 1) & 1) * SV + t];
 }
+// The same for grids whose S x S transition values do not fit the register file (176 < S <= ~380): the
+// plain-adjacency table of class 0 has few distinct values (sums of -pen x small integers), so the
+// workgroup keeps 8-bit CODES of all S x S values in LDS (126 KB at S = 355), row o = target state padded
+// to a multiple of 4, and looks the doubles up in a 256-entry LDS table (entry 255 = -inf pads the tiles).
+// Thread (o, p) walks its QPT codes a 32-bit word at a time.  Same values, comparison order and tie rule.
+__global__ __launch_bounds__(768) void k_viterbi_code(Dev d, int r0, int P, int QPT /* multiple of 4 */, const uint8_t *codeT /* [S][S]: (o, i) */,
+                                                      const double *valtab /* [256] */, uint16_t *bp_all, double *final_all) {
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    const int S = d.S, M = d.M, D = d.D, t = threadIdx.x, NT = blockDim.x, r = r0 + blockIdx.x;
+    const int SV = P * QPT + 4;
+    const int SC = P * QPT;                // code row stride (bytes), multiple of 4
+    double *V = (double *)smem_raw;        // [2][SV]
+    double *pdl = V + 2 * SV;              // [M*D]
+    double *val = pdl + ((M * D + 1) & ~1);   // [256]
+    uint8_t *cl = (uint8_t *)(val + 256);  // [S][SC]
+    uint16_t *bp = bp_all + (size_t)blockIdx.x * d.N * S;
+    const int o = t / P, p = t % P;
+    const bool act = o < S;
+    const int oc = act ? o : S - 1;
+    const int i0 = p * QPT;
+    const double *f = d.f + rs_off(d, r, 0);
+    for (int k = t; k < S * SC; k += NT) { const int oo = k / SC, ii = k - oo * SC; cl[k] = (ii < S && d.TC > 0) ? codeT[(size_t)oo * S + ii] : (uint8_t)255; }
+    for (int i = t; i < 2 * SV; i += NT) V[i] = 0.;
+    for (int i = t; i < 256; i += NT) val[i] = valtab[i];
+    __syncthreads();
+    if (t < S) V[t] = f[t];
+    __syncthreads();
+    const unsigned *cw = (const unsigned *)(cl + (size_t)oc * SC + i0);
+    const int NW = QPT / 4;
+    if (d.N > 1) {
+        double fn; int tcv, bsv;
+        gload8(fn, f + (size_t)1 * d.SP + oc); gload4(tcv, d.tclass); gload4(bsv, d.brk_slot);
+        gwait_all(fn, tcv, bsv);
+        for (int n = 1; n < d.N; n++) {
+            const int cur = (n - 1) & 1, nxt = n & 1, tn = n - 1;
+            const int tc = __builtin_amdgcn_readfirstlane(tcv), bs = __builtin_amdgcn_readfirstlane(bsv);
+            const double fcur = fn;
+            {
+                const int nn = n + 1 < d.N ? n + 1 : n;
+                gload8(fn, f + (size_t)nn * d.SP + oc); gload4(tcv, d.tclass + (nn - 1)); gload4(bsv, d.brk_slot + (nn - 1));
+            }
+            double best = -INFINITY; int bi = 0;
+            if (tc == 0 && bs < 0) {
+                if (act) {
+                    const double *Vc = V + cur * SV + i0;
+#pragma unroll 2
+                    for (int w = 0; w < NW; w++) {
+                        const unsigned c = cw[w];
+                        const double v0 = Vc[4 * w] + val[c & 255u], v1 = Vc[4 * w + 1] + val[(c >> 8) & 255u];
+                        const double v2 = Vc[4 * w + 2] + val[(c >> 16) & 255u], v3 = Vc[4 * w + 3] + val[c >> 24];
+                        if (v0 > best) { best = v0; bi = i0 + 4 * w; }
+                        if (v1 > best) { best = v1; bi = i0 + 4 * w + 1; }
+                        if (v2 > best) { best = v2; bi = i0 + 4 * w + 2; }
+                        if (v3 > best) { best = v3; bi = i0 + 4 * w + 3; }
+                    }
+                }
+            } else {
+                const double *pd = nullptr;
+                if (tc >= 0 && bs >= 0) {
+                    const double *pdg = d.pd_lt + ((size_t)r * d.NBE + bs) * M * D;
+                    for (int i = t; i < M * D; i += NT) pdl[i] = pdg[i];
+                    __syncthreads();
+                    pd = pdl;
+                }
+                if (act) for (int rr = 0; rr < QPT; rr++) {
+                    const int i = i0 + rr;
+                    if (i < S) {
+                        const double T = (tc < 0) ? 0. : trans_value(d, tn, i, o, pd);
+                        const double v = V[cur * SV + i] + T;
+                        if (v > best) { best = v; bi = i; }
+                    }
+                }
+            }
+            for (int off = 1; off < P; off <<= 1) {
+                const double ob = __shfl_xor(best, off, 64); const int oi = __shfl_xor(bi, off, 64);
+                if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+            }
+            gwait_all(fn, tcv, bsv);
+            if (act && p == 0) {
+                V[nxt * SV + o] = best + fcur;
+                gstore2(bp + (size_t)n * S + o, bi);
+            }
+            __syncthreads();
+        }
+    }
+    if (t < S) final_all[(size_t)blockIdx.x * S + t] = V[((d.N - 1) & 1) * SV + t];
+}
 // trace-back: one workgroup per restart; chunks of back-pointer rows staged through LDS
 __global__ void k_backtrace(Dev d, const uint16_t *bp_all, const double *final_all, int64_t *path_all, double *logprob_all, int ROWS) {
     extern __shared__ __align__(16) unsigned char smem_raw[];

@@ -230,6 +230,25 @@ def test_batched_decode_matches_oracle_paths(hip, oracle_mod, M, max_cn):
             b.infer_cn_batch(r0, nr)
 
 
+def test_decode_code_table_lattice_equals_plain_lattice(hip, monkeypatch):
+    """355 states (max_cn = 12): the lattice kernel that keeps 8-bit codes of the S x S transition values
+    in LDS against the plain kernel that reads the tabulated doubles (RMX_VITERBI_PLAIN), breakend and
+    telomere steps included: same paths and path log-probabilities, bit for bit."""
+    from remixt_amd import synthetic
+    from remixt_amd.restarts import RestartSet
+    e = synthetic.make_experiment(900, num_clones=3, max_copy_number=12, num_chains=5, seed=23, num_breakpoints=30)
+    ps = synthetic.make_init_params(e, 2, 12)
+    rs = RestartSet(e, ps, max_copy_number=12, num_clones=3, quiet=True)
+    b = rs.batch
+    assert b.num_cn_states == 355
+    b.variational_update(2)
+    cn, lp = b.infer_cn_batch(0, 2)
+    monkeypatch.setenv('RMX_VITERBI_PLAIN', '1')
+    cn_plain, lp_plain = b.infer_cn_batch(0, 2)
+    assert np.array_equal(cn, cn_plain) and np.array_equal(lp, lp_plain)
+    assert len(np.unique(cn[0].reshape(len(cn[0]), -1), axis=0)) > 3        # a non-trivial path
+
+
 def test_s165_matches_oracle(hip, oracle_mod):
     """BASELINE state grid (3 clones, max_cn=8 -> 165 states): register-stationary FB path vs oracle."""
     a, h, _ = H.make_model(hip, N=96, M=3, max_cn=8, chains=3, seed=7)

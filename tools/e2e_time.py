@@ -6,12 +6,12 @@ import numpy as np
 from remixt_amd import synthetic
 from remixt_amd.restarts import RestartGroups
 
-R = int(os.environ.get('RST', 16)); ITERS = int(os.environ.get('ITERS', 3))
+R = int(os.environ.get('RST', 16)); ITERS = int(os.environ.get('ITERS', 3)); MAXCN = int(os.environ.get('MAXCN', 8)); GROUPS = int(os.environ.get('GROUPS', 2))
 t = time.time()
-e = synthetic.make_experiment(int(os.environ.get('SEG', 50000)), num_clones=3, max_copy_number=8, num_chains=23, seed=0)
-ps = synthetic.make_init_params(e, R, 8, num_clones=3)
+e = synthetic.make_experiment(int(os.environ.get('SEG', 50000)), num_clones=3, max_copy_number=MAXCN, num_chains=23, seed=0)
+ps = synthetic.make_init_params(e, R, MAXCN, num_clones=3)
 print('synthetic experiment   %.2f s' % (time.time() - t)); t = time.time()
-rs = RestartGroups(e, ps, 8, groups=2, num_clones=3, device=0, quiet=True, seeds=list(range(R)))
+rs = RestartGroups(e, ps, MAXCN, groups=GROUPS, num_clones=3, device=0, quiet=True, seeds=list(range(R)))
 rs.synchronize()
 print('construct              %.2f s' % (time.time() - t)); t = time.time()
 el = rs.calculate_elbo()
