@@ -8,6 +8,8 @@ update for all restarts) and restarts are sharded over GPUs, one process per
 GPU, with ONE gather of the per-restart results at the end (RCCL over xGMI via
 torch.distributed; no communication during EM).
 """
+import os
+
 import numpy as np
 
 from .cn_model import BreakpointModel
@@ -84,14 +86,23 @@ class RestartSet(object):
         """cn_model.py:409-428 for every restart: batched variational sweeps, per-restart
         scipy M-steps, batched ELBO."""
         import time
+        from . import lockstep as _ls
         t_ = [time.perf_counter()]
-        self.variational_update(num_update_iter)
-        t_.append(time.perf_counter())
-
         # Lock-step parameter search needs the batched device objective and a private RNG stream per
         # restart (so that the order in which restarts draw their samples does not matter).
         lockstep = (self.lockstep and self.batch is not None and hasattr(self.batch, 'expected_log_likelihood_batch') and
                     all(m.rng is not None for m in self.models) and not any(m.check_elbo for m in self.models))
+        h_lockstep = lockstep and hasattr(self.batch, 'expected_log_likelihood_h_batch') and _ls.lbfgsb_available()
+        # the h M-step's (unweighted) samples are the first draws of the iteration whatever the sweeps give:
+        # a helper thread draws them while this thread waits on the sweeps
+        self._h_prefetch = None
+        if h_lockstep and any(m.do_h_update for m in self.models) and not os.environ.get('RMX_NO_SAMPLE_PREP'):
+            if getattr(self, '_prep_pool', None) is None:
+                from concurrent.futures import ThreadPoolExecutor
+                self._prep_pool = ThreadPoolExecutor(max_workers=1)
+            self._h_prefetch = ([m.rng.get_state() for m in self.models], self._prep_pool.submit(self._samples))
+        self.variational_update(num_update_iter)
+        t_.append(time.perf_counter())
 
         def mstep(r, with_h=True):
             m = self.models[r]
@@ -116,9 +127,8 @@ class RestartSet(object):
         # host threads so one restart's round trip overlaps the others' Python.  Both need a private
         # RNG stream per restart (seeds=...); with the reference's global numpy RNG the restarts run
         # one after the other.
-        from . import lockstep as _ls
         h_done = False
-        if lockstep and hasattr(self.batch, 'expected_log_likelihood_h_batch') and _ls.lbfgsb_available():
+        if h_lockstep:
             h_done = self._update_h_lockstep()
         threaded = (self.batch is not None and self.mstep_threads > 1 and
                     all(m.rng is not None for m in self.models))
@@ -218,10 +228,11 @@ class RestartSet(object):
         if not active:
             return True
         h_before = [np.array(m.model.h, dtype=float) for m in self.models]
-        rng_state = [m.rng.get_state() for m in self.models]
+        prefetch, self._h_prefetch = getattr(self, '_h_prefetch', None), None
+        rng_state = prefetch[0] if prefetch is not None else [m.rng.get_state() for m in self.models]
         try:
             ell_before = b.expected_log_likelihood_full(0, R)
-            samples = self._samples()
+            samples = prefetch[1].result() if prefetch is not None else self._samples()
             # the parameter M-steps' samples come next in every restart's RNG stream and depend on the outlier
             # indicators only: they are drawn on a helper thread while this thread waits on the h rounds
             self._start_param_sample_prep()
