@@ -186,14 +186,19 @@ class RestartSet(object):
     def _draw_param_samples(self, names):
         """Weighted samples of the listed parameters, parameter by parameter in the reference's order, and
         the outlier indicators they were weighted with: (samples {name: [per restart]}, indicators)."""
-        ind = [{'p_outlier_total': np.asarray(m.model.p_outlier_total), 'p_outlier_allele': np.asarray(m.model.p_outlier_allele)} for m in self.models]
-        samples = {}
-        for name in names:
-            weights = []
-            for m, c in zip(self.models, ind):
-                m._mstep_indicator_cache = c
-                weights.append(m.get_param_sample_weight(name))
-            samples[name] = self._samples(weights)
+        def one(r):
+            # a restart's indicators, then its draws for all listed parameters in order (its own RNG stream)
+            m = self.models[r]
+            c = {'p_outlier_total': np.asarray(m.model.p_outlier_total), 'p_outlier_allele': np.asarray(m.model.p_outlier_allele)}
+            m._mstep_indicator_cache = c
+            return c, [m._create_sample(m.get_param_sample_weight(name)) for name in names]
+        R = len(self.models)
+        if self.mstep_threads > 1 and R > 1:
+            per_restart = list(self._threads().map(one, range(R)))
+        else:
+            per_restart = [one(r) for r in range(R)]
+        ind = [c for c, _ in per_restart]
+        samples = dict((name, [smp[j] for _, smp in per_restart]) for j, name in enumerate(names))
         return samples, ind
 
     def _start_param_sample_prep(self):
