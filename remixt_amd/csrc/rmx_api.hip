@@ -1533,12 +1533,12 @@ static int run_ell_batch(rmx_batch *b, int nreq, const int32_t *restarts, bool g
     for (int i = 0; i < nreq * nout; i++) out[i] = b->h_pinned[i];
     return RMX_OK;
 }
-static int check_request_list(rmx_batch *b, int nreq, const int32_t *restarts) {
+static int check_request_list(rmx_batch *b, int nreq, const int32_t *restarts, bool need_sample = true) {
     std::vector<char> seen(b->R, 0);
     for (int i = 0; i < nreq; i++) {
         const int r = restarts[i];
         if (r < 0 || r >= b->R || seen[r]) return fail(RMX_EARG, "restart list must hold distinct valid restarts");
-        if (b->sample_count[r] < 0) return fail(RMX_EARG, "no sample set for a listed restart");
+        if (need_sample && b->sample_count[r] < 0) return fail(RMX_EARG, "no sample set for a listed restart");
         seen[r] = 1;
     }
     return RMX_OK;
@@ -1835,7 +1835,7 @@ int rmx_param_search_multi(rmx_batch *b, int32_t nreq, const int32_t *restarts, 
     if (!b || nreq < 1 || nreq > b->R || !restarts || nparams < 1 || nparams > 4 || !param_ids || !lo || !hi || !grids || G < 1 || !xopt || !lastval)
         return fail(RMX_EARG, "bad argument");
     int rc;
-    if ((rc = check_request_list(b, nreq, restarts))) return rc;
+    if ((rc = check_request_list(b, nreq, restarts, false))) return rc;      // (its samples live in the parameter slots)
     const Dev &d = b->d;
     const int Q = nreq * nparams;
     MultiVals mv;
@@ -1872,6 +1872,13 @@ int rmx_param_search_multi(rmx_batch *b, int32_t nreq, const int32_t *restarts, 
     }
     for (int j = 0; j < nparams; j++)
         for (int g = 0; g < G; g++) { mv.gv[j][g] = grids[(size_t)j * G + g]; mv.glv[j][g] = std::log(mv.gv[j][g]); }
+    // the candidates are evaluated against the restarts' device parameters and state tables: bring them up to date
+    // first (a rolled-back h, a parameter set since the last pass: the one-at-a-time search does this through the
+    // table rebuild of its first full evaluation)
+    {
+        std::lock_guard<std::mutex> lk(b->mu);
+        for (int i = 0; i < nreq; i++) if ((rc = ensure_tables(b, restarts[i], restarts[i] + 1, false))) return rc;
+    }
     // one round: requests cur[0..n) (indices q = j * nreq + i), their values vals[] (ignored in the grid stage)
     std::vector<double> out((size_t)Q * G);
     auto round = [&](int n_, const int *cur, const double *vals, bool grid_stage) -> int {

@@ -202,7 +202,7 @@ def test_batch_equals_single(hip):
 
 @pytest.mark.parametrize('M,max_cn', [(2, 4), (3, 3), (3, 6), (3, 8)])
 def test_batched_decode_matches_oracle_paths(hip, oracle_mod, M, max_cn):
-    """rmx_infer_cn_batch on grids of 9 / 20 / 84 / 165 states (different register-tile widths of the
+    """rmx_infer_cn_batch on grids of 9 / 20 / 97 / 165 states (different register-tile widths of the
     lattice kernel): every restart's path equals the oracle's Viterbi path of the same model, bit for bit;
     before the first update_p_cn every comparison ties and the first state wins (bpmodel.pyx:557-558)."""
     from remixt_amd import synthetic
@@ -343,8 +343,8 @@ def test_lockstep_mstep_equals_per_restart_mstep(hip):
     brute + fmin search gives (same evaluation sequence per restart)."""
     from remixt_amd import synthetic
     from remixt_amd.restarts import RestartSet
-    e = synthetic.make_experiment(600, num_clones=3, max_copy_number=3, num_chains=5, seed=6)
-    ps = synthetic.make_init_params(e, 4, 3)
+    e = synthetic.make_experiment(600, num_clones=3, max_copy_number=4, num_chains=5, seed=6)      # 47 states: strip kernels, lists of states with posterior mass
+    ps = synthetic.make_init_params(e, 4, 4)
     import os
     knobs = ('RMX_SEARCH_TABLES', 'RMX_SEARCH_LOOKAHEAD', 'RMX_SEARCH_SEQUENTIAL')
     configs = [
@@ -361,7 +361,7 @@ def test_lockstep_mstep_equals_per_restart_mstep(hip):
             os.environ.pop(k, None)
         for k in env:
             os.environ[k] = '1'
-        rs = RestartSet(e, ps, max_copy_number=3, num_clones=3, quiet=True, seeds=[5, 6, 7, 8], lockstep=lock,
+        rs = RestartSet(e, ps, max_copy_number=4, num_clones=3, quiet=True, seeds=[5, 6, 7, 8], lockstep=lock,
                         native_search=native, mstep_threads=1)
         rs.fit(num_em_iter=2, num_update_iter=2)
         out.append([(m.prev_elbo, np.array(m.h), m.get_likelihood_param_values()) for m in rs.models])
@@ -382,6 +382,45 @@ def test_lockstep_mstep_equals_per_restart_mstep(hip):
             np.testing.assert_allclose(h1, h2, rtol=1e-6)
             for k in p1:
                 assert abs(p1[k] - p2[k]) <= 1e-3 + 1e-5 * abs(p2[k]), k
+
+
+def test_param_search_multi_argument_checks(hip):
+    """rmx_param_search_multi: what does not qualify is refused (NotImplementedError -> the caller falls back
+    to rmx_param_search), bad arguments raise ValueError, and a qualifying call leaves the model untouched."""
+    from remixt_amd import synthetic
+    from remixt_amd.restarts import RestartSet
+    e = synthetic.make_experiment(500, num_clones=3, max_copy_number=6, num_chains=4, seed=3)
+    ps = synthetic.make_init_params(e, 2, 6)
+    rs = RestartSet(e, ps, max_copy_number=6, num_clones=3, quiet=True, seeds=[1, 2])
+    b = rs.batch
+    assert b.num_cn_states == 97       # (grids of <= 32 states have no lists of states with posterior mass: never qualify)
+    b.variational_update(1)
+    grid = np.mgrid[10.:2000.:complex(20)]
+    with pytest.raises(NotImplementedError):              # no slot sample was ever set
+        b.param_search_multi([0, 1], ['negbin_r_0'], [10.], [2000.], grid[None, :])
+    sample = np.zeros(b.num_segments, dtype=int); sample[::7] = 1
+    b.set_sample_slot(0, 0, sample)
+    with pytest.raises(ValueError):                       # restart 1 has no sample in slot 0
+        b.param_search_multi([0, 1], ['negbin_r_0'], [10.], [2000.], grid[None, :])
+    for r in range(2):
+        for slot in range(2):
+            b.set_sample_slot(r, slot, sample)
+    with pytest.raises(NotImplementedError):              # not one of the four standard parameters
+        b.param_search_multi([0, 1], ['negbin_hdel_mu'], [1e-9], [1e-4], np.mgrid[1e-9:1e-4:complex(20)][None, :])
+    with pytest.raises(NotImplementedError):              # listed twice
+        b.param_search_multi([0, 1], ['negbin_r_0', 'negbin_r_0'], [10., 10.], [2000., 2000.], np.stack([grid, grid]))
+    with pytest.raises(ValueError):
+        b.set_sample_slot(0, 4, sample)
+    before = [(b.get_param(r, 'negbin_r_0'), b.get_param(r, 'betabin_M_0')) for r in range(2)]
+    xopt, last = b.param_search_multi([0, 1], ['negbin_r_0', 'betabin_M_0'], [10., 10.], [2000., 2000.], np.stack([grid, grid]))
+    assert xopt.shape == (2, 2) and last.shape == (2, 2) and np.all((xopt >= 10.) & (xopt <= 2000.))
+    assert before == [(b.get_param(r, 'negbin_r_0'), b.get_param(r, 'betabin_M_0')) for r in range(2)]
+    # the same searches one at a time (full-sum objective constant included): same optimum up to rounding
+    for j, name in enumerate(['negbin_r_0', 'betabin_M_0']):
+        for r in range(2):
+            b._use_sample(r, sample)
+        one = b.param_search([0, 1], name, 10., 2000., grid)
+        np.testing.assert_allclose(one, xopt[j], rtol=1e-5, atol=1e-3)
 
 
 def test_restart_groups_do_not_change_results(hip):
