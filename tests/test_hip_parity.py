@@ -428,11 +428,11 @@ def test_restart_groups_do_not_change_results(hip):
     same fit as one batch of all restarts."""
     from remixt_amd import synthetic
     from remixt_amd.restarts import RestartGroups
-    e = synthetic.make_experiment(500, num_clones=3, max_copy_number=3, num_chains=4, seed=9)
-    ps = synthetic.make_init_params(e, 4, 3)
+    e = synthetic.make_experiment(500, num_clones=3, max_copy_number=4, num_chains=4, seed=9)      # 47 states: strip kernels, two streams per sweep, shared search rounds
+    ps = synthetic.make_init_params(e, 4, 4)
     out = []
     for groups in (1, 2):
-        rs = RestartGroups(e, ps, 3, groups=groups, num_clones=3, quiet=True, seeds=[1, 2, 3, 4])
+        rs = RestartGroups(e, ps, 4, groups=groups, num_clones=3, quiet=True, seeds=[1, 2, 3, 4])
         el = rs.calculate_elbo()
         for m, v in zip(rs.models, el):
             m.prev_elbo = float(v)
