@@ -162,11 +162,13 @@ def test_module_sum_product_max_product(hip, oracle_mod):
         assert np.allclose(a1, a2, rtol=1e-12, atol=1e-10) and np.allclose(b1, b2, rtol=1e-12, atol=1e-10)
 
 
-def test_full_fit_matches_oracle(hip, oracle_mod):
-    """Seeded EM trajectory (variational sweeps + scipy M-steps) on both kernels."""
+@pytest.mark.parametrize('max_cn', [3, 4])
+def test_full_fit_matches_oracle(hip, oracle_mod, max_cn):
+    """Seeded EM trajectory (variational sweeps + scipy M-steps) on both kernels; 20 states (row kernels) and
+    47 states (strip kernels, cell cache, trial / rollback and sparse trial passes of the M-steps)."""
     res = []
     for kern in (hip, oracle_mod):
-        m, h, e = H.make_model(kern, N=240, M=3, max_cn=3, chains=4, seed=5)
+        m, h, e = H.make_model(kern, N=240, M=3, max_cn=max_cn, chains=4, seed=5)
         m.num_em_iter = 2; m.num_update_iter = 2
         np.random.seed(11)
         m.fit(h)
