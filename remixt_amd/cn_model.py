@@ -615,7 +615,7 @@ class BreakpointModel(object):
         brk_cn = dict()
         best = log_breakpoint_p.argmax(axis=1) if m.num_breakpoints else []
         for k in range(m.num_breakpoints):
-            brk_cn[self.breakpoint_ids[k]] = brk_states[best[k]]
+            brk_cn[self.breakpoint_ids[k]] = np.array(brk_states[best[k]])      # a copy: brk_states may be a view of the kernel model's buffer
 
         return cn[self.seg_fwd_remap], brk_cn
 

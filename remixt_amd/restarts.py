@@ -530,13 +530,13 @@ def collect_fit_results(model, experiment, init_params, cn=None):
     if model.disable_breakpoints:
         brk_cn = decode_breakpoints_naive(cn, experiment.adjacencies, experiment.breakpoints)
     res = dict()
-    res['h'] = model.h
+    res['h'] = np.array(model.h, dtype=float)       # a copy: a kernel model may hand out a view of its own buffer
     res['cn'] = cn
     res['brk_cn'] = brk_cn
-    res['p_outlier_total'] = model.p_outlier_total
-    res['p_outlier_allele'] = model.p_outlier_allele
-    res['total_likelihood_mask'] = model.total_likelihood_mask
-    res['allele_likelihood_mask'] = model.allele_likelihood_mask
+    res['p_outlier_total'] = np.array(model.p_outlier_total)
+    res['p_outlier_allele'] = np.array(model.p_outlier_allele)
+    res['total_likelihood_mask'] = np.array(model.total_likelihood_mask)
+    res['allele_likelihood_mask'] = np.array(model.allele_likelihood_mask)
     stats = dict()
     stats['elbo'] = model.prev_elbo
     stats['elbo_diff'] = model.prev_elbo_diff
