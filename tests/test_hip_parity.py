@@ -344,11 +344,10 @@ def test_fused_sweeps_equal_separate_updates(hip):
     e = synthetic.make_experiment(700, num_clones=3, max_copy_number=8, num_chains=4, seed=11)
     ps = synthetic.make_init_params(e, 3, 8)
     outs = []
-    for fuse in (True, False):
-        if fuse:
-            os.environ.pop('RMX_NO_FUSE', None)
-        else:
-            os.environ['RMX_NO_FUSE'] = '1'
+    for knob in (None, 'RMX_NO_FUSE', 'RMX_ONE_STREAM'):      # default: fused passes, breakend branch on its own stream
+        os.environ.pop('RMX_NO_FUSE', None); os.environ.pop('RMX_ONE_STREAM', None)
+        if knob:
+            os.environ[knob] = '1'
         rs = RestartSet(e, ps, max_copy_number=8, num_clones=3, quiet=True)
         assert rs.batch.num_cn_states == 165
         rs.batch.variational_update(3)
@@ -356,11 +355,12 @@ def test_fused_sweeps_equal_separate_updates(hip):
         outs.append((el, [rs.batch.get_array(r, 'posterior_marginals') for r in range(3)],
                      [rs.batch.get_array(r, 'p_outlier_total') for r in range(3)], [rs.batch.get_array(r, 'p_outlier_allele') for r in range(3)],
                      [rs.batch.get_array(r, 'p_allele_swap') for r in range(3)], [rs.batch.get_array(r, 'p_breakpoint') for r in range(3)]))
-    os.environ.pop('RMX_NO_FUSE', None)
-    assert np.array_equal(outs[0][0], outs[1][0])
-    for k in range(1, 6):
-        for x, y in zip(outs[0][k], outs[1][k]):
-            assert np.array_equal(x, y), k
+    os.environ.pop('RMX_NO_FUSE', None); os.environ.pop('RMX_ONE_STREAM', None)
+    for other in outs[1:]:
+        assert np.array_equal(outs[0][0], other[0])
+        for k in range(1, 6):
+            for x, y in zip(outs[0][k], other[k]):
+                assert np.array_equal(x, y), k
 
 
 def test_lockstep_mstep_equals_per_restart_mstep(hip):
