@@ -1385,7 +1385,12 @@ static int queue_ell(rmx_batch *b, int r, bool grad, double *dst) {
         if ((rc = ensure_tables(b, r, r + 1, false))) return rc;
         {
             ProfScope ps(b, KID_ELL_LIST);
-            if (grad) hipLaunchKernelGGL(k_ell_list<true>, dim3(cnt), ell_block(b), 0, b->stream, b->d, r, list, partial);
+            const int32_t r32 = r;
+            // objective + gradient from the lists of states with posterior mass when they are current (the batched
+            // evaluation of the lock-step h M-step asks the same question: both drivers sum the same terms)
+            if (grad && ell_sparse_ok(b, 1, &r32)) hipLaunchKernelGGL(k_ell_list_sparse_grad, dim3((cnt + 7) / 8), dim3(256), 0, b->stream, b->d, r, list, cnt, partial);
+            else if (grad) hipLaunchKernelGGL(k_ell_list<true>, dim3(cnt), ell_block(b), 0, b->stream, b->d, r, list, partial);
+            else if (ell_sparse_ok(b, 1, &r32)) hipLaunchKernelGGL(k_ell_list_sparse_val, dim3((cnt + 7) / 8), dim3(256), 0, b->stream, b->d, r, list, cnt, partial);
             else hipLaunchKernelGGL(k_ell_list<false>, dim3(cnt), ell_block(b), 0, b->stream, b->d, r, list, partial);
         }
         { ProfScope ps(b, KID_ELL_FINAL); hipLaunchKernelGGL(k_ell_final, dim3(1), dim3(256), 0, b->stream, (const double *)partial, cnt, dst); }
@@ -1493,11 +1498,15 @@ static int run_ell_batch(rmx_batch *b, int nreq, const int32_t *restarts, bool g
         const int pstride = std::max(d.N, ELBO_BLOCKS) * W;
         if (maxcnt > 0) {
             ProfScope ps(b, KID_ELL_LIST);
-            if (grad) hipLaunchKernelGGL(k_ell_list_batch<true>, dim3(maxcnt, nreq), ell_block(b), 0, b->stream, b->d, (const int32_t *)b->d_rlist, (const RestartParams *)b->d_rp_stage,
+            if (grad && ell_sparse_ok(b, nreq, restarts))
+                hipLaunchKernelGGL(k_ell_list_batch_sparse_grad, dim3((maxcnt + 7) / 8, nreq), dim3(256), 0, b->stream, b->d, (const int32_t *)b->d_rlist, (const RestartParams *)b->d_rp_stage,
+                                   (const int32_t *)b->d_sample, (const int32_t *)b->d_counts, b->d_ell_partial, pstride);
+            else if (grad) hipLaunchKernelGGL(k_ell_list_batch<true>, dim3(maxcnt, nreq), ell_block(b), 0, b->stream, b->d, (const int32_t *)b->d_rlist, (const RestartParams *)b->d_rp_stage,
                                          (const int32_t *)b->d_sample, (const int32_t *)b->d_counts, b->d_ell_partial, pstride);
             else {
                 void (*kf)(Dev, const int32_t *, const RestartParams *, const int32_t *, const int32_t *, double *, int) = k_ell_list_batch<false, CM_ALL>;
-                const bool sparse = (mask == 1 || mask == 2 || mask == 4 || mask == 8) && ell_sparse_ok(b, nreq, restarts);
+                const bool sparse = (mask == 1 || mask == 2 || mask == 4 || mask == 8 || mask == CM_ALL) && ell_sparse_ok(b, nreq, restarts);
+                if (sparse && mask == CM_ALL) kf = k_ell_list_batch_sparse<CM_ALL>;
                 switch (mask) {
                 case 1: kf = sparse ? k_ell_list_batch_sparse<1> : k_ell_list_batch<false, 1>; break;
                 case 2: kf = sparse ? k_ell_list_batch_sparse<2> : k_ell_list_batch<false, 2>; break;

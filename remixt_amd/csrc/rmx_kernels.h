@@ -1820,6 +1820,75 @@ __global__ void k_elbo_final(Dev d, int r0, const double *partial, int nblk, con
 // OVR: the state-table entries that depend on the searched beta-binomial precision (M, lgamma(M p),
 // lgamma(M (1-p))) are recomputed from rp here instead of being read from the restart's tables, which
 // therefore need no rebuild per candidate value
+// one state's terms of E[ll] (and of d/dh when GRAD) under parameters rp: acc += ..., g[m] += ...
+template <bool GRAD, int MASK, bool OVR>
+__device__ __forceinline__ void ell_state_terms(const Dev &d, const RestartParams &rp, const SegCtx &sc, int r, int cls, int s, double ps_,
+                                                double qt0, double qt1, double qa0, double qa1, double qs0, double qs1,
+                                                double &acc, double (&g)[RMX_MAX_CLONES], unsigned &err) {
+    double LT[2], LA[4];
+    if (MASK == CM_ALL) cell_ll(d, rp, sc, r, cls, s, LT, LA, err);
+    else {
+        StateRegs st_; load_state_regs(d, r, cls, s, st_);
+        if (OVR && (MASK & (CM_LA0 | CM_LA1)) && !(st_.fl & ST_LOH_M)) {
+            const bool ok_ = !(st_.fl & (ST_E_BADP | ST_E_TD | ST_E_LOH));      // as state_tables_body
+            if (MASK & CM_LA0) { const double M_ = rp.p[RMX_P_BETABIN_M_0]; st_.M0 = M_; st_.lgA0 = ok_ ? lgamma_pos(M_ * st_.p) : 0.; st_.lgB0 = ok_ ? lgamma_pos(M_ * (1 - st_.p)) : 0.; }
+            if (MASK & CM_LA1) { const double M_ = rp.p[RMX_P_BETABIN_M_1]; st_.M1 = M_; st_.lgA1 = ok_ ? lgamma_pos(M_ * st_.p) : 0.; st_.lgB1 = ok_ ? lgamma_pos(M_ * (1 - st_.p)) : 0.; }
+        }
+        cell_ll_regs<MASK>(rp, sc, st_, LT, LA, err);
+    }
+    const double ps = ps_;
+    if (MASK & CM_LT0) acc += ps * qt0 * LT[0];
+    if (MASK & CM_LT1) acc += ps * qt1 * LT[1];
+    if (MASK & CM_LA0) { acc += ps * qa0 * qs0 * LA[0]; acc += ps * qa0 * qs1 * LA[1]; }
+    if (MASK & CM_LA1) { acc += ps * qa1 * qs0 * LA[2]; acc += ps * qa1 * qs1 * LA[3]; }
+    if (GRAD) {
+        const size_t si = ((size_t)r * d.C + cls) * d.SP + s;
+        const unsigned fl = d.stFlags[si];
+        const int8_t *cn = d.cn + ((size_t)cls * d.S + s) * d.M * 2;
+        const int8_t *tot = d.tot + ((size_t)cls * d.S + s) * d.M;
+        // total part (bpmodel.pyx:778-807)
+        if (sc.mt && !(fl & ST_HDEL_NB)) {
+            const double mu = d.stD[si] * sc.l;
+            const double r0_ = rp.p[RMX_P_NEGBIN_R_0], r1_ = rp.p[RMX_P_NEGBIN_R_1];
+            const double pm0 = sc.x / mu - (r0_ + sc.x) / (r0_ + mu), pm1 = sc.x / mu - (r1_ + sc.x) / (r1_ + mu);
+            if (pm0 != pm0 || pm1 != pm1) err |= RMX_ERR_NAN_GRAD;
+            for (int m = 0; m < d.M; m++) {
+                const double base = sc.l * (double)tot[m];
+                g[m] += ps * qt0 * (base * pm0); g[m] += ps * qt1 * (base * pm1);
+            }
+        }
+        // allele part (bpmodel.pyx:855-896)
+        if (sc.ma && !(fl & ST_GZ_ALLELE)) {
+            double minor = 0., total = 0.;
+            for (int m = 0; m < d.M; m++) { minor += rp.h[m] * (double)cn[m * 2]; total += rp.h[m] * (double)tot[m]; }
+            if (total <= 0.) err |= RMX_ERR_TOTAL_DEPTH;
+            else if (sc.ys != 0.) {
+                const double p = minor / total;
+                if (p <= 0. || (1 - p) <= 0.) err |= RMX_ERR_BAD_P;
+                else {
+                    double pp[4];
+#pragma unroll
+                    for (int v = 0; v < 2; v++) {
+                        const double Mv = v == 0 ? rp.p[RMX_P_BETABIN_M_0] : rp.p[RMX_P_BETABIN_M_1];
+                        const double dg_a = digamma_as103(Mv * p, err), dg_b = digamma_as103(Mv * (1 - p), err);
+#pragma unroll
+                        for (int w = 0; w < 2; w++) {
+                            const double k = w == 0 ? sc.y0 : sc.y1;
+                            pp[v * 2 + w] = (Mv * digamma_as103(k + Mv * p, err) + (-Mv) * digamma_as103(sc.ys - k + Mv * (1 - p), err)
+                                             - Mv * dg_a - (-Mv) * dg_b);
+                            if (pp[v * 2 + w] != pp[v * 2 + w]) err |= RMX_ERR_NAN_GRAD;
+                        }
+                    }
+                    for (int m = 0; m < d.M; m++) {
+                        const double base = ((double)cn[m * 2] * total - minor * (double)tot[m]) / (total * total);
+                        g[m] += ps * qa0 * qs0 * (base * pp[0]); g[m] += ps * qa0 * qs1 * (base * pp[1]);
+                        g[m] += ps * qa1 * qs0 * (base * pp[2]); g[m] += ps * qa1 * qs1 * (base * pp[3]);
+                    }
+                }
+            }
+        }
+    }
+}
 template <bool GRAD, int MASK = CM_ALL, bool OVR = false>
 __device__ __forceinline__ void ell_segment(const Dev &d, const RestartParams &rp, int r, int n, double *prow) {
     __shared__ double scratch[8];
@@ -1848,69 +1917,7 @@ __device__ __forceinline__ void ell_segment(const Dev &d, const RestartParams &r
             continue;
         }
         if (s >= d.S) continue;
-        double LT[2], LA[4];
-        if (MASK == CM_ALL) cell_ll(d, rp, sc, r, cls, s, LT, LA, err);
-        else {
-            StateRegs st_; load_state_regs(d, r, cls, s, st_);
-            if (OVR && (MASK & (CM_LA0 | CM_LA1)) && !(st_.fl & ST_LOH_M)) {
-                const bool ok_ = !(st_.fl & (ST_E_BADP | ST_E_TD | ST_E_LOH));      // as state_tables_body
-                if (MASK & CM_LA0) { const double M_ = rp.p[RMX_P_BETABIN_M_0]; st_.M0 = M_; st_.lgA0 = ok_ ? lgamma_pos(M_ * st_.p) : 0.; st_.lgB0 = ok_ ? lgamma_pos(M_ * (1 - st_.p)) : 0.; }
-                if (MASK & CM_LA1) { const double M_ = rp.p[RMX_P_BETABIN_M_1]; st_.M1 = M_; st_.lgA1 = ok_ ? lgamma_pos(M_ * st_.p) : 0.; st_.lgB1 = ok_ ? lgamma_pos(M_ * (1 - st_.p)) : 0.; }
-            }
-            cell_ll_regs<MASK>(rp, sc, st_, LT, LA, err);
-        }
-        const double ps = ps_;
-        if (MASK & CM_LT0) acc += ps * qt0 * LT[0];
-        if (MASK & CM_LT1) acc += ps * qt1 * LT[1];
-        if (MASK & CM_LA0) { acc += ps * qa0 * qs0 * LA[0]; acc += ps * qa0 * qs1 * LA[1]; }
-        if (MASK & CM_LA1) { acc += ps * qa1 * qs0 * LA[2]; acc += ps * qa1 * qs1 * LA[3]; }
-        if (GRAD) {
-            const size_t si = ((size_t)r * d.C + cls) * d.SP + s;
-            const unsigned fl = d.stFlags[si];
-            const int8_t *cn = d.cn + ((size_t)cls * d.S + s) * d.M * 2;
-            const int8_t *tot = d.tot + ((size_t)cls * d.S + s) * d.M;
-            // total part (bpmodel.pyx:778-807)
-            if (sc.mt && !(fl & ST_HDEL_NB)) {
-                const double mu = d.stD[si] * sc.l;
-                const double r0_ = rp.p[RMX_P_NEGBIN_R_0], r1_ = rp.p[RMX_P_NEGBIN_R_1];
-                const double pm0 = sc.x / mu - (r0_ + sc.x) / (r0_ + mu), pm1 = sc.x / mu - (r1_ + sc.x) / (r1_ + mu);
-                if (pm0 != pm0 || pm1 != pm1) err |= RMX_ERR_NAN_GRAD;
-                for (int m = 0; m < d.M; m++) {
-                    const double base = sc.l * (double)tot[m];
-                    g[m] += ps * qt0 * (base * pm0); g[m] += ps * qt1 * (base * pm1);
-                }
-            }
-            // allele part (bpmodel.pyx:855-896)
-            if (sc.ma && !(fl & ST_GZ_ALLELE)) {
-                double minor = 0., total = 0.;
-                for (int m = 0; m < d.M; m++) { minor += rp.h[m] * (double)cn[m * 2]; total += rp.h[m] * (double)tot[m]; }
-                if (total <= 0.) err |= RMX_ERR_TOTAL_DEPTH;
-                else if (sc.ys != 0.) {
-                    const double p = minor / total;
-                    if (p <= 0. || (1 - p) <= 0.) err |= RMX_ERR_BAD_P;
-                    else {
-                        double pp[4];
-#pragma unroll
-                        for (int v = 0; v < 2; v++) {
-                            const double Mv = v == 0 ? rp.p[RMX_P_BETABIN_M_0] : rp.p[RMX_P_BETABIN_M_1];
-                            const double dg_a = digamma_as103(Mv * p, err), dg_b = digamma_as103(Mv * (1 - p), err);
-#pragma unroll
-                            for (int w = 0; w < 2; w++) {
-                                const double k = w == 0 ? sc.y0 : sc.y1;
-                                pp[v * 2 + w] = (Mv * digamma_as103(k + Mv * p, err) + (-Mv) * digamma_as103(sc.ys - k + Mv * (1 - p), err)
-                                                 - Mv * dg_a - (-Mv) * dg_b);
-                                if (pp[v * 2 + w] != pp[v * 2 + w]) err |= RMX_ERR_NAN_GRAD;
-                            }
-                        }
-                        for (int m = 0; m < d.M; m++) {
-                            const double base = ((double)cn[m * 2] * total - minor * (double)tot[m]) / (total * total);
-                            g[m] += ps * qa0 * qs0 * (base * pp[0]); g[m] += ps * qa0 * qs1 * (base * pp[1]);
-                            g[m] += ps * qa1 * qs0 * (base * pp[2]); g[m] += ps * qa1 * qs1 * (base * pp[3]);
-                        }
-                    }
-                }
-            }
-        }
+        ell_state_terms<GRAD, MASK, OVR>(d, rp, sc, r, cls, s, ps_, qt0, qt1, qa0, qa1, qs0, qs1, acc, g, err);
     }
     acc = block_sum_rt(acc, scratch);
     if (threadIdx.x == 0) prow[0] = acc;
@@ -1967,6 +1974,56 @@ __device__ __forceinline__ void ell_segment_sparse(const Dev &d, const RestartPa
     acc = group_sum(acc, 32);
     if (lane == 0) prow[0] = acc;
     if (err) atomicOr(&d.err[r], err);
+}
+// E[ll] and d/dh of one sampled segment from its list of states with posterior mass: half a wave per segment,
+// a lane per listed state (ell_segment_sparse with the gradient terms; all four likelihood components)
+__device__ __forceinline__ void ell_segment_sparse_grad(const Dev &d, const RestartParams &rp, int r, int n, double *prow) {
+    const int lane = threadIdx.x & 31;
+    SegCtx sc;
+    sc.x = d.x[n]; sc.l = d.l[n]; sc.logl = d.logl[n]; sc.y0 = d.y[2 * (size_t)n]; sc.y1 = d.y[2 * (size_t)n + 1]; sc.ys = sc.y0 + sc.y1;
+    sc.mt = d.mask_t[n]; sc.ma = d.mask_a[n];
+    const double k_ = seg_const_value(rp, sc.x, sc.y0, sc.ys, lane & 7);
+#pragma unroll
+    for (int i = 0; i < 4; i++) { sc.cnb[i] = __shfl(k_, i, 32); sc.cbb[i] = __shfl(k_, 4 + i, 32); }
+    const int cls = d.seg_class[n];
+    const size_t rn = (size_t)r * d.N + n;
+    const double qt0 = d.qt[rn * 2], qt1 = d.qt[rn * 2 + 1], qa0 = d.qa[rn * 2], qa1 = d.qa[rn * 2 + 1];
+    const double qs0 = d.qs[rn * 2], qs1 = d.qs[rn * 2 + 1];
+    const double *post = d.post + rs_off(d, r, n);
+    unsigned err = 0;
+    double acc = 0., g[RMX_MAX_CLONES] = {0., 0., 0., 0.};
+    const int cnt = d.sig_cnt[rn];
+    if (cnt == 255) { for (int s = lane; s < d.S; s += 32) ell_state_terms<true, CM_ALL, false>(d, rp, sc, r, cls, s, post[s], qt0, qt1, qa0, qa1, qs0, qs1, acc, g, err); }
+    else {
+        if (lane < cnt) { const int s = (int)d.sig_idx[rn * RMX_SIGK + lane]; ell_state_terms<true, CM_ALL, false>(d, rp, sc, r, cls, s, post[s], qt0, qt1, qa0, qa1, qs0, qs1, acc, g, err); }
+        for (int s = lane; s < d.S; s += 32) cell_static_errors<CM_ALL>(sc, d.stFlags[((size_t)r * d.C + cls) * d.SP + s], err);
+    }
+    acc = group_sum(acc, 32);
+    if (lane == 0) prow[0] = acc;
+#pragma unroll
+    for (int m = 0; m < RMX_MAX_CLONES; m++) { const double gm = group_sum(g[m], 32); if (lane == 0) prow[1 + m] = gm; }
+    if (err) atomicOr(&d.err[r], err);
+}
+// value only (all four components): the same per-state terms and summation as ell_segment_sparse_grad's value
+__global__ __launch_bounds__(256) void k_ell_list_sparse_val(Dev d, int r, const int32_t *list, int count, double *partial) {
+    const int i = blockIdx.x * 8 + (threadIdx.x >> 5);
+    if (i >= count) return;
+    ell_segment_sparse<CM_ALL, false>(d, d.rp[r], r, list[i], partial + (size_t)i * (1 + RMX_MAX_CLONES));
+}
+// grid (ceil(count / 8)), block 256: restart r's sampled segments, half a wave each
+__global__ __launch_bounds__(256) void k_ell_list_sparse_grad(Dev d, int r, const int32_t *list, int count, double *partial) {
+    const int i = blockIdx.x * 8 + (threadIdx.x >> 5);
+    if (i >= count) return;
+    ell_segment_sparse_grad(d, d.rp[r], r, list[i], partial + (size_t)i * (1 + RMX_MAX_CLONES));
+}
+// grid (ceil(maxcount / 8), nreq), block 256
+__global__ __launch_bounds__(256) void k_ell_list_batch_sparse_grad(Dev d, const int32_t *rlist, const RestartParams *stage, const int32_t *samples, const int32_t *counts,
+                                                                    double *partial, int pstride) {
+    const int r = rlist[blockIdx.y];
+    const int i = blockIdx.x * 8 + (threadIdx.x >> 5);
+    if (i >= counts[r]) return;
+    const int n = samples[(size_t)r * d.N + i];
+    ell_segment_sparse_grad(d, stage[blockIdx.y], r, n, partial + (size_t)r * pstride + (size_t)i * (1 + RMX_MAX_CLONES));
 }
 template <bool GRAD>
 __global__ void k_ell_list(Dev d, int r, const int32_t *list, double *partial) {
