@@ -1940,7 +1940,11 @@ __device__ __forceinline__ void ell_segment_sparse(const Dev &d, const RestartPa
     SegCtx sc;
     sc.x = d.x[n]; sc.l = d.l[n]; sc.logl = d.logl[n]; sc.y0 = d.y[2 * (size_t)n]; sc.y1 = d.y[2 * (size_t)n + 1]; sc.ys = sc.y0 + sc.y1;
     sc.mt = d.mask_t[n]; sc.ma = d.mask_a[n];
-    const double k_ = seg_const_value(rp, sc.x, sc.y0, sc.ys, lane & 7);      // lanes 0..7 hold the eight per-segment constants
+    // lanes 0..7 hold the eight per-segment constants; only the family the components in MASK read is evaluated
+    // (the two families are divergent branches of 3 and 5 lgamma's: a negative-binomial search skips the longer one)
+    double k_ = 0.;
+    if ((MASK & (CM_LT0 | CM_LT1)) && (lane & 7) < 4) k_ = seg_const_value(rp, sc.x, sc.y0, sc.ys, lane & 7);
+    if ((MASK & (CM_LA0 | CM_LA1)) && (lane & 7) >= 4) k_ = seg_const_value(rp, sc.x, sc.y0, sc.ys, lane & 7);
 #pragma unroll
     for (int i = 0; i < 4; i++) { sc.cnb[i] = __shfl(k_, i, 32); sc.cbb[i] = __shfl(k_, 4 + i, 32); }
     const int cls = d.seg_class[n];
