@@ -184,8 +184,10 @@ def test_full_fit_matches_oracle(hip, oracle_mod, max_cn):
     assert np.allclose(q1, q2, rtol=1e-5, atol=1e-8)
 
 
-def test_restart_driver_matches_oracle_driver(hip, oracle_mod):
-    """The batched restart driver on the device (lock-step M-steps through scipy's own optimiser steps) against
+@pytest.mark.parametrize('normal_contamination', [True, False])
+def test_restart_driver_matches_oracle_driver(hip, oracle_mod, normal_contamination):
+    """(normal_contamination=False adds the six hdel / LOH likelihood parameters to the M-step.)
+    The batched restart driver on the device (lock-step M-steps through scipy's own optimiser steps) against
     the same driver over the CPU oracle (one model per restart, scipy per restart): same seeded trajectories --
     ELBO to 1e-6, decoded copy number identical -- and the native shared-round searches stay within the same
     bounds on this data."""
@@ -195,9 +197,19 @@ def test_restart_driver_matches_oracle_driver(hip, oracle_mod):
     ps = synthetic.make_init_params(e, 2, 4)
     runs = []
     for kern, native in ((oracle_mod, False), (None, False), (None, True)):
-        rs = RestartSet(e, ps, max_copy_number=4, num_clones=3, quiet=True, seeds=[3, 4], kernel_module=kern, native_search=native, mstep_threads=1)
+        rs = RestartSet(e, ps, max_copy_number=4, num_clones=3, quiet=True, seeds=[3, 4], kernel_module=kern, native_search=native, mstep_threads=1,
+                        normal_contamination=normal_contamination)
+        assert len(rs.models[0].likelihood_params) == (4 if normal_contamination else 10)
+        if not normal_contamination:
+            # on this data fewer segments carry homozygous-deletion posterior mass than the M-step sample holds:
+            # numpy's choice(replace=False, p=...) raises in the reference (cn_model.py:477), and so do both drivers
+            with pytest.raises(ValueError, match='Fewer non-zero entries in p than size'):
+                rs.fit(num_em_iter=2, num_update_iter=2)
+            continue
         rs.fit(num_em_iter=2, num_update_iter=2)
         runs.append(rs.results())
+    if not normal_contamination:
+        return
     for other in runs[1:]:
         for a, b in zip(runs[0], other):
             assert np.isclose(a['stats']['elbo'], b['stats']['elbo'], rtol=1e-6), (a['stats']['elbo'], b['stats']['elbo'])
