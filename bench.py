@@ -7,10 +7,21 @@ One "step" = ONE EM iteration (reference remixt/cn_model.py:409-418: 5
 variational sweeps + the h M-step + the likelihood-parameter M-steps + the ELBO)
 for EVERY restart resident on the GPU.  Workload at N=1 = BASELINE.json
 configs[2]: 50k segments, 3 clones (normal + 2 tumour), max_cn = 8 (165 states),
-16 (h, divergence-weight) restarts.  With N > 1 every rank fits its own 16
-restarts (weak scaling; restarts are independent, reference
-remixt/workflow.py:329-340) and the per-restart results are all-gathered once at
-the end over RCCL.
+16 (h, divergence-weight) restarts.
+
+`--gpus N` with N > 1 and no WORLD_SIZE in the environment starts N ranks itself
+(`python -m torch.distributed.run`, one process per GPU, RCCL) as a child process
+BEFORE anything touches the GPU and exits with the child's code; under the
+driver's own torchrun launch the ranks find WORLD_SIZE set and just run.
+
+Scaling modes (restarts are independent units, reference remixt/workflow.py:329-340;
+no collective during EM, ONE all-gather of the per-restart result records at the end):
+  default                 weak: every rank fits its own `--restarts` (16) restarts
+  --total-restarts T      strong: T restarts in total, restart i on rank i mod N
+                          (BASELINE configs[3]: T = 64 -> 8 per GPU at N = 8)
+  --datasets 2            BASELINE configs[4]: two tumour samples sharing segmentation and
+                          breakpoints, fitted independently (reference workflow.py:472-485),
+                          `--restarts` / `--total-restarts` split evenly between them
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline`
 (dominant kernel, HIP-event timed on the batch stream) and `cpu_baseline`.
@@ -18,6 +29,7 @@ Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline`
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -28,12 +40,16 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8.0 TB/s spec
 FP64_PEAK_TFLOPS = 78.6    # dense FP64 rate of MI355X (vector = matrix on gfx950): 256 CUs x 4 SIMDs x 16 FMA lanes x 2.4 GHz
-# algorithmic HBM bytes per (segment,state) cell per variational update, split by kernel
+# algorithmic HBM bytes per (segment,state) cell per variational update, split by kernel (this design's
+# own passes); SURVEY.md 8(d)'s model for the whole update is 88 B per cell
 ALG_BYTES_PER_CELL = {
     'k_framelogprob': 64.0,      # read the 6 cached likelihood components, write f and exp(f - rowmax)
     'k_fb': 32.0,                # read exp(f - rowmax) (fwd) + write alpha + read it again (bwd) + write beta
     'k_marginals<true>': 72.0,   # read alpha, beta and the 6 cached components, write the posterior
 }
+SURVEY_BYTES_PER_CELL = 88.0
+SWEEP_KERNELS = ('k_framelogprob', 'k_fb', 'k_marginals<true>', 'k_pairwise', 'k_brk_update', 'k_brk_lut',
+                 'k_update_outlier_total', 'k_update_outlier_allele', 'k_update_allele_swap')
 
 
 def alg_flops_per_cell(name, S):
@@ -42,7 +58,7 @@ def alg_flops_per_cell(name, S):
     return 4.0 * S if name == 'k_fb' else None
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=6)
@@ -50,119 +66,244 @@ def parse():
     ap.add_argument('--segments', type=int, default=50000)
     ap.add_argument('--clones', type=int, default=3)
     ap.add_argument('--max-cn', type=int, default=8)
-    ap.add_argument('--restarts', type=int, default=16, help='restarts per GPU')
+    ap.add_argument('--restarts', type=int, default=16, help='restarts per GPU (weak scaling, the default)')
+    ap.add_argument('--total-restarts', type=int, default=0, help='strong scaling: this many restarts in total, sharded over the GPUs (BASELINE configs[3]: 64)')
+    ap.add_argument('--datasets', type=int, default=1, help='2 = BASELINE configs[4]: two tumour samples on the same segmentation / breakpoints, fitted independently')
     ap.add_argument('--update-iters', type=int, default=5)
-    ap.add_argument('--groups', type=int, default=2, help='restart groups per GPU (own stream + host thread each; results do not depend on it)')
+    ap.add_argument('--groups', type=int, default=2, help='restart groups per GPU and dataset (own stream + host thread each; results do not depend on it)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--cpu-sample-segments', type=int, default=800)
+    ap.add_argument('--cpu-sample-segments', type=int, default=160)
     ap.add_argument('--profile-all', action='store_true', help='HIP-event every kernel (default: only the variational-sweep kernels; the M-step objective kernels are ~3000 tiny launches per step)')
     ap.add_argument('--no-extra-states', action='store_true', help='skip the additional 355-state (max_cn = 12) measurement at N = 1')
+    ap.add_argument('--no-fit-from-init', action='store_true', help='skip the construct -> 5 EM iterations -> decode wall-clock measurement at N = 1')
     ap.add_argument('--no-mstep', action='store_true', help='diagnostic only: variational sweeps without M-steps (NOT the reported metric)')
-    return ap.parse_args()
+    ap.add_argument('--master-port', type=int, default=0, help='rendezvous port when bench.py starts the ranks itself (0 = pick a free one)')
+    ap.add_argument('--cpu-leg', action='store_true', help=argparse.SUPPRESS)       # internal: the CPU baseline child process
+    return ap.parse_args(argv)
 
 
-def cpu_baseline(args, cores_note=1):
-    """Reference CPU path timed on this box's host cores on a bounded sample.
+# ---------------------------------------------------------------------------------------------------
+# launching N ranks
+# ---------------------------------------------------------------------------------------------------
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
 
-    One EM iteration of one restart on `cpu_sample_segments` segments with the same
-    state grid; every loop of the reference is linear in N, so the per-EM-iteration
-    time is scaled by N_full / N_sample.  kind = "reference" when the compiled
-    reference kernel (oracle/_ref, built from /root/reference/remixt/bpmodel.pyx)
-    travelled with the repo, else "port" (oracle/remixt_oracle.c)."""
+
+def spawn_ranks(args):
+    """`bench.py --gpus N` outside torchrun: start the N ranks as a CHILD process (never an exec of this one)
+    before torch is imported here, and return its exit code."""
+    port = args.master_port or _free_port()
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus),
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+    return subprocess.run(cmd, env=env).returncode
+
+
+# ---------------------------------------------------------------------------------------------------
+# CPU baseline: the C restatement (oracle/remixt_oracle.c, "port") on the box's host cores.  Runs in a
+# child process started before this process touches the GPU.
+# ---------------------------------------------------------------------------------------------------
+def _cpu_one(job):
+    """One EM iteration of one restart on the CPU restatement; returns the wall time split into the part that
+    grows with N (sweeps, full-data objectives, ELBO) and the sampled M-step objectives (constant in N once
+    N >= 2000: the reference's sample is min(200, N / 10) segments, cn_model.py:476)."""
+    ns, clones, max_cn, update_iters, restart = job
+    import types
+    from oracle import oracle
     from remixt_amd import synthetic
     from remixt_amd.cn_model import BreakpointModel
-    from oracle import refload
-    kind = 'port'
-    kern = None
-    if refload.have_ref_binary():
-        try:
-            kern = refload.load_ref_bpmodel(); kind = 'reference'
-        except Exception:
-            kern = None
-    if kern is None:
-        from oracle import oracle as kern
-        kern.build()
-    ns = args.cpu_sample_segments
-    e = synthetic.make_experiment(ns, num_clones=args.clones, max_copy_number=args.max_cn, num_chains=4, seed=123)
-    p = synthetic.make_init_params(e, 1, args.max_cn, num_clones=args.clones)[0]
-    m = BreakpointModel(e.x, e.l, e.adjacencies, e.breakpoints, max_copy_number=args.max_cn,
-                        divergence_weight=p['divergence_weight'], max_depth=p['max_depth'], kernel_module=kern, quiet=True)
-    m.num_update_iter = args.update_iters
-    m._attach_model(m._build_model(synthetic.h_init_from_params(p, args.clones)))
+    oracle.build()
+    acc = {'sample_s': 0.0, 'sample_size': 0}
+
+    class Timed(oracle.RemixtModel):
+        def _timed(self, fn, sample, *a):
+            part = int(np.count_nonzero(sample)) < self.num_segments
+            t0 = time.perf_counter()
+            out = fn(self, sample, *a)
+            if part:
+                acc['sample_s'] += time.perf_counter() - t0
+                acc['sample_size'] = int(np.count_nonzero(sample))
+            return out
+
+        def calculate_expected_log_likelihood(self, sample):
+            return self._timed(oracle.RemixtModel.calculate_expected_log_likelihood, sample)
+
+        def calculate_expected_log_likelihood_partial_h(self, sample, out):
+            return self._timed(oracle.RemixtModel.calculate_expected_log_likelihood_partial_h, sample, out)
+
+    kern = types.SimpleNamespace(RemixtModel=Timed)
+    e = synthetic.make_experiment(ns, num_clones=clones, max_copy_number=max_cn, num_chains=4, seed=123)
+    p = synthetic.make_init_params(e, restart + 1, max_cn, num_clones=clones)[restart]
+    m = BreakpointModel(e.x, e.l, e.adjacencies, e.breakpoints, max_copy_number=max_cn,
+                        divergence_weight=p['divergence_weight'], max_depth=p['max_depth'], kernel_module=kern, quiet=True,
+                        rng=np.random.RandomState(1000 + restart))
+    m.num_update_iter = update_iters
+    m._attach_model(m._build_model(synthetic.h_init_from_params(p, clones)))
     m.prev_elbo = m.model.calculate_elbo()
-    np.random.seed(0)
-    t0 = time.time()
-    m.em_iteration(0)
-    dt = time.time() - t0
-    scale = float(args.segments) / float(ns)
-    return {
-        'value': 1.0 / (dt * scale), 'unit': 'EM iterations/s', 'cores': 1, 'kind': kind,
-        'sample': 'one EM iteration of one restart on %d segments x %d states (%.1f s), scaled linearly to %d segments'
-                  % (ns, m.model.num_cn_states, dt, args.segments),
-    }
-
-
-def extra_states(args, rs_main, device):
-    """EM iterations/s at max_cn = 12 (355 states), everything else as the headline workload."""
-    import gc
-    import torch
-    from remixt_amd import synthetic
-    from remixt_amd.restarts import RestartGroups
-    for s_ in rs_main.sets:          # release the headline batches' device memory
-        s_.batch = None
-        for m in s_.models:
-            m.model = None
-    gc.collect()
-    max_cn, R = 12, args.restarts
-    e = synthetic.make_experiment(args.segments, num_clones=args.clones, max_copy_number=max_cn, num_chains=23, seed=0)
-    params = synthetic.make_init_params(e, R, max_cn, num_clones=args.clones)
-    # one group: at 355 states the forward-backward launch dominates and 4 restarts per workgroup beat the overlap of two groups
-    rs = RestartGroups(e, params, max_cn, groups=1, num_clones=args.clones, device=device, quiet=True, seeds=[1000 + i for i in range(R)])
-    S = rs.batches[0].num_cn_states
-    for m, v in zip(rs.models, rs.calculate_elbo()):
-        m.prev_elbo = float(v)
-    rs.run(1, 0, args.update_iters)
-    rs.synchronize(); torch.cuda.synchronize()
-    nsteps = 2
     t0 = time.perf_counter()
-    elbo = rs.run(nsteps, 1, args.update_iters)
-    rs.synchronize(); torch.cuda.synchronize()
+    try:
+        m.em_iteration(0)
+    except ValueError:          # an unsuccessful L-BFGS-B run ends the reference's restart; the time spent still counts
+        pass
     dt = time.perf_counter() - t0
-    return {'states': S, 'max_cn': max_cn, 'restart_groups': 1, 'value': R * nsteps / dt, 'unit': 'EM iterations/s', 'ms_per_step': dt / nsteps * 1e3, 'steps': nsteps,
-            'seg_state_cells_per_s': float(rs.batches[0].num_segments) * S * R * args.update_iters * nsteps / dt, 'elbo_best': float(np.max(elbo))}
+    return {'total_s': dt, 'sample_s': acc['sample_s'], 'sample_size': acc['sample_size'], 'N1': int(m.model.num_segments), 'S': int(m.model.num_cn_states)}
+
+
+def cpu_leg(args):
+    """Child process: (1) one restart on one core, (2) one restart per host core side by side (the reference's
+    own parallelism model: one process per init_id, workflow.py:329-340)."""
+    import multiprocessing as mp
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    cores = max(1, min(cores, 16))      # the GPU box's CPU share for one GPU
+    ns = args.cpu_sample_segments
+    job = (ns, args.clones, args.max_cn, args.update_iters)
+    one = _cpu_one(job + (0,))
+    scale = float(args.segments) / float(ns)
+    full_sample = min(200, args.segments // 10)
+
+    def full_time(r):
+        # linear part scaled by N_full / N_sample, sampled objectives by the ratio of the sample sizes
+        return (r['total_s'] - r['sample_s']) * scale + r['sample_s'] * (float(full_sample) / max(1, r['sample_size']))
+    t_one = full_time(one)
+    multi = None
+    if cores > 1:
+        ctx = mp.get_context('fork')
+        t0 = time.perf_counter()
+        with ctx.Pool(cores) as pool:
+            rs = pool.map(_cpu_one, [job + (i,) for i in range(cores)])
+        wall = time.perf_counter() - t0
+        # all cores busy for the slowest worker's time; throughput = restarts / scaled time of the slowest
+        multi = {'cores': cores, 'value': cores / max(full_time(r) for r in rs), 'wall_s': wall}
+    out = {'value': 1.0 / t_one, 'unit': 'EM iterations/s', 'cores': 1, 'kind': 'port',
+           'sample': 'one EM iteration of one restart of oracle/remixt_oracle.c on %d segments (%d after breakend remap) x %d states: %.2f s, of which %.2f s '
+                     'sampled M-step objectives (%d-segment samples); scaled to %d segments (linear part x %.0f, sampled part x %.1f)'
+                     % (ns, one['N1'], one['S'], one['total_s'], one['sample_s'], one['sample_size'], args.segments, scale,
+                        float(full_sample) / max(1, one['sample_size'])),
+           'seconds_per_em_iteration_full_size': t_one}
+    if multi:
+        out['all_cores'] = {'value': multi['value'], 'unit': 'EM iterations/s', 'cores': multi['cores'],
+                            'sample': 'the same sample, one restart per core on %d cores at once (%.1f s wall)' % (multi['cores'], multi['wall_s'])}
+    print('CPU_LEG ' + json.dumps(out), flush=True)
+
+
+def cpu_baseline(args):
+    """Run the CPU leg as a child process (no GPU in it) and attach the port-vs-reference calibration measured in
+    the build container by oracle/calibrate.py (the reference itself never travels to the GPU box)."""
+    cmd = [sys.executable, os.path.abspath(__file__), '--cpu-leg', '--segments', str(args.segments), '--clones', str(args.clones),
+           '--max-cn', str(args.max_cn), '--update-iters', str(args.update_iters), '--cpu-sample-segments', str(args.cpu_sample_segments)]
+    env = dict(os.environ, OMP_NUM_THREADS='1', OPENBLAS_NUM_THREADS='1', MKL_NUM_THREADS='1')
+    try:
+        res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+        line = [l for l in res.stdout.splitlines() if l.startswith('CPU_LEG ')]
+        if not line:
+            return {'error': 'cpu leg failed: ' + (res.stderr or res.stdout)[-400:]}
+        out = json.loads(line[-1][len('CPU_LEG '):])
+    except Exception as err:
+        return {'error': 'cpu leg failed: %s' % err}
+    try:
+        cal = json.load(open(os.path.join(ROOT, 'profiles', 'cpu_calibration.json')))
+        out['calibration'] = {'port_seconds_over_reference_seconds': cal['port_over_reference'], 'where': cal['where'],
+                              'note': 'compiled reference kernel (remixt/bpmodel.pyx) vs this port on the same sample in the build container; '
+                                      'reference-equivalent value = value x this ratio'}
+        out['reference_equivalent_value'] = out['value'] * cal['port_over_reference']
+    except Exception:
+        out['calibration'] = None
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------
+def build_datasets(args):
+    """The experiment(s) of the run: dataset 0 is the headline synthetic experiment; with --datasets 2 the second
+    tumour sample has the same segments, adjacencies and breakpoints and its own read counts (another seed's
+    counts on dataset 0's segmentation), SURVEY.md 8(d)."""
+    from remixt_amd import synthetic
+    e0 = synthetic.make_experiment(args.segments, num_clones=args.clones, max_copy_number=args.max_cn, num_chains=23, seed=0)
+    out = [e0]
+    for d in range(1, args.datasets):
+        out.append(synthetic.resample_counts(e0, seed=100 + d))
+    return out
 
 
 def main():
     args = parse()
-    import torch
-    import torch.distributed as dist
-    world = int(os.environ.get('WORLD_SIZE', '1'))
+    if args.cpu_leg:
+        return cpu_leg(args)
+    env_world = os.environ.get('WORLD_SIZE')
+    if env_world is None and args.gpus > 1:
+        sys.exit(spawn_ranks(args))
+    world = int(env_world or '1')
+    if world != args.gpus:
+        raise SystemExit('bench.py: --gpus %d but WORLD_SIZE=%d: launch with --nproc-per-node equal to --gpus' % (args.gpus, world))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+
+    # the CPU leg runs first, in a child process, before this process initialises the GPU
+    cpu = None
+    if world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(args)
+
+    import torch
+    import torch.distributed as dist
+    backend = None
     if world > 1:
-        # RCCL over xGMI; BENCH_DIST_BACKEND=gloo rehearses the multi-rank control flow where ranks share a GPU
+        # RCCL over xGMI; BENCH_DIST_BACKEND=gloo rehearses the multi-rank control flow where ranks share a GPU (or have none)
         backend = os.environ.get('BENCH_DIST_BACKEND', 'nccl')
         if backend != 'nccl':
             local_rank = local_rank % max(1, torch.cuda.device_count())
-        torch.cuda.set_device(local_rank)
+        if torch.cuda.is_available():
+            torch.cuda.set_device(local_rank)
         if backend == 'nccl':
             dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
         else:
             dist.init_process_group(backend)
     device = local_rank if world > 1 else 0
-    torch.cuda.set_device(device)
+    kernel_module = None
+    if os.environ.get('BENCH_KERNEL') == 'oracle':      # CPU rehearsal of the launch / shard / gather logic (tests only; never a reported number)
+        from oracle import oracle as kernel_module
+    else:
+        torch.cuda.set_device(device)
 
     from remixt_amd import synthetic
-    from remixt_amd.restarts import RestartGroups, _pack
+    from remixt_amd.restarts import RestartGroups, DatasetGroups, _pack
 
-    R = args.restarts
-    e = synthetic.make_experiment(args.segments, num_clones=args.clones, max_copy_number=args.max_cn, num_chains=23, seed=0)
-    all_params = synthetic.make_init_params(e, R * world, args.max_cn, num_clones=args.clones)
-    mine = all_params[rank::world]
-    rs = RestartGroups(e, mine, args.max_cn, groups=args.groups, num_clones=args.clones, device=device, quiet=True,
-                       seeds=[1000 + rank + world * i for i in range(R)])
-    b = rs.batches[0]
-    N1, S = b.num_segments, b.num_cn_states
+    # ---- which restarts does this rank fit -----------------------------------------------------------
+    strong = args.total_restarts > 0
+    total = args.total_restarts if strong else args.restarts * world
+    ND = max(1, args.datasets)
+    datasets = build_datasets(args)
+    per_ds = total // ND
+    units = []                                                  # (dataset, restart id within the dataset), in global order
+    for dsi in range(ND):
+        units.extend((dsi, i) for i in range(per_ds))
+    mine = units[rank::world]
+    all_params = [synthetic.make_init_params(datasets[dsi], per_ds, args.max_cn, num_clones=args.clones) for dsi in range(ND)]
+    sets = []
+    for dsi in range(ND):
+        ids = [i for (d_, i) in mine if d_ == dsi]
+        if ids:
+            sets.append((datasets[dsi], [all_params[dsi][i] for i in ids], [1000 + 7919 * dsi + i for i in ids]))
+    R = len(mine)
+    if R == 0:
+        raise SystemExit('bench.py: rank %d has no restart (total %d over %d ranks)' % (rank, total, world))
+    if len(sets) == 1:
+        e, params, seeds = sets[0]
+        rs = RestartGroups(e, params, args.max_cn, groups=args.groups, num_clones=args.clones, device=device, quiet=True, seeds=seeds,
+                           kernel_module=kernel_module)
+    else:
+        rs = DatasetGroups([s[0] for s in sets], [s[1] for s in sets], args.max_cn, groups=args.groups, num_clones=args.clones, device=device,
+                           quiet=True, seeds=[s[2] for s in sets], kernel_module=kernel_module)
+    e = sets[0][0]
+    on_gpu = kernel_module is None
+    m0 = rs.models[0]
+    N1, S = int(m0.model.num_segments), int(m0.model.num_cn_states)
     elbo0 = rs.calculate_elbo()
     for m, v in zip(rs.models, elbo0):
         m.prev_elbo = float(v)
@@ -180,34 +321,56 @@ def main():
 
     def fence():
         rs.synchronize()
-        torch.cuda.synchronize()
+        if on_gpu:
+            torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
-            torch.cuda.synchronize()
+            if on_gpu:
+                torch.cuda.synchronize()
 
-    for b_ in rs.batches:
-        b_.profile_reset(); b_.profile_enable(1 if args.profile_all else 2)
+    if on_gpu:
+        for b_ in rs.batches:
+            b_.profile_reset(); b_.profile_enable(1 if args.profile_all else 2)
     fence()
     t0 = time.perf_counter()
     elbo = steps(args.warmup, args.steps)
     fence()
     dt = time.perf_counter() - t0
-    for b_ in rs.batches:
-        b_.profile_enable(0)
-    prof = rs.profile()
+    prof = {}
+    if on_gpu:
+        for b_ in rs.batches:
+            b_.profile_enable(0)
+        prof = rs.profile()
+    observed_world = 1
+    gathered = None
     if world > 1:
+        observed_world = dist.get_world_size()
         cdev = 'cuda' if dist.get_backend() == 'nccl' else 'cpu'
         tt = torch.tensor([dt], dtype=torch.float64, device=cdev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
+        cnt = torch.tensor([float(R)], dtype=torch.float64, device=cdev)
+        dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
+        total_fitted = int(round(float(cnt.item())))
         # final gather of the per-restart results (outside the timed region: it happens once per fit)
         res = rs.results()
         names = list(rs.models[0].likelihood_params)
         ids = list(e.breakpoints.keys())
         packs = [_pack(r_, len(e.x), args.clones, len(ids), len(names), ids, names) for r_ in res]
-        ft = torch.from_numpy(np.stack([p_[0] for p_ in packs])).to(cdev)
+        per_rank = (total + world - 1) // world
+        fbuf = np.full((per_rank, len(packs[0][0])), np.nan)
+        for j, p_ in enumerate(packs):
+            fbuf[j] = p_[0]
+        ft = torch.from_numpy(fbuf).to(cdev)
         out = [torch.empty_like(ft) for _ in range(world)]
+        tg0 = time.perf_counter()
         dist.all_gather(out, ft)
+        if cdev == 'cuda':
+            torch.cuda.synchronize()
+        gathered = {'records': int(sum(int(np.isfinite(o.cpu().numpy()[:, 0]).sum()) for o in out)), 'bytes_per_rank': int(fbuf.nbytes),
+                    'seconds': time.perf_counter() - tg0}
+    else:
+        total_fitted = R
 
     if rank == 0:
         total_ms = sum(v[0] for v in prof.values())
@@ -217,37 +380,9 @@ def main():
         hot = [(k, prof[k]) for k in ALG_BYTES_PER_CELL if k in prof]
         dom = max(hot, key=lambda kv: kv[1][0]) if hot else (None, (0., 0))
         cells_total = float(N1) * S * R
-        cells_per_launch = cells_total / len(rs.sets)     # every group launches over its own restarts
-        roof = None
-        if dom[0] is not None:
-            name, (ms, n) = dom
-            avg_ms = ms / max(n, 1)
-            alg = ALG_BYTES_PER_CELL.get(name)
-            hbm_gbs = alg * cells_per_launch / (avg_ms * 1e-3) / 1e9
-            traffic = None
-            try:   # PMC traffic of the same kernel on the same launch shape, measured offline (profiles/)
-                tj = json.load(open(os.path.join(ROOT, 'profiles', 'traffic_r01.json')))
-                w = tj['workload']
-                if (w['segments'], w['states'], w['restarts']) == (args.segments, S, R // len(rs.sets)):
-                    traffic = tj['kernels'][name]['hbm_bytes_per_launch']
-            except Exception:
-                traffic = None
-            fl = alg_flops_per_cell(name, S)
-            if fl is not None:
-                # the forward-backward recursion: S^2 FP64 FMAs per segment, direction and restart on vector
-                # v_fmac_f64 (no MFMA: matrix x vector with a sequential dependency between segments)
-                achieved = fl * cells_per_launch / (avg_ms * 1e-3) / 1e12
-                roof = {'bound': 'mfma', 'kernel': name, 'achieved': achieved, 'peak': FP64_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                        'frac': achieved / FP64_PEAK_TFLOPS, 'traffic': traffic, 'avg_launch_ms': avg_ms, 'launches': n,
-                        'alg_flops_per_launch': fl * cells_per_launch, 'alg_bytes_per_launch': alg * cells_per_launch,
-                        'hbm_gbs_at_alg_bytes': hbm_gbs,
-                        'note': 'FP64 vector FMA bound (v_fmac_f64 with DPP row broadcast), peak = dense FP64 rate; '
-                                'restart groups launch concurrently on separate streams, so avg_launch_ms includes time shared with the other group\'s kernels'}
-            else:
-                roof = {'bound': 'hbm', 'kernel': name, 'achieved': hbm_gbs, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                        'frac': hbm_gbs / HBM_PEAK_GBS, 'traffic': traffic, 'avg_launch_ms': avg_ms, 'launches': n,
-                        'alg_bytes_per_launch': alg * cells_per_launch}
-        # the HBM-streaming passes of the sweep, same construction (algorithmic bytes / HIP-event launch time)
+        nbatches = max(1, len(rs.batches)) if on_gpu else 1
+        cells_per_launch = cells_total / nbatches        # every group launches over its own restarts
+        roof = roofline_object(dom, cells_per_launch, S, args, R // nbatches)
         others = []
         for name in ('k_framelogprob', 'k_marginals<true>'):
             if name in prof and prof[name][1]:
@@ -255,41 +390,165 @@ def main():
                 gbs = ALG_BYTES_PER_CELL[name] * cells_per_launch / (avg * 1e-3) / 1e9
                 others.append({'kernel': name, 'bound': 'hbm', 'achieved': gbs, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': gbs / HBM_PEAK_GBS,
                                'avg_launch_ms': avg, 'launches': prof[name][1]})
-        # whole variational update (all kernels of one sweep) against the 88 B/cell model
-        upd = sum(prof.get(k, (0., 0))[0] for k in ('k_framelogprob', 'k_fb', 'k_marginals<true>', 'k_pairwise', 'k_brk_update',
-                                                       'k_brk_lut', 'k_update_outlier_total', 'k_update_outlier_allele', 'k_update_allele_swap'))
+        upd = sum(prof.get(k, (0., 0))[0] for k in SWEEP_KERNELS)
         nupd = prof.get('k_fb', (0., 1))[1]
         sweep_ms = upd / max(nupd, 1)
+
+        def hbm_frac(bytes_per_cell):
+            return (bytes_per_cell * cells_per_launch / (sweep_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if sweep_ms else None
+        if ND > 1:
+            wl = ('BASELINE configs[4]: %d tumour samples on one segmentation (%d segments, %d after breakend remap) and breakpoint set, fitted independently, '
+                  '%d clones, max_cn=%d (%d states), %d restarts in total' % (ND, args.segments, N1, args.clones, args.max_cn, S, total))
+        elif strong:
+            wl = ('BASELINE configs[3]: %d segments (%d after breakend remap), %d clones, max_cn=%d (%d states), %d restarts in total sharded over %d GPU(s)'
+                  % (args.segments, N1, args.clones, args.max_cn, S, total, world))
+        else:
+            wl = ('BASELINE configs[2]: %d segments (%d after breakend remap), %d clones, max_cn=%d (%d states), %d restarts/GPU'
+                  % (args.segments, N1, args.clones, args.max_cn, S, args.restarts))
+        wl += ', %d variational sweeps + M-steps per EM iteration' % args.update_iters
         line = {
-            'metric': 'EM iterations/sec (%dk seg x %d states x %d restarts/GPU)' % (args.segments // 1000, S, R),
-            'value': (R * world * args.steps) / dt, 'unit': 'EM iterations/s', 'n_gpus': world, 'steps': args.steps,
-            'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak',
+            'metric': 'EM iterations/sec (%dk seg x %d states)' % (args.segments // 1000, S),
+            'value': (total_fitted * args.steps) / dt, 'unit': 'EM iterations/s', 'n_gpus': world, 'steps': args.steps,
+            'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'strong' if strong else 'weak',
             'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
-            'config': {'workload': 'BASELINE configs[2]: %d segments (%d after breakend remap), %d clones, max_cn=%d (%d states), %d restarts/GPU, %d variational sweeps + M-steps per EM iteration'
-                                   % (args.segments, N1, args.clones, args.max_cn, S, R, args.update_iters),
-                       'segments': args.segments, 'states': S, 'restarts_per_gpu': R, 'restart_groups': len(rs.sets), 'mstep': not args.no_mstep},
-            'seg_state_cells_per_s': cells_total * world * args.update_iters * args.steps / dt,
+            'config': {'workload': wl, 'segments': args.segments, 'states': S, 'restarts_total': total_fitted, 'restarts_this_rank': R,
+                       'datasets': ND, 'restart_groups': nbatches, 'mstep': not args.no_mstep,
+                       'world_size_observed': observed_world, 'backend': backend},
+            'seg_state_cells_per_s': float(N1) * S * total_fitted * args.update_iters * args.steps / dt,
             'roofline': roof,
             'roofline_other': others,
             'variational_sweep': {'device_ms_per_sweep_all_restarts': sweep_ms,
-                                  'hbm_frac_168B_per_cell': (168.0 * cells_per_launch / (sweep_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if sweep_ms else None},
+                                  'hbm_frac_88B_per_cell_survey_model': hbm_frac(SURVEY_BYTES_PER_CELL),
+                                  'hbm_frac_168B_per_cell_this_design': hbm_frac(168.0)},
             'device_ms_total': total_ms,
             'kernels': dict((k, {'ms': round(v[0], 3), 'n': v[1]}) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])),
-            'elbo_best': float(np.max(elbo)),
+            'elbo_best': float(np.nanmax(elbo)),
         }
-        if world == 1 and not args.no_extra_states and args.max_cn == 8 and not args.no_mstep:
+        if gathered:
+            line['final_gather'] = gathered
+        single = world == 1 and on_gpu and ND == 1 and not strong and not args.no_mstep
+        if single and not args.no_fit_from_init:
+            try:
+                line['fit_from_init'] = fit_from_init(args, rs, device)
+            except Exception as err:
+                line['fit_from_init'] = {'error': str(err)}
+        if single and not args.no_extra_states and args.max_cn == 8:
             # "also report S = 355 at max_cn = 12" (the reference's default max_copy_number):
             # same segments / restarts / step definition, reported next to the headline configuration
             try:
                 line['states_355'] = extra_states(args, rs, device)
             except Exception as err:      # never let the extra measurement hide the headline number
                 line['states_355'] = {'error': str(err)}
-        if not args.no_cpu_baseline and world == 1:      # reported baseline, rank 0 at N = 1 only
-            line['cpu_baseline'] = cpu_baseline(args)
-        print(json.dumps(line))
+        if cpu is not None:
+            line['cpu_baseline'] = cpu
+        print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def roofline_object(dom, cells_per_launch, S, args, restarts_per_launch, traffic_file='traffic_r02.json'):
+    if dom[0] is None:
+        return None
+    name, (ms, n) = dom
+    avg_ms = ms / max(n, 1)
+    alg = ALG_BYTES_PER_CELL.get(name)
+    hbm_gbs = alg * cells_per_launch / (avg_ms * 1e-3) / 1e9
+    traffic = None
+    for tf in (traffic_file, 'traffic_r01.json'):
+        try:   # PMC traffic of the same kernel on the same launch shape, measured offline (profiles/)
+            tj = json.load(open(os.path.join(ROOT, 'profiles', tf)))
+            w = tj['workload']
+            if (w['segments'], w['states'], w['restarts']) == (args.segments, S, restarts_per_launch):
+                traffic = tj['kernels'][name]['hbm_bytes_per_launch']
+                break
+        except Exception:
+            continue
+    fl = alg_flops_per_cell(name, S)
+    if fl is not None:
+        # the forward-backward recursion: S^2 FP64 FMAs per segment, direction and restart
+        achieved = fl * cells_per_launch / (avg_ms * 1e-3) / 1e12
+        return {'bound': 'fp64', 'kernel': name, 'achieved': achieved, 'peak': FP64_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                'frac': achieved / FP64_PEAK_TFLOPS, 'traffic': traffic, 'avg_launch_ms': avg_ms, 'launches': n,
+                'alg_flops_per_launch': fl * cells_per_launch, 'alg_bytes_per_launch': alg * cells_per_launch,
+                'hbm_gbs_at_alg_bytes': hbm_gbs, 'hbm_frac_at_alg_bytes': hbm_gbs / HBM_PEAK_GBS,
+                'note': 'FP64 FMA bound (the contract\'s "mfma" class: peak = dense FP64 rate, the same for vector and matrix FP64 on gfx950); '
+                        'restart groups launch concurrently on separate streams, so avg_launch_ms includes time shared with the other group\'s kernels'}
+    return {'bound': 'hbm', 'kernel': name, 'achieved': hbm_gbs, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+            'frac': hbm_gbs / HBM_PEAK_GBS, 'traffic': traffic, 'avg_launch_ms': avg_ms, 'launches': n,
+            'alg_bytes_per_launch': alg * cells_per_launch}
+
+
+def _release(rs_main):
+    import gc
+    for s_ in rs_main.sets:          # release the headline batches' device memory
+        s_.batch = None
+        for m in s_.models:
+            m.model = None
+    gc.collect()
+
+
+def fit_from_init(args, rs_main, device):
+    """A real fit, wall clock: construct the models (remap, uploads), 5 EM iterations FROM THE INITIALISATION
+    (reference defaults.py:154), Viterbi decode and result records, for the GPU's 16 restarts."""
+    import torch
+    from remixt_amd import synthetic
+    from remixt_amd.restarts import RestartGroups
+    _release(rs_main)
+    R = args.restarts
+    e = synthetic.make_experiment(args.segments, num_clones=args.clones, max_copy_number=args.max_cn, num_chains=23, seed=0)
+    params = synthetic.make_init_params(e, R, args.max_cn, num_clones=args.clones)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    rs = RestartGroups(e, params, args.max_cn, groups=args.groups, num_clones=args.clones, device=device, quiet=True, seeds=[1000 + i for i in range(R)])
+    rs.synchronize()
+    t1 = time.perf_counter()
+    elbo = rs.fit(5, args.update_iters)
+    rs.synchronize()
+    t2 = time.perf_counter()
+    res = rs.results()
+    t3 = time.perf_counter()
+    out = {'restarts': R, 'em_iterations': 5, 'construct_s': t1 - t0, 'em_s': t2 - t1, 'decode_and_results_s': t3 - t2, 'total_s': t3 - t0,
+           'em_iterations_per_s_from_init': R * 5 / (t2 - t1), 'em_iterations_per_s_whole_fit': R * 5 / (t3 - t0),
+           'elbo_best': float(np.nanmax(elbo)), 'failed_restarts': int(sum(1 for r in res if r['stats'].get('error_message')))}
+    _release(rs)
+    return out
+
+
+def extra_states(args, rs_main, device):
+    """EM iterations/s at max_cn = 12 (355 states), everything else as the headline workload."""
+    import torch
+    from remixt_amd import synthetic
+    from remixt_amd.restarts import RestartGroups
+    _release(rs_main)
+    max_cn, R = 12, args.restarts
+    e = synthetic.make_experiment(args.segments, num_clones=args.clones, max_copy_number=max_cn, num_chains=23, seed=0)
+    params = synthetic.make_init_params(e, R, max_cn, num_clones=args.clones)
+    # one group: at 355 states the forward-backward launch dominates and 4 restarts per workgroup beat the overlap of two groups
+    rs = RestartGroups(e, params, max_cn, groups=1, num_clones=args.clones, device=device, quiet=True, seeds=[1000 + i for i in range(R)])
+    b = rs.batches[0]
+    S, N1 = b.num_cn_states, b.num_segments
+    for m, v in zip(rs.models, rs.calculate_elbo()):
+        m.prev_elbo = float(v)
+    rs.run(1, 0, args.update_iters)
+    rs.synchronize(); torch.cuda.synchronize()
+    nsteps = 6
+    b.profile_reset(); b.profile_enable(2)
+    t0 = time.perf_counter()
+    elbo = rs.run(nsteps, 1, args.update_iters)
+    rs.synchronize(); torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    b.profile_enable(0)
+    prof = rs.profile()
+    hot = [(k, prof[k]) for k in ALG_BYTES_PER_CELL if k in prof]
+    dom = max(hot, key=lambda kv: kv[1][0]) if hot else (None, (0., 0))
+    a355 = argparse.Namespace(**vars(args)); a355.max_cn = max_cn
+    out = {'states': S, 'max_cn': max_cn, 'restart_groups': 1, 'value': R * nsteps / dt, 'unit': 'EM iterations/s', 'ms_per_step': dt / nsteps * 1e3, 'steps': nsteps,
+           'seg_state_cells_per_s': float(N1) * S * R * args.update_iters * nsteps / dt, 'elbo_best': float(np.nanmax(elbo)),
+           'roofline': roofline_object(dom, float(N1) * S * R, S, a355, R, traffic_file='traffic_r02_s355.json'),
+           'kernels': dict((k, {'ms': round(v[0], 3), 'n': v[1]}) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0]))}
+    _release(rs)
+    return out
 
 
 if __name__ == '__main__':

@@ -213,6 +213,13 @@ def store_fit_results(store, experiment, fit_results, key_prefix):
 def store_optimal_solution(stats, store, config):
     """analysis/pipeline.py:253-264: best ELBO among the solutions under max_prop_diverge."""
     max_prop_diverge = defaults.get_param(config, 'max_prop_diverge')
+    # a restart whose h M-step failed ends the reference's whole workflow (cn_model.py:510-521 raises inside its
+    # job); the batched driver records the failure instead, and such a restart is never the optimal solution
+    if 'error_message' in stats.columns:
+        failed = stats['error_message'].fillna('').astype(str) != ''
+        if failed.all():
+            raise ValueError('every restart failed: ' + '; '.join(sorted(set(stats['error_message'].astype(str)))))
+        stats = stats[~failed]
     if (stats['proportion_divergent'] < max_prop_diverge).any():
         stats = stats[stats['proportion_divergent'] < max_prop_diverge].copy()
     stats = stats.sort_values('elbo', ascending=False)

@@ -516,7 +516,79 @@ class RestartGroups(object):
         """{kernel: (ms, launches)} summed over the groups' batches."""
         out = {}
         for rs in self.sets:
+            if rs.batch is None:
+                continue
             for k, (ms, n) in rs.batch.profile().items():
+                a = out.get(k, (0., 0))
+                out[k] = (a[0] + ms, a[1] + n)
+        return out
+
+
+class DatasetGroups(object):
+    """Several datasets resident on one GPU at once (BASELINE configs[4]: the tumour samples of one patient share
+    the segmentation and the breakpoints and are fitted independently, reference remixt/workflow.py:472-485): one
+    RestartGroups per dataset, all free-running on their own host threads and HIP streams.  Nothing is shared
+    between datasets on the device, so every dataset's results equal its single-dataset fit bit for bit."""
+
+    def __init__(self, experiments, init_params, max_copy_number, groups=2, seeds=None, **kwargs):
+        if len(experiments) != len(init_params):
+            raise ValueError('one list of restarts per dataset')
+        self.parts = [RestartGroups(e, p, max_copy_number, groups=groups, seeds=(seeds[i] if seeds is not None else None), **kwargs)
+                      for i, (e, p) in enumerate(zip(experiments, init_params))]
+        self.sets = [rs for part in self.parts for rs in part.sets]
+        self.models = [m for part in self.parts for m in part.models]
+        self.init_params = [p for part in self.parts for p in part.init_params]
+        self.experiments = list(experiments)
+        self._pool = None
+
+    @property
+    def num_restarts(self):
+        return len(self.models)
+
+    @property
+    def batches(self):
+        return [rs.batch for rs in self.sets]
+
+    def _map(self, fn):
+        if len(self.parts) == 1:
+            return [fn(self.parts[0])]
+        if self._pool is None:
+            from concurrent.futures import ThreadPoolExecutor
+            self._pool = ThreadPoolExecutor(max_workers=len(self.parts))
+        return list(self._pool.map(fn, self.parts))
+
+    def calculate_elbo(self):
+        return np.concatenate(self._map(lambda part: part.calculate_elbo()))
+
+    def variational_update(self, iters=1):
+        self._map(lambda part: part.variational_update(iters))
+
+    def fit(self, num_em_iter=5, num_update_iter=5):
+        return np.concatenate(self._map(lambda part: part.fit(num_em_iter, num_update_iter)))
+
+    def run(self, num_em_iter, start=0, num_update_iter=5):
+        return np.concatenate(self._map(lambda part: part.run(num_em_iter, start, num_update_iter)))
+
+    def synchronize(self):
+        for part in self.parts:
+            part.synchronize()
+
+    def results(self):
+        """Per-restart result dicts, dataset after dataset (each with 'dataset' = its index)."""
+        out = []
+        for i, part in enumerate(self._map(lambda part: part.results())):
+            for r in part:
+                r['dataset'] = i
+                out.append(r)
+        return out
+
+    def results_by_dataset(self):
+        return self._map(lambda part: part.results())
+
+    def profile(self):
+        out = {}
+        for part in self.parts:
+            for k, (ms, n) in part.profile().items():
                 a = out.get(k, (0., 0))
                 out[k] = (a[0] + ms, a[1] + n)
         return out
@@ -563,15 +635,30 @@ def shard_indices(num_items, world_size, rank):
     return list(range(rank, num_items, world_size))
 
 
+_HDR = 5      # elbo, elbo_diff, ploidy, proportion_divergent, failure code
+_FAILURE_TEXT = {1: 'optimization failed (h kept)', 2: 'gradiant error (h kept)', 3: 'restart failed'}
+
+
+def _failure_code(message):
+    """A restart's error message as a number for the fixed-size float record (0 = none)."""
+    if not message:
+        return 0
+    for code, text in _FAILURE_TEXT.items():
+        if message.startswith(text.split(' (')[0]):
+            return code
+    return 3
+
+
 def _pack(res, N, M, K, nparams, brk_ids, param_names):
     """One restart's results as (float64 vector, int8 vector) of fixed length."""
-    f = np.zeros(4 + M + nparams + 4 * N, dtype=np.float64)
+    f = np.zeros(_HDR + M + nparams + 4 * N, dtype=np.float64)
     st = res['stats']
     f[0] = st['elbo']; f[1] = st['elbo_diff'] if st['elbo_diff'] is not None else np.nan
     f[2] = st['ploidy']; f[3] = st['proportion_divergent']
-    f[4:4 + M] = res['h']
-    f[4 + M:4 + M + nparams] = [st[k] for k in param_names]
-    o = 4 + M + nparams
+    f[4] = float(_failure_code(st.get('error_message', '')))
+    f[_HDR:_HDR + M] = res['h']
+    f[_HDR + M:_HDR + M + nparams] = [st[k] for k in param_names]
+    o = _HDR + M + nparams
     f[o:o + 2 * N] = res['p_outlier_total'].ravel(); f[o + 2 * N:o + 4 * N] = res['p_outlier_allele'].ravel()
     i8 = np.zeros(N * M * 2 + K * M + 2 * N, dtype=np.int8)
     i8[:N * M * 2] = res['cn'].ravel()
@@ -583,8 +670,8 @@ def _pack(res, N, M, K, nparams, brk_ids, param_names):
 
 def _unpack(f, i8, N, M, K, nparams, brk_ids, param_names, init_params):
     res = dict()
-    res['h'] = f[4:4 + M].copy()
-    o = 4 + M + nparams
+    res['h'] = f[_HDR:_HDR + M].copy()
+    o = _HDR + M + nparams
     res['p_outlier_total'] = f[o:o + 2 * N].reshape(N, 2).copy()
     res['p_outlier_allele'] = f[o + 2 * N:o + 4 * N].reshape(N, 2).copy()
     res['cn'] = i8[:N * M * 2].astype(np.int64).reshape(N, M, 2)
@@ -592,11 +679,12 @@ def _unpack(f, i8, N, M, K, nparams, brk_ids, param_names, init_params):
     res['brk_cn'] = dict((k, bc[i]) for i, k in enumerate(brk_ids))
     res['total_likelihood_mask'] = i8[N * M * 2 + K * M:N * M * 2 + K * M + N].astype(np.int64)
     res['allele_likelihood_mask'] = i8[N * M * 2 + K * M + N:].astype(np.int64)
+    code = int(f[4]) if np.isfinite(f[4]) else 3
     st = {'elbo': float(f[0]), 'elbo_diff': float(f[1]), 'ploidy': float(f[2]), 'proportion_divergent': float(f[3]),
-          'error_message': '', 'num_clones': M, 'num_segments': N, 'mode_idx': init_params.get('mode_idx', 0),
-          'divergence_weight': init_params['divergence_weight']}
+          'error_message': _FAILURE_TEXT.get(code, '') if code else '', 'num_clones': M, 'num_segments': N,
+          'mode_idx': init_params.get('mode_idx', 0), 'divergence_weight': init_params['divergence_weight']}
     for j, k in enumerate(param_names):
-        st[k] = float(f[4 + M + j])
+        st[k] = float(f[_HDR + M + j])
     res['stats'] = st
     return res
 
@@ -636,7 +724,7 @@ def fit_restarts_distributed(experiment, init_params, max_copy_number, num_clone
             [] if nc else ['negbin_hdel_mu', 'negbin_hdel_r_0', 'negbin_hdel_r_1', 'betabin_loh_p', 'betabin_loh_M_0', 'betabin_loh_M_1'])
     nparams = len(param_names)
     per_rank = (len(init_params) + world - 1) // world
-    flen = 4 + M + nparams + 4 * N
+    flen = _HDR + M + nparams + 4 * N
     ilen = N * M * 2 + K * M + 2 * N
     fbuf = np.full((per_rank, flen), np.nan); ibuf = np.zeros((per_rank, ilen), dtype=np.int8)
     for j, res in enumerate(local):
@@ -660,10 +748,19 @@ def fit_restarts_distributed(experiment, init_params, max_copy_number, num_clone
 
 def select_optimal(results, max_prop_diverge=0.5):
     """store_optimal_solution (analysis/pipeline.py:253-264): best ELBO among solutions
-    with proportion_divergent < max_prop_diverge (all solutions if none qualifies)."""
+    with proportion_divergent < max_prop_diverge (all solutions if none qualifies).
+
+    In the reference a restart whose h M-step fails raises (cn_model.py:510-521) and takes the whole
+    workflow down; here such a restart is recorded (stats['error_message']) and can never be selected.
+    A NaN ELBO sorts last, as in pandas' sort_values(ascending=False)."""
     ids = sorted(results)
-    ok = [i for i in ids if results[i]['stats']['proportion_divergent'] < max_prop_diverge]
-    pool = ok if ok else ids
+    alive = [i for i in ids if not results[i]['stats'].get('error_message')]
+    if not alive:
+        raise ValueError('every restart failed: ' + '; '.join(sorted(set(results[i]['stats']['error_message'] for i in ids))))
+    ok = [i for i in alive if results[i]['stats']['proportion_divergent'] < max_prop_diverge]
+    pool = ok if ok else alive
+    finite = [i for i in pool if np.isfinite(results[i]['stats']['elbo'])]
+    pool = finite if finite else pool
     # pandas sort_values(ascending=False) is a stable sort on -elbo: first maximum wins
     best = max(pool, key=lambda i: (results[i]['stats']['elbo'], -i))
     return best

@@ -136,6 +136,34 @@ def make_experiment(num_segments, num_clones=3, max_copy_number=8, num_chains=23
     return SyntheticExperiment(x, l, adjacencies, breakpoints, chrom, h, cn)
 
 
+def resample_counts(experiment, seed, h=None):
+    """A second tumour sample of the same patient: the segmentation, reference adjacencies, breakpoints and
+    clone genomes of `experiment`, its own clone mixture `h` (default: the tumour clones' shares exchanged)
+    and its own read counts, drawn like make_experiment's.  The reference fits the samples of a patient
+    independently on one segmentation (remixt/workflow.py:472-485)."""
+    rng = np.random.default_rng(seed)
+    l, cn = np.asarray(experiment.l), np.asarray(experiment.cn)
+    N = len(l)
+    if h is None:
+        h = np.asarray(experiment.h, dtype=float).copy()
+        if len(h) > 2:
+            h[1:] = h[1:][::-1]
+    tot = cn.sum(axis=2)
+    mu = l * (tot * h[None, :]).sum(axis=1) + 1e-16
+    r = np.where(rng.random(N) < 0.01, 10., 1000.)
+    x_total = rng.negative_binomial(r, r / (r + mu)).astype(float)
+    phi = rng.uniform(0.05, 0.2, size=N)
+    n_allele = np.floor(phi * x_total)
+    depth0 = (cn[:, :, 0] * h[None, :]).sum(axis=1)
+    p_true = np.clip(depth0 / np.maximum((tot * h[None, :]).sum(axis=1), 1e-12), 1e-3, 1 - 1e-3)
+    Mdisp = np.where(rng.random(N) < 0.01, 10., 2000.)
+    pb = rng.beta(Mdisp * p_true, Mdisp * (1 - p_true))
+    a0 = rng.binomial(n_allele.astype(np.int64), pb).astype(float)
+    a1 = n_allele - a0
+    x = np.stack([np.maximum(a0, a1), np.minimum(a0, a1), x_total], axis=1)
+    return SyntheticExperiment(x, l, experiment.adjacencies, experiment.breakpoints, experiment.segment_chromosome_id, h, cn)
+
+
 def make_init_params(experiment, num_restarts, max_copy_number, num_clones=3):
     """Restart grid in the shape of analysis/pipeline.py:42-58, 96-103: depth modes x
     tumour_mix_fractions x divergence_weights, all with one common max_depth."""

@@ -31,13 +31,61 @@ WORKER = textwrap.dedent('''
 ''') % ROOT
 
 
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _bench(extra, env_extra=None):
+    """Run bench.py on the CPU oracle kernel (launch / shard / gather logic only) and return its JSON line."""
+    import json
+    env = dict(os.environ, BENCH_KERNEL='oracle', BENCH_DIST_BACKEND='gloo', MASTER_ADDR='127.0.0.1')
+    env.pop('WORLD_SIZE', None); env.pop('RANK', None); env.pop('LOCAL_RANK', None)
+    env.update(env_extra or {})
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--segments', '80', '--max-cn', '2', '--steps', '1', '--warmup', '0',
+                          '--no-cpu-baseline'] + extra, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, out.stdout          # exactly ONE JSON line, from rank 0
+    return json.loads(lines[0])
+
+
+def test_bench_gpus_2_launches_two_ranks():
+    """`python bench.py --gpus 2` outside torchrun starts the two ranks itself (--gpus was ignored)."""
+    line = _bench(['--gpus', '2', '--restarts', '2'])
+    assert line['n_gpus'] == 2 and line['config']['world_size_observed'] == 2
+    assert line['scaling'] == 'weak' and line['config']['restarts_total'] == 4 and line['config']['restarts_this_rank'] == 2
+    assert line['final_gather']['records'] == 4
+    assert line['value'] > 0 and np.isfinite(line['elbo_best'])
+
+
+def test_bench_strong_scaling_and_two_datasets():
+    """BASELINE configs[3] / configs[4] shapes: a fixed total sharded over the ranks, two datasets side by side."""
+    line = _bench(['--gpus', '2', '--total-restarts', '6', '--datasets', '2'])
+    assert line['n_gpus'] == 2 and line['scaling'] == 'strong'
+    assert line['config']['restarts_total'] == 6 and line['config']['datasets'] == 2 and line['final_gather']['records'] == 6
+    assert 'configs[4]' in line['config']['workload']
+    one = _bench(['--gpus', '1', '--total-restarts', '6'])
+    assert one['n_gpus'] == 1 and one['scaling'] == 'strong' and 'configs[3]' in one['config']['workload']
+
+
+def test_bench_refuses_a_world_size_that_contradicts_gpus():
+    env = dict(os.environ, BENCH_KERNEL='oracle', WORLD_SIZE='2', RANK='0', LOCAL_RANK='0')
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '4', '--no-cpu-baseline'], env=env, capture_output=True, text=True, timeout=120)
+    assert out.returncode != 0 and 'WORLD_SIZE' in (out.stderr + out.stdout)
+
+
 def test_two_rank_gloo_matches_single_process(tmp_path):
     script = tmp_path / 'worker.py'
     script.write_text(WORKER)
     out2 = tmp_path / 'two.pkl'
     env = dict(os.environ, MASTER_ADDR='127.0.0.1')
     subprocess.check_call([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=2', '--master-addr', '127.0.0.1',
-                           '--master-port', '29533', str(script), str(out2)], env=env, timeout=600)
+                           '--master-port', str(_free_port()), str(script), str(out2)], env=env, timeout=600)
     import pickle
     two, best2 = pickle.load(open(out2, 'rb'))
     # single process, no process group
