@@ -119,6 +119,33 @@ int rmx_synchronize(rmx_batch *b);
  * 3 num breakend segments, 4 padded row stride of [N][S] device arrays */
 int rmx_info(rmx_batch *b, int32_t what, int64_t *out);
 
+/* -- tuning options ------------------------------------------------------- */
+/* Not part of the reference protocol: which of this library's equivalent kernels / launch shapes run.  Results do not
+ * depend on them beyond rounding (tests/test_hip_*.py compare the alternatives); they exist so that tests can put a
+ * small problem on the launch shape a large one gets, and for A/B measurements.  rmx_set_default_option applies to
+ * batches created afterwards (process-wide); rmx_set_option to one batch (creation-time options: RMX_EARG). */
+enum rmx_option_id {
+    RMX_OPT_FB_KERNEL = 0,      /* forward-backward: 0 auto, 1 general single-vector kernel for every chain, 2 tabulated weights
+                                   instead of on-the-fly weights for grids beyond the register-resident kernel (S > 176) */
+    RMX_OPT_FB_NV,              /* restarts advanced by one forward-backward workgroup: 0 auto (fills the chip), 1, 2, 4, 8, 16 */
+    RMX_OPT_FB_BREAKEND_CODES,  /* 1 (default): breakend steps from pair codes + clone-product tables; 0: per-clone distance tables */
+    RMX_OPT_FUSE_SWEEPS,        /* 1 (default): marginals + indicator updates + next frame pass as one kernel between sweeps */
+    RMX_OPT_TWO_STREAMS,        /* 1 (default): breakend branch of a sweep on a second stream next to the marginal pass */
+    RMX_OPT_VITERBI_PLAIN,      /* 1: decode with the table-reading lattice kernel */
+    RMX_OPT_SEARCH_MODE,        /* parameter searches: 0 shared rounds, table-free (default); 1 one parameter at a time; 2 with
+                                   table rebuilds per candidate; 3 with look-ahead evaluations; 4 on the full objective */
+    RMX_OPT_ELL_DENSE,          /* 1: sampled objectives over all states instead of the lists of states with posterior mass */
+    RMX_OPT_STRIP,              /* 1 (default): strip kernels for the (segment x state) passes when 32 < S <= 384 */
+    RMX_OPT_CELL_CACHE,         /* creation time, 1 (default): cache the six likelihood values of every cell */
+    RMX_OPT_SPARSE_TRIAL,       /* creation time, 1 (default): keep per-segment lists of states with posterior mass */
+    RMX_OPT_FB_DEBUG,           /* creation time, 1: cycle counters of the forward-backward kernel through rmx_info(20..) */
+    RMX_OPT_PAIRWISE_KERNEL,    /* breakend pairwise reductions: 0 auto, 1 general kernel (k_pairwise) */
+    RMX_OPT_COUNT
+};
+int rmx_set_default_option(int32_t option_id, int32_t value);
+int rmx_set_option(rmx_batch *b, int32_t option_id, int32_t value);
+int rmx_get_option(rmx_batch *b, int32_t option_id, int32_t *value);
+
 /* -- attributes ----------------------------------------------------------- */
 int rmx_set_param(rmx_batch *b, int32_t r, int32_t param_id, double value);
 int rmx_get_param(rmx_batch *b, int32_t r, int32_t param_id, double *value);
@@ -209,6 +236,17 @@ int rmx_trial_rollback(rmx_batch *b, int32_t r, int32_t param_id, const double *
 /* per-cell values, for tests (:751-776, :809-853): u/v/w in {0,1} */
 int rmx_log_likelihood_total(rmx_batch *b, int32_t r, int32_t n, int32_t s, int32_t u, double *out);
 int rmx_log_likelihood_allele(rmx_batch *b, int32_t r, int32_t n, int32_t s, int32_t v, int32_t w, double *out);
+
+/* The other per-cell cpdef methods of RemixtModel for segment n, state s (no caller in cn_model.py; part of the protocol):
+ * which = 0 calculate_expected_total_reads (bpmodel.pyx:686-698) -> out[0]
+ *         1 calculate_expected_total_reads_partial_h (:700-708) -> out[0..M)
+ *         2 calculate_expected_allele_ratio (:710-725) -> out[0]     (RMX_EVALUE: total_depth <= 0)
+ *         3 calculate_expected_allele_ratio_partial_h (:727-745) -> out[0..M)
+ *         4 calculate_log_prior_cn (:747-750) -> out[0]
+ *         5 calculate_log_likelihood_total_partial_h (:778-807), outlier state u -> out[0..M)
+ *         6 calculate_log_likelihood_allele_partial_h (:855-896), outlier state v, allele w -> out[0..M)
+ * out must hold RMX_MAX_CLONES doubles. */
+int rmx_cell_quantity(rmx_batch *b, int32_t r, int32_t n, int32_t s, int32_t which, int32_t u, int32_t v, int32_t w, double *out);
 
 /* -- decoding ------------------------------------------------------------- */
 /* infer_cn (:1197-1210): Viterbi over the framelogprob / log_transmat of the last

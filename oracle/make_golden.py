@@ -175,6 +175,90 @@ def model_case(cm, name, N, M, max_cn, chains, seed, normal_contamination=True, 
     print(name, 'N1', m.N1, 'S', S, 'elbo', float(out['s1/update_p_outlier_allele/elbo']), 'fit elbo', float(out['fit/elbo']), 'failed', int(out['fit/failed']))
 
 
+def add_shared_boundary_breakpoints(e, N):
+    """Two extra breakpoints with one breakend each on the SAME boundary (segment a, side 1) and (a + 1, side 0):
+    the remap has to insert a zero-length segment there (cn_model.py:86-161)."""
+    used = set(be for bp in e.breakpoints.values() for be in bp)
+    adj = e.adjacencies
+    brk = dict(e.breakpoints)
+    for a in range(2, N - 3):
+        far1, far2 = (N - 2, 0), (1, 1)
+        ends = [(a, 1), (a + 1, 0), far1, far2]
+        if (a, a + 1) in adj and not any(x in used for x in ends) and abs(a - (N - 2)) > 2 and a > 3:
+            brk['shared_a'] = frozenset([(a, 1), far1])
+            brk['shared_b'] = frozenset([(a + 1, 0), far2])
+            return brk
+    raise RuntimeError('no free boundary for the shared-boundary breakpoints')
+
+
+def grid_case(cm, name, N, M, max_cn, chains, seed, K, transition_model=0, disable_breakpoints=False, shared_boundary=True):
+    """A model at one of the benchmark's state grids (165 states at max_cn = 8, 355 at max_cn = 12) or on a dark
+    corner of the protocol (transition_model = 1, num_clones = 4, disable_breakpoints) with K >= 6 breakpoints, two of
+    them at one boundary.  The dense (N-1) x S x S arrays are not recorded, and the (N x S) arrays only after
+    update_p_cn and at the end of a sweep; everything else after every coordinate update of two sweeps."""
+    e = synthetic.make_experiment(N, num_clones=M, max_copy_number=max_cn, num_chains=chains, seed=seed, num_breakpoints=K)
+    brk = add_shared_boundary_breakpoints(e, N) if shared_boundary else dict(e.breakpoints)
+    x = e.x.copy(); l = e.l.copy()
+    p = synthetic.make_init_params(e, 1, max_cn, num_clones=M)[0]
+    h_init = synthetic.h_init_from_params(p, M) if M <= 3 else np.array([p['h_normal']] + [p['h_tumour'] * f for f in (0.5, 0.3, 0.2)])
+    kw = dict(max_copy_number=max_cn, divergence_weight=p['divergence_weight'], max_depth=p['max_depth'],
+              transition_model=transition_model, disable_breakpoints=disable_breakpoints)
+    out = {'x': x, 'l': l, 'adjacencies': adjacency_array(e.adjacencies), 'h_init': h_init, 'num_clones': np.array(M),
+           'max_copy_number': np.array(max_cn), 'divergence_weight': np.array(p['divergence_weight']),
+           'max_depth': np.array(p['max_depth']), 'normal_contamination': np.array(True), 'normal_copies': np.array([[1, 1]] * N),
+           'transition_model': np.array(transition_model), 'disable_breakpoints': np.array(disable_breakpoints)}
+    out['breakpoint_ids'], out['breakends'] = breakpoint_array(brk)
+    with quiet():
+        m = cm.BreakpointModel(x, l, e.adjacencies, brk, **kw)
+        m.num_em_iter = 0
+        m.fit(h_init)
+    mod = m.model
+    S = mod.num_cn_states
+    out['elbo_init'] = np.array(m.prev_elbo)
+    out['is_telomere'] = m.is_telomere; out['breakpoint_idx'] = m.breakpoint_idx; out['breakpoint_orient'] = m.breakpoint_orient
+    out['brk_states'] = np.asarray(mod.brk_states)
+    rng = np.random.RandomState(seed)
+    cells = np.stack([rng.randint(0, m.N1, 16), rng.randint(0, S, 16)], axis=1)
+    out['cells'] = cells
+    out['cell_ll_total'] = np.array([[mod.calculate_log_likelihood_total(int(n), int(s), u) for u in range(2)] for n, s in cells])
+    out['cell_ll_allele'] = np.array([[mod.calculate_log_likelihood_allele(int(n), int(s), v, w) for v in range(2) for w in range(2)] for n, s in cells])
+    small = ['p_breakpoint', 'p_outlier_total', 'p_outlier_allele', 'p_allele_swap']
+    with quiet():
+        for sweep in range(2):
+            for step in STEPS:
+                getattr(mod, step)()
+                pre = 's%d/%s/' % (sweep, step)
+                for a in small:
+                    out[pre + a] = np.asarray(getattr(mod, a)).copy()
+                if step in ('update_p_cn', 'update_p_outlier_allele'):
+                    out[pre + 'posterior_marginals'] = np.asarray(mod.posterior_marginals).copy()
+                    out[pre + 'framelogprob'] = np.asarray(mod.framelogprob).copy()
+                out[pre + 'hmm_log_norm_const'] = np.array(mod.hmm_log_norm_const)
+                # (after a transition_model change the ELBO between update_p_cn and update_p_breakpoint mixes the two
+                # models' tables -- recorded all the same: it is what the reference returns)
+                out[pre + 'elbo'] = np.array(mod.calculate_elbo())
+    sample = (rng.rand(m.N1) < 0.3).astype(np.int64)
+    ones = np.ones(m.N1, dtype=np.int64)
+    out['sample'] = sample
+    out['ell_sample'] = np.array(mod.calculate_expected_log_likelihood(sample)); out['ell_all'] = np.array(mod.calculate_expected_log_likelihood(ones))
+    g = np.zeros(M); mod.calculate_expected_log_likelihood_partial_h(sample, g); out['grad_sample'] = g
+    cn = np.zeros((m.N1, M, 2), dtype=int)
+    mod.infer_cn(cn)
+    out['infer_cn'] = cn
+    with quiet():
+        cn2, brk_cn = m.optimal_cn()
+    out['optimal_cn'] = cn2
+    if not disable_breakpoints:
+        out['brk_cn'] = np.array([brk_cn[k] for k in out['breakpoint_ids']])
+    if disable_breakpoints:
+        naive = cm.decode_breakpoints_naive(cn2, e.adjacencies, brk)
+        out['brk_cn_naive'] = np.array([naive[k] for k in out['breakpoint_ids']])
+    np.savez_compressed(os.path.join(OUT, name + '.npz'), **out)
+    nbe = int((m.breakpoint_idx >= 0).sum())
+    print(name, 'N1', m.N1, 'S', S, 'K', len(brk), 'breakend adjacencies', nbe, 'elbo', float(out['s1/update_p_outlier_allele/elbo']),
+          'bytes', os.path.getsize(os.path.join(OUT, name + '.npz')))
+
+
 def chain_kats(bp):
     out = {}
     rng = np.random.RandomState(0)
@@ -453,6 +537,15 @@ def evaluation_case(name, N, seed):
     print(name, 'cases', len(EVALUATION_CASES))
 
 
+def grid_cases(cm):
+    # the benchmark's state grids and the protocol's dark corners (item 8)
+    grid_case(cm, 'grid_s165', N=36, M=3, max_cn=8, chains=2, seed=21, K=7)
+    grid_case(cm, 'grid_s355', N=30, M=3, max_cn=12, chains=2, seed=22, K=6)
+    grid_case(cm, 'grid_tmodel1', N=40, M=3, max_cn=3, chains=2, seed=23, K=6, transition_model=1)
+    grid_case(cm, 'grid_m4', N=30, M=4, max_cn=3, chains=2, seed=24, K=6)
+    grid_case(cm, 'grid_nobrk', N=40, M=3, max_cn=3, chains=2, seed=25, K=6, disable_breakpoints=True)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     build_ref.build()
@@ -465,6 +558,7 @@ def main():
     model_case(cm, 'model_m3', N=48, M=3, max_cn=3, chains=3, seed=2, zero_alleles=(5, 17), short=(9,))
     model_case(cm, 'model_nonormal', N=36, M=2, max_cn=3, chains=2, seed=3, normal_contamination=False, zero_alleles=(4,))
     model_case(cm, 'model_malex', N=36, M=3, max_cn=2, chains=3, seed=4, male_x=True)
+    grid_cases(cm)
     pipeline_case('pipeline_init', N=1200, seed=5)
     experiment_case('experiment_tables', N=240, seed=8)
     pipeline_case('pipeline_init_strict', N=900, seed=6, min_ploidy=7.5, max_ploidy=8.0, random_seed=99)

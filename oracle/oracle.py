@@ -65,6 +65,8 @@ def lib():
     L.rmxo_log_likelihood_total.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
     L.rmxo_log_likelihood_allele.restype = C.c_double
     L.rmxo_log_likelihood_allele.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]
+    L.rmxo_cell_quantity.restype = C.c_int
+    L.rmxo_cell_quantity.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _dp]
     L.rmxo_sum_product.restype = None
     L.rmxo_sum_product.argtypes = [_dp, _dp, _dp, _dp, C.c_int, C.c_int]
     L.rmxo_max_product.restype = C.c_double
@@ -283,6 +285,33 @@ class RemixtModel(object):
 
     def calculate_log_likelihood_allele(self, n, s, v, w):
         r = self._L.rmxo_log_likelihood_allele(self._p, n, s, v, w); self._check(); return r
+
+    # remaining per-cell cpdef methods (bpmodel.pyx:686-749, 778-807, 855-896)
+    def _cell(self, which, n, s, u=0, v=0, w=0):
+        out = np.zeros(8)
+        self._L.rmxo_cell_quantity(self._p, int(n), int(s), which, int(u), int(v), int(w), _pd(out)); self._check()
+        return out
+
+    def calculate_expected_total_reads(self, n, s):
+        return float(self._cell(0, n, s)[0])
+
+    def calculate_expected_total_reads_partial_h(self, n, s, partial_h):
+        partial_h[:] = self._cell(1, n, s)[:self.num_clones]
+
+    def calculate_expected_allele_ratio(self, n, s):
+        return float(self._cell(2, n, s)[0])
+
+    def calculate_expected_allele_ratio_partial_h(self, n, s, partial_h):
+        partial_h[:] = self._cell(3, n, s)[:self.num_clones]
+
+    def calculate_log_prior_cn(self, n, s):
+        return float(self._cell(4, n, s)[0])
+
+    def calculate_log_likelihood_total_partial_h(self, n, s, u, partial_h):
+        partial_h[:] = self._cell(5, n, s, u=u)[:self.num_clones]
+
+    def calculate_log_likelihood_allele_partial_h(self, n, s, v, w, partial_h):
+        partial_h[:] = self._cell(6, n, s, v=v, w=w)[:self.num_clones]
 
     def infer_cn(self, cn):
         out = np.zeros((self.num_segments, self.num_clones, 2), dtype=np.int64)

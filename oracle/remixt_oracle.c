@@ -292,6 +292,30 @@ static void log_likelihood_allele_partial_h(rmxo_model *m, int n, int s, int v, 
     for (int c = 0; c < M; c++) ph[c] *= pp;
 }
 
+/* the per-cell cpdef methods as one exported entry (same numbering as rmx_cell_quantity in include/remixt_amd.h):
+ * 0 expected_total_reads, 1 its partial_h, 2 expected_allele_ratio, 3 its partial_h (:727-745), 4 log_prior_cn,
+ * 5 log_likelihood_total_partial_h (u), 6 log_likelihood_allele_partial_h (v, w) */
+int rmxo_cell_quantity(rmxo_model *m, int n, int s, int which, int u, int v, int w, double *out) {
+    const int M = m->M;
+    double minor_depth = 0., total_depth = 0.;
+    switch (which) {
+    case 0: out[0] = expected_total_reads(m, n, s); break;
+    case 1: for (int c = 0; c < M; c++) out[c] = m->l[n] * (double)TOT(m, n, s, c); break;
+    case 2: out[0] = expected_allele_ratio(m, n, s, NULL, NULL); break;
+    case 3:
+        expected_allele_ratio(m, n, s, &minor_depth, &total_depth);
+        if (!m->err)
+            for (int c = 0; c < M; c++)
+                out[c] = (((double)CN(m, n, s, c, 0) * total_depth - minor_depth * (double)TOT(m, n, s, c)) / (total_depth * total_depth));
+        break;
+    case 4: out[0] = log_prior_cn(m, n, s); break;
+    case 5: log_likelihood_total_partial_h(m, n, s, u, out); break;
+    case 6: log_likelihood_allele_partial_h(m, n, s, v, w, out); break;
+    default: return -1;
+    }
+    return m->err;
+}
+
 /* ---- bpmodel.pyx:898-919 update_framelogprob ---------------------------- */
 int rmxo_update_framelogprob(rmxo_model *m) {
     const int S = m->S;

@@ -36,6 +36,9 @@ SYMBOLS = {
     "rmx_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
     "rmx_synchronize": (C.c_int, [C.c_void_p]),
     "rmx_info": (C.c_int, [C.c_void_p, C.c_int32, _ip]),
+    "rmx_set_default_option": (C.c_int, [C.c_int32, C.c_int32]),
+    "rmx_set_option": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32]),
+    "rmx_get_option": (C.c_int, [C.c_void_p, C.c_int32, _i32p]),
     "rmx_set_param": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_double]),
     "rmx_get_param": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, _dp]),
     "rmx_set_transition_model": (C.c_int, [C.c_void_p, C.c_int32]),
@@ -67,6 +70,7 @@ SYMBOLS = {
     "rmx_trial_rollback": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, _dp]),
     "rmx_log_likelihood_total": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _dp]),
     "rmx_log_likelihood_allele": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _dp]),
+    "rmx_cell_quantity": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _dp]),
     "rmx_infer_cn": (C.c_int, [C.c_void_p, C.c_int32, _ip, _dp]),
     "rmx_infer_cn_batch": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, _ip, _dp]),
     "rmx_sum_product": (C.c_int, [_dp, _dp, _dp, _dp, C.c_int32, C.c_int32, C.c_int32]),

@@ -1,77 +1,120 @@
-"""Candidate haploid depths from read depth (reference remixt/analysis/readdepth.py:12-147): the
-initialisations whose grid with the tumour mix fractions and divergence weights is the restart set
-the GPUs shard."""
+"""Read-depth initialisation of the restart grid: per-segment allele depths -> modes of the minor depth ->
+candidate (normal, tumour) haploid depths -> ploidy of a candidate.
+
+Behaviour follows the reference's `remixt/analysis/readdepth.py` (calculate_depth :12-57,
+calculate_minor_modes :60-90, calculate_candidate_h_monoclonal :93-126, estimate_ploidy :129-147) and is
+pinned by tests/golden/pipeline_init*.npz, recorded from the reference's own functions.  The
+implementation is array-first: the depths are computed once into a `_Depths` record straight from the
+experiment's count matrix, and the pandas table the reference's callers expect is only a view of it.
+"""
+import collections
+
 import numpy as np
+import pandas as pd
 
 from .. import likelihood
-from . import experiment as _experiment
+
+_Depths = collections.namedtuple('_Depths', 'length major minor total high_quality measurable')
+
+_KMEANS_CLUSTERS = 5          # readdepth.py:75
+_MIN_CLUSTER_SHARE = 0.01     # readdepth.py:83
+_TRIM_PERCENTILE = 95         # readdepth.py:70
+_RESAMPLE_DRAWS = 10000       # remixt/utils.py:24
+
+
+def _above_lowest_decile(values):
+    return values > np.percentile(values, 10)
+
+
+def _depths(experiment):
+    """Allele-specific read depth per segment and the two per-segment flags of the reference's table."""
+    counts = np.asarray(experiment.x, dtype=float)
+    major_reads, minor_reads, reads = counts[:, 0], counts[:, 1], counts[:, 2]
+    length = np.asarray(experiment.l, dtype=float)
+    phased = minor_reads + major_reads
+    with np.errstate(divide='ignore', invalid='ignore'):
+        minor_share = minor_reads / (major_reads + minor_reads)
+        minor_share = np.where(np.isnan(minor_share), 0., minor_share)          # no phased read at all: all depth to the major allele
+        major = reads * (1. - minor_share) / length
+        minor = reads * minor_share / length
+        total = reads / length
+        # share of the annotated segment that is mappable ("length" is the mappable length)
+        span = np.asarray(experiment.segment_end) - np.asarray(experiment.segment_start) + 1
+        covered = length / span
+    high_quality = _above_lowest_decile(length) & _above_lowest_decile(phased) & _above_lowest_decile(covered)
+    # a depth is only defined where the segment has length and both the phased and the total read
+    # fraction can be measured (likelihood.py:71-90)
+    p = likelihood.proportion_measureable_matrix(likelihood.estimate_phi(experiment.x))
+    measurable = (length > 0) & np.all(p > 0, axis=1)
+    return _Depths(length, major, minor, total, high_quality, measurable)
 
 
 def calculate_depth(experiment):
-    """readdepth.py:12-57: table with columns chromosome, start, end, length, major, minor, total,
-    high_quality; segments with zero length or no genotypable reads are dropped."""
-    data = _experiment.create_segment_table(experiment)
-    data['segment_length'] = data['end'] - data['start'] + 1
-    data['length_ratio'] = data['length'] / data['segment_length']
-    data['allele_readcount'] = data['minor_readcount'] + data['major_readcount']
-    data['high_quality'] = (
-        (data['length'] > np.percentile(data['length'].values, 10)) &
-        (data['allele_readcount'] > np.percentile(data['allele_readcount'].values, 10)) &
-        (data['length_ratio'] > np.percentile(data['length_ratio'].values, 10)))
-    phi = likelihood.estimate_phi(experiment.x)
-    p = likelihood.proportion_measureable_matrix(phi)
-    data = data[(data['length'] > 0) & np.all(p > 0, axis=1)]
-    data = data.rename(columns={'major_depth': 'major', 'minor_depth': 'minor', 'total_depth': 'total'})
-    return data[['chromosome', 'start', 'end', 'length', 'major', 'minor', 'total', 'high_quality']]
+    """Table of the measurable segments (original index kept) with columns chromosome, start, end, length,
+    major, minor, total, high_quality."""
+    d = _depths(experiment)
+    keep = np.nonzero(d.measurable)[0]
+    table = collections.OrderedDict()
+    table['chromosome'] = np.asarray(experiment.segment_chromosome_id)[keep]
+    table['start'] = np.asarray(experiment.segment_start)[keep]
+    table['end'] = np.asarray(experiment.segment_end)[keep]
+    for name in ('length', 'major', 'minor', 'total', 'high_quality'):
+        table[name] = getattr(d, name)[keep]
+    return pd.DataFrame(table, index=keep)
 
 
-def weighted_resample(data, weights, num_samples=10000):
-    """remixt/utils.py:24-29: multinomial resample; the global numpy RNG state is restored afterwards
-    (TempRandomSeed saves and restores it -- the draw itself uses the state as it is)."""
-    norm_weights = weights.astype(float) / float(weights.sum())
-    state = np.random.get_state()
-    counts = np.random.multinomial(num_samples, norm_weights)
-    np.random.set_state(state)
-    return np.repeat(data, counts)
+def weighted_resample(data, weights, num_samples=_RESAMPLE_DRAWS):
+    """Multinomial bootstrap of `data` with probabilities proportional to `weights` (remixt/utils.py:24-29).
+    The reference wraps the draw in a context manager that saves and restores the global generator's state
+    without reseeding: the draw uses the state as it stands and leaves it untouched."""
+    share = weights.astype(float) / float(weights.sum())
+    saved = np.random.get_state()
+    try:
+        times = np.random.multinomial(num_samples, share)
+    finally:
+        np.random.set_state(saved)
+    return np.repeat(data, times)
 
 
 def calculate_minor_modes(read_depth):
-    """readdepth.py:60-90: k-means (k = 5, sklearn defaults, global numpy RNG) on a length-weighted
-    resample of the minor depths below their 95th percentile; clusters under 1 % are dropped."""
-    import sklearn.cluster
-    amp_rd = np.percentile(read_depth['minor'], 95)
-    read_depth = read_depth[read_depth['minor'] < amp_rd]
-    rd_samples = weighted_resample(read_depth['minor'].values, read_depth['length'].values)
-    kmm = sklearn.cluster.KMeans(n_clusters=5)
-    kmm.fit(rd_samples.reshape((rd_samples.size, 1)))
-    means = kmm.cluster_centers_[:, 0]
-    cluster_idx = kmm.predict(rd_samples.reshape((rd_samples.size, 1)))
-    cluster_counts = np.bincount(cluster_idx)
-    cluster_prop = cluster_counts.astype(float) / cluster_counts.sum()
-    return means[cluster_prop >= 0.01]
+    """Modes of the minor-allele depth: centres of a 5-means clustering (scikit-learn defaults, global numpy
+    generator) of a length-weighted bootstrap of the depths under their 95th percentile, without the clusters
+    holding less than 1 % of the bootstrap."""
+    from sklearn.cluster import KMeans
+    minor = np.asarray(read_depth['minor'])
+    length = np.asarray(read_depth['length'])
+    body = minor < np.percentile(minor, _TRIM_PERCENTILE)
+    draws = weighted_resample(minor[body], length[body]).reshape(-1, 1)
+    model = KMeans(n_clusters=_KMEANS_CLUSTERS)
+    model.fit(draws)
+    membership = np.bincount(model.predict(draws))
+    share = membership.astype(float) / membership.sum()
+    return model.cluster_centers_[:, 0][share >= _MIN_CLUSTER_SHARE]
 
 
 def calculate_candidate_h_monoclonal(minor_modes, h_normal=None, h_tumour=None):
-    """readdepth.py:93-126: (h_normal, h_tumour) candidates; every mode above the normal depth is
-    tried as one and as two minor copies."""
+    """(normal, tumour) haploid depth candidates.  The lowest mode is the normal depth unless given; each higher
+    mode is read once as one tumour minor copy and once as two.  With both depths given there is one candidate."""
     if h_normal is None:
         h_normal = minor_modes.min()
     if h_tumour is not None:
         return np.array([[h_normal, h_tumour]])
-    h_candidates = list()
-    for h_t in minor_modes:
-        if h_t <= h_normal:
-            continue
-        h_t = h_t - h_normal
-        for scale in (1., 0.5):
-            h_candidates.append(np.array([h_normal, h_t * scale]))
-    return h_candidates
+    tumour_steps = [mode - h_normal for mode in minor_modes if mode > h_normal]
+    return [np.array([h_normal, step * copies_share]) for step in tumour_steps for copies_share in (1., 0.5)]
 
 
 def estimate_ploidy(h, experiment):
-    """readdepth.py:129-147: length-weighted mean of the raw total copy number."""
-    read_depth = calculate_depth(experiment).copy()
-    read_depth['major_raw'] = (read_depth['major'] - h[0]) / h[1:].sum()
-    read_depth['minor_raw'] = (read_depth['minor'] - h[0]) / h[1:].sum()
-    major, minor, length = read_depth.replace(np.inf, np.nan).dropna()[['major_raw', 'minor_raw', 'length']].values.T
-    return ((major + minor) * length).sum() / length.sum()
+    """Length-weighted mean tumour copy number implied by haploid depths `h` = (normal, tumour clones...): each
+    allele's depth less one normal copy, in units of the summed tumour depth.  Segments whose depths are
+    undefined or +inf do not count."""
+    d = _depths(experiment)
+    tumour_depth = h[1:].sum()
+    rows = d.measurable
+    major_copies = (d.major[rows] - h[0]) / tumour_depth
+    minor_copies = (d.minor[rows] - h[0]) / tumour_depth
+    length = d.length[rows]
+    columns = (length, d.major[rows], d.minor[rows], d.total[rows], major_copies, minor_copies)
+    usable = np.ones(length.shape, dtype=bool)
+    for c in columns:
+        usable &= ~(np.isnan(c) | (c == np.inf))
+    return ((major_copies[usable] + minor_copies[usable]) * length[usable]).sum() / length[usable].sum()

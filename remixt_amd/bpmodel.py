@@ -45,6 +45,20 @@ _WRITABLE = {'h', 'p_breakpoint', 'p_allele_swap', 'p_outlier_total', 'p_outlier
 _STATE_TABLES = {'cn_states_total': 0, 'num_alleles_subclonal': 1, 'is_hdel': 2, 'is_loh': 3}
 
 
+# enum rmx_option_id (include/remixt_amd.h)
+OPTION_IDS = dict((n, i) for i, n in enumerate((
+    'fb_kernel', 'fb_nv', 'fb_breakend_codes', 'fuse_sweeps', 'two_streams', 'viterbi_plain', 'search_mode', 'ell_dense', 'strip',
+    'cell_cache', 'sparse_trial', 'fb_debug', 'pairwise_kernel')))
+
+
+def set_default_option(name, value):
+    """Process-wide default of a tuning option for batches created afterwards (tests and A/B measurements)."""
+    lib = _lib.load()
+    rc = lib.rmx_set_default_option(OPTION_IDS[name], int(value))
+    if rc:
+        _raise(lib, rc)
+
+
 def _raise(lib, rc):
     msg = lib.rmx_last_error().decode()
     if rc == RMX_EVALUE:
@@ -178,6 +192,15 @@ class RemixtBatch(object):
 
     def synchronize(self):
         self._ck(self._lib.rmx_synchronize(self._handle))
+
+    def set_option(self, name, value):
+        """Tuning option of this batch (include/remixt_amd.h rmx_option_id): which equivalent kernel / launch shape runs."""
+        self._ck(self._lib.rmx_set_option(self._handle, OPTION_IDS[name], int(value)))
+
+    def get_option(self, name):
+        out = C.c_int32(0)
+        self._ck(self._lib.rmx_get_option(self._handle, OPTION_IDS[name], C.byref(out)))
+        return int(out.value)
 
     def model(self, r):
         return RemixtModel._from_batch(self, r)
@@ -581,6 +604,36 @@ class RemixtModel(object):
         b = self._batch
         b._ck(b._lib.rmx_log_likelihood_allele(b._handle, self._r, int(n), int(s), int(v), int(w), C.byref(out)))
         return float(out.value)
+
+    # the remaining per-cell cpdef methods (bpmodel.pyx:686-749, 778-807, 855-896); partial_h is the caller's (M,) array
+    def _cell(self, which, n, s, u=0, v=0, w=0):
+        b = self._batch
+        if not (0 <= int(n) < b.num_segments and 0 <= int(s) < b.num_cn_states):
+            raise IndexError('segment / state index out of range')       # the reference's bounds-checked memoryviews
+        out = np.zeros(MAX_CLONES)
+        b._ck(b._lib.rmx_cell_quantity(b._handle, self._r, int(n), int(s), which, int(u), int(v), int(w), out.ctypes.data_as(_dp)))
+        return out
+
+    def calculate_expected_total_reads(self, n, s):
+        return float(self._cell(0, n, s)[0])
+
+    def calculate_expected_total_reads_partial_h(self, n, s, partial_h):
+        partial_h[:] = self._cell(1, n, s)[:self._batch.num_clones]
+
+    def calculate_expected_allele_ratio(self, n, s):
+        return float(self._cell(2, n, s)[0])
+
+    def calculate_expected_allele_ratio_partial_h(self, n, s, partial_h):
+        partial_h[:] = self._cell(3, n, s)[:self._batch.num_clones]
+
+    def calculate_log_prior_cn(self, n, s):
+        return float(self._cell(4, n, s)[0])
+
+    def calculate_log_likelihood_total_partial_h(self, n, s, u, partial_h):
+        partial_h[:] = self._cell(5, n, s, u=u)[:self._batch.num_clones]
+
+    def calculate_log_likelihood_allele_partial_h(self, n, s, v, w, partial_h):
+        partial_h[:] = self._cell(6, n, s, v=v, w=w)[:self._batch.num_clones]
 
     def infer_cn(self, cn):
         out, _ = self._batch.infer_cn(self._r)

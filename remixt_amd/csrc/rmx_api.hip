@@ -35,7 +35,12 @@ static const char *kKernelNames[KID_COUNT] = {
 
 struct ProfRec { int id; hipEvent_t a, b; };
 
+// tuning options (include/remixt_amd.h rmx_option_id): process-wide defaults, copied into a batch at creation
+static int g_opt_default[RMX_OPT_COUNT] = {0, 0, 1, 1, 1, 0, 0, 0, 1, 1, 1, 0, 0};
+static std::mutex g_opt_mu;
+
 struct rmx_batch {
+    int opt[RMX_OPT_COUNT];
     int device = 0;
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr;     // breakend branch of a sweep (pairwise reductions, p_breakpoint) next to the marginal pass
@@ -412,7 +417,7 @@ static void configure_fb(rmx_batch *b) {
     while (S * (PG + 1) <= 1024 && (S + PG) / (PG + 1) >= 1 && PG < 16) PG++;
     // multi-vector register kernel (chains of one state-table class): rows per slice for 8 slices
     b->fbv_rpt = 0;
-    if (!getenv("RMX_FB_GENERIC")) { for (int v : {2, 6, 14, 22}) if (8 * v >= S) { b->fbv_rpt = v; break; } }
+    if (b->opt[RMX_OPT_FB_KERNEL] != 1) { for (int v : {2, 6, 14, 22}) if (8 * v >= S) { b->fbv_rpt = v; break; } }
     fb_layout(b, 0, PG, b->fbG, b->fbG_lds, nullptr);
     // more than 64 KiB of dynamic LDS needs an explicit opt-in per kernel
     hipFuncSetAttribute((const void *)fb_kernel_for(0), hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->fbG_lds);
@@ -468,7 +473,7 @@ template <int NS> static cells_kernel_t cells_kernel_ns(int mode, int mask, int 
     case 12: return k_cells<NS, 2, 12, 0>; case 15: return k_cells<NS, 2, 15, 0>; default: return k_cells<NS, 2, 31, 0>;
     }
 }
-static bool use_strip(rmx_batch *b) { return b->d.S > 32 && b->d.S <= 384 && !getenv("RMX_NO_STRIP"); }
+static bool use_strip(rmx_batch *b) { return b->d.S > 32 && b->d.S <= 384 && b->opt[RMX_OPT_STRIP]; }
 static cells_kernel_t cells_kernel(rmx_batch *b, int mode, int mask, int cache) {
     const int ns = (b->d.S + 63) / 64;
     switch (ns) { case 1: return cells_kernel_ns<1>(mode, mask, cache); case 2: return cells_kernel_ns<2>(mode, mask, cache);
@@ -481,7 +486,7 @@ static dim3 ell_block(rmx_batch *b) { return dim3(std::min(256, ((b->d.S + 63) /
 // listed restart's lists belong to its current posterior (both evaluation paths of rmx_param_search ask
 // this same question, so they sum the same terms in the same order)
 static bool ell_sparse_ok(rmx_batch *b, int n, const int32_t *restarts) {
-    if (!b->d.sig_cnt || getenv("RMX_ELL_DENSE")) return false;
+    if (!b->d.sig_cnt || b->opt[RMX_OPT_ELL_DENSE]) return false;
     for (int i = 0; i < n; i++) if (!b->sig_valid[restarts[i]]) return false;
     return true;
 }
@@ -541,14 +546,10 @@ static int launch_pairwise_breakends(rmx_batch *b, int r0, int r1, int mode) {
     ProfScope ps(b, KID_PAIRWISE);
     const Dev &d = b->d;
     const int nt = ((d.S + 63) / 64) * 64;
-    const size_t lds = ((size_t)((d.S + 1) & ~1) + ((d.M * d.D + 1) & ~1) + 128 + (size_t)nt * d.M * (d.cn_max + 2)) * 8 + (size_t)d.S * 4 + 64;
     const size_t lds2 = ((size_t)((d.S + 7) & ~7) + b->pe2p + 128 + (size_t)nt * (d.M - 1) * (d.cn_max + 2) + nt + 3 * d.M * d.D) * 8 + (size_t)((d.S + 7) & ~7) * 4 + (size_t)d.S * 4 + 64;
-    if (mode == 0 && b->pcode_ok && lds2 <= 150 * 1024 && !getenv("RMX_PAIRWISE_OLD") && !getenv("RMX_PAIRWISE_V1")) {
+    if (mode == 0 && b->pcode_ok && lds2 <= 150 * 1024 && b->opt[RMX_OPT_PAIRWISE_KERNEL] == 0) {
         HIPCHK(hipFuncSetAttribute((const void *)k_pairwise_be2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
         hipLaunchKernelGGL(k_pairwise_be2, dim3(d.NBE, r1 - r0), dim3(nt), lds2, b->stream, b->d, r0, b->pe2p, b->spc);
-    } else if (mode == 0 && lds <= 150 * 1024 && !getenv("RMX_PAIRWISE_OLD")) {
-        HIPCHK(hipFuncSetAttribute((const void *)k_pairwise_be, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(k_pairwise_be, dim3(d.NBE, r1 - r0), dim3(nt), lds, b->stream, b->d, r0);
     } else {
         hipLaunchKernelGGL(k_pairwise, dim3(d.NBE, r1 - r0), dim3(256), 0, b->stream, b->d, r0, mode, (const int32_t *)nullptr, (double *)nullptr);
     }
@@ -577,6 +578,35 @@ static inline void bind_device(const rmx_batch *b) {
 extern "C" {
 
 const char *rmx_last_error(void) { return g_err.c_str(); }
+
+static bool option_value_ok(int id, int v) {
+    switch (id) {
+    case RMX_OPT_FB_KERNEL: return v >= 0 && v <= 2;
+    case RMX_OPT_FB_NV: return v == 0 || v == 1 || v == 2 || v == 4 || v == 8 || v == 16;
+    case RMX_OPT_SEARCH_MODE: return v >= 0 && v <= 4;
+    case RMX_OPT_PAIRWISE_KERNEL: return v == 0 || v == 1;
+    default: return v == 0 || v == 1;
+    }
+}
+int rmx_set_default_option(int32_t id, int32_t value) {
+    if (id < 0 || id >= RMX_OPT_COUNT || !option_value_ok(id, value)) return fail(RMX_EARG, "bad option id / value");
+    std::lock_guard<std::mutex> lk(g_opt_mu);
+    g_opt_default[id] = value;
+    return RMX_OK;
+}
+static void configure_fb(rmx_batch *b);
+int rmx_set_option(rmx_batch *b, int32_t id, int32_t value) {
+    if (!b || id < 0 || id >= RMX_OPT_COUNT || !option_value_ok(id, value)) return fail(RMX_EARG, "bad option id / value");
+    if (id == RMX_OPT_CELL_CACHE || id == RMX_OPT_SPARSE_TRIAL || id == RMX_OPT_FB_DEBUG) return fail(RMX_EARG, "creation-time option: use rmx_set_default_option before rmx_batch_create");
+    b->opt[id] = value;
+    if (id == RMX_OPT_FB_KERNEL) configure_fb(b);
+    return RMX_OK;
+}
+int rmx_get_option(rmx_batch *b, int32_t id, int32_t *value) {
+    if (!b || !value || id < 0 || id >= RMX_OPT_COUNT) return fail(RMX_EARG, "bad option id");
+    *value = b->opt[id];
+    return RMX_OK;
+}
 
 int rmx_compress_cn_states(const int64_t *cn_states, int32_t N, int32_t S, int32_t M, int32_t max_classes,
                            int32_t *seg_class_out, int64_t *classes_out, int32_t *num_classes) {
@@ -617,6 +647,7 @@ int rmx_batch_create(const rmx_problem *pr, int32_t R, const double *h_init, con
     for (int n = 0; n < N; n++) if (pr->seg_class[n] < 0 || pr->seg_class[n] >= C) return fail(RMX_EARG, "seg_class out of range");
 
     rmx_batch *b = new rmx_batch();
+    { std::lock_guard<std::mutex> lk(g_opt_mu); memcpy(b->opt, g_opt_default, sizeof b->opt); }
     b->device = device; b->R = R;
     HIPCHK(hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking));
     b->own_stream = true;
@@ -752,14 +783,13 @@ int rmx_batch_create(const rmx_problem *pr, int32_t R, const double *h_init, con
     DA(err, uint32_t, R)
 #undef DA
     d.lc = nullptr; d.sig_idx = nullptr; d.sig_cnt = nullptr;
-    if (S > 32 && S <= 384 && !getenv("RMX_NO_SPARSE_TRIAL")) {
+    if (S > 32 && S <= 384 && b->opt[RMX_OPT_SPARSE_TRIAL]) {
         uint16_t *pi_ = nullptr; uint8_t *pc_ = nullptr;
         if (dalloc(b, &pi_, RN * RMX_SIGK) == RMX_OK && dalloc(b, &pc_, RN) == RMX_OK) { d.sig_idx = pi_; d.sig_cnt = pc_; }
     }
     {
         const size_t bytes = RNS * 6 * 8;
-        const char *env = getenv("RMX_CELL_CACHE");
-        const bool want = env ? atoi(env) != 0 : true;
+        const bool want = b->opt[RMX_OPT_CELL_CACHE] != 0;
         if (want && S > 32 && S <= 384 && bytes <= ((size_t)96 << 30)) { double *p_ = nullptr; if (dalloc(b, &p_, RNS * 6) == RMX_OK) { d.lc = p_; b->use_cache = true; } }
     }
     if ((rc = dalloc(b, &b->d_lt_valid, R)) || (rc = dalloc(b, &b->d_partial, (size_t)R * ELBO_BLOCKS * 2)) || (rc = dalloc(b, &b->d_out4, (size_t)R * 4)) ||
@@ -826,7 +856,7 @@ int rmx_batch_create(const rmx_problem *pr, int32_t R, const double *h_init, con
         HIPCHK(hipMemset(d.hist, 0, BEW * 8)); HIPCHK(hipMemset(d.be_jt, 0, (size_t)R * d.NBE * 8)); HIPCHK(hipMemset(d.be_ja, 0, (size_t)R * d.NBE * 8));
         HIPCHK(hipMemset(d.pd_lt, 0, BEW * 8));
     }
-    if (getenv("RMX_FB_DEBUG")) { if ((rc = dalloc(b, &b->d_dbg, 32))) { rmx_batch_destroy(b); return rc; } HIPCHK(hipMemset(b->d_dbg, 0, 256)); }
+    if (b->opt[RMX_OPT_FB_DEBUG]) { if ((rc = dalloc(b, &b->d_dbg, 32))) { rmx_batch_destroy(b); return rc; } HIPCHK(hipMemset(b->d_dbg, 0, 256)); }
     b->G = S > 32 ? 64 : (S > 16 ? 32 : (S > 8 ? 16 : 8));
     configure_fb(b);
     if (b->fbG_lds > 160 * 1024) { rmx_batch_destroy(b); return fail(RMX_EUNSUPPORTED, "LDS budget exceeded"); }
@@ -1115,7 +1145,7 @@ static int p_cn_front(rmx_batch *b, int r0, int r1, bool skip_frame, bool snapsh
             const int nr = r1 - r0;
             int NV = 1;
             while (NV < 4 && (long)b->n_fast * 2 * ((nr + NV - 1) / NV) > 256) NV *= 2;
-            if (const char *env = getenv("RMX_FB_NV")) { const int want = atoi(env); if (want == 1 || want == 2 || want == 4) NV = std::min(want, std::max(1, nr)); if (NV == 3) NV = 2; }
+            { const int want = b->opt[RMX_OPT_FB_NV]; if (want == 1 || want == 2 || want == 4) NV = want; }
             FbvArgs v;
             v.S = d.S; v.SP = d.SP; v.M = d.M; v.D = d.D; v.C = d.C; v.N = d.N; v.NBE = d.NBE; v.cn_max = d.cn_max;
             v.r0 = r0; v.r1 = r1; v.pen = d.pen; v.pad_ = 0;
@@ -1134,7 +1164,7 @@ static int p_cn_front(rmx_batch *b, int r0, int r1, bool skip_frame, bool snapsh
                 // breakend fast path: product tables + pair codes in LDS (the allele-distance matrix is then
                 // not needed there)
                 const size_t code_bytes = (size_t)FBV_P * rpt * d.SP * 2;
-                const bool want_code = d.pe2_lt != nullptr && b->max_adist < 64 && (d.SP & 1) == 0 && !getenv("RMX_FB_NO_CODE");
+                const bool want_code = d.pe2_lt != nullptr && b->max_adist < 64 && (d.SP & 1) == 0 && b->opt[RMX_OPT_FB_BREAKEND_CODES];
                 size_t base_ = ((size_t)NV * 2 * v.SPAD + (size_t)NV * FBV_P * d.SP + NV * 4 + 128) * 8 +
                                (((size_t)d.C * d.S * d.M + 15) & ~(size_t)15) + 64 + (size_t)b->be_cap * 4;
                 size_t fixed;
@@ -1157,12 +1187,12 @@ static int p_cn_front(rmx_batch *b, int r0, int r1, bool skip_frame, bool snapsh
                 done_fast = true; fast = true;
             }
         }
-        if (!done_fast && b->fbv_rpt == 0 && b->fbk_ok && d.pe2_lt && b->n_fast > 0 && !getenv("RMX_FB_GENERIC") && !getenv("RMX_FB_NO_FBK")) {
+        if (!done_fast && b->fbv_rpt == 0 && b->fbk_ok && d.pe2_lt && b->n_fast > 0 && b->opt[RMX_OPT_FB_KERNEL] == 0) {
             // state grid too large for register-resident weights: weights from packed copy numbers on the fly
             const int nr = r1 - r0;
             int NV = 1;
             while (NV < 4 && (long)b->n_fast * 2 * ((nr + NV - 1) / NV) > 256) NV *= 2;
-            if (const char *env = getenv("RMX_FB_NV")) { const int want = atoi(env); if (want == 1 || want == 2 || want == 4) NV = want; }
+            { const int want = b->opt[RMX_OPT_FB_NV]; if (want == 1 || want == 2 || want == 4) NV = want; }
             FbvArgs v;
             memset(&v, 0, sizeof v);
             v.S = d.S; v.SP = d.SP; v.M = d.M; v.D = d.D; v.C = d.C; v.N = d.N; v.NBE = d.NBE; v.cn_max = d.cn_max;
@@ -1249,9 +1279,9 @@ int rmx_variational_update(rmx_batch *b, int32_t r0, int32_t r1, int32_t iters) 
     // Between two sweeps of this call everything from the marginals of sweep i to the frame
     // log-probabilities of sweep i+1 is local to a segment: one fused pass (k_cells MODE 3) instead of
     // marginals + update_p_outlier_total + update_p_outlier_allele + update_p_allele_swap + frame pass.
-    const bool fusable = use_strip(b) && b->use_cache && !getenv("RMX_NO_FUSE");
+    const bool fusable = use_strip(b) && b->use_cache && b->opt[RMX_OPT_FUSE_SWEEPS];
     // the breakend branch of a sweep (pairwise reductions, update_p_breakpoint) next to its marginal pass
-    const bool two_streams = use_strip(b) && b->d.NBE > 0 && !getenv("RMX_ONE_STREAM");
+    const bool two_streams = use_strip(b) && b->d.NBE > 0 && b->opt[RMX_OPT_TWO_STREAMS];
     if (two_streams && !b->stream2) {
         HIPCHK(hipStreamCreateWithFlags(&b->stream2, hipStreamNonBlocking));
         HIPCHK(hipEventCreateWithFlags(&b->ev_fb, hipEventDisableTiming));
@@ -1676,7 +1706,7 @@ int rmx_param_search(rmx_batch *b, int32_t nreq, const int32_t *restarts, int32_
     // moving part.  (Differs from the full sum by rounding only; RMX_SEARCH_FULL=1 evaluates everything.)
     static const int comp_bits[RMX_P_HMM_LOG_NORM_CONST] = {CM_LT0, CM_LT1, CM_LT0 | CM_LT1, CM_LT0, CM_LT1, CM_LA0, CM_LA1, CM_LA0 | CM_LA1, CM_LA0, CM_LA1, 0, 0, 0};
     int mask = comp_bits[param_id] & CM_ALL;
-    if (mask == 0 || getenv("RMX_SEARCH_FULL")) mask = CM_ALL;
+    if (mask == 0 || b->opt[RMX_OPT_SEARCH_MODE] == 4) mask = CM_ALL;
     std::vector<double> vals(nreq), out(nreq), best(nreq, INFINITY), x0(nreq), cst(nreq, 0.);
     auto eval = [&](int n_, const int32_t *rl_, const double *v_, double *o_, const int *who) -> int {
         for (int i = 0; i < n_; i++)
@@ -1701,7 +1731,7 @@ int rmx_param_search(rmx_batch *b, int32_t nreq, const int32_t *restarts, int32_
     // and the whole grid in ONE launch.
     const bool table_free = (mask == CM_LT0 || mask == CM_LT1 || mask == CM_LA0 || mask == CM_LA1) && nreq <= 16 && G <= 32 &&
                             (param_id == RMX_P_NEGBIN_R_0 || param_id == RMX_P_NEGBIN_R_1 || param_id == RMX_P_BETABIN_M_0 || param_id == RMX_P_BETABIN_M_1) &&
-                            !getenv("RMX_SEARCH_TABLES");
+                            b->opt[RMX_OPT_SEARCH_MODE] != 2;
     std::vector<double> lastval(nreq, grid[0]);
     const bool sparse_search = ell_sparse_ok(b, nreq, restarts);
     auto search_eval = [&](int n_, const int *who, const double *v_, int Gz, bool per_request, double *o_) -> int {
@@ -1762,7 +1792,7 @@ int rmx_param_search(rmx_batch *b, int32_t nreq, const int32_t *restarts, int32_
     // (taken from the other restart group's sweeps) than the halved round count returns (measured on
     // MI355X at the benchmark shape: 69.3 ms per step with, 66.2 ms without).
     constexpr int LOOK = 4;
-    const bool lookahead = table_free && getenv("RMX_SEARCH_LOOKAHEAD");
+    const bool lookahead = table_free && b->opt[RMX_OPT_SEARCH_MODE] == 3;
     struct Seen { double x[LOOK], f[LOOK]; int n = 0; };
     std::vector<Seen> seen(nreq);
     auto pump = [&](int i, double f) {
@@ -2060,6 +2090,19 @@ int rmx_log_likelihood_total(rmx_batch *b, int32_t r, int32_t n, int32_t s, int3
 int rmx_log_likelihood_allele(rmx_batch *b, int32_t r, int32_t n, int32_t s, int32_t v, int32_t w, double *out) { BIND(b);
     double o[6]; int rc = cell_probe(b, r, n, s, o); if (rc) return rc; *out = o[2 + (v ? 2 : 0) + (w ? 1 : 0)]; return RMX_OK;
 }
+int rmx_cell_quantity(rmx_batch *b, int32_t r, int32_t n, int32_t s, int32_t which, int32_t u, int32_t v, int32_t w, double *out) { BIND(b);
+    if (!b || !out || r < 0 || r >= b->R || n < 0 || n >= b->d.N || s < 0 || s >= b->d.S || which < 0 || which > 6) return fail(RMX_EARG, "index out of range");
+    static const int want[7] = {1, 1, 2, 2, 4, 8, 16}, off[7] = {0, 1, 5, 6, 10, 11, 15}, cnt_m[7] = {0, 1, 0, 1, 0, 1, 1};
+    int rc = ensure_tables(b, r, r + 1, false);      // publishes h / the parameters to the device copy the probe reads
+    if (rc) return rc;
+    double *dst = b->d_grid_out + (size_t)r * 64 * (1 + RMX_MAX_CLONES);      // the restart's scratch row
+    hipLaunchKernelGGL(k_cell_probe_h, dim3(1), dim3(1), 0, b->stream, b->d, r, n, s, u ? 1 : 0, v ? 1 : 0, w ? 1 : 0, want[which], dst);
+    HIPCHK(hipMemcpyAsync(b->h_pinned, dst, 19 * 8, hipMemcpyDeviceToHost, b->stream));
+    if ((rc = check_errors(b, r, r + 1))) return rc;
+    const int cnt = cnt_m[which] ? b->d.M : 1;
+    for (int i = 0; i < cnt; i++) out[i] = b->h_pinned[off[which] + i];
+    return RMX_OK;
+}
 
 // ---- decoding -----------------------------------------------------------------------------
 static int viterbi_P(int S) { int P = 1; while (S * P * 2 <= 1024 && P < 64) P *= 2; return P; }
@@ -2077,7 +2120,7 @@ static int viterbi_paths(rmx_batch *b, int r0, int nr, std::vector<int64_t> &pat
         b->vit_cap = nr;
     }
     const int Pr = viterbi_reg_P(S), QPT = (S + Pr - 1) / Pr;
-    const bool reg = QPT <= 44 && !getenv("RMX_VITERBI_PLAIN");
+    const bool reg = QPT <= 44 && !b->opt[RMX_OPT_VITERBI_PLAIN];
     // code-table lattice (k_viterbi_code): V rows, breakend table, value table, S rows of P * QPT4 codes
     const int QPT4 = ((QPT + 3) / 4) * 4;
     const size_t code_lds = b->vit_code_ok ? (size_t)(2 * (Pr * QPT4 + 4) + ((M * d.D + 1) & ~1) + 256) * 8 + (size_t)S * Pr * QPT4 : (size_t)1 << 30;
@@ -2088,7 +2131,7 @@ static int viterbi_paths(rmx_batch *b, int r0, int nr, std::vector<int64_t> &pat
           if (QPT <= 8) VREG(8); else if (QPT <= 16) VREG(16); else if (QPT <= 24) VREG(24); else if (QPT <= 32) VREG(32);
           else if (QPT <= 36) VREG(36); else if (QPT <= 40) VREG(40); else VREG(44);
 #undef VREG
-      } else if (code_lds <= kLdsBudget && !getenv("RMX_VITERBI_PLAIN")) {
+      } else if (code_lds <= kLdsBudget && !b->opt[RMX_OPT_VITERBI_PLAIN]) {
           const int NT = ((S * Pr + 63) / 64) * 64;
           HIPCHK(hipFuncSetAttribute((const void *)k_viterbi_code, hipFuncAttributeMaxDynamicSharedMemorySize, (int)code_lds));
           hipLaunchKernelGGL(k_viterbi_code, dim3(nr), dim3(NT), code_lds, b->stream, b->d, r0, Pr, QPT4,

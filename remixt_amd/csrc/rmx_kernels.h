@@ -1479,99 +1479,14 @@ __global__ void k_pairwise(Dev d, int r0, int mode, const int32_t *list, double 
 }
 
 // =============================================================================
-// k_pairwise_be: the production form of k_pairwise for breakend adjacencies (mode 0).
-// Thread i owns row i of the pairwise posterior joint[i][j] = fa[i] * W[i][j] * g[j] and walks j.
-// For a fixed row the histogram key  tot_i,c - tot_j,c  depends on j only through tot_j,c, so each
-// thread accumulates into PRIVATE LDS bins indexed by tot_j,c (no atomics, fixed order); the bins are
-// folded into the per-distance histogram afterwards in thread order.  The weights come from the
-// exponentiated distance tables (no exp per pair) and the expectation of log_transmat is rebuilt from
-// the histogram:  sum joint*T = -pen * ( sum_c sum_d hist_c[d] * pd_c[d] + sum joint*a ).
-// grid (NBE, nr), block NT = ceil(S/64)*64, dynamic LDS.
-// =============================================================================
-__global__ void k_pairwise_be(Dev d, int r0) {
-    extern __shared__ __align__(16) unsigned char smem_raw[];
-    __shared__ double scratch[16];
-    __shared__ double zsh, jash;
-    const int r = r0 + blockIdx.y, slot = blockIdx.x;
-    const int n = d.be_n[slot];
-    const int S = d.S, M = d.M, D = d.D, t = threadIdx.x, NT = blockDim.x;
-    const int NB = d.cn_max + 2;                          // totals 0 .. cn_max+1
-    const int tc = d.tclass[n];
-    const int ca = d.seg_class[n], cb = d.seg_class[n + 1];
-    double *gvec = (double *)smem_raw;                    // [S]
-    double *pe = gvec + ((S + 1) & ~1);                   // [M*D] exp(-pen*pd_lt), 1 for a telomere
-    double *wa = pe + ((M * D + 1) & ~1);                 // [128]
-    double *bins = wa + 128;                              // [NT][M][NB]
-    int *totb = (int *)(bins + (size_t)NT * M * NB);      // [S] totals of the j-side states, one byte per clone
-    const double *fb = d.fb + rs_off(d, r, n + 1), *fe = d.fe + rs_off(d, r, n + 1);
-    for (int j = t; j < S; j += NT) {
-        gvec[j] = fe[j] * fb[j];
-        int pk = 0;
-        for (int c = 0; c < M; c++) pk |= ((int)d.tot[((size_t)cb * S + j) * M + c] & 0xff) << (8 * c);
-        totb[j] = pk;
-    }
-    const double *peg = d.pe_lt + ((size_t)r * d.NBE + slot) * ((M * D + 1) & ~1);
-    for (int i = t; i < M * D; i += NT) pe[i] = tc >= 0 ? peg[i] : 1.0;
-    for (int i = t; i < 128; i += NT) wa[i] = tc >= 0 ? exp(-d.pen * (double)i) : 1.0;
-    double *mybins = bins + (size_t)t * M * NB;
-    for (int i = 0; i < M * NB; i++) mybins[i] = 0.;
-    __syncthreads();
-    double z = 0., ja = 0.;
-    if (t < S) {
-        const double fai = d.fa[rs_off(d, r, n) + t];
-        int ta[RMX_MAX_CLONES];
-#pragma unroll
-        for (int c = 0; c < RMX_MAX_CLONES; c++) ta[c] = c < M ? (int)d.tot[((size_t)ca * S + t) * M + c] + d.cn_max + 1 : 0;
-        const int8_t *arow = tc >= 0 ? d.af + ((size_t)tc * S + t) * S : nullptr;
-        for (int j = 0; j < S; j++) {
-            const int a = arow ? (int)arow[j] : 0;
-            const int pk = totb[j];
-            double w = wa[a];
-#pragma unroll
-            for (int c = 0; c < RMX_MAX_CLONES; c++) if (c < M) w *= pe[c * D + ta[c] - ((pk >> (8 * c)) & 0xff)];
-            const double J = fai * w * gvec[j];
-            z += J; ja += J * (double)a;
-#pragma unroll
-            for (int c = 0; c < RMX_MAX_CLONES; c++) if (c < M) unsafeAtomicAdd(&mybins[c * NB + ((pk >> (8 * c)) & 0xff)], J);   // private address: a fire-and-forget ds_add_f64, no read latency
-        }
-    }
-    // deterministic block sums
-    z = group_sum(z, 64); ja = group_sum(ja, 64);
-    if ((t & 63) == 0) { scratch[t >> 6] = z; scratch[8 + (t >> 6)] = ja; }
-    __syncthreads();
-    if (t == 0) { double zz = 0., aa = 0.; for (int w_ = 0; w_ < NT / 64; w_++) { zz += scratch[w_]; aa += scratch[8 + w_]; } zsh = zz; jash = aa; }
-    __syncthreads();
-    const double zz = zsh;
-    // fold the private bins: hist[c][d] = sum_i bins[i][c][tot_i,c - d]
-    double *hist = d.hist + ((size_t)r * d.NBE + slot) * M * D;
-    for (int i = t; i < M * D; i += NT) {
-        const int c = i / D, dv = i % D - (d.cn_max + 1);
-        double acc = 0.;
-        for (int row = 0; row < S; row++) {
-            const int tj = (int)d.tot[((size_t)ca * S + row) * M + c] - dv;
-            if (tj >= 0 && tj < NB) acc += bins[((size_t)row * M + c) * NB + tj];
-        }
-        hist[i] = acc / zz;
-    }
-    __syncthreads();
-    if (t == 0) {
-        d.be_ja[(size_t)r * d.NBE + slot] = jash / zz;
-        double jt = 0.;
-        if (tc >= 0) {
-            const double *pd = d.pd_lt + ((size_t)r * d.NBE + slot) * M * D;
-            for (int i = 0; i < M * D; i++) jt += hist[i] * (-d.pen * pd[i]);
-            jt += -d.pen * (jash / zz);
-        }
-        d.be_jt[(size_t)r * d.NBE + slot] = jt;
-    }
-}
-
-// =============================================================================
-// k_pairwise_be2: k_pairwise_be with the weight of a state pair taken from the per-breakend clone-product
+// k_pairwise_be2: the production form of k_pairwise for breakend adjacencies (mode 0).  Thread i owns row i of the
+// pairwise posterior joint[i][j] = fa[i] * W[i][j] * g[j] and walks j, accumulating into PRIVATE LDS bins indexed by the
+// column state's totals (no atomics between threads, fixed order); the expectation of log_transmat is rebuilt from the
+// histogram: sum joint*T = -pen * (sum_c sum_d hist_c[d] * pd_c[d] + sum joint*a).  The weight of a state pair is taken from the per-breakend clone-product
 // table (k_brk_lut) through a precomputed 16-bit pair code, and with the columns walked in the order of
 // their tumour-clone totals (t1, t2): the histogram contribution of a whole run of equal totals is
 // flushed to the thread's private bins once per run (about S/3 + 9 LDS adds per row at M = 3 instead
-// of 3 S).  M in {2, 3}; same reductions downstream as k_pairwise_be.
+// of 3 S).  M in {2, 3}.
 // grid (NBE, nr), block NT = ceil(S/64)*64, dynamic LDS.
 // =============================================================================
 __global__ void k_pairwise_be2(Dev d, int r0, int PE2P, int SPC) {
@@ -2249,6 +2164,67 @@ __global__ void k_cell_probe(Dev d, int r, int n, int s, double *out6) {
     unsigned err = 0; double LT[2], LA[4];
     cell_ll(d, rp, sc, r, d.seg_class[n], s, LT, LA, err);
     out6[0] = LT[0]; out6[1] = LT[1]; out6[2] = LA[0]; out6[3] = LA[1]; out6[4] = LA[2]; out6[5] = LA[3];
+    if (err) atomicOr(&d.err[r], err);
+}
+
+// The other per-cell cpdef methods of RemixtModel for one (segment n, state s), reference accumulation order:
+//   out[0]            calculate_expected_total_reads                     (bpmodel.pyx:686-698)
+//   out[1 .. 1+M)     calculate_expected_total_reads_partial_h           (:700-708)
+//   out[5]            calculate_expected_allele_ratio                    (:710-725)  [error: total_depth <= 0]
+//   out[6 .. 6+M)     calculate_expected_allele_ratio_partial_h          (:727-745)
+//   out[10]           calculate_log_prior_cn                             (:747-750)
+//   out[11 .. 11+M)   calculate_log_likelihood_total_partial_h (u)       (:778-807)
+//   out[15 .. 15+M)   calculate_log_likelihood_allele_partial_h (v, w)   (:855-896)
+// `want` selects which groups are evaluated (bit 0: total reads, 1: allele ratio, 2: prior, 3: d ll_total, 4: d ll_allele),
+// so that a query raises only the errors the reference's method would raise.
+__global__ void k_cell_probe_h(Dev d, int r, int n, int s, int u, int v, int w, int want, double *out) {
+    const RestartParams &rp = d.rp[r];
+    const int cls = d.seg_class[n], M = d.M;
+    const int8_t *cn = d.cn + ((size_t)cls * d.S + s) * M * 2;
+    const int8_t *tot = d.tot + ((size_t)cls * d.S + s) * M;
+    const unsigned sf = d.sflags[(size_t)cls * d.S + s];
+    const double l = d.l[n];
+    unsigned err = 0;
+    for (int i = 0; i < 19; i++) out[i] = 0.;
+    double mu = 0.;
+    for (int m = 0; m < M; m++) mu += rp.h[m] * (double)tot[m];
+    mu *= l;
+    if (want & 1) { out[0] = mu; for (int m = 0; m < M; m++) out[1 + m] = l * (double)tot[m]; }
+    double minor = 0., total = 0.;
+    for (int m = 0; m < M; m++) { minor += rp.h[m] * (double)cn[m * 2]; total += rp.h[m] * (double)tot[m]; }
+    if (want & 2) {
+        if (total <= 0.) err |= RMX_ERR_TOTAL_DEPTH;
+        else {
+            out[5] = minor / total;
+            for (int m = 0; m < M; m++) out[6 + m] = ((double)cn[m * 2] * total - minor * (double)tot[m]) / (total * total);
+        }
+    }
+    if (want & 4) out[10] = -1.0 * (double)((sf >> 2) & 3) * l * rp.p[RMX_P_DIVERGENCE_WEIGHT];
+    if ((want & 8) && d.mask_t[n] && !(!d.nc && (sf & 1u))) {
+        const double rr = u == 0 ? rp.p[RMX_P_NEGBIN_R_0] : rp.p[RMX_P_NEGBIN_R_1];
+        const double x = d.x[n];
+        const double pm = x / mu - (rr + x) / (rr + mu);
+        if (pm != pm) err |= RMX_ERR_NAN_GRAD;
+        for (int m = 0; m < M; m++) out[11 + m] = (l * (double)tot[m]) * pm;
+    }
+    if ((want & 16) && d.mask_a[n] && !(!d.nc && (sf & 2u))) {
+        if (total <= 0.) err |= RMX_ERR_TOTAL_DEPTH;
+        else {
+            const double p = minor / total;
+            const double Mv = v == 0 ? rp.p[RMX_P_BETABIN_M_0] : rp.p[RMX_P_BETABIN_M_1];
+            const double y0 = d.y[2 * (size_t)n], y1 = d.y[2 * (size_t)n + 1], ys = y0 + y1;
+            if (ys != 0.) {
+                const double k = w == 0 ? y0 : y1;
+                if (p <= 0. || (1 - p) <= 0.) err |= RMX_ERR_BAD_P;
+                else {
+                    const double pp = (Mv * digamma_as103(k + Mv * p, err) + (-Mv) * digamma_as103(ys - k + Mv * (1 - p), err)
+                                       - Mv * digamma_as103(Mv * p, err) - (-Mv) * digamma_as103(Mv * (1 - p), err));
+                    if (pp != pp) err |= RMX_ERR_NAN_GRAD;
+                    for (int m = 0; m < M; m++) out[15 + m] = (((double)cn[m * 2] * total - minor * (double)tot[m]) / (total * total)) * pp;
+                }
+            }
+        }
+    }
     if (err) atomicOr(&d.err[r], err);
 }
 

@@ -20,12 +20,14 @@ class RestartSet(object):
     """R restarts of one experiment advancing in lockstep on one device."""
 
     def __init__(self, experiment, init_params, max_copy_number, num_clones=3, device=0, quiet=True,
-                 kernel_module=None, seeds=None, strict=False, mstep_threads=8, lockstep=True, native_search=True, **model_kwargs):
+                 kernel_module=None, seeds=None, strict=False, mstep_threads=8, lockstep=True, native_search=True, sample_prep=True,
+                 options=None, h_init=None, **model_kwargs):
         self.experiment = experiment
         self.native_search = native_search
         self.strict = strict
         self.mstep_threads = mstep_threads
         self.lockstep = lockstep
+        self.sample_prep = sample_prep      # draw the M-step samples on a helper thread while the device works
         self.error_messages = {}
         self.init_params = list(init_params)
         R = len(self.init_params)
@@ -46,7 +48,11 @@ class RestartSet(object):
                 experiment.x, experiment.l, experiment.adjacencies, experiment.breakpoints,
                 max_copy_number=max_copy_number, divergence_weight=p['divergence_weight'], max_depth=p['max_depth'],
                 kernel_module=kernel_module, device=device, quiet=quiet, rng=rng, remap_cache=remap_cache, **model_kwargs))
-        self.h_init = np.array([synthetic.h_init_from_params(p, num_clones) for p in self.init_params])
+        # initial haploid depths: analysis/pipeline.py:128-132 from each restart's init parameters unless given (R, M)
+        if h_init is not None:
+            self.h_init = np.asarray(h_init, dtype=float).reshape(R, num_clones)
+        else:
+            self.h_init = np.array([synthetic.h_init_from_params(p, num_clones) for p in self.init_params])
         m0 = self.models[0]
         kern = m0._kernel_module()
         self.batch = None
@@ -58,6 +64,8 @@ class RestartSet(object):
                 self.h_init, m0.l1, m0.x1[:, 2].copy(), m0.x1[:, 0:2].copy(), m0.is_telomere, m0.breakpoint_idx,
                 m0.breakpoint_orient, m0.transition_log_prob, [p['divergence_weight'] for p in self.init_params],
                 device=device)
+            for name, value in (options or {}).items():      # tuning options of the batch (tests, A/B measurements)
+                self.batch.set_option(name, value)
             for r, m in enumerate(self.models):
                 m._attach_model(self.batch.model(r))
         else:
@@ -96,7 +104,7 @@ class RestartSet(object):
         # the h M-step's (unweighted) samples are the first draws of the iteration whatever the sweeps give:
         # a helper thread draws them while this thread waits on the sweeps
         self._h_prefetch = None
-        if h_lockstep and any(m.do_h_update for m in self.models) and not os.environ.get('RMX_NO_SAMPLE_PREP'):
+        if h_lockstep and any(m.do_h_update for m in self.models) and self.sample_prep:
             if getattr(self, '_prep_pool', None) is None:
                 from concurrent.futures import ThreadPoolExecutor
                 self._prep_pool = ThreadPoolExecutor(max_workers=1)
@@ -171,14 +179,13 @@ class RestartSet(object):
 
     def _multi_param_names(self):
         """The leading standard likelihood parameters, whose searches can share their rounds."""
-        import os
         b = self.batch
         first = []
         for name in self.models[0].likelihood_params:
             if name not in self._MULTI_PARAMS or len(first) == 4:
                 break
             first.append(name)
-        sequential = any(os.environ.get(k) for k in ('RMX_SEARCH_SEQUENTIAL', 'RMX_SEARCH_TABLES', 'RMX_SEARCH_FULL', 'RMX_SEARCH_LOOKAHEAD'))
+        sequential = b is not None and hasattr(b, 'get_option') and b.get_option('search_mode') != 0
         if not (first and self.native_search and b is not None and hasattr(b, 'param_search_multi')) or sequential:
             return []
         return first
@@ -202,10 +209,9 @@ class RestartSet(object):
         return samples, ind
 
     def _start_param_sample_prep(self):
-        import os
         self._param_prep = None
         names = self._multi_param_names()
-        if not names or os.environ.get('RMX_NO_SAMPLE_PREP'):
+        if not names or not self.sample_prep:
             return
         if getattr(self, '_prep_pool', None) is None:
             from concurrent.futures import ThreadPoolExecutor

@@ -11,6 +11,9 @@ GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
 STEPS = ['update_p_allele_swap', 'update_p_cn', 'update_p_breakpoint', 'update_p_outlier_total', 'update_p_outlier_allele']
 STATE = ['framelogprob', 'posterior_marginals', 'p_breakpoint', 'p_outlier_total', 'p_outlier_allele', 'p_allele_swap']
 MODEL_CASES = ['model_m2', 'model_m3', 'model_nonormal', 'model_malex']
+# the benchmark's state grids (165 / 355 states) and the protocol's dark corners, K >= 8 breakpoints, two breakends at
+# one boundary, dense arrays not recorded (oracle/make_golden.py grid_case)
+GRID_CASES = ['grid_s165', 'grid_s355', 'grid_tmodel1', 'grid_m4', 'grid_nobrk']
 
 
 def load(name):
@@ -26,6 +29,10 @@ def inputs(g):
     kw = dict(max_copy_number=int(g['max_copy_number']), divergence_weight=float(g['divergence_weight']),
               max_depth=float(g['max_depth']), normal_contamination=bool(g['normal_contamination']),
               normal_copies=g['normal_copies'])
+    if 'transition_model' in g.files:
+        kw['transition_model'] = int(g['transition_model'])
+    if 'disable_breakpoints' in g.files:
+        kw['disable_breakpoints'] = bool(g['disable_breakpoints'])
     return g['x'], g['l'], adjacencies, breakpoints, kw
 
 
@@ -100,6 +107,60 @@ def replay(name, kernel, rtol, atol, dense=True, cells=True):
     cn2, brk = m.optimal_cn()
     assert np.array_equal(cn2, g['optimal_cn'])
     assert np.array_equal(np.array([brk[str(k)] for k in g['breakpoint_ids']]), g['brk_cn'])
+    return m
+
+
+def replay_grid(name, kernel, rtol, atol, elbo_every_step=True, mixed_elbo=False):
+    """Replay of a grid_*.npz fixture: every recorded quantity after every coordinate update of two sweeps."""
+    g = load(name)
+    m = build(g, kernel)
+    assert np.array_equal(m.is_telomere, g['is_telomere'])
+    assert np.array_equal(m.breakpoint_idx, g['breakpoint_idx']) and np.array_equal(m.breakpoint_orient, g['breakpoint_orient'])
+    m.num_em_iter = 0
+    m.fit(g['h_init'])
+    mod = m.model
+    assert np.array_equal(np.asarray(mod.brk_states), g['brk_states'])
+    check(m.prev_elbo, g['elbo_init'], rtol, atol, 'elbo_init')
+    for (n, s), lt, la in zip(g['cells'], g['cell_ll_total'], g['cell_ll_allele']):
+        for u in range(2):
+            check(mod.calculate_log_likelihood_total(int(n), int(s), u), lt[u], rtol, atol, 'll_total')
+        for v in range(2):
+            for w in range(2):
+                check(mod.calculate_log_likelihood_allele(int(n), int(s), v, w), la[v * 2 + w], rtol, atol, 'll_allele')
+    tm1 = int(g['transition_model']) == 1
+    for sweep in range(2):
+        for step in STEPS:
+            getattr(mod, step)()
+            pre = 's%d/%s/' % (sweep, step)
+            for a in ('p_breakpoint', 'p_outlier_total', 'p_outlier_allele', 'p_allele_swap', 'posterior_marginals', 'framelogprob'):
+                if pre + a in g.files:
+                    check(getattr(mod, a), g[pre + a], rtol, atol, pre + a)
+            check(mod.hmm_log_norm_const, g[pre + 'hmm_log_norm_const'], rtol, atol, pre + 'logZ')
+            # transition_model = 1, first sweep: between update_p_cn (log_transmat under model 1) and update_p_breakpoint
+            # (cached_log_transmat still the constructor's model-0 tables) energy and entropy read different tables at
+            # every plain adjacency; kernels that never materialise them refuse that one state (DESIGN.md 2)
+            mixed = tm1 and sweep == 0 and step == 'update_p_cn'
+            if elbo_every_step and (mixed_elbo or not mixed):
+                check(mod.calculate_elbo(), g[pre + 'elbo'], rtol, atol, pre + 'elbo')
+    M = int(g['num_clones'])
+    ones = np.ones(m.N1, dtype=np.int64)
+    check(mod.calculate_expected_log_likelihood(g['sample']), g['ell_sample'], rtol, atol, 'ell_sample')
+    check(mod.calculate_expected_log_likelihood(ones), g['ell_all'], rtol, atol, 'ell_all')
+    ga = np.zeros(M)
+    mod.calculate_expected_log_likelihood_partial_h(g['sample'], ga)
+    check(ga, g['grad_sample'], max(rtol, 1e-9), 1e-6, 'grad_sample')
+    cn = np.zeros((m.N1, M, 2), dtype=int)
+    mod.infer_cn(cn)
+    assert np.array_equal(cn, g['infer_cn']), 'Viterbi decode differs'
+    cn2, brk = m.optimal_cn()
+    assert np.array_equal(cn2, g['optimal_cn'])
+    if 'brk_cn' in g.files:
+        assert np.array_equal(np.array([brk[str(k)] for k in g['breakpoint_ids']]), g['brk_cn'])
+    if 'brk_cn_naive' in g.files:
+        from remixt_amd.cn_model import decode_breakpoints_naive
+        x, l, adj, brks, kw = inputs(g)
+        naive = decode_breakpoints_naive(cn2, adj, brks)
+        assert np.array_equal(np.array([naive[str(k)] for k in g['breakpoint_ids']]), g['brk_cn_naive'])
     return m
 
 

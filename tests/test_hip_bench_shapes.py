@@ -1,0 +1,238 @@
+"""GPU parity on the shapes the benchmark runs ("what's weak" 1-3): the HIP path against the CPU oracle at
+165 and 355 states, several restarts per forward-backward workgroup, dozens of breakend adjacencies (two of them at one
+boundary) -- posteriors, p_breakpoint, log Z and ELBO after EVERY coordinate update, not only decoded paths -- and the
+protocol's rarely used corners: transition_model = 1, four clones, disable_breakpoints, breakpoint_init, check_elbo.
+
+Tolerance: 1e-6 relative is the requirement (north_star); asserted at 1e-8 / 1e-9.  Viterbi paths bit-exact."""
+import numpy as np
+import pytest
+
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+STEPS = ('update_p_allele_swap', 'update_p_cn', 'update_p_breakpoint', 'update_p_outlier_total', 'update_p_outlier_allele')
+ARRAYS = ('posterior_marginals', 'p_breakpoint', 'p_outlier_total', 'p_outlier_allele', 'p_allele_swap', 'framelogprob')
+
+
+@pytest.fixture(scope='module')
+def hip():
+    from remixt_amd import bpmodel
+    return bpmodel
+
+
+def _two_sets(oracle_mod, e, ps, max_cn, M, options=None, **kw):
+    from remixt_amd.restarts import RestartSet
+    dev = RestartSet(e, ps, max_copy_number=max_cn, num_clones=M, quiet=True, options=options, **kw)
+    ora = RestartSet(e, ps, max_copy_number=max_cn, num_clones=M, quiet=True, kernel_module=oracle_mod, **kw)
+    return dev, ora
+
+
+def _compare_after_every_update(dev, ora, sweeps=2, elbo_rtol=1e-8):
+    b = dev.batch
+    R = len(dev.models)
+    np.testing.assert_allclose(b.calculate_elbo(), [m.model.calculate_elbo() for m in ora.models], rtol=1e-9)
+    for sweep in range(sweeps):
+        for step in STEPS:
+            getattr(b, step)()                                 # all restarts in ONE launch sequence
+            for m in ora.models:
+                getattr(m.model, step)()
+            tag = 'sweep %d %s' % (sweep, step)
+            for r in range(R):
+                for name in ARRAYS:
+                    got, want = b.get_array(r, name), np.asarray(getattr(ora.models[r].model, name))
+                    assert got.shape == want.shape
+                    assert H.close(got, want, rtol=1e-8, atol=1e-11), '%s restart %d %s: max rel err %.3e' % (tag, r, name, H.maxerr(got, want))
+                assert np.isclose(b.get_param(r, 'hmm_log_norm_const'), ora.models[r].model.hmm_log_norm_const, rtol=1e-10), tag
+            np.testing.assert_allclose(b.calculate_elbo(), [m.model.calculate_elbo() for m in ora.models], rtol=elbo_rtol, err_msg=tag)
+    cn, _ = b.infer_cn_batch(0, R)
+    for r in range(R):
+        ref = np.zeros_like(cn[r]); ora.models[r].model.infer_cn(ref)
+        assert np.array_equal(cn[r], ref), 'Viterbi path of restart %d differs' % r
+
+
+@pytest.mark.parametrize('R,NV', [(4, 4), (8, 2), (8, 4), (3, 2)])
+def test_s165_restart_batch_with_dense_breakends_matches_oracle(hip, oracle_mod, R, NV):
+    """165 states, R restarts in one batch on the benchmark's launch shapes (NV = 2: two restart groups of 8; NV = 4: one
+    group of 16; (3, 2): a ragged last workgroup), 24 breakpoints + two sharing a boundary on 110 segments -> ~50 breakend
+    adjacencies, i.e. every other step of k_fbv takes the breakend branch, and k_pairwise / k_brk_lut see all of them."""
+    from remixt_amd import synthetic
+    e = synthetic.make_experiment(110, num_clones=3, max_copy_number=8, num_chains=2, seed=31, num_breakpoints=24)
+    e.breakpoints = H.add_shared_boundary_breakpoints(e)
+    ps = synthetic.make_init_params(e, R, 8)
+    dev, ora = _two_sets(oracle_mod, e, ps, 8, 3, options={'fb_nv': NV})
+    b = dev.batch
+    assert b.num_cn_states == 165 and b.info(3) >= 48 and b.info(10) == 2 and b.info(11) == 0      # breakend adjacencies; both chains on k_fbv
+    _compare_after_every_update(dev, ora)
+
+
+def test_s165_generic_kernel_and_plain_breakend_tables_match_oracle(hip, oracle_mod):
+    """The same problem through the kernels the defaults do not select: general forward-backward kernel, breakend steps
+    from per-clone distance tables, the general pairwise kernel."""
+    from remixt_amd import synthetic
+    e = synthetic.make_experiment(90, num_clones=3, max_copy_number=8, num_chains=2, seed=33, num_breakpoints=12)
+    e.breakpoints = H.add_shared_boundary_breakpoints(e)
+    ps = synthetic.make_init_params(e, 2, 8)
+    for options in ({'fb_kernel': 1}, {'fb_breakend_codes': 0, 'fb_nv': 2}, {'pairwise_kernel': 1}):
+        dev, ora = _two_sets(oracle_mod, e, ps, 8, 3, options=options)
+        _compare_after_every_update(dev, ora, sweeps=1)
+
+
+@pytest.mark.parametrize('options', [{}, {'fb_nv': 4}, {'fb_kernel': 2}, {'viterbi_plain': 1}])
+def test_s355_matches_oracle(hip, oracle_mod, options):
+    """355 states (max_cn = 12, the "~400 states" of BASELINE's metric): k_fbk (weights rebuilt from packed copy numbers), the
+    general kernel on tabulated weights, k_viterbi_code and the plain lattice, each against the oracle -- not against each other."""
+    from remixt_amd import synthetic
+    R = 4 if options.get('fb_nv') == 4 else 2
+    e = synthetic.make_experiment(44, num_clones=3, max_copy_number=12, num_chains=2, seed=41, num_breakpoints=8)
+    e.breakpoints = H.add_shared_boundary_breakpoints(e)
+    ps = synthetic.make_init_params(e, R, 12)
+    dev, ora = _two_sets(oracle_mod, e, ps, 12, 3, options=options)
+    assert dev.batch.num_cn_states == 355 and dev.batch.info(3) >= 16
+    _compare_after_every_update(dev, ora)
+
+
+@pytest.mark.parametrize('max_cn', [3, 6])
+def test_transition_model_1_matches_oracle(hip, oracle_mod, max_cn):
+    """transition_model = 1 (bpmodel.pyx:606-616: 0/1 cost per changed copy number instead of |d|), set after construction
+    like cn_model.py:404: the plain tables are rebuilt, the SAD closed form of k_fbk no longer applies, breakend tables use
+    the other cost.  ELBO is compared where the reference's two snapshots belong to the same model."""
+    a, h, _ = H.make_model(hip, N=80, M=3, max_cn=max_cn, chains=3, seed=50 + max_cn, transition_model=1)
+    b, _, _ = H.make_model(oracle_mod, N=80, M=3, max_cn=max_cn, chains=3, seed=50 + max_cn, transition_model=1)
+    ma, mb = H.attach(a, h), H.attach(b, h)
+    assert ma.transition_model == 1 and mb.transition_model == 1
+    assert np.isclose(ma.calculate_elbo(), mb.calculate_elbo(), rtol=1e-9)          # still the constructor's model-0 snapshot
+    for it in range(2):
+        for step in STEPS:
+            getattr(ma, step)(); getattr(mb, step)()
+            H.compare_models(ma, mb, dense=(it == 0 and max_cn == 3), tag='%d/%s' % (it, step))
+            if not (it == 0 and step == 'update_p_cn'):
+                assert np.isclose(ma.calculate_elbo(), mb.calculate_elbo(), rtol=1e-8), (it, step)
+        assert np.isclose(ma.hmm_log_norm_const, mb.hmm_log_norm_const, rtol=1e-10)
+    if max_cn == 3:
+        with pytest.raises(NotImplementedError):
+            # the one unsupported state: energy and entropy read tables of different models at every plain adjacency
+            c, hc, _ = H.make_model(hip, N=80, M=3, max_cn=max_cn, chains=3, seed=50 + max_cn, transition_model=1)
+            mc = H.attach(c, hc)
+            mc.update_p_cn()
+            mc.calculate_elbo()
+    cna = np.zeros((ma.num_segments, 3, 2), dtype=int); cnb = cna.copy()
+    ma.infer_cn(cna); mb.infer_cn(cnb)
+    assert np.array_equal(cna, cnb)
+
+
+def test_transition_model_1_at_355_states_deselects_the_closed_form_kernel(hip, oracle_mod):
+    from remixt_amd import synthetic
+    e = synthetic.make_experiment(40, num_clones=3, max_copy_number=12, num_chains=2, seed=43, num_breakpoints=6)
+    ps = synthetic.make_init_params(e, 2, 12)
+    dev, ora = _two_sets(oracle_mod, e, ps, 12, 3, transition_model=1)
+    for m in ora.models:
+        assert m.model.transition_model == 1
+    b = dev.batch
+    assert b.transition_model == 1
+    for step in STEPS:
+        getattr(b, step)()
+        for m in ora.models:
+            getattr(m.model, step)()
+    for r in range(2):
+        for name in ARRAYS:
+            assert H.close(b.get_array(r, name), np.asarray(getattr(ora.models[r].model, name)), rtol=1e-8, atol=1e-11), name
+    np.testing.assert_allclose(b.calculate_elbo(), [m.model.calculate_elbo() for m in ora.models], rtol=1e-8)
+
+
+@pytest.mark.parametrize('max_cn,N', [(2, 90), (3, 60)])
+def test_four_clones_match_oracle(hip, oracle_mod, max_cn, N):
+    """num_clones = 4 (RMX_MAX_CLONES): 3 tumour clones, 117 states at max_cn = 3."""
+    from remixt_amd import synthetic
+    e = synthetic.make_experiment(N, num_clones=4, max_copy_number=max_cn, num_chains=2, seed=60 + max_cn, num_breakpoints=8)
+    e.breakpoints = H.add_shared_boundary_breakpoints(e)
+    ps = synthetic.make_init_params(e, 2, max_cn, num_clones=4)
+    hs = [np.array([p['h_normal']] + [p['h_tumour'] * f for f in (0.5, 0.3, 0.2)]) for p in ps]
+    from remixt_amd.restarts import RestartSet
+    sets = []
+    for kern in (None, oracle_mod):
+        rs = RestartSet(e, ps, max_copy_number=max_cn, num_clones=4, quiet=True, kernel_module=kern, h_init=hs)
+        sets.append(rs)
+    dev, ora = sets
+    assert dev.batch.num_clones == 4
+    _compare_after_every_update(dev, ora)
+    # the M-step objectives with a 4-vector gradient
+    sample = (np.random.RandomState(1).rand(dev.batch.num_segments) < 0.4).astype(int)
+    for r in range(2):
+        ma, mb = dev.models[r].model, ora.models[r].model
+        assert np.isclose(ma.calculate_expected_log_likelihood(sample), mb.calculate_expected_log_likelihood(sample), rtol=1e-9)
+        ga, gb = np.zeros(4), np.zeros(4)
+        ma.calculate_expected_log_likelihood_partial_h(sample, ga); mb.calculate_expected_log_likelihood_partial_h(sample, gb)
+        assert np.allclose(ga, gb, rtol=1e-7, atol=1e-6)
+
+
+def test_disable_breakpoints_fit_matches_oracle(hip, oracle_mod):
+    """disable_breakpoints=True (cn_model.py:187-190): num_breakpoints = 0, no breakend adjacency anywhere, naive breakpoint
+    decoding afterwards (analysis/pipeline.py:205-206)."""
+    from remixt_amd.cn_model import decode_breakpoints_naive
+    res = []
+    for kern in (hip, oracle_mod):
+        m, h, e = H.make_model(kern, N=200, M=3, max_cn=4, chains=4, seed=71, disable_breakpoints=True)
+        m.num_em_iter = 2; m.num_update_iter = 2
+        np.random.seed(5)
+        m.fit(h)
+        assert m.model.num_breakpoints == 0 and np.asarray(m.model.p_breakpoint).shape[0] == 0
+        cn, brk = m.optimal_cn()
+        assert brk == {}
+        res.append((m.prev_elbo, np.array(m.h), cn, decode_breakpoints_naive(cn, e.adjacencies, e.breakpoints), np.array(m.p_outlier_total)))
+    (e1, h1, c1, b1, q1), (e2, h2, c2, b2, q2) = res
+    assert np.isclose(e1, e2, rtol=1e-6) and np.allclose(h1, h2, rtol=1e-5) and np.array_equal(c1, c2)
+    assert all(np.array_equal(b1[k], b2[k]) for k in b1) and np.allclose(q1, q2, rtol=1e-5, atol=1e-8)
+
+
+def test_breakpoint_init_and_check_elbo_match_oracle(hip, oracle_mod):
+    """breakpoint_init (cn_model.py:389-402: p_breakpoint seeded before the first sweep -- the device tables that depend on
+    it must follow) and check_elbo=True (:430-442: an ELBO before and after every coordinate update and M-step; raises when
+    one decreases it)."""
+    from remixt_amd import synthetic
+    e = synthetic.make_experiment(160, num_clones=3, max_copy_number=4, num_chains=3, seed=81, num_breakpoints=10)
+    init = dict((bp, np.array([0, 1, 1])) for bp in e.breakpoints.values())
+    res = []
+    for kern in (hip, oracle_mod):
+        m, h, _ = H.make_model(kern, N=160, M=3, max_cn=4, chains=3, seed=81, breakpoint_init=init, experiment=e)
+        mod = H.attach(m, h)
+        p0 = np.asarray(mod.p_breakpoint).copy()
+        assert np.allclose(p0.max(axis=1), 1000. / (1000. + p0.shape[1] - 1))
+        elbo0 = mod.calculate_elbo()
+        m.check_elbo = True
+        m.variational_update()
+        m.prev_elbo = mod.calculate_elbo()
+        np.random.seed(3)
+        m.num_update_iter = 1
+        m.em_iteration(0)
+        res.append((elbo0, p0, np.asarray(mod.p_breakpoint).copy(), np.asarray(mod.posterior_marginals).copy(), m.prev_elbo, np.array(m.h)))
+    (ea, pa, qa, post_a, fa, ha), (eb, pb, qb, post_b, fb, hb) = res
+    assert np.isclose(ea, eb, rtol=1e-9) and np.array_equal(pa, pb)
+    assert H.close(qa, qb, rtol=1e-8, atol=1e-11) and H.close(post_a, post_b, rtol=1e-7, atol=1e-10)
+    assert np.isclose(fa, fb, rtol=1e-6) and np.allclose(ha, hb, rtol=1e-5)
+
+
+def test_per_cell_accessors_match_oracle(hip, oracle_mod):
+    """The per-cell cpdef methods of RemixtModel (bpmodel.pyx:686-749, 778-807, 855-896)."""
+    a, h, _ = H.make_model(hip, N=60, M=3, max_cn=4, chains=2, seed=91)
+    b, _, _ = H.make_model(oracle_mod, N=60, M=3, max_cn=4, chains=2, seed=91)
+    ma, mb = H.attach(a, h), H.attach(b, h)
+    rng = np.random.RandomState(0)
+    for _ in range(40):
+        n, s = int(rng.randint(0, ma.num_segments)), int(rng.randint(0, ma.num_cn_states))
+        assert np.isclose(ma.calculate_expected_total_reads(n, s), mb.calculate_expected_total_reads(n, s), rtol=1e-14)
+        assert np.isclose(ma.calculate_expected_allele_ratio(n, s), mb.calculate_expected_allele_ratio(n, s), rtol=1e-14)
+        assert ma.calculate_log_prior_cn(n, s) == mb.calculate_log_prior_cn(n, s)
+        ga, gb = np.zeros(3), np.zeros(3)
+        ma.calculate_expected_total_reads_partial_h(n, s, ga); mb.calculate_expected_total_reads_partial_h(n, s, gb)
+        assert np.array_equal(ga, gb)
+        ma.calculate_expected_allele_ratio_partial_h(n, s, ga); mb.calculate_expected_allele_ratio_partial_h(n, s, gb)
+        assert np.allclose(ga, gb, rtol=1e-12, atol=1e-15)
+        for u in range(2):
+            ga, gb = np.zeros(3), np.zeros(3)
+            ma.calculate_log_likelihood_total_partial_h(n, s, u, ga); mb.calculate_log_likelihood_total_partial_h(n, s, u, gb)
+            assert np.allclose(ga, gb, rtol=1e-9, atol=1e-9), (n, s, u, ga, gb)
+            for w in range(2):
+                ga, gb = np.zeros(3), np.zeros(3)
+                ma.calculate_log_likelihood_allele_partial_h(n, s, u, w, ga); mb.calculate_log_likelihood_allele_partial_h(n, s, u, w, gb)
+                assert np.allclose(ga, gb, rtol=1e-8, atol=1e-8), (n, s, u, w, ga, gb)

@@ -73,20 +73,20 @@ def test_viterbi_path_is_a_valid_decode_and_repeatable(fullsize):
     assert dominant_ok > 0.9
 
 
-def test_batched_decode_equals_the_per_restart_lattice(fullsize, monkeypatch):
+def test_batched_decode_equals_the_per_restart_lattice(fullsize):
     """rmx_infer_cn_batch (transition values in registers, restarts side by side) against the plain
-    one-restart kernel (RMX_VITERBI_PLAIN): same paths and path log-probabilities, bit for bit."""
+    one-restart kernel (option viterbi_plain): same paths and path log-probabilities, bit for bit."""
     e, rs = fullsize
     b = rs.batch
     b.variational_update(1)
     cn_all, lp_all = b.infer_cn_batch(0, 3)
-    monkeypatch.setenv('RMX_VITERBI_PLAIN', '1')
+    b.set_option('viterbi_plain', 1)
     for r in range(3):
         cn, lp = b.infer_cn(r)
         assert np.array_equal(cn, cn_all[r]) and lp == lp_all[r]
     cn_plain, lp_plain = b.infer_cn_batch(1, 2)          # the plain kernel's own multi-restart launch
     assert np.array_equal(cn_plain, cn_all[1:3]) and np.array_equal(lp_plain, lp_all[1:3])
-    monkeypatch.delenv('RMX_VITERBI_PLAIN')
+    b.set_option('viterbi_plain', 0)
     res = rs.results()
     for r in range(3):
         cn_r, brk_r = rs.models[r].optimal_cn()

@@ -267,9 +267,9 @@ def test_batched_decode_matches_oracle_paths(hip, oracle_mod, M, max_cn):
             b.infer_cn_batch(r0, nr)
 
 
-def test_decode_code_table_lattice_equals_plain_lattice(hip, monkeypatch):
+def test_decode_code_table_lattice_equals_plain_lattice(hip):
     """355 states (max_cn = 12): the lattice kernel that keeps 8-bit codes of the S x S transition values
-    in LDS against the plain kernel that reads the tabulated doubles (RMX_VITERBI_PLAIN), breakend and
+    in LDS against the plain kernel that reads the tabulated doubles (option viterbi_plain), breakend and
     telomere steps included: same paths and path log-probabilities, bit for bit."""
     from remixt_amd import synthetic
     from remixt_amd.restarts import RestartSet
@@ -280,7 +280,7 @@ def test_decode_code_table_lattice_equals_plain_lattice(hip, monkeypatch):
     assert b.num_cn_states == 355
     b.variational_update(2)
     cn, lp = b.infer_cn_batch(0, 2)
-    monkeypatch.setenv('RMX_VITERBI_PLAIN', '1')
+    b.set_option('viterbi_plain', 1)
     cn_plain, lp_plain = b.infer_cn_batch(0, 2)
     assert np.array_equal(cn, cn_plain) and np.array_equal(lp, lp_plain)
     assert len(np.unique(cn[0].reshape(len(cn[0]), -1), axis=0)) > 3        # a non-trivial path
@@ -303,20 +303,18 @@ def test_s165_matches_oracle(hip, oracle_mod):
 
 
 def test_fb_register_and_generic_paths_agree(hip):
-    """Long chains (prefetch ring wraps many times): the register-stationary kernel and the generic
-    kernel (RMX_FB_GENERIC=1) must produce the same posteriors; repeated runs are bit-identical."""
-    import os
+    """Long chains: the register-stationary kernel and the general kernel (option fb_kernel = 1) must produce the
+    same posteriors; repeated runs are bit-identical."""
     outs = []
     for generic in (False, True, False):
-        if generic:
-            os.environ['RMX_FB_GENERIC'] = '1'
-        else:
-            os.environ.pop('RMX_FB_GENERIC', None)
-        m, h, _ = H.make_model(hip, N=6000, M=3, max_cn=8, chains=5, seed=3)
-        mm = H.attach(m, h)
+        hip.set_default_option('fb_kernel', 1 if generic else 0)
+        try:
+            m, h, _ = H.make_model(hip, N=6000, M=3, max_cn=8, chains=5, seed=3)
+            mm = H.attach(m, h)
+        finally:
+            hip.set_default_option('fb_kernel', 0)
         m.variational_update(); m.variational_update()
         outs.append((mm.posterior_marginals, mm.hmm_log_norm_const, mm.calculate_elbo(), mm.p_breakpoint))
-    os.environ.pop('RMX_FB_GENERIC', None)
     assert np.allclose(outs[0][0], outs[1][0], rtol=1e-9, atol=1e-13)
     assert np.isclose(outs[0][1], outs[1][1], rtol=1e-12) and np.isclose(outs[0][2], outs[1][2], rtol=1e-12)
     assert np.array_equal(outs[0][0], outs[2][0]) and outs[0][1] == outs[2][1] and outs[0][2] == outs[2][2]
@@ -325,21 +323,20 @@ def test_fb_register_and_generic_paths_agree(hip):
 
 def test_s355_on_the_fly_weights_match_tabulated(hip):
     """max_cn = 12 (355 states): the S x S weights do not fit the register file; k_fbk rebuilds them from
-    byte-packed copy numbers (two SADs and a min per pair).  Must agree with the generic kernel that reads
-    the tabulated weights (RMX_FB_NO_FBK=1), breakend steps included, and be repeatable bit for bit."""
-    import os
+    byte-packed copy numbers (two SADs and a min per pair).  Must agree with the general kernel that reads
+    the tabulated weights (option fb_kernel = 2), breakend steps included, and be repeatable bit for bit.
+    (Both against the oracle: tests/test_hip_bench_shapes.py.)"""
     outs = []
     for mode in ('fbk', 'generic', 'fbk'):
-        if mode == 'generic':
-            os.environ['RMX_FB_NO_FBK'] = '1'
-        else:
-            os.environ.pop('RMX_FB_NO_FBK', None)
-        m, h, _ = H.make_model(hip, N=1500, M=3, max_cn=12, chains=4, seed=13)
-        mm = H.attach(m, h)
+        hip.set_default_option('fb_kernel', 2 if mode == 'generic' else 0)
+        try:
+            m, h, _ = H.make_model(hip, N=1500, M=3, max_cn=12, chains=4, seed=13)
+            mm = H.attach(m, h)
+        finally:
+            hip.set_default_option('fb_kernel', 0)
         assert mm.num_cn_states == 355
         m.variational_update(); m.variational_update()
         outs.append((mm.posterior_marginals, mm.hmm_log_norm_const, mm.calculate_elbo(), mm.p_breakpoint))
-    os.environ.pop('RMX_FB_NO_FBK', None)
     assert np.allclose(outs[0][0], outs[1][0], rtol=1e-9, atol=1e-13)
     assert np.isclose(outs[0][1], outs[1][1], rtol=1e-12) and np.isclose(outs[0][2], outs[1][2], rtol=1e-12)
     assert np.allclose(outs[0][3], outs[1][3], rtol=1e-9, atol=1e-13)
@@ -350,24 +347,19 @@ def test_fused_sweeps_equal_separate_updates(hip):
     """rmx_variational_update fuses marginals + outlier / allele-swap updates + the next sweep's frame
     pass into one kernel between sweeps; the result must equal the separate coordinate updates bit
     for bit (S = 165: strip kernels with the cell cache)."""
-    import os
     from remixt_amd import synthetic
     from remixt_amd.restarts import RestartSet
     e = synthetic.make_experiment(700, num_clones=3, max_copy_number=8, num_chains=4, seed=11)
     ps = synthetic.make_init_params(e, 3, 8)
     outs = []
-    for knob in (None, 'RMX_NO_FUSE', 'RMX_ONE_STREAM'):      # default: fused passes, breakend branch on its own stream
-        os.environ.pop('RMX_NO_FUSE', None); os.environ.pop('RMX_ONE_STREAM', None)
-        if knob:
-            os.environ[knob] = '1'
-        rs = RestartSet(e, ps, max_copy_number=8, num_clones=3, quiet=True)
+    for knob in (None, 'fuse_sweeps', 'two_streams'):      # default: fused passes, breakend branch on its own stream
+        rs = RestartSet(e, ps, max_copy_number=8, num_clones=3, quiet=True, options=({knob: 0} if knob else None))
         assert rs.batch.num_cn_states == 165
         rs.batch.variational_update(3)
         el = rs.batch.calculate_elbo()
         outs.append((el, [rs.batch.get_array(r, 'posterior_marginals') for r in range(3)],
                      [rs.batch.get_array(r, 'p_outlier_total') for r in range(3)], [rs.batch.get_array(r, 'p_outlier_allele') for r in range(3)],
                      [rs.batch.get_array(r, 'p_allele_swap') for r in range(3)], [rs.batch.get_array(r, 'p_breakpoint') for r in range(3)]))
-    os.environ.pop('RMX_NO_FUSE', None); os.environ.pop('RMX_ONE_STREAM', None)
     for other in outs[1:]:
         assert np.array_equal(outs[0][0], other[0])
         for k in range(1, 6):
@@ -382,28 +374,20 @@ def test_lockstep_mstep_equals_per_restart_mstep(hip):
     from remixt_amd.restarts import RestartSet
     e = synthetic.make_experiment(600, num_clones=3, max_copy_number=4, num_chains=5, seed=6)      # 47 states: strip kernels, lists of states with posterior mass
     ps = synthetic.make_init_params(e, 4, 4)
-    import os
-    knobs = ('RMX_SEARCH_TABLES', 'RMX_SEARCH_LOOKAHEAD', 'RMX_SEARCH_SEQUENTIAL')
     configs = [
-        (True, True, ()),                          # 0: native, the four standard searches in shared rounds
-        (True, False, ()),                         # 1: python lock-step
-        (False, False, ()),                        # 2: per-restart scipy
-        (True, True, ('RMX_SEARCH_TABLES',)),      # 3: native, one parameter at a time, table-rebuilding evaluation rounds
-        (True, True, ('RMX_SEARCH_LOOKAHEAD',)),   # 4: native, one at a time, rounds that also evaluate the optimisers' possible next points
-        (True, True, ('RMX_SEARCH_SEQUENTIAL',)),  # 5: native, one at a time, table-free rounds
+        (True, True, 0),      # 0: native, the four standard searches in shared rounds
+        (True, False, 0),     # 1: python lock-step
+        (False, False, 0),    # 2: per-restart scipy
+        (True, True, 2),      # 3: native, one parameter at a time, table-rebuilding evaluation rounds
+        (True, True, 3),      # 4: native, one at a time, rounds that also evaluate the optimisers' possible next points
+        (True, True, 1),      # 5: native, one at a time, table-free rounds
     ]
     out = []
-    for lock, native, env in configs:
-        for k in knobs:
-            os.environ.pop(k, None)
-        for k in env:
-            os.environ[k] = '1'
+    for lock, native, mode in configs:
         rs = RestartSet(e, ps, max_copy_number=4, num_clones=3, quiet=True, seeds=[5, 6, 7, 8], lockstep=lock,
-                        native_search=native, mstep_threads=1)
+                        native_search=native, mstep_threads=1, options={'search_mode': mode})
         rs.fit(num_em_iter=2, num_update_iter=2)
         out.append([(m.prev_elbo, np.array(m.h), m.get_likelihood_param_values()) for m in rs.models])
-    for k in knobs:
-        os.environ.pop(k, None)
     # the table-free search kernel evaluates exactly what the table-rebuilding rounds evaluate, and the
     # optional look-ahead evaluations change nothing any optimiser sees
     for (e1, h1, p1), (e2, h2, p2) in list(zip(out[5], out[3])) + list(zip(out[5], out[4])):

@@ -12,6 +12,13 @@ def test_oracle_replays_reference(oracle_mod, name):
     GR.replay(name, oracle_mod, rtol=1e-11, atol=1e-13)
 
 
+@pytest.mark.parametrize('name', GR.GRID_CASES)
+def test_oracle_replays_reference_at_bench_grids_and_dark_corners(oracle_mod, name):
+    """165 / 355 states with 8-9 breakpoints (two breakends at one boundary), transition_model = 1, four clones,
+    disable_breakpoints: pins the oracle where the benchmark runs and where the protocol is rarely exercised."""
+    GR.replay_grid(name, oracle_mod, rtol=1e-11, atol=1e-13, mixed_elbo=True)
+
+
 @pytest.mark.parametrize('name', ['model_m2', 'model_malex'])
 def test_oracle_full_fit_trajectory(oracle_mod, name):
     GR.replay_fit(name, oracle_mod, rtol_elbo=1e-9, rtol_h=1e-7, rtol_param=1e-6)

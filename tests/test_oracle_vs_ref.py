@@ -59,3 +59,45 @@ def test_host_class_equals_reference_host_class(oracle_mod):
     assert m.prev_elbo == r.prev_elbo and np.array_equal(m.h, r.h)
     assert m.get_likelihood_param_values() == r.get_likelihood_param_values()
     assert np.array_equal(cn, rcn) and all(np.array_equal(brk[k], rbrk[k]) for k in brk)
+
+
+@pytest.mark.parametrize('nc', [True, False])
+def test_per_cell_accessors_equal_reference_kernel(oracle_mod, nc):
+    """The per-cell cpdef methods (bpmodel.pyx:686-749, 778-807, 855-896) that cn_model.py never calls: oracle vs the
+    compiled reference, cell by cell -- this pins the checker of tests/test_hip_bench_shapes.py::test_per_cell_accessors."""
+    ref = refload.load_ref_bpmodel()
+    a, h, _ = H.make_model(oracle_mod, N=40, M=3, max_cn=3, chains=2, seed=77, normal_contamination=nc)
+    b, _, _ = H.make_model(ref, N=40, M=3, max_cn=3, chains=2, seed=77, normal_contamination=nc)
+    ma, mb = H.attach(a, h), H.attach(b, h)
+    rng = np.random.RandomState(1)
+    checked = 0
+    for _ in range(60):
+        n, s = int(rng.randint(0, ma.num_segments)), int(rng.randint(0, ma.num_cn_states))
+        assert ma.calculate_expected_total_reads(n, s) == mb.calculate_expected_total_reads(n, s)
+        assert ma.calculate_log_prior_cn(n, s) == mb.calculate_log_prior_cn(n, s)
+        ga, gb = np.zeros(3), np.zeros(3)
+        ma.calculate_expected_total_reads_partial_h(n, s, ga); mb.calculate_expected_total_reads_partial_h(n, s, gb)
+        assert np.array_equal(ga, gb)
+        try:
+            want = mb.calculate_expected_allele_ratio(n, s)
+        except ValueError:
+            with pytest.raises(ValueError):
+                ma.calculate_expected_allele_ratio(n, s)
+            continue
+        assert ma.calculate_expected_allele_ratio(n, s) == want
+        ma.calculate_expected_allele_ratio_partial_h(n, s, ga); mb.calculate_expected_allele_ratio_partial_h(n, s, gb)
+        assert np.array_equal(ga, gb)
+        for u in range(2):
+            ma.calculate_log_likelihood_total_partial_h(n, s, u, ga); mb.calculate_log_likelihood_total_partial_h(n, s, u, gb)
+            assert np.allclose(ga, gb, rtol=1e-14, atol=0)
+            for w in range(2):
+                try:
+                    mb.calculate_log_likelihood_allele_partial_h(n, s, u, w, gb)
+                except ValueError:
+                    with pytest.raises(ValueError):
+                        ma.calculate_log_likelihood_allele_partial_h(n, s, u, w, ga)
+                    continue
+                ma.calculate_log_likelihood_allele_partial_h(n, s, u, w, ga)
+                assert np.allclose(ga, gb, rtol=1e-12, atol=1e-12)
+                checked += 1
+    assert checked > 50

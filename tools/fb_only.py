@@ -8,7 +8,16 @@ N = int(os.environ.get('SEG', 50000)); R = int(os.environ.get('RST', 16)); K = o
 mcn = int(os.environ.get('MAXCN', 8))
 e = synthetic.make_experiment(N, num_clones=3, max_copy_number=mcn, num_chains=int(os.environ.get('CHAINS', 23)), seed=0, num_breakpoints=int(K) if K else None)
 ps = synthetic.make_init_params(e, R, mcn)
-rs = RestartSet(e, ps, mcn, num_clones=3, quiet=True)
+from remixt_amd import bpmodel
+DEBUG = bool(os.environ.get('FB_DEBUG'))
+if DEBUG:
+    bpmodel.set_default_option('fb_debug', 1)
+opts = {}
+if os.environ.get('NV'):
+    opts['fb_nv'] = int(os.environ['NV'])
+if os.environ.get('FB_KERNEL'):
+    opts['fb_kernel'] = int(os.environ['FB_KERNEL'])
+rs = RestartSet(e, ps, mcn, num_clones=3, quiet=True, options=opts)
 b = rs.batch
 print('info rpt,P,NT,BLK,lds,nfast,ngen', [b.info(i) for i in (5, 6, 7, 8, 9, 10, 11)], 'NBE', b.info(3), 'S', b.num_cn_states)
 b.variational_update(1)
@@ -20,8 +29,7 @@ print('wall ms per sweep', dt / it * 1e3)
 for k, v in sorted(b.profile().items(), key=lambda kv: -kv[1][0]):
     print('%-28s %9.3f ms  n=%d  avg %.3f' % (k, v[0], v[1], v[0] / v[1]))
 
-import os
-if os.environ.get('RMX_FB_DEBUG'):
+if DEBUG:
     c0, w0, c1, w1, ln = [b.info(i) for i in (20, 21, 22, 23, 24)]
     print('debug: steps', ln, 'shader cycles/step', (c1 - c0) / max(ln - 1, 1), 'wall us/step', (w1 - w0) / 100.0 / max(ln - 1, 1), 'clock GHz', (c1 - c0) / ((w1 - w0) * 10.0))
     print('stamps wave0 :', [round(b.info(28 + i) / max(ln - 1, 1)) for i in range(10)])
