@@ -62,6 +62,8 @@ struct rmx_batch {
     bool use_cache = false;
     std::vector<int> comp_dirty;       // which components of (A, B, PF/PP) are stale: CM_* bits, 16 = PF/PP
     std::vector<int> lt_valid;
+    std::vector<int> lt_model, cached_model;   // per restart: the transition model of the log_transmat / cached_log_transmat snapshot
+    double *Tval_m[2] = {nullptr, nullptr}; int8_t *af_m[2] = {nullptr, nullptr};   // plain tables of either transition model once it has been current
     std::vector<double> plain_T_init;  // [R]
     std::vector<double> logZ;          // last hmm_log_norm_const
     std::vector<char> logz_dirty;
@@ -365,8 +367,19 @@ static int build_transitions(rmx_batch *b) {
         HIPCHK(hipMemcpy((void *)b->d.Wb, Wb.data(), Wb.size() * 8, hipMemcpyHostToDevice));
         HIPCHK(hipMemcpy((void *)b->d.af, af.data(), af.size(), hipMemcpyHostToDevice));
         HIPCHK(hipMemcpy((void *)b->d.ab, ab.data(), ab.size(), hipMemcpyHostToDevice));
+        // the plain tables of this model, kept for the snapshots (log_transmat / cached_log_transmat) that outlive a model change
+        int rc2;
+        if (!b->Tval_m[model] && ((rc2 = dalloc(b, &b->Tval_m[model], Tval.size())) || (rc2 = dalloc(b, &b->af_m[model], af.size())))) return rc2;
+        HIPCHK(hipMemcpy(b->Tval_m[model], Tval.data(), Tval.size() * 8, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(b->af_m[model], af.data(), af.size(), hipMemcpyHostToDevice));
     }
     return RMX_OK;
+}
+// the batch's device view with the plain tables of transition model `model` (snapshot consumers)
+static Dev dev_for_model(const rmx_batch *b, int model) {
+    Dev d2 = b->d;
+    if (model != b->d.tmodel && b->Tval_m[model]) { d2.Tval = b->Tval_m[model]; d2.af = b->af_m[model]; d2.tmodel = model; }
+    return d2;
 }
 
 static double plain_T_mean_sum(rmx_batch *b) {
@@ -551,7 +564,7 @@ static int launch_pairwise_breakends(rmx_batch *b, int r0, int r1, int mode) {
         HIPCHK(hipFuncSetAttribute((const void *)k_pairwise_be2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
         hipLaunchKernelGGL(k_pairwise_be2, dim3(d.NBE, r1 - r0), dim3(nt), lds2, b->stream, b->d, r0, b->pe2p, b->spc);
     } else {
-        hipLaunchKernelGGL(k_pairwise, dim3(d.NBE, r1 - r0), dim3(256), 0, b->stream, b->d, r0, mode, (const int32_t *)nullptr, (double *)nullptr);
+        hipLaunchKernelGGL(k_pairwise, dim3(d.NBE, r1 - r0), dim3(256), 0, b->stream, b->d, r0, mode, (const int32_t *)nullptr, (double *)nullptr, PairAux{});
     }
     HIPCHK(hipGetLastError());
     return RMX_OK;
@@ -817,7 +830,7 @@ int rmx_batch_create(const rmx_problem *pr, int32_t R, const double *h_init, con
 
     // per-restart initial state (bpmodel.pyx:546-597)
     b->sample_cache.assign(R, std::vector<int64_t>()); b->sample_count.assign(R, -1);
-    b->rp.resize(R); b->tables_dirty.assign(R, 1); b->segc_dirty.assign(R, 1); b->ab_dirty.assign(R, 1); b->comp_dirty.assign(R, 31); b->cache_stale.assign(R, 15); b->sig_valid.assign(R, 0); b->lt_valid.assign(R, 0); b->logZ.assign(R, 0.); b->logz_dirty.assign(R, 0);
+    b->rp.resize(R); b->tables_dirty.assign(R, 1); b->segc_dirty.assign(R, 1); b->ab_dirty.assign(R, 1); b->comp_dirty.assign(R, 31); b->cache_stale.assign(R, 15); b->sig_valid.assign(R, 0); b->lt_valid.assign(R, 0); b->lt_model.assign(R, 0); b->cached_model.assign(R, 0); b->logZ.assign(R, 0.); b->logz_dirty.assign(R, 0);
     for (int r = 0; r < R; r++) {
         RestartParams &p = b->rp[r];
         memset(&p, 0, sizeof p);
@@ -1014,10 +1027,12 @@ int rmx_get_array(rmx_batch *b, int32_t r, int32_t id, void *dst) { BIND(b);
         const size_t cnt = (size_t)(d.N - 1) * d.S * d.S;
         double *tmp = nullptr;
         HIPCHK(hipMalloc((void **)&tmp, cnt * 8));
+        // each snapshot with the plain tables of the transition model it was taken under
         if (id == RMX_A_JOINT_POSTERIOR_MARGINALS)
-            hipLaunchKernelGGL(k_materialize_joint, dim3(d.N - 1), dim3(256), 0, b->stream, d, r, b->lt_valid[r] ? 0 : 1, tmp);
+            hipLaunchKernelGGL(k_materialize_joint, dim3(d.N - 1), dim3(256), 0, b->stream, dev_for_model(b, b->lt_model[r]), r, b->lt_valid[r] ? 0 : 1, tmp);
         else
-            hipLaunchKernelGGL(k_materialize_T, dim3(d.N - 1), dim3(256), 0, b->stream, d, r, id == RMX_A_LOG_TRANSMAT ? 0 : 1,
+            hipLaunchKernelGGL(k_materialize_T, dim3(d.N - 1), dim3(256), 0, b->stream,
+                               dev_for_model(b, id == RMX_A_LOG_TRANSMAT ? b->lt_model[r] : b->cached_model[r]), r, id == RMX_A_LOG_TRANSMAT ? 0 : 1,
                                (id == RMX_A_LOG_TRANSMAT && !b->lt_valid[r]) ? 1 : 0, tmp);
         hipError_t e = hipMemcpyAsync(dst, tmp, cnt * 8, hipMemcpyDeviceToHost, b->stream);
         hipStreamSynchronize(b->stream);
@@ -1222,6 +1237,7 @@ static int p_cn_front(rmx_batch *b, int r0, int r1, bool skip_frame, bool snapsh
         }
         HIPCHK(hipGetLastError());
     }
+    for (int r = r0; r < r1; r++) b->lt_model[r] = b->d.tmodel;
     for (int r = r0; r < r1; r++) { if (!b->lt_valid[r]) { b->lt_valid[r] = 1; int one = 1; HIPCHK(hipMemcpyAsync(b->d_lt_valid + r, &one, 4, hipMemcpyHostToDevice, b->stream)); } }
     return RMX_OK;
 }
@@ -1253,7 +1269,7 @@ static int do_update_p_breakpoint(rmx_batch *b, int r0, int r1) {
     int rc = launch_brk_lut(b, r0, r1, b->d.pd_cached, nullptr);
     if (rc) return rc;
     const double pti = plain_T_mean_sum(b);
-    for (int r = r0; r < r1; r++) b->plain_T_init[r] = pti;
+    for (int r = r0; r < r1; r++) { b->plain_T_init[r] = pti; b->cached_model[r] = b->d.tmodel; }
     return RMX_OK;
 }
 static int do_indicator(rmx_batch *b, int r0, int r1, int which) {
@@ -1331,7 +1347,11 @@ static int elbo_parts(rmx_batch *b, int r0, int r1, bool exact_parts, double *ou
         const int np = (int)b->plain_list.size();
         if (!b->d_plain_list) { if ((rc = dalloc(b, &b->d_plain_list, np)) || (rc = dalloc(b, &b->d_plain_jt, (size_t)b->R * np))) return rc;
             HIPCHK(hipMemcpy(b->d_plain_list, b->plain_list.data(), (size_t)np * 4, hipMemcpyHostToDevice)); }
-        { ProfScope ps(b, KID_PAIRWISE); hipLaunchKernelGGL(k_pairwise, dim3(np, nr), dim3(256), 0, b->stream, b->d, r0, 0, (const int32_t *)b->d_plain_list, b->d_plain_jt); }
+        { ProfScope ps(b, KID_PAIRWISE);
+          // (the joint belongs to the log_transmat snapshot: plain tables of the model each restart's snapshot was taken under)
+          for (int r = r0; r < r1; r++)
+              hipLaunchKernelGGL(k_pairwise, dim3(np, 1), dim3(256), 0, b->stream, dev_for_model(b, b->lt_model[r]), r, 0, (const int32_t *)b->d_plain_list,
+                                 b->d_plain_jt + (size_t)(r - r0) * np, PairAux{}); }
         std::vector<double> jt((size_t)nr * np);
         HIPCHK(hipMemcpyAsync(jt.data(), b->d_plain_jt, jt.size() * 8, hipMemcpyDeviceToHost, b->stream));
         HIPCHK(hipStreamSynchronize(b->stream));
@@ -1357,6 +1377,51 @@ static int elbo_parts(rmx_batch *b, int r0, int r1, bool exact_parts, double *ou
     if (d_fp) hipFree(d_fp);
     if (rc) return rc;
     for (int r = r0; r < r1; r++) if (b->lt_valid[r]) { b->logZ[r] = out4[(r - r0) * 4 + 3]; b->logz_dirty[r] = 0; }
+    // A transition-model change between the two snapshots (cn_model.py:404 sets the model after the constructor cached
+    // model-0 tables; bpmodel.pyx:939 vs :985): the entropy reads log_transmat (model of the last update_p_cn), the energy
+    // cached_log_transmat (model of the last update_p_breakpoint / the constructor).  Their plain-adjacency terms no longer
+    // cancel and the allele-flip term of the breakend adjacencies differs: both are summed explicitly here.
+    for (int r = r0; r < r1; r++) {
+        if (!b->lt_valid[r] || b->lt_model[r] == b->cached_model[r]) continue;
+        const int lm = b->lt_model[r], cm = b->cached_model[r];
+        if (!b->Tval_m[lm] || !b->Tval_m[cm]) return fail(RMX_EUNSUPPORTED, "transition tables of a previous model are not available");
+        const Dev dl = dev_for_model(b, lm);
+        const Dev &d = b->d;
+        const int np = (int)b->plain_list.size();
+        double e_corr = 0., h_corr = 0.;
+        double *d_jt2 = nullptr;
+        std::vector<double> jt(np), jt2(np);
+        if (np > 0) {
+            if (!b->d_plain_list) { if ((rc = dalloc(b, &b->d_plain_list, np)) || (rc = dalloc(b, &b->d_plain_jt, (size_t)b->R * np))) return rc;
+                HIPCHK(hipMemcpy(b->d_plain_list, b->plain_list.data(), (size_t)np * 4, hipMemcpyHostToDevice)); }
+            HIPCHK(hipMalloc((void **)&d_jt2, (size_t)np * 8));
+            PairAux ax{}; ax.Tval2 = b->Tval_m[cm]; ax.jt2_out = d_jt2; ax.no_state = 1;
+            hipLaunchKernelGGL(k_pairwise, dim3(np, 1), dim3(256), 0, b->stream, dl, r, 0, (const int32_t *)b->d_plain_list, b->d_plain_jt, ax);
+            HIPCHK(hipMemcpyAsync(jt.data(), b->d_plain_jt, (size_t)np * 8, hipMemcpyDeviceToHost, b->stream));
+            HIPCHK(hipMemcpyAsync(jt2.data(), d_jt2, (size_t)np * 8, hipMemcpyDeviceToHost, b->stream));
+            HIPCHK(hipStreamSynchronize(b->stream));
+            hipFree(d_jt2);
+            double sl = 0., sc = 0.;
+            for (int j = 0; j < np; j++) { sl += jt[j]; sc += jt2[j]; }
+            if (exact_parts) e_corr += sc - sl;              // both parts already contain the lt-model sum: the energy's becomes the cached model's
+            else { e_corr += sc; h_corr += sl; }
+        }
+        if (d.NBE > 0) {
+            // breakend adjacencies: the energy's allele-flip term under the cached model's table instead of the snapshot's
+            double *d_ja2 = nullptr;
+            HIPCHK(hipMalloc((void **)&d_ja2, (size_t)d.NBE * 8));
+            PairAux ax{}; ax.af2 = b->af_m[cm]; ax.ja2_out = d_ja2; ax.no_state = 1;
+            hipLaunchKernelGGL(k_pairwise, dim3(d.NBE, 1), dim3(256), 0, b->stream, dl, r, 0, (const int32_t *)nullptr, (double *)nullptr, ax);
+            std::vector<double> ja2(d.NBE), ja(d.NBE);
+            HIPCHK(hipMemcpyAsync(ja2.data(), d_ja2, (size_t)d.NBE * 8, hipMemcpyDeviceToHost, b->stream));
+            HIPCHK(hipMemcpyAsync(ja.data(), d.be_ja + (size_t)r * d.NBE, (size_t)d.NBE * 8, hipMemcpyDeviceToHost, b->stream));
+            HIPCHK(hipStreamSynchronize(b->stream));
+            hipFree(d_ja2);
+            for (int sl_ = 0; sl_ < d.NBE; sl_++) if (b->tclass[b->be_n[sl_]] >= 0) e_corr += -d.pen * (ja2[sl_] - ja[sl_]);
+        }
+        double *o = out4 + (size_t)(r - r0) * 4;
+        o[0] += e_corr; o[1] += h_corr; o[2] = o[0] - o[1];
+    }
     return RMX_OK;
 }
 int rmx_calculate_elbo(rmx_batch *b, int32_t r0, int32_t r1, double *out) { BIND(b);
@@ -2109,7 +2174,10 @@ static int viterbi_P(int S) { int P = 1; while (S * P * 2 <= 1024 && P < 64) P *
 static int viterbi_reg_P(int S) { int P = 1; while (S * P * 2 <= 768 && P < 64) P *= 2; return P; }
 
 // Viterbi paths of restarts r0 .. r0+nr-1: forward lattices side by side (one workgroup each), then the trace-backs
-static int viterbi_paths(rmx_batch *b, int r0, int nr, std::vector<int64_t> &paths, std::vector<double> &lps) {
+static int viterbi_paths(rmx_batch *b, int r0, int nr, std::vector<int64_t> &paths, std::vector<double> &lps, int model) {
+    // the lattice runs on the log_transmat snapshot: plain tables of the transition model it was taken under
+    const Dev dv = dev_for_model(b, model);
+    const bool cur_model = model == b->d.tmodel;
     const Dev &d = b->d;
     const int N = d.N, S = d.S, M = d.M;
     int rc;
@@ -2127,18 +2195,18 @@ static int viterbi_paths(rmx_batch *b, int r0, int nr, std::vector<int64_t> &pat
     { ProfScope ps(b, KID_VITERBI);
       if (reg) {
           const int NT = ((S * Pr + 63) / 64) * 64;
-#define VREG(Q) hipLaunchKernelGGL(k_viterbi_reg<Q>, dim3(nr), dim3(NT), (size_t)(2 * (Pr * QPT + Q) + M * d.D) * 8, b->stream, b->d, r0, Pr, b->d_bp, b->d_final)
+#define VREG(Q) hipLaunchKernelGGL(k_viterbi_reg<Q>, dim3(nr), dim3(NT), (size_t)(2 * (Pr * QPT + Q) + M * d.D) * 8, b->stream, dv, r0, Pr, b->d_bp, b->d_final)
           if (QPT <= 8) VREG(8); else if (QPT <= 16) VREG(16); else if (QPT <= 24) VREG(24); else if (QPT <= 32) VREG(32);
           else if (QPT <= 36) VREG(36); else if (QPT <= 40) VREG(40); else VREG(44);
 #undef VREG
-      } else if (code_lds <= kLdsBudget && !b->opt[RMX_OPT_VITERBI_PLAIN]) {
+      } else if (cur_model && code_lds <= kLdsBudget && !b->opt[RMX_OPT_VITERBI_PLAIN]) {
           const int NT = ((S * Pr + 63) / 64) * 64;
           HIPCHK(hipFuncSetAttribute((const void *)k_viterbi_code, hipFuncAttributeMaxDynamicSharedMemorySize, (int)code_lds));
           hipLaunchKernelGGL(k_viterbi_code, dim3(nr), dim3(NT), code_lds, b->stream, b->d, r0, Pr, QPT4,
                              (const uint8_t *)b->d_vit_code, (const double *)b->d_vit_val, b->d_bp, b->d_final);
       } else {
           const int P = viterbi_P(S), NT = ((S * P + 63) / 64) * 64;
-          hipLaunchKernelGGL(k_viterbi, dim3(nr), dim3(NT), (size_t)(2 * S + M * d.D) * 8, b->stream, b->d, r0, P, b->d_bp, b->d_final);
+          hipLaunchKernelGGL(k_viterbi, dim3(nr), dim3(NT), (size_t)(2 * S + M * d.D) * 8, b->stream, dv, r0, P, b->d_bp, b->d_final);
       } }
     int rows = std::max(1, std::min(256, (48 * 1024) / (2 * S)));
     { ProfScope ps(b, KID_BACKTRACE);
@@ -2161,8 +2229,8 @@ int rmx_infer_cn_batch(rmx_batch *b, int32_t r0, int32_t nr, int64_t *cn_out, do
     std::vector<int64_t> all((size_t)nr * N, 0); std::vector<double> lp(nr, (double)N);
     for (int i = 0; i < nr;) {
         if (!b->lt_valid[r0 + i]) { i++; continue; }
-        int j = i; while (j < nr && b->lt_valid[r0 + j]) j++;
-        int rc = viterbi_paths(b, r0 + i, j - i, paths, lps); if (rc) return rc;
+        int j = i; while (j < nr && b->lt_valid[r0 + j] && b->lt_model[r0 + j] == b->lt_model[r0 + i]) j++;
+        int rc = viterbi_paths(b, r0 + i, j - i, paths, lps, b->lt_model[r0 + i]); if (rc) return rc;
         memcpy(all.data() + (size_t)i * N, paths.data(), (size_t)(j - i) * N * 8);
         for (int k = i; k < j; k++) lp[k] = lps[k - i];
         i = j;

@@ -1414,7 +1414,12 @@ __device__ __forceinline__ double trans_value(const Dev &d, int n, int i, int j,
 // update_p_cn, :566-567) with log_transmat == 0.
 // grid (nlist, nr), block 256.  list == nullptr -> breakend slots.
 // =============================================================================
-__global__ void k_pairwise(Dev d, int r0, int mode, const int32_t *list, double *jt_out) {
+// aux (optional, all null by default): a second plain table / allele-flip table (the tables of ANOTHER transition
+// model, for the ELBO in the state where log_transmat and cached_log_transmat belong to different models):
+//   jt2_out = sum joint * Tval2 (plain adjacencies: list given), ja2_out = sum joint * af2; no_state: do not write
+//   hist / be_jt / be_ja (the run only produces the aux sums)
+struct PairAux { const double *Tval2; const int8_t *af2; double *jt2_out; double *ja2_out; int no_state; int pad_; };
+__global__ void k_pairwise(Dev d, int r0, int mode, const int32_t *list, double *jt_out, PairAux aux) {
     __shared__ double hw[4][RMX_MAX_CLONES * 64];
     __shared__ double gvec[1024];
     __shared__ double scratch[8];
@@ -1433,7 +1438,7 @@ __global__ void k_pairwise(Dev d, int r0, int mode, const int32_t *list, double 
         for (int j = t; j < S; j += 256) gvec[j] = fe[j] * fb[j];
     }
     __syncthreads();
-    double z = 0., jt = 0., ja = 0.;
+    double z = 0., jt = 0., ja = 0., jt2 = 0., ja2 = 0.;
     for (int idx = t; idx < S * S; idx += 256) {
         const int i = idx / S, j = idx - i * S;
         double T = 0., J;
@@ -1442,12 +1447,14 @@ __global__ void k_pairwise(Dev d, int r0, int mode, const int32_t *list, double 
         z += J; jt += J * T;
         if (tc >= 0) {
             ja += J * (double)d.af[((size_t)tc * S + i) * S + j];
-            if (slot >= 0)
+            if (aux.Tval2) jt2 += J * aux.Tval2[((size_t)tc * S + i) * S + j];
+            if (aux.af2) ja2 += J * (double)aux.af2[((size_t)tc * S + i) * S + j];
+            if (slot >= 0 && !aux.no_state)
                 for (int c = 0; c < M; c++) {
                     const int dd = (int)d.tot[((size_t)ca * S + i) * M + c] - (int)d.tot[((size_t)cb * S + j) * M + c];
                     atomicAdd(&hw[wv][c * 64 + dd + d.cn_max + 1], J);
                 }
-        } else if (slot >= 0) {
+        } else if (slot >= 0 && !aux.no_state) {
             for (int c = 0; c < M; c++) {
                 const int dd = (int)d.tot[((size_t)ca * S + i) * M + c] - (int)d.tot[((size_t)cb * S + j) * M + c];
                 atomicAdd(&hw[wv][c * 64 + dd + d.cn_max + 1], J);
@@ -1461,16 +1468,20 @@ __global__ void k_pairwise(Dev d, int r0, int mode, const int32_t *list, double 
     __shared__ double jtsh;
     if (t == 0) jtsh = jt;
     ja = block_sum<256>(ja, scratch);
+    if (aux.jt2_out) { jt2 = block_sum<256>(jt2, scratch); }
+    if (aux.ja2_out) { ja2 = block_sum<256>(ja2, scratch); }
     __syncthreads();
     const double zz = zsh;
     if (t == 0) {
-        if (slot >= 0) {
+        if (slot >= 0 && !aux.no_state) {
             d.be_jt[(size_t)r * d.NBE + slot] = jtsh / zz;
             d.be_ja[(size_t)r * d.NBE + slot] = ja / zz;
         }
         if (jt_out) jt_out[(size_t)(r - r0) * gridDim.x + blockIdx.x] = jtsh / zz;
+        if (aux.jt2_out) aux.jt2_out[(size_t)(r - r0) * gridDim.x + blockIdx.x] = jt2 / zz;
+        if (aux.ja2_out) aux.ja2_out[(size_t)(r - r0) * gridDim.x + blockIdx.x] = ja2 / zz;
     }
-    if (slot >= 0)
+    if (slot >= 0 && !aux.no_state)
         for (int i = t; i < M * D; i += 256) {
             const int c = i / D, dd = i % D;
             const double v = ((hw[0][c * 64 + dd] + hw[1][c * 64 + dd]) + hw[2][c * 64 + dd]) + hw[3][c * 64 + dd];
