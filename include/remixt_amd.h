@@ -112,6 +112,10 @@ int rmx_compress_cn_states(const int64_t *cn_states, int32_t N, int32_t S, int32
                            int32_t max_classes, int32_t *seg_class_out, int64_t *classes_out,
                            int32_t *num_classes);
 const char *rmx_last_error(void);
+/* The restarts whose device-side checks (the reference's ValueError / AssertionError sites) fired in the calling thread's last
+ * failing call: up to `cap` indices into out, returns their number.  Every flagged restart's error state is cleared when
+ * the call reports, and rmx_last_error() describes the lowest one; a batched caller fails exactly the listed restarts. */
+int rmx_last_error_restarts(int32_t *out, int32_t cap);
 /* use an externally owned HIP stream (e.g. torch's current stream); NULL = own */
 int rmx_set_stream(rmx_batch *b, void *hip_stream);
 int rmx_synchronize(rmx_batch *b);

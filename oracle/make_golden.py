@@ -537,6 +537,34 @@ def evaluation_case(name, N, seed):
     print(name, 'cases', len(EVALUATION_CASES))
 
 
+def distribution_cases():
+    """NegBinDistribution / BetaBinDistribution of the reference's likelihood.py (:569-662, :949-1084): log pmf and every
+    partial derivative on seeded inputs that include zero counts, tiny means and out-of-range means."""
+    lik = refload.load_ref_analysis()[0]
+    rng = np.random.RandomState(11)
+    out = {}
+    x = np.concatenate([rng.poisson(2000., 40), [0, 0, 5, 1]]).astype(float)
+    mu = np.concatenate([rng.uniform(500., 4000., 40), [1e-5, 3., 7., 1e-9]])
+    for r in (500., 10., 1.5):
+        d = lik.NegBinDistribution(); d.r = r
+        out['nb/%g/ll' % r] = d.log_likelihood(x, mu.copy())
+        out['nb/%g/dmu' % r] = d.log_likelihood_partial_mu(x, mu)
+        out['nb/%g/dr' % r] = d.log_likelihood_partial_r(x, mu)
+    d = lik.NegBinDistribution()
+    out['nb/clip/ll'] = d.log_likelihood(np.array([3., 4.]), np.array([-100., -600.]))      # q outside [0, 1] -> 1/2
+    n = np.concatenate([rng.poisson(300., 40), [10, 100, 0]]).astype(float)
+    p = np.concatenate([rng.uniform(0.02, 0.98, 40), [1e-3, 0.4, 0.5]])
+    k = np.concatenate([rng.binomial(n[:40].astype(int), p[:40]), [0, 40, 0]]).astype(float)
+    for M in (500., 10., 2000.):
+        d = lik.BetaBinDistribution(); d.M = M
+        out['bb/%g/ll' % M] = d.log_likelihood(k, n, p)
+        out['bb/%g/dp' % M] = d.log_likelihood_partial_p(k, n, p)
+        out['bb/%g/dM' % M] = d.log_likelihood_partial_M(k, n, p)
+    out.update(nb_x=x, nb_mu=mu, bb_k=k, bb_n=n, bb_p=p)
+    np.savez_compressed(os.path.join(OUT, 'distributions.npz'), **out)
+    print('distributions', len(out), 'arrays')
+
+
 def grid_cases(cm):
     # the benchmark's state grids (VERDICT r1 item 5) and the protocol's dark corners (item 8)
     grid_case(cm, 'grid_s165', N=36, M=3, max_cn=8, chains=2, seed=21, K=7)
@@ -559,6 +587,7 @@ def main():
     model_case(cm, 'model_nonormal', N=36, M=2, max_cn=3, chains=2, seed=3, normal_contamination=False, zero_alleles=(4,))
     model_case(cm, 'model_malex', N=36, M=3, max_cn=2, chains=3, seed=4, male_x=True)
     grid_cases(cm)
+    distribution_cases()
     pipeline_case('pipeline_init', N=1200, seed=5)
     experiment_case('experiment_tables', N=240, seed=8)
     pipeline_case('pipeline_init_strict', N=900, seed=6, min_ploidy=7.5, max_ploidy=8.0, random_seed=99)

@@ -33,6 +33,7 @@ SYMBOLS = {
     "rmx_batch_destroy": (C.c_int, [C.c_void_p]),
     "rmx_compress_cn_states": (C.c_int, [_ip, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _i32p, _ip, _i32p]),
     "rmx_last_error": (C.c_char_p, []),
+    "rmx_last_error_restarts": (C.c_int, [_i32p, C.c_int32]),
     "rmx_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
     "rmx_synchronize": (C.c_int, [C.c_void_p]),
     "rmx_info": (C.c_int, [C.c_void_p, C.c_int32, _ip]),

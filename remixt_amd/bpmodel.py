@@ -59,12 +59,24 @@ def set_default_option(name, value):
         _raise(lib, rc)
 
 
+def last_error_restarts():
+    """Restarts flagged by the calling thread's last failing call (rmx_last_error_restarts)."""
+    lib = _lib.load()
+    buf = (C.c_int32 * 256)()
+    n = lib.rmx_last_error_restarts(buf, 256)
+    return [int(buf[i]) for i in range(min(n, 256))]
+
+
 def _raise(lib, rc):
     msg = lib.rmx_last_error().decode()
     if rc == RMX_EVALUE:
-        raise ValueError(msg)
+        err = ValueError(msg)
+        err.restarts = last_error_restarts()
+        raise err
     if rc == RMX_EASSERT:
-        raise AssertionError(msg)
+        err = AssertionError(msg)
+        err.restarts = last_error_restarts()
+        raise err
     if rc == RMX_EUNSUPPORTED:
         raise NotImplementedError(msg)
     if rc == RMX_EARG:

@@ -175,16 +175,35 @@ struct ProfScope {
 
 // ---- error translation -------------------------------------------------------
 static int translate_error(rmx_batch *b, int r, uint32_t v);
+// the restarts a failing batched call flagged (this thread's last failure): rmx_last_error_restarts
+static thread_local std::vector<int32_t> g_err_restarts;
+// Every flagged error word of a call is cleared on the device before the call reports -- a word left set would
+// surface in a later, unrelated call of that restart -- and the lowest flagged restart is the one reported;
+// the full list stays readable through rmx_last_error_restarts so that a batched caller can fail only those.
 static int check_errors(rmx_batch *b, int r0, int r1) {
     uint32_t *e = b->h_err;      // pinned: the copy is queued behind the caller's own result copy, one wait for both
     HIPCHK(hipMemcpyAsync(e, b->d.err, sizeof(uint32_t) * b->R, hipMemcpyDeviceToHost, b->stream));
     HIPCHK(hipStreamSynchronize(b->stream));
-    for (int r = r0; r < r1; r++) {
-        if (!e[r]) continue;
-        HIPCHK(hipMemsetAsync(b->d.err + r, 0, sizeof(uint32_t), b->stream));
-        return translate_error(b, r, e[r]);
+    int first = -1;
+    for (int r = r0; r < r1; r++) if (e[r]) { if (first < 0) { first = r; g_err_restarts.clear(); } g_err_restarts.push_back(r); }
+    if (first < 0) return RMX_OK;
+    HIPCHK(hipMemsetAsync(b->d.err + r0, 0, sizeof(uint32_t) * (size_t)(r1 - r0), b->stream));
+    return translate_error(b, first, e[first]);
+}
+// the same for a request list whose error words came back with the results (words[i] belongs to restart_of(i))
+template <typename F> static int report_request_errors(rmx_batch *b, int n, const uint32_t *words, F restart_of) {
+    int first = -1;
+    for (int i = 0; i < n; i++) {
+        if (!words[i]) continue;
+        const int r = restart_of(i);
+        if (first < 0) { first = i; g_err_restarts.clear(); }
+        if (std::find(g_err_restarts.begin(), g_err_restarts.end(), r) == g_err_restarts.end()) {
+            g_err_restarts.push_back(r);
+            HIPCHK(hipMemsetAsync(b->d.err + r, 0, sizeof(uint32_t), b->stream));
+        }
     }
-    return RMX_OK;
+    if (first < 0) return RMX_OK;
+    return translate_error(b, restart_of(first), words[first]);
 }
 static int translate_error(rmx_batch *b, int r, uint32_t v) {
     char buf[160];
@@ -591,6 +610,11 @@ static inline void bind_device(const rmx_batch *b) {
 extern "C" {
 
 const char *rmx_last_error(void) { return g_err.c_str(); }
+int rmx_last_error_restarts(int32_t *out, int32_t cap) {
+    const int n = (int)g_err_restarts.size();
+    for (int i = 0; i < n && i < cap; i++) out[i] = g_err_restarts[i];
+    return n;
+}
 
 static bool option_value_ok(int id, int v) {
     switch (id) {
@@ -1624,12 +1648,7 @@ static int run_ell_batch(rmx_batch *b, int nreq, const int32_t *restarts, bool g
     }
     if (by_value) {
         HIPCHK(hipStreamSynchronize(b->stream));
-        for (int i = 0; i < nreq; i++) {
-            if (!eres[i]) continue;
-            const uint32_t v = eres[i];
-            HIPCHK(hipMemsetAsync(b->d.err + restarts[i], 0, sizeof(uint32_t), b->stream));
-            return translate_error(b, restarts[i], v);
-        }
+        if (int rc_ = report_request_errors(b, nreq, eres, [&](int i) { return (int)restarts[i]; })) return rc_;
     } else {
         int rc = check_errors(b, 0, b->R);
         if (rc) return rc;
@@ -1823,12 +1842,7 @@ int rmx_param_search(rmx_batch *b, int32_t nreq, const int32_t *restarts, int32_
             HIPCHK(hipGetLastError());
         }
         HIPCHK(hipStreamSynchronize(b->stream));
-        for (int i = 0; i < n_; i++) {
-            if (!b->h_err[i]) continue;
-            const uint32_t ev = b->h_err[i];
-            HIPCHK(hipMemsetAsync(b->d.err + sv.rlist[i], 0, sizeof(uint32_t), b->stream));
-            return translate_error(b, sv.rlist[i], ev);
-        }
+        if (int rc_ = report_request_errors(b, n_, b->h_err, [&](int i) { return (int)sv.rlist[i]; })) return rc_;
         for (int i = 0; i < n_; i++)
             for (int g = 0; g < Gz; g++) o_[i * Gz + g] = b->h_pinned[i * Gz + g] + cst[who ? who[i] : i];
         return RMX_OK;
@@ -2008,12 +2022,7 @@ int rmx_param_search_multi(rmx_batch *b, int32_t nreq, const int32_t *restarts, 
             HIPCHK(hipGetLastError());
         }
         HIPCHK(hipStreamSynchronize(b->stream));
-        for (int k = 0; k < n_; k++) {
-            if (!b->h_err[k]) continue;
-            const uint32_t ev = b->h_err[k];
-            HIPCHK(hipMemsetAsync(b->d.err + m2.rlist[k], 0, sizeof(uint32_t), b->stream));
-            return translate_error(b, m2.rlist[k], ev);
-        }
+        if (int rc_ = report_request_errors(b, n_, b->h_err, [&](int k) { return (int)m2.rlist[k]; })) return rc_;
         for (int k = 0; k < n_ * m2.Gz; k++) out[k] = b->h_pinned[k];
         return RMX_OK;
     };

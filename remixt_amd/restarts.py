@@ -241,26 +241,44 @@ class RestartSet(object):
         h_before = [np.array(m.model.h, dtype=float) for m in self.models]
         prefetch, self._h_prefetch = getattr(self, '_h_prefetch', None), None
         rng_state = prefetch[0] if prefetch is not None else [m.rng.get_state() for m in self.models]
+        dead = {}      # restart -> message: its objective raised one of the reference's ValueErrors during the search
         try:
             ell_before = b.expected_log_likelihood_full(0, R)
             samples = prefetch[1].result() if prefetch is not None else self._samples()
             # the parameter M-steps' samples come next in every restart's RNG stream and depend on the outlier
             # indicators only: they are drawn on a helper thread while this thread waits on the h rounds
             self._start_param_sample_prep()
-            for r in active:
-                b._use_sample(r, samples[r])
             bounds = [(1e-8, 10.)] * b.num_clones
+            while True:
+                live = [r for r in active if r not in dead]
+                for r in live:
+                    b._use_sample(r, samples[r])
 
-            def evaluate(ids, xs):
-                f, g = b.expected_log_likelihood_h_batch([active[i] for i in ids], np.stack(xs))
-                return [(-float(f[k]), -g[k]) for k in range(len(ids))]
-            results = lockstep.run_lockstep([lockstep.lbfgsb_gen(h_before[r], bounds) for r in active], evaluate)
+                def evaluate(ids, xs):
+                    f, g = b.expected_log_likelihood_h_batch([live[i] for i in ids], np.stack(xs))
+                    return [(-float(f[k]), -g[k]) for k in range(len(ids))]
+                try:
+                    results = lockstep.run_lockstep([lockstep.lbfgsb_gen(h_before[r], bounds) for r in live], evaluate) if live else []
+                    break
+                except ValueError as err:
+                    # The reference raises inside that restart's own process (e.g. total_depth <= 0 at a trial h) and only
+                    # that restart dies; the batched call names the restarts it flagged.  They keep their h, the others
+                    # start their (deterministic) optimiser runs again without them.
+                    flagged = [r for r in getattr(err, 'restarts', []) if r in live]
+                    if not flagged or self.strict:
+                        raise
+                    for r in flagged:
+                        dead[r] = str(err).splitlines()[0] + ' (h kept)'
+                    for r in live:
+                        self.models[r].model.h = h_before[r]
         except ValueError:
             self._drop_param_sample_prep()
             for r, m in enumerate(self.models):
                 m.model.h = h_before[r]
                 m.rng.set_state(rng_state[r])
             return False
+        self.error_messages.update(dead)
+        active = [r for r in active if r not in dead]
         failed = set()
         trial = hasattr(b, 'expected_log_likelihood_full_trial')
         for r, res in zip(active, results):

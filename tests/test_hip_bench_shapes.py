@@ -246,3 +246,81 @@ def test_per_cell_accessors_match_oracle(hip, oracle_mod):
                 ga, gb = np.zeros(3), np.zeros(3)
                 ma.calculate_log_likelihood_allele_partial_h(n, s, u, w, ga); mb.calculate_log_likelihood_allele_partial_h(n, s, u, w, gb)
                 assert np.allclose(ga, gb, rtol=1e-8, atol=1e-8), (n, s, u, w, ga, gb)
+
+
+def test_two_datasets_on_one_gpu_equal_their_single_dataset_fits(hip):
+    """BASELINE configs[4]: two tumour samples on one segmentation and breakpoint set, fitted independently side by side
+    (reference workflow.py:472-485) -- each dataset's results must equal its own single-dataset fit bit for bit."""
+    from remixt_amd import synthetic
+    from remixt_amd.restarts import DatasetGroups, RestartGroups
+    e0 = synthetic.make_experiment(400, num_clones=3, max_copy_number=4, num_chains=4, seed=14, num_breakpoints=12)
+    e1 = synthetic.resample_counts(e0, seed=101)
+    assert e1.breakpoints is e0.breakpoints and not np.array_equal(e0.x, e1.x)
+    ps = [synthetic.make_init_params(e, 4, 4) for e in (e0, e1)]
+    seeds = [[1, 2, 3, 4], [11, 12, 13, 14]]
+    both = DatasetGroups([e0, e1], ps, 4, groups=2, num_clones=3, quiet=True, seeds=seeds)
+    elbo = both.fit(num_em_iter=2, num_update_iter=2)
+    res = both.results_by_dataset()
+    for i, e in enumerate((e0, e1)):
+        one = RestartGroups(e, ps[i], 4, groups=2, num_clones=3, quiet=True, seeds=seeds[i])
+        el = one.fit(num_em_iter=2, num_update_iter=2)
+        assert np.array_equal(el, elbo[4 * i:4 * i + 4])
+        for a, b in zip(one.results(), res[i]):
+            assert a['stats']['elbo'] == b['stats']['elbo'] and np.array_equal(a['h'], b['h']) and np.array_equal(a['cn'], b['cn'])
+            assert all(np.array_equal(a['brk_cn'][k], b['brk_cn'][k]) for k in a['brk_cn'])
+            assert np.array_equal(a['p_outlier_total'], b['p_outlier_total'])
+
+
+def test_every_flagged_restart_is_reported_and_cleared(hip):
+    """a batched call that flags several restarts used to clear only the first one's error word; the others
+    surfaced in later, unrelated calls."""
+    from remixt_amd import synthetic
+    from remixt_amd.restarts import RestartSet
+    e = synthetic.make_experiment(150, num_clones=3, max_copy_number=4, num_chains=3, seed=19)
+    ps = synthetic.make_init_params(e, 4, 4)
+    rs = RestartSet(e, ps, 4, num_clones=3, quiet=True, seeds=[1, 2, 3, 4])
+    b = rs.batch
+    h = [b.get_array(r, 'h') for r in range(4)]
+    for r in (1, 3):
+        b.set_array(r, 'h', -h[r])                       # total_depth <= 0 in every state (bpmodel.pyx:721)
+    with pytest.raises(ValueError, match='total_depth <= 0') as info:
+        b.update_p_cn()
+    assert info.value.restarts == [1, 3] and 'restart 1' in str(info.value)
+    for r in (1, 3):
+        b.set_array(r, 'h', h[r])
+    b.update_p_cn(3, 4)                                   # restart 3's word was cleared together with restart 1's
+    b.update_p_cn()
+    assert np.all(np.isfinite(b.calculate_elbo()))
+
+
+def test_lockstep_h_step_fails_only_the_flagged_restart(hip, monkeypatch):
+    """A ValueError of the reference raised by ONE restart's trial h during the lock-step h M-step ends that restart's h
+    update only; the others get exactly the h they get when that restart is not there."""
+    from remixt_amd import synthetic, lockstep
+    from remixt_amd.restarts import RestartSet
+    e = synthetic.make_experiment(300, num_clones=3, max_copy_number=4, num_chains=3, seed=23)
+    ps = synthetic.make_init_params(e, 3, 4)
+
+    def run(poison):
+        rs = RestartSet(e, ps, 4, num_clones=3, quiet=True, seeds=[5, 6, 7])
+        el = rs.calculate_elbo()
+        for m, v in zip(rs.models, el):
+            m.prev_elbo = float(v)
+        if poison:
+            real = rs.batch.expected_log_likelihood_h_batch
+            state = {'n': 0}
+
+            def poisoned(restarts, hs):
+                hs = np.array(hs, dtype=float)
+                state['n'] += 1
+                if state['n'] == 2 and 1 in restarts:
+                    hs[list(restarts).index(1)] *= -1.          # the optimiser of restart 1 "proposes" a negative depth
+                return real(restarts, hs)
+            monkeypatch.setattr(rs.batch, 'expected_log_likelihood_h_batch', poisoned)
+        rs.em_iteration(0, 2)
+        return rs
+    bad, good = run(True), run(False)
+    assert list(bad.error_messages) == [1] and 'total_depth' in bad.error_messages[1]
+    for r in (0, 2):
+        assert np.array_equal(bad.models[r].h, good.models[r].h)
+    assert np.all(np.isfinite([m.prev_elbo for m in bad.models]))
