@@ -759,6 +759,293 @@ __global__ __launch_bounds__(NTMAX) void k_fbv(FbvArgs a) {
 }
 
 // =============================================================================
+// k_fbm: the production forward-backward kernel for S <= 176 -- the S x S product of a step on the FP64 matrix cores.
+//
+// One workgroup advances FOUR restarts of one (chain, direction) in lock step.  The plain-adjacency weights do not
+// depend on the restart, so a step is the 4 x S by S x S product  out[i][o] = sum_q a_i[q] W[q][o]  (i = restart).
+// `v_mfma_f64_4x4x4f64` is four independent 4x4x4 products ("blocks"; lane 16 k + 4 b + r holds element [r][k] of block
+// b's A and [k][r] of its B, lane 16 r + 4 b + c element [r][c] of its result): with the vectors as the A operand of all
+// four blocks and four column groups of W as the B operands, one instruction multiplies 4 restarts x 4 reduction rows x
+// 16 output columns.  Measured (tools/micro/mfma64_bench.hip): 16 FMA / cycle / SIMD, 20 % above what v_fmac_f64
+// reaches, at 1/4 of the issue slots of the vector formulation and without cross-lane broadcasts.
+//   * wave w < NW = ceil(S / 15) owns output columns 15 w .. 15 w + 14 for the WHOLE reduction index: W[:, cols] sits in
+//     its registers as KB = ceil(S / 4) B operands (lane 16 k + c holds W[4 kb + k][15 w + c]), so a column's sum is finished
+//     inside one lane -- no partial sums through LDS, no cross-lane traffic, ONE barrier per step; four accumulators
+//     (k-blocks mod 4) keep the matrix pipe's dependent-issue latency covered and are added in a fixed order;
+//   * the 16th column of every wave's tile is an all-ones column: its result is sum_q a_i[q], the sum of the PREVIOUS row,
+//     for free (165 states = 11 waves x 15 columns).  Any positive per-row factor is a legal scale; the one
+//     used is the power of two 2^e <= sum < 2^(e+1): exact, and available to the whole DPP row through one row_newbcast --
+//     no maximum reduction, no LDS atomics, no second barrier;
+//   * the A operand of k-block kb (lane 16 k + 4 b + i holds a_i[4 kb + k]) is one conflict-free ds_read_b64 (a broadcast
+//     over b) from the restart-interleaved vector image in LDS; k-blocks are stored in pairs so that one ds_read_b128 brings a
+//     lane its elements of two; the reads are issued through untracked asm FBM_DEPTH pairs ahead of the MFMAs that consume
+//     them, into a ring of registers, and retired by counted lgkmcnt waits (LDS returns in order);
+//   * result lane 16 i + c holds out_i[15 w + c]: it scales by that power of two, multiplies by its emission value (one
+//     global load, issued at the top of the step through untracked asm), stores the row and publishes the new vector
+//     element; wave 0's sum lanes store the forward scales for hmm_log_norm_const;
+//   * the three waves of a SIMD run at different priorities, so that one wave's result code overlaps the others' products
+//     instead of all three leaving the matrix pipe idle together (tools/micro/fbm_loop_bench.hip);
+//   * breakend steps (2 % of the steps): the weights are restart-specific, W_i[q][o] = exp(-pen a(q,o)) * tab_i[idx(q,o)]
+//     with the clone-product tables of k_brk_lut (LDS-DMA, a run of plain steps ahead) and 16-bit pair codes in LDS, read
+//     into registers at the start of the step; each k-block issues four MFMAs, one per restart's B operand, and result row i keeps accumulator i.
+// Summation order is fixed: repeated runs are bit-identical.
+// grid (chains of one state-table class, ceil(restarts / 4), 2 directions), block 64 NW.
+// =============================================================================
+struct FbmArgs {
+    int S, SP, M, D, C, N, NBE, cn_max, r0, r1, PE2P, SPC, VR, pad_;
+    double pen;
+    const int32_t *chain_start, *chain_end, *chain_list, *chain_tc, *chain_cls, *be_n, *chain_be;
+    const double *fe, *Wf, *Wb, *pe2_lt;
+    const int8_t *af, *ab, *tot;
+    double *fa, *fb, *mrow;
+    uint32_t *err;
+    unsigned long long *dbg;
+};
+// maximum over the 16 lanes of a DPP row (every lane of the row gets it)
+__device__ __forceinline__ unsigned row_max_u32(unsigned v) {
+    v = max(v, (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x121, 0xf, 0xf, false));   // row_ror:1
+    v = max(v, (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x122, 0xf, 0xf, false));   // row_ror:2
+    v = max(v, (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x124, 0xf, 0xf, false));   // row_ror:4
+    v = max(v, (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x128, 0xf, 0xf, false));   // row_ror:8
+    return v;
+}
+#define FBM_NV 4
+#define FBM_DEPTH 4          // A operands in flight, in PAIRS of k-blocks
+#define FBM_RING (FBM_DEPTH + 1)
+typedef double fbm_d2 __attribute__((ext_vector_type(2)));
+// LDS read / wait the COMPILER does not track (see gload8): the value is valid only after fbm_wait<younger reads in flight>
+template <int OFF> __device__ __forceinline__ void fbm_rd(fbm_d2 &dst, unsigned addr) {
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF) : "memory");
+}
+template <int CNT> __device__ __forceinline__ void fbm_wait(fbm_d2 &x) { asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(x) : "n"(CNT) : "memory"); }
+// position (in doubles) of vector element (state q, restart i) in the LDS image: k-blocks in pairs, [pair][k][i][parity], so
+// that one 16-byte read gives a lane its A elements of two consecutive k-blocks
+__device__ __forceinline__ int fbm_pos(int q, int i) { return ((((q >> 3) * 4 + (q & 3)) * 4 + i) << 1) + ((q >> 2) & 1); }
+// the products of a plain step: pair PI of KB / 2 pairs of k-blocks.  The A operands arrive through a ring of FBM_RING
+// registers: pair PI + FBM_DEPTH is requested into the slot whose MFMAs were issued one pair ago.
+template <int PI, int KB> struct fbm_chain {
+    static __device__ __forceinline__ void run(fbm_d2 (&ring)[FBM_RING], const double (&w)[KB], unsigned addr, double (&acc)[4]) {
+        constexpr int NP = KB / 2;
+        constexpr int younger = (NP - 1 - PI) < (FBM_DEPTH - 1) ? (NP - 1 - PI) : (FBM_DEPTH - 1);
+        fbm_wait<younger>(ring[PI % FBM_RING]);
+        acc[(2 * PI) & 3] = __builtin_amdgcn_mfma_f64_4x4x4f64(ring[PI % FBM_RING].x, w[2 * PI], acc[(2 * PI) & 3], 0, 0, 0);
+        acc[(2 * PI + 1) & 3] = __builtin_amdgcn_mfma_f64_4x4x4f64(ring[PI % FBM_RING].y, w[2 * PI + 1], acc[(2 * PI + 1) & 3], 0, 0, 0);
+        if constexpr (PI + FBM_DEPTH < NP) fbm_rd<(PI + FBM_DEPTH) * 256>(ring[(PI + FBM_DEPTH) % FBM_RING], addr);
+        if constexpr (PI + 1 < NP) fbm_chain<PI + 1, KB>::run(ring, w, addr, acc);
+    }
+    template <int I> static __device__ __forceinline__ void fill(fbm_d2 (&ring)[FBM_RING], unsigned addr) {
+        fbm_rd<I * 256>(ring[I], addr);
+        if constexpr (I + 1 < FBM_DEPTH && I + 1 < KB / 2) fill<I + 1>(ring, addr);
+    }
+};
+
+template <int KB>
+__global__ __launch_bounds__(768) void k_fbm(FbmArgs a) {
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    static_assert(KB % 2 == 0 && KB / 2 >= FBM_DEPTH, "k-blocks come in pairs; ring no deeper than the chain");
+    const int chain = a.chain_list[blockIdx.x], dir = blockIdx.z;
+    const int rg0 = a.r0 + blockIdx.y * FBM_NV;                 // first restart of this workgroup
+    const int nv = min(FBM_NV, a.r1 - rg0);                     // restarts actually present
+    const int S = a.S, SP = a.SP, M = a.M, D = a.D, VR = a.VR, SPC = a.SPC;
+    const int n0 = a.chain_start[chain], n1 = a.chain_end[chain], len = n1 - n0 + 1;
+    const int t = threadIdx.x, NT = blockDim.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6), NW = NT >> 6;
+    const int kq = lane >> 4, c16 = lane & 15, ib = lane & 3;   // operand roles: k inside the k-block, column inside the tile, restart of the A element
+    const int id = lane >> 4;                                   // result role: restart (numerically kq)
+    const bool is_sum = c16 == 15;                              // the tile's 16th column is the all-ones column: its result is the vector's sum
+    const int col = wave * 15 + c16;                            // (state columns 15 w .. 15 w + 14)
+    // ---- LDS carve-up ---------------------------------------------------------------------------
+    double *vec = (double *)smem_raw;                           // [2][VR][4]   vectors, restart-interleaved, double-buffered by step parity
+    double *tab = vec + (size_t)2 * VR * 4;                     // [2][4][PE2P] clone-product weights of the current and the next breakend (LDS-DMA)
+    double *wa = tab + (size_t)2 * 4 * a.PE2P;                  // [64]         exp(-pen * allele distance)
+    unsigned *codel = (unsigned *)(wa + 64);                    // [KB / 2][4][SPC] pair codes of (row q -> column o), two k-blocks per word
+    int *bel = (int *)(codel + (size_t)(KB / 2) * 4 * SPC);     // adjacencies of this chain's breakends
+    const int be_lo = a.chain_be[2 * chain], be_hi = a.chain_be[2 * chain + 1];
+    if (be_hi > be_lo) {
+        // code of the pair (row q -> column o) at a breakend adjacency of this chain and direction: index of the
+        // clone-product weight (differences of the tumour clones' totals; the normal clone's is 0 inside a class)
+        // in the low 10 bits, the allele distance (< 64) above; word [p][k][o] holds rows 4 (2 p) + k and 4 (2 p + 1) + k.
+        // Rows / columns past S: 0.
+        const int8_t *src = (dir == 0 ? a.af : a.ab) + (size_t)a.chain_tc[chain] * S * S;
+        const int8_t *tg = a.tot + (size_t)a.chain_cls[chain] * S * M;
+        const int off_ = a.cn_max + 1, sg_ = dir == 0 ? 1 : -1;
+        for (int i = t; i < (KB / 2) * 4 * SPC; i += NT) {
+            const int o = i % SPC, pk_ = i / SPC, k_ = pk_ & 3, p_ = pk_ >> 2;
+            unsigned word = 0;
+            for (int h = 0; h < 2; h++) {
+                const int q = 4 * (2 * p_ + h) + k_;
+                if (q < S && o < S) {
+                    int idx = 0;
+                    for (int c = 1; c < M; c++) idx = idx * D + sg_ * ((int)tg[q * M + c] - (int)tg[o * M + c]) + off_;
+                    word |= ((unsigned)idx | ((unsigned)src[(size_t)q * S + o] << 10)) << (16 * h);
+                }
+            }
+            codel[i] = word;
+        }
+        for (int i = t; i < be_hi - be_lo; i += NT) bel[i] = a.be_n[be_lo + i];
+    }
+    for (int i = t; i < 2 * VR * 4; i += NT) vec[i] = 0.;
+    for (int i = t; i < 64; i += NT) wa[i] = exp(-a.pen * (double)i);
+    // ---- stationary weights: B operands of this wave's 15 columns and the ones column, every k-block ---------------
+    double w[KB];
+    {
+        const double *Wmat = (dir == 0 ? a.Wf : a.Wb) + (size_t)a.chain_tc[chain] * S * S;
+#pragma unroll
+        for (int kb = 0; kb < KB; kb++) {
+            const int q = 4 * kb + kq;
+            w[kb] = q < S ? (is_sum ? 1.0 : (col < S ? Wmat[(size_t)q * S + col] : 0.)) : 0.;
+        }
+#pragma unroll
+        for (int kb = 0; kb < KB; kb++) asm volatile("" : "+v"(w[kb]));      // their loads retire here, not inside the step loop
+    }
+    __syncthreads();
+
+#define ROW(k) (dir == 0 ? n0 + (k) : n1 - (k))
+#define ADJ(k) (dir == 0 ? n0 + (k) - 1 : n1 - (k))
+    const int be_step = dir == 0 ? 1 : -1;
+    int be_i = dir == 0 ? be_lo : be_hi - 1;                                   // slot of the next breakend step
+    int be_adj = (be_i >= be_lo && be_i < be_hi) ? __builtin_amdgcn_readfirstlane(bel[be_i - be_lo]) : -2;   // its adjacency
+    const int rstep = dir == 0 ? SP : -SP;
+    const bool mine = !is_sum && col < VR;                      // this lane publishes a vector element (possibly a padding column: zero)
+    const bool live = !is_sum && col < S && id < nv;            // ... of an existing column and restart
+    const size_t lane_off = ((size_t)(rg0 + (id < nv ? id : 0)) * a.N + ROW(0)) * SP + (col < S ? col : S - 1);
+    double *outp = (dir == 0 ? a.fa : a.fb) + lane_off;
+    const double *eptr = a.fe + lane_off;
+    double *vput = vec + fbm_pos(mine ? col : 0, id);            // this lane's element of the vector image (buffer 0)
+    const unsigned ap0 = lds_addr(vec + (kq * 4 + ib) * 2);      // A operands of k-blocks 0 and 1 (buffer 0); pair p: + 256 p bytes
+    const bool scribe = dir == 0 && wave == 0 && is_sum && id < nv;   // this lane records the forward scales of restart id
+    double *mptr = a.mrow + (size_t)(rg0 + (id < nv ? id : 0)) * a.N + ROW(0);
+    // the three waves of a SIMD (w, w + 4, w + 8) at different issue priorities
+    if (wave < 4) __builtin_amdgcn_s_setprio(2); else if (wave < 8) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
+    // The clone-product tables of a breakend step (k_brk_lut: PE2P doubles per restart) travel by LDS-DMA into one of two
+    // buffers a whole run of plain steps ahead of the step that reads them: requested right after the previous breakend
+    // step (the first one here), retired by the vmcnt(0) every wave executes in each step, published by the steps' barriers.
+    const int NCH = (a.PE2P * 8 + 1023) >> 10;                   // 1 KiB pieces per table
+#define FBM_FETCH(slot_, buf_)                                                                                                     \
+    for (int task_ = wave; task_ < nv * NCH; task_ += NW) {                                                                        \
+        const int i_ = task_ / NCH, c_ = task_ - i_ * NCH, e16_ = c_ * 64 + lane;     /* restart, piece, 16-byte element */        \
+        const unsigned dst_ = __builtin_amdgcn_readfirstlane(lds_addr(tab + (size_t)((buf_) * 4 + i_) * a.PE2P) + (unsigned)(c_ * 1024)); \
+        if (e16_ * 2 < a.PE2P) glds16(a.pe2_lt + ((size_t)(rg0 + i_) * a.NBE + (slot_)) * a.PE2P + e16_ * 2, dst_);               \
+    }
+    int be_buf = 0;                                              // buffer holding the tables of breakend slot be_i
+    if (be_adj >= 0) FBM_FETCH(be_i, 0)
+    // ---- step 0 ------------------------------------------------------------------------------------------------
+    {
+        double e0 = 0.;
+        if (live) { e0 = *eptr; gstore8(outp, (dir == 0) ? e0 : 1.0); }
+        if (mine) *vput = live ? e0 : 0.;
+    }
+    eptr += rstep;
+    FB_BARRIER();
+    if (a.dbg && t == 0 && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0) { a.dbg[0] = clock64(); a.dbg[1] = wall_clock64(); a.dbg[4] = len; }
+    // the tail of a step, common to plain and breakend steps: `sum` = this lane's product (lane 15 of every DPP row: the
+    // sum of the previous row, from the ones column, whose power of two is this step's scale -- broadcast inside the
+    // row, no LDS, no reduction)
+#define FBM_FINISH(sum_, e_, k_)                                                                                                   \
+    {                                                                                                                              \
+        const unsigned hs_ = (unsigned)__builtin_amdgcn_update_dpp(0, __double2hiint(sum_), 0x15F, 0xf, 0xf, false);   /* row_newbcast:15 */ \
+        double m_, inv_;                                                                                                           \
+        pow2_scale(hs_, m_, inv_);                                                                                                 \
+        outp += rstep;                                                                                                             \
+        gwait8(e_);        /* a step old by now, like this wave's previous result store */                                        \
+        const double val_ = (sum_) * inv_;                                                                                         \
+        const double vecv_ = val_ * (e_);                                                                                          \
+        if (live) gstore8(outp, (dir == 0) ? vecv_ : val_);                                                                        \
+        if (mine) vput[(size_t)((k_) & 1) * VR * 4] = live ? vecv_ : 0.;                                                           \
+        if (scribe) gstore8(mptr, m_);                           /* the scale of row k-1 for hmm_log_norm_const */                \
+        mptr += dir == 0 ? 1 : -1;                                                                                                 \
+        FB_BARRIER();                                                                                                              \
+    }
+    // Plain steps run in their own tight loops between the chain's breakend steps: nothing of the breakend code (tracked
+    // loads, a second barrier, the walk over the chain's breakends) is inside them -- with it in the same loop body every
+    // plain step paid ~750 cycles for the compiler's conservative waits at the merge.
+    int k = 1;
+    while (k < len) {
+        const int k_be = be_adj >= 0 ? (dir == 0 ? be_adj - n0 + 1 : n1 - be_adj) : len;      // step that crosses the next breakend adjacency
+        const int k_stop = k_be < len ? k_be : len;
+        for (; k < k_stop; k++) {
+            double e;
+            gload8(e, eptr);                                     // consumed in FBM_FINISH, after the products
+            eptr += rstep;
+            double acc[4] = {0., 0., 0., 0.};
+            fbm_d2 ring[FBM_RING];
+            const unsigned apc = ap0 + (unsigned)((k - 1) & 1) * (unsigned)(VR * 32);
+            fbm_chain<0, KB>::template fill<0>(ring, apc);
+            fbm_chain<0, KB>::run(ring, w, apc, acc);
+            const double sum = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+            FBM_FINISH(sum, e, k)
+        }
+        if (k < len) {
+            // ---- breakend step: its tables were requested a run of plain steps ago; every wave has retired its own requests
+            // (vmcnt(0) in each step) unless the previous step was a breakend step too
+            const double *tb = tab + (size_t)be_buf * 4 * a.PE2P;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            FB_BARRIER();
+            be_i += be_step;
+            be_adj = (be_i >= be_lo && be_i < be_hi) ? __builtin_amdgcn_readfirstlane(bel[be_i - be_lo]) : -2;
+            be_buf ^= 1;
+            if (be_adj >= 0) FBM_FETCH(be_i, be_buf)            // the next breakend's tables, into the other buffer
+            double e;
+            gload8(e, eptr);
+            eptr += rstep;
+            double acc[FBM_NV] = {0., 0., 0., 0.};
+            const fbm_d2 *apc = reinterpret_cast<const fbm_d2 *>(vec + (size_t)((k - 1) & 1) * VR * 4 + (kq * 4 + ib) * 2);     // pair p: + 16 p
+            // the reduction index in chunks of CHP pairs of k-blocks: a chunk's pair codes come first (one round trip, then every
+            // LDS address of the chunk is known); chunks keep the step inside the register budget next to the resident W operands
+            constexpr int NPAIR = KB / 2;
+            constexpr int CHP = NPAIR % 11 == 0 ? 11 : (NPAIR % 9 == 0 ? 9 : (NPAIR % 8 == 0 ? 8 : (NPAIR % 7 == 0 ? 7 : (NPAIR % 4 == 0 ? 4 : 1))));
+            const unsigned *cw = codel + (size_t)kq * SPC + (col < SPC ? col : 0);
+#pragma unroll 1
+            for (int c0 = 0; c0 < NPAIR; c0 += CHP) {
+                unsigned cpk[CHP];
+#pragma unroll
+                for (int u = 0; u < CHP; u++) cpk[u] = cw[(size_t)(c0 + u) * 4 * SPC];
+#pragma unroll
+                for (int u = 0; u < CHP; u++) {
+                    const fbm_d2 av = apc[(c0 + u) * 16];
+#pragma unroll
+                    for (int h = 0; h < 2; h++) {
+                        const unsigned c_ = (cpk[u] >> (16 * h)) & 0xffffu;
+                        const double wv = wa[c_ >> 10];
+                        const double *tp = tb + (c_ & 1023u);
+                        const double t0 = tp[0], t1 = tp[a.PE2P], t2 = tp[2 * a.PE2P], t3 = tp[3 * a.PE2P];
+                        const double one = 4 * (2 * (c0 + u) + h) + kq < S ? 1.0 : 0.;
+                        const double ak = h ? av.y : av.x;
+                        // (column 15 of restart 0's operand is the ones column: every row of that product holds its restart's sum)
+                        acc[0] = __builtin_amdgcn_mfma_f64_4x4x4f64(ak, is_sum ? one : wv * t0, acc[0], 0, 0, 0);
+                        acc[1] = __builtin_amdgcn_mfma_f64_4x4x4f64(ak, wv * t1, acc[1], 0, 0, 0);
+                        acc[2] = __builtin_amdgcn_mfma_f64_4x4x4f64(ak, wv * t2, acc[2], 0, 0, 0);
+                        acc[3] = __builtin_amdgcn_mfma_f64_4x4x4f64(ak, wv * t3, acc[3], 0, 0, 0);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);      // a pair of k-blocks at a time
+                }
+            }
+            const double sum = (is_sum || id == 0) ? acc[0] : (id == 1 ? acc[1] : (id == 2 ? acc[2] : acc[3]));   // result row i belongs to restart i's weights
+            FBM_FINISH(sum, e, k)
+            k++;
+        }
+    }
+#undef FBM_FINISH
+#undef FBM_FETCH
+    if (a.dbg && t == 0 && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0) { a.dbg[2] = clock64(); a.dbg[3] = wall_clock64(); }
+    // last row of each chain: its scale is not consumed by a later step, but the vanishing-row check needs the row's sum
+    if (wave == 0) {
+        const double *vb = vec + (size_t)((len - 1) & 1) * VR * 4;
+        double ps = 0.;
+        for (int q = c16; q < S; q += 16) ps += vb[fbm_pos(q, id)];
+        ps = group_sum(ps, 16);
+        if (c16 == 0 && id < nv) {
+            double m_, inv;
+            pow2_scale((unsigned)__double2hiint(ps), m_, inv);
+            if (dir == 0) gstore8(a.mrow + (size_t)(rg0 + id) * a.N + ROW(len - 1), m_);
+            if (!(m_ > 0.) || m_ == INFINITY) atomicOr(&a.err[rg0 + id], RMX_ERR_NAN_AB);
+        }
+    }
+#undef ROW
+#undef ADJ
+}
+
+// =============================================================================
 // k_fbk: forward-backward for state grids whose S x S weight matrix does not fit the register file
 // (S > 176, e.g. 355 states at max_cn = 12).  Same step structure, vector operand broadcast (DPP
 // row_newbcast), scaling, emission loads and breakend walk as k_fbv, but the plain-adjacency weight

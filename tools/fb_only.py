@@ -8,6 +8,9 @@ N = int(os.environ.get('SEG', 50000)); R = int(os.environ.get('RST', 16)); K = o
 mcn = int(os.environ.get('MAXCN', 8))
 e = synthetic.make_experiment(N, num_clones=3, max_copy_number=mcn, num_chains=int(os.environ.get('CHAINS', 23)), seed=0, num_breakpoints=int(K) if K else None)
 ps = synthetic.make_init_params(e, R, mcn)
+from remixt_amd import _lib
+if os.environ.get('STAMPS'):      # an alternative build of the library (per-phase cycle counters, experiments): STAMPS=<name> -> tools/micro/lib_<name>.so
+    _lib.LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'micro', 'lib_%s.so' % os.environ['STAMPS'])
 from remixt_amd import bpmodel
 DEBUG = bool(os.environ.get('FB_DEBUG'))
 if DEBUG:
@@ -20,10 +23,15 @@ if os.environ.get('FB_KERNEL'):
 rs = RestartSet(e, ps, mcn, num_clones=3, quiet=True, options=opts)
 b = rs.batch
 print('info rpt,P,NT,BLK,lds,nfast,ngen', [b.info(i) for i in (5, 6, 7, 8, 9, 10, 11)], 'NBE', b.info(3), 'S', b.num_cn_states)
-b.variational_update(1)
+def sweep(n):
+    try:
+        b.variational_update(n)
+    except (ValueError, AssertionError) as err:      # (experimental builds of the kernel may produce garbage: timing only)
+        print('sweep raised:', str(err)[:80])
+sweep(1)
 b.profile_reset(); b.profile_enable(True)
 b.synchronize(); t0 = time.time()
-b.variational_update(it)
+sweep(it)
 b.synchronize(); dt = time.time() - t0
 print('wall ms per sweep', dt / it * 1e3)
 for k, v in sorted(b.profile().items(), key=lambda kv: -kv[1][0]):
@@ -32,5 +40,5 @@ for k, v in sorted(b.profile().items(), key=lambda kv: -kv[1][0]):
 if DEBUG:
     c0, w0, c1, w1, ln = [b.info(i) for i in (20, 21, 22, 23, 24)]
     print('debug: steps', ln, 'shader cycles/step', (c1 - c0) / max(ln - 1, 1), 'wall us/step', (w1 - w0) / 100.0 / max(ln - 1, 1), 'clock GHz', (c1 - c0) / ((w1 - w0) * 10.0))
-    print('stamps wave0 :', [round(b.info(28 + i) / max(ln - 1, 1)) for i in range(10)])
-    print('stamps waveN :', [round(b.info(38 + i) / max(ln - 1, 1)) for i in range(10)])
+    for wv in range(3):
+        print('stamps wave %d (cycles per step: top / products / exchange-write / exchange-read+sum / result code / barrier):' % (4 * wv), [round(b.info(28 + 6 * wv + i) / max(ln - 1, 1)) for i in range(6)])
