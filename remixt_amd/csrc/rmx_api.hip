@@ -806,11 +806,13 @@ int rmx_batch_create(const rmx_problem *pr, int32_t R, const double *h_init, con
     DA(A, double, RN * 2) DA(Bv, double, RN * 4) DA(rowPF, double, RN) DA(rowPP, double, RN) DA(rowZ, double, RN)
     const size_t BEW = (size_t)R * d.NBE * M * d.D;
     DA(pd_lt, double, BEW) DA(pe_lt, double, (size_t)R * d.NBE * ((M * d.D + 1) & ~1) + 2)
-    d.pe2_lt = nullptr; b->pe2p = 0;
+    d.pe2_lt = nullptr; d.pe2x_lt = nullptr; b->pe2p = 0;
     if (M >= 2 && M <= 3 && d.D <= 31 && d.NBE > 0) {
         int n2 = M == 2 ? d.D : d.D * d.D;
         b->pe2p = (n2 + 1) & ~1;
         DA(pe2_lt, double, (size_t)R * d.NBE * b->pe2p + 2)
+        DA(pe2x_lt, double, (size_t)((R + 3) / 4) * d.NBE * b->pe2p * 4 + 2)
+        HIPCHK(hipMemset(d.pe2x_lt, 0, ((size_t)((R + 3) / 4) * d.NBE * b->pe2p * 4 + 2) * 8));
         b->spc = ((S + 63) / 64) * 64;
         DA(pcode, uint16_t, (size_t)std::max(d.TC, 1) * ((S + 7) & ~7) * b->spc) DA(jord, int32_t, (size_t)C * S) DA(jmeta, int32_t, (size_t)C * S)
     } else { d.pcode = nullptr; d.jord = nullptr; d.jmeta = nullptr; }
@@ -1189,15 +1191,15 @@ static int p_cn_front(rmx_batch *b, int r0, int r1, bool skip_frame, bool snapsh
             FbmArgs m;
             memset(&m, 0, sizeof m);
             m.S = d.S; m.SP = d.SP; m.M = d.M; m.D = d.D; m.C = d.C; m.N = d.N; m.NBE = d.NBE; m.cn_max = d.cn_max; m.r0 = r0; m.r1 = r1;
-            m.PE2P = d.NBE > 0 ? b->pe2p : 0; m.SPC = ((NCT * 15 + 15) / 16) * 16; m.VR = std::max(4 * KB, ((NCT * 15 + 7) / 8) * 8); m.pen = d.pen;
+            m.PE2P = d.NBE > 0 ? b->pe2p : 0; m.SPC = NCT * 16; m.VR = std::max(4 * KB, ((NCT * 15 + 7) / 8) * 8); m.pen = d.pen;
             m.chain_start = d.chain_start; m.chain_end = d.chain_end; m.chain_list = d.chain_list_fast; m.chain_tc = d.chain_tc; m.chain_cls = d.chain_cls;
-            m.be_n = d.be_n; m.chain_be = d.chain_be; m.fe = d.fe; m.Wf = d.Wf; m.Wb = d.Wb; m.pe2_lt = d.pe2_lt; m.af = d.af; m.ab = d.ab; m.tot = d.tot;
+            m.be_n = d.be_n; m.chain_be = d.chain_be; m.fe = d.fe; m.Wf = d.Wf; m.Wb = d.Wb; m.pe2_lt = d.pe2x_lt; m.af = d.af; m.ab = d.ab; m.tot = d.tot;
             m.fa = d.fa; m.fb = d.fb; m.mrow = d.mrow; m.err = d.err; m.dbg = b->d_dbg;
             const size_t lds = (size_t)2 * m.VR * 4 * 8 + (size_t)2 * 4 * m.PE2P * 8 + 64 * 8 + (size_t)(KB / 2) * 4 * m.SPC * 4 + (size_t)b->be_cap * 4 + 64;
             void (*kf)(FbmArgs) = KB == 8 ? k_fbm<8> : (KB == 16 ? k_fbm<16> : (KB == 28 ? k_fbm<28> : (KB == 36 ? k_fbm<36> : (KB == 42 ? k_fbm<42> : k_fbm<44>))));
             if (KB > 0 && NCT <= 12 && lds <= kLdsBudget) {
                 HIPCHK(hipFuncSetAttribute((const void *)kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-                hipLaunchKernelGGL(kf, dim3(b->n_fast, (nr + FBM_NV - 1) / FBM_NV, 2), dim3(64 * NCT), lds, b->stream, m);
+                hipLaunchKernelGGL(kf, dim3(b->n_fast, ((r1 - 1) >> 2) - (r0 >> 2) + 1, 2), dim3(64 * NCT), lds, b->stream, m);
                 done_fast = true; fast = true;
             }
         }

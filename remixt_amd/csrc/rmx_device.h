@@ -86,6 +86,7 @@ struct Dev {
     double *pd_lt, *pd_cached;           // [R][NBE][M][D]
     double *pe_lt;                       // [R][NBE][MDP] exp(-pen * pd_lt), rows padded to 16 bytes
     double *pe2_lt;                      // [R][NBE][PE2P] product of pe_lt over the clones by tumour-clone differences (M <= 3), or null
+    double *pe2x_lt;                     // [ceil(R/4)][NBE][PE2P][4] the same, the four restarts of a k_fbm workgroup interleaved, or null
     double *hist;                        // [R][NBE][M][D]
     double *be_jt, *be_ja;               // [R][NBE]
     uint32_t *err;                       // [R]

@@ -844,8 +844,9 @@ __global__ __launch_bounds__(768) void k_fbm(FbmArgs a) {
     extern __shared__ __align__(16) unsigned char smem_raw[];
     static_assert(KB % 2 == 0 && KB / 2 >= FBM_DEPTH, "k-blocks come in pairs; ring no deeper than the chain");
     const int chain = a.chain_list[blockIdx.x], dir = blockIdx.z;
-    const int rg0 = a.r0 + blockIdx.y * FBM_NV;                 // first restart of this workgroup
-    const int nv = min(FBM_NV, a.r1 - rg0);                     // restarts actually present
+    // restarts in absolute quads (4 g .. 4 g + 3: the interleave of the breakend tables); of a quad, those inside [r0, r1)
+    const int quad = (a.r0 >> 2) + blockIdx.y, rg0 = quad * FBM_NV;
+    const int v_lo = max(a.r0 - rg0, 0), v_hi = min(a.r1 - rg0, FBM_NV);      // present: v_lo <= i < v_hi
     const int S = a.S, SP = a.SP, M = a.M, D = a.D, VR = a.VR, SPC = a.SPC;
     const int n0 = a.chain_start[chain], n1 = a.chain_end[chain], len = n1 - n0 + 1;
     const int t = threadIdx.x, NT = blockDim.x, lane = t & 63;
@@ -856,7 +857,7 @@ __global__ __launch_bounds__(768) void k_fbm(FbmArgs a) {
     const int col = wave * 15 + c16;                            // (state columns 15 w .. 15 w + 14)
     // ---- LDS carve-up ---------------------------------------------------------------------------
     double *vec = (double *)smem_raw;                           // [2][VR][4]   vectors, restart-interleaved, double-buffered by step parity
-    double *tab = vec + (size_t)2 * VR * 4;                     // [2][4][PE2P] clone-product weights of the current and the next breakend (LDS-DMA)
+    double *tab = vec + (size_t)2 * VR * 4;                     // [2][PE2P][4] clone-product weights of the current and the next breakend, restart-interleaved (LDS-DMA)
     double *wa = tab + (size_t)2 * 4 * a.PE2P;                  // [64]         exp(-pen * allele distance)
     unsigned *codel = (unsigned *)(wa + 64);                    // [KB / 2][4][SPC] pair codes of (row q -> column o), two k-blocks per word
     int *bel = (int *)(codel + (size_t)(KB / 2) * 4 * SPC);     // adjacencies of this chain's breakends
@@ -869,12 +870,15 @@ __global__ __launch_bounds__(768) void k_fbm(FbmArgs a) {
         const int8_t *src = (dir == 0 ? a.af : a.ab) + (size_t)a.chain_tc[chain] * S * S;
         const int8_t *tg = a.tot + (size_t)a.chain_cls[chain] * S * M;
         const int off_ = a.cn_max + 1, sg_ = dir == 0 ? 1 : -1;
+        const unsigned ones_code = (unsigned)(M == 2 ? D : D * D);      // table entry n2 holds 1 (k_brk_lut), allele distance 0: weight 1
         for (int i = t; i < (KB / 2) * 4 * SPC; i += NT) {
-            const int o = i % SPC, pk_ = i / SPC, k_ = pk_ & 3, p_ = pk_ >> 2;
+            const int ls = i % SPC, pk_ = i / SPC, k_ = pk_ & 3, p_ = pk_ >> 2;      // lane slot 16 w + c: state column 15 w + c, c = 15: the ones column
+            const int o = (ls >> 4) * 15 + (ls & 15);
             unsigned word = 0;
             for (int h = 0; h < 2; h++) {
                 const int q = 4 * (2 * p_ + h) + k_;
-                if (q < S && o < S) {
+                if ((ls & 15) == 15) word |= ones_code << (16 * h);
+                else if (q < S && o < S) {
                     int idx = 0;
                     for (int c = 1; c < M; c++) idx = idx * D + sg_ * ((int)tg[q * M + c] - (int)tg[o * M + c]) + off_;
                     word |= ((unsigned)idx | ((unsigned)src[(size_t)q * S + o] << 10)) << (16 * h);
@@ -907,25 +911,26 @@ __global__ __launch_bounds__(768) void k_fbm(FbmArgs a) {
     int be_adj = (be_i >= be_lo && be_i < be_hi) ? __builtin_amdgcn_readfirstlane(bel[be_i - be_lo]) : -2;   // its adjacency
     const int rstep = dir == 0 ? SP : -SP;
     const bool mine = !is_sum && col < VR;                      // this lane publishes a vector element (possibly a padding column: zero)
-    const bool live = !is_sum && col < S && id < nv;            // ... of an existing column and restart
-    const size_t lane_off = ((size_t)(rg0 + (id < nv ? id : 0)) * a.N + ROW(0)) * SP + (col < S ? col : S - 1);
+    const bool present = id >= v_lo && id < v_hi;
+    const bool live = !is_sum && col < S && present;            // ... of an existing column and restart
+    const size_t lane_off = ((size_t)(rg0 + (present ? id : v_lo)) * a.N + ROW(0)) * SP + (col < S ? col : S - 1);
     double *outp = (dir == 0 ? a.fa : a.fb) + lane_off;
     const double *eptr = a.fe + lane_off;
     double *vput = vec + fbm_pos(mine ? col : 0, id);            // this lane's element of the vector image (buffer 0)
     const unsigned ap0 = lds_addr(vec + (kq * 4 + ib) * 2);      // A operands of k-blocks 0 and 1 (buffer 0); pair p: + 256 p bytes
-    const bool scribe = dir == 0 && wave == 0 && is_sum && id < nv;   // this lane records the forward scales of restart id
-    double *mptr = a.mrow + (size_t)(rg0 + (id < nv ? id : 0)) * a.N + ROW(0);
+    const bool scribe = dir == 0 && wave == 0 && is_sum && present;   // this lane records the forward scales of restart id
+    double *mptr = a.mrow + (size_t)(rg0 + (present ? id : v_lo)) * a.N + ROW(0);
     // the three waves of a SIMD (w, w + 4, w + 8) at different issue priorities
     if (wave < 4) __builtin_amdgcn_s_setprio(2); else if (wave < 8) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
     // The clone-product tables of a breakend step (k_brk_lut: PE2P doubles per restart) travel by LDS-DMA into one of two
     // buffers a whole run of plain steps ahead of the step that reads them: requested right after the previous breakend
     // step (the first one here), retired by the vmcnt(0) every wave executes in each step, published by the steps' barriers.
-    const int NCH = (a.PE2P * 8 + 1023) >> 10;                   // 1 KiB pieces per table
+    const int NCH = (a.PE2P * 32 + 1023) >> 10;                  // 1 KiB pieces of a quad's interleaved table
 #define FBM_FETCH(slot_, buf_)                                                                                                     \
-    for (int task_ = wave; task_ < nv * NCH; task_ += NW) {                                                                        \
-        const int i_ = task_ / NCH, c_ = task_ - i_ * NCH, e16_ = c_ * 64 + lane;     /* restart, piece, 16-byte element */        \
-        const unsigned dst_ = __builtin_amdgcn_readfirstlane(lds_addr(tab + (size_t)((buf_) * 4 + i_) * a.PE2P) + (unsigned)(c_ * 1024)); \
-        if (e16_ * 2 < a.PE2P) glds16(a.pe2_lt + ((size_t)(rg0 + i_) * a.NBE + (slot_)) * a.PE2P + e16_ * 2, dst_);               \
+    for (int c_ = wave; c_ < NCH; c_ += NW) {                                                                                      \
+        const int e16_ = c_ * 64 + lane;                                              /* 16-byte element of the table */          \
+        const unsigned dst_ = __builtin_amdgcn_readfirstlane(lds_addr(tab + (size_t)(buf_) * 4 * a.PE2P) + (unsigned)(c_ * 1024)); \
+        if (e16_ * 2 < a.PE2P * 4) glds16(a.pe2_lt + ((size_t)quad * a.NBE + (slot_)) * a.PE2P * 4 + e16_ * 2, dst_);             \
     }
     int be_buf = 0;                                              // buffer holding the tables of breakend slot be_i
     if (be_adj >= 0) FBM_FETCH(be_i, 0)
@@ -979,12 +984,18 @@ __global__ __launch_bounds__(768) void k_fbm(FbmArgs a) {
             // ---- breakend step: its tables were requested a run of plain steps ago; every wave has retired its own requests
             // (vmcnt(0) in each step) unless the previous step was a breakend step too
             const double *tb = tab + (size_t)be_buf * 4 * a.PE2P;
+#ifdef RMX_FB_STAMPS
+            unsigned long long stamp_acc[6] = {0, 0, 0, 0, 0, 0}, stamp_last;
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_last) :: "memory");
+#endif
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             FB_BARRIER();
+            FB_STAMP(0)
             be_i += be_step;
             be_adj = (be_i >= be_lo && be_i < be_hi) ? __builtin_amdgcn_readfirstlane(bel[be_i - be_lo]) : -2;
             be_buf ^= 1;
             if (be_adj >= 0) FBM_FETCH(be_i, be_buf)            // the next breakend's tables, into the other buffer
+            FB_STAMP(1)
             double e;
             gload8(e, eptr);
             eptr += rstep;
@@ -994,7 +1005,7 @@ __global__ __launch_bounds__(768) void k_fbm(FbmArgs a) {
             // LDS address of the chunk is known); chunks keep the step inside the register budget next to the resident W operands
             constexpr int NPAIR = KB / 2;
             constexpr int CHP = NPAIR % 11 == 0 ? 11 : (NPAIR % 9 == 0 ? 9 : (NPAIR % 8 == 0 ? 8 : (NPAIR % 7 == 0 ? 7 : (NPAIR % 4 == 0 ? 4 : 1))));
-            const unsigned *cw = codel + (size_t)kq * SPC + (col < SPC ? col : 0);
+            const unsigned *cw = codel + (size_t)kq * SPC + (wave * 16 + c16);
 #pragma unroll 1
             for (int c0 = 0; c0 < NPAIR; c0 += CHP) {
                 unsigned cpk[CHP];
@@ -1007,21 +1018,26 @@ __global__ __launch_bounds__(768) void k_fbm(FbmArgs a) {
                     for (int h = 0; h < 2; h++) {
                         const unsigned c_ = (cpk[u] >> (16 * h)) & 0xffffu;
                         const double wv = wa[c_ >> 10];
-                        const double *tp = tb + (c_ & 1023u);
-                        const double t0 = tp[0], t1 = tp[a.PE2P], t2 = tp[2 * a.PE2P], t3 = tp[3 * a.PE2P];
-                        const double one = 4 * (2 * (c0 + u) + h) + kq < S ? 1.0 : 0.;
+                        const double2 t01_ = *reinterpret_cast<const double2 *>(tb + (size_t)(c_ & 1023u) * 4);
+                        const double2 t23_ = *reinterpret_cast<const double2 *>(tb + (size_t)(c_ & 1023u) * 4 + 2);
+                        const double t0 = t01_.x, t1 = t01_.y, t2 = t23_.x, t3 = t23_.y;
                         const double ak = h ? av.y : av.x;
-                        // (column 15 of restart 0's operand is the ones column: every row of that product holds its restart's sum)
-                        acc[0] = __builtin_amdgcn_mfma_f64_4x4x4f64(ak, is_sum ? one : wv * t0, acc[0], 0, 0, 0);
+                        // (the ones column's code selects weight 1 for every restart: every row of each product holds its restart's sum)
+                        acc[0] = __builtin_amdgcn_mfma_f64_4x4x4f64(ak, wv * t0, acc[0], 0, 0, 0);
                         acc[1] = __builtin_amdgcn_mfma_f64_4x4x4f64(ak, wv * t1, acc[1], 0, 0, 0);
                         acc[2] = __builtin_amdgcn_mfma_f64_4x4x4f64(ak, wv * t2, acc[2], 0, 0, 0);
                         acc[3] = __builtin_amdgcn_mfma_f64_4x4x4f64(ak, wv * t3, acc[3], 0, 0, 0);
                     }
-                    __builtin_amdgcn_sched_barrier(0);      // a pair of k-blocks at a time
+                    if (u & 1) __builtin_amdgcn_sched_barrier(0);      // two pairs of k-blocks at a time (register budget)
                 }
             }
-            const double sum = (is_sum || id == 0) ? acc[0] : (id == 1 ? acc[1] : (id == 2 ? acc[2] : acc[3]));   // result row i belongs to restart i's weights
+            const double sum = id == 0 ? acc[0] : (id == 1 ? acc[1] : (id == 2 ? acc[2] : acc[3]));   // result row i belongs to restart i's weights
+            FB_STAMP(2)
             FBM_FINISH(sum, e, k)
+            FB_STAMP(3)
+#ifdef RMX_FB_STAMPS
+            if (a.dbg && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && lane == 0 && (wave & 3) == 0) { for (int i = 0; i < 4; i++) a.dbg[8 + (wave >> 2) * 6 + i] += stamp_acc[i]; if (wave == 0) a.dbg[5] += 1; }
+#endif
             k++;
         }
     }
@@ -1034,7 +1050,7 @@ __global__ __launch_bounds__(768) void k_fbm(FbmArgs a) {
         double ps = 0.;
         for (int q = c16; q < S; q += 16) ps += vb[fbm_pos(q, id)];
         ps = group_sum(ps, 16);
-        if (c16 == 0 && id < nv) {
+        if (c16 == 0 && present) {
             double m_, inv;
             pow2_scale((unsigned)__double2hiint(ps), m_, inv);
             if (dir == 0) gstore8(a.mrow + (size_t)(rg0 + id) * a.N + ROW(len - 1), m_);
@@ -1671,6 +1687,7 @@ __global__ void k_brk_lut(Dev d, int r0, double *dst_base, double *exp_base, dou
             double v = 0.;
             if (i < n2) v = d.M == 2 ? p0 * pes[64 + i] : (p0 * pes[64 + i / d.D]) * pes[128 + i % d.D];
             pr[i] = v;
+            if (d.pe2x_lt) d.pe2x_lt[((((size_t)(r >> 2) * d.NBE + slot) * PE2P + i) << 2) + (r & 3)] = i == n2 ? 1.0 : v;   // (entry n2, the pad: weight of k_fbm's ones column)
         }
     }
 }

@@ -40,5 +40,6 @@ for k, v in sorted(b.profile().items(), key=lambda kv: -kv[1][0]):
 if DEBUG:
     c0, w0, c1, w1, ln = [b.info(i) for i in (20, 21, 22, 23, 24)]
     print('debug: steps', ln, 'shader cycles/step', (c1 - c0) / max(ln - 1, 1), 'wall us/step', (w1 - w0) / 100.0 / max(ln - 1, 1), 'clock GHz', (c1 - c0) / ((w1 - w0) * 10.0))
+    nbe = max(b.info(25), 1)
     for wv in range(3):
-        print('stamps wave %d (cycles per step: top / products / exchange-write / exchange-read+sum / result code / barrier):' % (4 * wv), [round(b.info(28 + 6 * wv + i) / max(ln - 1, 1)) for i in range(6)])
+        print('breakend-step stamps wave %d (cycles per breakend step of chain 0: entry wait+barrier / walk+fetch issue / products / finish):' % (4 * wv), [round(b.info(28 + 6 * wv + i) / nbe) for i in range(4)], 'breakend steps', nbe)
