@@ -1822,19 +1822,41 @@ __global__ void k_pairwise_be2(Dev d, int r0, int PE2P, int SPC) {
     double *fold = zrow + NT;                             // [3][M*D] partial sums of the fold
     int *jm = (int *)(fold + 3 * M * D);                  // [S8] jmeta of class cb, zero-padded
     int *toti = jm + ((S + 7) & ~7);                      // [S] totals of the row states (class ca), one byte per clone
+    // every global read of the prologue is issued before the first is consumed (one round trip, not a chain of them):
+    // the column order is applied afterwards, LDS to LDS
     const double *fb = d.fb + rs_off(d, r, n + 1), *fe = d.fe + rs_off(d, r, n + 1);
-    for (int jj = t; jj < ((S + 7) & ~7); jj += NT) {
-        if (jj < S) { const int j = d.jord[(size_t)cb * S + jj]; gvec[jj] = fe[j] * fb[j]; jm[jj] = d.jmeta[(size_t)cb * S + jj]; }
-        else { gvec[jj] = 0.; jm[jj] = 0; }
-    }
-    for (int i = t; i < S; i += NT) {
-        int pk = 0;
-        for (int c = 0; c < M; c++) pk |= ((int)d.tot[((size_t)ca * S + i) * M + c] & 0xff) << (8 * c);
-        toti[i] = pk;
-    }
+    double *glin = bins + ((S + 7) & ~7);                 // [S] fe*fb in state order (parked, like the column order, in the not yet used bins area)
+    const int S8_ = (S + 7) & ~7;
     const double *tg = d.pe2_lt + ((size_t)r * d.NBE + slot) * PE2P;
-    for (int i = t; i < PE2P; i += NT) tab[i] = tc >= 0 ? tg[i] : 1.0;
+    {
+        double gl_[4]; int jo_[4], jm_[4], tk_[4]; double tb_[8];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {           // S <= 4 NT (NT >= 64, S <= 1024 but this kernel is only selected for S <= 255: pe2 tables)
+            const int jj = t + u * NT;
+            gl_[u] = jj < S ? fe[jj] * fb[jj] : 0.;
+            jo_[u] = jj < S ? d.jord[(size_t)cb * S + jj] : 0;
+            jm_[u] = jj < S ? d.jmeta[(size_t)cb * S + jj] : 0;
+            int pk = 0;
+            if (jj < S) for (int c = 0; c < M; c++) pk |= ((int)d.tot[((size_t)ca * S + jj) * M + c] & 0xff) << (8 * c);
+            tk_[u] = pk;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++) { const int i = t + u * NT; tb_[u] = (tc >= 0 && i < PE2P) ? tg[i] : 1.0; }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int jj = t + u * NT;
+            if (jj < S) { glin[jj] = gl_[u]; toti[jj] = tk_[u]; }
+            if (jj < S8_) { jm[jj] = jj < S ? jm_[u] : 0; zrow[jj < NT ? jj : 0] = 0.; }
+            if (jj < S8_) ((int *)(bins))[jj] = jo_[u];       // the column order, parked in the (not yet used) bins area
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++) { const int i = t + u * NT; if (i < PE2P) tab[i] = tb_[u]; }
+        for (int i = t + 8 * NT; i < PE2P; i += NT) tab[i] = tc >= 0 ? tg[i] : 1.0;
+    }
     for (int i = t; i < 128; i += NT) wa[i] = tc >= 0 ? exp(-d.pen * (double)i) : 1.0;
+    __syncthreads();
+    for (int jj = t; jj < S8_; jj += NT) gvec[jj] = jj < S ? glin[((int *)(bins))[jj]] : 0.;
+    __syncthreads();
     double *mybins = bins + (size_t)t * (M - 1) * NB;     // plane c-1 for tumour clone c
     for (int i = 0; i < (M - 1) * NB; i++) mybins[i] = 0.;
     zrow[t] = 0.;

@@ -18,6 +18,8 @@ if DEBUG:
 opts = {}
 if os.environ.get('NV'):
     opts['fb_nv'] = int(os.environ['NV'])
+if os.environ.get('ONE_STREAM'):
+    opts['two_streams'] = 0
 if os.environ.get('FB_KERNEL'):
     opts['fb_kernel'] = int(os.environ['FB_KERNEL'])
 rs = RestartSet(e, ps, mcn, num_clones=3, quiet=True, options=opts)
