@@ -78,6 +78,8 @@ def parse(argv=None):
     ap.add_argument('--no-fit-from-init', action='store_true', help='skip the construct -> 5 EM iterations -> decode wall-clock measurement at N = 1')
     ap.add_argument('--no-mstep', action='store_true', help='diagnostic only: variational sweeps without M-steps (NOT the reported metric)')
     ap.add_argument('--master-port', type=int, default=0, help='rendezvous port when bench.py starts the ranks itself (0 = pick a free one)')
+    ap.add_argument('--option', action='append', default=[], metavar='NAME=VALUE',
+                    help='A/B measurements: a tuning option of the library (include/remixt_amd.h, enum rmx_option_id) for every batch of this run')
     ap.add_argument('--cpu-leg', action='store_true', help=argparse.SUPPRESS)       # internal: the CPU baseline child process
     return ap.parse_args(argv)
 
@@ -273,6 +275,11 @@ def main():
 
     from remixt_amd import synthetic
     from remixt_amd.restarts import RestartGroups, DatasetGroups, _pack
+    if args.option and kernel_module is None:
+        from remixt_amd import bpmodel
+        for item in args.option:
+            name, value = item.split('=')
+            bpmodel.set_default_option(name, int(value))
 
     # ---- which restarts does this rank fit -----------------------------------------------------------
     strong = args.total_restarts > 0

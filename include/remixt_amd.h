@@ -215,6 +215,11 @@ int rmx_param_search(rmx_batch *b, int32_t nreq, const int32_t *restarts, int32_
  * [nparams][nreq] = optimiser result and last evaluated point (the state the acceptance test of
  * cn_model.py:563-569 looks at).  The model is not modified.  RMX_EUNSUPPORTED: use rmx_param_search. */
 int rmx_set_sample_slot(rmx_batch *b, int32_t r, int32_t slot, const int64_t *sample);
+/* The M-step samples (cn_model.py:475-480) of several restarts in one call and one device transfer: list i
+ * is the ascending segment indices indices[offsets[i] .. offsets[i+1]) of restart restarts[i]; slots[i] = -1:
+ * the restart's current sample (as rmx_set_sample), 0..3: its parameter slot (as rmx_set_sample_slot). */
+int rmx_set_sample_lists(rmx_batch *b, int32_t nlists, const int32_t *restarts, const int32_t *slots,
+                         const int32_t *offsets, const int32_t *indices);
 int rmx_param_search_multi(rmx_batch *b, int32_t nreq, const int32_t *restarts, int32_t nparams,
                            const int32_t *param_ids, const double *lo, const double *hi,
                            const double *grids, int32_t G, double *xopt, double *lastval);

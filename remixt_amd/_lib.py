@@ -64,6 +64,7 @@ SYMBOLS = {
     "rmx_expected_ll_batch": (C.c_int, [C.c_void_p, C.c_int32, _i32p, C.c_int32, _dp, _dp]),
     "rmx_param_search": (C.c_int, [C.c_void_p, C.c_int32, _i32p, C.c_int32, C.c_double, C.c_double, _dp, C.c_int32, _dp]),
     "rmx_set_sample_slot": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, _ip]),
+    "rmx_set_sample_lists": (C.c_int, [C.c_void_p, C.c_int32, _i32p, _i32p, _i32p, _i32p]),
     "rmx_param_search_multi": (C.c_int, [C.c_void_p, C.c_int32, _i32p, C.c_int32, _i32p, _dp, _dp, _dp, C.c_int32, _dp, _dp]),
     "rmx_expected_ll_h_batch": (C.c_int, [C.c_void_p, C.c_int32, _i32p, _dp, _dp]),
     "rmx_expected_ll_full": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, _dp]),

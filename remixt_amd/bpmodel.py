@@ -378,6 +378,25 @@ class RemixtBatch(object):
             raise ValueError('sample must have length num_segments')
         self._ck(self._lib.rmx_set_sample_slot(self._handle, int(r), int(slot), s64.ctypes.data_as(_ip)))
 
+    def set_sample_lists(self, entries):
+        """M-step samples of several restarts in one call (rmx_set_sample_lists).  `entries`: (restart, slot, mask, indices) with
+        slot -1 = the restart's current sample (what _use_sample uploads) or 0..3 = its parameter slot of param_search_multi;
+        `indices` = np.flatnonzero(mask), `mask` the dense array the per-restart calls take (kept for _use_sample's identity test)."""
+        if not entries:
+            return
+        rl = np.array([e[0] for e in entries], dtype=np.int32)
+        sl = np.array([e[1] for e in entries], dtype=np.int32)
+        idx = [np.ascontiguousarray(e[3], dtype=np.int32).ravel() for e in entries]
+        off = np.zeros(len(entries) + 1, dtype=np.int32)
+        off[1:] = np.cumsum([len(i) for i in idx])
+        flat = np.concatenate(idx) if len(idx) else np.zeros(0, dtype=np.int32)
+        flat = np.ascontiguousarray(flat, dtype=np.int32)
+        self._ck(self._lib.rmx_set_sample_lists(self._handle, len(entries), rl.ctypes.data_as(_i32p), sl.ctypes.data_as(_i32p),
+                                                off.ctypes.data_as(_i32p), flat.ctypes.data_as(_i32p)))
+        for r, slot, mask, _ in entries:
+            if slot < 0:
+                self._samples[int(r)] = mask
+
     def param_search_multi(self, restarts, names, los, his, grids):
         """The searches of param_search for several of the four standard likelihood parameters at once
         (rmx_param_search_multi; samples from set_sample_slot, slot = position in `names`).  Returns

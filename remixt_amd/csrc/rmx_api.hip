@@ -69,11 +69,15 @@ struct rmx_batch {
     std::vector<char> logz_dirty;
     int *d_lt_valid = nullptr;
     // scratch
-    double *d_partial = nullptr;       // ELBO partials [R][ELBO_BLOCKS][2]
+    double *d_partial = nullptr;       // ELBO partials [R][ELBO_BLOCKS][3]
+    double *d_be_e = nullptr;          // ELBO: energy term of every breakend slot [R][NBE]
     double *d_out4 = nullptr;          // [R][4]
     double *d_ell_partial = nullptr;   // [max(N,ELBO_BLOCKS)][1+MAXC]
     double *d_ell_out = nullptr;       // [1+MAXC]
     double *h_pinned = nullptr;        // pinned staging [max(4R, 16)]
+    int32_t *h_lists = nullptr;        // pinned staging of rmx_set_sample_lists (read by the device in place)
+    size_t h_lists_cap = 0;
+    hipEvent_t ev_lists = nullptr;     // the scatter kernel that last read h_lists
     uint32_t *h_err = nullptr;         // pinned [4R+64]: landing area of check_errors / per-request error words
     int32_t *d_sample = nullptr;       // [R][N] index lists of the current M-step samples
     int32_t *d_msample = nullptr, *d_mcounts = nullptr;   // [4][R][N], [4][R]: per parameter slot, for rmx_param_search_multi
@@ -462,13 +466,25 @@ static void fill_logr(RestartParams &rp) { rp.logr[0] = std::log(rp.p[RMX_P_NEGB
 // per-segment constant table ([8][N] lgamma differences) only when a full pass over all segments
 // needs it (need_segc) -- the sampled M-step objective evaluates its own segments' constants.
 static int ensure_tables(rmx_batch *b, int r0, int r1, bool need_segc = true) {
-    for (int r = r0; r < r1; r++) {
-        if (b->tables_dirty[r]) {
-            fill_logr(b->rp[r]);
+    {
+        // parameters travel by value in the kernel arguments, up to 16 restarts per launch
+        StageArgs sa;
+        int n_ = 0;
+        auto flush = [&]() {
+            if (!n_) return;
             ProfScope ps(b, KID_STATE_TABLES);
-            hipLaunchKernelGGL(k_state_tables_one, dim3(b->d.C), dim3(256), 0, b->stream, b->d, r, b->rp[r]);
+            if (n_ == 1) hipLaunchKernelGGL(k_state_tables_one, dim3(b->d.C), dim3(256), 0, b->stream, b->d, (int)sa.rlist[0], sa.rp[0]);
+            else hipLaunchKernelGGL(k_state_tables_many, dim3(b->d.C, n_), dim3(256), 0, b->stream, b->d, sa);
+            n_ = 0;
+        };
+        for (int r = r0; r < r1; r++) {
+            if (!b->tables_dirty[r]) continue;
+            fill_logr(b->rp[r]);
+            sa.rlist[n_] = r; sa.rp[n_] = b->rp[r];
+            if (++n_ == 16) flush();
             b->tables_dirty[r] = 0; b->segc_dirty[r] = 1; b->ab_dirty[r] = 1;
         }
+        flush();
     }
     if (need_segc) {
         int r = r0;
@@ -831,7 +847,7 @@ int rmx_batch_create(const rmx_problem *pr, int32_t R, const double *h_init, con
         const bool want = b->opt[RMX_OPT_CELL_CACHE] != 0;
         if (want && S > 32 && S <= 384 && bytes <= ((size_t)96 << 30)) { double *p_ = nullptr; if (dalloc(b, &p_, RNS * 6) == RMX_OK) { d.lc = p_; b->use_cache = true; } }
     }
-    if ((rc = dalloc(b, &b->d_lt_valid, R)) || (rc = dalloc(b, &b->d_partial, (size_t)R * ELBO_BLOCKS * 2)) || (rc = dalloc(b, &b->d_out4, (size_t)R * 4)) ||
+    if ((rc = dalloc(b, &b->d_lt_valid, R)) || (rc = dalloc(b, &b->d_partial, (size_t)R * ELBO_BLOCKS * 3)) || (rc = dalloc(b, &b->d_be_e, (size_t)R * std::max(d.NBE, 1))) || (rc = dalloc(b, &b->d_out4, (size_t)R * 4)) ||
         (rc = dalloc(b, &b->d_ell_partial, (size_t)R * std::max(N, ELBO_BLOCKS) * (1 + RMX_MAX_CLONES))) || (rc = dalloc(b, &b->d_ell_out, (size_t)R * 8)) ||
         (rc = dalloc(b, &b->d_sample, (size_t)R * N)) || (rc = dalloc(b, &b->d_grid_out, (size_t)R * 64 * (1 + RMX_MAX_CLONES))) ||
         (rc = dalloc(b, &b->d_rlist, R)) || (rc = dalloc(b, &b->d_counts, R)) || (rc = dalloc(b, &b->d_rp_stage, R)) || (rc = dalloc(b, &b->d_batch_out, (size_t)R * 8))) { rmx_batch_destroy(b); return rc; }
@@ -916,6 +932,8 @@ int rmx_batch_destroy(rmx_batch *b) { BIND(b);
     prof_collect(b);
     for (void *p : b->allocs) hipFree(p);
     if (b->h_pinned) hipHostFree(b->h_pinned);
+    if (b->h_lists) hipHostFree(b->h_lists);
+    if (b->ev_lists) hipEventDestroy(b->ev_lists);
     if (b->h_err) hipHostFree(b->h_err);
     if (b->h_batch) hipHostFree(b->h_batch);
     for (auto e : b->ev_pool) hipEventDestroy(e);
@@ -1410,13 +1428,14 @@ static int elbo_parts(rmx_batch *b, int r0, int r1, bool exact_parts, double *ou
         HIPCHK(hipMemcpy(d_fp, plain_host.data(), nr * 8, hipMemcpyHostToDevice));
         full_plain = d_fp;
     }
-    { ProfScope ps(b, KID_ELBO_SEG); hipLaunchKernelGGL(k_elbo_seg, dim3(ELBO_BLOCKS, nr), dim3(256), 0, b->stream, b->d, r0, b->d_partial); }
+    { ProfScope ps(b, KID_ELBO_SEG); hipLaunchKernelGGL(k_elbo_seg, dim3(ELBO_BLOCKS, nr), dim3(256), 0, b->stream, b->d, r0, b->d_partial, b->d_be_e); }
     // plain_T_init may differ per restart only in exotic call orders: one launch per run of equal values
     for (int r = r0; r < r1;) {
         int e = r + 1;
         while (e < r1 && b->plain_T_init[e] == b->plain_T_init[r]) e++;
         ProfScope ps(b, KID_ELBO_FINAL);
-        hipLaunchKernelGGL(k_elbo_final, dim3(e - r), dim3(256), 0, b->stream, b->d, r, b->d_partial + (size_t)(r - r0) * ELBO_BLOCKS * 2, ELBO_BLOCKS,
+        hipLaunchKernelGGL(k_elbo_final, dim3(e - r), dim3(256), 0, b->stream, b->d, r, b->d_partial + (size_t)(r - r0) * ELBO_BLOCKS * 3,
+                           b->d_be_e + (size_t)(r - r0) * b->d.NBE, ELBO_BLOCKS,
                            (const int *)b->d_lt_valid, b->plain_T_init[r], full_plain ? full_plain + (r - r0) : nullptr, b->d_out4 + (size_t)(r - r0) * 4);
         r = e;
     }
@@ -1504,6 +1523,7 @@ static int set_sample(rmx_batch *b, int r, const int64_t *sample) {
     std::vector<int64_t> &cache = b->sample_cache[r];
     if ((int)cache.size() == d.N && memcmp(cache.data(), sample, (size_t)d.N * 8) == 0) return RMX_OK;
     cache.assign(sample, sample + d.N);
+    if (b->ev_lists) HIPCHK(hipEventSynchronize(b->ev_lists));       // a pending rmx_set_sample_lists scatter must not land after this upload
     std::vector<int32_t> idx;
     idx.reserve(256);
     for (int n = 0; n < d.N; n++) if (sample[n] != 0) idx.push_back(n);
@@ -1956,9 +1976,54 @@ int rmx_set_sample_slot(rmx_batch *b, int32_t r, int32_t slot, const int64_t *sa
     idx.reserve(256);
     for (int n = 0; n < d.N; n++) if (sample[n] != 0) idx.push_back(n);
     const size_t q = (size_t)slot * b->R + r;
+    if (b->ev_lists) HIPCHK(hipEventSynchronize(b->ev_lists));
     b->msample_count[q] = (int)idx.size();
     { int32_t c32 = (int32_t)idx.size(); HIPCHK(hipMemcpy(b->d_mcounts + q, &c32, 4, hipMemcpyHostToDevice)); }
     if (!idx.empty()) HIPCHK(hipMemcpy(b->d_msample + q * d.N, idx.data(), idx.size() * 4, hipMemcpyHostToDevice));
+    return RMX_OK;
+}
+
+int rmx_set_sample_lists(rmx_batch *b, int32_t nlists, const int32_t *restarts, const int32_t *slots, const int32_t *offsets, const int32_t *indices) { BIND(b);
+    if (!b || nlists < 0 || (nlists > 0 && (!restarts || !slots || !offsets))) return fail(RMX_EARG, "bad argument");
+    if (nlists == 0) return RMX_OK;
+    const Dev &d = b->d;
+    int rc;
+    bool any_slot = false;
+    if (offsets[0] != 0) return fail(RMX_EARG, "offsets must start at 0");
+    for (int i = 0; i < nlists; i++) {
+        if (restarts[i] < 0 || restarts[i] >= b->R || slots[i] < -1 || slots[i] > 3 || offsets[i + 1] < offsets[i] || offsets[i + 1] - offsets[i] > d.N)
+            return fail(RMX_EARG, "bad sample list");
+        if (offsets[i + 1] > offsets[i] && !indices) return fail(RMX_EARG, "bad argument");
+        for (int j = offsets[i]; j < offsets[i + 1]; j++)
+            if (indices[j] < 0 || indices[j] >= d.N || (j > offsets[i] && indices[j] <= indices[j - 1])) return fail(RMX_EARG, "sample indices must be ascending segment indices");
+        any_slot |= slots[i] >= 0;
+    }
+    if (any_slot && !b->d_msample) {
+        if ((rc = dalloc(b, &b->d_msample, (size_t)4 * b->R * d.N)) || (rc = dalloc(b, &b->d_mcounts, (size_t)4 * b->R))) return rc;
+        b->msample_count.assign((size_t)4 * b->R, -1);
+    }
+    const size_t total = (size_t)offsets[nlists], need = (size_t)4 * nlists + total;
+    if (b->ev_lists) HIPCHK(hipEventSynchronize(b->ev_lists));      // the previous scatter has read the staging area
+    else HIPCHK(hipEventCreateWithFlags(&b->ev_lists, hipEventDisableTiming));
+    if (need > b->h_lists_cap) {
+        if (b->h_lists) HIPCHK(hipHostFree(b->h_lists));
+        b->h_lists = nullptr; b->h_lists_cap = 0;
+        const size_t cap = std::max(need * 2, (size_t)4096);
+        HIPCHK(hipHostMalloc((void **)&b->h_lists, cap * 4));
+        b->h_lists_cap = cap;
+    }
+    int32_t *hd = b->h_lists, *body = b->h_lists + (size_t)4 * nlists;
+    for (int i = 0; i < nlists; i++) {
+        const int cnt = offsets[i + 1] - offsets[i], r = restarts[i];
+        hd[4 * i] = r; hd[4 * i + 1] = slots[i]; hd[4 * i + 2] = cnt; hd[4 * i + 3] = offsets[i];
+        if (slots[i] < 0) { b->sample_count[r] = cnt; b->sample_cache[r].clear(); }
+        else b->msample_count[(size_t)slots[i] * b->R + r] = cnt;
+    }
+    if (total) memcpy(body, indices, total * 4);
+    hipLaunchKernelGGL(k_scatter_samples, dim3(nlists), dim3(256), 0, b->stream, (const int32_t *)hd, (const int32_t *)body, b->d_sample, b->d_counts,
+                       b->d_msample, b->d_mcounts, d.N, b->R);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(b->ev_lists, b->stream));
     return RMX_OK;
 }
 

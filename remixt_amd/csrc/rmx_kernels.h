@@ -1990,18 +1990,19 @@ __global__ void k_brk_update(Dev d, int r0) {
 // ELBO pieces (bpmodel.pyx:1044-1123)
 // =============================================================================
 #define ELBO_BLOCKS 256
-// per-block partials: [r][ELBO_BLOCKS][2] (energy, entropy) over segments
-__global__ void k_elbo_seg(Dev d, int r0, double *partial) {
+// per-block partials: [r][ELBO_BLOCKS][3] (energy, entropy, log Z) over segments; be_e [nr][NBE]: energy term of every breakend slot
+__global__ void k_elbo_seg(Dev d, int r0, double *partial, double *be_e) {
     __shared__ double scratch[8];
     const int r = r0 + blockIdx.y;
     const RestartParams &rp = d.rp[r];
     const double pt = rp.p[RMX_P_PRIOR_OUTLIER_TOTAL], pa = rp.p[RMX_P_PRIOR_OUTLIER_ALLELE];
     const double l1t = log(1. - pt), l0t = log(pt), l1a = log(1. - pa), l0a = log(pa);
-    double en = 0., ent = 0.;
+    double en = 0., ent = 0., z = 0.;
     for (int n = blockIdx.x * blockDim.x + threadIdx.x; n < d.N; n += gridDim.x * blockDim.x) {
         const size_t rn = (size_t)r * d.N + n;
         const double qt0 = d.qt[rn * 2], qt1 = d.qt[rn * 2 + 1], qa0 = d.qa[rn * 2], qa1 = d.qa[rn * 2 + 1];
         const double qs0 = d.qs[rn * 2], qs1 = d.qs[rn * 2 + 1];
+        z += d.rowZ[rn];
         double e = d.rowPP[rn];
         e += qt0 * d.A[rn * 2] + qt1 * d.A[rn * 2 + 1];
         e += qt0 * l1t + qt1 * l0t;
@@ -2014,21 +2015,37 @@ __global__ void k_elbo_seg(Dev d, int r0, double *partial) {
     }
     en = block_sum<256>(en, scratch);
     ent = block_sum<256>(ent, scratch);
+    z = block_sum<256>(z, scratch);
     if (threadIdx.x == 0) {
-        partial[((size_t)(r - r0) * gridDim.x + blockIdx.x) * 2] = en;
-        partial[((size_t)(r - r0) * gridDim.x + blockIdx.x) * 2 + 1] = ent;
+        partial[((size_t)(r - r0) * gridDim.x + blockIdx.x) * 3] = en;
+        partial[((size_t)(r - r0) * gridDim.x + blockIdx.x) * 3 + 1] = ent;
+        partial[((size_t)(r - r0) * gridDim.x + blockIdx.x) * 3 + 2] = z;
+    }
+    // transition factor of the energy at breakend adjacencies, one thread per slot (the sum over a slot's table in index order)
+    for (int slot = blockIdx.x * blockDim.x + threadIdx.x; slot < d.NBE; slot += gridDim.x * blockDim.x) {
+        double e = 0.;
+        if (d.tclass[d.be_n[slot]] >= 0) {      // telomere: T == 0
+            const double *h = d.hist + ((size_t)r * d.NBE + slot) * d.M * d.D;
+            const double *pc = d.pd_cached + ((size_t)r * d.NBE + slot) * d.M * d.D;
+            for (int i = 0; i < d.M * d.D; i++) e += h[i] * (-d.pen * pc[i]);
+            e += -d.pen * d.be_ja[(size_t)r * d.NBE + slot];
+        }
+        be_e[(size_t)(r - r0) * d.NBE + slot] = e;
     }
 }
 // out[(r-r0)*4 + {0,1,2,3}] = energy, entropy, elbo, hmm_log_norm_const
 // lt_valid: update_p_cn has run (joint/log_transmat are live) ; plain_T_init: sum over plain
 // adjacencies of mean(cached_log_transmat) for the pre-update state ; full_plain: optional
 // sum over plain adjacencies of joint*T (adds to both energy and entropy when exact parts are requested)
-__global__ void k_elbo_final(Dev d, int r0, const double *partial, int nblk, const int *lt_valid, double plain_T_init,
+__global__ void k_elbo_final(Dev d, int r0, const double *partial, const double *be_e, int nblk, const int *lt_valid, double plain_T_init,
                              const double *full_plain, double *out) {
     __shared__ double scratch[8];
     const int r = r0 + blockIdx.x, t = threadIdx.x;
-    double en = 0., ent = 0.;
-    if (t == 0) for (int i = 0; i < nblk; i++) { en += partial[((size_t)(r - r0) * nblk + i) * 2]; ent += partial[((size_t)(r - r0) * nblk + i) * 2 + 1]; }
+    double en = 0., ent = 0., z = 0.;
+    if (t == 0) for (int i = 0; i < nblk; i++) {
+        const double *pp = partial + ((size_t)blockIdx.x * nblk + i) * 3;
+        en += pp[0]; ent += pp[1]; z += pp[2];
+    }
     // entropy of q(brk)
     double hb = 0.;
     for (int i = t; i < d.K * d.B; i += 256) hb += xlogx(d.pbrk[(size_t)r * d.K * d.B + i]);
@@ -2036,29 +2053,19 @@ __global__ void k_elbo_final(Dev d, int r0, const double *partial, int nblk, con
     // transition factors at breakend adjacencies
     double ec = 0., jt = 0.;
     for (int slot = t; slot < d.NBE; slot += 256) {
-        const int n = d.be_n[slot];
-        if (d.tclass[n] < 0) continue;   // telomere: T == 0
-        const double *h = d.hist + ((size_t)r * d.NBE + slot) * d.M * d.D;
-        const double *pc = d.pd_cached + ((size_t)r * d.NBE + slot) * d.M * d.D;
-        double e = 0.;
-        for (int i = 0; i < d.M * d.D; i++) e += h[i] * (-d.pen * pc[i]);
-        e += -d.pen * d.be_ja[(size_t)r * d.NBE + slot];
-        ec += e;
+        if (d.tclass[d.be_n[slot]] < 0) continue;   // telomere: T == 0
+        ec += be_e[(size_t)blockIdx.x * d.NBE + slot];
         jt += d.be_jt[(size_t)r * d.NBE + slot];
     }
     ec = block_sum<256>(ec, scratch);
     jt = block_sum<256>(jt, scratch);
-    // logZ
-    double z = 0.;
-    for (int n = t; n < d.N; n += 256) z += d.rowZ[(size_t)r * d.N + n];
-    z = block_sum<256>(z, scratch);
     if (t == 0) {
         const bool live = lt_valid[r] != 0;
         double energy = en + ec, entropy = ent + hb + (live ? jt : 0.);
         if (!live) energy += plain_T_init;
-        if (full_plain) { energy += full_plain[r - r0]; entropy += full_plain[r - r0]; }
-        out[(r - r0) * 4 + 0] = energy; out[(r - r0) * 4 + 1] = entropy; out[(r - r0) * 4 + 2] = energy - entropy;
-        out[(r - r0) * 4 + 3] = z;
+        if (full_plain) { energy += full_plain[blockIdx.x]; entropy += full_plain[blockIdx.x]; }
+        out[blockIdx.x * 4 + 0] = energy; out[blockIdx.x * 4 + 1] = entropy; out[blockIdx.x * 4 + 2] = energy - entropy;
+        out[blockIdx.x * 4 + 3] = z;
     }
 }
 
@@ -2330,6 +2337,23 @@ __global__ void k_state_tables_list_v(Dev d, StageArgs sa, int32_t *rlist_dev, R
     const int r = sa.rlist[blockIdx.y];
     const RestartParams rp = sa.rp[blockIdx.y];
     if (blockIdx.x == 0 && threadIdx.x == 0) { d.rp[r] = rp; rlist_dev[blockIdx.y] = r; stage_dev[blockIdx.y] = rp; }
+    state_tables_body(d, blockIdx.x, r, rp);
+}
+// M-step sample lists from a host-pinned staging area to their homes: header [nlists][4] = (restart, slot, count, offset of the
+// list in `indices`); slot -1: the restart's current sample, 0..3: parameter slot.  grid (nlists), block 256
+__global__ void k_scatter_samples(const int32_t *header, const int32_t *indices, int32_t *sample, int32_t *counts, int32_t *msample, int32_t *mcounts,
+                                  int N, int R) {
+    const int32_t *hd = header + 4 * blockIdx.x;
+    const int r = hd[0], slot = hd[1], cnt = hd[2], off = hd[3];
+    int32_t *dst = slot < 0 ? sample + (size_t)r * N : msample + ((size_t)slot * R + r) * N;
+    for (int i = threadIdx.x; i < cnt; i += blockDim.x) dst[i] = indices[off + i];
+    if (threadIdx.x == 0) { if (slot < 0) counts[r] = cnt; else mcounts[(size_t)slot * R + r] = cnt; }
+}
+// the same without the staging copies: the tables of up to 16 restarts whose parameters changed, one launch (ensure_tables)
+__global__ void k_state_tables_many(Dev d, StageArgs sa) {
+    const int r = sa.rlist[blockIdx.y];
+    const RestartParams rp = sa.rp[blockIdx.y];
+    if (blockIdx.x == 0 && threadIdx.x == 0) d.rp[r] = rp;
     state_tables_body(d, blockIdx.x, r, rp);
 }
 // grid (maxcount, nreq): block (i, j) evaluates sampled segment i of restart rlist[j]

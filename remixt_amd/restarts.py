@@ -108,7 +108,7 @@ class RestartSet(object):
             if getattr(self, '_prep_pool', None) is None:
                 from concurrent.futures import ThreadPoolExecutor
                 self._prep_pool = ThreadPoolExecutor(max_workers=1)
-            self._h_prefetch = ([m.rng.get_state() for m in self.models], self._prep_pool.submit(self._samples))
+            self._h_prefetch = ([m.rng.get_state() for m in self.models], self._prep_pool.submit(self._samples_and_lists))
         self.variational_update(num_update_iter)
         t_.append(time.perf_counter())
 
@@ -158,6 +158,13 @@ class RestartSet(object):
             m.record_elbo(float(e), i)
         return elbo
 
+    def _mark(self, label):
+        """Host-side time stamps of the M-step's stages (tools/mstep_marks.py): off unless `self.marks` is a list."""
+        marks = getattr(self, 'marks', None)
+        if marks is not None:
+            import time
+            marks.append((label, time.perf_counter()))
+
     def _threads(self):
         if getattr(self, '_pool', None) is None:
             from concurrent.futures import ThreadPoolExecutor
@@ -174,6 +181,11 @@ class RestartSet(object):
         if self.mstep_threads > 1 and R > 1:
             return list(self._threads().map(draw, range(R)))
         return [draw(r) for r in range(R)]
+
+    def _samples_and_lists(self):
+        """_samples() and, per mask, its ascending index list (the form rmx_set_sample_lists uploads in one transfer)."""
+        masks = self._samples()
+        return masks, [np.flatnonzero(s).astype(np.int32) for s in masks]
 
     _MULTI_PARAMS = ('negbin_r_0', 'negbin_r_1', 'betabin_M_0', 'betabin_M_1')
 
@@ -198,14 +210,16 @@ class RestartSet(object):
             m = self.models[r]
             c = {'p_outlier_total': np.asarray(m.model.p_outlier_total), 'p_outlier_allele': np.asarray(m.model.p_outlier_allele)}
             m._mstep_indicator_cache = c
-            return c, [m._create_sample(m.get_param_sample_weight(name)) for name in names]
+            masks = [m._create_sample(m.get_param_sample_weight(name)) for name in names]
+            return c, masks, [np.flatnonzero(s).astype(np.int32) for s in masks]
         R = len(self.models)
         if self.mstep_threads > 1 and R > 1:
             per_restart = list(self._threads().map(one, range(R)))
         else:
             per_restart = [one(r) for r in range(R)]
-        ind = [c for c, _ in per_restart]
-        samples = dict((name, [smp[j] for _, smp in per_restart]) for j, name in enumerate(names))
+        ind = [c for c, _, _ in per_restart]
+        samples = dict((name, [smp[j] for _, smp, _ in per_restart]) for j, name in enumerate(names))
+        self._param_sample_lists = dict((name, [lst[j] for _, _, lst in per_restart]) for j, name in enumerate(names))
         return samples, ind
 
     def _start_param_sample_prep(self):
@@ -243,16 +257,23 @@ class RestartSet(object):
         rng_state = prefetch[0] if prefetch is not None else [m.rng.get_state() for m in self.models]
         dead = {}      # restart -> message: its objective raised one of the reference's ValueErrors during the search
         try:
+            self._mark('h:start')
             ell_before = b.expected_log_likelihood_full(0, R)
-            samples = prefetch[1].result() if prefetch is not None else self._samples()
+            self._mark('h:ell_before')
+            samples, sample_lists = prefetch[1].result() if prefetch is not None else self._samples_and_lists()
+            self._mark('h:samples')
             # the parameter M-steps' samples come next in every restart's RNG stream and depend on the outlier
             # indicators only: they are drawn on a helper thread while this thread waits on the h rounds
             self._start_param_sample_prep()
             bounds = [(1e-8, 10.)] * b.num_clones
             while True:
                 live = [r for r in active if r not in dead]
-                for r in live:
-                    b._use_sample(r, samples[r])
+                if hasattr(b, 'set_sample_lists'):
+                    b.set_sample_lists([(r, -1, samples[r], sample_lists[r]) for r in live])      # one transfer
+                else:
+                    for r in live:
+                        b._use_sample(r, samples[r])
+                self._mark('h:use_sample')
 
                 def evaluate(ids, xs):
                     f, g = b.expected_log_likelihood_h_batch([live[i] for i in ids], np.stack(xs))
@@ -277,6 +298,7 @@ class RestartSet(object):
                 m.model.h = h_before[r]
                 m.rng.set_state(rng_state[r])
             return False
+        self._mark('h:rounds')
         self.error_messages.update(dead)
         active = [r for r in active if r not in dead]
         failed = set()
@@ -303,7 +325,9 @@ class RestartSet(object):
                 self.error_messages[r] = str(err).splitlines()[0] + ' (h kept)'
         # accept test on trial values; a restart that keeps its h is rolled back without a second pass
         # over the cells (its expectations and cell cache still belong to h_before)
+        self._mark('h:validate')
         ell_after = b.expected_log_likelihood_full_trial(0, R) if trial else None
+        self._mark('h:trial')
         for r in failed:
             if trial:
                 b.rollback_h(r, h_before[r])
@@ -321,6 +345,7 @@ class RestartSet(object):
                     b.rollback_h(r, h_before[r])
                 else:
                     m.model.h = h_before[r]
+        self._mark('h:accept')
         return True
 
     def _update_params_lockstep(self):
@@ -337,8 +362,10 @@ class RestartSet(object):
         # with the samples of the standard parameters, if the h M-step started the preparation)
         prep, self._param_prep = getattr(self, '_param_prep', None), None
         self._prepared = None
+        self._mark('p:start')
         if prep is not None:
             samples, ind = prep[1].result()
+            self._mark('p:prep_wait')
             self._prepared = (prep[0], samples)
             for m, c in zip(self.models, ind):
                 m._mstep_indicator_cache = c
@@ -362,20 +389,30 @@ class RestartSet(object):
             return {}, {}
         bounds = [self.models[0].likelihood_param_bounds[name] for name in first]
         prepared = getattr(self, '_prepared', None)
+        lists = None
         if prepared is not None and prepared[0] == first:
             samples = prepared[1]                  # drawn during the h M-step
+            lists = getattr(self, '_param_sample_lists', None)
         else:
             samples = {}
             for name in first:
                 samples[name] = self._samples([m.get_param_sample_weight(name) for m in self.models])
-        for j, name in enumerate(first):
-            for r, smp in enumerate(samples[name]):
-                b.set_sample_slot(r, j, smp)
+        self._mark('p:samples')
+        if hasattr(b, 'set_sample_lists'):
+            if lists is None or any(name not in lists for name in first):
+                lists = dict((name, [np.flatnonzero(s).astype(np.int32) for s in samples[name]]) for name in first)
+            b.set_sample_lists([(r, j, smp, lists[name][r]) for j, name in enumerate(first) for r, smp in enumerate(samples[name])])
+        else:
+            for j, name in enumerate(first):
+                for r, smp in enumerate(samples[name]):
+                    b.set_sample_slot(r, j, smp)
+        self._mark('p:set_slots')
         grids = np.array([np.mgrid[lo:hi:complex(20)] for lo, hi in bounds])
         try:
             xopt, last = b.param_search_multi(ids_all, first, [lo for lo, hi in bounds], [hi for lo, hi in bounds], grids)
         except NotImplementedError:
             return {}, samples           # the samples are drawn: the sequential searches below use them
+        self._mark('p:search')
         return dict((name, (xopt[j], last[j])) for j, name in enumerate(first)), samples
 
     def _params_lockstep_body(self, b, R, ids_all):
@@ -385,6 +422,7 @@ class RestartSet(object):
             lo, hi = self.models[0].likelihood_param_bounds[name]
             value_before = [b.get_param(r, name) for r in ids_all]
             ell_before = b.expected_log_likelihood_full(0, R)
+            self._mark('p:ell_before')
             if name in together:
                 # searched already, model untouched: put the parameter where the sequential search leaves it
                 # (the last point the optimiser evaluated, cn_model.py:563-569)
@@ -406,7 +444,9 @@ class RestartSet(object):
             # the accept test on trial values: a rejected value is rolled back without a second pass over
             # the cells (the restart's expectations and cell cache still belong to value_before)
             trial = hasattr(b, 'expected_log_likelihood_full_trial')
+            self._mark('p:set_trial')
             ell_after = b.expected_log_likelihood_full_trial(0, R) if trial else b.expected_log_likelihood_full(0, R)
+            self._mark('p:trial')
             for r, m in enumerate(self.models):
                 if ell_after[r] < ell_before[r]:
                     m._log('{} rejected, elbo before: {}, after: {}'.format(name, ell_before[r], ell_after[r]))
@@ -416,6 +456,7 @@ class RestartSet(object):
                         b.set_param(r, name, value_before[r])
                 else:
                     b.set_param(r, name, float(xopt[r]))
+            self._mark('p:accept')
 
     def _param_search_python(self, name, lo, hi, grid):
         """The search of rmx_param_search driven from Python generators (remixt_amd/lockstep.py)."""

@@ -444,6 +444,51 @@ def test_param_search_multi_argument_checks(hip):
         np.testing.assert_allclose(one, xopt[j], rtol=1e-5, atol=1e-3)
 
 
+def test_sample_lists_equal_dense_masks(hip):
+    """rmx_set_sample_lists (all samples of an M-step in one transfer) leaves the device exactly where the per-restart dense-mask
+    uploads leave it: sampled objectives, gradients and a shared-round search are bit-identical; bad lists are refused."""
+    from remixt_amd import synthetic
+    from remixt_amd.restarts import RestartSet
+    e = synthetic.make_experiment(500, num_clones=3, max_copy_number=6, num_chains=4, seed=3)
+    ps = synthetic.make_init_params(e, 3, 6)
+    grid = np.mgrid[10.:2000.:complex(20)]
+    rng = np.random.RandomState(4)
+    masks = []
+    outs = []
+    for mode in ('dense', 'lists'):
+        rs = RestartSet(e, ps, max_copy_number=6, num_clones=3, quiet=True, seeds=[1, 2, 3])
+        b = rs.batch
+        N = b.num_segments
+        if mode == 'dense':
+            for r in range(3):
+                m = np.zeros(N, dtype=int); m[rng.choice(N, size=40 + 7 * r, replace=False)] = 1
+                masks.append(m)
+        b.variational_update(1)
+        if mode == 'dense':
+            for r in range(3):
+                b._use_sample(r, masks[r])
+                for slot in range(2):
+                    b.set_sample_slot(r, slot, masks[(r + slot + 1) % 3])
+        else:
+            b.set_sample_lists([(r, -1, masks[r], np.flatnonzero(masks[r])) for r in range(3)] +
+                               [(r, slot, masks[(r + slot + 1) % 3], np.flatnonzero(masks[(r + slot + 1) % 3])) for r in range(3) for slot in range(2)])
+        f, g = b.expected_log_likelihood_h_batch([0, 1, 2], np.stack([np.array(b.get_array(r, 'h')) * 1.01 for r in range(3)]))
+        xopt, last = b.param_search_multi([0, 1, 2], ['negbin_r_0', 'betabin_M_0'], [10., 10.], [2000., 2000.], np.stack([grid, grid]))
+        single = [b.expected_log_likelihood(r, masks[r], want_grad=True) for r in range(3)]      # (identity-cached after the list upload)
+        outs.append((f, g, xopt, last, single))
+        if mode == 'lists':
+            with pytest.raises(ValueError):
+                b.set_sample_lists([(0, -1, masks[0], np.array([5, 3]))])                      # not ascending
+            with pytest.raises(ValueError):
+                b.set_sample_lists([(0, 4, masks[0], np.array([1, 2]))])                       # no such slot
+            with pytest.raises(ValueError):
+                b.set_sample_lists([(0, 0, masks[0], np.array([1, N]))])                       # past the last segment
+    a, c = outs
+    assert np.array_equal(a[0], c[0]) and np.array_equal(a[1], c[1]) and np.array_equal(a[2], c[2]) and np.array_equal(a[3], c[3])
+    for (e1, g1), (e2, g2) in zip(a[4], c[4]):
+        assert e1 == e2 and np.array_equal(g1, g2)
+
+
 def test_restart_groups_do_not_change_results(hip):
     """Restarts split into groups (own batch, stream and host thread each) give every restart the
     same fit as one batch of all restarts."""

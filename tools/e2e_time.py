@@ -11,6 +11,11 @@ t = time.time()
 e = synthetic.make_experiment(int(os.environ.get('SEG', 50000)), num_clones=3, max_copy_number=MAXCN, num_chains=23, seed=0)
 ps = synthetic.make_init_params(e, R, MAXCN, num_clones=3)
 print('synthetic experiment   %.2f s' % (time.time() - t)); t = time.time()
+# first touch of the GPU in this process: HIP runtime start-up and the load of the library's gfx950 code object (once per process,
+# whatever is fitted afterwards) -- timed on a two-segment problem so that `construct` below is the model construction alone
+_w = synthetic.make_experiment(40, num_clones=3, max_copy_number=2, num_chains=2, seed=1)
+RestartGroups(_w, synthetic.make_init_params(_w, 1, 2, num_clones=3), 2, groups=1, num_clones=3, device=0, quiet=True, seeds=[0]).synchronize()
+print('HIP start-up + code object load (once per process)  %.2f s' % (time.time() - t)); t = time.time()
 rs = RestartGroups(e, ps, MAXCN, groups=GROUPS, num_clones=3, device=0, quiet=True, seeds=list(range(R)))
 rs.synchronize()
 print('construct              %.2f s' % (time.time() - t)); t = time.time()

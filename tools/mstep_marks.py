@@ -1,0 +1,39 @@
+"""Host-side stage times of the M-steps of free-running restart groups at the benchmark configuration: where do the
+milliseconds between one sweep phase and the next go?  (RestartSet._mark stamps; mean over the timed EM iterations.)"""
+import sys, os, time, collections
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from remixt_amd import synthetic
+from remixt_amd.restarts import RestartGroups, RestartSet
+e = synthetic.make_experiment(50000, num_clones=3, max_copy_number=8, num_chains=23, seed=0)
+R, G = 16, int(os.environ.get('GROUPS', 2))
+ps = synthetic.make_init_params(e, R, 8)
+rs = RestartGroups(e, ps, 8, groups=G, num_clones=3, quiet=True, seeds=[1000 + i for i in range(R)])
+for m, v in zip(rs.models, rs.calculate_elbo()):
+    m.prev_elbo = float(v)
+rs.run(3, 0, 5)
+for s in rs.sets:
+    s.marks = []
+orig = RestartSet.em_iteration
+def wrapped(self, i=0, n=5):
+    self._mark('em:start')
+    out = orig(self, i, n)
+    self._mark('em:end')
+    return out
+RestartSet.em_iteration = wrapped
+NIT = 8
+t0 = time.time(); rs.run(NIT, 3, 5); rs.synchronize(); dt = time.time() - t0
+print('%d groups: %.1f ms per step, %.0f EM iterations/s' % (G, dt / NIT * 1e3, R * NIT / dt))
+for g, s in enumerate(rs.sets):
+    acc = collections.OrderedDict()
+    prev = None
+    seq = 0
+    for label, t in s.marks:
+        if label == 'em:start':
+            prev = t; seq = 0
+            continue
+        key = '%02d %s' % (seq, label); seq += 1
+        acc.setdefault(key, []).append((t - prev) * 1e3); prev = t
+    print('group %d' % g)
+    for key, v in acc.items():
+        print('   %-22s %7.2f ms' % (key, float(np.mean(v))))
