@@ -242,6 +242,13 @@ int rmx_expected_ll_full(rmx_batch *b, int32_t r0, int32_t r1, double *out);
  * accept (set the new value) | rmx_trial_rollback. */
 int rmx_expected_ll_full_trial(rmx_batch *b, int32_t r0, int32_t r1, double *out);
 int rmx_trial_rollback(rmx_batch *b, int32_t r, int32_t param_id, const double *values);
+/* The full-data E[ll] split into the four likelihood components that negbin_r_0, negbin_r_1, betabin_M_0 and
+ * betabin_M_1 move (out [r1-r0][4]; their sum is rmx_expected_ll_full up to rounding): trial = 0 at the committed values,
+ * trial = 1 with the changed parameters on trial (as rmx_expected_ll_full_trial).  The accept tests of the four
+ * parameters (cn_model.py:563-569, one update_param after the other) then take ONE pass over the cells: E[ll] with
+ * parameter j on trial and the earlier ones decided is a sum of component values of the two calls.  Afterwards, per
+ * parameter: rmx_set_param (accept) or rmx_trial_rollback (reject; only that parameter's components become current again). */
+int rmx_expected_ll_components(rmx_batch *b, int32_t r0, int32_t r1, int32_t trial, double *out);
 /* per-cell values, for tests (:751-776, :809-853): u/v/w in {0,1} */
 int rmx_log_likelihood_total(rmx_batch *b, int32_t r, int32_t n, int32_t s, int32_t u, double *out);
 int rmx_log_likelihood_allele(rmx_batch *b, int32_t r, int32_t n, int32_t s, int32_t v, int32_t w, double *out);

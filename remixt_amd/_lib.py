@@ -69,6 +69,7 @@ SYMBOLS = {
     "rmx_expected_ll_h_batch": (C.c_int, [C.c_void_p, C.c_int32, _i32p, _dp, _dp]),
     "rmx_expected_ll_full": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, _dp]),
     "rmx_expected_ll_full_trial": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, _dp]),
+    "rmx_expected_ll_components": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, _dp]),
     "rmx_trial_rollback": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, _dp]),
     "rmx_log_likelihood_total": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _dp]),
     "rmx_log_likelihood_allele": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _dp]),

@@ -434,6 +434,17 @@ class RemixtBatch(object):
         rollback_param / rollback_h (reject)."""
         return self._scalar_range(self._lib.rmx_expected_ll_full_trial, r0, r1)
 
+    # component of E[ll] each of the four standard likelihood parameters moves (column of expected_log_likelihood_components)
+    PARAM_COMPONENT = {'negbin_r_0': 0, 'negbin_r_1': 1, 'betabin_M_0': 2, 'betabin_M_1': 3}
+
+    def expected_log_likelihood_components(self, r0=None, r1=None, trial=False):
+        """[r1-r0][4]: E[ll] over all segments split into the components negbin_r_0, negbin_r_1, betabin_M_0, betabin_M_1 move,
+        at the committed values or (trial=True) with changed parameters on trial (rmx_expected_ll_components)."""
+        r0, r1 = self._range(r0, r1)
+        out = np.zeros((r1 - r0, 4), dtype=np.float64)
+        self._ck(self._lib.rmx_expected_ll_components(self._handle, r0, r1, 1 if trial else 0, out.ctypes.data_as(_dp)))
+        return out
+
     def rollback_param(self, r, name, value):
         v = _f64([value])
         self._ck(self._lib.rmx_trial_rollback(self._handle, int(r), PARAM_IDS[name], v.ctypes.data_as(_dp)))

@@ -69,7 +69,7 @@ struct rmx_batch {
     std::vector<char> logz_dirty;
     int *d_lt_valid = nullptr;
     // scratch
-    double *d_partial = nullptr;       // ELBO partials [R][ELBO_BLOCKS][3]
+    double *d_partial = nullptr;       // ELBO partials [R][ELBO_BLOCKS][3]; E[ll] component partials [R][4][ELBO_BLOCKS]
     double *d_be_e = nullptr;          // ELBO: energy term of every breakend slot [R][NBE]
     double *d_out4 = nullptr;          // [R][4]
     double *d_ell_partial = nullptr;   // [max(N,ELBO_BLOCKS)][1+MAXC]
@@ -847,7 +847,7 @@ int rmx_batch_create(const rmx_problem *pr, int32_t R, const double *h_init, con
         const bool want = b->opt[RMX_OPT_CELL_CACHE] != 0;
         if (want && S > 32 && S <= 384 && bytes <= ((size_t)96 << 30)) { double *p_ = nullptr; if (dalloc(b, &p_, RNS * 6) == RMX_OK) { d.lc = p_; b->use_cache = true; } }
     }
-    if ((rc = dalloc(b, &b->d_lt_valid, R)) || (rc = dalloc(b, &b->d_partial, (size_t)R * ELBO_BLOCKS * 3)) || (rc = dalloc(b, &b->d_be_e, (size_t)R * std::max(d.NBE, 1))) || (rc = dalloc(b, &b->d_out4, (size_t)R * 4)) ||
+    if ((rc = dalloc(b, &b->d_lt_valid, R)) || (rc = dalloc(b, &b->d_partial, (size_t)R * ELBO_BLOCKS * 4)) || (rc = dalloc(b, &b->d_be_e, (size_t)R * std::max(d.NBE, 1))) || (rc = dalloc(b, &b->d_out4, (size_t)R * 4)) ||
         (rc = dalloc(b, &b->d_ell_partial, (size_t)R * std::max(N, ELBO_BLOCKS) * (1 + RMX_MAX_CLONES))) || (rc = dalloc(b, &b->d_ell_out, (size_t)R * 8)) ||
         (rc = dalloc(b, &b->d_sample, (size_t)R * N)) || (rc = dalloc(b, &b->d_grid_out, (size_t)R * 64 * (1 + RMX_MAX_CLONES))) ||
         (rc = dalloc(b, &b->d_rlist, R)) || (rc = dalloc(b, &b->d_counts, R)) || (rc = dalloc(b, &b->d_rp_stage, R)) || (rc = dalloc(b, &b->d_batch_out, (size_t)R * 8))) { rmx_batch_destroy(b); return rc; }
@@ -970,13 +970,14 @@ int rmx_info(rmx_batch *b, int32_t what, int64_t *out) { BIND(b);
 }
 
 // ---- attributes -----------------------------------------------------------------
+// components of (A, B, PF/PP) a likelihood parameter moves (CM_* bits, 16 = PF/PP), by parameter id
+static const int kParamComponents[RMX_P_HMM_LOG_NORM_CONST] = {CM_LT0, CM_LT1, CM_LT0 | CM_LT1, CM_LT0, CM_LT1, CM_LA0, CM_LA1, CM_LA0 | CM_LA1, CM_LA0, CM_LA1, 0, 0, 16};
 int rmx_set_param(rmx_batch *b, int32_t r, int32_t id, double v) { BIND(b);
     if (r < 0 || r >= b->R || id < 0 || id >= RMX_P_HMM_LOG_NORM_CONST) return fail(RMX_EARG, "bad restart / param id");
     if (id == RMX_P_DIVERGENCE_WEIGHT) v = std::fabs(v);
     b->rp[r].p[id] = v; b->tables_dirty[r] = 1; b->ab_dirty[r] = 1;
-    static const int bits[RMX_P_HMM_LOG_NORM_CONST] = {CM_LT0, CM_LT1, CM_LT0 | CM_LT1, CM_LT0, CM_LT1, CM_LA0, CM_LA1, CM_LA0 | CM_LA1, CM_LA0, CM_LA1, 0, 0, 16};
-    b->comp_dirty[r] |= bits[id];
-    b->cache_stale[r] |= (bits[id] & 15);
+    b->comp_dirty[r] |= kParamComponents[id];
+    b->cache_stale[r] |= (kParamComponents[id] & 15);
     return RMX_OK;
 }
 int rmx_get_param(rmx_batch *b, int32_t r, int32_t id, double *v) { BIND(b);
@@ -2183,8 +2184,8 @@ int rmx_expected_ll_full(rmx_batch *b, int32_t r0, int32_t r1, double *out) { BI
 // same order, as a refresh would produce -- while the restart's own (A, B), its cell cache and its
 // staleness flags stay as they are.  A rejected value then costs no second pass over the cells:
 // rmx_trial_rollback puts the old value back and declares (A, B) / cache current again.
-int rmx_expected_ll_full_trial(rmx_batch *b, int32_t r0, int32_t r1, double *out) { BIND(b);
-    RANGE_CHECK();
+// the stale components of (A, B) of restarts [r0, r1) at their current (trial) parameter values into the scratch copy d2
+static int trial_pass(rmx_batch *b, int r0, int r1, Dev &d2) {
     int rc = ensure_tables(b, r0, r1);
     if (rc) return rc;
     const Dev &d = b->d;
@@ -2192,7 +2193,7 @@ int rmx_expected_ll_full_trial(rmx_batch *b, int32_t r0, int32_t r1, double *out
     const size_t RN0 = (size_t)r0 * d.N, cnt = (size_t)nr * d.N;
     HIPCHK(hipMemcpyAsync(b->d_A2 + RN0 * 2, d.A + RN0 * 2, cnt * 16, hipMemcpyDeviceToDevice, b->stream));
     HIPCHK(hipMemcpyAsync(b->d_Bv2 + RN0 * 4, d.Bv + RN0 * 4, cnt * 32, hipMemcpyDeviceToDevice, b->stream));
-    Dev d2 = b->d;
+    d2 = b->d;
     d2.A = b->d_A2; d2.Bv = b->d_Bv2; d2.lc = nullptr;
     for (int r = r0; r < r1;) {
         const int mask = use_strip(b) ? cover_mask(b->comp_dirty[r] & 15) : (b->comp_dirty[r] ? 15 : 0);
@@ -2216,12 +2217,42 @@ int rmx_expected_ll_full_trial(rmx_batch *b, int32_t r0, int32_t r1, double *out
         }
         r = e;
     }
+    return RMX_OK;
+}
+int rmx_expected_ll_full_trial(rmx_batch *b, int32_t r0, int32_t r1, double *out) { BIND(b);
+    RANGE_CHECK();
+    Dev d2;
+    int rc = trial_pass(b, r0, r1, d2);
+    if (rc) return rc;
+    const int nr = r1 - r0;
     { ProfScope ps(b, KID_ELL_FULL); hipLaunchKernelGGL(k_ell_full_batch, dim3(ELBO_BLOCKS, nr), dim3(256), 0, b->stream, d2, r0, b->d_partial); }
     { ProfScope ps(b, KID_ELL_FINAL); hipLaunchKernelGGL(k_sum_partials, dim3(nr), dim3(256), 0, b->stream, (const double *)b->d_partial, ELBO_BLOCKS, b->d_out4); }
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(b->h_pinned, b->d_out4, (size_t)nr * 8, hipMemcpyDeviceToHost, b->stream));
     if ((rc = check_errors(b, r0, r1))) return rc;
     for (int i = 0; i < nr; i++) out[i] = b->h_pinned[i];
+    return RMX_OK;
+}
+// The full-data E[ll] of restarts [r0, r1) split into its four likelihood components (out[i][c]: NB total with u = 0 / 1, BB
+// allele with v = 0 / 1 -- the parts negbin_r_0, negbin_r_1, betabin_M_0, betabin_M_1 move).  trial = 0: at the current
+// values (like rmx_expected_ll_full); trial = 1: with the changed parameters on trial (like rmx_expected_ll_full_trial).
+// With it the accept tests of the four standard parameters (cn_model.py:563-569, one after the other) need one pass over
+// the cells instead of four: their components are disjoint, so E[ll] with parameter j on trial and the earlier ones
+// decided is a sum of component values from the two calls.
+int rmx_expected_ll_components(rmx_batch *b, int32_t r0, int32_t r1, int32_t trial, double *out) { BIND(b);
+    RANGE_CHECK();
+    if (!out) return fail(RMX_EARG, "bad argument");
+    int rc;
+    Dev d2 = b->d;
+    if (trial) { if ((rc = trial_pass(b, r0, r1, d2))) return rc; }
+    else if ((rc = ensure_ab(b, r0, r1))) return rc;
+    const int nr = r1 - r0;
+    { ProfScope ps(b, KID_ELL_FULL); hipLaunchKernelGGL(k_ell_comp_batch, dim3(ELBO_BLOCKS, nr), dim3(256), 0, b->stream, d2, r0, b->d_partial); }
+    { ProfScope ps(b, KID_ELL_FINAL); hipLaunchKernelGGL(k_sum_partials, dim3(nr * 4), dim3(256), 0, b->stream, (const double *)b->d_partial, ELBO_BLOCKS, b->d_out4); }
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(b->h_pinned, b->d_out4, (size_t)nr * 32, hipMemcpyDeviceToHost, b->stream));
+    if ((rc = check_errors(b, r0, r1))) return rc;
+    for (int i = 0; i < nr * 4; i++) out[i] = b->h_pinned[i];
     return RMX_OK;
 }
 // Undo a trial: param_id >= 0 puts likelihood parameter param_id of restart r back to values[0];
@@ -2234,7 +2265,11 @@ int rmx_trial_rollback(rmx_batch *b, int32_t r, int32_t param_id, const double *
     if (param_id >= 0) b->rp[r].p[param_id] = param_id == RMX_P_DIVERGENCE_WEIGHT ? std::fabs(values[0]) : values[0];
     else for (int m = 0; m < b->d.M; m++) b->rp[r].h[m] = values[m];
     b->tables_dirty[r] = 1; b->segc_dirty[r] = 1;      // the device tables hold the trial values
-    b->ab_dirty[r] = 0; b->comp_dirty[r] = 0; b->cache_stale[r] = 0;
+    if (param_id >= 0 && param_id < RMX_P_HMM_LOG_NORM_CONST) {
+        // only this parameter's components become current again (others may be on trial at the same time: rmx_expected_ll_components)
+        b->comp_dirty[r] &= ~kParamComponents[param_id]; b->cache_stale[r] &= ~(kParamComponents[param_id] & 15);
+        b->ab_dirty[r] = b->comp_dirty[r] != 0;
+    } else { b->ab_dirty[r] = 0; b->comp_dirty[r] = 0; b->cache_stale[r] = 0; }
     return RMX_OK;
 }
 

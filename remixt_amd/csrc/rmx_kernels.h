@@ -2501,6 +2501,26 @@ __global__ void k_ell_full_batch(Dev d, int r0, double *partial) {
     acc = block_sum<256>(acc, scratch);
     if (threadIdx.x == 0) partial[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = acc;
 }
+// the same sum split into the four likelihood components (NB total u = 0 / 1, BB allele v = 0 / 1: what negbin_r_0/1 and
+// betabin_M_0/1 move): partial[((r-r0) * 4 + c)][blk]
+__global__ void k_ell_comp_batch(Dev d, int r0, double *partial) {
+    __shared__ double scratch[8];
+    const int r = r0 + blockIdx.y;
+    double c0 = 0., c1 = 0., c2 = 0., c3 = 0.;
+    for (int n = blockIdx.x * blockDim.x + threadIdx.x; n < d.N; n += gridDim.x * blockDim.x) {
+        const size_t rn = (size_t)r * d.N + n;
+        const double qt0 = d.qt[rn * 2], qt1 = d.qt[rn * 2 + 1], qa0 = d.qa[rn * 2], qa1 = d.qa[rn * 2 + 1];
+        const double qs0 = d.qs[rn * 2], qs1 = d.qs[rn * 2 + 1];
+        c0 += qt0 * d.A[rn * 2]; c1 += qt1 * d.A[rn * 2 + 1];
+        c2 += qa0 * qs0 * d.Bv[rn * 4] + qa0 * qs1 * d.Bv[rn * 4 + 1];
+        c3 += qa1 * qs0 * d.Bv[rn * 4 + 2] + qa1 * qs1 * d.Bv[rn * 4 + 3];
+    }
+    c0 = block_sum<256>(c0, scratch); c1 = block_sum<256>(c1, scratch); c2 = block_sum<256>(c2, scratch); c3 = block_sum<256>(c3, scratch);
+    if (threadIdx.x == 0) {
+        double *pp = partial + (size_t)blockIdx.y * 4 * gridDim.x + blockIdx.x;
+        pp[0] = c0; pp[gridDim.x] = c1; pp[2 * gridDim.x] = c2; pp[3 * gridDim.x] = c3;
+    }
+}
 __global__ void k_sum_partials(const double *partial, int n, double *out) {   // grid (nr)
     __shared__ double scratch[8];
     double a = 0.;

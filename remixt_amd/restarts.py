@@ -21,13 +21,14 @@ class RestartSet(object):
 
     def __init__(self, experiment, init_params, max_copy_number, num_clones=3, device=0, quiet=True,
                  kernel_module=None, seeds=None, strict=False, mstep_threads=8, lockstep=True, native_search=True, sample_prep=True,
-                 options=None, h_init=None, **model_kwargs):
+                 options=None, h_init=None, joint_accept=True, **model_kwargs):
         self.experiment = experiment
         self.native_search = native_search
         self.strict = strict
         self.mstep_threads = mstep_threads
         self.lockstep = lockstep
         self.sample_prep = sample_prep      # draw the M-step samples on a helper thread while the device works
+        self.joint_accept = joint_accept    # accept tests of the parameters searched together from one pass over the cells
         self.error_messages = {}
         self.init_params = list(init_params)
         R = len(self.init_params)
@@ -415,9 +416,46 @@ class RestartSet(object):
         self._mark('p:search')
         return dict((name, (xopt[j], last[j])) for j, name in enumerate(first)), samples
 
+    def _accept_standard_params_together(self, b, R, ids_all, lead, together):
+        """The accept tests of the parameters searched together (cn_model.py:563-569, one update_param after the other) from ONE
+        pass over the cells: the parameters move disjoint components of the full-data E[ll], so E[ll] with parameter j at
+        the last point its optimiser evaluated and the earlier parameters decided is a sum of component values at the
+        committed and at the tried parameters (rmx_expected_ll_components; differs from the four full sums by rounding)."""
+        comp = b.PARAM_COMPONENT
+        value_before = dict((name, [b.get_param(r, name) for r in ids_all]) for name in lead)
+        cur = b.expected_log_likelihood_components(0, R)
+        self._mark('p:ell_before')
+        for name in lead:
+            last = together[name][1]
+            for r in ids_all:
+                b.set_param(r, name, float(last[r]))          # where the sequential search leaves it
+        tried = b.expected_log_likelihood_components(0, R, trial=True)
+        self._mark('p:trial')
+
+        def total(v):
+            return (v[0] + v[1]) + (v[2] + v[3])
+        for name in lead:
+            c = comp[name]
+            xopt = together[name][0]
+            for r, m in enumerate(self.models):
+                ell_before = total(cur[r])
+                after = np.array(cur[r]); after[c] = tried[r, c]
+                ell_after = total(after)
+                if ell_after < ell_before:
+                    m._log('{} rejected, elbo before: {}, after: {}'.format(name, ell_before, ell_after))
+                    b.rollback_param(r, name, value_before[name][r])
+                else:
+                    b.set_param(r, name, float(xopt[r]))
+                    cur[r, c] = tried[r, c]
+        self._mark('p:accept')
+
     def _params_lockstep_body(self, b, R, ids_all):
         names = list(self.models[0].likelihood_params)
         together, drawn = self._search_standard_params_together(b, R, ids_all, names)
+        lead = [name for name in names if name in together]
+        if lead and self.joint_accept and hasattr(b, 'expected_log_likelihood_components') and names[:len(lead)] == lead:
+            self._accept_standard_params_together(b, R, ids_all, lead, together)
+            names = names[len(lead):]
         for name in names:
             lo, hi = self.models[0].likelihood_param_bounds[name]
             value_before = [b.get_param(r, name) for r in ids_all]

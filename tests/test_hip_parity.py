@@ -381,16 +381,21 @@ def test_lockstep_mstep_equals_per_restart_mstep(hip):
         (True, True, 2),      # 3: native, one parameter at a time, table-rebuilding evaluation rounds
         (True, True, 3),      # 4: native, one at a time, rounds that also evaluate the optimisers' possible next points
         (True, True, 1),      # 5: native, one at a time, table-free rounds
+        (True, True, 0),      # 6: as 0, but one accept pass over the cells per parameter instead of one for all four
     ]
     out = []
-    for lock, native, mode in configs:
+    for ci, (lock, native, mode) in enumerate(configs):
         rs = RestartSet(e, ps, max_copy_number=4, num_clones=3, quiet=True, seeds=[5, 6, 7, 8], lockstep=lock,
-                        native_search=native, mstep_threads=1, options={'search_mode': mode})
+                        native_search=native, mstep_threads=1, options={'search_mode': mode}, joint_accept=ci != 6)
         rs.fit(num_em_iter=2, num_update_iter=2)
         out.append([(m.prev_elbo, np.array(m.h), m.get_likelihood_param_values()) for m in rs.models])
     # the table-free search kernel evaluates exactly what the table-rebuilding rounds evaluate, and the
     # optional look-ahead evaluations change nothing any optimiser sees
     for (e1, h1, p1), (e2, h2, p2) in list(zip(out[5], out[3])) + list(zip(out[5], out[4])):
+        assert e1 == e2 and np.array_equal(h1, h2) and p1 == p2
+    # the joint accept test decides what the four sequential ones decide (its E[ll] values differ from theirs by rounding only),
+    # and the decisions are all that reaches the model
+    for (e1, h1, p1), (e2, h2, p2) in zip(out[0], out[6]):
         assert e1 == e2 and np.array_equal(h1, h2) and p1 == p2
     # python lock-step == per-restart scipy path, bit for bit
     for (e1, h1, p1), (e2, h2, p2) in zip(out[1], out[2]):
