@@ -80,6 +80,7 @@ def parse(argv=None):
     ap.add_argument('--master-port', type=int, default=0, help='rendezvous port when bench.py starts the ranks itself (0 = pick a free one)')
     ap.add_argument('--option', action='append', default=[], metavar='NAME=VALUE',
                     help='A/B measurements: a tuning option of the library (include/remixt_amd.h, enum rmx_option_id) for every batch of this run')
+    ap.add_argument('--lib', default=None, help='A/B measurements: an alternative build of libremixt_hip.so for this run')
     ap.add_argument('--cpu-leg', action='store_true', help=argparse.SUPPRESS)       # internal: the CPU baseline child process
     return ap.parse_args(argv)
 
@@ -273,6 +274,9 @@ def main():
     else:
         torch.cuda.set_device(device)
 
+    if args.lib:
+        from remixt_amd import _lib as _libmod
+        _libmod.LIB_PATH = os.path.abspath(args.lib)
     from remixt_amd import synthetic
     from remixt_amd.restarts import RestartGroups, DatasetGroups, _pack
     if args.option and kernel_module is None:
