@@ -1326,16 +1326,27 @@ static int do_update_p_cn(rmx_batch *b, int r0, int r1, bool skip_frame = false,
     if ((rc = p_cn_front(b, r0, r1, skip_frame)) || (rc = launch_pairwise_breakends(b, r0, r1, 0))) return rc;
     return p_cn_marginals(b, r0, r1, fuse_next);
 }
-static int do_update_p_breakpoint(rmx_batch *b, int r0, int r1) {
+// snapshot: also write the NEXT sweep's log_transmat tables (T of the p_breakpoint computed here, bpmodel.pyx:939) -- the caller then
+// skips its own launch_brk_lut(pd_lt)
+static int do_update_p_breakpoint(rmx_batch *b, int r0, int r1, bool snapshot = false) {
     const Dev &d = b->d;
-    if (d.K > 0) {
+    if (d.K > 0 && d.NBE > 0) {
+        // probabilities and the tables that follow from them in one launch
         ProfScope ps(b, KID_BRK_UPDATE);
-        hipLaunchKernelGGL(k_brk_update, dim3(d.K, r1 - r0), dim3(128), (size_t)d.B * 16, b->stream, b->d, r0);
+        hipLaunchKernelGGL(k_brk_update_lut, dim3(d.K, r1 - r0), dim3(128), (size_t)d.B * 16, b->stream, b->d, r0, b->d.pd_cached,
+                           snapshot ? b->d.pd_lt : (double *)nullptr, b->d.pe_lt, b->d.pe2_lt, b->pe2p);
         HIPCHK(hipGetLastError());
+    } else {
+        if (d.K > 0) {
+            ProfScope ps(b, KID_BRK_UPDATE);
+            hipLaunchKernelGGL(k_brk_update, dim3(d.K, r1 - r0), dim3(128), (size_t)d.B * 16, b->stream, b->d, r0);
+            HIPCHK(hipGetLastError());
+        }
+        // cached_log_transmat := T(new p_breakpoint)  (bpmodel.pyx:985)
+        int rc = launch_brk_lut(b, r0, r1, b->d.pd_cached, nullptr);
+        if (rc) return rc;
+        if (snapshot && (rc = launch_brk_lut(b, r0, r1, b->d.pd_lt, b->d.pe_lt))) return rc;
     }
-    // cached_log_transmat := T(new p_breakpoint)  (bpmodel.pyx:985)
-    int rc = launch_brk_lut(b, r0, r1, b->d.pd_cached, nullptr);
-    if (rc) return rc;
     const double pti = plain_T_mean_sum(b);
     for (int r = r0; r < r1; r++) { b->plain_T_init[r] = pti; b->cached_model[r] = b->d.tmodel; }
     return RMX_OK;
@@ -1384,10 +1395,9 @@ int rmx_variational_update(rmx_batch *b, int32_t r0, int32_t r1, int32_t iters) 
             HIPCHK(hipStreamWaitEvent(b->stream2, b->ev_fb, 0));
             b->stream = b->stream2;
             rc = launch_pairwise_breakends(b, r0, r1, 0);
-            if (!rc) rc = do_update_p_breakpoint(b, r0, r1);
-            // the next sweep's transition snapshot is T(the p_breakpoint just computed): build it here, off the main stream
-            snapshot_done = false;
-            if (!rc && it + 1 < iters) { rc = launch_brk_lut(b, r0, r1, b->d.pd_lt, b->d.pe_lt); snapshot_done = true; }
+            // the next sweep's transition snapshot is T(the p_breakpoint just computed): built with it, off the main stream
+            snapshot_done = it + 1 < iters;
+            if (!rc) rc = do_update_p_breakpoint(b, r0, r1, snapshot_done);
             b->stream = main_stream;
             if (rc) return rc;
             HIPCHK(hipEventRecord(b->ev_brk, b->stream2));

@@ -1654,12 +1654,13 @@ __global__ void k_update_allele_swap(Dev d, int r0) {     // bpmodel.pyx:1025-10
 // two outermost slots d = +-(cn_max+1) (buffer of length 2(cn_max+1), :600).
 // grid (NBE, nr), block 64 (>= M*D threads looped)
 // =============================================================================
-__global__ void k_brk_lut(Dev d, int r0, double *dst_base, double *exp_base, double *prod_base, int PE2P) {
-    __shared__ double pes[RMX_MAX_CLONES * 64];
-    const int slot = blockIdx.x, r = r0 + blockIdx.y;
-    const int n = d.be_n[slot], k = d.brk_idx[n], orient = d.brk_orient[n];
-    const double *pb = d.pbrk + ((size_t)r * d.K + k) * d.B;
+// tables of breakend slot `slot` of restart r from the breakpoint's probabilities pb[0..B) (global or LDS): dst (and dst2 when given)
+// [M][D]; exp_base / prod_base as below.  Every thread of the block calls it; `pes` is block-shared scratch [RMX_MAX_CLONES * 64].
+__device__ __forceinline__ void brk_lut_body(const Dev &d, int r, int slot, const double *pb, double *dst_base, double *dst2_base, double *exp_base,
+                                             double *prod_base, int PE2P, double *pes) {
+    const int n = d.be_n[slot], orient = d.brk_orient[n];
     double *dst = dst_base + ((size_t)r * d.NBE + slot) * d.M * d.D;
+    double *dst2 = dst2_base ? dst2_base + ((size_t)r * d.NBE + slot) * d.M * d.D : nullptr;
     for (int i = threadIdx.x; i < d.M * d.D; i += blockDim.x) {
         const int m = i / d.D, dd = i % d.D;
         const int dv = dd - (d.cn_max + 1);
@@ -1672,6 +1673,7 @@ __global__ void k_brk_lut(Dev d, int r0, double *dst_base, double *exp_base, dou
             for (int b = 0; b < d.B; b++) acc += pb[b] * g_transition(d.tmodel, dv - orient * d.brk_states[b * d.M + m]);
         }
         dst[i] = acc;
+        if (dst2) dst2[i] = acc;
         if (exp_base) { const double ev = exp(-d.pen * acc); exp_base[((size_t)r * d.NBE + slot) * ((d.M * d.D + 1) & ~1) + i] = ev; if (prod_base && d.D <= 64) pes[m * 64 + dd] = ev; }
     }
     if (exp_base && prod_base && d.D <= 64) {
@@ -1690,6 +1692,12 @@ __global__ void k_brk_lut(Dev d, int r0, double *dst_base, double *exp_base, dou
             if (d.pe2x_lt) d.pe2x_lt[((((size_t)(r >> 2) * d.NBE + slot) * PE2P + i) << 2) + (r & 3)] = i == n2 ? 1.0 : v;   // (entry n2, the pad: weight of k_fbm's ones column)
         }
     }
+}
+__global__ void k_brk_lut(Dev d, int r0, double *dst_base, double *exp_base, double *prod_base, int PE2P) {
+    __shared__ double pes[RMX_MAX_CLONES * 64];
+    const int slot = blockIdx.x, r = r0 + blockIdx.y;
+    const int k = d.brk_idx[d.be_n[slot]];
+    brk_lut_body(d, r, slot, d.pbrk + ((size_t)r * d.K + k) * d.B, dst_base, nullptr, exp_base, prod_base, PE2P, pes);
 }
 
 // log transition value of adjacency (n, n+1) for states (i, j), reference
@@ -1948,11 +1956,9 @@ __global__ void k_pairwise_be2(Dev d, int r0, int PE2P, int SPC) {
 // update_p_breakpoint (bpmodel.pyx:964-985, 618-637) from the breakend histograms
 // grid (K, nr), block 128
 // =============================================================================
-__global__ void k_brk_update(Dev d, int r0) {
-    extern __shared__ double lp[];   // [B] then [B]
-    const int k = blockIdx.x, r = r0 + blockIdx.y;
+// the update of breakpoint k's probabilities into pb (global) and, normalised, into y (LDS); lp, y: [B] each
+__device__ __forceinline__ void brk_update_body(const Dev &d, int r, int k, double *lp, double *y) {
     const int B = d.B, M = d.M, D = d.D;
-    double *y = lp + B;
     for (int b = threadIdx.x; b < B; b += blockDim.x) {
         double acc = 0.;
         for (int e = d.bk_ptr[k]; e < d.bk_ptr[k + 1]; e++) {
@@ -1982,8 +1988,29 @@ __global__ void k_brk_update(Dev d, int r0) {
     __syncthreads();
     double s = 0.;
     for (int b = 0; b < B; b++) s += y[b];
+    __syncthreads();
     double *pb = d.pbrk + ((size_t)r * d.K + k) * B;
-    for (int b = threadIdx.x; b < B; b += blockDim.x) pb[b] = y[b] / s;
+    for (int b = threadIdx.x; b < B; b += blockDim.x) { const double v = y[b] / s; pb[b] = v; y[b] = v; }
+}
+__global__ void k_brk_update(Dev d, int r0) {
+    extern __shared__ double lp[];   // [B] then [B]
+    brk_update_body(d, r0 + blockIdx.y, blockIdx.x, lp, lp + d.B);
+}
+// update_p_breakpoint and the tables that follow from it in ONE launch: breakpoint k's new probabilities stay in LDS and feed the
+// distance tables of its breakend slots -- cached_log_transmat's (cached_base) and, when lt_base is given, the next sweep's
+// log_transmat snapshot with its exponentials and clone products (what two k_brk_lut launches wrote).  Same arithmetic per output.
+// grid (K, nr), block 128, dynamic LDS 2 B doubles
+__global__ void k_brk_update_lut(Dev d, int r0, double *cached_base, double *lt_base, double *exp_base, double *prod_base, int PE2P) {
+    extern __shared__ double lp[];   // [B] then [B]
+    __shared__ double pes[RMX_MAX_CLONES * 64];
+    const int k = blockIdx.x, r = r0 + blockIdx.y;
+    double *y = lp + d.B;
+    brk_update_body(d, r, k, lp, y);
+    __syncthreads();
+    for (int e = d.bk_ptr[k]; e < d.bk_ptr[k + 1]; e++) {
+        brk_lut_body(d, r, d.bk_slots[e], y, cached_base, lt_base, lt_base ? exp_base : nullptr, lt_base ? prod_base : nullptr, PE2P, pes);
+        __syncthreads();
+    }
 }
 
 // =============================================================================
