@@ -38,6 +38,10 @@ struct ProfRec { int id; hipEvent_t a, b; };
 // tuning options (include/remixt_amd.h rmx_option_id): process-wide defaults, copied into a batch at creation
 static int g_opt_default[RMX_OPT_COUNT] = {0, 0, 1, 1, 1, 0, 0, 0, 1, 1, 1, 0, 0};
 static std::mutex g_opt_mu;
+#include <chrono>
+static double g_tacc[8] = {0,0,0,0,0,0,0,0};
+static inline double now_us() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+extern "C" void rmx_dbg_times(double *o) { for (int i = 0; i < 8; i++) { o[i] = g_tacc[i]; g_tacc[i] = 0; } }
 
 struct rmx_batch {
     int opt[RMX_OPT_COUNT];
@@ -85,6 +89,7 @@ struct rmx_batch {
     double *d_mpartial = nullptr; size_t mpartial_cap = 0;
     std::vector<std::vector<int64_t>> sample_cache; std::vector<int> sample_count;
     double *d_grid_out = nullptr;      // [R][64][1+MAXC]
+    unsigned *d_done = nullptr;        // [R] per-request completion tickets of the fused objective kernels (zero between launches)
     int32_t *d_rlist = nullptr, *d_counts = nullptr; RestartParams *d_rp_stage = nullptr; double *d_batch_out = nullptr;   // [R] each
     void *h_batch = nullptr;           // pinned staging for the batched objective
     std::vector<int32_t> plain_list; int32_t *d_plain_list = nullptr; double *d_plain_jt = nullptr;
@@ -850,7 +855,8 @@ int rmx_batch_create(const rmx_problem *pr, int32_t R, const double *h_init, con
     if ((rc = dalloc(b, &b->d_lt_valid, R)) || (rc = dalloc(b, &b->d_partial, (size_t)R * ELBO_BLOCKS * 4)) || (rc = dalloc(b, &b->d_be_e, (size_t)R * std::max(d.NBE, 1))) || (rc = dalloc(b, &b->d_out4, (size_t)R * 4)) ||
         (rc = dalloc(b, &b->d_ell_partial, (size_t)R * std::max(N, ELBO_BLOCKS) * (1 + RMX_MAX_CLONES))) || (rc = dalloc(b, &b->d_ell_out, (size_t)R * 8)) ||
         (rc = dalloc(b, &b->d_sample, (size_t)R * N)) || (rc = dalloc(b, &b->d_grid_out, (size_t)R * 64 * (1 + RMX_MAX_CLONES))) ||
-        (rc = dalloc(b, &b->d_rlist, R)) || (rc = dalloc(b, &b->d_counts, R)) || (rc = dalloc(b, &b->d_rp_stage, R)) || (rc = dalloc(b, &b->d_batch_out, (size_t)R * 8))) { rmx_batch_destroy(b); return rc; }
+        (rc = dalloc(b, &b->d_done, std::max(R, 16))) || (rc = dalloc(b, &b->d_rlist, R)) || (rc = dalloc(b, &b->d_counts, R)) || (rc = dalloc(b, &b->d_rp_stage, R)) || (rc = dalloc(b, &b->d_batch_out, (size_t)R * 8))) { rmx_batch_destroy(b); return rc; }
+    HIPCHK(hipMemset(b->d_done, 0, sizeof(unsigned) * (size_t)std::max(R, 16)));
     HIPCHK(hipHostMalloc((void **)&b->h_pinned, sizeof(double) * (size_t)(R + 1) * 64 * (1 + RMX_MAX_CLONES)));
     HIPCHK(hipHostMalloc((void **)&b->h_err, sizeof(uint32_t) * ((size_t)R * 4 + 64)));      // one word per request of a round (<= 4R in rmx_param_search_multi)
     HIPCHK(hipHostMalloc(&b->h_batch, (size_t)R * (sizeof(RestartParams) + 64) + 4096));
@@ -1659,6 +1665,7 @@ static int run_ell_batch(rmx_batch *b, int nreq, const int32_t *restarts, bool g
     for (int i = nreq; by_value && i < 16; i++) { hs[i] = hs[0]; hl[i] = hl[0]; }
     double *res = by_value ? b->h_pinned : b->d_batch_out;          // host-pinned memory is device-accessible
     uint32_t *eres = by_value ? b->h_err : nullptr;
+    const double t_a = now_us();
     {
         std::lock_guard<std::mutex> lk(b->mu);
         if (by_value) {
@@ -1671,11 +1678,16 @@ static int run_ell_batch(rmx_batch *b, int nreq, const int32_t *restarts, bool g
             hipLaunchKernelGGL(k_state_tables_list, dim3(d.C, nreq), dim3(256), 0, b->stream, b->d, (const int32_t *)b->d_rlist, (const RestartParams *)b->d_rp_stage);
         }
         const int pstride = std::max(d.N, ELBO_BLOCKS) * W;
+        bool final_done = false;
         if (maxcnt > 0) {
             ProfScope ps(b, KID_ELL_LIST);
-            if (grad && ell_sparse_ok(b, nreq, restarts))
-                hipLaunchKernelGGL(k_ell_list_batch_sparse_grad, dim3((maxcnt + 7) / 8, nreq), dim3(256), 0, b->stream, b->d, (const int32_t *)b->d_rlist, (const RestartParams *)b->d_rp_stage,
-                                   (const int32_t *)b->d_sample, (const int32_t *)b->d_counts, b->d_ell_partial, pstride);
+            if (grad && ell_sparse_ok(b, nreq, restarts)) {
+                // (the final sums ride in the same launch: the block that finishes a request last reduces its partials)
+                hipLaunchKernelGGL(k_ell_list_batch_sparse_grad_final, dim3((maxcnt + 7) / 8, nreq), dim3(256), 0, b->stream, b->d, (const int32_t *)b->d_rlist,
+                                   (const RestartParams *)b->d_rp_stage, (const int32_t *)b->d_sample, (const int32_t *)b->d_counts, b->d_ell_partial, pstride,
+                                   b->d_done, res, nout, eres);
+                final_done = true;
+            }
             else if (grad) hipLaunchKernelGGL(k_ell_list_batch<true>, dim3(maxcnt, nreq), ell_block(b), 0, b->stream, b->d, (const int32_t *)b->d_rlist, (const RestartParams *)b->d_rp_stage,
                                          (const int32_t *)b->d_sample, (const int32_t *)b->d_counts, b->d_ell_partial, pstride);
             else {
@@ -1696,14 +1708,16 @@ static int run_ell_batch(rmx_batch *b, int nreq, const int32_t *restarts, bool g
                                    (const int32_t *)b->d_sample, (const int32_t *)b->d_counts, b->d_ell_partial, pstride);
             }
         }
-        { ProfScope ps(b, KID_ELL_FINAL); hipLaunchKernelGGL(k_ell_final_batch, dim3(nreq), dim3(256), 0, b->stream, b->d, (const int32_t *)b->d_rlist, (const int32_t *)b->d_counts,
+        if (!final_done) { ProfScope ps(b, KID_ELL_FINAL); hipLaunchKernelGGL(k_ell_final_batch, dim3(nreq), dim3(256), 0, b->stream, b->d, (const int32_t *)b->d_rlist, (const int32_t *)b->d_counts,
                                                              (const double *)b->d_ell_partial, pstride, res, nout, eres); }
         HIPCHK(hipGetLastError());
         for (int i = 0; i < nreq; i++) { b->tables_dirty[restarts[i]] = 0; b->segc_dirty[restarts[i]] = 1; b->ab_dirty[restarts[i]] = 1; }   // comp_dirty / cache_stale: set by the callers' setters
         if (!by_value) HIPCHK(hipMemcpyAsync(b->h_pinned, b->d_batch_out, (size_t)nreq * nout * 8, hipMemcpyDeviceToHost, b->stream));
     }
+    const double t_b = now_us();
     if (by_value) {
         HIPCHK(hipStreamSynchronize(b->stream));
+        if (grad) { g_tacc[3] += t_b - t_a; g_tacc[4] += now_us() - t_b; }
         if (int rc_ = report_request_errors(b, nreq, eres, [&](int i) { return (int)restarts[i]; })) return rc_;
     } else {
         int rc = check_errors(b, 0, b->R);
@@ -2163,13 +2177,18 @@ int rmx_param_search_multi(rmx_batch *b, int32_t nreq, const int32_t *restarts, 
 // One candidate haploid-depth vector per listed restart: E[ll] and dE[ll]/dh on each restart's
 // current sample (the objective / gradient pair of BreakpointModel.update_h, cn_model.py:484-498),
 // the evaluation round of a lock-step L-BFGS-B.  h [nreq][M]; out [nreq][1 + RMX_MAX_CLONES].
-int rmx_expected_ll_h_batch(rmx_batch *b, int32_t nreq, const int32_t *restarts, const double *h, double *out) { BIND(b);
+int rmx_expected_ll_h_batch(rmx_batch *b, int32_t nreq, const int32_t *restarts, const double *h, double *out) { const double t0 = now_us(); BIND(b);
     if (!b || nreq < 1 || nreq > b->R || !restarts || !h || !out) return fail(RMX_EARG, "bad argument");
+    const double t1 = now_us();
     int rc = check_request_list(b, nreq, restarts);
     if (rc) return rc;
     for (int i = 0; i < nreq; i++)
         if ((rc = rmx_set_array(b, restarts[i], RMX_A_H, h + (size_t)i * b->d.M))) return rc;
-    return run_ell_batch(b, nreq, restarts, true, out);
+    const double t2 = now_us();
+    rc = run_ell_batch(b, nreq, restarts, true, out);
+    const double t3 = now_us();
+    g_tacc[0] += t1 - t0; g_tacc[1] += t2 - t1; g_tacc[2] += t3 - t2; g_tacc[7] += 1;
+    return rc;
 }
 
 // Full-data E[ll] (sample of all ones, :1125-1157) for a restart range from the per-segment

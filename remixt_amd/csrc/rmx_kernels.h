@@ -2315,6 +2315,33 @@ __global__ __launch_bounds__(256) void k_ell_list_batch_sparse_grad(Dev d, const
     const int n = samples[(size_t)r * d.N + i];
     ell_segment_sparse_grad(d, stage[blockIdx.y], r, n, partial + (size_t)r * pstride + (size_t)i * (1 + RMX_MAX_CLONES));
 }
+// The same with the deterministic final sum of k_ell_final_batch folded in: the block that finishes a request's partials last
+// (ticket from a per-request counter, which it resets) reduces them in k_ell_final_batch's order and writes out[j][0..nout) and the
+// request's error word to host-visible memory -- one launch and one kernel boundary fewer per round of the lock-step h M-step.
+__global__ __launch_bounds__(256) void k_ell_list_batch_sparse_grad_final(Dev d, const int32_t *rlist, const RestartParams *stage, const int32_t *samples,
+                                                                          const int32_t *counts, double *partial, int pstride, unsigned *done,
+                                                                          double *out, int nout, uint32_t *err_out) {
+    __shared__ double scratch[8];
+    __shared__ int last;
+    const int r = rlist[blockIdx.y];
+    const int i = blockIdx.x * 8 + (threadIdx.x >> 5);
+    const int cnt = counts[r];
+    if (i < cnt) ell_segment_sparse_grad(d, stage[blockIdx.y], r, samples[(size_t)r * d.N + i], partial + (size_t)r * pstride + (size_t)i * (1 + RMX_MAX_CLONES));
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) last = atomicAdd(&done[blockIdx.y], 1u) == gridDim.x - 1;
+    __syncthreads();
+    if (!last) return;
+    __threadfence();
+    if (threadIdx.x == 0) { done[blockIdx.y] = 0; if (err_out) err_out[blockIdx.y] = __hip_atomic_load(&d.err[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+    const int W = 1 + RMX_MAX_CLONES;
+    for (int c = 0; c < nout; c++) {
+        double a = 0.;
+        for (int k = threadIdx.x; k < cnt; k += 256) a += __hip_atomic_load(&partial[(size_t)r * pstride + (size_t)k * W + c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        a = block_sum<256>(a, scratch);
+        if (threadIdx.x == 0) out[(size_t)blockIdx.y * nout + c] = a;
+    }
+}
 template <bool GRAD>
 __global__ void k_ell_list(Dev d, int r, const int32_t *list, double *partial) {
     ell_segment<GRAD>(d, d.rp[r], r, list[blockIdx.x], partial + (size_t)blockIdx.x * (1 + RMX_MAX_CLONES));

@@ -276,9 +276,12 @@ class RestartSet(object):
                         b._use_sample(r, samples[r])
                 self._mark('h:use_sample')
 
-                def evaluate(ids, xs):
-                    f, g = b.expected_log_likelihood_h_batch([live[i] for i in ids], np.stack(xs))
-                    return [(-float(f[k]), -g[k]) for k in range(len(ids))]
+                if hasattr(b, 'h_batch_evaluator'):
+                    evaluate = b.h_batch_evaluator(live)
+                else:
+                    def evaluate(ids, xs):
+                        f, g = b.expected_log_likelihood_h_batch([live[i] for i in ids], np.stack(xs))
+                        return [(-float(f[k]), -g[k]) for k in range(len(ids))]
                 try:
                     results = lockstep.run_lockstep([lockstep.lbfgsb_gen(h_before[r], bounds) for r in live], evaluate) if live else []
                     break

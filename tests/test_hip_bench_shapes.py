@@ -308,16 +308,22 @@ def test_lockstep_h_step_fails_only_the_flagged_restart(hip, monkeypatch):
         for m, v in zip(rs.models, el):
             m.prev_elbo = float(v)
         if poison:
-            real = rs.batch.expected_log_likelihood_h_batch
+            make = rs.batch.h_batch_evaluator
             state = {'n': 0}
 
-            def poisoned(restarts, hs):
-                hs = np.array(hs, dtype=float)
-                state['n'] += 1
-                if state['n'] == 2 and 1 in restarts:
-                    hs[list(restarts).index(1)] *= -1.          # the optimiser of restart 1 "proposes" a negative depth
-                return real(restarts, hs)
-            monkeypatch.setattr(rs.batch, 'expected_log_likelihood_h_batch', poisoned)
+            def poisoned_factory(restarts):
+                restarts = list(restarts)
+                evaluate = make(restarts)
+
+                def poisoned(ids, xs):
+                    xs = [np.array(x, dtype=float) for x in xs]
+                    state['n'] += 1
+                    listed = [restarts[i] for i in ids]
+                    if state['n'] == 2 and 1 in listed:
+                        xs[listed.index(1)] *= -1.          # the optimiser of restart 1 "proposes" a negative depth
+                    return evaluate(ids, xs)
+                return poisoned
+            monkeypatch.setattr(rs.batch, 'h_batch_evaluator', poisoned_factory)
         rs.em_iteration(0, 2)
         return rs
     bad, good = run(True), run(False)

@@ -4,11 +4,17 @@ import sys, os, time, collections
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from remixt_amd import synthetic
+if os.environ.get('MARKS_LIB'):      # an alternative build of the library (A/B)
+    from remixt_amd import _lib as _libmod
+    _libmod.LIB_PATH = os.path.abspath(os.environ['MARKS_LIB'])
 from remixt_amd.restarts import RestartGroups, RestartSet
 e = synthetic.make_experiment(50000, num_clones=3, max_copy_number=8, num_chains=23, seed=0)
 R, G = 16, int(os.environ.get('GROUPS', 2))
 ps = synthetic.make_init_params(e, R, 8)
-rs = RestartGroups(e, ps, 8, groups=G, num_clones=3, quiet=True, seeds=[1000 + i for i in range(R)])
+kw = {}
+if os.environ.get('H_HALVES'):
+    kw['h_halves'] = bool(int(os.environ['H_HALVES']))
+rs = RestartGroups(e, ps, 8, groups=G, num_clones=3, quiet=True, seeds=[1000 + i for i in range(R)], **kw)
 for m, v in zip(rs.models, rs.calculate_elbo()):
     m.prev_elbo = float(v)
 rs.run(3, 0, 5)
@@ -37,3 +43,4 @@ for g, s in enumerate(rs.sets):
     print('group %d' % g)
     for key, v in acc.items():
         print('   %-22s %7.2f ms' % (key, float(np.mean(v))))
+
