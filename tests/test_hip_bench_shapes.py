@@ -331,3 +331,41 @@ def test_lockstep_h_step_fails_only_the_flagged_restart(hip, monkeypatch):
     for r in (0, 2):
         assert np.array_equal(bad.models[r].h, good.models[r].h)
     assert np.all(np.isfinite([m.prev_elbo for m in bad.models]))
+
+
+def test_baseline_config0_shape_full_fit_matches_oracle(hip, oracle_mod):
+    """BASELINE configs[0]: 1 000 segments, 2 clones, max_cn = 4, a single h initialisation -- the reference's own CPU-runnable case,
+    as a seeded EM fit (sweeps + scipy M-steps) on the device and on the oracle: ELBO to 1e-6, decoded copy number identical."""
+    res = []
+    for kern in (hip, oracle_mod):
+        m, h, e = H.make_model(kern, N=1000, M=2, max_cn=4, chains=23, seed=101)
+        m.num_em_iter = 3; m.num_update_iter = 5
+        np.random.seed(7)
+        m.fit(h)
+        cn, brk = m.optimal_cn()
+        res.append((m.prev_elbo, np.array(m.h), m.get_likelihood_param_values(), cn, brk))
+    (e1, h1, p1, cn1, b1), (e2, h2, p2, cn2, b2) = res
+    assert np.isclose(e1, e2, rtol=1e-6), (e1, e2)
+    np.testing.assert_allclose(h1, h2, rtol=1e-5)
+    for k in p1:
+        assert np.isclose(p1[k], p2[k], rtol=1e-4), (k, p1[k], p2[k])
+    assert np.array_equal(cn1, cn2) and all(np.array_equal(b1[k], b2[k]) for k in b1)
+
+
+def test_baseline_config1_shape_matches_oracle(hip, oracle_mod):
+    """BASELINE configs[1]: 10 000 segments, 2 clones, max_cn = 6, a single h initialisation: the likelihood fill, the
+    forward-backward sweep, the ELBO and the Viterbi decode of the device against the oracle at the full size of the configuration."""
+    a, h, e = H.make_model(hip, N=10000, M=2, max_cn=6, chains=23, seed=202)
+    b, _, _ = H.make_model(oracle_mod, experiment=e, M=2, max_cn=6)
+    ma, mb = H.attach(a, h), H.attach(b, h)
+    assert ma.num_cn_states == mb.num_cn_states
+    for sweep in range(2):
+        for step in ('update_p_allele_swap', 'update_p_cn', 'update_p_breakpoint', 'update_p_outlier_total', 'update_p_outlier_allele'):
+            getattr(ma, step)(); getattr(mb, step)()
+        H.compare_models(ma, mb, tag='configs[1] sweep %d' % sweep)
+        assert ma.calculate_elbo() == pytest.approx(mb.calculate_elbo(), rel=1e-9)
+    s = np.ones(ma.num_segments, dtype=np.int64)
+    assert ma.calculate_expected_log_likelihood(s) == pytest.approx(mb.calculate_expected_log_likelihood(s), rel=1e-9)
+    cna = np.zeros((ma.num_segments, 2, 2), dtype=int); cnb = cna.copy()
+    ma.infer_cn(cna); mb.infer_cn(cnb)
+    assert np.array_equal(cna, cnb)
