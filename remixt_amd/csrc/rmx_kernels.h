@@ -1456,6 +1456,8 @@ __global__ __launch_bounds__(256) void k_cells(Dev d, int r0) {
                 for (int k = 0; k < NS; k++) { const int s = lane + 64 * k; pv[k] = s < S ? d.post[ro + s] : 0.; }
             }
             double a0 = 0., a1 = 0., b0 = 0., b1 = 0., b2 = 0., b3 = 0., pf = 0., pp = 0.;
+            double fq[6] = {0., 0., 0., 0., 0., 0.};      // MODE 1: the indicators this sweep's frame log-probabilities were built from
+            if (MODE == 1) { fq[0] = d.qt[rn * 2]; fq[1] = d.qt[rn * 2 + 1]; fq[2] = d.qa[rn * 2]; fq[3] = d.qa[rn * 2 + 1]; fq[4] = d.qs[rn * 2]; fq[5] = d.qs[rn * 2 + 1]; }
 #pragma unroll
             for (int k = 0; k < NS; k++) {
                 const int s = lane + 64 * k;
@@ -1473,7 +1475,18 @@ __global__ __launch_bounds__(256) void k_cells(Dev d, int r0) {
                     }
                     a0 += ps * LT[0]; a1 += ps * LT[1];
                     b0 += ps * LA[0]; b1 += ps * LA[1]; b2 += ps * LA[2]; b3 += ps * LA[3];
-                    if (MODE == 1 || (MODE == 2 && (MASK & 16))) { pf += ps * d.f[ro + s]; pp += ps * (-1.0 * (CACHE == 2 ? nsub_of(cls, s) : st[k].nsub) * sc.l * divw); }
+                    if (MODE == 1) {
+                        // this sweep's frame log-probability from the values in registers (update_framelogprob's operations on the
+                        // indicators it read): the fused passes in front of this one do not write f, this pass does
+                        double f = 0.;
+                        f += fq[0] * LT[0]; f += fq[1] * LT[1];
+                        f += fq[2] * fq[4] * LA[0]; f += fq[2] * fq[5] * LA[1]; f += fq[3] * fq[4] * LA[2]; f += fq[3] * fq[5] * LA[3];
+                        f += -1.0 * (CACHE == 2 ? nsub_of(cls, s) : st[k].nsub) * sc.l * divw;
+                        d.f[ro + s] = f;
+                        pf += ps * f;
+                    }
+                    if (MODE == 2 && (MASK & 16)) pf += ps * d.f[ro + s];
+                    if (MODE == 1 || (MODE == 2 && (MASK & 16))) pp += ps * (-1.0 * (CACHE == 2 ? nsub_of(cls, s) : st[k].nsub) * sc.l * divw);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -1555,8 +1568,7 @@ __global__ __launch_bounds__(256) void k_cells(Dev d, int r0) {
                         f += qa0 * qs0 * LA[0]; f += qa0 * qs1 * LA[1]; f += qa1 * qs0 * LA[2]; f += qa1 * qs1 * LA[3];
                         f += -1.0 * nsub_of(cls, s) * sc.l * divw;
                         if (f != f) err |= RMX_ERR_NAN_F;
-                        d.f[ro + s] = f;
-                        fv[k] = f;
+                        fv[k] = f;      // (not stored: the call's last, unfused marginal pass writes the plane)
                         vmax = fmax(vmax, f);
                     }
                 }
