@@ -1382,6 +1382,15 @@ __global__ __launch_bounds__(256) void k_cells(Dev d, int r0) {
         const double pt_ = rp.p[RMX_P_PRIOR_OUTLIER_TOTAL], pa_ = rp.p[RMX_P_PRIOR_OUTLIER_ALLELE];
         lp_prior[0] = log(1. - pt_); lp_prior[1] = log(pt_); lp_prior[2] = log(1. - pa_); lp_prior[3] = log(pa_);
     }
+    // posterior passes: the forward / backward rows of the NEXT segment of the strip are requested while this one is processed
+    // (the pass is a chain of dependent steps per segment: rows -> sum -> six planes -> sums -> indicators -> write)
+    constexpr bool PREFETCH = (MODE == 1 || MODE == 3) && NS >= 2 && NS <= 4;      // (where the extra registers do not cost a wave per SIMD)
+    double pfa[PREFETCH ? NS : 1], pfb[PREFETCH ? NS : 1];
+    if (PREFETCH) {
+        const size_t ro0 = ((size_t)r * d.N + nbeg) * d.SP;
+#pragma unroll
+        for (int k = 0; k < NS; k++) { const int s = lane + 64 * k; pfa[k] = s < S ? d.fa[ro0 + s] : 0.; pfb[k] = s < S ? d.fb[ro0 + s] : 0.; }
+    }
     for (int n = nbeg; n < nend; n++) {     // n is wave-uniform (SGPR)
         const int cls = d.seg_class[n];
         if (CACHE != 2 && cls != cur_cls) {
@@ -1427,7 +1436,15 @@ __global__ __launch_bounds__(256) void k_cells(Dev d, int r0) {
             double sum = 0.;
             if (M1) {
 #pragma unroll
-                for (int k = 0; k < NS; k++) { const int s = lane + 64 * k; pv[k] = s < S ? d.fa[ro + s] * d.fb[ro + s] : 0.; sum += pv[k]; }
+                for (int k = 0; k < NS; k++) {
+                    const int s = lane + 64 * k;
+                    pv[k] = PREFETCH ? pfa[PREFETCH ? k : 0] * pfb[PREFETCH ? k : 0] : (s < S ? d.fa[ro + s] * d.fb[ro + s] : 0.);
+                    sum += pv[k];
+                }
+                if (PREFETCH && n + 1 < nend) {
+#pragma unroll
+                    for (int k = 0; k < NS; k++) { const int s = lane + 64 * k; pfa[PREFETCH ? k : 0] = s < S ? d.fa[ro + d.SP + s] : 0.; pfb[PREFETCH ? k : 0] = s < S ? d.fb[ro + d.SP + s] : 0.; }
+                }
                 sum = group_sum(sum, 64);
                 if (!(sum > 0.) || sum != sum || sum == INFINITY) err |= RMX_ERR_NAN_POST;
                 double s2 = 0.;
