@@ -9,7 +9,7 @@ if os.environ.get('MARKS_LIB'):      # an alternative build of the library (A/B)
     _libmod.LIB_PATH = os.path.abspath(os.environ['MARKS_LIB'])
 from remixt_amd.restarts import RestartGroups, RestartSet
 e = synthetic.make_experiment(50000, num_clones=3, max_copy_number=8, num_chains=23, seed=0)
-R, G = 16, int(os.environ.get('GROUPS', 2))
+R, G = 16, int(os.environ.get('NGROUPS', 2))
 ps = synthetic.make_init_params(e, R, 8)
 kw = {}
 if os.environ.get('H_HALVES'):

@@ -5,7 +5,7 @@ import numpy as np
 from remixt_amd import synthetic
 from remixt_amd.restarts import RestartGroups, RestartSet
 e = synthetic.make_experiment(50000, num_clones=3, max_copy_number=8, num_chains=23, seed=0)
-R, G = 16, int(os.environ.get('GROUPS', 2))
+R, G = 16, int(os.environ.get('NGROUPS', 2))
 ps = synthetic.make_init_params(e, R, 8)
 rs = RestartGroups(e, ps, 8, groups=G, num_clones=3, quiet=True, seeds=[1000 + i for i in range(R)])
 for m, v in zip(rs.models, rs.calculate_elbo()):
