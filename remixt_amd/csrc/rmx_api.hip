@@ -38,10 +38,6 @@ struct ProfRec { int id; hipEvent_t a, b; };
 // tuning options (include/remixt_amd.h rmx_option_id): process-wide defaults, copied into a batch at creation
 static int g_opt_default[RMX_OPT_COUNT] = {0, 0, 1, 1, 1, 0, 0, 0, 1, 1, 1, 0, 0};
 static std::mutex g_opt_mu;
-#include <chrono>
-static double g_tacc[8] = {0,0,0,0,0,0,0,0};
-static inline double now_us() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
-extern "C" void rmx_dbg_times(double *o) { for (int i = 0; i < 8; i++) { o[i] = g_tacc[i]; g_tacc[i] = 0; } }
 
 struct rmx_batch {
     int opt[RMX_OPT_COUNT];
@@ -1665,7 +1661,6 @@ static int run_ell_batch(rmx_batch *b, int nreq, const int32_t *restarts, bool g
     for (int i = nreq; by_value && i < 16; i++) { hs[i] = hs[0]; hl[i] = hl[0]; }
     double *res = by_value ? b->h_pinned : b->d_batch_out;          // host-pinned memory is device-accessible
     uint32_t *eres = by_value ? b->h_err : nullptr;
-    const double t_a = now_us();
     {
         std::lock_guard<std::mutex> lk(b->mu);
         if (by_value) {
@@ -1714,10 +1709,8 @@ static int run_ell_batch(rmx_batch *b, int nreq, const int32_t *restarts, bool g
         for (int i = 0; i < nreq; i++) { b->tables_dirty[restarts[i]] = 0; b->segc_dirty[restarts[i]] = 1; b->ab_dirty[restarts[i]] = 1; }   // comp_dirty / cache_stale: set by the callers' setters
         if (!by_value) HIPCHK(hipMemcpyAsync(b->h_pinned, b->d_batch_out, (size_t)nreq * nout * 8, hipMemcpyDeviceToHost, b->stream));
     }
-    const double t_b = now_us();
     if (by_value) {
         HIPCHK(hipStreamSynchronize(b->stream));
-        if (grad) { g_tacc[3] += t_b - t_a; g_tacc[4] += now_us() - t_b; }
         if (int rc_ = report_request_errors(b, nreq, eres, [&](int i) { return (int)restarts[i]; })) return rc_;
     } else {
         int rc = check_errors(b, 0, b->R);
@@ -2177,18 +2170,13 @@ int rmx_param_search_multi(rmx_batch *b, int32_t nreq, const int32_t *restarts, 
 // One candidate haploid-depth vector per listed restart: E[ll] and dE[ll]/dh on each restart's
 // current sample (the objective / gradient pair of BreakpointModel.update_h, cn_model.py:484-498),
 // the evaluation round of a lock-step L-BFGS-B.  h [nreq][M]; out [nreq][1 + RMX_MAX_CLONES].
-int rmx_expected_ll_h_batch(rmx_batch *b, int32_t nreq, const int32_t *restarts, const double *h, double *out) { const double t0 = now_us(); BIND(b);
+int rmx_expected_ll_h_batch(rmx_batch *b, int32_t nreq, const int32_t *restarts, const double *h, double *out) { BIND(b);
     if (!b || nreq < 1 || nreq > b->R || !restarts || !h || !out) return fail(RMX_EARG, "bad argument");
-    const double t1 = now_us();
     int rc = check_request_list(b, nreq, restarts);
     if (rc) return rc;
     for (int i = 0; i < nreq; i++)
         if ((rc = rmx_set_array(b, restarts[i], RMX_A_H, h + (size_t)i * b->d.M))) return rc;
-    const double t2 = now_us();
-    rc = run_ell_batch(b, nreq, restarts, true, out);
-    const double t3 = now_us();
-    g_tacc[0] += t1 - t0; g_tacc[1] += t2 - t1; g_tacc[2] += t3 - t2; g_tacc[7] += 1;
-    return rc;
+    return run_ell_batch(b, nreq, restarts, true, out);
 }
 
 // Full-data E[ll] (sample of all ones, :1125-1157) for a restart range from the per-segment

@@ -23,6 +23,14 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, n), 'missing export: ' + n
 
 
+def test_library_exports_nothing_undeclared():
+    """Every rmx_* entry point the library exports is declared (and documented) in the header: no debugging hooks ship."""
+    import subprocess
+    out = subprocess.run(['nm', '-D', '--defined-only', _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = sorted(set(line.split()[-1] for line in out.splitlines() if line.split()[-1].startswith('rmx_') and ' T ' in line))
+    assert exported == declared_symbols()
+
+
 def test_binding_table_matches_header():
     assert sorted(_lib.SYMBOLS) == declared_symbols()
     lib = _lib.load()

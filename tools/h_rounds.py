@@ -37,9 +37,3 @@ for i in range(NIT):
 print('%d rounds per M-step; per round: %.1f us in the objective call, %.1f us outside (optimiser steps); %.2f ms per M-step' % (
     acc['n'] / NIT, acc['in'] / acc['n'] * 1e6, (tot - acc['in']) / acc['n'] * 1e6, tot / NIT * 1e3))
 
-import ctypes
-from remixt_amd import _lib as _l
-o = (ctypes.c_double * 8)()
-_l.load().rmx_dbg_times(o)
-n = max(o[7], 1)
-print('inside the C call: bind %.1f, set h %.1f, run_ell_batch %.1f (launches %.1f, wait %.1f) us' % (o[0] / n, o[1] / n, o[2] / n, o[3] / n, o[4] / n))
