@@ -77,10 +77,11 @@ __global__ void k_state_tables_one(Dev d, int r, RestartParams rp) {
 __device__ __forceinline__ double seg_const_value(const RestartParams &rp, double x, double y0, double ys, int i) {
     // i in 0..3: NB constants [u*2+var]; i in 4..7: BB constants [v*2+var]
     if (i < 4) {
-        const double rr = rp.p[i == 0 ? RMX_P_NEGBIN_R_0 : (i == 1 ? RMX_P_NEGBIN_HDEL_R_0 : (i == 2 ? RMX_P_NEGBIN_R_1 : RMX_P_NEGBIN_HDEL_R_1))];
+        // (values selected, not an index: a parameter copy changed in registers -- the table-free searches -- must not need an indexable home in scratch)
+        const double rr = i == 0 ? rp.p[RMX_P_NEGBIN_R_0] : (i == 1 ? rp.p[RMX_P_NEGBIN_HDEL_R_0] : (i == 2 ? rp.p[RMX_P_NEGBIN_R_1] : rp.p[RMX_P_NEGBIN_HDEL_R_1]));
         return lgamma_pos(x + rr) - lgamma_pos(x + 1) - lgamma_pos(rr);
     }
-    const double MM = rp.p[i == 4 ? RMX_P_BETABIN_M_0 : (i == 5 ? RMX_P_BETABIN_LOH_M_0 : (i == 6 ? RMX_P_BETABIN_M_1 : RMX_P_BETABIN_LOH_M_1))];
+    const double MM = i == 4 ? rp.p[RMX_P_BETABIN_M_0] : (i == 5 ? rp.p[RMX_P_BETABIN_LOH_M_0] : (i == 6 ? rp.p[RMX_P_BETABIN_M_1] : rp.p[RMX_P_BETABIN_LOH_M_1]));
     return (lgamma_pos(ys + 1) - lgamma_pos(y0 + 1) - lgamma_pos(ys - y0 + 1)) - lgamma_pos(ys + MM) + lgamma_pos(MM);
 }
 __global__ void k_seg_const(Dev d, int r0) {
@@ -2537,14 +2538,14 @@ __global__ __launch_bounds__(256) void k_ell_search_multi(Dev d, MultiVals mv, c
     const int i = blockIdx.x * 8 + (threadIdx.x >> 5);
     if (i >= counts[sl * d.R + r]) return;
     const int n = samples[((size_t)sl * d.R + r) * d.N + i];
-    RestartParams rp = d.rp[r];
     const double v = mv.grid_stage ? mv.gv[sl][gz] : mv.v[req], lv = mv.grid_stage ? mv.glv[sl][gz] : mv.lv[req];
     double *prow = partial + ((size_t)(req * mv.Gz + gz) * maxcnt + i);
+    // (a copy of the restart's parameters per case, changed at a constant index: one copy changed under a switch lives in scratch)
     switch (mv.maskbit[sl]) {
-    case CM_LT0: rp.p[RMX_P_NEGBIN_R_0] = v; rp.logr[0] = lv; ell_segment_sparse<CM_LT0, true>(d, rp, r, n, prow); break;
-    case CM_LT1: rp.p[RMX_P_NEGBIN_R_1] = v; rp.logr[1] = lv; ell_segment_sparse<CM_LT1, true>(d, rp, r, n, prow); break;
-    case CM_LA0: rp.p[RMX_P_BETABIN_M_0] = v; ell_segment_sparse<CM_LA0, true>(d, rp, r, n, prow); break;
-    default:     rp.p[RMX_P_BETABIN_M_1] = v; ell_segment_sparse<CM_LA1, true>(d, rp, r, n, prow); break;
+    case CM_LT0: { RestartParams rp = d.rp[r]; rp.p[RMX_P_NEGBIN_R_0] = v; rp.logr[0] = lv; ell_segment_sparse<CM_LT0, true>(d, rp, r, n, prow); break; }
+    case CM_LT1: { RestartParams rp = d.rp[r]; rp.p[RMX_P_NEGBIN_R_1] = v; rp.logr[1] = lv; ell_segment_sparse<CM_LT1, true>(d, rp, r, n, prow); break; }
+    case CM_LA0: { RestartParams rp = d.rp[r]; rp.p[RMX_P_BETABIN_M_0] = v; ell_segment_sparse<CM_LA0, true>(d, rp, r, n, prow); break; }
+    default:     { RestartParams rp = d.rp[r]; rp.p[RMX_P_BETABIN_M_1] = v; ell_segment_sparse<CM_LA1, true>(d, rp, r, n, prow); break; }
     }
 }
 // grid (nreq * Gz): fixed-order sum of the partials of (request, candidate), as k_ell_search_final
