@@ -443,6 +443,12 @@ def main():
                 line['fit_from_init'] = fit_from_init(args, rs, device)
             except Exception as err:
                 line['fit_from_init'] = {'error': str(err)}
+        if single and not args.no_extra_states and args.groups != 1:
+            # the forward-backward kernel at its other launch shape: all 16 restarts of the GPU in one launch (one restart group)
+            try:
+                line['roofline_one_group'] = one_group_roofline(args, rs, device)
+            except Exception as err:
+                line['roofline_one_group'] = {'error': str(err)}
         if single and not args.no_extra_states and args.max_cn == 8:
             # "also report S = 355 at max_cn = 12" (the reference's default max_copy_number):
             # same segments / restarts / step definition, reported next to the headline configuration
@@ -522,6 +528,41 @@ def fit_from_init(args, rs_main, device):
     out = {'restarts': R, 'em_iterations': 5, 'construct_s': t1 - t0, 'em_s': t2 - t1, 'decode_and_results_s': t3 - t2, 'total_s': t3 - t0,
            'em_iterations_per_s_from_init': R * 5 / (t2 - t1), 'em_iterations_per_s_whole_fit': R * 5 / (t3 - t0),
            'elbo_best': float(np.nanmax(elbo)), 'failed_restarts': int(sum(1 for r in res if r['stats'].get('error_message')))}
+    _release(rs)
+    return out
+
+
+def one_group_roofline(args, rs_main, device):
+    """The headline workload with ALL restarts of the GPU in one restart group: what the forward-backward kernel reaches when a
+    launch carries 16 restarts instead of 8 (its duration is the latency of the chain of steps, not a function of the restart
+    count), and what the step then costs (the M-steps are no longer hidden behind another group's sweeps)."""
+    import torch
+    from remixt_amd import synthetic
+    from remixt_amd.restarts import RestartGroups
+    _release(rs_main)
+    R = args.restarts
+    e = synthetic.make_experiment(args.segments, num_clones=args.clones, max_copy_number=args.max_cn, num_chains=23, seed=0)
+    params = synthetic.make_init_params(e, R, args.max_cn, num_clones=args.clones)
+    rs = RestartGroups(e, params, args.max_cn, groups=1, num_clones=args.clones, device=device, quiet=True, seeds=[1000 + i for i in range(R)])
+    b = rs.batches[0]
+    S, N1 = b.num_cn_states, b.num_segments
+    for m, v in zip(rs.models, rs.calculate_elbo()):
+        m.prev_elbo = float(v)
+    rs.run(2, 0, args.update_iters)
+    rs.synchronize(); torch.cuda.synchronize()
+    nsteps = 6
+    b.profile_reset(); b.profile_enable(2)
+    t0 = time.perf_counter()
+    rs.run(nsteps, 2, args.update_iters)
+    rs.synchronize(); torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    b.profile_enable(0)
+    prof = rs.profile()
+    out = roofline_object(('k_fb', prof['k_fb']), float(N1) * S * R, S, args, R, traffic_file='traffic_r02_16.json')
+    out['restart_groups'] = 1
+    out['restarts_per_launch'] = R
+    out['em_iterations_per_s_with_one_group'] = R * nsteps / dt
+    out['note'] = 'one restart group: every forward-backward launch carries all %d restarts of the GPU' % R
     _release(rs)
     return out
 
