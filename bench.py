@@ -81,6 +81,7 @@ def parse(argv=None):
     ap.add_argument('--option', action='append', default=[], metavar='NAME=VALUE',
                     help='A/B measurements: a tuning option of the library (include/remixt_amd.h, enum rmx_option_id) for every batch of this run')
     ap.add_argument('--lib', default=None, help='A/B measurements: an alternative build of libremixt_hip.so for this run')
+    ap.add_argument('--switch-interval-us', type=float, default=0., help='A/B measurements: sys.setswitchinterval for the restart groups\' host threads (0 = leave Python\'s 5 ms)')
     ap.add_argument('--cpu-leg', action='store_true', help=argparse.SUPPRESS)       # internal: the CPU baseline child process
     return ap.parse_args(argv)
 
@@ -97,12 +98,12 @@ def _free_port():
     return port
 
 
-def spawn_ranks(args):
+def spawn_ranks(args, script=None):
     """`bench.py --gpus N` outside torchrun: start the N ranks as a CHILD process (never an exec of this one)
-    before torch is imported here, and return its exit code."""
+    before torch is imported here, and return its exit code.  `script`: the program every rank runs (this file)."""
     port = args.master_port or _free_port()
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus),
-           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+           '--master-addr', '127.0.0.1', '--master-port', str(port), script or os.path.abspath(__file__)] + sys.argv[1:]
     env = dict(os.environ, MASTER_ADDR='127.0.0.1', HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
     return subprocess.run(cmd, env=env).returncode
 
@@ -235,13 +236,18 @@ def build_datasets(args):
     return out
 
 
-def main():
-    args = parse()
+def main(argv=None, kernel_module=None, dist_backend='nccl', script=None):
+    """The benchmark.  The keyword arguments exist for tests/bench_rehearsal.py ONLY (a world of gloo ranks on a
+    machine without GPUs rehearsing the launch / shard / gather logic over a stand-in kernel module): this program
+    itself always runs the HIP library over RCCL and has no switch, flag or environment variable that selects anything else."""
+    args = parse(argv)
     if args.cpu_leg:
         return cpu_leg(args)
+    if args.switch_interval_us > 0:
+        sys.setswitchinterval(args.switch_interval_us * 1e-6)
     env_world = os.environ.get('WORLD_SIZE')
     if env_world is None and args.gpus > 1:
-        sys.exit(spawn_ranks(args))
+        sys.exit(spawn_ranks(args, script))
     world = int(env_world or '1')
     if world != args.gpus:
         raise SystemExit('bench.py: --gpus %d but WORLD_SIZE=%d: launch with --nproc-per-node equal to --gpus' % (args.gpus, world))
@@ -257,8 +263,7 @@ def main():
     import torch.distributed as dist
     backend = None
     if world > 1:
-        # RCCL over xGMI; BENCH_DIST_BACKEND=gloo rehearses the multi-rank control flow where ranks share a GPU (or have none)
-        backend = os.environ.get('BENCH_DIST_BACKEND', 'nccl')
+        backend = dist_backend          # RCCL over xGMI
         if backend != 'nccl':
             local_rank = local_rank % max(1, torch.cuda.device_count())
         if torch.cuda.is_available():
@@ -268,17 +273,14 @@ def main():
         else:
             dist.init_process_group(backend)
     device = local_rank if world > 1 else 0
-    kernel_module = None
-    if os.environ.get('BENCH_KERNEL') == 'oracle':      # CPU rehearsal of the launch / shard / gather logic (tests only; never a reported number)
-        from oracle import oracle as kernel_module
-    else:
+    if kernel_module is None:
         torch.cuda.set_device(device)
 
     if args.lib:
         from remixt_amd import _lib as _libmod
         _libmod.LIB_PATH = os.path.abspath(args.lib)
     from remixt_amd import synthetic
-    from remixt_amd.restarts import RestartGroups, DatasetGroups, _pack
+    from remixt_amd.restarts import RestartGroups, DatasetGroups, gather_result_records
     if args.option and kernel_module is None:
         from remixt_amd import bpmodel
         for item in args.option:
@@ -363,23 +365,23 @@ def main():
         cnt = torch.tensor([float(R)], dtype=torch.float64, device=cdev)
         dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
         total_fitted = int(round(float(cnt.item())))
-        # final gather of the per-restart results (outside the timed region: it happens once per fit)
-        res = rs.results()
+        # final gather of the per-restart results (outside the timed region: it happens once per fit): the same
+        # function and the same two records (float64 + int8) per restart as fit_restarts_distributed.  In the
+        # weak / strong single-dataset modes unit j of rank g is restart g + j * world, i.e. shard_indices' order.
+        res = rs.results()               # this rank's units in the order of `mine`: dataset after dataset, ascending restart id
         names = list(rs.models[0].likelihood_params)
-        ids = list(e.breakpoints.keys())
-        packs = [_pack(r_, len(e.x), args.clones, len(ids), len(names), ids, names) for r_ in res]
-        per_rank = (total + world - 1) // world
-        fbuf = np.full((per_rank, len(packs[0][0])), np.nan)
-        for j, p_ in enumerate(packs):
-            fbuf[j] = p_[0]
-        ft = torch.from_numpy(fbuf).to(cdev)
-        out = [torch.empty_like(ft) for _ in range(world)]
-        tg0 = time.perf_counter()
-        dist.all_gather(out, ft)
-        if cdev == 'cuda':
-            torch.cuda.synchronize()
-        gathered = {'records': int(sum(int(np.isfinite(o.cpu().numpy()[:, 0]).sum()) for o in out)), 'bytes_per_rank': int(fbuf.nbytes),
-                    'seconds': time.perf_counter() - tg0}
+        gathered = {'records': 0, 'seconds': 0.0, 'bytes_per_rank': 0}
+        pos = 0
+        for dsi in range(ND):
+            ids = [i for (d_, i) in mine if d_ == dsi]
+            tm = {}
+            allres = gather_result_records(res[pos:pos + len(ids)], datasets[dsi], all_params[dsi], args.clones, names, device=device, timing=tm,
+                                           local_ids=ids)
+            pos += len(ids)
+            gathered['records'] += int(sum(1 for r_ in allres.values() if np.isfinite(r_['stats']['elbo'])))
+            gathered['seconds'] += tm['seconds']; gathered['bytes_per_rank'] += tm['bytes_per_rank']
+            gathered['float_record_bytes'] = tm['float_record_bytes']; gathered['int8_record_bytes'] = tm['int8_record_bytes']
+        gathered['note'] = 'per dataset two all_gathers (float64 record + int8 record per restart) through restarts.gather_result_records'
     else:
         total_fitted = R
 

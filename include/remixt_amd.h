@@ -113,8 +113,10 @@ int rmx_compress_cn_states(const int64_t *cn_states, int32_t N, int32_t S, int32
                            int32_t *num_classes);
 const char *rmx_last_error(void);
 /* The restarts whose device-side checks (the reference's ValueError / AssertionError sites) fired in the calling thread's last
- * failing call: up to `cap` indices into out, returns their number.  Every flagged restart's error state is cleared when
- * the call reports, and rmx_last_error() describes the lowest one; a batched caller fails exactly the listed restarts. */
+ * failing call: up to `cap` indices into out (out may be NULL with cap 0), returns their number.  Every flagged restart's
+ * error state is cleared when the call reports, and rmx_last_error() describes the lowest one; a batched caller fails exactly
+ * the listed restarts.  A failing call that flagged no restart (bad argument, device failure, unsupported shape) leaves the
+ * list empty: it never describes an earlier call. */
 int rmx_last_error_restarts(int32_t *out, int32_t cap);
 /* use an externally owned HIP stream (e.g. torch's current stream); NULL = own */
 int rmx_set_stream(rmx_batch *b, void *hip_stream);
@@ -131,7 +133,7 @@ int rmx_info(rmx_batch *b, int32_t what, int64_t *out);
 enum rmx_option_id {
     RMX_OPT_FB_KERNEL = 0,      /* forward-backward: 0 auto, 1 general single-vector kernel for every chain, 2 tabulated weights
                                    instead of on-the-fly weights for grids beyond the register-resident kernel (S > 176) */
-    RMX_OPT_FB_NV,              /* restarts advanced by one forward-backward workgroup: 0 auto (fills the chip), 1, 2, 4, 8, 16 */
+    RMX_OPT_FB_NV,              /* restarts advanced by one forward-backward workgroup: 0 auto, 1, 2, 4 (the shapes that exist) */
     RMX_OPT_FB_BREAKEND_CODES,  /* 1 (default): breakend steps from pair codes + clone-product tables; 0: per-clone distance tables */
     RMX_OPT_FUSE_SWEEPS,        /* 1 (default): marginals + indicator updates + next frame pass as one kernel between sweeps */
     RMX_OPT_TWO_STREAMS,        /* 1 (default): breakend branch of a sweep on a second stream next to the marginal pass */

@@ -62,9 +62,12 @@ def set_default_option(name, value):
 def last_error_restarts():
     """Restarts flagged by the calling thread's last failing call (rmx_last_error_restarts)."""
     lib = _lib.load()
-    buf = (C.c_int32 * 256)()
-    n = lib.rmx_last_error_restarts(buf, 256)
-    return [int(buf[i]) for i in range(min(n, 256))]
+    n = lib.rmx_last_error_restarts(None, 0)      # the count first: the list is as long as the batch has restarts
+    if n <= 0:
+        return []
+    buf = (C.c_int32 * n)()
+    n = min(n, lib.rmx_last_error_restarts(buf, n))
+    return [int(buf[i]) for i in range(n)]
 
 
 def _raise(lib, rc):

@@ -13,10 +13,16 @@
 #include <vector>
 
 #include "rmx_kernels.h"
+#include "rmx_host.h"
 
 // ---------------------------------------------------------------------------
 static thread_local std::string g_err;
-static int fail(int code, const std::string &msg) { g_err = msg; return code; }
+// the restarts a failing batched call flagged (this thread's last failure): rmx_last_error_restarts.  A failure that
+// flags no restart (bad argument, device error, unsupported shape) leaves the list EMPTY: fail() clears it, the
+// device-check reporters fill it and report through fail_flagged()
+static thread_local std::vector<int32_t> g_err_restarts;
+static int fail(int code, const std::string &msg) { g_err = msg; g_err_restarts.clear(); return code; }
+static int fail_flagged(int code, const std::string &msg) { g_err = msg; return code; }
 #define HIPCHK(call)                                                                         \
     do {                                                                                     \
         hipError_t e_ = (call);                                                              \
@@ -180,8 +186,6 @@ struct ProfScope {
 
 // ---- error translation -------------------------------------------------------
 static int translate_error(rmx_batch *b, int r, uint32_t v);
-// the restarts a failing batched call flagged (this thread's last failure): rmx_last_error_restarts
-static thread_local std::vector<int32_t> g_err_restarts;
 // Every flagged error word of a call is cleared on the device before the call reports -- a word left set would
 // surface in a later, unrelated call of that restart -- and the lowest flagged restart is the one reported;
 // the full list stays readable through rmx_last_error_restarts so that a batched caller can fail only those.
@@ -212,16 +216,16 @@ template <typename F> static int report_request_errors(rmx_batch *b, int n, cons
 }
 static int translate_error(rmx_batch *b, int r, uint32_t v) {
     char buf[160];
-    if (v & RMX_ERR_NAN_LL) { snprintf(buf, sizeof buf, "ll is nan (restart %d)", r); return fail(RMX_EVALUE, buf); }
-    if (v & RMX_ERR_TOTAL_DEPTH) { snprintf(buf, sizeof buf, "total_depth <= 0 (restart %d)", r); return fail(RMX_EVALUE, buf); }
-    if (v & RMX_ERR_LOH_P) { snprintf(buf, sizeof buf, "expected p 0 or 1 for loh state (restart %d)", r); return fail(RMX_EVALUE, buf); }
-    if (v & RMX_ERR_BAD_P) { snprintf(buf, sizeof buf, "p <= 0 or (1 - p) <= 0. (restart %d)", r); return fail(RMX_EVALUE, buf); }
-    if (v & RMX_ERR_DIGAMMA) { snprintf(buf, sizeof buf, "x <= 0.0 in digamma (restart %d)", r); return fail(RMX_EVALUE, buf); }
-    if (v & RMX_ERR_NAN_GRAD) { snprintf(buf, sizeof buf, "partial derivative is nan (restart %d)", r); return fail(RMX_EVALUE, buf); }
-    if (v & RMX_ERR_NAN_F) { snprintf(buf, sizeof buf, "nan in framelogprob (restart %d)", r); return fail(RMX_EASSERT, buf); }
-    if (v & RMX_ERR_NAN_AB) { snprintf(buf, sizeof buf, "nan in alphas/betas (restart %d)", r); return fail(RMX_EASSERT, buf); }
-    if (v & RMX_ERR_NAN_POST) { snprintf(buf, sizeof buf, "nan in posterior marginals (restart %d)", r); return fail(RMX_EASSERT, buf); }
-    snprintf(buf, sizeof buf, "device error bits 0x%x (restart %d)", v, r); return fail(RMX_EVALUE, buf);
+    if (v & RMX_ERR_NAN_LL) { snprintf(buf, sizeof buf, "ll is nan (restart %d)", r); return fail_flagged(RMX_EVALUE, buf); }
+    if (v & RMX_ERR_TOTAL_DEPTH) { snprintf(buf, sizeof buf, "total_depth <= 0 (restart %d)", r); return fail_flagged(RMX_EVALUE, buf); }
+    if (v & RMX_ERR_LOH_P) { snprintf(buf, sizeof buf, "expected p 0 or 1 for loh state (restart %d)", r); return fail_flagged(RMX_EVALUE, buf); }
+    if (v & RMX_ERR_BAD_P) { snprintf(buf, sizeof buf, "p <= 0 or (1 - p) <= 0. (restart %d)", r); return fail_flagged(RMX_EVALUE, buf); }
+    if (v & RMX_ERR_DIGAMMA) { snprintf(buf, sizeof buf, "x <= 0.0 in digamma (restart %d)", r); return fail_flagged(RMX_EVALUE, buf); }
+    if (v & RMX_ERR_NAN_GRAD) { snprintf(buf, sizeof buf, "partial derivative is nan (restart %d)", r); return fail_flagged(RMX_EVALUE, buf); }
+    if (v & RMX_ERR_NAN_F) { snprintf(buf, sizeof buf, "nan in framelogprob (restart %d)", r); return fail_flagged(RMX_EASSERT, buf); }
+    if (v & RMX_ERR_NAN_AB) { snprintf(buf, sizeof buf, "nan in alphas/betas (restart %d)", r); return fail_flagged(RMX_EASSERT, buf); }
+    if (v & RMX_ERR_NAN_POST) { snprintf(buf, sizeof buf, "nan in posterior marginals (restart %d)", r); return fail_flagged(RMX_EASSERT, buf); }
+    snprintf(buf, sizeof buf, "device error bits 0x%x (restart %d)", v, r); return fail_flagged(RMX_EVALUE, buf);
 }
 
 // Completion + error check for ONE restart that does not wait for other restarts' queued work:
@@ -636,7 +640,7 @@ int rmx_last_error_restarts(int32_t *out, int32_t cap) {
 static bool option_value_ok(int id, int v) {
     switch (id) {
     case RMX_OPT_FB_KERNEL: return v >= 0 && v <= 2;
-    case RMX_OPT_FB_NV: return v == 0 || v == 1 || v == 2 || v == 4 || v == 8 || v == 16;
+    case RMX_OPT_FB_NV: return v == 0 || v == 1 || v == 2 || v == 4;      // the workgroup shapes that exist (k_fbv 1 / 2 / 4, k_fbm 4)
     case RMX_OPT_SEARCH_MODE: return v >= 0 && v <= 4;
     case RMX_OPT_PAIRWISE_KERNEL: return v == 0 || v == 1;
     default: return v == 0 || v == 1;
@@ -652,35 +656,24 @@ static void configure_fb(rmx_batch *b);
 int rmx_set_option(rmx_batch *b, int32_t id, int32_t value) {
     if (!b || id < 0 || id >= RMX_OPT_COUNT || !option_value_ok(id, value)) return fail(RMX_EARG, "bad option id / value");
     if (id == RMX_OPT_CELL_CACHE || id == RMX_OPT_SPARSE_TRIAL || id == RMX_OPT_FB_DEBUG) return fail(RMX_EARG, "creation-time option: use rmx_set_default_option before rmx_batch_create");
+    BIND(b);      // configure_fb sets function attributes (the > 64 KiB LDS opt-in) on the calling thread's current device
     b->opt[id] = value;
     if (id == RMX_OPT_FB_KERNEL) configure_fb(b);
     return RMX_OK;
 }
 int rmx_get_option(rmx_batch *b, int32_t id, int32_t *value) {
     if (!b || !value || id < 0 || id >= RMX_OPT_COUNT) return fail(RMX_EARG, "bad option id");
+    BIND(b);
     *value = b->opt[id];
     return RMX_OK;
 }
 
 int rmx_compress_cn_states(const int64_t *cn_states, int32_t N, int32_t S, int32_t M, int32_t max_classes,
                            int32_t *seg_class_out, int64_t *classes_out, int32_t *num_classes) {
-    if (!cn_states || !seg_class_out || !classes_out || !num_classes) return fail(RMX_EARG, "null argument");
-    const size_t tsz = (size_t)S * M * 2;
-    int C = 0;
-    for (int n = 0; n < N; n++) {
-        const int64_t *t = cn_states + (size_t)n * tsz;
-        int found = -1;
-        if (n > 0 && memcmp(t, classes_out + (size_t)seg_class_out[n - 1] * tsz, tsz * 8) == 0) found = seg_class_out[n - 1];
-        for (int c = 0; c < C && found < 0; c++) if (memcmp(t, classes_out + (size_t)c * tsz, tsz * 8) == 0) found = c;
-        if (found < 0) {
-            if (C >= max_classes) return fail(RMX_EUNSUPPORTED, "too many distinct per-segment state tables");
-            memcpy(classes_out + (size_t)C * tsz, t, tsz * 8);
-            found = C++;
-        }
-        seg_class_out[n] = found;
-    }
-    *num_classes = C;
-    return RMX_OK;
+    const int rc = rmxh::compress_cn_states(cn_states, N, S, M, max_classes, seg_class_out, classes_out, num_classes);
+    if (rc == RMX_EARG) return fail(RMX_EARG, "null argument");
+    if (rc == RMX_EUNSUPPORTED) return fail(RMX_EUNSUPPORTED, "too many distinct per-segment state tables");
+    return rc;
 }
 
 int rmx_batch_create(const rmx_problem *pr, int32_t R, const double *h_init, const double *divw, int32_t device, rmx_batch **out) {
@@ -1120,18 +1113,7 @@ int rmx_calculate_log_transmat(rmx_batch *b, int32_t r, double *dst) { BIND(b);
 // sequential accumulation, hence the same indices.  *positive receives count_nonzero(p > 0).  No device work,
 // no Python objects: host threads run it concurrently.
 int rmx_weighted_search(const double *p, int64_t n, const double *u, int32_t k, int64_t *out, int64_t *positive) {
-    if (!p || n < 1 || (k > 0 && (!u || !out))) return fail(RMX_EARG, "bad argument");
-    std::vector<double> cdf((size_t)n);
-    double acc = 0.;
-    int64_t pos = 0;
-    for (int64_t i = 0; i < n; i++) { acc += p[i]; cdf[(size_t)i] = acc; pos += p[i] > 0.; }
-    const double last = cdf[(size_t)n - 1];
-    for (int64_t i = 0; i < n; i++) cdf[(size_t)i] /= last;
-    for (int32_t j = 0; j < k; j++) {
-        const int64_t idx = (int64_t)(std::upper_bound(cdf.begin(), cdf.end(), u[j]) - cdf.begin());
-        out[j] = std::min<int64_t>(idx, n - 1);
-    }
-    if (positive) *positive = pos;
+    if (rmxh::weighted_search(p, n, u, k, out, positive)) return fail(RMX_EARG, "bad argument");
     return RMX_OK;
 }
 
@@ -1744,95 +1726,7 @@ int rmx_expected_ll_batch(rmx_batch *b, int32_t nreq, const int32_t *restarts, i
 // resumable state machine: same floating-point operations in the same order as scipy's
 // _minimize_neldermead (python twin: remixt_amd/lockstep.py fmin_1d; tests compare the two).
 namespace {
-struct Nm1 {
-    enum { START, W_INIT0, W_INIT1, W_XR, W_XE, W_XC, W_XCC, W_SHRINK, DONE };
-    double s0 = 0, s1 = 0, f0 = INFINITY, f1 = INFINITY, xbar = 0, xr = 0, fxr = 0, xe = 0, xc = 0, xcc = 0, req = 0, last = 0;
-    int fcalls = 0, iters = 0, state = START;
-    static constexpr int maxfun = 200, maxiter = 200;
-    static constexpr double xatol = 1e-4, fatol = 1e-4;
-    bool request(double x, int next) { if (fcalls >= maxfun) return false; fcalls++; req = x; last = x; state = next; return true; }
-    void sort() { if (f1 < f0) { std::swap(f0, f1); std::swap(s0, s1); } }
-    // feed the value of the last request (ignored on the first call); true = `req` holds the next point
-    bool advance(double x0, double f) {
-#pragma clang fp contract(off)
-        switch (state) {
-        case START:
-            s0 = x0; s1 = x0 != 0. ? (1 + 0.05) * x0 : 0.00025;
-            if (request(s0, W_INIT0)) return true;
-            goto init_done;
-        case W_INIT0:
-            f0 = f;
-            if (request(s1, W_INIT1)) return true;
-            goto init_done;
-        case W_INIT1:
-            f1 = f;
-            goto init_done;
-        case W_XR:
-            fxr = f;
-            if (fxr < f0) {
-                xe = 3. * xbar - 2. * s1;
-                if (request(xe, W_XE)) return true;
-                goto maxfun_exit;
-            }
-            // N = 1: fsim[-2] is fsim[0], so "fxr < fsim[-2]" cannot hold here
-            if (fxr < f1) {
-                xc = 1.5 * xbar - 0.5 * s1;
-                if (request(xc, W_XC)) return true;
-                goto maxfun_exit;
-            }
-            xcc = 0.5 * xbar + 0.5 * s1;
-            if (request(xcc, W_XCC)) return true;
-            goto maxfun_exit;
-        case W_XE:
-            if (f < fxr) { s1 = xe; f1 = f; } else { s1 = xr; f1 = fxr; }
-            goto iter_done;
-        case W_XC:
-            if (f <= fxr) { s1 = xc; f1 = f; goto iter_done; }
-            goto shrink;
-        case W_XCC:
-            if (f < f1) { s1 = xcc; f1 = f; goto iter_done; }
-            goto shrink;
-        case W_SHRINK:
-            f1 = f;
-            goto iter_done;
-        default:
-            return false;
-        }
-    shrink:
-        s1 = s0 + 0.5 * (s1 - s0);
-        if (request(s1, W_SHRINK)) return true;
-        goto maxfun_exit;
-    init_done:
-        sort();
-        iters = 1;
-        goto loop_top;
-    iter_done:
-        iters++;
-    maxfun_exit:
-        sort();
-    loop_top:
-        if (fcalls < maxfun && iters < maxiter) {
-            if (!(fabs(s1 - s0) <= xatol && fabs(f0 - f1) <= fatol)) {
-                xbar = s0 / 1;
-                xr = 2. * xbar - 1. * s1;
-                if (request(xr, W_XR)) return true;
-                goto maxfun_exit;      // cannot happen (fcalls < maxfun was just checked); mirrors the python flow
-            }
-        }
-        state = DONE;
-        return false;
-    }
-    double xopt() const { return s0; }
-    // the points the NEXT call of advance() can request, whatever value the pending request gets (same
-    // expressions as above): after the first initial point the second one; after a reflection the
-    // expansion, the outside and the inside contraction
-    int lookahead(double out[3]) const {
-#pragma clang fp contract(off)
-        if (state == W_INIT0) { out[0] = s1; return 1; }
-        if (state == W_XR) { out[0] = 3. * xbar - 2. * s1; out[1] = 1.5 * xbar - 0.5 * s1; out[2] = 0.5 * xbar + 0.5 * s1; return 3; }
-        return 0;
-    }
-};
+using rmxh::Nm1;
 }  // namespace
 
 // scipy.optimize.brute(nll, ranges=[(lo, hi)], Ns=G, full_output=True)[0] for one likelihood parameter

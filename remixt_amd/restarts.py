@@ -250,7 +250,12 @@ class RestartSet(object):
         from . import lockstep
         b = self.batch
         R = len(self.models)
-        active = [r for r, m in enumerate(self.models) if m.do_h_update]
+        # a restart whose h M-step failed once is out of the selection for good (error_messages is never cleared):
+        # it keeps its h from then on instead of failing -- and forcing a second lock-step run -- in every later iteration
+        gone = getattr(self, '_h_failed', None)
+        if gone is None:
+            gone = self._h_failed = set()
+        active = [r for r, m in enumerate(self.models) if m.do_h_update and r not in gone]
         if not active:
             return True
         h_before = [np.array(m.model.h, dtype=float) for m in self.models]
@@ -304,6 +309,7 @@ class RestartSet(object):
             return False
         self._mark('h:rounds')
         self.error_messages.update(dead)
+        gone.update(dead)
         active = [r for r in active if r not in dead]
         failed = set()
         trial = hasattr(b, 'expected_log_likelihood_full_trial')
@@ -326,6 +332,7 @@ class RestartSet(object):
                 if self.strict:
                     raise
                 failed.add(r)
+                gone.add(r)
                 self.error_messages[r] = str(err).splitlines()[0] + ' (h kept)'
         # accept test on trial values; a restart that keeps its h is rolled back without a second pass
         # over the cells (its expectations and cell cache still belong to h_before)
@@ -812,8 +819,6 @@ def fit_restarts_distributed(experiment, init_params, max_copy_number, num_clone
     mine = shard_indices(len(init_params), world, rank)
     if device is None:
         device = (torch.cuda.current_device() if torch.cuda.is_available() else 0)
-    N = len(experiment.x); M = num_clones
-    brk_ids = list(experiment.breakpoints.keys()); K = len(brk_ids)
     local = []
     param_names = None
     if mine:
@@ -828,6 +833,25 @@ def fit_restarts_distributed(experiment, init_params, max_copy_number, num_clone
         nc = model_kwargs.get('normal_contamination', True)
         param_names = ['negbin_r_0', 'negbin_r_1', 'betabin_M_0', 'betabin_M_1'] + (
             [] if nc else ['negbin_hdel_mu', 'negbin_hdel_r_0', 'negbin_hdel_r_1', 'betabin_loh_p', 'betabin_loh_M_0', 'betabin_loh_M_1'])
+    return gather_result_records(local, experiment, init_params, num_clones, param_names, device=device)
+
+
+def gather_result_records(local, experiment, init_params, num_clones, param_names, device=None, timing=None, local_ids=None):
+    """The one collective of the path: every rank contributes the fixed-size records of the restarts
+    it fitted (`local`, in the order of shard_indices) -- one float64 record (ELBO, h, parameters, outlier
+    probabilities, failure code) and one int8 record (cn, brk_cn, masks) per restart -- and every rank gets the
+    results of all `len(init_params)` restarts back, keyed by restart id (`collate` stores all of them,
+    analysis/pipeline.py:289-291).  Two all_gathers (RCCL over xGMI with the nccl backend; gloo in the CPU tests); a
+    process without a process group just repacks.  `timing`: a dict that receives the message size and the seconds
+    spent in the collectives.  `local_ids`: the restart ids of `local` when the ranks' shares are not shard_indices'
+    (several datasets cut over the ranks as one list of units); they are gathered first (one small all_gather)."""
+    import time
+    import torch
+    import torch.distributed as dist
+    distributed = dist.is_available() and dist.is_initialized()
+    world = dist.get_world_size() if distributed else 1
+    N = len(experiment.x); M = num_clones
+    brk_ids = list(experiment.breakpoints.keys()); K = len(brk_ids)
     nparams = len(param_names)
     per_rank = (len(init_params) + world - 1) // world
     flen = _HDR + M + nparams + 4 * N
@@ -835,8 +859,22 @@ def fit_restarts_distributed(experiment, init_params, max_copy_number, num_clone
     fbuf = np.full((per_rank, flen), np.nan); ibuf = np.zeros((per_rank, ilen), dtype=np.int8)
     for j, res in enumerate(local):
         fbuf[j], ibuf[j] = _pack(res, N, M, K, nparams, brk_ids, param_names)
+    if local_ids is not None:
+        ids_t = np.full((per_rank,), -1, dtype=np.int64); ids_t[:len(local_ids)] = local_ids
+    t0 = time.perf_counter()
+    ids_all = None
+    if distributed and local_ids is not None:
+        dev_ = torch.device('cuda', device if device is not None else torch.cuda.current_device()) if dist.get_backend() == 'nccl' else torch.device('cpu')
+        it_ = torch.from_numpy(ids_t).to(dev_)
+        got = [torch.empty_like(it_) for _ in range(world)]
+        dist.all_gather(got, it_)
+        ids_all = [t.cpu().numpy() for t in got]
+    elif local_ids is not None:
+        ids_all = [ids_t]
     if distributed:
         on_gpu = dist.get_backend() == 'nccl'
+        if device is None:
+            device = torch.cuda.current_device() if on_gpu else 0
         dev = torch.device('cuda', device) if on_gpu else torch.device('cpu')
         ft = torch.from_numpy(fbuf).to(dev); it = torch.from_numpy(ibuf).to(dev)
         fall = [torch.empty_like(ft) for _ in range(world)]; iall = [torch.empty_like(it) for _ in range(world)]
@@ -845,9 +883,13 @@ def fit_restarts_distributed(experiment, init_params, max_copy_number, num_clone
         fall = [t.cpu().numpy() for t in fall]; iall = [t.cpu().numpy() for t in iall]
     else:
         fall, iall = [fbuf], [ibuf]
+    if timing is not None:
+        timing.update({'seconds': time.perf_counter() - t0, 'bytes_per_rank': int(fbuf.nbytes + ibuf.nbytes),
+                       'float_record_bytes': int(flen * 8), 'int8_record_bytes': int(ilen), 'records_per_rank': int(per_rank)})
     results = {}
     for g in range(world):
-        for j, i in enumerate(shard_indices(len(init_params), world, g)):
+        ids_g = shard_indices(len(init_params), world, g) if ids_all is None else [int(i) for i in ids_all[g] if i >= 0]
+        for j, i in enumerate(ids_g):
             results[i] = _unpack(fall[g][j], iall[g][j], N, M, K, nparams, brk_ids, param_names, init_params[i])
     return results
 

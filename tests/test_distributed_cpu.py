@@ -41,12 +41,13 @@ def _free_port():
 
 
 def _bench(extra, env_extra=None):
-    """Run bench.py on the CPU oracle kernel (launch / shard / gather logic only) and return its JSON line."""
+    """Run bench.main() through tests/bench_rehearsal.py (CPU oracle kernel, gloo: launch / shard / gather logic only) and
+    return its JSON line."""
     import json
-    env = dict(os.environ, BENCH_KERNEL='oracle', BENCH_DIST_BACKEND='gloo', MASTER_ADDR='127.0.0.1')
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1')
     env.pop('WORLD_SIZE', None); env.pop('RANK', None); env.pop('LOCAL_RANK', None)
     env.update(env_extra or {})
-    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--segments', '80', '--max-cn', '2', '--steps', '1', '--warmup', '0',
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'tests', 'bench_rehearsal.py'), '--segments', '80', '--max-cn', '2', '--steps', '1', '--warmup', '0',
                           '--no-cpu-baseline'] + extra, env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith('{')]
@@ -60,6 +61,9 @@ def test_bench_gpus_2_launches_two_ranks():
     assert line['n_gpus'] == 2 and line['config']['world_size_observed'] == 2
     assert line['scaling'] == 'weak' and line['config']['restarts_total'] == 4 and line['config']['restarts_this_rank'] == 2
     assert line['final_gather']['records'] == 4
+    # the gather is the real message: a float64 and an int8 record per restart
+    assert line['final_gather']['int8_record_bytes'] > 0 and line['final_gather']['bytes_per_rank'] == 2 * (
+        line['final_gather']['float_record_bytes'] + line['final_gather']['int8_record_bytes'])
     assert line['value'] > 0 and np.isfinite(line['elbo_best'])
 
 
@@ -74,9 +78,18 @@ def test_bench_strong_scaling_and_two_datasets():
 
 
 def test_bench_refuses_a_world_size_that_contradicts_gpus():
-    env = dict(os.environ, BENCH_KERNEL='oracle', WORLD_SIZE='2', RANK='0', LOCAL_RANK='0')
+    env = dict(os.environ, WORLD_SIZE='2', RANK='0', LOCAL_RANK='0')
     out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '4', '--no-cpu-baseline'], env=env, capture_output=True, text=True, timeout=120)
     assert out.returncode != 0 and 'WORLD_SIZE' in (out.stderr + out.stdout)
+
+
+def test_bench_has_no_switch_that_times_the_checker():
+    """outside the CPU-baseline leg bench.py never names the oracle, and reads no environment variable
+    that could select a kernel module or a process-group backend."""
+    src = open(os.path.join(ROOT, 'bench.py')).read()
+    main_part = src[src.index('def build_datasets'):]
+    assert 'oracle' not in main_part.replace('oracle/', '')
+    assert 'BENCH_KERNEL' not in src and 'BENCH_DIST_BACKEND' not in src
 
 
 def test_two_rank_gloo_matches_single_process(tmp_path):

@@ -1,0 +1,131 @@
+"""CPU: AddressSanitizer + UndefinedBehaviorSanitizer builds of the native CPU-side code.
+
+(1) oracle/remixt_oracle.c built with gcc -fsanitize=address,undefined replays every golden model, grid and chain case of
+    tests/test_oracle_golden.py in a child interpreter that preloads the sanitizer runtimes;
+(2) the host-only pieces of the C ABI (remixt_amd/csrc/rmx_host.h: rmx_weighted_search, rmx_compress_cn_states, the
+    Nelder-Mead state machine of rmx_param_search) built the same way into a small harness (tests/csrc/host_sanitize.cpp)
+    and compared with numpy, with remixt_amd.lockstep.fmin_1d and with scipy.optimize.fmin.
+GPU sanitizers are not available on the pool (task statement); the device code is covered by the parity tests instead."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SAN = ['-fsanitize=address,undefined', '-fno-sanitize-recover=all', '-fno-omit-frame-pointer', '-g', '-O1']
+
+
+def _runtime(name):
+    path = subprocess.run(['gcc', '-print-file-name=' + name], capture_output=True, text=True).stdout.strip()
+    if not os.path.isabs(path) or not os.path.exists(path):
+        pytest.skip('no %s in this toolchain' % name)
+    return path
+
+
+def test_oracle_replays_the_goldens_under_asan_and_ubsan(tmp_path):
+    lib = str(tmp_path / 'libremixt_oracle_san.so')
+    subprocess.check_call(['gcc', '-std=c99', '-fPIC', '-shared', '-ffp-contract=off'] + SAN +
+                          ['-o', lib, os.path.join(ROOT, 'oracle', 'remixt_oracle.c'), '-lm'])
+    env = dict(os.environ, RMX_ORACLE_LIB=lib, LD_PRELOAD=_runtime('libasan.so') + ':' + _runtime('libubsan.so'),
+               ASAN_OPTIONS='detect_leaks=0:halt_on_error=1:abort_on_error=0', UBSAN_OPTIONS='halt_on_error=1:print_stacktrace=1',
+               PYTHONMALLOC='malloc')
+    out = subprocess.run([sys.executable, '-m', 'pytest', os.path.join(ROOT, 'tests', 'test_oracle_golden.py'), '-x', '-q', '-p', 'no:cacheprovider'],
+                         env=env, capture_output=True, text=True, timeout=1500, cwd=ROOT)
+    text = out.stdout + out.stderr
+    assert out.returncode == 0, text[-3000:]
+    assert 'AddressSanitizer' not in text and 'runtime error' not in text, text[-3000:]
+    assert ' passed' in text
+
+
+@pytest.fixture(scope='module')
+def harness(tmp_path_factory):
+    exe = str(tmp_path_factory.mktemp('san') / 'host_sanitize')
+    subprocess.check_call(['g++', '-std=c++17', '-ffp-contract=off', '-Wno-unknown-pragmas'] + SAN +
+                          ['-o', exe, os.path.join(ROOT, 'tests', 'csrc', 'host_sanitize.cpp')])
+
+    def run(*args):
+        out = subprocess.run([exe] + [str(a) for a in args], capture_output=True, text=True, timeout=120,
+                             env=dict(os.environ, ASAN_OPTIONS='detect_leaks=1:halt_on_error=1', UBSAN_OPTIONS='halt_on_error=1'))
+        assert out.returncode == 0 and 'Sanitizer' not in out.stderr and 'runtime error' not in out.stderr, out.stderr[-2000:]
+        return out.stdout.splitlines()
+    return run
+
+
+def _objective(c, x):
+    if c == 0:
+        return (x - 1.3) * (x - 1.3) + 0.1 * abs(x)
+    if c == 1:
+        return abs(x - 250.) * 0.01 + 3.
+    if c == 2:
+        t = x * 0.001 - 0.7
+        return t * t * t * t - 0.3 * t * t + 0.05 * t
+    if c == 3:
+        return np.inf if (x < 10. or x > 3000.) else (x - 1999.5) * (x - 1999.5) * 1e-6
+    return 0. * x + 1.
+
+
+@pytest.mark.parametrize('case,x0', [(0, 0.), (0, 5.), (1, 10.), (1, 249.99), (2, 1.), (2, 1500.), (3, 2000.), (3, 11.), (4, 3.)])
+def test_nelder_mead_state_machine_under_sanitizers_equals_fmin_1d_and_scipy(harness, case, x0):
+    import scipy.optimize
+    from remixt_amd import lockstep
+    lines = harness('nm', case, repr(float(x0)))
+    reqs = [float(l.split()[1]) for l in lines if l.startswith('req')]
+    xopt, fcalls = float(lines[-1].split()[1]), int(lines[-1].split()[3])
+    # python twin, evaluation by evaluation
+    gen = lockstep.fmin_1d(float(x0))
+    seen = []
+    try:
+        x = next(gen)
+        while True:
+            seen.append(float(x[0]))
+            x = gen.send(_objective(case, float(x[0])))
+    except StopIteration as stop:
+        res = stop.value
+    assert seen == reqs                      # bit for bit, in order
+    assert float(res[0][0]) == xopt and int(res[3]) == fcalls
+    with np.errstate(invalid='ignore'):      # scipy itself subtracts infinities on objective 3
+        ref = scipy.optimize.fmin(lambda v: _objective(case, float(v[0])), [float(x0)], full_output=True, disp=False)
+    assert float(ref[0][0]) == xopt and int(ref[3]) == fcalls
+
+
+def _splitmix(seed):
+    state = [seed & (2 ** 64 - 1)]
+
+    def nxt():
+        state[0] = (state[0] + 0x9E3779B97F4A7C15) & (2 ** 64 - 1)
+        z = state[0]
+        z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & (2 ** 64 - 1)
+        z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & (2 ** 64 - 1)
+        return z ^ (z >> 31)
+    return nxt
+
+
+@pytest.mark.parametrize('seed,n,k', [(1, 1, 3), (2, 7, 0), (3, 1000, 200), (4, 50000, 200)])
+def test_weighted_search_under_sanitizers_equals_numpy(harness, seed, n, k):
+    lines = harness('ws', seed, n, k)
+    nxt = _splitmix(seed)
+    unit = lambda: float(nxt() >> 11) / 9007199254740992.
+    p = np.array([(0. if t < 0.3 else t) for t in (unit() for _ in range(n))])
+    p[n - 1] = 0.
+    u = np.array([unit() for _ in range(k)])
+    if k:
+        u[0] = 0.
+    head = lines[0].split()
+    assert head[1] == '0'
+    if p.sum() > 0:
+        cdf = np.cumsum(p); cdf /= cdf[-1]
+        want = np.minimum(np.searchsorted(cdf, u, side='right'), n - 1)
+        assert [int(v) for v in head[5:]] == [int(v) for v in want]
+        assert int(head[3]) == int(np.count_nonzero(p > 0))
+    assert lines[1] == 'null 5 empty 5'
+
+
+@pytest.mark.parametrize('seed,N,S,M', [(5, 1, 4, 2), (6, 300, 9, 2), (7, 200, 47, 3)])
+def test_compress_cn_states_under_sanitizers(harness, seed, N, S, M):
+    lines = harness('cc', seed, N, S, M)
+    head = lines[0].split()
+    assert head[1] == '0' and 1 <= int(head[3]) <= 3 and head[5] == '0'
+    if int(head[3]) > 1:
+        assert lines[1] == 'too_few rc 4'
