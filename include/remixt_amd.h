@@ -122,7 +122,11 @@ int rmx_last_error_restarts(int32_t *out, int32_t cap);
 int rmx_set_stream(rmx_batch *b, void *hip_stream);
 int rmx_synchronize(rmx_batch *b);
 /* derived sizes: 0 cn_max (bpmodel.pyx:489), 1 num chains, 2 num transition classes,
- * 3 num breakend segments, 4 padded row stride of [N][S] device arrays */
+ * 3 num breakend segments, 4 padded row stride of [N][S] device arrays; 10 / 11 chains on the register-resident
+ * forward-backward kernels / on the general one; 12 the forward-backward kernel the last update_p_cn launched for the
+ * former (1 k_fbm: FP64 matrix cores, 2 k_fbv: vector FMA, 3 k_fbk: weights from packed copy numbers, 4 k_fbq: matrix cores with
+ * weights from 8-bit codes; 0: general kernel k_fb<0> only), 13 restarts per workgroup of that launch, 14 the lattice kernel of
+ * the last decode (1 k_viterbi_reg, 2 k_viterbi_code, 3 k_viterbi) */
 int rmx_info(rmx_batch *b, int32_t what, int64_t *out);
 
 /* -- tuning options ------------------------------------------------------- */

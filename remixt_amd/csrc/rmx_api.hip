@@ -102,6 +102,8 @@ struct rmx_batch {
     // FB launch configuration
     FbLaunch fbG{}; size_t fbG_lds = 0;   // generic kernel configuration
     int n_fast = 0, n_generic = 0;
+    // which kernels the last update_p_cn / decode launched (rmx_info 12..14; tests assert the shape they mean to cover)
+    int last_fb_kernel = 0, last_fb_nv = 0, last_viterbi = 0;
     unsigned long long *d_dbg = nullptr;
     int fbv_rpt = 0;   // rows per slice of the multi-vector kernel (0 = not applicable)
     int G = 64;
@@ -956,6 +958,7 @@ int rmx_info(rmx_batch *b, int32_t what, int64_t *out) { BIND(b);
     case 0: *out = b->d.cn_max; break; case 1: *out = b->d.NC; break; case 2: *out = b->d.TC; break; case 3: *out = b->d.NBE; break;
     case 4: *out = b->d.SP; break; case 5: *out = b->fbv_rpt; break; case 6: *out = b->fbG.P; break; case 7: *out = b->fbG.NT; break;
     case 8: *out = b->fbG.BLK; break; case 9: *out = (int64_t)b->fbG_lds; break; case 10: *out = b->n_fast; break; case 11: *out = b->n_generic; break;
+    case 12: *out = b->last_fb_kernel; break; case 13: *out = b->last_fb_nv; break; case 14: *out = b->last_viterbi; break;
     case 20: case 21: case 22: case 23: case 24: case 25: case 26: case 27: case 28: case 29: case 30: case 31: case 32: case 33: case 34: case 35: case 36: case 37: case 38: case 39:
     case 40: case 41: case 42: case 43: case 44: case 45: case 46: case 47: case 48: case 49: case 50: case 51:
         { if (!b->d_dbg) { *out = 0; break; } unsigned long long v[32]; HIPCHK(hipStreamSynchronize(b->stream)); HIPCHK(hipMemcpy(v, b->d_dbg, 256, hipMemcpyDeviceToHost)); *out = (int64_t)v[what - 20]; break; }
@@ -1203,7 +1206,7 @@ static int p_cn_front(rmx_batch *b, int r0, int r1, bool skip_frame, bool snapsh
             if (KB > 0 && NCT <= 12 && lds <= kLdsBudget) {
                 HIPCHK(hipFuncSetAttribute((const void *)kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
                 hipLaunchKernelGGL(kf, dim3(b->n_fast, ((r1 - 1) >> 2) - (r0 >> 2) + 1, 2), dim3(64 * NCT), lds, b->stream, m);
-                done_fast = true; fast = true;
+                done_fast = true; fast = true; b->last_fb_kernel = 1; b->last_fb_nv = 4;
             }
         }
         if (!done_fast && b->fbv_rpt > 0 && b->n_fast > 0) {
@@ -1251,7 +1254,7 @@ static int p_cn_front(rmx_batch *b, int r0, int r1, bool skip_frame, bool snapsh
             if (kf && nt <= 768 && lds <= kLdsBudget) {
                 HIPCHK(hipFuncSetAttribute((const void *)kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
                 hipLaunchKernelGGL(kf, dim3(b->n_fast, (nr + NV - 1) / NV, 2), dim3(nt), lds, b->stream, v);
-                done_fast = true; fast = true;
+                done_fast = true; fast = true; b->last_fb_kernel = 2; b->last_fb_nv = NV;
             }
         }
         if (!done_fast && b->fbv_rpt == 0 && b->fbk_ok && d.pe2_lt && b->n_fast > 0 && b->opt[RMX_OPT_FB_KERNEL] == 0) {
@@ -1279,9 +1282,10 @@ static int p_cn_front(rmx_batch *b, int r0, int r1, bool skip_frame, bool snapsh
                 void (*kf)(FbvArgs, const double *, const uint32_t *, const uint32_t *) = NV == 1 ? k_fbk<1, 768> : (NV == 2 ? k_fbk<2, 768> : k_fbk<4, 768>);
                 HIPCHK(hipFuncSetAttribute((const void *)kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
                 hipLaunchKernelGGL(kf, dim3(b->n_fast, (nr + NV - 1) / NV, 2), dim3(nt), lds, b->stream, v, (const double *)b->d_wk, (const uint32_t *)b->d_cnpack, (const uint32_t *)b->d_totpack);
-                done_fast = true; fast = true;
+                done_fast = true; fast = true; b->last_fb_kernel = 3; b->last_fb_nv = NV;
             }
         }
+        if (!fast) { b->last_fb_kernel = 0; b->last_fb_nv = 1; }
         const int ngen = fast ? b->n_generic : d.NC;
         if (ngen > 0) {
             a.amat_lds = 0; a.P = b->fbG.P; a.BLK = b->fbG.BLK; a.SPAD = b->fbG.SPAD; a.chain_list = fast ? d.chain_list_generic : d.chain_list_all;
@@ -2238,6 +2242,7 @@ static int viterbi_paths(rmx_batch *b, int r0, int nr, std::vector<int64_t> &pat
     const int QPT4 = ((QPT + 3) / 4) * 4;
     const size_t code_lds = b->vit_code_ok ? (size_t)(2 * (Pr * QPT4 + 4) + ((M * d.D + 1) & ~1) + 256) * 8 + (size_t)S * Pr * QPT4 : (size_t)1 << 30;
     { ProfScope ps(b, KID_VITERBI);
+      b->last_viterbi = reg ? 1 : ((cur_model && code_lds <= kLdsBudget && !b->opt[RMX_OPT_VITERBI_PLAIN]) ? 2 : 3);
       if (reg) {
           const int NT = ((S * Pr + 63) / 64) * 64;
 #define VREG(Q) hipLaunchKernelGGL(k_viterbi_reg<Q>, dim3(nr), dim3(NT), (size_t)(2 * (Pr * QPT + Q) + M * d.D) * 8, b->stream, dv, r0, Pr, b->d_bp, b->d_final)

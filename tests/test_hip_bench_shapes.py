@@ -53,17 +53,19 @@ def _compare_after_every_update(dev, ora, sweeps=2, elbo_rtol=1e-8):
 
 @pytest.mark.parametrize('R,NV', [(4, 4), (8, 2), (8, 4), (3, 2)])
 def test_s165_restart_batch_with_dense_breakends_matches_oracle(hip, oracle_mod, R, NV):
-    """165 states, R restarts in one batch on the benchmark's launch shapes (NV = 2: two restart groups of 8; NV = 4: one
-    group of 16; (3, 2): a ragged last workgroup), 24 breakpoints + two sharing a boundary on 110 segments -> ~50 breakend
-    adjacencies, i.e. every other step of k_fbv takes the breakend branch, and k_pairwise / k_brk_lut see all of them."""
+    """165 states, R restarts in one batch, 24 breakpoints + two sharing a boundary on 110 segments -> ~50 breakend adjacencies, i.e.
+    every other step takes the breakend branch, and k_pairwise_be2 / k_brk_lut see all of them.  NV = 4: the production kernel
+    k_fbm (FP64 matrix cores, quads of restarts; R = 4 one full quad, R = 8 two); NV = 2: the vector-FMA kernel k_fbv with two
+    restarts per workgroup ((3, 2): a ragged last workgroup).  Which one ran is asserted through rmx_info(12 / 13)."""
     from remixt_amd import synthetic
     e = synthetic.make_experiment(110, num_clones=3, max_copy_number=8, num_chains=2, seed=31, num_breakpoints=24)
     e.breakpoints = H.add_shared_boundary_breakpoints(e)
     ps = synthetic.make_init_params(e, R, 8)
     dev, ora = _two_sets(oracle_mod, e, ps, 8, 3, options={'fb_nv': NV})
     b = dev.batch
-    assert b.num_cn_states == 165 and b.info(3) >= 48 and b.info(10) == 2 and b.info(11) == 0      # breakend adjacencies; both chains on k_fbv
+    assert b.num_cn_states == 165 and b.info(3) >= 48 and b.info(10) == 2 and b.info(11) == 0      # breakend adjacencies; both chains on the register-resident kernels
     _compare_after_every_update(dev, ora)
+    assert (b.info(12), b.info(13)) == ((1, 4) if NV == 4 else (2, 2))                              # k_fbm / k_fbv<., 2>
 
 
 def test_s165_generic_kernel_and_plain_breakend_tables_match_oracle(hip, oracle_mod):
@@ -369,3 +371,136 @@ def test_baseline_config1_shape_matches_oracle(hip, oracle_mod):
     cna = np.zeros((ma.num_segments, 2, 2), dtype=int); cnb = cna.copy()
     ma.infer_cn(cna); mb.infer_cn(cnb)
     assert np.array_equal(cna, cnb)
+
+
+# ---- state grids beyond the benchmark's (kernels generic in S <= 1024, M <= 4) ------------------------------------
+@pytest.mark.parametrize('M,max_cn,S,N,fb,vit', [
+    (4, 4, 207, 30, None, None),   # four clones with breakends above 176 states
+    (4, 6, 457, 28, None, None),
+    (3, 13, 413, 30, 0, 3),        # three clones above 355 states: the general kernel k_fb<0> (weights from L2), the plain lattice
+    (3, 16, 617, 26, 0, 3),
+    (3, 20, 951, 22, 0, 3),        # the largest three-clone grid below 1 024 states
+])
+def test_large_state_grids_match_oracle(hip, oracle_mod, M, max_cn, S, N, fb, vit):
+    """every coordinate update of two sweeps and the decode against the oracle at the four-clone grids of
+    cn_model.py:228-253 (207 / 457 states) and at three-clone grids up to 951 states, with a record of the forward-backward /
+    lattice kernel each one selects (rmx_info 12 / 14)."""
+    from remixt_amd import synthetic
+    e = synthetic.make_experiment(N, num_clones=M, max_copy_number=max_cn, num_chains=2, seed=60 + max_cn, num_breakpoints=5)
+    e.breakpoints = H.add_shared_boundary_breakpoints(e)
+    ps = synthetic.make_init_params(e, 2, max_cn, num_clones=M)
+    fr = (0.6, 0.4) if M == 3 else (0.5, 0.3, 0.2)
+    hs = [np.array([p['h_normal']] + [p['h_tumour'] * f for f in fr]) for p in ps]
+    dev, ora = _two_sets(oracle_mod, e, ps, max_cn, M, h_init=hs)
+    b = dev.batch
+    assert b.num_cn_states == S and b.info(3) >= 10
+    _compare_after_every_update(dev, ora, sweeps=2)
+    got = (b.info(12), b.info(14))
+    print('state grid M=%d max_cn=%d S=%d: forward-backward kernel %d (restarts per workgroup %d), lattice kernel %d' % (M, max_cn, S, got[0], b.info(13), got[1]))
+    if fb is not None:
+        assert got == (fb, vit), ('kernel selection changed', got)
+
+
+def test_kernel_selection_at_the_benchmark_grids(hip):
+    """Which kernels the parametrisations above really run (docstrings named k_fbv where k_fbm runs)."""
+    from remixt_amd import synthetic
+    from remixt_amd.restarts import RestartSet
+    want = {(8, None): (1, 4, 1), (8, 2): (2, 2, 1), (8, 1): (2, 1, 1), (12, None): (3, None, 2)}
+    for (max_cn, nv), (fb, nvx, vit) in want.items():
+        e = synthetic.make_experiment(60, num_clones=3, max_copy_number=max_cn, num_chains=2, seed=3, num_breakpoints=4)
+        rs = RestartSet(e, synthetic.make_init_params(e, 4, max_cn), max_cn, num_clones=3, quiet=True, options=({'fb_nv': nv} if nv else None))
+        rs.batch.variational_update(1)
+        rs.batch.infer_cn_batch(0, 2)
+        got = (rs.batch.info(12), rs.batch.info(13), rs.batch.info(14))
+        assert got[0] == fb and got[2] == vit and (nvx is None or got[1] == nvx), (max_cn, nv, got)
+
+
+# ---- ADVICE r2 ------------------------------------------------------------------------------------------------------------------
+def test_an_unflagged_failure_does_not_inherit_the_previous_calls_restart_list(hip):
+    """rmx_last_error_restarts describes the calling thread's LAST failing call only: a device-flagged failure followed by a
+    failure that flags no restart (bad argument) must report an empty list (it used to keep the earlier one, and the batched
+    driver would have failed the wrong restarts)."""
+    from remixt_amd import synthetic
+    from remixt_amd.restarts import RestartSet
+    e = synthetic.make_experiment(200, num_clones=3, max_copy_number=4, num_chains=3, seed=5)
+    rs = RestartSet(e, synthetic.make_init_params(e, 3, 4), 4, num_clones=3, quiet=True, seeds=[1, 2, 3])
+    b = rs.batch
+    b.variational_update(1)
+    smp = np.zeros(b.num_segments, dtype=np.int64); smp[::3] = 1
+    for r in range(3):
+        b._use_sample(r, smp)
+    hs = np.array([np.asarray(m.model.h, dtype=float) for m in rs.models])
+    hs[1] *= -1.                                              # total_depth <= 0 for restart 1 only
+    with pytest.raises(ValueError) as flagged:
+        b.expected_log_likelihood_h_batch([0, 1, 2], hs)
+    assert flagged.value.restarts == [1]
+    for r, m in enumerate(rs.models):
+        m.model.h = np.abs(hs[r])
+    with pytest.raises(ValueError) as plain:
+        b.set_option('fb_nv', 16)                             # no such workgroup shape any more: RMX_EARG, flags nothing
+    assert getattr(plain.value, 'restarts', []) == [] and hip.last_error_restarts() == []
+
+
+def test_a_restart_whose_h_step_failed_is_not_retried_in_later_iterations(hip, monkeypatch):
+    """a restart flagged during the lock-step h M-step stays out of later h M-steps (its message is never
+    cleared, it can never be selected), so the next EM iteration runs the lock-step rounds exactly once."""
+    from remixt_amd import synthetic, lockstep
+    from remixt_amd.restarts import RestartSet
+    e = synthetic.make_experiment(300, num_clones=3, max_copy_number=4, num_chains=3, seed=23)
+    ps = synthetic.make_init_params(e, 3, 4)
+    rs = RestartSet(e, ps, 4, num_clones=3, quiet=True, seeds=[5, 6, 7])
+    for m, v in zip(rs.models, rs.calculate_elbo()):
+        m.prev_elbo = float(v)
+    make = rs.batch.h_batch_evaluator
+    poison = {'on': True, 'n': 0}
+
+    def factory(restarts):
+        restarts = list(restarts)
+        evaluate = make(restarts)
+
+        def wrapped(ids, xs):
+            xs = [np.array(x, dtype=float) for x in xs]
+            poison['n'] += 1
+            listed = [restarts[i] for i in ids]
+            if poison['on'] and poison['n'] == 2 and 1 in listed:
+                xs[listed.index(1)] *= -1.
+            return evaluate(ids, xs)
+        return wrapped
+    monkeypatch.setattr(rs.batch, 'h_batch_evaluator', factory)
+    rs.em_iteration(0, 2)
+    assert list(rs.error_messages) == [1]
+    poison['on'] = False
+    runs = []
+    real = lockstep.run_lockstep
+    monkeypatch.setattr(lockstep, 'run_lockstep', lambda gens, ev: (runs.append(len(gens)), real(gens, ev))[1])
+    h1 = np.array(rs.models[1].h, dtype=float)
+    rs.em_iteration(1, 2)
+    assert runs == [2]                                        # one lock-step run, without restart 1
+    assert np.array_equal(np.array(rs.models[1].h, dtype=float), h1) and list(rs.error_messages) == [1]
+
+
+@pytest.mark.parametrize('seed,N,max_cn,nc', [(71, 400, 4, True), (72, 500, 3, True), (73, 300, 4, True), (34, 48, 2, False), (33, 48, 2, False)])
+def test_joint_accept_decides_like_the_sequential_accept_tests(hip, seed, N, max_cn, nc):
+    """the accept tests of the four standard parameters from ONE pass over the cells (component sums, the default)
+    against the reference's four sequential full-data tests (RestartSet(joint_accept=False)) on several seeds and shapes,
+    rejections included (the second EM iteration starts near the optimum, where trial values are often rejected; without
+    normal contamination six more parameters follow sequentially): same decisions, hence bit-identical h, parameters, ELBO."""
+    from remixt_amd import synthetic
+    from remixt_amd.restarts import RestartSet
+    # (without normal contamination the weighted samples of the hdel / LOH parameters need min(200, N / 10) segments with
+    # posterior mass on such states -- numpy's "Fewer non-zero entries in p than size" otherwise, in the reference too: short genomes)
+    e = synthetic.make_experiment(N, num_clones=3, max_copy_number=max_cn, num_chains=(3 if nc else 2), seed=seed)
+    ps = synthetic.make_init_params(e, 4, max_cn)
+    out = []
+    rejected = []
+    for joint in (True, False):
+        rs = RestartSet(e, ps, max_cn, num_clones=3, quiet=False, seeds=[seed + i for i in range(4)], joint_accept=joint, normal_contamination=nc)
+        logs = []
+        for m in rs.models:
+            m._log = lambda msg, logs=logs: logs.append(msg)
+        rs.fit(num_em_iter=3, num_update_iter=2)
+        out.append([(m.prev_elbo, np.array(m.h), sorted(m.get_likelihood_param_values().items())) for m in rs.models])
+        rejected.append(sorted(l.split(' rejected')[0] for l in logs if 'rejected' in l))
+    assert rejected[0] == rejected[1]
+    for a, b_ in zip(*out):
+        assert a[0] == b_[0] and np.array_equal(a[1], b_[1]) and a[2] == b_[2]

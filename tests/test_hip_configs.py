@@ -1,0 +1,158 @@
+"""GPU: BASELINE.json configs[2] / [3] / [4] AT THEIR WORKLOAD (50 000 segments x 165 states), through size-independent
+properties (no -m gpu test ran 64 restarts, two datasets, or an EM iteration with M-steps at this size).
+
+The oracle needs 33 GB and ~15 minutes per restart and sweep here, so what is asserted is what the domain guarantees at any
+size: an EM iteration (coordinate-ascent sweeps + M-steps whose accept tests compare full-data E[ll], cn_model.py:497-505,
+563-569) never lowers a restart's ELBO; restarts are independent (reference: one process per init_id, workflow.py:329-340), so
+a restart's trajectory is BIT-IDENTICAL whatever batch, restart group, dataset group or GPU share it runs in; posterior rows
+are distributions; the batched decode equals the plain lattice.  Equality with the oracle at these state grids is the
+business of tests/test_hip_bench_shapes.py (small N)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+SEG, MAX_CN, M = 50000, 8, 3
+
+
+@pytest.fixture(scope='module')
+def hip():
+    from remixt_amd import bpmodel
+    return bpmodel
+
+
+@pytest.fixture(scope='module')
+def workload(hip):
+    from remixt_amd import synthetic
+    e = synthetic.make_experiment(SEG, num_clones=M, max_copy_number=MAX_CN, num_chains=23, seed=0)
+    e2 = synthetic.resample_counts(e, seed=101)           # configs[4]: second tumour sample, same segmentation and breakpoints
+    params64 = synthetic.make_init_params(e, 64, MAX_CN, num_clones=M)
+    return e, e2, params64
+
+
+def _seeds(ids, base=1000):
+    return [base + i for i in ids]
+
+
+def _state(rs):
+    """What a restart's EM trajectory leaves behind: (ELBO, h, likelihood parameters) per restart."""
+    out = []
+    for m in rs.models:
+        pv = m.get_likelihood_param_values()
+        out.append((float(m.prev_elbo), np.array(m.h, dtype=float), np.array([pv[k] for k in sorted(pv)])))
+    return out
+
+
+def _run(rs, iters=1):
+    e0 = np.asarray(rs.calculate_elbo(), dtype=float)
+    for m, v in zip(rs.models, e0):
+        m.prev_elbo = float(v)
+    elbo = e0
+    for i in range(iters):
+        new = np.asarray(rs.run(1, i, 5), dtype=float)
+        assert np.all(np.isfinite(new))
+        assert np.all(new >= elbo - 1e-9 * np.abs(elbo)), ('an EM iteration lowered an ELBO', i, elbo, new)
+        elbo = new
+    rs.synchronize()
+    return e0, elbo
+
+
+def _same(a, b):
+    return a[0] == b[0] and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
+
+
+def _release(rs):
+    import gc
+    for s_ in rs.sets:
+        s_.batch = None
+        for m in s_.models:
+            m.model = None
+    gc.collect()
+
+
+def test_config2_bench_shape_em_iterations_with_msteps(workload):
+    """The benchmark's own shape: 16 restarts as 2 restart groups of 8, EM iterations WITH M-steps (5 sweeps, lock-step h
+    M-step, shared-round parameter searches, joint accept, ELBO): ELBO never decreases, and every restart's trajectory equals
+    the one-group run (forward-backward launches of 16) bit for bit."""
+    from remixt_amd.restarts import RestartGroups
+    e, _, p64 = workload
+    ids = list(range(16))
+    out = {}
+    for groups in (2, 1):
+        rs = RestartGroups(e, [p64[i] for i in ids], MAX_CN, groups=groups, num_clones=M, quiet=True, seeds=_seeds(ids))
+        b = rs.batches[0]
+        assert b.num_cn_states == 165 and b.num_segments >= SEG
+        e0, e2 = _run(rs, iters=2)
+        assert b.info(12) == 1 and b.info(13) == 4          # k_fbm, four restarts per workgroup
+        out[groups] = _state(rs)
+        _release(rs)
+    for r in ids:
+        assert _same(out[2][r], out[1][r]), ('restart %d: 2 groups vs 1 group' % r, out[2][r], out[1][r])
+
+
+def test_config3_per_gpu_share_and_the_whole_job_on_one_gpu(workload):
+    """configs[3]: 64 restarts sharded over 8 GPUs, restart i on rank i mod 8.  Rank 0's share (8 restarts, 2 groups of 4) and
+    the WHOLE 64-restart job on this one GPU (4 groups of 16: the `bench.py --total-restarts 64` shape): ELBO monotone for all
+    64; the share's restarts come out bit-identical inside the whole; posteriors are distributions; the batched decode of a
+    group equals the plain lattice."""
+    from remixt_amd.restarts import RestartGroups, shard_indices
+    e, _, p64 = workload
+    share = shard_indices(64, 8, 0)
+    assert share == list(range(0, 64, 8))
+    rs = RestartGroups(e, [p64[i] for i in share], MAX_CN, groups=2, num_clones=M, quiet=True, seeds=_seeds(share))
+    _run(rs, iters=1)
+    part = dict(zip(share, _state(rs)))
+    _release(rs)
+
+    ids = list(range(64))
+    rs = RestartGroups(e, p64, MAX_CN, groups=4, num_clones=M, quiet=True, seeds=_seeds(ids))
+    assert len(rs.batches) == 4 and all(b.num_restarts == 16 for b in rs.batches)
+    _run(rs, iters=1)
+    whole = _state(rs)
+    for i in share:
+        assert _same(part[i], whole[i]), ('restart %d: alone on a rank vs inside the 64-restart job' % i, part[i], whole[i])
+    b = rs.batches[3]
+    for r in (0, 15):
+        post = b.get_array(r, 'posterior_marginals')
+        assert post.min() >= 0. and np.allclose(post.sum(axis=1), 1., rtol=0, atol=1e-12)
+        pb = b.get_array(r, 'p_breakpoint')
+        assert pb.min() >= 0. and np.allclose(pb.sum(axis=1), 1., rtol=0, atol=1e-12)
+    cn_all, lp_all = b.infer_cn_batch(0, 16)
+    assert b.info(14) == 1                                   # k_viterbi_reg
+    b.set_option('viterbi_plain', 1)
+    for r in (0, 7, 15):
+        cn, lp = b.infer_cn(r)
+        assert np.array_equal(cn, cn_all[r]) and lp == lp_all[r]
+    b.set_option('viterbi_plain', 0)
+    _release(rs)
+
+
+def test_config4_two_datasets_at_the_workload(workload):
+    """configs[4]: two tumour samples on one segmentation and breakpoint set, fitted independently (workflow.py:472-485): a
+    GPU's share of the 64-restart job (8 units = 4 restarts per dataset) and 8 restarts per dataset, through DatasetGroups at
+    50 000 x 165.  ELBO monotone; dataset 1's restarts equal their single-dataset fit bit for bit; the two datasets differ."""
+    from remixt_amd import synthetic
+    from remixt_amd.restarts import DatasetGroups, RestartGroups
+    e, e2, p64 = workload
+    p2 = synthetic.make_init_params(e2, 64, MAX_CN, num_clones=M)
+    for per_ds in (4, 8):
+        ids = list(range(per_ds))
+        dg = DatasetGroups([e, e2], [[p64[i] for i in ids], [p2[i] for i in ids]], MAX_CN, groups=2, num_clones=M, quiet=True,
+                           seeds=[_seeds(ids), _seeds(ids, 8919)])
+        assert len(dg.batches) == 4
+        _run(dg, iters=1)
+        both = _state(dg)
+        res = dg.results_by_dataset() if per_ds == 4 else None
+        _release(dg)
+        alone = RestartGroups(e2, [p2[i] for i in ids], MAX_CN, groups=2, num_clones=M, quiet=True, seeds=_seeds(ids, 8919))
+        _run(alone, iters=1)
+        single = _state(alone)
+        for r in ids:
+            assert _same(both[per_ds + r], single[r]), ('dataset 1 restart %d: next to dataset 0 vs alone' % r)
+            assert both[r][0] != both[per_ds + r][0]                       # different read counts, different fits
+        if res is not None:
+            sres = alone.results()
+            for r in ids:
+                assert np.array_equal(res[1][r]['cn'], sres[r]['cn'])
+                assert all(np.array_equal(res[1][r]['brk_cn'][k], sres[r]['brk_cn'][k]) for k in sres[r]['brk_cn'])
+        _release(alone)

@@ -28,14 +28,17 @@ def test_hip_replays_reference_tight(hip, name):
 
 @pytest.mark.parametrize('name', GR.GRID_CASES)
 def test_hip_replays_reference_at_bench_grids_and_dark_corners(hip, name):
-    """The reference's own numbers at 165 states (k_fbv), 355 states (k_fbk / k_viterbi_code), transition_model = 1,
+    """The reference's own numbers at 165 states (k_fbm: FP64 matrix cores, 4 restarts per workgroup -- one present here), 355 states
+    (k_fbk / k_viterbi_code; test_kernel_selection_at_the_benchmark_grids asserts the selection through rmx_info), transition_model = 1,
     four clones and disable_breakpoints, 8-9 breakpoints with two breakends at one boundary."""
     GR.replay_grid(name, hip, rtol=1e-6, atol=1e-9, mixed_elbo=True)
     GR.replay_grid(name, hip, rtol=1e-9, atol=1e-11, mixed_elbo=True)
 
 
-@pytest.mark.parametrize('name', ['model_m2', 'model_m3', 'model_malex', 'model_nonormal'])
+@pytest.mark.parametrize('name', GR.FIT_CASES)
 def test_hip_full_fit_trajectory(hip, name):
+    """Seeded EM trajectories recorded from the reference, the ten-parameter no-normal-contamination M-step included.  ELBO 1e-6;
+    h 1e-4 and parameters 1e-3: two EM iterations of scipy optimisers amplify the kernels' last-bit differences."""
     GR.replay_fit(name, hip, rtol_elbo=1e-6, rtol_h=1e-4, rtol_param=1e-3)
 
 

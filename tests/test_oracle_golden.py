@@ -19,9 +19,16 @@ def test_oracle_replays_reference_at_bench_grids_and_dark_corners(oracle_mod, na
     GR.replay_grid(name, oracle_mod, rtol=1e-11, atol=1e-13, mixed_elbo=True)
 
 
-@pytest.mark.parametrize('name', ['model_m2', 'model_malex'])
+@pytest.mark.parametrize('name', GR.FIT_CASES)
 def test_oracle_full_fit_trajectory(oracle_mod, name):
+    """Seeded EM trajectories of the reference (scipy M-steps; the two no-normal-contamination cases run the ten-parameter
+    M-step of cn_model.py:198-226).  Tolerances: an optimiser trajectory amplifies last-bit differences of the objective."""
     GR.replay_fit(name, oracle_mod, rtol_elbo=1e-9, rtol_h=1e-7, rtol_param=1e-6)
+
+
+def test_no_fixture_records_a_failed_reference_fit():
+    for name in GR.MODEL_CASES:
+        assert int(GR.load(name)['fit/failed']) == 0, name
 
 
 def test_oracle_chain_kats(oracle_mod):

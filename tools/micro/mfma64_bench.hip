@@ -1,7 +1,20 @@
 // Microbenchmark + operand-layout probe of the FP64 MFMA instructions of gfx950 (design input for the forward-backward kernel).
-//   hipcc --offload-arch=gfx950 -O3 -o mfma64_bench mfma64_bench.hip && ./mfma64_bench
+//   hipcc --offload-arch=gfx950 -O3 -o mfma64_bench mfma64_bench.hip && ./mfma64_bench [layout] [throughput]
+//   (no argument = both phases; profiles/r03_mfma64_probe.txt is the output the lane maps of DESIGN.md 4.4 were read from)
+//
+// History of a GPU memory-access fault (round 2, gpurun_out/mfma64.txt, 09:05): the first version of this probe allocated
+// `dout` for the layout phase and the one-CU throughput launches only; the last launch of the throughput phase (grid 1024 x
+// 768 threads, every thread storing out[blockIdx.x * blockDim.x + threadIdx.x]) wrote 786 432 doubles = 6.3 MB past it.
+// The log seems to stop inside the layout phase because stdout was a pipe (block-buffered, cut at a 4 096-byte boundary): the
+// fault is the out-of-bounds store of that last launch, not the lane-map kernels (which write 64 / 256 doubles).  The rerun one
+// minute later (mfma64b.txt, clean) had the larger allocation -- and the layout phase switched off by a constant, which is why
+// the lane maps could not be regenerated from the committed file.  Now: every launch goes through launch_checked(), which
+// refuses a launch whose grid x block exceeds the allocation; HIP return codes are checked; stdout is line-buffered; the
+// phases are argv switches.
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cstdlib>
+#include <cstring>
 #include <vector>
 typedef double d4 __attribute__((ext_vector_type(4)));
 
@@ -74,13 +87,20 @@ template <int NACC> __global__ void benchv(double *out, int iters, unsigned long
     if (threadIdx.x == 0 && blockIdx.x == 0) cyc[0] = t1 - t0;
 }
 
+#define CK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #call, hipGetErrorString(e_)); exit(1); } } while (0)
+static size_t g_out_doubles = 0;      // capacity of dout: no launch may have more threads than this
+static void check_fits(int grid, int block, int per_thread = 1) {
+    if ((size_t)grid * block * per_thread > g_out_doubles) { fprintf(stderr, "launch %d x %d x %d exceeds the %zu-double output buffer\n", grid, block, per_thread, g_out_doubles); exit(1); }
+}
 template <typename K> double run(K kern, int waves, int nacc, int iters, double *dout, unsigned long long *dcyc, int grid = 1) {
-    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    check_fits(grid, 64 * waves);
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * waves), 0, 0, dout, iters, dcyc);
-    hipDeviceSynchronize();
-    hipEventRecord(e0);
+    CK(hipGetLastError());
+    CK(hipDeviceSynchronize());
+    CK(hipEventRecord(e0));
     hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * waves), 0, 0, dout, iters, dcyc);
-    hipEventRecord(e1); hipEventSynchronize(e1);
+    CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
     float ms; hipEventElapsedTime(&ms, e0, e1);
     unsigned long long c; hipMemcpy(&c, dcyc, 8, hipMemcpyDeviceToHost);
     // s_memtime-style counter runs at 100 MHz: report wall time per instruction per SIMD instead
@@ -88,11 +108,16 @@ template <typename K> double run(K kern, int waves, int nacc, int iters, double 
     return ms * 1e6 / per_simd;   // ns per instruction on one SIMD
 }
 
-int main() {
+int main(int argc, char **argv) {
+    setvbuf(stdout, nullptr, _IOLBF, 0);
+    bool layout = argc < 2, throughput = argc < 2;
+    for (int i = 1; i < argc; i++) { layout |= !strcmp(argv[i], "layout"); throughput |= !strcmp(argv[i], "throughput"); }
     double *dout; unsigned long long *dcyc;
-    hipMalloc(&dout, (size_t)1024 * 768 * 8 * 2); hipMalloc(&dcyc, 64);   // largest launch: 1024 blocks x 768 threads, one double each
-    const bool layout = false;
+    const int kMaxGrid = 1024, kMaxBlock = 768;                            // the largest launch below: one double per thread
+    g_out_doubles = (size_t)kMaxGrid * kMaxBlock;
+    CK(hipMalloc(&dout, g_out_doubles * sizeof(double))); CK(hipMalloc(&dcyc, 64));
     if (layout) {
+    check_fits(1, 64, 4);
     std::vector<double> h(256);
     int amap[64][64];
     printf("== v_mfma_f64_4x4x4f64: for each (A lane, B lane) pair that multiplies: D lane ==\n");
@@ -119,6 +144,7 @@ int main() {
         printf("\n");
     }
     }
+    if (!throughput) return 0;
     // ---------------- throughput (one CU: grid 1) ----------------
     const int iters = 20000;
     printf("== ns per instruction on one SIMD (2.4 GHz: 1 ns = 2.4 cycles) ==\n");
@@ -130,6 +156,6 @@ int main() {
     }
     printf("== all CUs busy (grid 1024, 12 waves per block) ==\n");
     printf("4x4x4 nacc4 %.2f | 16x16x4 nacc2 %.2f | v_fmac nacc8 %.2f (ns per instruction per SIMD, 4 blocks/CU-round)\n",
-           run(bench4<4>, 12, 4, iters, dout, dcyc, 1024) / 4, run(bench16<2>, 12, 2, iters, dout, dcyc, 1024) / 4, run(benchv<8>, 12, 8, iters, dout, dcyc, 1024) / 4);
+           run(bench4<4>, 12, 4, iters, dout, dcyc, kMaxGrid) / 4, run(bench16<2>, 12, 2, iters, dout, dcyc, kMaxGrid) / 4, run(benchv<8>, 12, 8, iters, dout, dcyc, kMaxGrid) / 4);
     return 0;
 }
