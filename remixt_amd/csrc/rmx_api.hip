@@ -1257,6 +1257,28 @@ static int p_cn_front(rmx_batch *b, int r0, int r1, bool skip_frame, bool snapsh
                 done_fast = true; fast = true; b->last_fb_kernel = 2; b->last_fb_nv = NV;
             }
         }
+        if (!done_fast && b->fbv_rpt == 0 && b->fbk_ok && d.pe2x_lt && b->n_fast > 0 && b->opt[RMX_OPT_FB_KERNEL] == 0 && d.S <= 360 &&
+            (b->opt[RMX_OPT_FB_NV] == 0 || b->opt[RMX_OPT_FB_NV] == 4)) {
+            // state grid too large for register-resident weights, matrix cores: 8-bit distances in registers, B operands
+            // looked up in a 64-entry LDS table (k_fbq); fb_nv = 1 / 2 selects the vector kernel k_fbk below instead
+            const int KB = d.S <= 256 ? 64 : 90;
+            const int NWq = (d.S + 29) / 30;
+            FbmArgs m;
+            memset(&m, 0, sizeof m);
+            m.S = d.S; m.SP = d.SP; m.M = d.M; m.D = d.D; m.C = d.C; m.N = d.N; m.NBE = d.NBE; m.cn_max = d.cn_max; m.r0 = r0; m.r1 = r1;
+            m.PE2P = b->pe2p; m.SPC = 0; m.VR = std::max(4 * KB, ((NWq * 30 + 7) / 8) * 8); m.pen = d.pen;
+            m.chain_start = d.chain_start; m.chain_end = d.chain_end; m.chain_list = d.chain_list_fast; m.chain_tc = d.chain_tc; m.chain_cls = d.chain_cls;
+            m.be_n = d.be_n; m.chain_be = d.chain_be; m.fe = d.fe; m.Wf = d.Wf; m.Wb = d.Wb; m.pe2_lt = d.pe2x_lt; m.af = d.af; m.ab = d.ab; m.tot = d.tot;
+            m.fa = d.fa; m.fb = d.fb; m.mrow = d.mrow; m.err = d.err; m.dbg = b->d_dbg;
+            const size_t lds = (size_t)2 * m.VR * 4 * 8 + (size_t)2 * 4 * m.PE2P * 8 + 64 * 8 + (size_t)4 * KB * 4 + (size_t)b->be_cap * 4 + 64;
+            void (*kf)(FbmArgs, const double *, const uint32_t *, const uint32_t *) = KB == 64 ? k_fbq<64> : k_fbq<90>;
+            if (NWq <= 12 && 4 * KB >= d.S && lds <= kLdsBudget) {
+                HIPCHK(hipFuncSetAttribute((const void *)kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                hipLaunchKernelGGL(kf, dim3(b->n_fast, ((r1 - 1) >> 2) - (r0 >> 2) + 1, 2), dim3(64 * NWq), lds, b->stream, m,
+                                   (const double *)b->d_wk, (const uint32_t *)b->d_cnpack, (const uint32_t *)b->d_totpack);
+                done_fast = true; fast = true; b->last_fb_kernel = 4; b->last_fb_nv = 4;
+            }
+        }
         if (!done_fast && b->fbv_rpt == 0 && b->fbk_ok && d.pe2_lt && b->n_fast > 0 && b->opt[RMX_OPT_FB_KERNEL] == 0) {
             // state grid too large for register-resident weights: weights from packed copy numbers on the fly
             const int nr = r1 - r0;

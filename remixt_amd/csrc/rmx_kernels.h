@@ -1063,6 +1063,282 @@ __global__ __launch_bounds__(768) void k_fbm(FbmArgs a) {
 }
 
 // =============================================================================
+// k_fbq: the matrix-core forward-backward kernel for state grids whose S x S weights do not fit the register file
+// (176 < S <= 360: 355 states at the reference's default max_copy_number = 12, the "~400 states" of BASELINE's metric).
+//
+// Same step as k_fbm -- four restarts of one (chain, direction) per workgroup, out[i][o] = sum_q a_i[q] W[q][o] on
+// v_mfma_f64_4x4x4f64, column-owner waves, the ones column for the row scale, one barrier per step -- but the B operands are
+// not resident: a plain-adjacency weight is exp(-pen k) with k = min(SAD(cn_q, cn_o), SAD(cn_q, swap_alleles(cn_o))) < 64
+// (k_fbk's closed form, verified by the host against the tabulated log-weights: fbk_ok), so what a wave keeps in registers is
+// the 8-BIT k of its column tiles for the whole reduction index (KB bytes per lane and tile instead of KB doubles), and every
+// B operand is one conflict-poor ds_read_b64 from a 64-entry table of exp(-pen k) in LDS.  Per MFMA the LDS moves 512 B for the
+// B operand and 256 B for the A operand (one ds_read_b128 feeds two k-blocks of BOTH tiles of the wave): 3 of the 4 LDS cycles
+// a CU has per MFMA at the matrix pipe's full rate (MI355X_MICROARCH.md, LDS: 256 B per clock for ds_read_b64 / b128).
+//   * wave w owns TWO tiles of 15 state columns + a ones column: columns 30 w .. 30 w + 29 (12 waves at 355 states);
+//   * all LDS reads of the plain steps go through untracked asm into a ring, FBQ_DEPTH pairs of k-blocks ahead of the
+//     MFMAs that consume them (5 reads per pair: the A pair and four table lookups), retired by counted lgkmcnt waits;
+//   * breakend steps (2 % of the steps): W_i[q][o] = exp(-pen (k - SAD(tot_q, tot_o))) * tab_i[idx(tot_q - tot_o)] from the
+//     packed totals (LDS for the rows, registers for the columns) and the quad's interleaved clone-product table (LDS-DMA a
+//     run of plain steps ahead, as k_fbm); four MFMAs per k-block and tile, one per restart's B operand.
+// Summation order is fixed: repeated runs are bit-identical.
+// grid (chains of one state-table class, ceil(restarts / 4), 2 directions), block 64 ceil(S / 30).
+// =============================================================================
+#define FBQ_DEPTH 3
+#define FBQ_RING (FBQ_DEPTH + 1)
+struct fbq_slot { fbm_d2 a; double b[4]; };      // A operands of a pair of k-blocks; B operands [k-block of the pair][tile]
+__device__ __forceinline__ void fbq_rd64(double &dst, unsigned addr) { asm volatile("ds_read_b64 %0, %1" : "=v"(dst) : "v"(addr) : "memory"); }
+template <int CNT> __device__ __forceinline__ void fbq_wait(fbq_slot &x) {
+    asm volatile("s_waitcnt lgkmcnt(%5)" : "+v"(x.a), "+v"(x.b[0]), "+v"(x.b[1]), "+v"(x.b[2]), "+v"(x.b[3]) : "n"(CNT) : "memory");
+}
+// A lane keeps the distance k of (row 4 kb + kq, its column) as the 9-bit field 8 k -- the byte offset of exp(-pen k) in the table at
+// LDS address 0 -- three k-blocks per register: one v_bfe_u32 per B-operand address.
+#define FBQ_ADDR(c_, kb_) (((c_)[(kb_) / 3] >> (9 * ((kb_) % 3))) & 0x1ffu)
+template <int KB> struct fbq_chain {
+    static constexpr int NP = KB / 2, NW32 = (KB + 2) / 3;
+    // requests of pair P: the A pair, then the table entries of k-blocks 2 P, 2 P + 1 for tiles 0 and 1
+    template <int P> static __device__ __forceinline__ void issue(fbq_slot &s, unsigned apc, unsigned wt, const unsigned (&c0)[NW32], const unsigned (&c1)[NW32]) {
+        fbm_rd<P * 256>(s.a, apc);
+        constexpr int k0 = 2 * P, k1 = 2 * P + 1;
+        (void)wt;      // the table sits at LDS address 0 (checked at kernel entry): the field is the address
+        fbq_rd64(s.b[0], FBQ_ADDR(c0, k0));
+        fbq_rd64(s.b[1], FBQ_ADDR(c1, k0));
+        fbq_rd64(s.b[2], FBQ_ADDR(c0, k1));
+        fbq_rd64(s.b[3], FBQ_ADDR(c1, k1));
+    }
+    template <int P> static __device__ __forceinline__ void run(fbq_slot (&ring)[FBQ_RING], unsigned apc, unsigned wt, const unsigned (&c0)[NW32], const unsigned (&c1)[NW32],
+                                                                double (&acc)[4]) {
+        constexpr int younger = (NP - 1 - P) < (FBQ_DEPTH - 1) ? (NP - 1 - P) : (FBQ_DEPTH - 1);
+        fbq_slot &s = ring[P % FBQ_RING];
+        fbq_wait<5 * younger>(s);
+        acc[0] = __builtin_amdgcn_mfma_f64_4x4x4f64(s.a.x, s.b[0], acc[0], 0, 0, 0);      // tile 0, even k-block
+        acc[1] = __builtin_amdgcn_mfma_f64_4x4x4f64(s.a.x, s.b[1], acc[1], 0, 0, 0);      // tile 1, even k-block
+        acc[2] = __builtin_amdgcn_mfma_f64_4x4x4f64(s.a.y, s.b[2], acc[2], 0, 0, 0);      // tile 0, odd k-block
+        acc[3] = __builtin_amdgcn_mfma_f64_4x4x4f64(s.a.y, s.b[3], acc[3], 0, 0, 0);      // tile 1, odd k-block
+        if constexpr (P + FBQ_DEPTH < NP) issue<P + FBQ_DEPTH>(ring[(P + FBQ_DEPTH) % FBQ_RING], apc, wt, c0, c1);
+        if constexpr (P + 1 < NP) run<P + 1>(ring, apc, wt, c0, c1, acc);
+    }
+    template <int I> static __device__ __forceinline__ void fill(fbq_slot (&ring)[FBQ_RING], unsigned apc, unsigned wt, const unsigned (&c0)[NW32], const unsigned (&c1)[NW32]) {
+        issue<I>(ring[I], apc, wt, c0, c1);
+        if constexpr (I + 1 < FBQ_DEPTH && I + 1 < NP) fill<I + 1>(ring, apc, wt, c0, c1);
+    }
+};
+
+template <int KB>
+__global__ __launch_bounds__(768) void k_fbq(FbmArgs a, const double *wk, const uint32_t *cnpack, const uint32_t *totpack) {
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    static_assert(KB % 2 == 0 && KB / 2 >= FBQ_DEPTH, "k-blocks come in pairs; ring no deeper than the chain");
+    constexpr int NW32 = (KB + 2) / 3;
+    const int chain = a.chain_list[blockIdx.x], dir = blockIdx.z;
+    const int quad = (a.r0 >> 2) + blockIdx.y, rg0 = quad * FBM_NV;
+    const int v_lo = max(a.r0 - rg0, 0), v_hi = min(a.r1 - rg0, FBM_NV);
+    const int S = a.S, SP = a.SP, M = a.M, D = a.D, VR = a.VR;
+    const int n0 = a.chain_start[chain], n1 = a.chain_end[chain], len = n1 - n0 + 1;
+    const int t = threadIdx.x, NT = blockDim.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6), NW = NT >> 6;
+    const int kq = lane >> 4, c16 = lane & 15, ib = lane & 3, id = lane >> 4;
+    const bool is_sum = c16 == 15;
+    const int col0 = (2 * wave) * 15 + c16, col1 = (2 * wave + 1) * 15 + c16;      // this lane's state column in tile 0 / tile 1
+    const int cls = a.chain_cls[chain];
+    // ---- LDS carve-up ---------------------------------------------------------------------------
+    double *wtab = (double *)smem_raw;                          // [64]         exp(-pen k), at LDS offset 0 of the dynamic segment: a lookup's address is 8 k + base
+    double *vec = wtab + 64;                                    // [2][VR][4]   vectors, restart-interleaved, double-buffered by step parity
+    double *tab = vec + (size_t)2 * VR * 4;                     // [2][PE2P][4] clone-product weights of the current and the next breakend (LDS-DMA)
+    uint32_t *tpl = (uint32_t *)(tab + (size_t)2 * 4 * a.PE2P); // [4 KB]       packed totals of the row states (0 past S)
+    int *bel = (int *)(tpl + 4 * KB);                           // adjacencies of this chain's breakends
+    const int be_lo = a.chain_be[2 * chain], be_hi = a.chain_be[2 * chain + 1];
+    for (int i = t; i < be_hi - be_lo; i += NT) bel[i] = a.be_n[be_lo + i];
+    for (int i = t; i < 4 * KB; i += NT) tpl[i] = i < S ? totpack[(size_t)cls * S + i] : 0u;
+    for (int i = t; i < 2 * VR * 4; i += NT) vec[i] = 0.;
+    for (int i = t; i < 64; i += NT) wtab[i] = wk[(size_t)a.chain_tc[chain] * 64 + i];
+    // ---- this lane's 8-bit distances: rows 4 kb + kq against its two columns, every k-block ---------------------
+    // (rows past S multiply vector elements that are always 0, columns past S are never published: their codes only have to
+    // be valid table indices; the ones columns' code is 0: weight exp(0) = 1)
+    auto swap_alleles = [](uint32_t x) { return ((x & 0x00ff00ffu) << 8) | ((x >> 8) & 0x00ff00ffu); };
+    const uint32_t co0 = (!is_sum && col0 < S) ? cnpack[(size_t)cls * S + col0] : 0u, co1 = (!is_sum && col1 < S) ? cnpack[(size_t)cls * S + col1] : 0u;
+    const uint32_t co0s = swap_alleles(co0), co1s = swap_alleles(co1);
+    const uint32_t to0 = (!is_sum && col0 < S) ? totpack[(size_t)cls * S + col0] : 0u, to1 = (!is_sum && col1 < S) ? totpack[(size_t)cls * S + col1] : 0u;
+    unsigned c0[NW32], c1[NW32];
+#pragma unroll
+    for (int i = 0; i < NW32; i++) { c0[i] = 0u; c1[i] = 0u; }
+#pragma unroll
+    for (int kb = 0; kb < KB; kb++) {
+        const int q = 4 * kb + kq;
+        const uint32_t cq = q < S ? cnpack[(size_t)cls * S + q] : 0u;
+        unsigned k0 = min(__builtin_amdgcn_sad_u8(cq, co0, 0u), __builtin_amdgcn_sad_u8(cq, co0s, 0u));
+        unsigned k1 = min(__builtin_amdgcn_sad_u8(cq, co1, 0u), __builtin_amdgcn_sad_u8(cq, co1s, 0u));
+        if (is_sum || q >= S || col0 >= S) k0 = 0u;
+        if (is_sum || q >= S || col1 >= S) k1 = 0u;
+        c0[kb / 3] |= ((k0 & 63u) << 3) << (9 * (kb % 3));
+        c1[kb / 3] |= ((k1 & 63u) << 3) << (9 * (kb % 3));
+    }
+#pragma unroll
+    for (int i = 0; i < NW32; i++) asm volatile("" : "+v"(c0[i]), "+v"(c1[i]));      // their loads retire here, not inside the step loop
+    __syncthreads();
+
+#define ROW(k) (dir == 0 ? n0 + (k) : n1 - (k))
+    const int be_step = dir == 0 ? 1 : -1;
+    int be_i = dir == 0 ? be_lo : be_hi - 1;
+    int be_adj = (be_i >= be_lo && be_i < be_hi) ? __builtin_amdgcn_readfirstlane(bel[be_i - be_lo]) : -2;
+    const int rstep = dir == 0 ? SP : -SP;
+    const bool present = id >= v_lo && id < v_hi;
+    const bool mine0 = !is_sum && col0 < VR, mine1 = !is_sum && col1 < VR;
+    const bool live0 = !is_sum && col0 < S && present, live1 = !is_sum && col1 < S && present;
+    const size_t row_off = ((size_t)(rg0 + (present ? id : v_lo)) * a.N + ROW(0)) * SP;
+    const size_t off0 = row_off + (col0 < S ? col0 : S - 1), off1 = row_off + (col1 < S ? col1 : S - 1);
+    double *outp0 = (dir == 0 ? a.fa : a.fb) + off0, *outp1 = (dir == 0 ? a.fa : a.fb) + off1;
+    const double *eptr0 = a.fe + off0, *eptr1 = a.fe + off1;
+    double *vput0 = vec + fbm_pos(mine0 ? col0 : 0, id), *vput1 = vec + fbm_pos(mine1 ? col1 : 0, id);
+    const unsigned ap0 = lds_addr(vec + (kq * 4 + ib) * 2);
+    const unsigned wt = lds_addr(wtab);
+    if (wt != 0u) {      // (uniform) the lookups address the table from LDS address 0: this kernel must not have static LDS in front of it
+        if (t == 0) atomicOr(&a.err[rg0 + v_lo], RMX_ERR_NAN_AB);
+        return;
+    }
+    const bool scribe = dir == 0 && wave == 0 && is_sum && present;
+    double *mptr = a.mrow + (size_t)(rg0 + (present ? id : v_lo)) * a.N + ROW(0);
+    if (wave < 4) __builtin_amdgcn_s_setprio(2); else if (wave < 8) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
+    const int NCH = (a.PE2P * 32 + 1023) >> 10;
+#define FBQ_FETCH(slot_, buf_)                                                                                                     \
+    for (int c_ = wave; c_ < NCH; c_ += NW) {                                                                                      \
+        const int e16_ = c_ * 64 + lane;                                                                                           \
+        const unsigned dst_ = __builtin_amdgcn_readfirstlane(lds_addr(tab + (size_t)(buf_) * 4 * a.PE2P) + (unsigned)(c_ * 1024)); \
+        if (e16_ * 2 < a.PE2P * 4) glds16(a.pe2_lt + ((size_t)quad * a.NBE + (slot_)) * a.PE2P * 4 + e16_ * 2, dst_);             \
+    }
+    int be_buf = 0;
+    if (be_adj >= 0) FBQ_FETCH(be_i, 0)
+    // ---- step 0 ------------------------------------------------------------------------------------------------
+    {
+        double e0 = 0., e1 = 0.;
+        if (live0) { e0 = *eptr0; gstore8(outp0, (dir == 0) ? e0 : 1.0); }
+        if (live1) { e1 = *eptr1; gstore8(outp1, (dir == 0) ? e1 : 1.0); }
+        if (mine0) *vput0 = live0 ? e0 : 0.;
+        if (mine1) *vput1 = live1 ? e1 : 0.;
+    }
+    eptr0 += rstep; eptr1 += rstep;
+    FB_BARRIER();
+    if (a.dbg && t == 0 && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0) { a.dbg[0] = clock64(); a.dbg[1] = wall_clock64(); a.dbg[4] = len; }
+    // tail of a step (k_fbm's FBM_FINISH for two tiles): tile 0's ones column holds the sum of the previous row
+#define FBQ_FINISH(s0_, s1_, e0_, e1_, k_)                                                                                         \
+    {                                                                                                                              \
+        const unsigned hs_ = (unsigned)__builtin_amdgcn_update_dpp(0, __double2hiint(s0_), 0x15F, 0xf, 0xf, false);   /* row_newbcast:15 */ \
+        double m_, inv_;                                                                                                           \
+        pow2_scale(hs_, m_, inv_);                                                                                                 \
+        outp0 += rstep; outp1 += rstep;                                                                                            \
+        gwait8(e0_); gwait8(e1_);                                                                                                  \
+        const double val0_ = (s0_) * inv_, val1_ = (s1_) * inv_;                                                                   \
+        const double vv0_ = val0_ * (e0_), vv1_ = val1_ * (e1_);                                                                   \
+        if (live0) gstore8(outp0, (dir == 0) ? vv0_ : val0_);                                                                      \
+        if (live1) gstore8(outp1, (dir == 0) ? vv1_ : val1_);                                                                      \
+        if (mine0) vput0[(size_t)((k_) & 1) * VR * 4] = live0 ? vv0_ : 0.;                                                         \
+        if (mine1) vput1[(size_t)((k_) & 1) * VR * 4] = live1 ? vv1_ : 0.;                                                         \
+        if (scribe) gstore8(mptr, m_);                                                                                             \
+        mptr += dir == 0 ? 1 : -1;                                                                                                 \
+        FB_BARRIER();                                                                                                              \
+    }
+    const int sgn = dir == 0 ? 1 : -1, toff = a.cn_max + 1;
+    const unsigned ones_idx = (unsigned)(M == 2 ? D : D * D);      // table entry n2 holds 1 (k_brk_lut)
+    int k = 1;
+    while (k < len) {
+        const int k_be = be_adj >= 0 ? (dir == 0 ? be_adj - n0 + 1 : n1 - be_adj) : len;
+        const int k_stop = k_be < len ? k_be : len;
+        for (; k < k_stop; k++) {
+            double e0, e1;
+            gload8(e0, eptr0); gload8(e1, eptr1);
+            eptr0 += rstep; eptr1 += rstep;
+            // (the lookup addresses derive from loop-invariant registers: without this the compiler hoists all 4 KB of them out of
+            // the step loop and spills them)
+#pragma unroll
+            for (int i = 0; i < NW32; i++) asm volatile("" : "+v"(c0[i]), "+v"(c1[i]));
+            double acc[4] = {0., 0., 0., 0.};
+            fbq_slot ring[FBQ_RING];
+            const unsigned apc = ap0 + (unsigned)((k - 1) & 1) * (unsigned)(VR * 32);
+            fbq_chain<KB>::template fill<0>(ring, apc, wt, c0, c1);
+            fbq_chain<KB>::template run<0>(ring, apc, wt, c0, c1, acc);
+            const double s0 = acc[0] + acc[2], s1 = acc[1] + acc[3];
+            FBQ_FINISH(s0, s1, e0, e1, k)
+        }
+        if (k < len) {
+            // ---- breakend step ----------------------------------------------------------------------------------
+            const double *tb = tab + (size_t)be_buf * 4 * a.PE2P;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            FB_BARRIER();
+            be_i += be_step;
+            be_adj = (be_i >= be_lo && be_i < be_hi) ? __builtin_amdgcn_readfirstlane(bel[be_i - be_lo]) : -2;
+            be_buf ^= 1;
+            if (be_adj >= 0) FBQ_FETCH(be_i, be_buf)
+            double e0, e1;
+            gload8(e0, eptr0); gload8(e1, eptr1);
+            eptr0 += rstep; eptr1 += rstep;
+            double acc0[FBM_NV] = {0., 0., 0., 0.}, acc1[FBM_NV] = {0., 0., 0., 0.};
+            const fbm_d2 *apc = reinterpret_cast<const fbm_d2 *>(vec + (size_t)((k - 1) & 1) * VR * 4 + (kq * 4 + ib) * 2);     // pair p: + 16 p
+            const int to0a = (int)(to0 & 0xff), to0b = (int)((to0 >> 8) & 0xff), to1a = (int)(to1 & 0xff), to1b = (int)((to1 >> 8) & 0xff);
+#pragma unroll
+            for (int p = 0; p < KB / 2; p++) {      // fully unrolled: the code registers need compile-time indices
+                const fbm_d2 av = apc[p * 16];
+#pragma unroll
+                for (int h = 0; h < 2; h++) {
+                    const int kb = 2 * p + h;
+                    const uint32_t tq = tpl[4 * kb + kq];
+                    const int tqa = (int)(tq & 0xff), tqb = (int)((tq >> 8) & 0xff);
+                    const double ak = h ? av.y : av.x;
+                    // tile 0
+                    {
+                        const unsigned kk = FBQ_ADDR(c0, kb) >> 3;
+                        unsigned ac = kk - __builtin_amdgcn_sad_u8(tq, to0, 0u);
+                        int ix = sgn * (tqa - to0a) + toff;
+                        if (M == 3) ix = ix * D + sgn * (tqb - to0b) + toff;
+                        if (is_sum) { ac = 0u; ix = (int)ones_idx; }
+                        const double wv = wtab[ac & 63u];
+                        const double2 t01 = *reinterpret_cast<const double2 *>(tb + (size_t)ix * 4);
+                        const double2 t23 = *reinterpret_cast<const double2 *>(tb + (size_t)ix * 4 + 2);
+                        acc0[0] = __builtin_amdgcn_mfma_f64_4x4x4f64(ak, wv * t01.x, acc0[0], 0, 0, 0);
+                        acc0[1] = __builtin_amdgcn_mfma_f64_4x4x4f64(ak, wv * t01.y, acc0[1], 0, 0, 0);
+                        acc0[2] = __builtin_amdgcn_mfma_f64_4x4x4f64(ak, wv * t23.x, acc0[2], 0, 0, 0);
+                        acc0[3] = __builtin_amdgcn_mfma_f64_4x4x4f64(ak, wv * t23.y, acc0[3], 0, 0, 0);
+                    }
+                    // tile 1
+                    {
+                        const unsigned kk = FBQ_ADDR(c1, kb) >> 3;
+                        unsigned ac = kk - __builtin_amdgcn_sad_u8(tq, to1, 0u);
+                        int ix = sgn * (tqa - to1a) + toff;
+                        if (M == 3) ix = ix * D + sgn * (tqb - to1b) + toff;
+                        if (is_sum) { ac = 0u; ix = (int)ones_idx; }
+                        const double wv = wtab[ac & 63u];
+                        const double2 t01 = *reinterpret_cast<const double2 *>(tb + (size_t)ix * 4);
+                        const double2 t23 = *reinterpret_cast<const double2 *>(tb + (size_t)ix * 4 + 2);
+                        acc1[0] = __builtin_amdgcn_mfma_f64_4x4x4f64(ak, wv * t01.x, acc1[0], 0, 0, 0);
+                        acc1[1] = __builtin_amdgcn_mfma_f64_4x4x4f64(ak, wv * t01.y, acc1[1], 0, 0, 0);
+                        acc1[2] = __builtin_amdgcn_mfma_f64_4x4x4f64(ak, wv * t23.x, acc1[2], 0, 0, 0);
+                        acc1[3] = __builtin_amdgcn_mfma_f64_4x4x4f64(ak, wv * t23.y, acc1[3], 0, 0, 0);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);      // a pair of k-blocks at a time (register budget)
+            }
+            const double s0 = id == 0 ? acc0[0] : (id == 1 ? acc0[1] : (id == 2 ? acc0[2] : acc0[3]));
+            const double s1 = id == 0 ? acc1[0] : (id == 1 ? acc1[1] : (id == 2 ? acc1[2] : acc1[3]));
+            FBQ_FINISH(s0, s1, e0, e1, k)
+            k++;
+        }
+    }
+#undef FBQ_FINISH
+#undef FBQ_FETCH
+    if (a.dbg && t == 0 && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0) { a.dbg[2] = clock64(); a.dbg[3] = wall_clock64(); }
+    if (wave == 0) {
+        const double *vb = vec + (size_t)((len - 1) & 1) * VR * 4;
+        double ps = 0.;
+        for (int q = c16; q < S; q += 16) ps += vb[fbm_pos(q, id)];
+        ps = group_sum(ps, 16);
+        if (c16 == 0 && present) {
+            double m_, inv;
+            pow2_scale((unsigned)__double2hiint(ps), m_, inv);
+            if (dir == 0) gstore8(a.mrow + (size_t)(rg0 + id) * a.N + ROW(len - 1), m_);
+            if (!(m_ > 0.) || m_ == INFINITY) atomicOr(&a.err[rg0 + id], RMX_ERR_NAN_AB);
+        }
+    }
+#undef ROW
+}
+
+// =============================================================================
 // k_fbk: forward-backward for state grids whose S x S weight matrix does not fit the register file
 // (S > 176, e.g. 355 states at max_cn = 12).  Same step structure, vector operand broadcast (DPP
 // row_newbcast), scaling, emission loads and breakend walk as k_fbv, but the plain-adjacency weight
