@@ -458,6 +458,11 @@ def main(argv=None, kernel_module=None, dist_backend='nccl', script=None):
                 line['states_355'] = extra_states(args, rs, device)
             except Exception as err:      # never let the extra measurement hide the headline number
                 line['states_355'] = {'error': str(err)}
+        if single and not args.no_extra_states and args.max_cn == 8 and args.restarts == 16:
+            try:
+                line['strong_scaling_proxy'] = strong_scaling_proxy(args, rs, device)
+            except Exception as err:
+                line['strong_scaling_proxy'] = {'error': str(err)}
         if cpu is not None:
             line['cpu_baseline'] = cpu
         print(json.dumps(line), flush=True)
@@ -569,40 +574,73 @@ def one_group_roofline(args, rs_main, device):
     return out
 
 
-def extra_states(args, rs_main, device):
-    """EM iterations/s at max_cn = 12 (355 states), everything else as the headline workload."""
+def _timed_run(args, device, restarts, groups, max_cn, nsteps, warm, seeds_base=1000):
+    """Build `restarts` restarts of the headline experiment (at max_cn) in `groups` restart groups, run `warm` untimed and
+    `nsteps` timed EM iterations with HIP-event kernel times: (rs, S, N1, seconds, elbo, profile)."""
     import torch
     from remixt_amd import synthetic
     from remixt_amd.restarts import RestartGroups
-    _release(rs_main)
-    max_cn, R = 12, args.restarts
     e = synthetic.make_experiment(args.segments, num_clones=args.clones, max_copy_number=max_cn, num_chains=23, seed=0)
-    params = synthetic.make_init_params(e, R, max_cn, num_clones=args.clones)
-    # one group: at 355 states the forward-backward launch dominates and 4 restarts per workgroup beat the overlap of two groups
-    rs = RestartGroups(e, params, max_cn, groups=1, num_clones=args.clones, device=device, quiet=True, seeds=[1000 + i for i in range(R)])
+    params = synthetic.make_init_params(e, restarts, max_cn, num_clones=args.clones)
+    rs = RestartGroups(e, params, max_cn, groups=groups, num_clones=args.clones, device=device, quiet=True, seeds=[seeds_base + i for i in range(restarts)])
     b = rs.batches[0]
     S, N1 = b.num_cn_states, b.num_segments
     for m, v in zip(rs.models, rs.calculate_elbo()):
         m.prev_elbo = float(v)
-    rs.run(1, 0, args.update_iters)
+    rs.run(warm, 0, args.update_iters)
     rs.synchronize(); torch.cuda.synchronize()
-    nsteps = 6
-    b.profile_reset(); b.profile_enable(2)
+    for b_ in rs.batches:
+        b_.profile_reset(); b_.profile_enable(2)
     t0 = time.perf_counter()
-    elbo = rs.run(nsteps, 1, args.update_iters)
+    elbo = rs.run(nsteps, warm, args.update_iters)
     rs.synchronize(); torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    b.profile_enable(0)
-    prof = rs.profile()
+    for b_ in rs.batches:
+        b_.profile_enable(0)
+    return rs, S, N1, dt, elbo, rs.profile()
+
+
+def extra_states(args, rs_main, device):
+    """EM iterations/s at max_cn = 12 (355 states: the reference's default max_copy_number, defaults.py:117, and the "~400 states"
+    BASELINE.json's metric string is quoted on), everything else as the headline workload; 20 timed steps like the headline."""
+    _release(rs_main)
+    max_cn, R, nsteps = 12, args.restarts, 20
+    # one group: at 355 states the forward-backward launch dominates the step and carries all 16 restarts
+    rs, S, N1, dt, elbo, prof = _timed_run(args, device, R, 1, max_cn, nsteps, 2)
     hot = [(k, prof[k]) for k in ALG_BYTES_PER_CELL if k in prof]
     dom = max(hot, key=lambda kv: kv[1][0]) if hot else (None, (0., 0))
     a355 = argparse.Namespace(**vars(args)); a355.max_cn = max_cn
-    out = {'states': S, 'max_cn': max_cn, 'restart_groups': 1, 'value': R * nsteps / dt, 'unit': 'EM iterations/s', 'ms_per_step': dt / nsteps * 1e3, 'steps': nsteps,
+    out = {'metric': 'EM iterations/sec (%dk seg x %d states)' % (args.segments // 1000, S), 'states': S, 'max_cn': max_cn, 'restart_groups': 1,
+           'value': R * nsteps / dt, 'unit': 'EM iterations/s', 'ms_per_step': dt / nsteps * 1e3, 'steps': nsteps, 'warmup': 2,
            'seg_state_cells_per_s': float(N1) * S * R * args.update_iters * nsteps / dt, 'elbo_best': float(np.nanmax(elbo)),
-           'roofline': roofline_object(dom, float(N1) * S * R, S, a355, R, traffic_file='traffic_r02_s355.json'),
+           'forward_backward_kernel': {1: 'k_fbm', 2: 'k_fbv', 3: 'k_fbk', 4: 'k_fbq', 0: 'k_fb<0>'}.get(rs.batches[0].info(12)),
+           'roofline': roofline_object(dom, float(N1) * S * R, S, a355, R, traffic_file='traffic_r03_s355.json'),
            'kernels': dict((k, {'ms': round(v[0], 3), 'n': v[1]}) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0]))}
     _release(rs)
     return out
+
+
+def strong_scaling_proxy(args, rs_main, device):
+    """BASELINE configs[3] without an 8-GPU node: the 64-restart job on THIS GPU, and one rank's share of it
+    (8 restarts) on this GPU.  Restarts are independent and nothing is exchanged during EM, so 8 GPUs with 8 restarts each run at
+    8 x the one-share rate: predicted speed-up of 8 GPUs over 1 on the fixed job = 8 x it/s(8) / it/s(64)."""
+    _release(rs_main)
+    nsteps = 8
+    rs, S, N1, dt64, _, prof64 = _timed_run(args, device, 64, 4, args.max_cn, nsteps, 2)
+    fb64 = prof64.get('k_fb', (0., 1))
+    _release(rs)
+    rs, S, N1, dt8, _, prof8 = _timed_run(args, device, 8, args.groups, args.max_cn, nsteps, 2)
+    fb8 = prof8.get('k_fb', (0., 1))
+    _release(rs)
+    its64, its8 = 64 * nsteps / dt64, 8 * nsteps / dt8
+    return {'workload': 'BASELINE configs[3]: 64 restarts, %d segments x %d states' % (args.segments, S),
+            'one_gpu_64_restarts': {'value': its64, 'unit': 'EM iterations/s', 'ms_per_step': dt64 / nsteps * 1e3, 'restart_groups': 4,
+                                    'fb_avg_launch_ms': fb64[0] / max(fb64[1], 1), 'fb_restarts_per_launch': 16},
+            'one_rank_share_8_restarts': {'value': its8, 'unit': 'EM iterations/s', 'ms_per_step': dt8 / nsteps * 1e3, 'restart_groups': args.groups,
+                                          'fb_avg_launch_ms': fb8[0] / max(fb8[1], 1), 'fb_restarts_per_launch': 8 // max(1, args.groups)},
+            'predicted_speedup_8_gpus_over_1': 8. * its8 / its64, 'target': 6.0,
+            'note': 'a forward-backward launch takes the same time for 4, 8 or 16 restarts (a chain of 2 173 dependent steps per chromosome): one GPU '
+                    'amortises that latency over 64 restarts, a rank holding 8 cannot'}
 
 
 if __name__ == '__main__':

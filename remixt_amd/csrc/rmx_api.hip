@@ -1270,7 +1270,7 @@ static int p_cn_front(rmx_batch *b, int r0, int r1, bool skip_frame, bool snapsh
             m.chain_start = d.chain_start; m.chain_end = d.chain_end; m.chain_list = d.chain_list_fast; m.chain_tc = d.chain_tc; m.chain_cls = d.chain_cls;
             m.be_n = d.be_n; m.chain_be = d.chain_be; m.fe = d.fe; m.Wf = d.Wf; m.Wb = d.Wb; m.pe2_lt = d.pe2x_lt; m.af = d.af; m.ab = d.ab; m.tot = d.tot;
             m.fa = d.fa; m.fb = d.fb; m.mrow = d.mrow; m.err = d.err; m.dbg = b->d_dbg;
-            const size_t lds = (size_t)2 * m.VR * 4 * 8 + (size_t)2 * 4 * m.PE2P * 8 + 64 * 8 + (size_t)4 * KB * 4 + (size_t)b->be_cap * 4 + 64;
+            const size_t lds = (size_t)2 * m.VR * 4 * 8 + (size_t)2 * 4 * m.PE2P * 8 + 64 * 32 * 8 + 64 * 8 + (size_t)4 * KB * 4 + (size_t)b->be_cap * 4 + 64;
             void (*kf)(FbmArgs, const double *, const uint32_t *, const uint32_t *) = KB == 64 ? k_fbq<64> : k_fbq<90>;
             if (NWq <= 12 && 4 * KB >= d.S && lds <= kLdsBudget) {
                 HIPCHK(hipFuncSetAttribute((const void *)kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

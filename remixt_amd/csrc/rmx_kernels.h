@@ -1070,10 +1070,12 @@ __global__ __launch_bounds__(768) void k_fbm(FbmArgs a) {
 // v_mfma_f64_4x4x4f64, column-owner waves, the ones column for the row scale, one barrier per step -- but the B operands are
 // not resident: a plain-adjacency weight is exp(-pen k) with k = min(SAD(cn_q, cn_o), SAD(cn_q, swap_alleles(cn_o))) < 64
 // (k_fbk's closed form, verified by the host against the tabulated log-weights: fbk_ok), so what a wave keeps in registers is
-// the 8-BIT k of its column tiles for the whole reduction index (KB bytes per lane and tile instead of KB doubles), and every
-// B operand is one conflict-poor ds_read_b64 from a 64-entry table of exp(-pen k) in LDS.  Per MFMA the LDS moves 512 B for the
-// B operand and 256 B for the A operand (one ds_read_b128 feeds two k-blocks of BOTH tiles of the wave): 3 of the 4 LDS cycles
-// a CU has per MFMA at the matrix pipe's full rate (MI355X_MICROARCH.md, LDS: 256 B per clock for ds_read_b64 / b128).
+// the SMALL INTEGER k of its column tiles for the whole reduction index (KB 16-bit fields per lane and tile instead of KB doubles),
+// and every B operand is one ds_read_b64 from a table of exp(-pen k) in LDS.  The table is stored 32 times, entry k of copy j at
+// byte 256 k + 8 j, and lane l reads copy l mod 32: whatever the k's of a wave are, the 32 lanes of an LDS lane group hit 32
+// different bank pairs (measured with one copy: +5 200 cycles per step of bank conflicts on top of 10 400; tools/fbq_variants.sh).
+// Per MFMA the LDS moves 512 B for the B operand and 256 B for the A operand (one ds_read_b128 feeds two k-blocks of BOTH tiles of
+// the wave): 3 of the 4 LDS cycles a CU has per MFMA at the matrix pipe's full rate (MI355X_MICROARCH.md, LDS: 256 B per clock).
 //   * wave w owns TWO tiles of 15 state columns + a ones column: columns 30 w .. 30 w + 29 (12 waves at 355 states);
 //   * all LDS reads of the plain steps go through untracked asm into a ring, FBQ_DEPTH pairs of k-blocks ahead of the
 //     MFMAs that consume them (5 reads per pair: the A pair and four table lookups), retired by counted lgkmcnt waits;
@@ -1083,27 +1085,32 @@ __global__ __launch_bounds__(768) void k_fbm(FbmArgs a) {
 // Summation order is fixed: repeated runs are bit-identical.
 // grid (chains of one state-table class, ceil(restarts / 4), 2 directions), block 64 ceil(S / 30).
 // =============================================================================
-#define FBQ_DEPTH 3
+#define FBQ_DEPTH 2
 #define FBQ_RING (FBQ_DEPTH + 1)
 struct fbq_slot { fbm_d2 a; double b[4]; };      // A operands of a pair of k-blocks; B operands [k-block of the pair][tile]
 __device__ __forceinline__ void fbq_rd64(double &dst, unsigned addr) { asm volatile("ds_read_b64 %0, %1" : "=v"(dst) : "v"(addr) : "memory"); }
 template <int CNT> __device__ __forceinline__ void fbq_wait(fbq_slot &x) {
     asm volatile("s_waitcnt lgkmcnt(%5)" : "+v"(x.a), "+v"(x.b[0]), "+v"(x.b[1]), "+v"(x.b[2]), "+v"(x.b[3]) : "n"(CNT) : "memory");
 }
-// A lane keeps the distance k of (row 4 kb + kq, its column) as the 9-bit field 8 k -- the byte offset of exp(-pen k) in the table at
-// LDS address 0 -- three k-blocks per register: one v_bfe_u32 per B-operand address.
-#define FBQ_ADDR(c_, kb_) (((c_)[(kb_) / 3] >> (9 * ((kb_) % 3))) & 0x1ffu)
+// A lane keeps the distance k of (row 4 kb + kq, its column) as the 16-bit LDS address of ITS copy of exp(-pen k) -- 256 k + 8 (lane
+// mod 32), the table at LDS address 0 -- two k-blocks per register: one VALU operation per B-operand address.
+#define FBQ_ADDR(c_, kb_) (((kb_) & 1) ? ((c_)[(kb_) >> 1] >> 16) : ((c_)[(kb_) >> 1] & 0xffffu))
 template <int KB> struct fbq_chain {
-    static constexpr int NP = KB / 2, NW32 = (KB + 2) / 3;
+    static constexpr int NP = KB / 2, NW32 = KB / 2;
     // requests of pair P: the A pair, then the table entries of k-blocks 2 P, 2 P + 1 for tiles 0 and 1
     template <int P> static __device__ __forceinline__ void issue(fbq_slot &s, unsigned apc, unsigned wt, const unsigned (&c0)[NW32], const unsigned (&c1)[NW32]) {
-        fbm_rd<P * 256>(s.a, apc);
         constexpr int k0 = 2 * P, k1 = 2 * P + 1;
         (void)wt;      // the table sits at LDS address 0 (checked at kernel entry): the field is the address
-        fbq_rd64(s.b[0], FBQ_ADDR(c0, k0));
-        fbq_rd64(s.b[1], FBQ_ADDR(c1, k0));
-        fbq_rd64(s.b[2], FBQ_ADDR(c0, k1));
-        fbq_rd64(s.b[3], FBQ_ADDR(c1, k1));
+        // The four address extractions back to back, THEN the reads: a vector instruction between two FP64 MFMAs costs ~9 cycles
+        // of matrix-pipe time, four in a row ~5 each (tools/micro/mfma64_bench.hip, "beside other work")
+        unsigned a0 = FBQ_ADDR(c0, k0), a1 = FBQ_ADDR(c1, k0), a2 = FBQ_ADDR(c0, k1), a3 = FBQ_ADDR(c1, k1);
+        asm volatile("" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3));
+        __builtin_amdgcn_sched_barrier(0);
+        fbm_rd<P * 256>(s.a, apc);
+        fbq_rd64(s.b[0], a0);
+        fbq_rd64(s.b[1], a1);
+        fbq_rd64(s.b[2], a2);
+        fbq_rd64(s.b[3], a3);
     }
     template <int P> static __device__ __forceinline__ void run(fbq_slot (&ring)[FBQ_RING], unsigned apc, unsigned wt, const unsigned (&c0)[NW32], const unsigned (&c1)[NW32],
                                                                 double (&acc)[4]) {
@@ -1114,6 +1121,7 @@ template <int KB> struct fbq_chain {
         acc[1] = __builtin_amdgcn_mfma_f64_4x4x4f64(s.a.x, s.b[1], acc[1], 0, 0, 0);      // tile 1, even k-block
         acc[2] = __builtin_amdgcn_mfma_f64_4x4x4f64(s.a.y, s.b[2], acc[2], 0, 0, 0);      // tile 0, odd k-block
         acc[3] = __builtin_amdgcn_mfma_f64_4x4x4f64(s.a.y, s.b[3], acc[3], 0, 0, 0);      // tile 1, odd k-block
+        __builtin_amdgcn_sched_barrier(0);
         if constexpr (P + FBQ_DEPTH < NP) issue<P + FBQ_DEPTH>(ring[(P + FBQ_DEPTH) % FBQ_RING], apc, wt, c0, c1);
         if constexpr (P + 1 < NP) run<P + 1>(ring, apc, wt, c0, c1, acc);
     }
@@ -1127,7 +1135,7 @@ template <int KB>
 __global__ __launch_bounds__(768) void k_fbq(FbmArgs a, const double *wk, const uint32_t *cnpack, const uint32_t *totpack) {
     extern __shared__ __align__(16) unsigned char smem_raw[];
     static_assert(KB % 2 == 0 && KB / 2 >= FBQ_DEPTH, "k-blocks come in pairs; ring no deeper than the chain");
-    constexpr int NW32 = (KB + 2) / 3;
+    constexpr int NW32 = KB / 2;
     const int chain = a.chain_list[blockIdx.x], dir = blockIdx.z;
     const int quad = (a.r0 >> 2) + blockIdx.y, rg0 = quad * FBM_NV;
     const int v_lo = max(a.r0 - rg0, 0), v_hi = min(a.r1 - rg0, FBM_NV);
@@ -1140,16 +1148,21 @@ __global__ __launch_bounds__(768) void k_fbq(FbmArgs a, const double *wk, const 
     const int col0 = (2 * wave) * 15 + c16, col1 = (2 * wave + 1) * 15 + c16;      // this lane's state column in tile 0 / tile 1
     const int cls = a.chain_cls[chain];
     // ---- LDS carve-up ---------------------------------------------------------------------------
-    double *wtab = (double *)smem_raw;                          // [64]         exp(-pen k), at LDS offset 0 of the dynamic segment: a lookup's address is 8 k + base
-    double *vec = wtab + 64;                                    // [2][VR][4]   vectors, restart-interleaved, double-buffered by step parity
+    double *wtab = (double *)smem_raw;                          // [64][32]     exp(-pen k), 32 copies (entry k of copy j at 32 k + j), at LDS address 0
+    double *vec = wtab + 64 * 32;                                // [2][VR][4]   vectors, restart-interleaved, double-buffered by step parity
     double *tab = vec + (size_t)2 * VR * 4;                     // [2][PE2P][4] clone-product weights of the current and the next breakend (LDS-DMA)
-    uint32_t *tpl = (uint32_t *)(tab + (size_t)2 * 4 * a.PE2P); // [4 KB]       packed totals of the row states (0 past S)
-    int *bel = (int *)(tpl + 4 * KB);                           // adjacencies of this chain's breakends
+    int *upl = (int *)(tab + (size_t)2 * 4 * a.PE2P);           // [4 KB]       32 U_q of the row states, U = index of the state's tumour totals in the clone-product table's order (0 past S)
+    double *wup = (double *)(upl + 4 * KB);                     // [64]         exp(+pen kt): turns a table entry into the factor on the PLAIN weight (below)
+    int *bel = (int *)(wup + 64);                               // adjacencies of this chain's breakends
     const int be_lo = a.chain_be[2 * chain], be_hi = a.chain_be[2 * chain + 1];
     for (int i = t; i < be_hi - be_lo; i += NT) bel[i] = a.be_n[be_lo + i];
-    for (int i = t; i < 4 * KB; i += NT) tpl[i] = i < S ? totpack[(size_t)cls * S + i] : 0u;
+    for (int i = t; i < 4 * KB; i += NT) {
+        const uint32_t tp = i < S ? totpack[(size_t)cls * S + i] : 0u;
+        upl[i] = 32 * (M == 3 ? (int)(tp & 0xff) * D + (int)((tp >> 8) & 0xff) : (int)(tp & 0xff));
+    }
+    for (int i = t; i < 64; i += NT) wup[i] = exp(a.pen * (double)i);
     for (int i = t; i < 2 * VR * 4; i += NT) vec[i] = 0.;
-    for (int i = t; i < 64; i += NT) wtab[i] = wk[(size_t)a.chain_tc[chain] * 64 + i];
+    for (int i = t; i < 64 * 32; i += NT) wtab[i] = wk[(size_t)a.chain_tc[chain] * 64 + (i >> 5)];
     // ---- this lane's 8-bit distances: rows 4 kb + kq against its two columns, every k-block ---------------------
     // (rows past S multiply vector elements that are always 0, columns past S are never published: their codes only have to
     // be valid table indices; the ones columns' code is 0: weight exp(0) = 1)
@@ -1168,8 +1181,8 @@ __global__ __launch_bounds__(768) void k_fbq(FbmArgs a, const double *wk, const 
         unsigned k1 = min(__builtin_amdgcn_sad_u8(cq, co1, 0u), __builtin_amdgcn_sad_u8(cq, co1s, 0u));
         if (is_sum || q >= S || col0 >= S) k0 = 0u;
         if (is_sum || q >= S || col1 >= S) k1 = 0u;
-        c0[kb / 3] |= ((k0 & 63u) << 3) << (9 * (kb % 3));
-        c1[kb / 3] |= ((k1 & 63u) << 3) << (9 * (kb % 3));
+        c0[kb >> 1] |= (((k0 & 63u) << 8) | ((unsigned)(lane & 31) << 3)) << (16 * (kb & 1));
+        c1[kb >> 1] |= (((k1 & 63u) << 8) | ((unsigned)(lane & 31) << 3)) << (16 * (kb & 1));
     }
 #pragma unroll
     for (int i = 0; i < NW32; i++) asm volatile("" : "+v"(c0[i]), "+v"(c1[i]));      // their loads retire here, not inside the step loop
@@ -1235,8 +1248,16 @@ __global__ __launch_bounds__(768) void k_fbq(FbmArgs a, const double *wk, const 
         mptr += dir == 0 ? 1 : -1;                                                                                                 \
         FB_BARRIER();                                                                                                              \
     }
+    // Breakend steps.  W_i[q][o] = exp(-pen (k - kt)) tab_i[ix] with kt = SAD(tot_q, tot_o) and ix the index of the total differences in
+    // the clone-product table; kt is a function of ix, so tab2_i[ix] = tab_i[ix] exp(+pen kt(ix)) -- one pass over the 730-entry table
+    // when it has landed -- leaves W_i[q][o] = W[q][o] tab2_i[ix]: the PLAIN weight (the same lookup as in a plain step) times one table
+    // entry whose byte address is sgn 32 (U_q - U_o) + const: one v_mad per B operand instead of a dozen integer operations.
     const int sgn = dir == 0 ? 1 : -1, toff = a.cn_max + 1;
-    const unsigned ones_idx = (unsigned)(M == 2 ? D : D * D);      // table entry n2 holds 1 (k_brk_lut)
+    const int ones_idx = M == 2 ? D : D * D;                       // table entry n2 holds 1 (k_brk_lut)
+    const int ucst = M == 3 ? toff * (D + 1) : toff;
+    auto u_of = [&](uint32_t tp) { return M == 3 ? (int)(tp & 0xff) * D + (int)((tp >> 8) & 0xff) : (int)(tp & 0xff); };
+    const int umul = is_sum ? 0 : sgn;                             // the ones columns read entry n2 whatever the row
+    const int uoff0 = is_sum ? 32 * ones_idx : 32 * (ucst - sgn * u_of(to0)), uoff1 = is_sum ? 32 * ones_idx : 32 * (ucst - sgn * u_of(to1));
     int k = 1;
     while (k < len) {
         const int k_be = be_adj >= 0 ? (dir == 0 ? be_adj - n0 + 1 : n1 - be_adj) : len;
@@ -1269,43 +1290,43 @@ __global__ __launch_bounds__(768) void k_fbq(FbmArgs a, const double *wk, const 
             double e0, e1;
             gload8(e0, eptr0); gload8(e1, eptr1);
             eptr0 += rstep; eptr1 += rstep;
+            // tab -> tab2 in place (every entry once; the pad entry n2 stays 1), then a barrier: the products read all of it
+            {
+                double *tw = tab + (size_t)(be_buf ^ 1) * 4 * a.PE2P;      // (be_buf was flipped above: this step's table)
+                for (int e_ = t; e_ < ones_idx; e_ += NT) {
+                    const int kt_ = M == 3 ? abs(e_ / D - toff) + abs(e_ % D - toff) : abs(e_ - toff);
+                    const double f_ = wup[kt_ & 63];
+                    double2 *row = reinterpret_cast<double2 *>(tw + (size_t)e_ * 4);
+                    double2 r01 = row[0], r23 = row[1];
+                    r01.x *= f_; r01.y *= f_; r23.x *= f_; r23.y *= f_;
+                    row[0] = r01; row[1] = r23;
+                }
+            }
+            FB_BARRIER();
             double acc0[FBM_NV] = {0., 0., 0., 0.}, acc1[FBM_NV] = {0., 0., 0., 0.};
             const fbm_d2 *apc = reinterpret_cast<const fbm_d2 *>(vec + (size_t)((k - 1) & 1) * VR * 4 + (kq * 4 + ib) * 2);     // pair p: + 16 p
-            const int to0a = (int)(to0 & 0xff), to0b = (int)((to0 >> 8) & 0xff), to1a = (int)(to1 & 0xff), to1b = (int)((to1 >> 8) & 0xff);
+            const char *tbb = reinterpret_cast<const char *>(tb);
 #pragma unroll
-            for (int p = 0; p < KB / 2; p++) {      // fully unrolled: the code registers need compile-time indices
+            for (int p = 0; p < KB / 2; p++) {      // fully unrolled: the address registers need compile-time indices
                 const fbm_d2 av = apc[p * 16];
 #pragma unroll
                 for (int h = 0; h < 2; h++) {
                     const int kb = 2 * p + h;
-                    const uint32_t tq = tpl[4 * kb + kq];
-                    const int tqa = (int)(tq & 0xff), tqb = (int)((tq >> 8) & 0xff);
+                    const int uq = upl[4 * kb + kq];
                     const double ak = h ? av.y : av.x;
-                    // tile 0
-                    {
-                        const unsigned kk = FBQ_ADDR(c0, kb) >> 3;
-                        unsigned ac = kk - __builtin_amdgcn_sad_u8(tq, to0, 0u);
-                        int ix = sgn * (tqa - to0a) + toff;
-                        if (M == 3) ix = ix * D + sgn * (tqb - to0b) + toff;
-                        if (is_sum) { ac = 0u; ix = (int)ones_idx; }
-                        const double wv = wtab[ac & 63u];
-                        const double2 t01 = *reinterpret_cast<const double2 *>(tb + (size_t)ix * 4);
-                        const double2 t23 = *reinterpret_cast<const double2 *>(tb + (size_t)ix * 4 + 2);
+                    {   // tile 0
+                        const double wv = *reinterpret_cast<const double *>(reinterpret_cast<const char *>(wtab) + FBQ_ADDR(c0, kb));
+                        const char *row = tbb + (__mul24(uq, umul) + uoff0);
+                        const double2 t01 = *reinterpret_cast<const double2 *>(row), t23 = *reinterpret_cast<const double2 *>(row + 16);
                         acc0[0] = __builtin_amdgcn_mfma_f64_4x4x4f64(ak, wv * t01.x, acc0[0], 0, 0, 0);
                         acc0[1] = __builtin_amdgcn_mfma_f64_4x4x4f64(ak, wv * t01.y, acc0[1], 0, 0, 0);
                         acc0[2] = __builtin_amdgcn_mfma_f64_4x4x4f64(ak, wv * t23.x, acc0[2], 0, 0, 0);
                         acc0[3] = __builtin_amdgcn_mfma_f64_4x4x4f64(ak, wv * t23.y, acc0[3], 0, 0, 0);
                     }
-                    // tile 1
-                    {
-                        const unsigned kk = FBQ_ADDR(c1, kb) >> 3;
-                        unsigned ac = kk - __builtin_amdgcn_sad_u8(tq, to1, 0u);
-                        int ix = sgn * (tqa - to1a) + toff;
-                        if (M == 3) ix = ix * D + sgn * (tqb - to1b) + toff;
-                        if (is_sum) { ac = 0u; ix = (int)ones_idx; }
-                        const double wv = wtab[ac & 63u];
-                        const double2 t01 = *reinterpret_cast<const double2 *>(tb + (size_t)ix * 4);
-                        const double2 t23 = *reinterpret_cast<const double2 *>(tb + (size_t)ix * 4 + 2);
+                    {   // tile 1
+                        const double wv = *reinterpret_cast<const double *>(reinterpret_cast<const char *>(wtab) + FBQ_ADDR(c1, kb));
+                        const char *row = tbb + (__mul24(uq, umul) + uoff1);
+                        const double2 t01 = *reinterpret_cast<const double2 *>(row), t23 = *reinterpret_cast<const double2 *>(row + 16);
                         acc1[0] = __builtin_amdgcn_mfma_f64_4x4x4f64(ak, wv * t01.x, acc1[0], 0, 0, 0);
                         acc1[1] = __builtin_amdgcn_mfma_f64_4x4x4f64(ak, wv * t01.y, acc1[1], 0, 0, 0);
                         acc1[2] = __builtin_amdgcn_mfma_f64_4x4x4f64(ak, wv * t23.x, acc1[2], 0, 0, 0);

@@ -68,6 +68,32 @@ template <int NACC> __global__ void bench16(double *out, int iters, unsigned lon
     out[blockIdx.x * blockDim.x + threadIdx.x] = s;
     if (threadIdx.x == 0 && blockIdx.x == 0) cyc[0] = t1 - t0;
 }
+// FP64 MFMA with NVALU cheap integer vector instructions (v_bfe_u32: the operand-address extraction of k_fbq) and NLDS
+// ds_read_b64 (per-lane bank pair: conflict-free) per MFMA, 4 accumulators: does the matrix pipe run beside the vector ALU?
+template <int NVALU, int NLDS> __global__ void bench4mix(double *out, int iters, unsigned long long *cyc) {
+    __shared__ double tab[64 * 32];
+    for (int i = threadIdx.x; i < 64 * 32; i += blockDim.x) tab[i] = 1.0 + i * 1e-9;
+    __syncthreads();
+    double a = threadIdx.x * 1e-3, b = 1.0 + threadIdx.x * 1e-6;
+    double acc[4] = {0., 0., 0., 0.};
+    unsigned c = threadIdx.x * 2654435761u, x = 0;
+    double l[4] = {b, b, b, b};
+    const unsigned lane_off = (threadIdx.x & 31) * 8;
+    unsigned long long t0 = __builtin_readcyclecounter();
+    for (int it = 0; it < iters; it++) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            acc[i] = __builtin_amdgcn_mfma_f64_4x4x4f64(a, l[i], acc[i], 0, 0, 0);
+#pragma unroll
+            for (int v = 0; v < NVALU; v++) asm volatile("v_bfe_u32 %0, %1, %2, 9" : "=v"(x) : "v"(c), "n"((i * 3 + v) % 23));
+            if (NLDS) { unsigned ad = ((c >> (i + 3)) & 0x3f00u) | lane_off; asm volatile("ds_read_b64 %0, %1" : "=v"(l[i]) : "v"(ad) : "memory"); }
+        }
+        if (NLDS) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(l[0]), "+v"(l[1]), "+v"(l[2]), "+v"(l[3]) :: "memory");
+    }
+    unsigned long long t1 = __builtin_readcyclecounter();
+    out[blockIdx.x * blockDim.x + threadIdx.x] = (acc[0] + acc[1]) + (acc[2] + acc[3]) + (double)x;
+    if (threadIdx.x == 0 && blockIdx.x == 0) cyc[0] = t1 - t0;
+}
 // vector FMA reference: same shape
 template <int NACC> __global__ void benchv(double *out, int iters, unsigned long long *cyc) {
     double a = threadIdx.x * 1e-3, b = 1.0 + threadIdx.x * 1e-6;
@@ -154,6 +180,10 @@ int main(int argc, char **argv) {
                run(bench16<1>, waves, 1, iters, dout, dcyc), run(bench16<2>, waves, 2, iters, dout, dcyc), run(bench16<4>, waves, 4, iters, dout, dcyc),
                run(benchv<4>, waves, 4, iters, dout, dcyc), run(benchv<8>, waves, 8, iters, dout, dcyc));
     }
+    printf("== v_mfma_f64_4x4x4 beside other work, 12 waves per CU (3 per SIMD), ns per MFMA per SIMD: does integer VALU / LDS issue cost matrix-pipe time? ==\n");
+    printf("valu0 %.2f | valu1 %.2f | valu2 %.2f | valu4 %.2f | lds1 (address from the data path: 2 extra VALU) %.2f | valu1+lds1 %.2f\n",
+           run(bench4mix<0, 0>, 12, 4, iters, dout, dcyc), run(bench4mix<1, 0>, 12, 4, iters, dout, dcyc), run(bench4mix<2, 0>, 12, 4, iters, dout, dcyc),
+           run(bench4mix<4, 0>, 12, 4, iters, dout, dcyc), run(bench4mix<0, 1>, 12, 4, iters, dout, dcyc), run(bench4mix<1, 1>, 12, 4, iters, dout, dcyc));
     printf("== all CUs busy (grid 1024, 12 waves per block) ==\n");
     printf("4x4x4 nacc4 %.2f | 16x16x4 nacc2 %.2f | v_fmac nacc8 %.2f (ns per instruction per SIMD, 4 blocks/CU-round)\n",
            run(bench4<4>, 12, 4, iters, dout, dcyc, kMaxGrid) / 4, run(bench16<2>, 12, 2, iters, dout, dcyc, kMaxGrid) / 4, run(benchv<8>, 12, 8, iters, dout, dcyc, kMaxGrid) / 4);
