@@ -80,6 +80,8 @@ def parse(argv=None):
     ap.add_argument('--master-port', type=int, default=0, help='rendezvous port when bench.py starts the ranks itself (0 = pick a free one)')
     ap.add_argument('--option', action='append', default=[], metavar='NAME=VALUE',
                     help='A/B measurements: a tuning option of the library (include/remixt_amd.h, enum rmx_option_id) for every batch of this run')
+    ap.add_argument('--host-option', action='append', default=[], metavar='NAME=VALUE',
+                    help='A/B measurements: a keyword of remixt_amd.restarts.RestartSet (sample_prep, mstep_threads, joint_accept, lockstep, native_search) for this run')
     ap.add_argument('--lib', default=None, help='A/B measurements: an alternative build of libremixt_hip.so for this run')
     ap.add_argument('--switch-interval-us', type=float, default=0., help='A/B measurements: sys.setswitchinterval for the restart groups\' host threads (0 = leave Python\'s 5 ms)')
     ap.add_argument('--cpu-leg', action='store_true', help=argparse.SUPPRESS)       # internal: the CPU baseline child process
@@ -306,13 +308,14 @@ def main(argv=None, kernel_module=None, dist_backend='nccl', script=None):
     R = len(mine)
     if R == 0:
         raise SystemExit('bench.py: rank %d has no restart (total %d over %d ranks)' % (rank, total, world))
+    host_kw = dict((item.split('=')[0], int(item.split('=')[1])) for item in args.host_option)
     if len(sets) == 1:
         e, params, seeds = sets[0]
         rs = RestartGroups(e, params, args.max_cn, groups=args.groups, num_clones=args.clones, device=device, quiet=True, seeds=seeds,
-                           kernel_module=kernel_module)
+                           kernel_module=kernel_module, **host_kw)
     else:
         rs = DatasetGroups([s[0] for s in sets], [s[1] for s in sets], args.max_cn, groups=args.groups, num_clones=args.clones, device=device,
-                           quiet=True, seeds=[s[2] for s in sets], kernel_module=kernel_module)
+                           quiet=True, seeds=[s[2] for s in sets], kernel_module=kernel_module, **host_kw)
     e = sets[0][0]
     on_gpu = kernel_module is None
     m0 = rs.models[0]

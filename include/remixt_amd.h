@@ -162,6 +162,10 @@ int rmx_get_param(rmx_batch *b, int32_t r, int32_t param_id, double *value);
 int rmx_set_transition_model(rmx_batch *b, int32_t model);  /* bpmodel.pyx:456, 606-616 */
 int rmx_set_array(rmx_batch *b, int32_t r, int32_t array_id, const void *host_src);
 int rmx_get_array(rmx_batch *b, int32_t r, int32_t array_id, void *host_dst);
+/* The attributes p_outlier_total / p_outlier_allele (bpmodel.pyx:419-421) of restarts [r0, r1) in one transfer on a copy stream of
+ * the batch's own, into pinned host memory the batch owns: *total / *allele point to [r1 - r0][N][2] float64, valid until the
+ * next call.  What BreakpointModel.get_param_sample_weight (cn_model.py:323-352) reads at the start of every M-step. */
+int rmx_fetch_indicators(rmx_batch *b, int32_t r0, int32_t r1, const double **total, const double **allele);
 /* read-only derived state tables, (N,S[,M]) int64 like the reference attributes
  * cn_states_total / num_alleles_subclonal / is_hdel / is_loh (bpmodel.pyx:497-507):
  * which = 0..3 in that order */
@@ -172,6 +176,13 @@ int rmx_calculate_log_transmat(rmx_batch *b, int32_t r, double *dst);
  * uniform draw u[j] selects from cumsum(p) / sum -- numpy's cumsum / searchsorted(side='right') with the same
  * accumulation order; *positive = count_nonzero(p > 0).  Runs without the GIL, no device involved. */
 int rmx_weighted_search(const double *p, int64_t n, const double *u, int32_t k, int64_t *out, int64_t *positive);
+/* One round of that sampling without a normalised copy of the weights (host only, no GIL, no device): weights w[i * stride] / norm
+ * (a column of the (N, 2) outlier indicators the sample of negbin_r_* / betabin_M_* is weighted with, cn_model.py:323-352); the k
+ * uniform draws u pick indices from the cumulative sum as rmx_weighted_search does; indices not yet in found[0 .. *nfound) are
+ * appended in the order of the draws, up to cap (numpy's unique-by-first-occurrence of the concatenation).  *positive = number of
+ * positive weights (fewer than the sample size: numpy's "Fewer non-zero entries in p than size"). */
+int rmx_weighted_sample_round(const double *w, int64_t n, int64_t stride, double norm, const double *u, int32_t k,
+                              int64_t *found, int32_t *nfound, int32_t cap, int64_t *positive);
 int rmx_get_state_table(rmx_batch *b, int32_t which, int64_t *host_dst);
 
 /* -- coordinate updates (bpmodel.pyx cpdef methods), restarts [r0,r1) ------ */

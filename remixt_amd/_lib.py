@@ -45,8 +45,10 @@ SYMBOLS = {
     "rmx_set_transition_model": (C.c_int, [C.c_void_p, C.c_int32]),
     "rmx_set_array": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
     "rmx_get_array": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
+    "rmx_fetch_indicators": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(_dp), C.POINTER(_dp)]),
     "rmx_calculate_log_transmat": (C.c_int, [C.c_void_p, C.c_int32, _dp]),
     "rmx_weighted_search": (C.c_int, [_dp, C.c_int64, _dp, C.c_int32, _ip, _ip]),
+    "rmx_weighted_sample_round": (C.c_int, [_dp, C.c_int64, C.c_int64, C.c_double, _dp, C.c_int32, _ip, _i32p, C.c_int32, _ip]),
     "rmx_get_state_table": (C.c_int, [C.c_void_p, C.c_int32, _ip]),
     "rmx_update_framelogprob": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32]),
     "rmx_update_p_cn": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32]),

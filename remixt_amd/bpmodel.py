@@ -238,6 +238,15 @@ class RemixtBatch(object):
             self._ck(self._lib.rmx_get_array(self._handle, r, ARRAY_IDS[name], out.ctypes.data_as(C.c_void_p)))
         return out
 
+    def fetch_indicators(self, r0=None, r1=None):
+        """(p_outlier_total, p_outlier_allele) of restarts [r0, r1) as [r1 - r0][N][2] float64 arrays: views of pinned memory
+        the batch owns, overwritten by the next call (rmx_fetch_indicators: one transfer on a copy stream)."""
+        r0, r1 = self._range(r0, r1)
+        pt, pa = _dp(), _dp()
+        self._ck(self._lib.rmx_fetch_indicators(self._handle, r0, r1, C.byref(pt), C.byref(pa)))
+        shape = (r1 - r0, self.num_segments, 2)
+        return np.ctypeslib.as_array(pt, shape=shape), np.ctypeslib.as_array(pa, shape=shape)
+
     def set_array(self, r, name, value):
         if name not in _WRITABLE:
             raise AttributeError('%s is read-only' % name)
@@ -439,15 +448,20 @@ class RemixtBatch(object):
         p_rl, p_h, p_out = rl.ctypes.data_as(_i32p), h.ctypes.data_as(_dp), out.ctypes.data_as(_dp)
         fn, handle, lib = self._lib.rmx_expected_ll_h_batch, self._handle, self._lib
 
+        neg = np.zeros((max(n, 1), 1 + MAX_CLONES), dtype=np.float64)
+
         def evaluate(ids, xs):
+            """(-E[ll] (k,), -dE[ll]/dh (k, M)) at the rows of xs (a (k, M) array or a list of k vectors); the arrays are views
+            of buffers the next call overwrites."""
             k = len(ids)
             for j in range(k):
                 rl[j] = live[ids[j]]
-                h[j] = xs[j]
+            h[:k] = xs
             rc = fn(handle, k, p_rl, p_h, p_out)
             if rc:
                 _raise(lib, rc)
-            return [(-float(out[j, 0]), -out[j, 1:1 + M]) for j in range(k)]
+            np.negative(out[:k], out=neg[:k])
+            return neg[:k, 0], neg[:k, 1:1 + M]
         return evaluate
 
     def expected_log_likelihood_full(self, r0=None, r1=None):

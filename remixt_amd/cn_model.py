@@ -105,15 +105,78 @@ def _native_weighted_search():
     return _NATIVE_SEARCH[1]
 
 
+class WeightColumn(object):
+    """Sample weights given as a column of an (N, 2) float64 indicator array plus their sum -- what get_param_sample_weight
+    returns for negbin_r_* / betabin_M_* when asked not to materialise `column / norm`: _sample_without_replacement then runs
+    each round of draws in one native call on the strided column (rmx_weighted_sample_round; same values, same draws)."""
+    __slots__ = ('array', 'column', 'norm')
+
+    def __init__(self, array, column, norm):
+        self.array, self.column, self.norm = array, int(column), float(norm)
+
+    def dense(self):
+        return self.array[:, self.column] / self.norm
+
+
+_NATIVE_ROUND = [False, None]
+
+
+def _native_sample_round():
+    """rmx_weighted_sample_round of the HIP library if it is loadable (host code, runs without the GIL), else None."""
+    if _NATIVE_ROUND[0]:
+        return _NATIVE_ROUND[1]
+    _NATIVE_ROUND[0] = True
+    try:
+        import ctypes as C
+        from . import _lib
+        lib = _lib.load()
+        fn = lib.rmx_weighted_sample_round
+        dp, ip, i32p = C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_int32)
+
+        def round_(wc, u, found, nfound, cap):
+            """Append the new distinct indices the draws `u` select to found[:nfound]; returns (nfound, positive weights)."""
+            a = wc.array
+            if a.dtype != np.float64 or a.ndim != 2 or not a.flags.c_contiguous:
+                raise TypeError('indicator array must be C-contiguous float64')
+            nf = C.c_int32(nfound); pos = C.c_int64(0)
+            base = C.cast(a.ctypes.data + 8 * wc.column, dp)
+            rc = fn(base, a.shape[0], a.shape[1], wc.norm, u.ctypes.data_as(dp), len(u), found.ctypes.data_as(ip), C.byref(nf), cap, C.byref(pos))
+            if rc != 0:
+                raise RuntimeError('rmx_weighted_sample_round failed')
+            return int(nf.value), int(pos.value)
+        _NATIVE_ROUND[1] = round_
+    except Exception:
+        _NATIVE_ROUND[1] = None
+    return _NATIVE_ROUND[1]
+
+
 def _sample_without_replacement(rng, n, size, p=None):
     """`size` distinct indices from range(n), successively with probability proportional to p
     (uniform if None): the distribution of numpy's choice(n, size, replace=False, p=p).  numpy
     re-normalises and re-accumulates p after every batch of draws and permutes all n items in the
     uniform case; drawing WITH replacement from the one cumulative distribution and keeping first
     occurrences is the same process (a repeat is exactly a draw the renormalised distribution would
-    not have produced) and needs one cumsum / no permutation."""
+    not have produced) and needs one cumsum / no permutation.  p may be a WeightColumn (see there)."""
     if size > n:
         raise ValueError("Cannot take a larger sample than population when 'replace=False'")
+    if isinstance(p, WeightColumn):
+        round_ = _native_sample_round()
+        if round_ is None:
+            p = p.dense()
+        else:
+            # the same rounds as below -- draws, cumulative sum, binary search, first occurrences -- each round one native call
+            found = np.empty(size + size // 2 + 8, dtype=np.int64)
+            nfound = 0
+            while nfound < size:
+                k = size - nfound
+                k += k // 2 + 8
+                u = rng.rand(k)
+                if len(found) < nfound + k:
+                    found = np.concatenate([found[:nfound], np.empty(k, dtype=np.int64)])
+                nfound, positive = round_(p, u, found, nfound, len(found))
+                if positive < size:
+                    raise ValueError("Fewer non-zero entries in p than size")
+            return found[:size].copy()
     cdf = None
     native = _native_weighted_search() if p is not None else None
     if p is not None and native is None:
@@ -332,17 +395,21 @@ class BreakpointModel(object):
     def _get_loh_weights(self):
         return self._state_weights(self.model.is_loh)
 
-    def get_param_sample_weight(self, name):
-        """Segment weights for the stochastic M-step of one parameter (cn_model.py:323-352)."""
+    def get_param_sample_weight(self, name, as_column=False):
+        """Segment weights for the stochastic M-step of one parameter (cn_model.py:323-352).  as_column: for the parameters
+        weighted by one column of an outlier indicator array, that column and its sum (WeightColumn) instead of a normalised copy."""
         m = self.model
         # (RestartSet passes the outlier indicators it fetched once for the whole M-step: they do not change in it)
         cache = getattr(self, '_mstep_indicator_cache', None) or {}
+        column = None
         if name in ('negbin_r_0', 'negbin_r_1'):
             q = cache.get('p_outlier_total')
-            weights = (np.asarray(m.p_outlier_total) if q is None else q)[:, int(name[-1])]
+            column = (np.asarray(m.p_outlier_total) if q is None else q)
+            weights = column[:, int(name[-1])]
         elif name in ('betabin_M_0', 'betabin_M_1'):
             q = cache.get('p_outlier_allele')
-            weights = (np.asarray(m.p_outlier_allele) if q is None else q)[:, int(name[-1])]
+            column = (np.asarray(m.p_outlier_allele) if q is None else q)
+            weights = column[:, int(name[-1])]
         elif name == 'negbin_hdel_mu':
             weights = self._get_hdel_weights()
         elif name in ('negbin_hdel_r_0', 'negbin_hdel_r_1'):
@@ -355,6 +422,8 @@ class BreakpointModel(object):
             raise KeyError(name)
         norm = weights.sum()
         if norm > 0.:
+            if as_column and column is not None and column.dtype == np.float64 and column.ndim == 2 and column.flags.c_contiguous:
+                return WeightColumn(column, int(name[-1]), norm)
             return weights / norm
         self._log('nothing for ' + name)
         return None
@@ -475,16 +544,20 @@ class BreakpointModel(object):
             with self.elbo_check(name):
                 self.update_param(name)
 
-    def _create_sample(self, weights=None):
-        """Random subset of segments for the stochastic M-steps (cn_model.py:475-480; global numpy RNG)."""
+    def _draw_sample_indices(self, weights=None):
+        """The segments of a stochastic M-step sample (cn_model.py:475-480; global numpy RNG unless the model owns one)."""
         sample_size = int(min(200, self.model.num_segments / 10))
         if self.rng is not None:
             # private stream (RestartSet): the same distribution, drawn with one cumulative sum
-            sample_idxs = _sample_without_replacement(self.rng, self.model.num_segments, sample_size, weights)
-        else:
-            sample_idxs = np.random.choice(self.model.num_segments, size=sample_size, replace=False, p=weights)
+            return _sample_without_replacement(self.rng, self.model.num_segments, sample_size, weights)
+        if isinstance(weights, WeightColumn):
+            weights = weights.dense()
+        return np.random.choice(self.model.num_segments, size=sample_size, replace=False, p=weights)
+
+    def _create_sample(self, weights=None):
+        """Random subset of segments for the stochastic M-steps as the reference's 0 / 1 mask."""
         sample = np.zeros((self.model.num_segments,), dtype=int)
-        sample[sample_idxs] = 1
+        sample[self._draw_sample_indices(weights)] = 1
         return sample
 
     def _all_segments(self):

@@ -11,6 +11,8 @@
 #include <mutex>
 #include <string>
 #include <vector>
+#include <chrono>
+#include <cstdlib>
 
 #include "rmx_kernels.h"
 #include "rmx_host.h"
@@ -81,6 +83,8 @@ struct rmx_batch {
     double *d_ell_partial = nullptr;   // [max(N,ELBO_BLOCKS)][1+MAXC]
     double *d_ell_out = nullptr;       // [1+MAXC]
     double *h_pinned = nullptr;        // pinned staging [max(4R, 16)]
+    hipEvent_t ev_copy = nullptr;
+    double *h_ind = nullptr;           // pinned [2][R][N][2]: the outlier indicators of all restarts for the M-step's weighted samples (rmx_fetch_indicators)
     int32_t *h_lists = nullptr;        // pinned staging of rmx_set_sample_lists (read by the device in place)
     size_t h_lists_cap = 0;
     hipEvent_t ev_lists = nullptr;     // the scatter kernel that last read h_lists
@@ -104,6 +108,9 @@ struct rmx_batch {
     int n_fast = 0, n_generic = 0;
     // which kernels the last update_p_cn / decode launched (rmx_info 12..14; tests assert the shape they mean to cover)
     int last_fb_kernel = 0, last_fb_nv = 0, last_viterbi = 0;
+    // host-side stage clocks of the batched sampled-objective rounds (rmx_info 60..63): ns spent preparing + launching, ns waiting for the
+    // device, ns after the wait, rounds
+    long long t_launch_ns = 0, t_wait_ns = 0, t_post_ns = 0, n_rounds = 0;
     unsigned long long *d_dbg = nullptr;
     int fbv_rpt = 0;   // rows per slice of the multi-vector kernel (0 = not applicable)
     int G = 64;
@@ -938,6 +945,8 @@ int rmx_batch_destroy(rmx_batch *b) { BIND(b);
     if (b->tm_b) hipEventDestroy(b->tm_b);
     for (auto e : b->done_ev) hipEventDestroy(e);
     if (b->stream2) { hipStreamSynchronize(b->stream2); hipStreamDestroy(b->stream2); hipEventDestroy(b->ev_fb); hipEventDestroy(b->ev_brk); }
+    if (b->ev_copy) hipEventDestroy(b->ev_copy);
+    if (b->h_ind) { hipHostUnregister(b->h_ind); free(b->h_ind); }
     if (b->own_stream && b->stream) hipStreamDestroy(b->stream);
     delete b;
     return RMX_OK;
@@ -958,6 +967,7 @@ int rmx_info(rmx_batch *b, int32_t what, int64_t *out) { BIND(b);
     case 0: *out = b->d.cn_max; break; case 1: *out = b->d.NC; break; case 2: *out = b->d.TC; break; case 3: *out = b->d.NBE; break;
     case 4: *out = b->d.SP; break; case 5: *out = b->fbv_rpt; break; case 6: *out = b->fbG.P; break; case 7: *out = b->fbG.NT; break;
     case 8: *out = b->fbG.BLK; break; case 9: *out = (int64_t)b->fbG_lds; break; case 10: *out = b->n_fast; break; case 11: *out = b->n_generic; break;
+    case 60: *out = b->t_launch_ns; break; case 61: *out = b->t_wait_ns; break; case 62: *out = b->t_post_ns; break; case 63: *out = b->n_rounds; break;
     case 12: *out = b->last_fb_kernel; break; case 13: *out = b->last_fb_nv; break; case 14: *out = b->last_viterbi; break;
     case 20: case 21: case 22: case 23: case 24: case 25: case 26: case 27: case 28: case 29: case 30: case 31: case 32: case 33: case 34: case 35: case 36: case 37: case 38: case 39:
     case 40: case 41: case 42: case 43: case 44: case 45: case 46: case 47: case 48: case 49: case 50: case 51:
@@ -1117,6 +1127,49 @@ int rmx_calculate_log_transmat(rmx_batch *b, int32_t r, double *dst) { BIND(b);
 // no Python objects: host threads run it concurrently.
 int rmx_weighted_search(const double *p, int64_t n, const double *u, int32_t k, int64_t *out, int64_t *positive) {
     if (rmxh::weighted_search(p, n, u, k, out, positive)) return fail(RMX_EARG, "bad argument");
+    return RMX_OK;
+}
+
+int rmx_weighted_sample_round(const double *w, int64_t n, int64_t stride, double norm, const double *u, int32_t k,
+                              int64_t *found, int32_t *nfound, int32_t cap, int64_t *positive) {
+    if (rmxh::weighted_sample_round(w, n, stride, norm, u, k, found, nfound, cap, positive)) return fail(RMX_EARG, "bad argument");
+    return RMX_OK;
+}
+
+// p_outlier_total / p_outlier_allele of restarts [r0, r1) -- the weights of the M-step's samples (cn_model.py:323-352) -- in ONE
+// transfer beside the batch stream, behind everything queued on it so far, into pinned host memory owned by
+// the batch: 16 per-restart rmx_get_array calls on the batch stream put their staged pageable copies between the rounds of the h
+// M-step that runs meanwhile.  *total / *allele: [r1 - r0][N][2], valid until the next call.
+int rmx_fetch_indicators(rmx_batch *b, int32_t r0, int32_t r1, const double **total, const double **allele) { BIND(b);
+    RANGE_CHECK();
+    if (!total || !allele) return fail(RMX_EARG, "null argument");
+    const Dev &d = b->d;
+    const size_t per = (size_t)d.N * 2;
+    if (!b->h_ind) {
+        // ordinary (CPU-cached) pages, registered for DMA: the host reads every weight several times (sums, cumulative sums); memory
+        // from hipHostMalloc is mapped uncached on this platform and made those reads ~50x slower
+        const size_t bytes = sizeof(double) * 2 * (size_t)b->R * per;
+        void *p_ = nullptr;
+        if (posix_memalign(&p_, 4096, (bytes + 4095) & ~(size_t)4095) != 0) return fail(RMX_EDEVICE, "out of host memory");
+        memset(p_, 0, bytes);
+        if (hipHostRegister(p_, (bytes + 4095) & ~(size_t)4095, hipHostRegisterDefault) != hipSuccess) { free(p_); return fail(RMX_EDEVICE, "hipHostRegister failed"); }
+        b->h_ind = (double *)p_;
+    }
+    // The copy is queued on the batch stream itself.  A copy stream of its own, or the sweep's second stream, looks free during the
+    // M-step but is not: with the default four hardware queues the extra stream shares a queue with the OTHER restart group's main
+    // stream and the 0.3 ms copy waits behind that group's whole sweep phase (measured: 19 ms of waiting, or -- on the second
+    // stream -- the next sweeps 10 ms longer).  In order on the batch stream it delays one round of the h M-step by its own length.
+    hipStream_t cs = b->stream;
+    double *ht = b->h_ind + (size_t)r0 * per, *ha = b->h_ind + ((size_t)b->R + r0) * per;
+    if (!b->ev_copy) HIPCHK(hipEventCreateWithFlags(&b->ev_copy, hipEventDisableTiming));
+    {
+        std::lock_guard<std::mutex> lk(b->mu);      // (not between the launches of a round in flight on another thread)
+        HIPCHK(hipMemcpyAsync(ht, d.qt + (size_t)r0 * per, sizeof(double) * (size_t)(r1 - r0) * per, hipMemcpyDeviceToHost, cs));
+        HIPCHK(hipMemcpyAsync(ha, d.qa + (size_t)r0 * per, sizeof(double) * (size_t)(r1 - r0) * per, hipMemcpyDeviceToHost, cs));
+        HIPCHK(hipEventRecord(b->ev_copy, cs));
+    }
+    HIPCHK(hipEventSynchronize(b->ev_copy));      // the copies only: rounds queued behind them meanwhile are not waited for
+    *total = ht; *allele = ha;
     return RMX_OK;
 }
 
@@ -1649,8 +1702,10 @@ int rmx_expected_ll_param_grid(rmx_batch *b, int32_t r, int32_t param_id, const 
 // one host round trip for the whole list.
 // shared tail of the batched objective calls: stage the listed restarts' parameters, rebuild their
 // state tables, evaluate every restart's sample, reduce, copy back nout values per request
+static inline long long now_ns() { return std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 static int run_ell_batch(rmx_batch *b, int nreq, const int32_t *restarts, bool grad, double *out, int mask = CM_ALL) {
     const Dev &d = b->d;
+    const long long t_in = now_ns();
     const int W = 1 + RMX_MAX_CLONES;
     const int nout = grad ? W : 1;
     int maxcnt = 0;
@@ -1717,9 +1772,15 @@ static int run_ell_batch(rmx_batch *b, int nreq, const int32_t *restarts, bool g
         for (int i = 0; i < nreq; i++) { b->tables_dirty[restarts[i]] = 0; b->segc_dirty[restarts[i]] = 1; b->ab_dirty[restarts[i]] = 1; }   // comp_dirty / cache_stale: set by the callers' setters
         if (!by_value) HIPCHK(hipMemcpyAsync(b->h_pinned, b->d_batch_out, (size_t)nreq * nout * 8, hipMemcpyDeviceToHost, b->stream));
     }
+    const long long t_launched = now_ns();
     if (by_value) {
         HIPCHK(hipStreamSynchronize(b->stream));
+        const long long t_done = now_ns();
+        b->t_launch_ns += t_launched - t_in; b->t_wait_ns += t_done - t_launched; b->n_rounds++;
         if (int rc_ = report_request_errors(b, nreq, eres, [&](int i) { return (int)restarts[i]; })) return rc_;
+        for (int i = 0; i < nreq * nout; i++) out[i] = b->h_pinned[i];
+        b->t_post_ns += now_ns() - t_done;
+        return RMX_OK;
     } else {
         int rc = check_errors(b, 0, b->R);
         if (rc) return rc;

@@ -3,6 +3,7 @@
 //   compress_cn_states   rmx_compress_cn_states: dense (N,S,M,2) int64 state array -> class tables + class id per segment
 //   weighted_search      rmx_weighted_search: numpy's cumsum / searchsorted(side='right') for the weighted M-step samples
 //                        (reference remixt/cn_model.py:475-480)
+//   weighted_sample_round  rmx_weighted_sample_round: a whole round of that sampling from a strided weight column
 //   Nm1                  scipy.optimize.fmin (Nelder-Mead, one variable) as a resumable state machine: the polish stage
 //                        of scipy.optimize.brute in BreakpointModel.update_param (reference remixt/cn_model.py:553-561)
 // Status codes: 0 ok, 4 = RMX_EUNSUPPORTED, 5 = RMX_EARG (include/remixt_amd.h).
@@ -50,6 +51,36 @@ inline int weighted_search(const double *p, int64_t n, const double *u, int32_t 
         out[j] = std::min<int64_t>(idx, n - 1);
     }
     if (positive) *positive = pos;
+    return 0;
+}
+
+// One round of the weighted M-step sampling (remixt_amd/cn_model.py _sample_without_replacement: `size` distinct indices, successively
+// with probability proportional to the weights = numpy's choice(replace=False, p=...), reference remixt/cn_model.py:475-480): the
+// weights are w[i * stride] / norm (a column of an (N, 2) indicator array, normalised like numpy's `weights / weights.sum()`), the
+// k uniform draws u select indices from their cumulative sum exactly as weighted_search does, and the indices not seen before are
+// appended to found[0 .. *nfound) in the order of the draws (numpy: unique(concatenate(found, new)) by first occurrence), up to cap.
+inline int weighted_sample_round(const double *w, int64_t n, int64_t stride, double norm, const double *u, int32_t k,
+                                 int64_t *found, int32_t *nfound, int32_t cap, int64_t *positive) {
+    if (!w || n < 1 || stride < 1 || !(norm > 0.) || (k > 0 && !u) || !found || !nfound || *nfound < 0 || *nfound > cap) return 5;
+    std::vector<double> cdf((size_t)n);
+    double acc = 0.;
+    int64_t pos = 0;
+    for (int64_t i = 0; i < n; i++) { const double p = w[(size_t)(i * stride)] / norm; acc += p; cdf[(size_t)i] = acc; pos += p > 0.; }
+    const double last = cdf[(size_t)n - 1];
+    for (int64_t i = 0; i < n; i++) cdf[(size_t)i] /= last;
+    if (positive) *positive = pos;
+    std::vector<int64_t> seen(found, found + *nfound);
+    std::sort(seen.begin(), seen.end());
+    int32_t nf = *nfound;
+    for (int32_t j = 0; j < k && nf < cap; j++) {
+        int64_t idx = (int64_t)(std::upper_bound(cdf.begin(), cdf.end(), u[j]) - cdf.begin());
+        idx = std::min<int64_t>(idx, n - 1);
+        auto it = std::lower_bound(seen.begin(), seen.end(), idx);
+        if (it != seen.end() && *it == idx) continue;
+        seen.insert(it, idx);
+        found[nf++] = idx;
+    }
+    *nfound = nf;
     return 0;
 }
 

@@ -246,3 +246,96 @@ def lbfgsb_gen(x0, bounds, maxcor=10, ftol=2.2204460492503131e-09, gtol=1e-5, ma
         warnflag = 2
     msg = status_messages[task[0]] + ": " + task_messages[task[1]]
     return LbfgsbResult(x, f, g, nfev, n_iterations, warnflag, msg, warnflag == 0)
+
+
+class _LbfgsbState(object):
+    """Everything scipy's `_minimize_lbfgsb` keeps for one run (scipy 1.15), preallocated: the lean form of lbfgsb_gen for
+    lbfgsb_lockstep (no generator, no per-iteration array allocation).  Same calls of `_lbfgsb.setulb` with the same values."""
+    __slots__ = ('n', 'm', 'x', 'lo', 'hi', 'nbd', 'g', 'wa', 'iwa', 'task', 'ln_task', 'lsave', 'isave', 'dsave', 'cx', 'cf', 'cg',
+                 'f', 'nfev', 'nit', 'done', 'factr', 'gtol', 'maxls', 'maxfun', 'maxiter')
+
+    def __init__(self, x0, lo, hi, maxcor, ftol, gtol, maxfun, maxiter, maxls):
+        n = len(x0)
+        self.n, self.m = n, maxcor
+        self.lo, self.hi = lo, hi
+        self.nbd = np.full(n, 2, dtype=np.int32)
+        self.x = np.clip(np.asarray(x0, dtype=np.float64).ravel(), lo, hi)
+        self.g = np.zeros(n, dtype=np.float64)
+        m = maxcor
+        self.wa = np.zeros(2 * m * n + 5 * n + 11 * m * m + 8 * m, np.float64)
+        self.iwa = np.zeros(3 * n, dtype=np.int32)
+        self.task = np.zeros(2, dtype=np.int32); self.ln_task = np.zeros(2, dtype=np.int32)
+        self.lsave = np.zeros(4, dtype=np.int32); self.isave = np.zeros(44, dtype=np.int32); self.dsave = np.zeros(29, dtype=np.float64)
+        self.cx = self.x.copy(); self.cf = 0.0; self.cg = np.zeros(n, dtype=np.float64)
+        self.f = 0.0
+        self.nfev = 0; self.nit = 0; self.done = False
+        self.factr = ftol / np.finfo(float).eps; self.gtol = gtol; self.maxls = maxls; self.maxfun = maxfun; self.maxiter = maxiter
+
+
+def lbfgsb_lockstep(x0s, bounds, evaluate, maxcor=10, ftol=2.2204460492503131e-09, gtol=1e-5, maxfun=15000, maxiter=15000, maxls=20):
+    """scipy.optimize.minimize(method='L-BFGS-B', jac=True-style (f, g), bounds=bounds) for several starting points at once, the
+    runs advancing in lock step: `evaluate(ids, X)` gets the indices of the runs that wait for an evaluation and their points as
+    the rows of X (a (k, n) float64 array it may keep) and returns (F (k,), G (k, n)).  Each run makes exactly the calls of
+    `_lbfgsb.setulb` that lbfgsb_gen -- i.e. scipy's own driver -- makes, with the same values (tests/test_lockstep.py compares the
+    two and scipy.optimize.minimize bit for bit); only the Python around them is flat: no generators, arrays made once.
+    Returns the list of LbfgsbResult."""
+    from scipy.optimize import _lbfgsb
+    from scipy.optimize._lbfgsb_py import status_messages, task_messages
+    setulb = _lbfgsb.setulb
+    lo = np.array([b[0] for b in bounds], dtype=np.float64)
+    hi = np.array([b[1] for b in bounds], dtype=np.float64)
+    runs = [_LbfgsbState(x0, lo, hi, maxcor, ftol, gtol, maxfun, maxiter, maxls) for x0 in x0s]
+    n = len(lo)
+    X = np.zeros((len(runs), n), dtype=np.float64)
+
+    def advance(s, resumed):
+        """Run `s` until it wants (f, g) at a new point (True) or ends (False).  resumed: the evaluation an FG task asked for has
+        arrived -- finish that branch (f, g = cf, cg) first."""
+        if resumed:
+            s.f = s.cf; s.g[:] = s.cg
+        while True:
+            setulb(s.m, s.x, s.lo, s.hi, s.nbd, s.f, s.g, s.factr, s.gtol, s.wa, s.iwa, s.task, s.lsave, s.isave, s.dsave, s.maxls, s.ln_task)
+            t0 = s.task[0]
+            if t0 == 3:
+                if not np.array_equal(s.x, s.cx):
+                    s.cx[:] = s.x
+                    return True
+                s.f = s.cf; s.g[:] = s.cg
+            elif t0 == 1:
+                s.nit += 1
+                if s.nit >= s.maxiter:
+                    s.task[0] = 5; s.task[1] = 504
+                elif s.nfev > s.maxfun:
+                    s.task[0] = 5; s.task[1] = 502
+            else:
+                s.done = True
+                return False
+
+    # ScalarFunction.__init__: (f, g) at the clipped x0 -- the first FG request is served from this evaluation
+    waiting = list(range(len(runs)))
+    first = True
+    while waiting:
+        k = len(waiting)
+        for j, i in enumerate(waiting):
+            X[j] = runs[i].cx
+        F, G = evaluate(waiting, X[:k])
+        nxt = []
+        for j, i in enumerate(waiting):
+            s = runs[i]
+            s.cf = float(F[j]); s.cg[:] = G[j]; s.nfev += 1
+            if advance(s, not first):
+                nxt.append(i)
+        first = False
+        waiting = nxt
+    out = []
+    for s in runs:
+        t0 = int(s.task[0])
+        if t0 == 4:
+            warnflag = 0
+        elif s.nfev > s.maxfun or s.nit >= s.maxiter:
+            warnflag = 1
+        else:
+            warnflag = 2
+        msg = status_messages[t0] + ": " + task_messages[int(s.task[1])]
+        out.append(LbfgsbResult(s.x, s.f, s.cg.copy(), s.nfev, s.nit, warnflag, msg, warnflag == 0))
+    return out

@@ -16,11 +16,30 @@ from .cn_model import BreakpointModel
 from . import synthetic
 
 
+class SampleList(object):
+    """An M-step sample (cn_model.py:475-480) as the ascending list of its segments; converts to the reference's dense 0 / 1
+    mask on demand (np.asarray).  The batched driver uploads lists (rmx_set_sample_lists) and never needs the 50 000-entry mask
+    that BreakpointModel._create_sample builds; the object doubles as the identity token of RemixtBatch._use_sample."""
+    __slots__ = ('indices', 'n', '_mask')
+
+    def __init__(self, indices, n):
+        self.indices, self.n, self._mask = indices, int(n), None
+
+    def __array__(self, dtype=None, copy=None):
+        if self._mask is None:
+            self._mask = np.zeros((self.n,), dtype=int)
+            self._mask[self.indices] = 1
+        return self._mask if dtype is None else self._mask.astype(dtype)
+
+    def __len__(self):
+        return self.n
+
+
 class RestartSet(object):
     """R restarts of one experiment advancing in lockstep on one device."""
 
     def __init__(self, experiment, init_params, max_copy_number, num_clones=3, device=0, quiet=True,
-                 kernel_module=None, seeds=None, strict=False, mstep_threads=8, lockstep=True, native_search=True, sample_prep=True,
+                 kernel_module=None, seeds=None, strict=False, mstep_threads=2, lockstep=True, native_search=True, sample_prep=True,
                  options=None, h_init=None, joint_accept=True, **model_kwargs):
         self.experiment = experiment
         self.native_search = native_search
@@ -184,9 +203,10 @@ class RestartSet(object):
         return [draw(r) for r in range(R)]
 
     def _samples_and_lists(self):
-        """_samples() and, per mask, its ascending index list (the form rmx_set_sample_lists uploads in one transfer)."""
-        masks = self._samples()
-        return masks, [np.flatnonzero(s).astype(np.int32) for s in masks]
+        """One unweighted M-step sample per restart (the draws of _samples()), as SampleLists and as their ascending index lists
+        (the form rmx_set_sample_lists uploads in one transfer)."""
+        lists = [np.sort(m._draw_sample_indices(None)).astype(np.int32) for m in self.models]
+        return [SampleList(lst, m.model.num_segments) for lst, m in zip(lists, self.models)], lists
 
     _MULTI_PARAMS = ('negbin_r_0', 'negbin_r_1', 'betabin_M_0', 'betabin_M_1')
 
@@ -206,13 +226,19 @@ class RestartSet(object):
     def _draw_param_samples(self, names):
         """Weighted samples of the listed parameters, parameter by parameter in the reference's order, and
         the outlier indicators they were weighted with: (samples {name: [per restart]}, indicators)."""
+        fetched = self.batch.fetch_indicators() if (self.batch is not None and hasattr(self.batch, 'fetch_indicators')) else None
+
         def one(r):
             # a restart's indicators, then its draws for all listed parameters in order (its own RNG stream)
             m = self.models[r]
-            c = {'p_outlier_total': np.asarray(m.model.p_outlier_total), 'p_outlier_allele': np.asarray(m.model.p_outlier_allele)}
+            if fetched is not None:
+                c = {'p_outlier_total': fetched[0][r], 'p_outlier_allele': fetched[1][r]}      # views, valid for this M-step
+            else:
+                c = {'p_outlier_total': np.asarray(m.model.p_outlier_total), 'p_outlier_allele': np.asarray(m.model.p_outlier_allele)}
             m._mstep_indicator_cache = c
-            masks = [m._create_sample(m.get_param_sample_weight(name)) for name in names]
-            return c, masks, [np.flatnonzero(s).astype(np.int32) for s in masks]
+            # (the draws of m._create_sample(m.get_param_sample_weight(name)), without the normalised weight copies and the masks)
+            lists = [np.sort(m._draw_sample_indices(m.get_param_sample_weight(name, as_column=True))).astype(np.int32) for name in names]
+            return c, [SampleList(lst, m.model.num_segments) for lst in lists], lists
         R = len(self.models)
         if self.mstep_threads > 1 and R > 1:
             per_restart = list(self._threads().map(one, range(R)))
@@ -285,10 +311,11 @@ class RestartSet(object):
                     evaluate = b.h_batch_evaluator(live)
                 else:
                     def evaluate(ids, xs):
-                        f, g = b.expected_log_likelihood_h_batch([live[i] for i in ids], np.stack(xs))
-                        return [(-float(f[k]), -g[k]) for k in range(len(ids))]
+                        f, g = b.expected_log_likelihood_h_batch([live[i] for i in ids], np.asarray(xs, dtype=float))
+                        return -np.asarray(f), -np.asarray(g)
                 try:
-                    results = lockstep.run_lockstep([lockstep.lbfgsb_gen(h_before[r], bounds) for r in live], evaluate) if live else []
+                    # every restart's L-BFGS-B run (scipy's own routine, its evaluation sequence) in shared rounds
+                    results = lockstep.lbfgsb_lockstep([h_before[r] for r in live], bounds, evaluate) if live else []
                     break
                 except ValueError as err:
                     # The reference raises inside that restart's own process (e.g. total_depth <= 0 at a trial h) and only

@@ -3,6 +3,7 @@
 // process; it prints one line per case that the Python side compares with numpy / scipy / remixt_amd.lockstep.fmin_1d.
 //   host_sanitize nm <case> <x0>         Nelder-Mead on objective <case>: every requested point, then "xopt <x> fcalls <n>"
 //   host_sanitize ws <seed> <n> <k>      weighted_search on a seeded weight vector (zeros included): the k indices
+//   host_sanitize wr <seed> <n> <size> <k>  weighted_sample_round on a strided weight column until <size> distinct indices are found
 //   host_sanitize cc <seed> <N> <S> <M>  compress_cn_states on a seeded table sequence: classes, then the class ids
 #include <cstdio>
 #include <cstdlib>
@@ -57,6 +58,35 @@ int main(int argc, char **argv) {
         printf("\n");
         // argument errors must be refused, not dereferenced
         printf("null %d empty %d\n", rmxh::weighted_search(nullptr, n, u.data(), k, out.data(), &pos), rmxh::weighted_search(p.data(), 0, u.data(), k, out.data(), &pos));
+        return 0;
+    }
+    if (!strcmp(argv[1], "wr") && argc == 6) {
+        // weighted_sample_round on a strided column with zeros: rounds until `size` distinct indices are found; prints them
+        sm_state = strtoull(argv[2], 0, 10);
+        const int64_t n = atoll(argv[3]);
+        const int size = atoi(argv[4]), k = atoi(argv[5]);
+        std::vector<double> q((size_t)n * 2);
+        double norm = 0.;
+        for (int64_t i = 0; i < n; i++) { const double t = sm_unit(); q[(size_t)i * 2] = -1.; q[(size_t)i * 2 + 1] = t < 0.5 ? 0. : t; }
+        for (int64_t i = 0; i < n; i++) norm += q[(size_t)i * 2 + 1];
+        std::vector<int64_t> found((size_t)size);      // cap == size: the round must stop writing at the capacity
+        int32_t nf = 0, rounds = 0;
+        int64_t pos = -1;
+        while (nf < size && rounds < 50) {
+            std::vector<double> u((size_t)k);
+            for (auto &v : u) v = sm_unit();
+            const int rc = rmxh::weighted_sample_round(q.data() + 1, n, 2, norm, u.data(), k, found.data(), &nf, size, &pos);
+            if (rc) { printf("rc %d\n", rc); return 0; }
+            if (pos < size) break;
+            rounds++;
+        }
+        printf("rounds %d positive %lld idx", rounds, (long long)pos);
+        for (int i = 0; i < nf; i++) printf(" %lld", (long long)found[(size_t)i]);
+        printf("\n");
+        int32_t bad = 5;
+        printf("args %d %d %d\n", rmxh::weighted_sample_round(nullptr, n, 2, norm, nullptr, 0, found.data(), &nf, size, &pos),
+               rmxh::weighted_sample_round(q.data() + 1, n, 2, 0., nullptr, 0, found.data(), &nf, size, &pos),
+               rmxh::weighted_sample_round(q.data() + 1, n, 2, norm, nullptr, 0, found.data(), &bad, 4, &pos));
         return 0;
     }
     if (!strcmp(argv[1], "cc") && argc == 6) {

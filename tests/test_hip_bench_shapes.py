@@ -487,8 +487,8 @@ def test_a_restart_whose_h_step_failed_is_not_retried_in_later_iterations(hip, m
     assert list(rs.error_messages) == [1]
     poison['on'] = False
     runs = []
-    real = lockstep.run_lockstep
-    monkeypatch.setattr(lockstep, 'run_lockstep', lambda gens, ev: (runs.append(len(gens)), real(gens, ev))[1])
+    real = lockstep.lbfgsb_lockstep
+    monkeypatch.setattr(lockstep, 'lbfgsb_lockstep', lambda x0s, bounds, ev: (runs.append(len(x0s)), real(x0s, bounds, ev))[1])
     h1 = np.array(rs.models[1].h, dtype=float)
     rs.em_iteration(1, 2)
     assert runs == [2]                                        # one lock-step run, without restart 1

@@ -99,6 +99,50 @@ def test_lbfgsb_gen_reproduces_scipy_minimize():
         assert res.success == ref.success and res.message == ref.message
 
 
+def test_lbfgsb_lockstep_reproduces_scipy_minimize_for_every_run():
+    """The flat lock-step driver (what RestartSet's h M-step runs): several runs at once, each visiting the points of its own
+    scipy.optimize.minimize(method='L-BFGS-B') in the same order and ending on the same result bit for bit -- also when the runs
+    finish after different numbers of evaluations and when a start lies outside the bounds."""
+    import scipy.optimize
+    from remixt_amd import lockstep
+    if not lockstep.lbfgsb_available():
+        pytest.skip('scipy layout other than 1.15')
+    rng = np.random.RandomState(11)
+    n, R = 3, 7
+    probs = []
+    for r in range(R):
+        A = rng.randn(n, n); A = A @ A.T + np.eye(n)
+        c = rng.randn(n) * (r + 1)
+        probs.append((A, c))
+    fun = lambda r, x: float(0.5 * x @ probs[r][0] @ x - probs[r][1] @ x + np.sum(np.log1p(x * x)))
+    grad = lambda r, x: probs[r][0] @ x - probs[r][1] + 2 * x / (1 + x * x)
+    x0s = [rng.rand(n) * 12.0 for _ in range(R)]
+    bounds = [(1e-8, 10.)] * n
+    refs, seen_ref = [], []
+    for r in range(R):
+        seen = []
+        refs.append(scipy.optimize.minimize(lambda x, r=r, seen=seen: (seen.append(np.array(x)), fun(r, x))[1], x0s[r], method='L-BFGS-B',
+                                            jac=lambda x, r=r: grad(r, x), bounds=bounds))
+        seen_ref.append(seen)
+    seen = [[] for _ in range(R)]
+    rounds = []
+
+    def evaluate(ids, X):
+        rounds.append(list(ids))
+        F = np.zeros(len(ids)); G = np.zeros((len(ids), n))
+        for j, r in enumerate(ids):
+            seen[r].append(np.array(X[j])); F[j] = fun(r, X[j]); G[j] = grad(r, X[j])
+        return F, G
+    res = lockstep.lbfgsb_lockstep(x0s, bounds, evaluate)
+    assert rounds[0] == list(range(R)) and len(rounds) == max(len(s_) for s_ in seen)          # shared rounds
+    assert len(set(len(s_) for s_ in seen)) > 1                                                     # ... of runs of different lengths
+    for r in range(R):
+        assert len(seen[r]) == len(seen_ref[r]) and all(np.array_equal(a, b) for a, b in zip(seen[r], seen_ref[r]))
+        assert np.array_equal(res[r].x, refs[r].x) and res[r].fun == refs[r].fun and res[r].nfev == refs[r].nfev and res[r].nit == refs[r].nit
+        assert res[r].success == refs[r].success and res[r].message == refs[r].message
+        assert np.array_equal(res[r].jac, refs[r].jac)
+
+
 def test_lockstep_runs_generators_together():
     from remixt_amd import lockstep
     calls = []
@@ -129,3 +173,28 @@ def test_sample_without_replacement_matches_numpy_distribution():
     assert len(set(s.tolist())) == 200 and s.min() >= 0 and s.max() < 5000
     with pytest.raises(ValueError):
         draw(np.random.RandomState(0), 6, 3, np.array([.5, .5, 0, 0, 0, 0]))
+
+
+@pytest.mark.parametrize('n,size,zero_frac', [(50000, 200, 0.0), (3000, 200, 0.5), (400, 40, 0.8), (250, 25, 0.0)])
+def test_weight_column_sampling_equals_the_dense_weight_path(n, size, zero_frac):
+    """The restart driver draws its weighted M-step samples from a COLUMN of the outlier indicator array (WeightColumn ->
+    rmx_weighted_sample_round, one native call per round of draws, no normalised copy, no mask): same indices in the same
+    order and the same RNG stream afterwards as the dense path -- including rounds that have to be repeated because of
+    duplicate draws (few positive weights) and the "fewer non-zero entries" error."""
+    from remixt_amd import cn_model as cm
+    if cm._native_sample_round() is None:
+        pytest.skip('libremixt_hip.so not built')
+    rng = np.random.RandomState(n)
+    for col in (0, 1):
+        q = rng.rand(n, 2)
+        q[rng.rand(n) < zero_frac, col] = 0.
+        w = q[:, col]
+        norm = w.sum()
+        r1, r2 = np.random.RandomState(5), np.random.RandomState(5)
+        a = cm._sample_without_replacement(r1, n, size, cm.WeightColumn(q, col, norm))
+        b = cm._sample_without_replacement(r2, n, size, w / norm)
+        assert np.array_equal(a, b) and len(set(a.tolist())) == size
+        assert r1.rand() == r2.rand()                                  # the two consumed the same number of draws
+    q = np.zeros((n, 2)); q[:size - 1, 0] = 1.
+    with pytest.raises(ValueError):
+        cm._sample_without_replacement(np.random.RandomState(1), n, size, cm.WeightColumn(q, 0, q[:, 0].sum()))

@@ -122,6 +122,22 @@ def test_weighted_search_under_sanitizers_equals_numpy(harness, seed, n, k):
     assert lines[1] == 'null 5 empty 5'
 
 
+@pytest.mark.parametrize('seed,n,size,k', [(11, 50000, 200, 308), (12, 500, 200, 308), (13, 40, 20, 5)])
+def test_weighted_sample_round_under_sanitizers(harness, seed, n, size, k):
+    """Distinct, in range, positive-weight indices only; the capacity of `found` is respected; bad arguments are refused."""
+    lines = harness('wr', seed, n, size, k)
+    head = lines[0].split()
+    nxt = _splitmix(seed)
+    unit = lambda: float(nxt() >> 11) / 9007199254740992.
+    w = np.array([(0. if t < 0.5 else t) for t in (unit() for _ in range(n))])
+    idx = [int(v) for v in head[5:]]
+    assert len(idx) == len(set(idx)) <= size and all(0 <= i < n and w[i] > 0. for i in idx)
+    assert int(head[3]) == int(np.count_nonzero(w > 0))
+    if int(head[3]) >= size:
+        assert len(idx) == size
+    assert lines[1] == 'args 5 5 5'
+
+
 @pytest.mark.parametrize('seed,N,S,M', [(5, 1, 4, 2), (6, 300, 9, 2), (7, 200, 47, 3)])
 def test_compress_cn_states_under_sanitizers(harness, seed, N, S, M):
     lines = harness('cc', seed, N, S, M)

@@ -30,6 +30,7 @@ def factory(restarts):
 b.h_batch_evaluator = factory
 tot = 0.
 NIT = 6
+c0 = [b.info(i) for i in (60, 61, 62, 63)]
 for i in range(NIT):
     acc['t_first'] = None
     rs.em_iteration(2 + i, 5)
@@ -37,3 +38,7 @@ for i in range(NIT):
 print('%d rounds per M-step; per round: %.1f us in the objective call, %.1f us outside (optimiser steps); %.2f ms per M-step' % (
     acc['n'] / NIT, acc['in'] / acc['n'] * 1e6, (tot - acc['in']) / acc['n'] * 1e6, tot / NIT * 1e3))
 
+c1 = [b.info(i) for i in (60, 61, 62, 63)]
+n = max(c1[3] - c0[3], 1)
+print('inside the C call, per batched sampled-objective round (%d rounds, h rounds and others): %.1f us preparing + launching, %.1f us waiting for the device, %.1f us after the wait'
+      % (n, (c1[0] - c0[0]) / n * 1e-3, (c1[1] - c0[1]) / n * 1e-3, (c1[2] - c0[2]) / n * 1e-3))
