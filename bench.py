@@ -68,6 +68,7 @@ def parse(argv=None):
     ap.add_argument('--max-cn', type=int, default=8)
     ap.add_argument('--restarts', type=int, default=16, help='restarts per GPU (weak scaling, the default)')
     ap.add_argument('--total-restarts', type=int, default=0, help='strong scaling: this many restarts in total, sharded over the GPUs (BASELINE configs[3]: 64)')
+    ap.add_argument('--strong-total', type=int, default=64, help='N > 1 in the default (weak) mode also times the fixed job of BASELINE configs[3] with this many restarts in total; 0 = skip')
     ap.add_argument('--datasets', type=int, default=1, help='2 = BASELINE configs[4]: two tumour samples on the same segmentation / breakpoints, fitted independently')
     ap.add_argument('--update-iters', type=int, default=5)
     ap.add_argument('--groups', type=int, default=2, help='restart groups per GPU and dataset (own stream + host thread each; results do not depend on it)')
@@ -388,6 +389,16 @@ def main(argv=None, kernel_module=None, dist_backend='nccl', script=None):
     else:
         total_fitted = R
 
+    # N > 1: the weak-scaling line above keeps BASELINE configs[2]'s 16 restarts on every GPU, so that the driver's N = 1, 2, 4, 8
+    # values are the same per-GPU workload; the north-star's multi-GPU target is configs[3], a FIXED 64-restart job cut over the
+    # GPUs -- measured here as well, in the same process group, and reported beside it (`configs3_strong_64`)
+    strong64 = None
+    if world > 1 and not strong and ND == 1 and args.strong_total >= world:
+        try:
+            strong64 = strong_64_over_ranks(args, rs, device, rank, world, dist, torch, on_gpu, kernel_module, host_kw)
+        except Exception as err:
+            strong64 = {'error': str(err)}
+
     if rank == 0:
         total_ms = sum(v[0] for v in prof.values())
         # dominant kernel of the hot path = the data-parallel (segment x state) kernel with the largest
@@ -442,6 +453,8 @@ def main(argv=None, kernel_module=None, dist_backend='nccl', script=None):
         }
         if gathered:
             line['final_gather'] = gathered
+        if strong64 is not None:
+            line['configs3_strong_64'] = strong64
         single = world == 1 and on_gpu and ND == 1 and not strong and not args.no_mstep
         if single and not args.no_fit_from_init:
             try:
@@ -621,6 +634,46 @@ def extra_states(args, rs_main, device):
            'kernels': dict((k, {'ms': round(v[0], 3), 'n': v[1]}) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0]))}
     _release(rs)
     return out
+
+
+def strong_64_over_ranks(args, rs_main, device, rank, world, dist, torch, on_gpu, kernel_module, host_kw):
+    """BASELINE configs[3] on this process group: 64 restarts in total, restart i on rank i mod world, 8 timed EM iterations
+    between barriers, MAX over ranks."""
+    from remixt_amd import synthetic
+    from remixt_amd.restarts import RestartGroups
+    _release(rs_main)
+    e = synthetic.make_experiment(args.segments, num_clones=args.clones, max_copy_number=args.max_cn, num_chains=23, seed=0)
+    T = args.strong_total
+    params = synthetic.make_init_params(e, T, args.max_cn, num_clones=args.clones)
+    ids = list(range(rank, T, world))
+    groups = args.groups if len(ids) <= 16 else max(args.groups, (len(ids) + 15) // 16)
+    rs = RestartGroups(e, [params[i] for i in ids], args.max_cn, groups=groups, num_clones=args.clones, device=device, quiet=True,
+                       seeds=[1000 + i for i in ids], kernel_module=kernel_module, **host_kw)
+    for m, v in zip(rs.models, rs.calculate_elbo()):
+        m.prev_elbo = float(v)
+    nsteps = 8 if kernel_module is None else 1
+    warm = 2 if kernel_module is None else 0
+    if warm:
+        rs.run(warm, 0, args.update_iters)
+
+    def fence():
+        rs.synchronize()
+        if on_gpu:
+            torch.cuda.synchronize()
+        dist.barrier()
+    fence()
+    t0 = time.perf_counter()
+    rs.run(nsteps, warm, args.update_iters)
+    fence()
+    dt = time.perf_counter() - t0
+    cdev = 'cuda' if dist.get_backend() == 'nccl' else 'cpu'
+    tt = torch.tensor([dt], dtype=torch.float64, device=cdev)
+    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    dt = float(tt.item())
+    _release(rs)
+    return {'workload': 'BASELINE configs[3]: %d restarts in total over %d GPUs (%d on rank 0, %d restart groups each)' % (T, world, len(ids), groups),
+            'scaling': 'strong', 'value': T * nsteps / dt, 'unit': 'EM iterations/s', 'ms_per_step': dt / nsteps * 1e3, 'steps': nsteps, 'warmup': warm,
+            'restarts_total': T, 'restarts_this_rank': len(ids)}
 
 
 def strong_scaling_proxy(args, rs_main, device):

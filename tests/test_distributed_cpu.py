@@ -57,8 +57,11 @@ def _bench(extra, env_extra=None):
 
 def test_bench_gpus_2_launches_two_ranks():
     """`python bench.py --gpus 2` outside torchrun starts the two ranks itself (--gpus was ignored)."""
-    line = _bench(['--gpus', '2', '--restarts', '2'])
+    line = _bench(['--gpus', '2', '--restarts', '2', '--strong-total', '5'])
     assert line['n_gpus'] == 2 and line['config']['world_size_observed'] == 2
+    # ... and the fixed job of BASELINE configs[3] beside the weak-scaling line (5 restarts here: 3 + 2)
+    s64 = line['configs3_strong_64']
+    assert s64['scaling'] == 'strong' and s64['restarts_total'] == 5 and s64['restarts_this_rank'] == 3 and s64['value'] > 0
     assert line['scaling'] == 'weak' and line['config']['restarts_total'] == 4 and line['config']['restarts_this_rank'] == 2
     assert line['final_gather']['records'] == 4
     # the gather is the real message: a float64 and an int8 record per restart (SURVEY.md 8e)
