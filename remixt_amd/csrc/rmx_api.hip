@@ -1251,10 +1251,11 @@ static int p_cn_front(rmx_batch *b, int r0, int r1, bool skip_frame, bool snapsh
             memset(&m, 0, sizeof m);
             m.S = d.S; m.SP = d.SP; m.M = d.M; m.D = d.D; m.C = d.C; m.N = d.N; m.NBE = d.NBE; m.cn_max = d.cn_max; m.r0 = r0; m.r1 = r1;
             m.PE2P = d.NBE > 0 ? b->pe2p : 0; m.SPC = NCT * 16; m.VR = std::max(4 * KB, ((NCT * 15 + 7) / 8) * 8); m.pen = d.pen;
+            m.pad_ = d.tmodel;
             m.chain_start = d.chain_start; m.chain_end = d.chain_end; m.chain_list = d.chain_list_fast; m.chain_tc = d.chain_tc; m.chain_cls = d.chain_cls;
             m.be_n = d.be_n; m.chain_be = d.chain_be; m.fe = d.fe; m.Wf = d.Wf; m.Wb = d.Wb; m.pe2_lt = d.pe2x_lt; m.af = d.af; m.ab = d.ab; m.tot = d.tot;
             m.fa = d.fa; m.fb = d.fb; m.mrow = d.mrow; m.err = d.err; m.dbg = b->d_dbg;
-            const size_t lds = (size_t)2 * m.VR * 4 * 8 + (size_t)2 * 4 * m.PE2P * 8 + 64 * 8 + (size_t)(KB / 2) * 4 * m.SPC * 4 + (size_t)b->be_cap * 4 + 64;
+            const size_t lds = (size_t)2 * m.VR * 4 * 8 + (size_t)2 * 4 * m.PE2P * 8 + (size_t)6 * m.PE2P * 8 + 64 * 8 + (size_t)(KB / 2) * 4 * m.SPC * 4 + (size_t)b->be_cap * 4 + 64;
             void (*kf)(FbmArgs) = KB == 8 ? k_fbm<8> : (KB == 16 ? k_fbm<16> : (KB == 28 ? k_fbm<28> : (KB == 36 ? k_fbm<36> : (KB == 42 ? k_fbm<42> : k_fbm<44>))));
             if (KB > 0 && NCT <= 12 && lds <= kLdsBudget) {
                 HIPCHK(hipFuncSetAttribute((const void *)kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

@@ -786,14 +786,16 @@ __global__ __launch_bounds__(NTMAX) void k_fbv(FbvArgs a) {
 //     element; wave 0's sum lanes store the forward scales for hmm_log_norm_const;
 //   * the three waves of a SIMD run at different priorities, so that one wave's result code overlaps the others' products
 //     instead of all three leaving the matrix pipe idle together (tools/micro/fbm_loop_bench.hip);
-//   * breakend steps (2 % of the steps): the weights are restart-specific, W_i[q][o] = exp(-pen a(q,o)) * tab_i[idx(q,o)]
-//     with the clone-product tables of k_brk_lut (LDS-DMA, a run of plain steps ahead) and 16-bit pair codes in LDS, read
-//     into registers at the start of the step; each k-block issues four MFMAs, one per restart's B operand, and result row i keeps accumulator i.
+//   * breakend steps (2 % of the steps): the weights are restart-specific, W_i[q][o] = W[q][o] * tab2_i[idx(q,o)] (the plain weight
+//     times an entry of the clone-product table of k_brk_lut, rescaled in LDS when it has landed: LDS-DMA, a run of plain steps
+//     ahead).  Four restarts with four different B operands leave an MFMA one useful row in four, so these steps run on the vector
+//     ALU: lane (kq, c) multiplies its resident weights w[kb] by the table entries (16-bit row offsets per pair in LDS) and by its
+//     rows' vector elements of all four restarts; the four lanes of a column are added at the end.
 // Summation order is fixed: repeated runs are bit-identical.
 // grid (chains of one state-table class, ceil(restarts / 4), 2 directions), block 64 NW.
 // =============================================================================
 struct FbmArgs {
-    int S, SP, M, D, C, N, NBE, cn_max, r0, r1, PE2P, SPC, VR, pad_;
+    int S, SP, M, D, C, N, NBE, cn_max, r0, r1, PE2P, SPC, VR, pad_;      // pad_: the transition model of the tables (0 / 1)
     double pen;
     const int32_t *chain_start, *chain_end, *chain_list, *chain_tc, *chain_cls, *be_n, *chain_be;
     const double *fe, *Wf, *Wb, *pe2_lt;
@@ -859,30 +861,30 @@ __global__ __launch_bounds__(768) void k_fbm(FbmArgs a) {
     // ---- LDS carve-up ---------------------------------------------------------------------------
     double *vec = (double *)smem_raw;                           // [2][VR][4]   vectors, restart-interleaved, double-buffered by step parity
     double *tab = vec + (size_t)2 * VR * 4;                     // [2][PE2P][4] clone-product weights of the current and the next breakend, restart-interleaved (LDS-DMA)
-    double *wa = tab + (size_t)2 * 4 * a.PE2P;                  // [64]         exp(-pen * allele distance)
-    unsigned *codel = (unsigned *)(wa + 64);                    // [KB / 2][4][SPC] pair codes of (row q -> column o), two k-blocks per word
+    double *wa = tab + (size_t)2 * 4 * a.PE2P;                  // [64]         exp(+pen * kt), kt = sum of the absolute total differences a table entry stands for
+    double *tab2 = wa + 64;                                     // [PE2P][6]    this breakend step's rescaled table, rows of four restarts at a 48-byte stride (16 bank slots instead of 8)
+    unsigned *codel = (unsigned *)(tab2 + (size_t)6 * a.PE2P);  // [KB / 2][4][SPC] pair codes of (row q -> column o), two k-blocks per word
     int *bel = (int *)(codel + (size_t)(KB / 2) * 4 * SPC);     // adjacencies of this chain's breakends
     const int be_lo = a.chain_be[2 * chain], be_hi = a.chain_be[2 * chain + 1];
     if (be_hi > be_lo) {
-        // code of the pair (row q -> column o) at a breakend adjacency of this chain and direction: index of the
-        // clone-product weight (differences of the tumour clones' totals; the normal clone's is 0 inside a class)
-        // in the low 10 bits, the allele distance (< 64) above; word [p][k][o] holds rows 4 (2 p) + k and 4 (2 p + 1) + k.
-        // Rows / columns past S: 0.
-        const int8_t *src = (dir == 0 ? a.af : a.ab) + (size_t)a.chain_tc[chain] * S * S;
+        // code of the pair (row q -> column o) at a breakend adjacency of this chain and direction: 48 x the index of the
+        // clone-product weight (differences of the tumour clones' totals; the normal clone's is 0 inside a class) = the byte offset of
+        // its row of four restarts in the interleaved table; word [p][k][o] holds rows 4 (2 p) + k and 4 (2 p + 1) + k.
+        // Rows / columns past S: 0.  (The allele distance is not needed: the step multiplies the PLAIN weight, below.)
         const int8_t *tg = a.tot + (size_t)a.chain_cls[chain] * S * M;
         const int off_ = a.cn_max + 1, sg_ = dir == 0 ? 1 : -1;
-        const unsigned ones_code = (unsigned)(M == 2 ? D : D * D);      // table entry n2 holds 1 (k_brk_lut), allele distance 0: weight 1
+        const unsigned ones_code = (unsigned)(M == 2 ? D : D * D);      // table entry n2 holds 1 (k_brk_lut)
         for (int i = t; i < (KB / 2) * 4 * SPC; i += NT) {
             const int ls = i % SPC, pk_ = i / SPC, k_ = pk_ & 3, p_ = pk_ >> 2;      // lane slot 16 w + c: state column 15 w + c, c = 15: the ones column
             const int o = (ls >> 4) * 15 + (ls & 15);
             unsigned word = 0;
             for (int h = 0; h < 2; h++) {
                 const int q = 4 * (2 * p_ + h) + k_;
-                if ((ls & 15) == 15) word |= ones_code << (16 * h);
+                if ((ls & 15) == 15) word |= (ones_code * 48u) << (16 * h);
                 else if (q < S && o < S) {
                     int idx = 0;
                     for (int c = 1; c < M; c++) idx = idx * D + sg_ * ((int)tg[q * M + c] - (int)tg[o * M + c]) + off_;
-                    word |= ((unsigned)idx | ((unsigned)src[(size_t)q * S + o] << 10)) << (16 * h);
+                    word |= ((unsigned)idx * 48u) << (16 * h);
                 }
             }
             codel[i] = word;
@@ -890,7 +892,7 @@ __global__ __launch_bounds__(768) void k_fbm(FbmArgs a) {
         for (int i = t; i < be_hi - be_lo; i += NT) bel[i] = a.be_n[be_lo + i];
     }
     for (int i = t; i < 2 * VR * 4; i += NT) vec[i] = 0.;
-    for (int i = t; i < 64; i += NT) wa[i] = exp(-a.pen * (double)i);
+    for (int i = t; i < 64; i += NT) wa[i] = exp(a.pen * (double)i);      // exp(+pen kt): table entry -> factor on the plain weight (breakend steps)
     // ---- stationary weights: B operands of this wave's 15 columns and the ones column, every k-block ---------------
     double w[KB];
     {
@@ -997,42 +999,77 @@ __global__ __launch_bounds__(768) void k_fbm(FbmArgs a) {
             be_buf ^= 1;
             if (be_adj >= 0) FBM_FETCH(be_i, be_buf)            // the next breakend's tables, into the other buffer
             FB_STAMP(1)
+            // tab -> tab2 (rescaled, restrided): W_i[q][o] = exp(-pen (k - kt)) tab_i[ix] = W[q][o] tab2_i[ix] with tab2_i[ix] = tab_i[ix] exp(+pen kt(ix)),
+            // kt = the absolute total differences ix stands for -- the PLAIN weight, resident in this lane's registers, times one entry
+            {
+                const double *tw = tab + (size_t)(be_buf ^ 1) * 4 * a.PE2P;      // (be_buf was flipped above: this step's table)
+                const int n2_ = M == 2 ? D : D * D, toff_ = a.cn_max + 1;
+                for (int e_ = t; e_ <= n2_; e_ += NT) {      // (entry n2: the ones columns' 1)
+                    const int da_ = M == 3 ? abs(e_ / D - toff_) : abs(e_ - toff_), db_ = M == 3 ? abs(e_ % D - toff_) : 0;
+                    const int kt_ = a.pad_ == 0 ? da_ + db_ : (da_ != 0) + (db_ != 0);      // transition model 0: |d|, 1: [d != 0] (bpmodel.pyx:606-616)
+                    const double f_ = e_ < n2_ ? wa[kt_ & 63] : 1.0;
+                    const double2 *row = reinterpret_cast<const double2 *>(tw + (size_t)e_ * 4);
+                    double2 r01 = row[0], r23 = row[1];
+                    r01.x *= f_; r01.y *= f_; r23.x *= f_; r23.y *= f_;
+                    double2 *dst = reinterpret_cast<double2 *>(tab2 + (size_t)e_ * 6);
+                    dst[0] = r01; dst[1] = r23;
+                }
+            }
+            FB_BARRIER();
             double e;
             gload8(e, eptr);
             eptr += rstep;
+            // The weights differ per restart, so the four rows of an MFMA cannot share a B operand (four MFMAs per k-block, each with one
+            // useful row): the products run on the vector ALU instead.  Lane (kq, c) owns rows 4 kb + kq of column c -- exactly its B-operand
+            // registers w[kb] -- and accumulates acc_i += a_i[q] (w[kb] tab2_i[ix(q, c)]) for the four restarts; the four lanes of a column
+            // (kq = 0..3) are added at the end in a fixed order.  19 000 -> ~8 000 cycles per breakend step.
             double acc[FBM_NV] = {0., 0., 0., 0.};
-            const fbm_d2 *apc = reinterpret_cast<const fbm_d2 *>(vec + (size_t)((k - 1) & 1) * VR * 4 + (kq * 4 + ib) * 2);     // pair p: + 16 p
-            // the reduction index in chunks of CHP pairs of k-blocks: a chunk's pair codes come first (one round trip, then every
-            // LDS address of the chunk is known); chunks keep the step inside the register budget next to the resident W operands
-            constexpr int NPAIR = KB / 2;
-            constexpr int CHP = NPAIR % 11 == 0 ? 11 : (NPAIR % 9 == 0 ? 9 : (NPAIR % 8 == 0 ? 8 : (NPAIR % 7 == 0 ? 7 : (NPAIR % 4 == 0 ? 4 : 1))));
             const unsigned *cw = codel + (size_t)kq * SPC + (wave * 16 + c16);
-#pragma unroll 1
-            for (int c0 = 0; c0 < NPAIR; c0 += CHP) {
-                unsigned cpk[CHP];
+            const char *tbb = reinterpret_cast<const char *>(tab2);
+            (void)tb;
+            // all row offsets first (one LDS round trip), then the pairs with the next pair's operands requested before this pair's
+            // products: a pair is otherwise two dependent LDS round trips (offsets, then rows) in front of 16 FMAs
+            constexpr int NPAIR = KB / 2, CH0 = (NPAIR + 1) / 2;      // the offsets in two chunks (register budget)
+            unsigned cpk[CH0];
+            // vector elements: the MFMA A-operand image (lane (kq, c) reads a_{c mod 4}[4 kb + kq], two k-blocks per 16 bytes); restart i's
+            // element reaches all 16 lanes of the row through the FMA's own DPP operand (row_newbcast:i) -- 16 bytes of LDS per pair
+            // instead of 64
+            const fbm_d2 *apd = reinterpret_cast<const fbm_d2 *>(vec + (size_t)((k - 1) & 1) * VR * 4 + (kq * 4 + ib) * 2);     // pair p: + 16 p
+            fbm_d2 an;
+            double2 tn[4];
+#define FBM_BE_LOAD(p_, c_)                                                                                                        \
+            {                                                                                                                      \
+                an = apd[(p_) * 16];                                                                                               \
+                const char *r0_ = tbb + ((c_) & 0xffffu), *r1_ = tbb + ((c_) >> 16);                                               \
+                tn[0] = *reinterpret_cast<const double2 *>(r0_); tn[1] = *reinterpret_cast<const double2 *>(r0_ + 16);             \
+                tn[2] = *reinterpret_cast<const double2 *>(r1_); tn[3] = *reinterpret_cast<const double2 *>(r1_ + 16);             \
+            }
+#define FBM_BE_FMA(acc_, a_, x_, i_) asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:" #i_ " row_mask:0xf bank_mask:0xf" : "+v"(acc_) : "v"(a_), "v"(x_))
 #pragma unroll
-                for (int u = 0; u < CHP; u++) cpk[u] = cw[(size_t)(c0 + u) * 4 * SPC];
+            for (int c0 = 0; c0 < NPAIR; c0 += CH0) {
 #pragma unroll
-                for (int u = 0; u < CHP; u++) {
-                    const fbm_d2 av = apc[(c0 + u) * 16];
+                for (int u = 0; u < CH0; u++) if (c0 + u < NPAIR) cpk[u] = cw[(size_t)(c0 + u) * 4 * SPC];
+                FBM_BE_LOAD(c0, cpk[0])
 #pragma unroll
-                    for (int h = 0; h < 2; h++) {
-                        const unsigned c_ = (cpk[u] >> (16 * h)) & 0xffffu;
-                        const double wv = wa[c_ >> 10];
-                        const double2 t01_ = *reinterpret_cast<const double2 *>(tb + (size_t)(c_ & 1023u) * 4);
-                        const double2 t23_ = *reinterpret_cast<const double2 *>(tb + (size_t)(c_ & 1023u) * 4 + 2);
-                        const double t0 = t01_.x, t1 = t01_.y, t2 = t23_.x, t3 = t23_.y;
-                        const double ak = h ? av.y : av.x;
-                        // (the ones column's code selects weight 1 for every restart: every row of each product holds its restart's sum)
-                        acc[0] = __builtin_amdgcn_mfma_f64_4x4x4f64(ak, wv * t0, acc[0], 0, 0, 0);
-                        acc[1] = __builtin_amdgcn_mfma_f64_4x4x4f64(ak, wv * t1, acc[1], 0, 0, 0);
-                        acc[2] = __builtin_amdgcn_mfma_f64_4x4x4f64(ak, wv * t2, acc[2], 0, 0, 0);
-                        acc[3] = __builtin_amdgcn_mfma_f64_4x4x4f64(ak, wv * t3, acc[3], 0, 0, 0);
-                    }
-                    if (u & 1) __builtin_amdgcn_sched_barrier(0);      // two pairs of k-blocks at a time (register budget)
+                for (int u = 0; u < CH0; u++) {
+                    const int p = c0 + u;
+                    if (p >= NPAIR) break;
+                    const double ax = an.x, ay = an.y;                                 // k-blocks 2 p and 2 p + 1
+                    const double2 t0 = tn[0], t1 = tn[1], t2 = tn[2], t3 = tn[3];      // rows of k-block 2 p (t0, t1) and 2 p + 1 (t2, t3)
+                    if (u + 1 < CH0 && p + 1 < NPAIR) FBM_BE_LOAD(p + 1, cpk[u + 1])
+                    const double w0 = w[2 * p], w1 = w[2 * p + 1];
+                    const double x0 = w0 * t0.x, x1 = w0 * t0.y, x2 = w0 * t1.x, x3 = w0 * t1.y;
+                    const double y0 = w1 * t2.x, y1 = w1 * t2.y, y2 = w1 * t3.x, y3 = w1 * t3.y;
+                    FBM_BE_FMA(acc[0], ax, x0, 0); FBM_BE_FMA(acc[1], ax, x1, 1); FBM_BE_FMA(acc[2], ax, x2, 2); FBM_BE_FMA(acc[3], ax, x3, 3);
+                    FBM_BE_FMA(acc[0], ay, y0, 0); FBM_BE_FMA(acc[1], ay, y1, 1); FBM_BE_FMA(acc[2], ay, y2, 2); FBM_BE_FMA(acc[3], ay, y3, 3);
                 }
             }
-            const double sum = id == 0 ? acc[0] : (id == 1 ? acc[1] : (id == 2 ? acc[2] : acc[3]));   // result row i belongs to restart i's weights
+#undef FBM_BE_FMA
+#undef FBM_BE_LOAD
+            // the four row groups of a column: ((kq 0 + kq 1) + (kq 2 + kq 3)), the same value in all four lanes (a + b == b + a)
+#pragma unroll
+            for (int i = 0; i < FBM_NV; i++) { acc[i] += __shfl_xor(acc[i], 16); acc[i] += __shfl_xor(acc[i], 32); }
+            const double sum = id == 0 ? acc[0] : (id == 1 ? acc[1] : (id == 2 ? acc[2] : acc[3]));   // result lane (i, c) keeps restart i
             FB_STAMP(2)
             FBM_FINISH(sum, e, k)
             FB_STAMP(3)
