@@ -1116,9 +1116,9 @@ __global__ __launch_bounds__(768) void k_fbm(FbmArgs a) {
 //   * wave w owns TWO tiles of 15 state columns + a ones column: columns 30 w .. 30 w + 29 (12 waves at 355 states);
 //   * all LDS reads of the plain steps go through untracked asm into a ring, FBQ_DEPTH pairs of k-blocks ahead of the
 //     MFMAs that consume them (5 reads per pair: the A pair and four table lookups), retired by counted lgkmcnt waits;
-//   * breakend steps (2 % of the steps): W_i[q][o] = exp(-pen (k - SAD(tot_q, tot_o))) * tab_i[idx(tot_q - tot_o)] from the
-//     packed totals (LDS for the rows, registers for the columns) and the quad's interleaved clone-product table (LDS-DMA a
-//     run of plain steps ahead, as k_fbm); four MFMAs per k-block and tile, one per restart's B operand.
+//   * breakend steps (2 % of the steps): W_i[q][o] = W[q][o] tab2_i[idx(tot_q - tot_o)] -- the plain weight (the same lookup) times an
+//     entry of the quad's interleaved clone-product table (LDS-DMA a run of plain steps ahead, rescaled in LDS when it has landed;
+//     its byte address is one v_mad of the row's and the column's totals index) -- on the vector ALU, as in k_fbm.
 // Summation order is fixed: repeated runs are bit-identical.
 // grid (chains of one state-table class, ceil(restarts / 4), 2 directions), block 64 ceil(S / 30).
 // =============================================================================
@@ -1340,9 +1340,22 @@ __global__ __launch_bounds__(768) void k_fbq(FbmArgs a, const double *wk, const 
                 }
             }
             FB_BARRIER();
+            // Four restarts with four different weights leave an MFMA one useful row in four: these steps run on the vector ALU (as
+            // k_fbm's).  Lane (kq, c) owns rows 4 kb + kq of its two columns; restart i's vector element reaches the 16 lanes of the row
+            // through the FMA's DPP operand; the four lanes of a column are added at the end in a fixed order.
             double acc0[FBM_NV] = {0., 0., 0., 0.}, acc1[FBM_NV] = {0., 0., 0., 0.};
             const fbm_d2 *apc = reinterpret_cast<const fbm_d2 *>(vec + (size_t)((k - 1) & 1) * VR * 4 + (kq * 4 + ib) * 2);     // pair p: + 16 p
             const char *tbb = reinterpret_cast<const char *>(tb);
+            const char *wtb = reinterpret_cast<const char *>(wtab);
+#define FBQ_BE_FMA(acc_, a_, x_, i_) asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:" #i_ " row_mask:0xf bank_mask:0xf" : "+v"(acc_) : "v"(a_), "v"(x_))
+#define FBQ_BE_TILE(acc_, c_, uoff_, ak_)                                                                                          \
+            {                                                                                                                      \
+                const double wv = *reinterpret_cast<const double *>(wtb + FBQ_ADDR(c_, kb));                                       \
+                const char *row = tbb + (__mul24(uq, umul) + (uoff_));                                                             \
+                const double2 t01 = *reinterpret_cast<const double2 *>(row), t23 = *reinterpret_cast<const double2 *>(row + 16);   \
+                const double x0 = wv * t01.x, x1 = wv * t01.y, x2 = wv * t23.x, x3 = wv * t23.y;                                   \
+                FBQ_BE_FMA(acc_[0], ak_, x0, 0); FBQ_BE_FMA(acc_[1], ak_, x1, 1); FBQ_BE_FMA(acc_[2], ak_, x2, 2); FBQ_BE_FMA(acc_[3], ak_, x3, 3); \
+            }
 #pragma unroll
             for (int p = 0; p < KB / 2; p++) {      // fully unrolled: the address registers need compile-time indices
                 const fbm_d2 av = apc[p * 16];
@@ -1351,26 +1364,17 @@ __global__ __launch_bounds__(768) void k_fbq(FbmArgs a, const double *wk, const 
                     const int kb = 2 * p + h;
                     const int uq = upl[4 * kb + kq];
                     const double ak = h ? av.y : av.x;
-                    {   // tile 0
-                        const double wv = *reinterpret_cast<const double *>(reinterpret_cast<const char *>(wtab) + FBQ_ADDR(c0, kb));
-                        const char *row = tbb + (__mul24(uq, umul) + uoff0);
-                        const double2 t01 = *reinterpret_cast<const double2 *>(row), t23 = *reinterpret_cast<const double2 *>(row + 16);
-                        acc0[0] = __builtin_amdgcn_mfma_f64_4x4x4f64(ak, wv * t01.x, acc0[0], 0, 0, 0);
-                        acc0[1] = __builtin_amdgcn_mfma_f64_4x4x4f64(ak, wv * t01.y, acc0[1], 0, 0, 0);
-                        acc0[2] = __builtin_amdgcn_mfma_f64_4x4x4f64(ak, wv * t23.x, acc0[2], 0, 0, 0);
-                        acc0[3] = __builtin_amdgcn_mfma_f64_4x4x4f64(ak, wv * t23.y, acc0[3], 0, 0, 0);
-                    }
-                    {   // tile 1
-                        const double wv = *reinterpret_cast<const double *>(reinterpret_cast<const char *>(wtab) + FBQ_ADDR(c1, kb));
-                        const char *row = tbb + (__mul24(uq, umul) + uoff1);
-                        const double2 t01 = *reinterpret_cast<const double2 *>(row), t23 = *reinterpret_cast<const double2 *>(row + 16);
-                        acc1[0] = __builtin_amdgcn_mfma_f64_4x4x4f64(ak, wv * t01.x, acc1[0], 0, 0, 0);
-                        acc1[1] = __builtin_amdgcn_mfma_f64_4x4x4f64(ak, wv * t01.y, acc1[1], 0, 0, 0);
-                        acc1[2] = __builtin_amdgcn_mfma_f64_4x4x4f64(ak, wv * t23.x, acc1[2], 0, 0, 0);
-                        acc1[3] = __builtin_amdgcn_mfma_f64_4x4x4f64(ak, wv * t23.y, acc1[3], 0, 0, 0);
-                    }
+                    FBQ_BE_TILE(acc0, c0, uoff0, ak)
+                    FBQ_BE_TILE(acc1, c1, uoff1, ak)
                 }
                 __builtin_amdgcn_sched_barrier(0);      // a pair of k-blocks at a time (register budget)
+            }
+#undef FBQ_BE_TILE
+#undef FBQ_BE_FMA
+#pragma unroll
+            for (int i = 0; i < FBM_NV; i++) {
+                acc0[i] += __shfl_xor(acc0[i], 16); acc0[i] += __shfl_xor(acc0[i], 32);
+                acc1[i] += __shfl_xor(acc1[i], 16); acc1[i] += __shfl_xor(acc1[i], 32);
             }
             const double s0 = id == 0 ? acc0[0] : (id == 1 ? acc0[1] : (id == 2 ? acc0[2] : acc0[3]));
             const double s1 = id == 0 ? acc1[0] : (id == 1 ? acc1[1] : (id == 2 ? acc1[2] : acc1[3]));
