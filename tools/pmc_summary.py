@@ -10,7 +10,7 @@ import csv, glob, json, os, sys
 
 
 def fold(name):
-    for key, out in (('k_fbm', 'k_fb'), ('k_fbv', 'k_fb'), ('k_fbk', 'k_fb'), ('k_fb<', 'k_fb'), ('k_pairwise', 'k_pairwise')):
+    for key, out in (('k_fbm', 'k_fb'), ('k_fbq', 'k_fb'), ('k_fbv', 'k_fb'), ('k_fbk', 'k_fb'), ('k_fb<', 'k_fb'), ('k_pairwise', 'k_pairwise')):
         if key in name:
             return out
     if 'k_cells' in name:
