@@ -487,7 +487,7 @@ def main(argv=None, kernel_module=None, dist_backend='nccl', script=None):
         dist.destroy_process_group()
 
 
-def roofline_object(dom, cells_per_launch, S, args, restarts_per_launch, traffic_file='traffic_r02.json'):
+def roofline_object(dom, cells_per_launch, S, args, restarts_per_launch, traffic_file='traffic_r03.json'):
     if dom[0] is None:
         return None
     name, (ms, n) = dom
@@ -495,7 +495,7 @@ def roofline_object(dom, cells_per_launch, S, args, restarts_per_launch, traffic
     alg = ALG_BYTES_PER_CELL.get(name)
     hbm_gbs = alg * cells_per_launch / (avg_ms * 1e-3) / 1e9
     traffic = None
-    for tf in (traffic_file, 'traffic_r01.json'):
+    for tf in (traffic_file, 'traffic_r02.json', 'traffic_r01.json'):
         try:   # PMC traffic of the same kernel on the same launch shape, measured offline (profiles/)
             tj = json.load(open(os.path.join(ROOT, 'profiles', tf)))
             w = tj['workload']
@@ -581,7 +581,7 @@ def one_group_roofline(args, rs_main, device):
     dt = time.perf_counter() - t0
     b.profile_enable(0)
     prof = rs.profile()
-    out = roofline_object(('k_fb', prof['k_fb']), float(N1) * S * R, S, args, R, traffic_file='traffic_r02_16.json')
+    out = roofline_object(('k_fb', prof['k_fb']), float(N1) * S * R, S, args, R, traffic_file='traffic_r03_16.json')
     out['restart_groups'] = 1
     out['restarts_per_launch'] = R
     out['em_iterations_per_s_with_one_group'] = R * nsteps / dt

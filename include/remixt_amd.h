@@ -264,7 +264,12 @@ int rmx_trial_rollback(rmx_batch *b, int32_t r, int32_t param_id, const double *
  * trial = 1 with the changed parameters on trial (as rmx_expected_ll_full_trial).  The accept tests of the four
  * parameters (cn_model.py:563-569, one update_param after the other) then take ONE pass over the cells: E[ll] with
  * parameter j on trial and the earlier ones decided is a sum of component values of the two calls.  Afterwards, per
- * parameter: rmx_set_param (accept) or rmx_trial_rollback (reject; only that parameter's components become current again). */
+ * parameter: rmx_set_param (accept) or rmx_trial_rollback (reject; only that parameter's components become current again).
+ * trial = 2: the component sums of the expectations the LAST trial pass over this range left in scratch (rmx_expected_ll_full_trial or
+ * trial = 1), without another pass: right after the h M-step's accept test they are E[ll] at (accepted h, committed parameters),
+ * i.e. the "before" of the parameter accept tests, for every restart whose h was accepted (restarts whose h was rolled back: trial = 0,
+ * which costs no pass either).  A restart's own expectations then stay stale until the next ELBO / sweep: ONE full refresh per EM
+ * iteration instead of one after the h M-step and one after the parameter M-steps. */
 int rmx_expected_ll_components(rmx_batch *b, int32_t r0, int32_t r1, int32_t trial, double *out);
 /* per-cell values, for tests (:751-776, :809-853): u/v/w in {0,1} */
 int rmx_log_likelihood_total(rmx_batch *b, int32_t r, int32_t n, int32_t s, int32_t u, double *out);

@@ -479,10 +479,11 @@ class RemixtBatch(object):
 
     def expected_log_likelihood_components(self, r0=None, r1=None, trial=False):
         """[r1-r0][4]: E[ll] over all segments split into the components negbin_r_0, negbin_r_1, betabin_M_0, betabin_M_1 move,
-        at the committed values or (trial=True) with changed parameters on trial (rmx_expected_ll_components)."""
+        at the committed values or (trial=True) with changed parameters on trial (rmx_expected_ll_components); trial=2: from the
+        scratch expectations the last trial pass left behind, without another pass."""
         r0, r1 = self._range(r0, r1)
         out = np.zeros((r1 - r0, 4), dtype=np.float64)
-        self._ck(self._lib.rmx_expected_ll_components(self._handle, r0, r1, 1 if trial else 0, out.ctypes.data_as(_dp)))
+        self._ck(self._lib.rmx_expected_ll_components(self._handle, r0, r1, int(trial), out.ctypes.data_as(_dp)))
         return out
 
     def rollback_param(self, r, name, value):

@@ -69,6 +69,7 @@ struct rmx_batch {
     std::vector<int> cache_stale;      // components of the cell cache that are not current (CM_* bits); 15 = nothing cached
     bool use_cache = false;
     std::vector<int> comp_dirty;       // which components of (A, B, PF/PP) are stale: CM_* bits, 16 = PF/PP
+    std::vector<int> comp_base;        // ... of them, those stale because h changed (a parameter's rollback does not make these current again)
     std::vector<int> lt_valid;
     std::vector<int> lt_model, cached_model;   // per restart: the transition model of the log_transmat / cached_log_transmat snapshot
     double *Tval_m[2] = {nullptr, nullptr}; int8_t *af_m[2] = {nullptr, nullptr};   // plain tables of either transition model once it has been current
@@ -596,7 +597,7 @@ static int ensure_ab(rmx_batch *b, int r0, int r1) {
         } else {
             ProfScope ps(b, KID_MARGINALS_AB); hipLaunchKernelGGL(k_marginals<false>, row_grid(b, e - r), dim3(256), 0, b->stream, b->d, r, b->G);
         }
-        for (int i = r; i < e; i++) { b->ab_dirty[i] = 0; b->comp_dirty[i] = 0; }
+        for (int i = r; i < e; i++) { b->ab_dirty[i] = 0; b->comp_dirty[i] = 0; b->comp_base[i] = 0; }
         r = e;
     }
     HIPCHK(hipGetLastError());
@@ -876,7 +877,7 @@ int rmx_batch_create(const rmx_problem *pr, int32_t R, const double *h_init, con
 
     // per-restart initial state (bpmodel.pyx:546-597)
     b->sample_cache.assign(R, std::vector<int64_t>()); b->sample_count.assign(R, -1);
-    b->rp.resize(R); b->tables_dirty.assign(R, 1); b->segc_dirty.assign(R, 1); b->ab_dirty.assign(R, 1); b->comp_dirty.assign(R, 31); b->cache_stale.assign(R, 15); b->sig_valid.assign(R, 0); b->lt_valid.assign(R, 0); b->lt_model.assign(R, 0); b->cached_model.assign(R, 0); b->logZ.assign(R, 0.); b->logz_dirty.assign(R, 0);
+    b->rp.resize(R); b->tables_dirty.assign(R, 1); b->segc_dirty.assign(R, 1); b->ab_dirty.assign(R, 1); b->comp_dirty.assign(R, 31); b->comp_base.assign(R, 31); b->cache_stale.assign(R, 15); b->sig_valid.assign(R, 0); b->lt_valid.assign(R, 0); b->lt_model.assign(R, 0); b->cached_model.assign(R, 0); b->logZ.assign(R, 0.); b->logz_dirty.assign(R, 0);
     for (int r = 0; r < R; r++) {
         RestartParams &p = b->rp[r];
         memset(&p, 0, sizeof p);
@@ -1029,7 +1030,7 @@ int rmx_set_array(rmx_batch *b, int32_t r, int32_t id, const void *src) { BIND(b
     switch (id) {
     case RMX_A_H:
         for (int m = 0; m < d.M; m++) b->rp[r].h[m] = ((const double *)src)[m];
-        b->tables_dirty[r] = 1; b->ab_dirty[r] = 1; b->comp_dirty[r] = 31; b->cache_stale[r] = 15; return RMX_OK;
+        b->tables_dirty[r] = 1; b->ab_dirty[r] = 1; b->comp_dirty[r] = 31; b->comp_base[r] = 31; b->cache_stale[r] = 15; return RMX_OK;
     case RMX_A_P_BREAKPOINT:
         if (d.K) HIPCHK(hipMemcpyAsync(d.pbrk + (size_t)r * d.K * d.B, src, (size_t)d.K * d.B * 8, hipMemcpyHostToDevice, b->stream));
         break;
@@ -1038,13 +1039,13 @@ int rmx_set_array(rmx_batch *b, int32_t r, int32_t id, const void *src) { BIND(b
     case RMX_A_P_OUTLIER_ALLELE: HIPCHK(hipMemcpyAsync(d.qa + RN * 2, src, (size_t)d.N * 16, hipMemcpyHostToDevice, b->stream)); break;
     case RMX_A_POSTERIOR_MARGINALS:
         HIPCHK(hipMemcpy2DAsync(d.post + RN * d.SP, (size_t)d.SP * 8, src, (size_t)d.S * 8, (size_t)d.S * 8, d.N, hipMemcpyHostToDevice, b->stream));
-        b->ab_dirty[r] = 1; b->comp_dirty[r] = 31; b->sig_valid[r] = 0; break;
+        b->ab_dirty[r] = 1; b->comp_dirty[r] = 31; b->comp_base[r] = 31; b->sig_valid[r] = 0; break;
     case RMX_A_TOTAL_LIKELIHOOD_MASK: case RMX_A_ALLELE_LIKELIHOOD_MASK: {
         std::vector<uint8_t> m8(d.N);
         for (int n = 0; n < d.N; n++) m8[n] = ((const int64_t *)src)[n] != 0;
         HIPCHK(hipStreamSynchronize(b->stream));
         HIPCHK(hipMemcpy((void *)(id == RMX_A_TOTAL_LIKELIHOOD_MASK ? d.mask_t : d.mask_a), m8.data(), d.N, hipMemcpyHostToDevice));
-        for (int i = 0; i < b->R; i++) { b->ab_dirty[i] = 1; b->comp_dirty[i] = 31; b->cache_stale[i] = 15; }
+        for (int i = 0; i < b->R; i++) { b->ab_dirty[i] = 1; b->comp_dirty[i] = 31; b->comp_base[i] = 31; b->cache_stale[i] = 15; }
         return RMX_OK; }
     default: return fail(RMX_EARG, "array is read-only or unknown");
     }
@@ -1381,7 +1382,7 @@ static int p_cn_marginals(rmx_batch *b, int r0, int r1, bool fuse_next) {
         HIPCHK(hipGetLastError());
     }
     if (fuse_next && use_strip(b)) std::swap(b->d.fe, b->d.fe_alt);      // the fused pass left the next sweep's scaled emissions in the second buffer
-    for (int r = r0; r < r1; r++) { b->ab_dirty[r] = 0; b->comp_dirty[r] = 0; b->logz_dirty[r] = 1; b->sig_valid[r] = (!fuse_next && use_strip(b) && b->d.sig_cnt) ? 1 : 0; }
+    for (int r = r0; r < r1; r++) { b->ab_dirty[r] = 0; b->comp_dirty[r] = 0; b->comp_base[r] = 0; b->logz_dirty[r] = 1; b->sig_valid[r] = (!fuse_next && use_strip(b) && b->d.sig_cnt) ? 1 : 0; }
     return RMX_OK;
 }
 static int do_update_p_cn(rmx_batch *b, int r0, int r1, bool skip_frame = false, bool fuse_next = false) {
@@ -2243,7 +2244,8 @@ int rmx_expected_ll_components(rmx_batch *b, int32_t r0, int32_t r1, int32_t tri
     if (!out) return fail(RMX_EARG, "bad argument");
     int rc;
     Dev d2 = b->d;
-    if (trial) { if ((rc = trial_pass(b, r0, r1, d2))) return rc; }
+    if (trial == 2) { d2.A = b->d_A2; d2.Bv = b->d_Bv2; }      // the scratch expectations of the last trial pass over this range, as they are
+    else if (trial) { if ((rc = trial_pass(b, r0, r1, d2))) return rc; }
     else if ((rc = ensure_ab(b, r0, r1))) return rc;
     const int nr = r1 - r0;
     { ProfScope ps(b, KID_ELL_FULL); hipLaunchKernelGGL(k_ell_comp_batch, dim3(ELBO_BLOCKS, nr), dim3(256), 0, b->stream, d2, r0, b->d_partial); }
@@ -2266,9 +2268,11 @@ int rmx_trial_rollback(rmx_batch *b, int32_t r, int32_t param_id, const double *
     b->tables_dirty[r] = 1; b->segc_dirty[r] = 1;      // the device tables hold the trial values
     if (param_id >= 0 && param_id < RMX_P_HMM_LOG_NORM_CONST) {
         // only this parameter's components become current again (others may be on trial at the same time: rmx_expected_ll_components)
-        b->comp_dirty[r] &= ~kParamComponents[param_id]; b->cache_stale[r] &= ~(kParamComponents[param_id] & 15);
+        // (... unless they were stale already: an accepted h whose refresh is still pending, comp_base)
+        const int back = kParamComponents[param_id] & ~b->comp_base[r];
+        b->comp_dirty[r] &= ~back; b->cache_stale[r] &= ~(back & 15);
         b->ab_dirty[r] = b->comp_dirty[r] != 0;
-    } else { b->ab_dirty[r] = 0; b->comp_dirty[r] = 0; b->cache_stale[r] = 0; }
+    } else { b->ab_dirty[r] = 0; b->comp_dirty[r] = 0; b->comp_base[r] = 0; b->cache_stale[r] = 0; }
     return RMX_OK;
 }
 

@@ -373,6 +373,7 @@ class RestartSet(object):
                 self.models[r].model.h = h_before[r]
         if not trial:
             ell_after = b.expected_log_likelihood_full(0, R)
+        accepted = [False] * R
         for r in active:
             if r in failed:
                 continue
@@ -383,6 +384,10 @@ class RestartSet(object):
                     b.rollback_h(r, h_before[r])
                 else:
                     m.model.h = h_before[r]
+            else:
+                accepted[r] = True
+        # (the scratch expectations of the trial pass describe the state of every restart only if every restart kept its trial h)
+        self._h_trial_kept = accepted if (trial and len(active) == R) else None
         self._mark('h:accept')
         return True
 
@@ -460,7 +465,15 @@ class RestartSet(object):
         committed and at the tried parameters (rmx_expected_ll_components; differs from the four full sums by rounding)."""
         comp = b.PARAM_COMPONENT
         value_before = dict((name, [b.get_param(r, name) for r in ids_all]) for name in lead)
-        cur = b.expected_log_likelihood_components(0, R)
+        # E[ll] components before the parameter tests = at (h as decided, committed parameters).  Where the h M-step just ACCEPTED a new
+        # h, its accept test's trial pass left exactly these expectations in scratch: summing them costs no pass over the cells, and the
+        # restart's own expectations are refreshed once, after the parameter M-steps (by the ELBO), instead of here and there.
+        kept = getattr(self, '_h_trial_kept', None)
+        self._h_trial_kept = None
+        if kept is not None and len(kept) == R and all(kept):
+            cur = b.expected_log_likelihood_components(0, R, trial=2)
+        else:
+            cur = b.expected_log_likelihood_components(0, R)
         self._mark('p:ell_before')
         for name in lead:
             last = together[name][1]
