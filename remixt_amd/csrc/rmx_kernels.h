@@ -2695,12 +2695,15 @@ __global__ __launch_bounds__(256) void k_ell_list_batch_sparse_grad_final(Dev d,
     const int i = blockIdx.x * 8 + (threadIdx.x >> 5);
     const int cnt = counts[r];
     if (i < cnt) ell_segment_sparse_grad(d, stage[blockIdx.y], r, samples[(size_t)r * d.N + i], partial + (size_t)r * pstride + (size_t)i * (1 + RMX_MAX_CLONES));
-    __threadfence();
+    // ONE release per block, behind the barrier that orders the block's partial sums before it: a release fence writes the L2's dirty lines
+    // back (the XCDs' L2s are not coherent with each other), and next to another restart group's sweep kernels that is what a fence by all
+    // 256 threads of all 200 blocks was paying for
     __syncthreads();
-    if (threadIdx.x == 0) last = atomicAdd(&done[blockIdx.y], 1u) == gridDim.x - 1;
+    if (threadIdx.x == 0) { __threadfence(); last = atomicAdd(&done[blockIdx.y], 1u) == gridDim.x - 1; }
     __syncthreads();
     if (!last) return;
-    __threadfence();
+    if (threadIdx.x == 0) __threadfence();
+    __syncthreads();
     if (threadIdx.x == 0) { done[blockIdx.y] = 0; if (err_out) err_out[blockIdx.y] = __hip_atomic_load(&d.err[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
     const int W = 1 + RMX_MAX_CLONES;
     for (int c = 0; c < nout; c++) {
