@@ -509,7 +509,8 @@ def roofline_object(dom, cells_per_launch, S, args, restarts_per_launch, traffic
         # the forward-backward recursion: S^2 FP64 FMAs per segment, direction and restart
         achieved = fl * cells_per_launch / (avg_ms * 1e-3) / 1e12
         return {'bound': 'fp64', 'kernel': name, 'achieved': achieved, 'peak': FP64_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                'frac': achieved / FP64_PEAK_TFLOPS, 'traffic': traffic, 'avg_launch_ms': avg_ms, 'launches': n,
+                'frac': achieved / FP64_PEAK_TFLOPS, 'traffic': traffic, 'traffic_source': 'profiles/%s: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this kernel at this launch shape (tools/collect_profiles.sh), not collected in this run' % traffic_file,
+                'avg_launch_ms': avg_ms, 'launches': n,
                 'alg_flops_per_launch': fl * cells_per_launch, 'alg_bytes_per_launch': alg * cells_per_launch,
                 'hbm_gbs_at_alg_bytes': hbm_gbs, 'hbm_frac_at_alg_bytes': hbm_gbs / HBM_PEAK_GBS,
                 'note': 'FP64 FMA bound (the contract\'s "mfma" class: peak = dense FP64 rate, the same for vector and matrix FP64 on gfx950); '
