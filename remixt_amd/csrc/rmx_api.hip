@@ -610,7 +610,12 @@ static int launch_pairwise_breakends(rmx_batch *b, int r0, int r1, int mode) {
     const Dev &d = b->d;
     const int nt = ((d.S + 63) / 64) * 64;
     const size_t lds2 = ((size_t)((d.S + 7) & ~7) + b->pe2p + 128 + (size_t)nt * (d.M - 1) * (d.cn_max + 2) + nt + 3 * d.M * d.D) * 8 + (size_t)((d.S + 7) & ~7) * 4 + (size_t)d.S * 4 + 64;
-    if (mode == 0 && b->pcode_ok && lds2 <= 150 * 1024 && b->opt[RMX_OPT_PAIRWISE_KERNEL] == 0) {
+    const int S8p = (d.S + 7) & ~7;
+    const size_t lds_sp = (size_t)(4 * S8p + PSP_ROWS * 2 * (d.cn_max + 2) + 2 * PSP_ROWS + (d.M * d.D + 4) + 64) * 8 + (size_t)3 * S8p * 4 + 64;
+    // the sparse kernel (state pairs above the posterior threshold only) wherever the pair codes exist: auto, or option 3; 2 = the dense kernel
+    if (mode == 0 && b->pcode_ok && (b->opt[RMX_OPT_PAIRWISE_KERNEL] == 0 || b->opt[RMX_OPT_PAIRWISE_KERNEL] == 3) && d.M * d.D + 1 <= 255 && lds_sp <= 64 * 1024) {
+        hipLaunchKernelGGL(k_pairwise_sp, dim3(d.NBE, r1 - r0), dim3(256), lds_sp, b->stream, b->d, r0, b->pe2p, b->spc);
+    } else if (mode == 0 && b->pcode_ok && lds2 <= 150 * 1024 && (b->opt[RMX_OPT_PAIRWISE_KERNEL] == 0 || b->opt[RMX_OPT_PAIRWISE_KERNEL] == 2)) {
         HIPCHK(hipFuncSetAttribute((const void *)k_pairwise_be2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
         hipLaunchKernelGGL(k_pairwise_be2, dim3(d.NBE, r1 - r0), dim3(nt), lds2, b->stream, b->d, r0, b->pe2p, b->spc);
     } else {
@@ -652,7 +657,7 @@ static bool option_value_ok(int id, int v) {
     case RMX_OPT_FB_KERNEL: return v >= 0 && v <= 2;
     case RMX_OPT_FB_NV: return v == 0 || v == 1 || v == 2 || v == 4;      // the workgroup shapes that exist (k_fbv 1 / 2 / 4, k_fbm 4)
     case RMX_OPT_SEARCH_MODE: return v >= 0 && v <= 4;
-    case RMX_OPT_PAIRWISE_KERNEL: return v == 0 || v == 1;
+    case RMX_OPT_PAIRWISE_KERNEL: return v >= 0 && v <= 3;
     default: return v == 0 || v == 1;
     }
 }

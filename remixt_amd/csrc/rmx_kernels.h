@@ -2170,6 +2170,178 @@ __global__ void k_pairwise(Dev d, int r0, int mode, const int32_t *list, double 
 }
 
 // =============================================================================
+// k_pairwise_sp: the pairwise reductions at a breakend adjacency over the state pairs that CAN carry mass (round 3).
+//
+// joint[i][j] = fa_n[i] W_r[i][j] g_{n+1}[j] has the posteriors as its marginals: sum_j joint[i][j] / Z = post_n[i] and sum_i joint[i][j] / Z =
+// post_{n+1}[j], so joint[i][j] / Z <= min(post_n[i], post_{n+1}[j]): a pair with a row or a column below RMX_POST_EPS (1e-30) of the
+// posterior mass cannot move a rounded sum (all dropped pairs together: < S^2 1e-30).  The block forms both posteriors from the rows it needs
+// anyway (fa, fb of segments n and n+1), compacts the states above the threshold (~13 of 165, ~20 of 355) in state / column order, and walks
+// only their product: a few hundred pairs instead of 27 000 (165 states) or 126 000 (355 states: the dense kernel takes 7.3 ms per sweep there).
+// Fixed order everywhere, the scheme of k_pairwise_be2 on the lists: a thread per listed row walks the listed columns in the order of their
+// tumour-clone totals and flushes a run of equal totals into its private LDS bins; passes of 64 rows; one thread per histogram bin folds a
+// pass's rows in list order.  Any list length is handled (a flat posterior -- short segments with few reads -- makes it the dense product,
+// at the dense kernel's cost per pair).  Outputs as k_pairwise_be2: hist [M][D], be_ja, be_jt.  M in {2, 3}, pair codes as k_pairwise_be2.
+// grid (NBE, nr), block 256, dynamic LDS.
+// =============================================================================
+#define PSP_ROWS 64         // rows per pass (a thread per row with private histogram bins in LDS)
+__global__ __launch_bounds__(256) void k_pairwise_sp(Dev d, int r0, int PE2P, int SPC) {
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    __shared__ double scratch[16];
+    __shared__ double tot_n, tot_m;
+    __shared__ int NI, NJ;
+    const int r = r0 + blockIdx.y, slot = blockIdx.x;
+    const int n = d.be_n[slot];
+    const int S = d.S, M = d.M, D = d.D, t = threadIdx.x, NT = blockDim.x, lane = t & 63, wave = t >> 6;
+    const int S8 = (S + 7) & ~7;
+    const int NB = d.cn_max + 2;                          // totals 0 .. cn_max + 1
+    const int tc = d.tclass[n];
+    const int ca = d.seg_class[n], cb = d.seg_class[n + 1];
+    double *fav = (double *)smem_raw;                     // [S8] fa of segment n, state order
+    double *pn = fav + S8;                                // [S8] fa * fb of segment n
+    double *gv = pn + S8;                                 // [S8] fe * fb of segment n + 1, column (jord) order
+    double *pm = gv + S8;                                 // [S8] fa * fb of segment n + 1, column order
+    double *bins = pm + S8;                               // [PSP_ROWS][M - 1][NB] private bins of a pass's rows
+    double *zrow = bins + (size_t)PSP_ROWS * 2 * NB;      // [PSP_ROWS] row sums, [PSP_ROWS] row sums of joint * allele distance
+    double *hacc = zrow + 2 * PSP_ROWS;                   // [M * D + 2] histogram, total mass, allele-distance sum: accumulated over the passes
+    double *wa = hacc + ((M * D + 2 + 1) & ~1);           // [64] exp(-pen a)
+    int *li = (int *)(wa + 64);                           // [S8] rows above the threshold
+    int *lj = li + S8;                                    // [S8] columns (positions in jord order) above the threshold
+    int *lm = lj + S8;                                    // [S8] per listed column: t1 | t2 << 8 | run flags << 16 (as jmeta, flags for the LIST)
+    const double *fa0 = d.fa + rs_off(d, r, n), *fb0 = d.fb + rs_off(d, r, n);
+    const double *fa1 = d.fa + rs_off(d, r, n + 1), *fb1 = d.fb + rs_off(d, r, n + 1), *fe1 = d.fe + rs_off(d, r, n + 1);
+    double sn = 0., sm = 0.;
+    for (int s = t; s < S8; s += NT) {
+        double a0 = 0., p0 = 0., g1 = 0., p1 = 0.;
+        if (s < S) {
+            a0 = fa0[s]; p0 = a0 * fb0[s];
+            const int j = d.jord[(size_t)cb * S + s];
+            const double b1 = fb1[j];
+            g1 = fe1[j] * b1; p1 = fa1[j] * b1;
+        }
+        fav[s] = a0; pn[s] = p0; gv[s] = g1; pm[s] = p1;
+        sn += p0; sm += p1;
+    }
+    for (int i = t; i < 64; i += NT) wa[i] = tc >= 0 ? exp(-d.pen * (double)i) : 1.0;
+    for (int i = t; i < M * D + 2; i += NT) hacc[i] = 0.;
+    sn = group_sum(sn, 64); sm = group_sum(sm, 64);
+    if (lane == 0) { scratch[wave] = sn; scratch[8 + wave] = sm; }
+    __syncthreads();
+    if (t == 0) { double x = 0., y = 0.; for (int w_ = 0; w_ < NT / 64; w_++) { x += scratch[w_]; y += scratch[8 + w_]; } tot_n = x; tot_m = y; }
+    __syncthreads();
+    // compaction in index order: wave 0 the rows, wave 1 the columns (ballot + prefix count per group of 64)
+    if (wave < 2) {
+        const double *pp = wave == 0 ? pn : pm;
+        const double thr = RMX_POST_EPS * (wave == 0 ? tot_n : tot_m);
+        int *lst = wave == 0 ? li : lj;
+        int base = 0;
+        for (int s0 = 0; s0 < S; s0 += 64) {
+            const int s = s0 + lane;
+            const bool keep = s < S && pp[s] >= thr && pp[s] > 0.;
+            const unsigned long long bal = __ballot(keep);
+            if (keep) lst[base + __popcll(bal & ((1ull << lane) - 1ull))] = s;
+            base += __popcll(bal);
+        }
+        if (lane == 0) { if (wave == 0) NI = base; else NJ = base; }
+    }
+    __syncthreads();
+    const int ni = NI, nj = NJ;
+    // totals of the listed columns and the run flags OF THE LIST: bit 16 = last listed column of a (t1, t2) run, bit 17 = of a t1 run
+    for (int k = t; k < nj; k += NT) {
+        const int m_ = d.jmeta[(size_t)cb * S + lj[k]] & 0xffff;
+        const int mn = k + 1 < nj ? (d.jmeta[(size_t)cb * S + lj[k + 1]] & 0xffff) : -1;
+        int fl = 0;
+        if (mn < 0 || mn != m_) fl |= 1;
+        if (mn < 0 || (mn & 0xff) != (m_ & 0xff)) fl |= 2;
+        lm[k] = m_ | (fl << 16);
+    }
+    __syncthreads();
+    const uint16_t *prow = d.pcode + (size_t)(tc >= 0 ? tc : 0) * S8 * SPC;
+    const double *tg = d.pe2_lt + ((size_t)r * d.NBE + slot) * PE2P;
+    const int8_t *tota = d.tot + (size_t)ca * S * M;
+    const int off = d.cn_max + 1;
+    const int t0b = (int)d.tot[(size_t)cb * S * M];       // the normal clone's total is the same for every column of the class
+    for (int u0 = 0; u0 < ni; u0 += PSP_ROWS) {
+        const int nu = (ni - u0) < PSP_ROWS ? (ni - u0) : PSP_ROWS;
+        if (t < nu) {
+            double *mybins = bins + (size_t)t * 2 * NB;
+            for (int i = 0; i < (M - 1) * NB; i++) mybins[i] = 0.;
+            const int i = li[u0 + t];
+            const double fai = fav[i];
+            double z = 0., ja = 0., acc1 = 0., acc2 = 0.;
+            // chunks of 16 listed columns: their 16 codes are requested together, then their 16 table entries -- two memory round trips
+            // per chunk instead of two per column
+            for (int k0 = 0; k0 < nj; k0 += 16) {
+                unsigned cc[16]; double tw[16];
+#pragma unroll
+                for (int u = 0; u < 16; u++) { const int k = k0 + u; cc[u] = (tc >= 0 && k < nj) ? (unsigned)prow[(size_t)lj[k] * SPC + i] : 0u; }
+#pragma unroll
+                for (int u = 0; u < 16; u++) tw[u] = (tc >= 0 && k0 + u < nj) ? tg[cc[u] & 1023u] : 1.0;
+#pragma unroll
+                for (int u = 0; u < 16; u++) {
+                    const int k = k0 + u;
+                    if (k < nj) {
+                        const int a = (int)(cc[u] >> 10);
+                        const double w = tc >= 0 ? wa[a] * tw[u] : 1.0;
+                        const double J = fai * w * gv[lj[k]];
+                        z += J; ja += J * (double)a;
+                        acc2 += J;
+                        const int m_ = lm[k];
+                        if (m_ & 0x10000) {                            // last listed column of a (t1, t2) run
+                            if (M == 3) mybins[1 * NB + ((m_ >> 8) & 0xff)] += acc2;
+                            acc1 += acc2; acc2 = 0.;
+                            if (m_ & 0x20000) { mybins[0 * NB + (m_ & 0xff)] += acc1; acc1 = 0.; }   // last listed column of a t1 run
+                        }
+                    }
+                }
+            }
+            zrow[t] = z; zrow[PSP_ROWS + t] = ja;
+        }
+        __syncthreads();
+        // fold this pass's rows into the histogram, one thread per bin, rows in list order; total mass and allele-distance sum likewise
+        if (t < M * D) {
+            const int c = t / D, dv = t % D - off;
+            double acc = hacc[t];
+            for (int u = 0; u < nu; u++) {
+                const int tj = (int)tota[li[u0 + u] * M + c] - dv;      // the column total this bin pairs with the row's
+                if (c == 0) { if (tj == t0b) acc += zrow[u]; }
+                else if (tj >= 0 && tj < NB) acc += bins[((size_t)u * 2 + (c - 1)) * NB + tj];
+            }
+            hacc[t] = acc;
+        } else if (t == M * D) {
+            double acc = hacc[t];
+            for (int u = 0; u < nu; u++) acc += zrow[u];
+            hacc[t] = acc;
+        } else if (t == M * D + 1) {
+            double acc = hacc[t];
+            for (int u = 0; u < nu; u++) acc += zrow[PSP_ROWS + u];
+            hacc[t] = acc;
+        }
+        __syncthreads();
+    }
+    const double zz = hacc[M * D];
+    double *hist = d.hist + ((size_t)r * d.NBE + slot) * M * D;
+    double hv = 0.;
+    if (t < M * D) { hv = hacc[t] / zz; hist[t] = hv; }
+    __syncthreads();
+    if (t < M * D) hacc[t] = hv;
+    __syncthreads();
+    if (t < 64) {
+        double jt = 0.;
+        if (tc >= 0) {
+            const double *pd = d.pd_lt + ((size_t)r * d.NBE + slot) * M * D;
+            for (int i = t; i < M * D; i += 64) jt += hacc[i] * (-d.pen * pd[i]);
+        }
+        jt = group_sum(jt, 64);
+        if (t == 0) {
+            const double jaz = hacc[M * D + 1] / zz;
+            d.be_ja[(size_t)r * d.NBE + slot] = jaz;
+            if (tc >= 0) jt += -d.pen * jaz;
+            d.be_jt[(size_t)r * d.NBE + slot] = jt;
+        }
+    }
+}
+
+// =============================================================================
 // k_pairwise_be2: the production form of k_pairwise for breakend adjacencies (mode 0).  Thread i owns row i of the
 // pairwise posterior joint[i][j] = fa[i] * W[i][j] * g[j] and walks j, accumulating into PRIVATE LDS bins indexed by the
 // column state's totals (no atomics between threads, fixed order); the expectation of log_transmat is rebuilt from the
