@@ -149,7 +149,7 @@ enum rmx_option_id {
     RMX_OPT_CELL_CACHE,         /* creation time, 1 (default): cache the six likelihood values of every cell */
     RMX_OPT_SPARSE_TRIAL,       /* creation time, 1 (default): keep per-segment lists of states with posterior mass */
     RMX_OPT_FB_DEBUG,           /* creation time, 1: cycle counters of the forward-backward kernel through rmx_info(20..) */
-    RMX_OPT_PAIRWISE_KERNEL,    /* breakend pairwise reductions: 0 auto (k_pairwise_sp: the state pairs above the posterior threshold), 1 general kernel
+    RMX_OPT_PAIRWISE_KERNEL,    /* breakend pairwise reductions: 0 auto (above 200 states k_pairwise_sp: the state pairs above the posterior threshold; else k_pairwise_be2), 1 general kernel
                                    (k_pairwise), 2 the dense pair-code kernel (k_pairwise_be2), 3 k_pairwise_sp */
     RMX_OPT_COUNT
 };

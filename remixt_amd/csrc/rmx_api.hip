@@ -613,7 +613,10 @@ static int launch_pairwise_breakends(rmx_batch *b, int r0, int r1, int mode) {
     const int S8p = (d.S + 7) & ~7;
     const size_t lds_sp = (size_t)(4 * S8p + PSP_ROWS * 2 * (d.cn_max + 2) + 2 * PSP_ROWS + (d.M * d.D + 4) + 64) * 8 + (size_t)3 * S8p * 4 + 64;
     // the sparse kernel (state pairs above the posterior threshold only) wherever the pair codes exist: auto, or option 3; 2 = the dense kernel
-    if (mode == 0 && b->pcode_ok && (b->opt[RMX_OPT_PAIRWISE_KERNEL] == 0 || b->opt[RMX_OPT_PAIRWISE_KERNEL] == 3) && d.M * d.D + 1 <= 255 && lds_sp <= 64 * 1024) {
+    // (auto: above ~200 states, where the dense kernel's S^2 pairs per adjacency outweigh the sparse kernel's per-block latency chain; at 165 states the
+    // two are within 2 % of each other in the benchmark, the dense one ahead)
+    const bool want_sp = b->opt[RMX_OPT_PAIRWISE_KERNEL] == 3 || (b->opt[RMX_OPT_PAIRWISE_KERNEL] == 0 && d.S > 200);
+    if (mode == 0 && b->pcode_ok && want_sp && lds_sp <= 64 * 1024) {
         hipLaunchKernelGGL(k_pairwise_sp, dim3(d.NBE, r1 - r0), dim3(256), lds_sp, b->stream, b->d, r0, b->pe2p, b->spc);
     } else if (mode == 0 && b->pcode_ok && lds2 <= 150 * 1024 && (b->opt[RMX_OPT_PAIRWISE_KERNEL] == 0 || b->opt[RMX_OPT_PAIRWISE_KERNEL] == 2)) {
         HIPCHK(hipFuncSetAttribute((const void *)k_pairwise_be2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));

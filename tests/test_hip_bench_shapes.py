@@ -75,12 +75,12 @@ def test_s165_generic_kernel_and_plain_breakend_tables_match_oracle(hip, oracle_
     e = synthetic.make_experiment(90, num_clones=3, max_copy_number=8, num_chains=2, seed=33, num_breakpoints=12)
     e.breakpoints = H.add_shared_boundary_breakpoints(e)
     ps = synthetic.make_init_params(e, 2, 8)
-    for options in ({'fb_kernel': 1}, {'fb_breakend_codes': 0, 'fb_nv': 2}, {'pairwise_kernel': 1}):
+    for options in ({'fb_kernel': 1}, {'fb_breakend_codes': 0, 'fb_nv': 2}, {'pairwise_kernel': 1}, {'pairwise_kernel': 3}):      # (3: the sparse pairwise kernel, auto only above 200 states)
         dev, ora = _two_sets(oracle_mod, e, ps, 8, 3, options=options)
         _compare_after_every_update(dev, ora, sweeps=1)
 
 
-@pytest.mark.parametrize('options,fb', [({}, 4), ({'fb_nv': 4}, 4), ({'fb_nv': 2}, 3), ({'fb_nv': 1}, 3), ({'fb_kernel': 2}, 0), ({'viterbi_plain': 1}, 4)])
+@pytest.mark.parametrize('options,fb', [({}, 4), ({'fb_nv': 4}, 4), ({'fb_nv': 2}, 3), ({'fb_nv': 1}, 3), ({'fb_kernel': 2}, 0), ({'viterbi_plain': 1}, 4), ({'pairwise_kernel': 2}, 4)])
 def test_s355_matches_oracle(hip, oracle_mod, options, fb):
     """355 states (max_cn = 12, the "~400 states" of BASELINE's metric): k_fbq (FP64 matrix cores, B operands looked up from 8-bit
     distances; a quad with two and with four restarts present), k_fbk (vector FMA, weights rebuilt from packed copy numbers), the
