@@ -126,8 +126,18 @@ int rmx_synchronize(rmx_batch *b);
  * forward-backward kernels / on the general one; 12 the forward-backward kernel the last update_p_cn launched for the
  * former (1 k_fbm: FP64 matrix cores, 2 k_fbv: vector FMA, 3 k_fbk: weights from packed copy numbers, 4 k_fbq: matrix cores with
  * weights from 8-bit codes; 0: general kernel k_fb<0> only), 13 restarts per workgroup of that launch, 14 the lattice kernel of
- * the last decode (1 k_viterbi_reg, 2 k_viterbi_code, 3 k_viterbi) */
+ * the last decode (1 k_viterbi_reg, 2 k_viterbi_code, 3 k_viterbi); 64 / 65 / 66 of the batch's pair (rmx_pair_batches):
+ * forward-backward launches made for both sides at once, launches made for one side alone while paired, ns a side's host
+ * thread waited for the other side at a forward-backward point */
 int rmx_info(rmx_batch *b, int32_t what, int64_t *out);
+/* Pair two batches of ONE device holding the SAME experiment (the two restart groups of a GPU,
+ * reference remixt/analysis/pipeline.py:253-264: independent restarts), each driven by its own host thread on its own
+ * stream.  While both are inside rmx_variational_update, the forward-backward launches of their sweeps are issued as one
+ * launch over both ranges (every workgroup runs what it would run in a launch over its own batch: results do not change);
+ * a paired batch also reaches each sweep's forward-backward point only after the previous sweep's forward-backward has
+ * finished on the device.  `other` NULL: dissolve a's pair.  Not to be called while either batch is inside another call;
+ * destroying a batch dissolves its pair. */
+int rmx_pair_batches(rmx_batch *a, rmx_batch *other);
 
 /* -- tuning options ------------------------------------------------------- */
 /* Not part of the reference protocol: which of this library's equivalent kernels / launch shapes run.  Results do not

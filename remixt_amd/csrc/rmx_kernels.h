@@ -842,13 +842,14 @@ template <int PI, int KB> struct fbm_chain {
     }
 };
 
+// by: the workgroup's row of quads inside a's range (blockIdx.y of a launch over one batch)
 template <int KB>
-__global__ __launch_bounds__(768) void k_fbm(FbmArgs a) {
+__device__ __forceinline__ void fbm_body(const FbmArgs &a, const int by) {
     extern __shared__ __align__(16) unsigned char smem_raw[];
     static_assert(KB % 2 == 0 && KB / 2 >= FBM_DEPTH, "k-blocks come in pairs; ring no deeper than the chain");
     const int chain = a.chain_list[blockIdx.x], dir = blockIdx.z;
     // restarts in absolute quads (4 g .. 4 g + 3: the interleave of the breakend tables); of a quad, those inside [r0, r1)
-    const int quad = (a.r0 >> 2) + blockIdx.y, rg0 = quad * FBM_NV;
+    const int quad = (a.r0 >> 2) + by, rg0 = quad * FBM_NV;
     const int v_lo = max(a.r0 - rg0, 0), v_hi = min(a.r1 - rg0, FBM_NV);      // present: v_lo <= i < v_hi
     const int S = a.S, SP = a.SP, M = a.M, D = a.D, VR = a.VR, SPC = a.SPC;
     const int n0 = a.chain_start[chain], n1 = a.chain_end[chain], len = n1 - n0 + 1;
@@ -945,7 +946,7 @@ __global__ __launch_bounds__(768) void k_fbm(FbmArgs a) {
     }
     eptr += rstep;
     FB_BARRIER();
-    if (a.dbg && t == 0 && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0) { a.dbg[0] = clock64(); a.dbg[1] = wall_clock64(); a.dbg[4] = len; }
+    if (a.dbg && t == 0 && blockIdx.x == 0 && by == 0 && blockIdx.z == 0) { a.dbg[0] = clock64(); a.dbg[1] = wall_clock64(); a.dbg[4] = len; }
     // the tail of a step, common to plain and breakend steps: `sum` = this lane's product (lane 15 of every DPP row: the
     // sum of the previous row, from the ones column, whose power of two is this step's scale -- broadcast inside the
     // row, no LDS, no reduction)
@@ -1074,14 +1075,14 @@ __global__ __launch_bounds__(768) void k_fbm(FbmArgs a) {
             FBM_FINISH(sum, e, k)
             FB_STAMP(3)
 #ifdef RMX_FB_STAMPS
-            if (a.dbg && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && lane == 0 && (wave & 3) == 0) { for (int i = 0; i < 4; i++) a.dbg[8 + (wave >> 2) * 6 + i] += stamp_acc[i]; if (wave == 0) a.dbg[5] += 1; }
+            if (a.dbg && blockIdx.x == 0 && by == 0 && blockIdx.z == 0 && lane == 0 && (wave & 3) == 0) { for (int i = 0; i < 4; i++) a.dbg[8 + (wave >> 2) * 6 + i] += stamp_acc[i]; if (wave == 0) a.dbg[5] += 1; }
 #endif
             k++;
         }
     }
 #undef FBM_FINISH
 #undef FBM_FETCH
-    if (a.dbg && t == 0 && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0) { a.dbg[2] = clock64(); a.dbg[3] = wall_clock64(); }
+    if (a.dbg && t == 0 && blockIdx.x == 0 && by == 0 && blockIdx.z == 0) { a.dbg[2] = clock64(); a.dbg[3] = wall_clock64(); }
     // last row of each chain: its scale is not consumed by a later step, but the vanishing-row check needs the row's sum
     if (wave == 0) {
         const double *vb = vec + (size_t)((len - 1) & 1) * VR * 4;
@@ -1097,6 +1098,18 @@ __global__ __launch_bounds__(768) void k_fbm(FbmArgs a) {
     }
 #undef ROW
 #undef ADJ
+}
+template <int KB>
+__global__ __launch_bounds__(768) void k_fbm(FbmArgs a) { fbm_body<KB>(a, blockIdx.y); }
+// One launch over the ranges of TWO batches of the same experiment (rmx_pair_batches): rows of quads [0, ny0) belong to side 0,
+// the rest to side 1.  Each workgroup runs exactly the code of a launch over its own batch (the side is uniform per workgroup:
+// the arguments stay scalar loads from the kernel-argument segment), so results are bit-identical to two launches; what changes
+// is that 2 x 92 workgroups fill 184 of the 256 CUs at once instead of one after the other.
+struct FbmArgs2 { FbmArgs s[2]; int ny0; };
+template <int KB>
+__global__ __launch_bounds__(768) void k_fbm2(FbmArgs2 p) {
+    const int side = (int)blockIdx.y >= p.ny0 ? 1 : 0;
+    fbm_body<KB>(p.s[side], (int)blockIdx.y - (side ? p.ny0 : 0));
 }
 
 // =============================================================================

@@ -603,7 +603,7 @@ class RestartGroups(object):
     Restarts are independent (reference remixt/workflow.py:329-340) and every restart owns its RNG
     stream, so the results do not depend on the grouping."""
 
-    def __init__(self, experiment, init_params, max_copy_number, groups=2, seeds=None, **kwargs):
+    def __init__(self, experiment, init_params, max_copy_number, groups=2, seeds=None, pair_fb=0, **kwargs):
         init_params = list(init_params)
         R = len(init_params)
         groups = max(1, min(int(groups), R))
@@ -618,6 +618,12 @@ class RestartGroups(object):
         self.init_params = init_params
         self.experiment = experiment
         self._pool = None
+        # pair_fb: the two groups' forward-backward launches go out as one whenever both groups are inside a sweep (rmx_pair_batches;
+        # measured neutral on the bench -- the free-running groups already hide each group's marginal pass under the other's
+        # forward-backward, DESIGN 4.6 -- so off by default)
+        self.paired = bool(pair_fb) and len(self.sets) == 2 and all(getattr(rs.batch, 'pair_with', None) is not None for rs in self.sets)
+        if self.paired:
+            self.sets[0].batch.pair_with(self.sets[1].batch)
 
     @property
     def num_restarts(self):

@@ -78,16 +78,24 @@ def test_config2_bench_shape_em_iterations_with_msteps(workload):
     e, _, p64 = workload
     ids = list(range(16))
     out = {}
-    for groups in (2, 1):
-        rs = RestartGroups(e, [p64[i] for i in ids], MAX_CN, groups=groups, num_clones=M, quiet=True, seeds=_seeds(ids))
+    for groups, pair in ((2, 1), (2, 0), (1, 0)):
+        rs = RestartGroups(e, [p64[i] for i in ids], MAX_CN, groups=groups, num_clones=M, quiet=True, seeds=_seeds(ids), pair_fb=pair)
         b = rs.batches[0]
         assert b.num_cn_states == 165 and b.num_segments >= SEG
         e0, e2 = _run(rs, iters=2)
         assert b.info(12) == 1 and b.info(13) == 4          # k_fbm, four restarts per workgroup
-        out[groups] = _state(rs)
+        joint, solo, waited = b.pair_stats()
+        if pair:
+            # the two groups start their sweeps together: launches over both groups' restarts (k_fbm2) must have happened,
+            # and every forward-backward point of both groups is accounted for (2 iterations x 5 sweeps x 2 groups)
+            assert rs.paired and joint > 0 and 2 * joint + solo == 2 * 5 * 2, (joint, solo, waited)
+        else:
+            assert not rs.paired and (joint, solo) == (0, 0)
+        out[groups, pair] = _state(rs)
         _release(rs)
     for r in ids:
-        assert _same(out[2][r], out[1][r]), ('restart %d: 2 groups vs 1 group' % r, out[2][r], out[1][r])
+        assert _same(out[2, 1][r], out[1, 0][r]), ('restart %d: 2 paired groups vs 1 group' % r, out[2, 1][r], out[1, 0][r])
+        assert _same(out[2, 0][r], out[1, 0][r]), ('restart %d: 2 groups vs 1 group' % r, out[2, 0][r], out[1, 0][r])
 
 
 def test_config3_per_gpu_share_and_the_whole_job_on_one_gpu(workload):
