@@ -280,7 +280,10 @@ int rmx_trial_rollback(rmx_batch *b, int32_t r, int32_t param_id, const double *
  * trial = 1), without another pass: right after the h M-step's accept test they are E[ll] at (accepted h, committed parameters),
  * i.e. the "before" of the parameter accept tests, for every restart whose h was accepted (restarts whose h was rolled back: trial = 0,
  * which costs no pass either).  A restart's own expectations then stay stale until the next ELBO / sweep: ONE full refresh per EM
- * iteration instead of one after the h M-step and one after the parameter M-steps. */
+ * iteration instead of one after the h M-step and one after the parameter M-steps.
+ * trial = 3: the same per restart, for a range the last rmx_expected_ll_full_trial covered: the scratch sums for the restarts whose own
+ * expectations are stale (h kept), the sums of their own expectations for the others (rolled back, or untouched) -- the mixed outcome
+ * of a batch's h accept tests without a refresh pass; RMX_EUNSUPPORTED if that trial pass is not the last one over the range. */
 int rmx_expected_ll_components(rmx_batch *b, int32_t r0, int32_t r1, int32_t trial, double *out);
 /* per-cell values, for tests (:751-776, :809-853): u/v/w in {0,1} */
 int rmx_log_likelihood_total(rmx_batch *b, int32_t r, int32_t n, int32_t s, int32_t u, double *out);

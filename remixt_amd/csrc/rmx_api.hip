@@ -142,6 +142,7 @@ struct rmx_batch {
     std::vector<void *> allocs;
     // profiling
     bool fbk_ok = false;   // k_fbk usable: log-weights of every uniform class equal -pen * min(SAD, SAD swapped)
+    std::vector<double> trial_comp; int trial_comp_r0 = -1, trial_comp_r1 = -1;   // component sums of the last rmx_expected_ll_full_trial's scratch expectations
     double *d_A2 = nullptr, *d_Bv2 = nullptr;   // [R][N][2], [R][N][4]: (A, B) of a trial parameter value (rmx_expected_ll_full_trial)
     uint32_t *d_cnpack = nullptr, *d_totpack = nullptr; double *d_wk = nullptr;   // [C][S], [C][S], [TC][64]
     int pe2p = 0;     // padded row length of pe2_lt (0: no product table)
@@ -885,7 +886,7 @@ int rmx_batch_create(const rmx_problem *pr, int32_t R, const double *h_init, con
         const bool want = b->opt[RMX_OPT_CELL_CACHE] != 0;
         if (want && S > 32 && S <= 384 && bytes <= ((size_t)96 << 30)) { double *p_ = nullptr; if (dalloc(b, &p_, RNS * 6) == RMX_OK) { d.lc = p_; b->use_cache = true; } }
     }
-    if ((rc = dalloc(b, &b->d_lt_valid, R)) || (rc = dalloc(b, &b->d_partial, (size_t)R * ELBO_BLOCKS * 4)) || (rc = dalloc(b, &b->d_be_e, (size_t)R * std::max(d.NBE, 1))) || (rc = dalloc(b, &b->d_out4, (size_t)R * 4)) ||
+    if ((rc = dalloc(b, &b->d_lt_valid, R)) || (rc = dalloc(b, &b->d_partial, (size_t)R * ELBO_BLOCKS * 5)) || (rc = dalloc(b, &b->d_be_e, (size_t)R * std::max(d.NBE, 1))) || (rc = dalloc(b, &b->d_out4, (size_t)R * 5)) ||
         (rc = dalloc(b, &b->d_ell_partial, (size_t)R * std::max(N, ELBO_BLOCKS) * (1 + RMX_MAX_CLONES))) || (rc = dalloc(b, &b->d_ell_out, (size_t)R * 8)) ||
         (rc = dalloc(b, &b->d_sample, (size_t)R * N)) || (rc = dalloc(b, &b->d_grid_out, (size_t)R * 64 * (1 + RMX_MAX_CLONES))) ||
         (rc = dalloc(b, &b->d_done, std::max(R, 16))) || (rc = dalloc(b, &b->d_rlist, R)) || (rc = dalloc(b, &b->d_counts, R)) || (rc = dalloc(b, &b->d_rp_stage, R)) || (rc = dalloc(b, &b->d_batch_out, (size_t)R * 8))) { rmx_batch_destroy(b); return rc; }
@@ -2333,6 +2334,7 @@ int rmx_expected_ll_full(rmx_batch *b, int32_t r0, int32_t r1, double *out) { BI
 // rmx_trial_rollback puts the old value back and declares (A, B) / cache current again.
 // the stale components of (A, B) of restarts [r0, r1) at their current (trial) parameter values into the scratch copy d2
 static int trial_pass(rmx_batch *b, int r0, int r1, Dev &d2) {
+    b->trial_comp_r0 = b->trial_comp_r1 = -1;      // the scratch expectations are about to change
     int rc = ensure_tables(b, r0, r1);
     if (rc) return rc;
     const Dev &d = b->d;
@@ -2372,12 +2374,21 @@ int rmx_expected_ll_full_trial(rmx_batch *b, int32_t r0, int32_t r1, double *out
     int rc = trial_pass(b, r0, r1, d2);
     if (rc) return rc;
     const int nr = r1 - r0;
+    // ... and, behind it in the same queue and the same transfer, the four component sums of these scratch expectations: where the h M-step
+    // keeps its trial h they are the parameter M-steps' "before" values (rmx_expected_ll_components trial = 2), served from the host copy
+    double *cpart = b->d_partial + (size_t)b->R * ELBO_BLOCKS, *cout = b->d_out4 + b->R;
+    b->trial_comp_r0 = b->trial_comp_r1 = -1;
     { ProfScope ps(b, KID_ELL_FULL); hipLaunchKernelGGL(k_ell_full_batch, dim3(ELBO_BLOCKS, nr), dim3(256), 0, b->stream, d2, r0, b->d_partial); }
     { ProfScope ps(b, KID_ELL_FINAL); hipLaunchKernelGGL(k_sum_partials, dim3(nr), dim3(256), 0, b->stream, (const double *)b->d_partial, ELBO_BLOCKS, b->d_out4); }
+    { ProfScope ps(b, KID_ELL_FULL); hipLaunchKernelGGL(k_ell_comp_batch, dim3(ELBO_BLOCKS, nr), dim3(256), 0, b->stream, d2, r0, cpart); }
+    { ProfScope ps(b, KID_ELL_FINAL); hipLaunchKernelGGL(k_sum_partials, dim3(nr * 4), dim3(256), 0, b->stream, (const double *)cpart, ELBO_BLOCKS, cout); }
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(b->h_pinned, b->d_out4, (size_t)nr * 8, hipMemcpyDeviceToHost, b->stream));
+    HIPCHK(hipMemcpyAsync(b->h_pinned + nr, cout, (size_t)nr * 32, hipMemcpyDeviceToHost, b->stream));
     if ((rc = check_errors(b, r0, r1))) return rc;
     for (int i = 0; i < nr; i++) out[i] = b->h_pinned[i];
+    b->trial_comp.assign(b->h_pinned + nr, b->h_pinned + nr + (size_t)nr * 4);
+    b->trial_comp_r0 = r0; b->trial_comp_r1 = r1;
     return RMX_OK;
 }
 // The full-data E[ll] of restarts [r0, r1) split into its four likelihood components (out[i][c]: NB total with u = 0 / 1, BB
@@ -2391,6 +2402,29 @@ int rmx_expected_ll_components(rmx_batch *b, int32_t r0, int32_t r1, int32_t tri
     if (!out) return fail(RMX_EARG, "bad argument");
     int rc;
     Dev d2 = b->d;
+    if (trial == 2 && b->trial_comp_r0 == r0 && b->trial_comp_r1 == r1) {      // summed behind that trial pass already
+        for (int i = 0; i < (r1 - r0) * 4; i++) out[i] = b->trial_comp[i];
+        return RMX_OK;
+    }
+    if (trial == 3) {
+        // per restart: the scratch expectations of the last rmx_expected_ll_full_trial over this range where the restart's own are stale (it
+        // kept the trial h), its own where they are current (it was rolled back, or nothing changed) -- no pass over the cells for either
+        if (b->trial_comp_r0 != r0 || b->trial_comp_r1 != r1) return fail(RMX_EUNSUPPORTED, "no trial pass over this range to take the expectations from");
+        const int nr = r1 - r0;
+        bool own = false;
+        // (stale = some component is: ab_dirty alone is also raised by a table rebuild that changes no value, e.g. after a rollback)
+        for (int r = r0; r < r1; r++) own |= b->comp_dirty[r] == 0;
+        if (own) {
+            { ProfScope ps(b, KID_ELL_FULL); hipLaunchKernelGGL(k_ell_comp_batch, dim3(ELBO_BLOCKS, nr), dim3(256), 0, b->stream, d2, r0, b->d_partial); }
+            { ProfScope ps(b, KID_ELL_FINAL); hipLaunchKernelGGL(k_sum_partials, dim3(nr * 4), dim3(256), 0, b->stream, (const double *)b->d_partial, ELBO_BLOCKS, b->d_out4); }
+            HIPCHK(hipGetLastError());
+            HIPCHK(hipMemcpyAsync(b->h_pinned, b->d_out4, (size_t)nr * 32, hipMemcpyDeviceToHost, b->stream));
+            if ((rc = check_errors(b, r0, r1))) return rc;
+        }
+        for (int r = r0; r < r1; r++)
+            for (int c = 0; c < 4; c++) out[(r - r0) * 4 + c] = b->comp_dirty[r] != 0 ? b->trial_comp[(size_t)(r - r0) * 4 + c] : b->h_pinned[(r - r0) * 4 + c];
+        return RMX_OK;
+    }
     if (trial == 2) { d2.A = b->d_A2; d2.Bv = b->d_Bv2; }      // the scratch expectations of the last trial pass over this range, as they are
     else if (trial) { if ((rc = trial_pass(b, r0, r1, d2))) return rc; }
     else if ((rc = ensure_ab(b, r0, r1))) return rc;

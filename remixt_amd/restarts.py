@@ -470,9 +470,14 @@ class RestartSet(object):
         # restart's own expectations are refreshed once, after the parameter M-steps (by the ELBO), instead of here and there.
         kept = getattr(self, '_h_trial_kept', None)
         self._h_trial_kept = None
-        if kept is not None and len(kept) == R and all(kept):
-            cur = b.expected_log_likelihood_components(0, R, trial=2)
-        else:
+        cur = None
+        if kept is not None and len(kept) == R:
+            try:
+                # (restarts that kept their trial h: from the trial pass's scratch; rolled back ones: from their own, still current)
+                cur = b.expected_log_likelihood_components(0, R, trial=2 if all(kept) else 3)
+            except NotImplementedError:
+                cur = None
+        if cur is None:
             cur = b.expected_log_likelihood_components(0, R)
         self._mark('p:ell_before')
         for name in lead:

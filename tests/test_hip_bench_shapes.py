@@ -520,3 +520,40 @@ def test_joint_accept_decides_like_the_sequential_accept_tests(hip, seed, N, max
     assert rejected[0] == rejected[1]
     for a, b_ in zip(*out):
         assert a[0] == b_[0] and np.array_equal(a[1], b_[1]) and a[2] == b_[2]
+
+
+def test_components_after_a_mixed_h_accept_need_no_refresh_pass(hip):
+    """rmx_expected_ll_components(trial=3): after the h accept test of a batch in which some restarts keep their trial h and others are
+    rolled back, the "before" values of the parameter accept tests come from the trial pass's scratch expectations (kept) and from the
+    restart's own, still current ones (rolled back) -- equal, up to the rounding between the sparse trial pass and the dense refresh, to
+    what a refresh pass over the cells gives; and refused when the last pass over the range was not that trial pass."""
+    from remixt_amd import synthetic
+    from remixt_amd.restarts import RestartSet
+    e = synthetic.make_experiment(400, num_clones=3, max_copy_number=6, num_chains=4, seed=21)
+    ps = synthetic.make_init_params(e, 4, 6)
+    rs = RestartSet(e, ps, max_copy_number=6, num_clones=3, quiet=True, seeds=[1, 2, 3, 4])
+    b = rs.batch
+    R = 4
+    b.variational_update(2)
+    with pytest.raises(NotImplementedError):
+        b.expected_log_likelihood_components(0, R, trial=3)             # no trial pass yet
+    before = b.expected_log_likelihood_full(0, R)
+    own = b.expected_log_likelihood_components(0, R)
+    h0 = [np.array(b.get_array(r, 'h')) for r in range(R)]
+    for r in range(R):
+        rs.models[r].model.h = h0[r] * (1.02 + 0.01 * r)
+    after = b.expected_log_likelihood_full_trial(0, R)
+    assert np.all(np.isfinite(after)) and not np.allclose(after, before, rtol=1e-9)
+    for r in (1, 3):
+        b.rollback_h(r, h0[r])                                          # restarts 1 and 3 reject, 0 and 2 keep the trial h
+    mixed = b.expected_log_likelihood_components(0, R, trial=3)
+    for r in (1, 3):
+        assert np.array_equal(mixed[r], own[r])                         # their own expectations, untouched by the trial
+    for r in (0, 2):
+        assert abs(mixed[r].sum() - after[r]) <= 1e-9 * abs(after[r])   # the trial pass's E[ll], split into components
+    dense = b.expected_log_likelihood_components(0, R)                  # the refresh pass the mixed call saves
+    np.testing.assert_allclose(mixed, dense, rtol=1e-10)
+    tried = b.expected_log_likelihood_components(0, R, trial=True)      # a new trial pass over the range ...
+    with pytest.raises(NotImplementedError):
+        b.expected_log_likelihood_components(0, R, trial=3)             # ... ends the validity of the first one's sums
+    np.testing.assert_allclose(tried, dense, rtol=1e-10)                # (nothing on trial: the same expectations)
