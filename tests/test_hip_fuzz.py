@@ -1,0 +1,13 @@
+"""A fixed handful of tests/fuzz_small.py's randomised small, irregular problems (HIP path against the CPU oracle after every
+coordinate update): ragged restart counts, chains of two segments, breakpoints on a third of the segments, every forward-backward
+workgroup shape."""
+import pytest
+
+from tests import fuzz_small
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize('seed', [0, 1, 2, 3, 5, 8, 13, 21, 34, 55])
+def test_small_irregular_problem_matches_oracle(oracle_mod, seed):
+    fuzz_small.run_case(fuzz_small.draw_case(seed), oracle_mod)
