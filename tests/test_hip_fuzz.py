@@ -11,3 +11,10 @@ pytestmark = pytest.mark.gpu
 @pytest.mark.parametrize('seed', [0, 1, 2, 3, 5, 8, 13, 21, 34, 55])
 def test_small_irregular_problem_matches_oracle(oracle_mod, seed):
     fuzz_small.run_case(fuzz_small.draw_case(seed), oracle_mod)
+
+
+@pytest.mark.parametrize('seed', [6, 9, 13, 30, 53])
+def test_small_irregular_problem_fits_like_the_oracle_driver(oracle_mod, seed):
+    """Two whole EM iterations (sweeps, lock-step h M-step, shared-round searches, joint accept, ELBO) of the batched device driver against
+    the per-restart driver over the oracle."""
+    fuzz_small.run_fit_case(fuzz_small.draw_case(seed), oracle_mod)
