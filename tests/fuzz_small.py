@@ -13,8 +13,13 @@ import traceback
 import numpy as np
 
 
-def draw_case(seed):
+def draw_case(seed, big=False):
+    """big: the benchmark's state grids (3 clones, max copy number 8 or 12: 165 / 355 states) on 12-40 segments"""
     rng = np.random.RandomState(100003 * seed + 17)
+    if big:
+        N = int(rng.choice([12, 20, 33, 40]))
+        return dict(seed=seed, N=N, chains=int(rng.randint(1, 4)), M=3, max_cn=int(rng.choice([8, 12])), nbrk=int(rng.choice([1, 3, N // 4])),
+                    R=int(rng.randint(1, 10)), fb_nv=int(rng.choice([0, 0, 0, 1, 2, 4])), shared=bool(rng.randint(0, 2)))
     N = int(rng.choice([4, 5, 7, 12, 20, 33, 64, 90]))
     chains = int(rng.randint(1, min(6, N // 2) + 1))
     M = int(rng.choice([2, 3, 3]))
@@ -86,6 +91,7 @@ def run_fit_case(case, oracle_mod, em_iters=2):
 def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument('--seeds', default='0:40')
+    ap.add_argument('--big', action='store_true', help='165 / 355 states')
     ap.add_argument('--fit', action='store_true', help='whole EM iterations through the restart drivers instead of single coordinate updates')
     args = ap.parse_args(argv)
     lo, hi = [int(v) for v in args.seeds.split(':')]
@@ -93,7 +99,7 @@ def main(argv=None):
     oracle.build()
     bad = 0
     for seed in range(lo, hi):
-        case = draw_case(seed)
+        case = draw_case(seed, args.big)
         try:
             if args.fit:
                 if case['N'] < 20:
