@@ -1777,9 +1777,9 @@ static int queue_ell(rmx_batch *b, int r, bool grad, double *dst) {
             const int32_t r32 = r;
             // objective + gradient from the lists of states with posterior mass when they are current (the batched
             // evaluation of the lock-step h M-step asks the same question: both drivers sum the same terms)
-            if (grad && ell_sparse_ok(b, 1, &r32)) hipLaunchKernelGGL(k_ell_list_sparse_grad, dim3((cnt + 7) / 8), dim3(256), 0, b->stream, b->d, r, list, cnt, partial);
+            if (grad && ell_sparse_ok(b, 1, &r32)) hipLaunchKernelGGL(k_ell_list_sparse_grad, dim3((cnt + SEG_PER_BLOCK - 1) / SEG_PER_BLOCK), dim3(256), 0, b->stream, b->d, r, list, cnt, partial);
             else if (grad) hipLaunchKernelGGL(k_ell_list<true>, dim3(cnt), ell_block(b), 0, b->stream, b->d, r, list, partial);
-            else if (ell_sparse_ok(b, 1, &r32)) hipLaunchKernelGGL(k_ell_list_sparse_val, dim3((cnt + 7) / 8), dim3(256), 0, b->stream, b->d, r, list, cnt, partial);
+            else if (ell_sparse_ok(b, 1, &r32)) hipLaunchKernelGGL(k_ell_list_sparse_val, dim3((cnt + SEG_PER_BLOCK - 1) / SEG_PER_BLOCK), dim3(256), 0, b->stream, b->d, r, list, cnt, partial);
             else hipLaunchKernelGGL(k_ell_list<false>, dim3(cnt), ell_block(b), 0, b->stream, b->d, r, list, partial);
         }
         { ProfScope ps(b, KID_ELL_FINAL); hipLaunchKernelGGL(k_ell_final, dim3(1), dim3(256), 0, b->stream, (const double *)partial, cnt, dst); }
@@ -1891,7 +1891,7 @@ static int run_ell_batch(rmx_batch *b, int nreq, const int32_t *restarts, bool g
             ProfScope ps(b, KID_ELL_LIST);
             if (grad && ell_sparse_ok(b, nreq, restarts)) {
                 // (the final sums ride in the same launch: the block that finishes a request last reduces its partials)
-                hipLaunchKernelGGL(k_ell_list_batch_sparse_grad_final, dim3((maxcnt + 7) / 8, nreq), dim3(256), 0, b->stream, b->d, (const int32_t *)b->d_rlist,
+                hipLaunchKernelGGL(k_ell_list_batch_sparse_grad_final, dim3((maxcnt + SEG_PER_BLOCK - 1) / SEG_PER_BLOCK, nreq), dim3(256), 0, b->stream, b->d, (const int32_t *)b->d_rlist,
                                    (const RestartParams *)b->d_rp_stage, (const int32_t *)b->d_sample, (const int32_t *)b->d_counts, b->d_ell_partial, pstride,
                                    b->d_done, res, nout, eres);
                 final_done = true;
@@ -1911,7 +1911,7 @@ static int run_ell_batch(rmx_batch *b, int nreq, const int32_t *restarts, bool g
                 case 12: kf = k_ell_list_batch<false, 12>; break;
                 default: break;
                 }
-                hipLaunchKernelGGL(kf, sparse ? dim3((maxcnt + 7) / 8, nreq) : dim3(maxcnt, nreq), sparse ? dim3(256) : ell_block(b), 0, b->stream, b->d,
+                hipLaunchKernelGGL(kf, sparse ? dim3((maxcnt + SEG_PER_BLOCK - 1) / SEG_PER_BLOCK, nreq) : dim3(maxcnt, nreq), sparse ? dim3(256) : ell_block(b), 0, b->stream, b->d,
                                    (const int32_t *)b->d_rlist, (const RestartParams *)b->d_rp_stage,
                                    (const int32_t *)b->d_sample, (const int32_t *)b->d_counts, b->d_ell_partial, pstride);
             }
@@ -2029,7 +2029,7 @@ int rmx_param_search(rmx_batch *b, int32_t nreq, const int32_t *restarts, int32_
                 void (*kf)(Dev, SearchVals, const int32_t *, const int32_t *, double *, int) =
                     sparse_search ? (mask == CM_LT0 ? k_ell_search_sparse<CM_LT0> : (mask == CM_LT1 ? k_ell_search_sparse<CM_LT1> : (mask == CM_LA0 ? k_ell_search_sparse<CM_LA0> : k_ell_search_sparse<CM_LA1>)))
                                   : (mask == CM_LT0 ? k_ell_search<CM_LT0> : (mask == CM_LT1 ? k_ell_search<CM_LT1> : (mask == CM_LA0 ? k_ell_search<CM_LA0> : k_ell_search<CM_LA1>)));
-                hipLaunchKernelGGL(kf, sparse_search ? dim3((maxcnt + 7) / 8, n_, Gz) : dim3(maxcnt, n_, Gz), sparse_search ? dim3(256) : ell_block(b), 0, b->stream, b->d, sv,
+                hipLaunchKernelGGL(kf, sparse_search ? dim3((maxcnt + SEG_PER_BLOCK - 1) / SEG_PER_BLOCK, n_, Gz) : dim3(maxcnt, n_, Gz), sparse_search ? dim3(256) : ell_block(b), 0, b->stream, b->d, sv,
                                    (const int32_t *)b->d_sample, (const int32_t *)b->d_counts, b->d_ell_partial, std::max(maxcnt, 1));
             }
             { ProfScope ps(b, KID_ELL_FINAL); hipLaunchKernelGGL(k_ell_search_final, dim3(n_ * Gz), dim3(256), 0, b->stream, b->d, sv, (const int32_t *)b->d_counts, (const double *)b->d_ell_partial, std::max(maxcnt, 1), b->h_pinned, b->h_err); }
@@ -2253,7 +2253,7 @@ int rmx_param_search_multi(rmx_batch *b, int32_t nreq, const int32_t *restarts, 
             std::lock_guard<std::mutex> lk(b->mu);
             if (mc > 0) {
                 ProfScope ps(b, KID_ELL_LIST);
-                hipLaunchKernelGGL(k_ell_search_multi, dim3((mc + 7) / 8, n_, m2.Gz), dim3(256), 0, b->stream, b->d, m2, (const int32_t *)b->d_msample,
+                hipLaunchKernelGGL(k_ell_search_multi, dim3((mc + SEG_PER_BLOCK - 1) / SEG_PER_BLOCK, n_, m2.Gz), dim3(256), 0, b->stream, b->d, m2, (const int32_t *)b->d_msample,
                                    (const int32_t *)b->d_mcounts, b->d_mpartial, std::max(mc, 1));
             }
             { ProfScope ps(b, KID_ELL_FINAL); hipLaunchKernelGGL(k_ell_multi_final, dim3(n_ * m2.Gz), dim3(256), 0, b->stream, b->d, m2, (const int32_t *)b->d_mcounts,
@@ -2359,7 +2359,7 @@ static int trial_pass(rmx_batch *b, int r0, int r1, Dev &d2) {
                 case 4: kf = k_trial_sparse<4>; break; case 8: kf = k_trial_sparse<8>; break; case 12: kf = k_trial_sparse<12>; break;
                 default: kf = k_trial_sparse<15>; break;
                 }
-                hipLaunchKernelGGL(kf, dim3((d.N + 7) / 8, e - r), dim3(256), 0, b->stream, d2, r);
+                hipLaunchKernelGGL(kf, dim3((d.N + TRIAL_SEG_PER_BLOCK - 1) / TRIAL_SEG_PER_BLOCK, e - r), dim3(256), 0, b->stream, d2, r);
             }
             else if (use_strip(b)) hipLaunchKernelGGL(cells_kernel(b, 2, mask, 0), strip_grid(b, e - r), dim3(256), 0, b->stream, d2, r);
             else hipLaunchKernelGGL(k_marginals<false>, row_grid(b, e - r), dim3(256), 0, b->stream, d2, r, b->G);

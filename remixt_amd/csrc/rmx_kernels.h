@@ -10,6 +10,14 @@
 // the breakpoint update and the ELBO actually need it.
 #pragma once
 #include "rmx_device.h"
+// Lanes per segment in the kernels that walk the per-segment lists of states with posterior mass (mean 13 listed states, at most 32).
+// The sampled objectives of the M-step rounds (<= 200 segments per request: one workgroup wave, latency-bound) keep half a wave per
+// segment -- every listed state in one step; the trial passes over all segments (throughput-bound) take a quarter wave and a second
+// step for the segments with more than 16 listed states: 81 % instead of 40 % of the lanes at work (h:trial 1.6 -> 0.94 ms).
+#define SEGL 32
+#define SEG_PER_BLOCK (256 / SEGL)
+#define TRIAL_SEGL 16
+#define TRIAL_SEG_PER_BLOCK (256 / TRIAL_SEGL)
 
 // =============================================================================
 // per-restart tables
@@ -1955,14 +1963,14 @@ __global__ __launch_bounds__(256) void k_cells(Dev d, int r0) {
 // k_trial_sparse: the (A, B) expectations of the components in MASK at the restarts' CURRENT parameters
 // into d.A / d.Bv (the caller passes a Dev whose A / Bv point at scratch), from the per-segment lists of
 // states with posterior mass (built by the last marginal pass): ~13 of 165 states per segment carry all
-// of the posterior, the others cannot move the rounded sums (RMX_POST_EPS).  Half a wave per segment;
+// of the posterior, the others cannot move the rounded sums (RMX_POST_EPS).  A quarter wave per segment (TRIAL_SEGL);
 // segments whose list overflowed (count 255) walk all states.  State-table error flags are reported for
-// every state.  grid (ceil(N / 8), nr), block 256.
+// every state.  grid (ceil(N / 16), nr), block 256.
 // =============================================================================
 template <int MASK>
 __global__ __launch_bounds__(256) void k_trial_sparse(Dev d, int r0) {
     const int r = r0 + blockIdx.y;
-    const int n = blockIdx.x * 8 + (threadIdx.x >> 5), j = threadIdx.x & 31;
+    const int n = blockIdx.x * TRIAL_SEG_PER_BLOCK + (threadIdx.x / TRIAL_SEGL), j = threadIdx.x & (TRIAL_SEGL - 1);
     if (n >= d.N) return;
     const RestartParams &rp = d.rp[r];
     SegCtx sc; load_seg(d, r, n, sc);
@@ -1980,15 +1988,15 @@ __global__ __launch_bounds__(256) void k_trial_sparse(Dev d, int r0) {
         a0 += ps * LT[0]; a1 += ps * LT[1];
         b0 += ps * LA[0]; b1 += ps * LA[1]; b2 += ps * LA[2]; b3 += ps * LA[3];
     };
-    if (cnt == 255) { for (int s = j; s < d.S; s += 32) one(s); }
+    if (cnt == 255) { for (int s = j; s < d.S; s += TRIAL_SEGL) one(s); }
     else {
-        if (j < cnt) one((int)d.sig_idx[rn * RMX_SIGK + j]);
-        if (MASK & (CM_LA0 | CM_LA1)) for (int s = j; s < d.S; s += 32) cell_static_errors<MASK>(sc, d.stFlags[((size_t)r * d.C + cls) * d.SP + s], err);
+        for (int jj = j; jj < cnt; jj += TRIAL_SEGL) one((int)d.sig_idx[rn * RMX_SIGK + jj]);
+        if (MASK & (CM_LA0 | CM_LA1)) for (int s = j; s < d.S; s += TRIAL_SEGL) cell_static_errors<MASK>(sc, d.stFlags[((size_t)r * d.C + cls) * d.SP + s], err);
     }
-    if (MASK & CM_LT0) { a0 = group_sum(a0, 32); if (j == 0) d.A[rn * 2] = a0; }
-    if (MASK & CM_LT1) { a1 = group_sum(a1, 32); if (j == 0) d.A[rn * 2 + 1] = a1; }
-    if (MASK & CM_LA0) { b0 = group_sum(b0, 32); b1 = group_sum(b1, 32); if (j == 0) { d.Bv[rn * 4] = b0; d.Bv[rn * 4 + 1] = b1; } }
-    if (MASK & CM_LA1) { b2 = group_sum(b2, 32); b3 = group_sum(b3, 32); if (j == 0) { d.Bv[rn * 4 + 2] = b2; d.Bv[rn * 4 + 3] = b3; } }
+    if (MASK & CM_LT0) { a0 = group_sum(a0, TRIAL_SEGL); if (j == 0) d.A[rn * 2] = a0; }
+    if (MASK & CM_LT1) { a1 = group_sum(a1, TRIAL_SEGL); if (j == 0) d.A[rn * 2 + 1] = a1; }
+    if (MASK & CM_LA0) { b0 = group_sum(b0, TRIAL_SEGL); b1 = group_sum(b1, TRIAL_SEGL); if (j == 0) { d.Bv[rn * 4] = b0; d.Bv[rn * 4 + 1] = b1; } }
+    if (MASK & CM_LA1) { b2 = group_sum(b2, TRIAL_SEGL); b3 = group_sum(b3, TRIAL_SEGL); if (j == 0) { d.Bv[rn * 4 + 2] = b2; d.Bv[rn * 4 + 3] = b3; } }
     if (err) atomicOr(&d.err[r], err);
 }
 
@@ -2775,7 +2783,7 @@ __device__ __forceinline__ void ell_segment(const Dev &d, const RestartParams &r
 // on different segments.
 template <int MASK, bool OVR>
 __device__ __forceinline__ void ell_segment_sparse(const Dev &d, const RestartParams &rp, int r, int n, double *prow) {
-    const int lane = threadIdx.x & 31;      // half a wave per segment
+    const int lane = threadIdx.x & (SEGL - 1);      // SEGL lanes per segment
     SegCtx sc;
     sc.x = d.x[n]; sc.l = d.l[n]; sc.logl = d.logl[n]; sc.y0 = d.y[2 * (size_t)n]; sc.y1 = d.y[2 * (size_t)n + 1]; sc.ys = sc.y0 + sc.y1;
     sc.mt = d.mask_t[n]; sc.ma = d.mask_a[n];
@@ -2785,7 +2793,7 @@ __device__ __forceinline__ void ell_segment_sparse(const Dev &d, const RestartPa
     if ((MASK & (CM_LT0 | CM_LT1)) && (lane & 7) < 4) k_ = seg_const_value(rp, sc.x, sc.y0, sc.ys, lane & 7);
     if ((MASK & (CM_LA0 | CM_LA1)) && (lane & 7) >= 4) k_ = seg_const_value(rp, sc.x, sc.y0, sc.ys, lane & 7);
 #pragma unroll
-    for (int i = 0; i < 4; i++) { sc.cnb[i] = __shfl(k_, i, 32); sc.cbb[i] = __shfl(k_, 4 + i, 32); }
+    for (int i = 0; i < 4; i++) { sc.cnb[i] = __shfl(k_, i, SEGL); sc.cbb[i] = __shfl(k_, 4 + i, SEGL); }
     const int cls = d.seg_class[n];
     const size_t rn = (size_t)r * d.N + n;
     const double qt0 = d.qt[rn * 2], qt1 = d.qt[rn * 2 + 1], qa0 = d.qa[rn * 2], qa1 = d.qa[rn * 2 + 1];
@@ -2809,25 +2817,25 @@ __device__ __forceinline__ void ell_segment_sparse(const Dev &d, const RestartPa
         if (MASK & CM_LA1) { acc += ps * qa1 * qs0 * LA[2]; acc += ps * qa1 * qs1 * LA[3]; }
     };
     const int cnt = d.sig_cnt[rn];
-    if (cnt == 255) { for (int s = lane; s < d.S; s += 32) one(s); }
+    if (cnt == 255) { for (int s = lane; s < d.S; s += SEGL) one(s); }
     else {
-        if (lane < cnt) one((int)d.sig_idx[rn * RMX_SIGK + lane]);
-        for (int s = lane; s < d.S; s += 32) cell_static_errors<MASK>(sc, d.stFlags[((size_t)r * d.C + cls) * d.SP + s], err);
+        for (int jj = lane; jj < cnt; jj += SEGL) one((int)d.sig_idx[rn * RMX_SIGK + jj]);
+        for (int s = lane; s < d.S; s += SEGL) cell_static_errors<MASK>(sc, d.stFlags[((size_t)r * d.C + cls) * d.SP + s], err);
     }
-    acc = group_sum(acc, 32);
+    acc = group_sum(acc, SEGL);
     if (lane == 0) prow[0] = acc;
     if (err) atomicOr(&d.err[r], err);
 }
 // E[ll] and d/dh of one sampled segment from its list of states with posterior mass: half a wave per segment,
 // a lane per listed state (ell_segment_sparse with the gradient terms; all four likelihood components)
 __device__ __forceinline__ void ell_segment_sparse_grad(const Dev &d, const RestartParams &rp, int r, int n, double *prow) {
-    const int lane = threadIdx.x & 31;
+    const int lane = threadIdx.x & (SEGL - 1);
     SegCtx sc;
     sc.x = d.x[n]; sc.l = d.l[n]; sc.logl = d.logl[n]; sc.y0 = d.y[2 * (size_t)n]; sc.y1 = d.y[2 * (size_t)n + 1]; sc.ys = sc.y0 + sc.y1;
     sc.mt = d.mask_t[n]; sc.ma = d.mask_a[n];
     const double k_ = seg_const_value(rp, sc.x, sc.y0, sc.ys, lane & 7);
 #pragma unroll
-    for (int i = 0; i < 4; i++) { sc.cnb[i] = __shfl(k_, i, 32); sc.cbb[i] = __shfl(k_, 4 + i, 32); }
+    for (int i = 0; i < 4; i++) { sc.cnb[i] = __shfl(k_, i, SEGL); sc.cbb[i] = __shfl(k_, 4 + i, SEGL); }
     const int cls = d.seg_class[n];
     const size_t rn = (size_t)r * d.N + n;
     const double qt0 = d.qt[rn * 2], qt1 = d.qt[rn * 2 + 1], qa0 = d.qa[rn * 2], qa1 = d.qa[rn * 2 + 1];
@@ -2836,26 +2844,26 @@ __device__ __forceinline__ void ell_segment_sparse_grad(const Dev &d, const Rest
     unsigned err = 0;
     double acc = 0., g[RMX_MAX_CLONES] = {0., 0., 0., 0.};
     const int cnt = d.sig_cnt[rn];
-    if (cnt == 255) { for (int s = lane; s < d.S; s += 32) ell_state_terms<true, CM_ALL, false>(d, rp, sc, r, cls, s, post[s], qt0, qt1, qa0, qa1, qs0, qs1, acc, g, err); }
+    if (cnt == 255) { for (int s = lane; s < d.S; s += SEGL) ell_state_terms<true, CM_ALL, false>(d, rp, sc, r, cls, s, post[s], qt0, qt1, qa0, qa1, qs0, qs1, acc, g, err); }
     else {
-        if (lane < cnt) { const int s = (int)d.sig_idx[rn * RMX_SIGK + lane]; ell_state_terms<true, CM_ALL, false>(d, rp, sc, r, cls, s, post[s], qt0, qt1, qa0, qa1, qs0, qs1, acc, g, err); }
-        for (int s = lane; s < d.S; s += 32) cell_static_errors<CM_ALL>(sc, d.stFlags[((size_t)r * d.C + cls) * d.SP + s], err);
+        for (int jj = lane; jj < cnt; jj += SEGL) { const int s = (int)d.sig_idx[rn * RMX_SIGK + jj]; ell_state_terms<true, CM_ALL, false>(d, rp, sc, r, cls, s, post[s], qt0, qt1, qa0, qa1, qs0, qs1, acc, g, err); }
+        for (int s = lane; s < d.S; s += SEGL) cell_static_errors<CM_ALL>(sc, d.stFlags[((size_t)r * d.C + cls) * d.SP + s], err);
     }
-    acc = group_sum(acc, 32);
+    acc = group_sum(acc, SEGL);
     if (lane == 0) prow[0] = acc;
 #pragma unroll
-    for (int m = 0; m < RMX_MAX_CLONES; m++) { const double gm = group_sum(g[m], 32); if (lane == 0) prow[1 + m] = gm; }
+    for (int m = 0; m < RMX_MAX_CLONES; m++) { const double gm = group_sum(g[m], SEGL); if (lane == 0) prow[1 + m] = gm; }
     if (err) atomicOr(&d.err[r], err);
 }
 // value only (all four components): the same per-state terms and summation as ell_segment_sparse_grad's value
 __global__ __launch_bounds__(256) void k_ell_list_sparse_val(Dev d, int r, const int32_t *list, int count, double *partial) {
-    const int i = blockIdx.x * 8 + (threadIdx.x >> 5);
+    const int i = blockIdx.x * SEG_PER_BLOCK + (threadIdx.x / SEGL);
     if (i >= count) return;
     ell_segment_sparse<CM_ALL, false>(d, d.rp[r], r, list[i], partial + (size_t)i * (1 + RMX_MAX_CLONES));
 }
 // grid (ceil(count / 8)), block 256: restart r's sampled segments, half a wave each
 __global__ __launch_bounds__(256) void k_ell_list_sparse_grad(Dev d, int r, const int32_t *list, int count, double *partial) {
-    const int i = blockIdx.x * 8 + (threadIdx.x >> 5);
+    const int i = blockIdx.x * SEG_PER_BLOCK + (threadIdx.x / SEGL);
     if (i >= count) return;
     ell_segment_sparse_grad(d, d.rp[r], r, list[i], partial + (size_t)i * (1 + RMX_MAX_CLONES));
 }
@@ -2863,7 +2871,7 @@ __global__ __launch_bounds__(256) void k_ell_list_sparse_grad(Dev d, int r, cons
 __global__ __launch_bounds__(256) void k_ell_list_batch_sparse_grad(Dev d, const int32_t *rlist, const RestartParams *stage, const int32_t *samples, const int32_t *counts,
                                                                     double *partial, int pstride) {
     const int r = rlist[blockIdx.y];
-    const int i = blockIdx.x * 8 + (threadIdx.x >> 5);
+    const int i = blockIdx.x * SEG_PER_BLOCK + (threadIdx.x / SEGL);
     if (i >= counts[r]) return;
     const int n = samples[(size_t)r * d.N + i];
     ell_segment_sparse_grad(d, stage[blockIdx.y], r, n, partial + (size_t)r * pstride + (size_t)i * (1 + RMX_MAX_CLONES));
@@ -2877,7 +2885,7 @@ __global__ __launch_bounds__(256) void k_ell_list_batch_sparse_grad_final(Dev d,
     __shared__ double scratch[8];
     __shared__ int last;
     const int r = rlist[blockIdx.y];
-    const int i = blockIdx.x * 8 + (threadIdx.x >> 5);
+    const int i = blockIdx.x * SEG_PER_BLOCK + (threadIdx.x / SEGL);
     const int cnt = counts[r];
     if (i < cnt) ell_segment_sparse_grad(d, stage[blockIdx.y], r, samples[(size_t)r * d.N + i], partial + (size_t)r * pstride + (size_t)i * (1 + RMX_MAX_CLONES));
     // ONE release per block, behind the barrier that orders the block's partial sums before it: a release fence writes the L2's dirty lines
@@ -2981,7 +2989,7 @@ template <int MASK>
 __global__ __launch_bounds__(256) void k_ell_list_batch_sparse(Dev d, const int32_t *rlist, const RestartParams *stage, const int32_t *samples, const int32_t *counts,
                                                                double *partial, int pstride) {
     const int r = rlist[blockIdx.y];
-    const int i = blockIdx.x * 8 + (threadIdx.x >> 5);
+    const int i = blockIdx.x * SEG_PER_BLOCK + (threadIdx.x / SEGL);
     if (i >= counts[r]) return;
     const int n = samples[(size_t)r * d.N + i];
     ell_segment_sparse<MASK, false>(d, stage[blockIdx.y], r, n, partial + (size_t)r * pstride + (size_t)i * (1 + RMX_MAX_CLONES));
@@ -3030,7 +3038,7 @@ template <int MASK>
 __global__ __launch_bounds__(256) void k_ell_search_sparse(Dev d, SearchVals sv, const int32_t *samples, const int32_t *counts, double *partial, int maxcnt) {
     const int req = blockIdx.y, gz = blockIdx.z;
     const int r = sv.rlist[req];
-    const int i = blockIdx.x * 8 + (threadIdx.x >> 5);
+    const int i = blockIdx.x * SEG_PER_BLOCK + (threadIdx.x / SEGL);
     if (i >= counts[r]) return;
     const int n = samples[(size_t)r * d.N + i];
     RestartParams rp = d.rp[r];
@@ -3061,7 +3069,7 @@ struct MultiVals {
 __global__ __launch_bounds__(256) void k_ell_search_multi(Dev d, MultiVals mv, const int32_t *samples, const int32_t *counts, double *partial, int maxcnt) {
     const int req = blockIdx.y, gz = blockIdx.z;
     const int r = mv.rlist[req], sl = mv.slot[req];
-    const int i = blockIdx.x * 8 + (threadIdx.x >> 5);
+    const int i = blockIdx.x * SEG_PER_BLOCK + (threadIdx.x / SEGL);
     if (i >= counts[sl * d.R + r]) return;
     const int n = samples[((size_t)sl * d.R + r) * d.N + i];
     const double v = mv.grid_stage ? mv.gv[sl][gz] : mv.v[req], lv = mv.grid_stage ? mv.glv[sl][gz] : mv.lv[req];
