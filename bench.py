@@ -622,16 +622,18 @@ def extra_states(args, rs_main, device):
     BASELINE.json's metric string is quoted on), everything else as the headline workload; 20 timed steps like the headline."""
     _release(rs_main)
     max_cn, R, nsteps = 12, args.restarts, 20
-    # one group: at 355 states the forward-backward launch dominates the step and carries all 16 restarts
-    rs, S, N1, dt, elbo, prof = _timed_run(args, device, R, 1, max_cn, nsteps, 2)
+    # two restart groups, paced (RestartGroups pair_fb 'auto' above 200 states): 144 EM iterations/s against 134 for one group of 16 and 118
+    # for two free-running groups (tools/s355_groups.sh)
+    G355 = 2
+    rs, S, N1, dt, elbo, prof = _timed_run(args, device, R, G355, max_cn, nsteps, 2)
     hot = [(k, prof[k]) for k in ALG_BYTES_PER_CELL if k in prof]
     dom = max(hot, key=lambda kv: kv[1][0]) if hot else (None, (0., 0))
     a355 = argparse.Namespace(**vars(args)); a355.max_cn = max_cn
-    out = {'metric': 'EM iterations/sec (%dk seg x %d states)' % (args.segments // 1000, S), 'states': S, 'max_cn': max_cn, 'restart_groups': 1,
+    out = {'metric': 'EM iterations/sec (%dk seg x %d states)' % (args.segments // 1000, S), 'states': S, 'max_cn': max_cn, 'restart_groups': G355, 'paced_groups': bool(getattr(rs, 'paced', False)),
            'value': R * nsteps / dt, 'unit': 'EM iterations/s', 'ms_per_step': dt / nsteps * 1e3, 'steps': nsteps, 'warmup': 2,
            'seg_state_cells_per_s': float(N1) * S * R * args.update_iters * nsteps / dt, 'elbo_best': float(np.nanmax(elbo)),
            'forward_backward_kernel': {1: 'k_fbm', 2: 'k_fbv', 3: 'k_fbk', 4: 'k_fbq', 0: 'k_fb<0>'}.get(rs.batches[0].info(12)),
-           'roofline': roofline_object(dom, float(N1) * S * R, S, a355, R, traffic_file='traffic_r03_s355.json'),
+           'roofline': roofline_object(dom, float(N1) * S * R / G355, S, a355, R // G355, traffic_file='traffic_r03_s355_8.json'),
            'kernels': dict((k, {'ms': round(v[0], 3), 'n': v[1]}) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0]))}
     _release(rs)
     return out

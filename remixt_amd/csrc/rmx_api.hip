@@ -47,7 +47,7 @@ static const char *kKernelNames[KID_COUNT] = {
 struct ProfRec { int id; hipEvent_t a, b; };
 
 // tuning options (include/remixt_amd.h rmx_option_id): process-wide defaults, copied into a batch at creation
-static int g_opt_default[RMX_OPT_COUNT] = {0, 0, 1, 1, 1, 0, 0, 0, 1, 1, 1, 0, 0};
+static int g_opt_default[RMX_OPT_COUNT] = {0, 0, 1, 1, 1, 0, 0, 0, 1, 1, 1, 0, 0, 0};
 static std::mutex g_opt_mu;
 
 // Two batches of one device and one experiment whose sweeps run on different host threads (the two restart groups of a GPU):
@@ -61,7 +61,8 @@ struct FbPair {
     int fb_left[2] = {0, 0};          // forward-backward points a side will still reach in its current rmx_variational_update (0: not sweeping)
     int posted[2] = {0, 0};           // the side has posted a launch and waits
     int joined[2] = {0, 0};           // ... and the other side has launched it
-    FbmArgs args[2]; int ny[2] = {0, 0}, kb[2] = {0, 0}, nct[2] = {0, 0}; size_t lds[2] = {0, 0};
+    FbmArgs args[2]; int ny[2] = {0, 0}, kb[2] = {0, 0}, nct[2] = {0, 0}, kind[2] = {0, 0}; size_t lds[2] = {0, 0};      // kind: 1 k_fbm, 4 k_fbq
+    const double *wk[2] = {nullptr, nullptr}; const uint32_t *cnpack[2] = {nullptr, nullptr}, *totpack[2] = {nullptr, nullptr};      // (k_fbq's tables)
     hipEvent_t ready[2] = {nullptr, nullptr}, done[2] = {nullptr, nullptr};
     long long n_joint = 0, n_solo = 0, wait_ns = 0;
 };
@@ -1293,7 +1294,7 @@ static int do_framelogprob(rmx_batch *b, int r0, int r1) {
 // (2) -- and update_p_breakpoint behind it -- on a second stream next to (3).
 // The forward-backward point of a paired batch inside rmx_variational_update (FbPair).  *launched: the forward-backward of
 // m's range has been queued, by this side (for both) or by the other.
-static int fb_joint(rmx_batch *b, ProfScope &ps, const FbmArgs &m, int KB, int NCT, size_t lds, int ny, bool *launched) {
+static int fb_joint(rmx_batch *b, ProfScope &ps, int kind, const FbmArgs &m, int KB, int NCT, size_t lds, int ny, bool *launched) {
     FbPair *p = b->pair.get();
     const int x = b->pair_side, y = 1 - x;
     std::unique_lock<std::mutex> lk(p->mu);
@@ -1301,15 +1302,24 @@ static int fb_joint(rmx_batch *b, ProfScope &ps, const FbmArgs &m, int KB, int N
     b->pair_point_passed = true;
     if (p->posted[y]) {
         const FbmArgs &o = p->args[y];
-        const bool same = p->kb[y] == KB && p->nct[y] == NCT && p->lds[y] == lds && o.S == m.S && o.SP == m.SP && o.M == m.M && o.D == m.D && o.C == m.C &&
+        const bool same = p->kind[y] == kind && p->kb[y] == KB && p->nct[y] == NCT && p->lds[y] == lds && o.S == m.S && o.SP == m.SP && o.M == m.M && o.D == m.D && o.C == m.C &&
                           o.N == m.N && o.NBE == m.NBE && o.cn_max == m.cn_max && o.PE2P == m.PE2P && o.SPC == m.SPC && o.VR == m.VR && o.pad_ == m.pad_ && o.pen == m.pen;
         if (!same) { p->posted[y] = 0; p->n_solo++; p->cv.notify_all(); return RMX_OK; }      // both launch alone
         HIPCHK(hipStreamWaitEvent(b->stream, p->ready[y], 0));
         ps.restart(KID_FB_JOINT);
-        FbmArgs2 a2; a2.s[0] = m; a2.s[1] = o; a2.ny0 = ny;
-        void (*kf)(FbmArgs2) = KB == 8 ? k_fbm2<8> : (KB == 16 ? k_fbm2<16> : (KB == 28 ? k_fbm2<28> : (KB == 36 ? k_fbm2<36> : (KB == 42 ? k_fbm2<42> : k_fbm2<44>))));
-        HIPCHK(hipFuncSetAttribute((const void *)kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(kf, dim3(b->n_fast, ny + p->ny[y], 2), dim3(64 * NCT), lds, b->stream, a2);
+        if (kind == 1) {
+            FbmArgs2 a2; a2.s[0] = m; a2.s[1] = o; a2.ny0 = ny;
+            void (*kf)(FbmArgs2) = KB == 8 ? k_fbm2<8> : (KB == 16 ? k_fbm2<16> : (KB == 28 ? k_fbm2<28> : (KB == 36 ? k_fbm2<36> : (KB == 42 ? k_fbm2<42> : k_fbm2<44>))));
+            HIPCHK(hipFuncSetAttribute((const void *)kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL(kf, dim3(b->n_fast, ny + p->ny[y], 2), dim3(64 * NCT), lds, b->stream, a2);
+        } else {
+            FbqArgs2 a2; a2.s[0] = m; a2.s[1] = o; a2.ny0 = ny;
+            a2.wk[0] = b->d_wk; a2.cnpack[0] = b->d_cnpack; a2.totpack[0] = b->d_totpack;
+            a2.wk[1] = p->wk[y]; a2.cnpack[1] = p->cnpack[y]; a2.totpack[1] = p->totpack[y];
+            void (*kf)(FbqArgs2) = KB == 64 ? k_fbq2<64> : k_fbq2<90>;
+            HIPCHK(hipFuncSetAttribute((const void *)kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL(kf, dim3(b->n_fast, ny + p->ny[y], 2), dim3(64 * NCT), lds, b->stream, a2);
+        }
         HIPCHK(hipGetLastError());
         HIPCHK(hipEventRecord(p->done[y], b->stream));
         p->posted[y] = 0; p->joined[y] = 1; p->n_joint++;
@@ -1320,7 +1330,8 @@ static int fb_joint(rmx_batch *b, ProfScope &ps, const FbmArgs &m, int KB, int N
     if (p->fb_left[y] <= 0) { p->n_solo++; return RMX_OK; }       // the other side is not sweeping
     // first at the point: post, wait for the other side to arrive (it is inside a sweep: at most about one sweep away)
     HIPCHK(hipEventRecord(p->ready[x], b->stream));
-    p->args[x] = m; p->ny[x] = ny; p->kb[x] = KB; p->nct[x] = NCT; p->lds[x] = lds; p->posted[x] = 1; p->joined[x] = 0;
+    p->args[x] = m; p->ny[x] = ny; p->kb[x] = KB; p->nct[x] = NCT; p->lds[x] = lds; p->kind[x] = kind; p->posted[x] = 1; p->joined[x] = 0;
+    p->wk[x] = b->d_wk; p->cnpack[x] = b->d_cnpack; p->totpack[x] = b->d_totpack;
     const long long t0 = now_ns();
     p->cv.wait_for(lk, std::chrono::milliseconds(50), [&] { return !p->posted[x] || p->fb_left[y] <= 0; });
     p->wait_ns += now_ns() - t0;
@@ -1390,7 +1401,7 @@ static int p_cn_front(rmx_batch *b, int r0, int r1, bool skip_frame, bool snapsh
                 const int ny = ((r1 - 1) >> 2) - (r0 >> 2) + 1;
                 bool queued = false;
 
-                if (b->pair_sweeping && (rc = fb_joint(b, ps, m, KB, NCT, lds, ny, &queued))) return rc;
+                if (b->pair_sweeping && (rc = fb_joint(b, ps, 1, m, KB, NCT, lds, ny, &queued))) return rc;
                 if (!queued) {
                     HIPCHK(hipFuncSetAttribute((const void *)kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
                     hipLaunchKernelGGL(kf, dim3(b->n_fast, ny, 2), dim3(64 * NCT), lds, b->stream, m);
@@ -1462,9 +1473,14 @@ static int p_cn_front(rmx_batch *b, int r0, int r1, bool skip_frame, bool snapsh
             const size_t lds = (size_t)2 * m.VR * 4 * 8 + (size_t)2 * 4 * m.PE2P * 8 + 64 * 32 * 8 + 64 * 8 + (size_t)4 * KB * 4 + (size_t)b->be_cap * 4 + 64;
             void (*kf)(FbmArgs, const double *, const uint32_t *, const uint32_t *) = KB == 64 ? k_fbq<64> : k_fbq<90>;
             if (NWq <= 12 && 4 * KB >= d.S && lds <= kLdsBudget) {
-                HIPCHK(hipFuncSetAttribute((const void *)kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-                hipLaunchKernelGGL(kf, dim3(b->n_fast, ((r1 - 1) >> 2) - (r0 >> 2) + 1, 2), dim3(64 * NWq), lds, b->stream, m,
-                                   (const double *)b->d_wk, (const uint32_t *)b->d_cnpack, (const uint32_t *)b->d_totpack);
+                const int ny = ((r1 - 1) >> 2) - (r0 >> 2) + 1;
+                bool queued = false;
+                if (b->pair_sweeping && (rc = fb_joint(b, ps, 4, m, KB, NWq, lds, ny, &queued))) return rc;
+                if (!queued) {
+                    HIPCHK(hipFuncSetAttribute((const void *)kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                    hipLaunchKernelGGL(kf, dim3(b->n_fast, ny, 2), dim3(64 * NWq), lds, b->stream, m,
+                                       (const double *)b->d_wk, (const uint32_t *)b->d_cnpack, (const uint32_t *)b->d_totpack);
+                }
                 done_fast = true; fast = true; b->last_fb_kernel = 4; b->last_fb_nv = 4;
             }
         }
@@ -1591,15 +1607,16 @@ int rmx_variational_update(rmx_batch *b, int32_t r0, int32_t r1, int32_t iters) 
     // paired batches: a sweep's forward-backward point is reached in (device) real time -- not before the previous sweep's
     // forward-backward has finished -- so that the other side, arriving from its M-step, finds launches still to combine
     PairSweepGuard pair_guard(b, iters);
-    if (b->pair_sweeping && !b->ev_pair_fb) HIPCHK(hipEventCreateWithFlags(&b->ev_pair_fb, hipEventDisableTiming));
+    const bool paced = b->pair_sweeping || b->opt[RMX_OPT_PACE_SWEEPS];
+    if (paced && !b->ev_pair_fb) HIPCHK(hipEventCreateWithFlags(&b->ev_pair_fb, hipEventDisableTiming));
     for (int it = 0; it < iters; it++) {
         int rc;
-        if (b->pair_sweeping && it > 0) HIPCHK(hipEventSynchronize(b->ev_pair_fb));
+        if (paced && it > 0) HIPCHK(hipEventSynchronize(b->ev_pair_fb));
         const bool fused_in = fusable && it > 0, fuse_out = fusable && it + 1 < iters;
         if (!fused_in && (rc = do_indicator(b, r0, r1, 2))) return rc;
         if (two_streams) {
             if ((rc = p_cn_front(b, r0, r1, fused_in, snapshot_done))) return rc;
-            if (b->pair_sweeping) HIPCHK(hipEventRecord(b->ev_pair_fb, b->stream));
+            if (paced) HIPCHK(hipEventRecord(b->ev_pair_fb, b->stream));
             // breakend branch on the second stream: pairwise reductions -> p_breakpoint -> cached transition tables
             hipStream_t main_stream = b->stream;
             HIPCHK(hipEventRecord(b->ev_fb, main_stream));
@@ -1616,7 +1633,7 @@ int rmx_variational_update(rmx_batch *b, int32_t r0, int32_t r1, int32_t iters) 
             HIPCHK(hipStreamWaitEvent(main_stream, b->ev_brk, 0));
         } else {
             if ((rc = do_update_p_cn(b, r0, r1, fused_in, fuse_out)) || (rc = do_update_p_breakpoint(b, r0, r1))) return rc;
-            if (b->pair_sweeping) HIPCHK(hipEventRecord(b->ev_pair_fb, b->stream));
+            if (paced) HIPCHK(hipEventRecord(b->ev_pair_fb, b->stream));
         }
         if (!fuse_out && ((rc = do_indicator(b, r0, r1, 0)) || (rc = do_indicator(b, r0, r1, 1)))) return rc;
     }

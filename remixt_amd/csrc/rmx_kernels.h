@@ -1190,12 +1190,12 @@ template <int KB> struct fbq_chain {
 };
 
 template <int KB>
-__global__ __launch_bounds__(768) void k_fbq(FbmArgs a, const double *wk, const uint32_t *cnpack, const uint32_t *totpack) {
+__device__ __forceinline__ void fbq_body(const FbmArgs &a, const double *wk, const uint32_t *cnpack, const uint32_t *totpack, const int by) {
     extern __shared__ __align__(16) unsigned char smem_raw[];
     static_assert(KB % 2 == 0 && KB / 2 >= FBQ_DEPTH, "k-blocks come in pairs; ring no deeper than the chain");
     constexpr int NW32 = KB / 2;
     const int chain = a.chain_list[blockIdx.x], dir = blockIdx.z;
-    const int quad = (a.r0 >> 2) + blockIdx.y, rg0 = quad * FBM_NV;
+    const int quad = (a.r0 >> 2) + by, rg0 = quad * FBM_NV;
     const int v_lo = max(a.r0 - rg0, 0), v_hi = min(a.r1 - rg0, FBM_NV);
     const int S = a.S, SP = a.SP, M = a.M, D = a.D, VR = a.VR;
     const int n0 = a.chain_start[chain], n1 = a.chain_end[chain], len = n1 - n0 + 1;
@@ -1287,7 +1287,7 @@ __global__ __launch_bounds__(768) void k_fbq(FbmArgs a, const double *wk, const 
     }
     eptr0 += rstep; eptr1 += rstep;
     FB_BARRIER();
-    if (a.dbg && t == 0 && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0) { a.dbg[0] = clock64(); a.dbg[1] = wall_clock64(); a.dbg[4] = len; }
+    if (a.dbg && t == 0 && blockIdx.x == 0 && by == 0 && blockIdx.z == 0) { a.dbg[0] = clock64(); a.dbg[1] = wall_clock64(); a.dbg[4] = len; }
     // tail of a step (k_fbm's FBM_FINISH for two tiles): tile 0's ones column holds the sum of the previous row
 #define FBQ_FINISH(s0_, s1_, e0_, e1_, k_)                                                                                         \
     {                                                                                                                              \
@@ -1405,7 +1405,7 @@ __global__ __launch_bounds__(768) void k_fbq(FbmArgs a, const double *wk, const 
     }
 #undef FBQ_FINISH
 #undef FBQ_FETCH
-    if (a.dbg && t == 0 && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0) { a.dbg[2] = clock64(); a.dbg[3] = wall_clock64(); }
+    if (a.dbg && t == 0 && blockIdx.x == 0 && by == 0 && blockIdx.z == 0) { a.dbg[2] = clock64(); a.dbg[3] = wall_clock64(); }
     if (wave == 0) {
         const double *vb = vec + (size_t)((len - 1) & 1) * VR * 4;
         double ps = 0.;
@@ -1419,6 +1419,15 @@ __global__ __launch_bounds__(768) void k_fbq(FbmArgs a, const double *wk, const 
         }
     }
 #undef ROW
+}
+template <int KB>
+__global__ __launch_bounds__(768) void k_fbq(FbmArgs a, const double *wk, const uint32_t *cnpack, const uint32_t *totpack) { fbq_body<KB>(a, wk, cnpack, totpack, blockIdx.y); }
+// one launch over the ranges of two paired batches (see k_fbm2)
+struct FbqArgs2 { FbmArgs s[2]; const double *wk[2]; const uint32_t *cnpack[2], *totpack[2]; int ny0; };
+template <int KB>
+__global__ __launch_bounds__(768) void k_fbq2(FbqArgs2 p) {
+    const int side = (int)blockIdx.y >= p.ny0 ? 1 : 0;
+    fbq_body<KB>(p.s[side], p.wk[side], p.cnpack[side], p.totpack[side], (int)blockIdx.y - (side ? p.ny0 : 0));
 }
 
 // =============================================================================

@@ -577,3 +577,32 @@ def test_components_after_a_mixed_h_accept_need_no_refresh_pass(hip):
     with pytest.raises(NotImplementedError):
         b.expected_log_likelihood_components(0, R, trial=3)             # ... ends the validity of the first one's sums
     np.testing.assert_allclose(tried, dense, rtol=1e-10)                # (nothing on trial: the same expectations)
+
+
+@pytest.mark.parametrize('max_cn,kernel', [(12, 4), (8, 1)])
+def test_paired_groups_launch_one_forward_backward_kernel_for_both(hip, max_cn, kernel):
+    """rmx_pair_batches: while both restart groups are inside a sweep their forward-backward launches go out as ONE launch (k_fbq2 at 355
+    states, k_fbm2 at 165): the posteriors of every restart equal the one-group run's bit for bit, with combined launches (pair_fb=1), with the
+    pacing alone (pair_fb=2) and free-running (pair_fb=0)."""
+    from remixt_amd import synthetic
+    from remixt_amd.restarts import RestartGroups
+    e = synthetic.make_experiment(70, num_clones=3, max_copy_number=max_cn, num_chains=3, seed=12, num_breakpoints=6)
+    ps = synthetic.make_init_params(e, 8, max_cn)
+    out = {}
+    for groups, pair in ((1, 0), (2, 0), (2, 2), (2, 1)):
+        rs = RestartGroups(e, ps, max_cn, groups=groups, num_clones=3, quiet=True, seeds=list(range(8)), pair_fb=pair)
+        rs.variational_update(3)                      # both groups' threads enter their sweeps together
+        b = rs.batches[0]
+        assert b.info(12) == kernel and b.info(13) == 4
+        joint, solo, _ = b.pair_stats()
+        if pair == 1:
+            assert joint > 0 and 2 * joint + solo == 2 * 3
+        elif pair == 2:
+            assert rs.paced and (joint, solo) == (0, 0) and b.get_option('pace_sweeps') == 1
+        else:
+            assert (joint, solo) == (0, 0)
+        out[groups, pair] = [(np.array(m.model.posterior_marginals), np.array(m.model.p_breakpoint), np.array(m.model.p_allele_swap)) for m in rs.models]
+    for key in ((2, 0), (2, 2), (2, 1)):
+        for r in range(8):
+            for x, y in zip(out[key][r], out[1, 0][r]):
+                assert np.array_equal(x, y), (key, r)

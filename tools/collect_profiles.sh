@@ -22,6 +22,7 @@ pmc() { # tag, restarts, max_cn, states
 pmc 8 8 8 165
 pmc 16 16 8 165
 pmc s355 16 12 355
+pmc s355_8 8 12 355
 rocprofv3 --kernel-trace --stats -d $OUT/prof_s355 -o s --output-format csv -- python3 $ROOT/tools/fb_only.py > $OUT/prof_s355.log 2>&1
 cp $(find $OUT/prof_s355 -name "s_kernel_stats.csv" | head -1) $OUT/s355_kernel_stats.csv
 unset MAXCN
