@@ -522,6 +522,8 @@ def roofline_object(dom, cells_per_launch, S, args, restarts_per_launch, traffic
 
 def _release(rs_main):
     import gc
+    if rs_main is None:
+        return
     for s_ in rs_main.sets:          # release the headline batches' device memory
         s_.batch = None
         for m in s_.models:
@@ -556,7 +558,7 @@ def fit_from_init(args, rs_main, device):
     return out
 
 
-def one_group_roofline(args, rs_main, device):
+def one_group_roofline(args, rs_main, device, traffic_file='traffic_r03_16.json', nsteps=6):
     """The headline workload with ALL restarts of the GPU in one restart group: what the forward-backward kernel reaches when a
     launch carries 16 restarts instead of 8 (its duration is the latency of the chain of steps, not a function of the restart
     count), and what the step then costs (the M-steps are no longer hidden behind another group's sweeps)."""
@@ -574,7 +576,6 @@ def one_group_roofline(args, rs_main, device):
         m.prev_elbo = float(v)
     rs.run(2, 0, args.update_iters)
     rs.synchronize(); torch.cuda.synchronize()
-    nsteps = 6
     b.profile_reset(); b.profile_enable(2)
     t0 = time.perf_counter()
     rs.run(nsteps, 2, args.update_iters)
@@ -582,7 +583,7 @@ def one_group_roofline(args, rs_main, device):
     dt = time.perf_counter() - t0
     b.profile_enable(0)
     prof = rs.profile()
-    out = roofline_object(('k_fb', prof['k_fb']), float(N1) * S * R, S, args, R, traffic_file='traffic_r03_16.json')
+    out = roofline_object(('k_fb', prof['k_fb']), float(N1) * S * R, S, args, R, traffic_file=traffic_file)
     out['restart_groups'] = 1
     out['restarts_per_launch'] = R
     out['em_iterations_per_s_with_one_group'] = R * nsteps / dt
@@ -636,6 +637,11 @@ def extra_states(args, rs_main, device):
            'roofline': roofline_object(dom, float(N1) * S * R / G355, S, a355, R // G355, traffic_file='traffic_r03_s355_8.json'),
            'kernels': dict((k, {'ms': round(v[0], 3), 'n': v[1]}) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0]))}
     _release(rs)
+    # the forward-backward kernel at its other launch shape here too: all 16 restarts in one launch (one restart group)
+    try:
+        out['roofline_one_group'] = one_group_roofline(a355, None, device, traffic_file='traffic_r03_s355.json', nsteps=3)
+    except Exception as err:
+        out['roofline_one_group'] = {'error': str(err)}
     return out
 
 
