@@ -628,10 +628,12 @@ class RestartGroups(object):
         # groups when both are at the point; 0 = free-running.  Measured (tools/s355_groups.sh): at 165 states free-running wins
         # (407 it/s; paced 369, combined 403: the groups already hide each one's marginal pass under the other's forward-backward); at 355
         # states, where a forward-backward launch is 13 ms, free-running groups serialise (118 it/s, one group of 16: 134) and pacing wins
-        # (144).  'auto': pacing above 200 states.
+        # (144).  Groups of at most 4 restarts (a rank's share of 8 when 64 restarts are sharded over 8 GPUs) also gain from pacing at 165 states
+        # (2 x 4: 256 -> 272 it/s, 2 x 2: 148 -> 169; 2 x 6: 337 -> 326, 2 x 8: 407 -> 369).  'auto': pacing above 200 states or up to 4 restarts per group.
         if pair_fb == 'auto':
             b0 = self.sets[0].batch
-            pair_fb = 2 if (len(self.sets) >= 2 and b0 is not None and getattr(b0, 'num_cn_states', 0) > 200) else 0
+            small = max(len(rs.models) for rs in self.sets) <= 4
+            pair_fb = 2 if (len(self.sets) >= 2 and b0 is not None and (getattr(b0, 'num_cn_states', 0) > 200 or small)) else 0
         native = all(getattr(rs.batch, 'pair_with', None) is not None for rs in self.sets)
         self.paired = int(pair_fb) == 1 and len(self.sets) == 2 and native
         self.paced = int(pair_fb) == 2 and len(self.sets) >= 2 and native

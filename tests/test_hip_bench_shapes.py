@@ -586,7 +586,9 @@ def test_paired_groups_launch_one_forward_backward_kernel_for_both(hip, max_cn, 
     pacing alone (pair_fb=2) and free-running (pair_fb=0)."""
     from remixt_amd import synthetic
     from remixt_amd.restarts import RestartGroups
-    e = synthetic.make_experiment(70, num_clones=3, max_copy_number=max_cn, num_chains=3, seed=12, num_breakpoints=6)
+    # (long enough chains that a forward-backward launch takes about a millisecond: the second group's thread is then inside its call by the time
+    # the first reaches its second forward-backward point, so combined launches must happen)
+    e = synthetic.make_experiment(2400, num_clones=3, max_copy_number=max_cn, num_chains=3, seed=12, num_breakpoints=6)
     ps = synthetic.make_init_params(e, 8, max_cn)
     out = {}
     for groups, pair in ((1, 0), (2, 0), (2, 2), (2, 1)):
