@@ -51,7 +51,7 @@ def run_case(case, oracle_mod):
 
 def run_fit_case(case, oracle_mod, em_iters=2):
     """Whole EM iterations (sweeps, lock-step h M-step, parameter searches, accept tests, ELBO) of the batched driver on the device against
-    the per-restart driver over the oracle: same seeded trajectories -- ELBO to 1e-6, h to 1e-5, the same error messages."""
+    the per-restart driver over the oracle: same seeded trajectories -- ELBO to 1e-6, h to 1e-5 of its largest component, the same error messages."""
     from remixt_amd import synthetic
     from remixt_amd.restarts import RestartSet
     e = synthetic.make_experiment(case['N'], num_clones=case['M'], max_copy_number=case['max_cn'], num_chains=case['chains'],
@@ -84,7 +84,8 @@ def run_fit_case(case, oracle_mod, em_iters=2):
             skipped += 1
             continue
         assert np.isclose(a[1][r], b[1][r], rtol=1e-6), ('ELBO of restart %d' % r, a[1][r], b[1][r])
-        np.testing.assert_allclose(a[2][r], b[2][r], rtol=1e-5, err_msg='h of restart %d' % r)
+        # (a clone whose haploid depth is at the lower bound sits in a flat direction of the objective: absolute tolerance relative to the largest component)
+        np.testing.assert_allclose(a[2][r], b[2][r], rtol=1e-5, atol=1e-5 * float(np.max(np.abs(b[2][r]))), err_msg='h of restart %d' % r)
     return ('%d restart(s) failed their h M-step on one side; ' % skipped if skipped else '') + 'elbo ' + ' '.join('%.4f' % v for v in b[1])
 
 
