@@ -124,21 +124,10 @@ int rmx_synchronize(rmx_batch *b);
 /* derived sizes: 0 cn_max (bpmodel.pyx:489), 1 num chains, 2 num transition classes,
  * 3 num breakend segments, 4 padded row stride of [N][S] device arrays; 10 / 11 chains on the register-resident
  * forward-backward kernels / on the general one; 12 the forward-backward kernel the last update_p_cn launched for the
- * former (1 k_fbm: FP64 matrix cores, 2 k_fbv: vector FMA, 3 k_fbk: weights from packed copy numbers, 4 k_fbq: matrix cores with
+ * former (1 k_fbm: FP64 matrix cores at 4 restarts per workgroup, vector FMA at 2 / 1; 2 k_fbv: two-phase vector FMA, 3 k_fbk: weights from packed copy numbers, 4 k_fbq: matrix cores with
  * weights from 8-bit codes; 0: general kernel k_fb<0> only), 13 restarts per workgroup of that launch, 14 the lattice kernel of
- * the last decode (1 k_viterbi_reg, 2 k_viterbi_code, 3 k_viterbi); 64 / 65 / 66 of the batch's pair (rmx_pair_batches):
- * forward-backward launches made for both sides at once, launches made for one side alone while paired, ns a side's host
- * thread waited for the other side at a forward-backward point */
+ * the last decode (1 k_viterbi_reg, 2 k_viterbi_code, 3 k_viterbi) */
 int rmx_info(rmx_batch *b, int32_t what, int64_t *out);
-/* Pair two batches of ONE device holding the SAME experiment (the two restart groups of a GPU,
- * reference remixt/analysis/pipeline.py:253-264: independent restarts), each driven by its own host thread on its own
- * stream.  While both are inside rmx_variational_update, the forward-backward launches of their sweeps are issued as one
- * launch over both ranges (every workgroup runs what it would run in a launch over its own batch: results do not change);
- * a paired batch also reaches each sweep's forward-backward point only after the previous sweep's forward-backward has
- * finished on the device.  `other` NULL: dissolve a's pair.  Not to be called while either batch is inside another call;
- * destroying a batch dissolves its pair. */
-int rmx_pair_batches(rmx_batch *a, rmx_batch *other);
-
 /* -- tuning options ------------------------------------------------------- */
 /* Not part of the reference protocol: which of this library's equivalent kernels / launch shapes run.  Results do not
  * depend on them beyond rounding (tests/test_hip_*.py compare the alternatives); they exist so that tests can put a
@@ -146,8 +135,10 @@ int rmx_pair_batches(rmx_batch *a, rmx_batch *other);
  * batches created afterwards (process-wide); rmx_set_option to one batch (creation-time options: RMX_EARG). */
 enum rmx_option_id {
     RMX_OPT_FB_KERNEL = 0,      /* forward-backward: 0 auto, 1 general single-vector kernel for every chain, 2 tabulated weights
-                                   instead of on-the-fly weights for grids beyond the register-resident kernel (S > 176) */
-    RMX_OPT_FB_NV,              /* restarts advanced by one forward-backward workgroup: 0 auto, 1, 2, 4 (the shapes that exist) */
+                                   instead of on-the-fly weights for grids beyond the register-resident kernel (S > 176), 3 the two-phase
+                                   vector kernels (k_fbv up to 176 states, k_fbk above) instead of k_fbm / k_fbq */
+    RMX_OPT_FB_NV,              /* restarts advanced by one forward-backward workgroup: 0 auto (k_fbm: 4 on the matrix cores, or 2 / 1 on the
+                                   vector ALU while that many workgroups fit the chip's 256 CUs at once), 1, 2, 4 (the shapes that exist) */
     RMX_OPT_FB_BREAKEND_CODES,  /* 1 (default): breakend steps from pair codes + clone-product tables; 0: per-clone distance tables */
     RMX_OPT_FUSE_SWEEPS,        /* 1 (default): marginals + indicator updates + next frame pass as one kernel between sweeps */
     RMX_OPT_TWO_STREAMS,        /* 1 (default): breakend branch of a sweep on a second stream next to the marginal pass */
@@ -162,8 +153,7 @@ enum rmx_option_id {
     RMX_OPT_PAIRWISE_KERNEL,    /* breakend pairwise reductions: 0 auto (above 200 states k_pairwise_sp: the state pairs above the posterior threshold; else k_pairwise_be2), 1 general kernel
                                    (k_pairwise), 2 the dense pair-code kernel (k_pairwise_be2), 3 k_pairwise_sp */
     RMX_OPT_PACE_SWEEPS,        /* 1: rmx_variational_update reaches each sweep's forward-backward point only after the previous sweep's
-                                   forward-backward launch has finished on the device, instead of queueing all its sweeps at once (what a
-                                   paired batch always does); for restart groups that share a GPU -- at 355 states two paced groups of 8
+                                   forward-backward launch has finished on the device, instead of queueing all its sweeps at once; for restart groups that share a GPU -- at 355 states two paced groups of 8
                                    make 144 EM iterations/s, free-running ones 118 */
     RMX_OPT_COUNT
 };
@@ -177,9 +167,9 @@ int rmx_get_param(rmx_batch *b, int32_t r, int32_t param_id, double *value);
 int rmx_set_transition_model(rmx_batch *b, int32_t model);  /* bpmodel.pyx:456, 606-616 */
 int rmx_set_array(rmx_batch *b, int32_t r, int32_t array_id, const void *host_src);
 int rmx_get_array(rmx_batch *b, int32_t r, int32_t array_id, void *host_dst);
-/* The attributes p_outlier_total / p_outlier_allele (bpmodel.pyx:419-421) of restarts [r0, r1) in one transfer on a copy stream of
- * the batch's own, into pinned host memory the batch owns: *total / *allele point to [r1 - r0][N][2] float64, valid until the
- * next call.  What BreakpointModel.get_param_sample_weight (cn_model.py:323-352) reads at the start of every M-step. */
+/* The attributes p_outlier_total / p_outlier_allele (bpmodel.pyx:419-421) of restarts [r0, r1) in one transfer into registered
+ * host memory the batch owns: *total / *allele point to [r1 - r0][N][2] float64, valid until the next call.  The two copies are
+ * queued IN ORDER on the batch's stream (behind everything already queued there) and the call returns when they have landed.  What BreakpointModel.get_param_sample_weight (cn_model.py:323-352) reads at the start of every M-step. */
 int rmx_fetch_indicators(rmx_batch *b, int32_t r0, int32_t r1, const double **total, const double **allele);
 /* read-only derived state tables, (N,S[,M]) int64 like the reference attributes
  * cn_states_total / num_alleles_subclonal / is_hdel / is_loh (bpmodel.pyx:497-507):

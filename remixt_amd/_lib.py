@@ -45,7 +45,6 @@ SYMBOLS = {
     "rmx_set_transition_model": (C.c_int, [C.c_void_p, C.c_int32]),
     "rmx_set_array": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
     "rmx_get_array": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
-    "rmx_pair_batches": (C.c_int, [C.c_void_p, C.c_void_p]),
     "rmx_fetch_indicators": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(_dp), C.POINTER(_dp)]),
     "rmx_calculate_log_transmat": (C.c_int, [C.c_void_p, C.c_int32, _dp]),
     "rmx_weighted_search": (C.c_int, [_dp, C.c_int64, _dp, C.c_int32, _ip, _ip]),

@@ -208,15 +208,6 @@ class RemixtBatch(object):
     def synchronize(self):
         self._ck(self._lib.rmx_synchronize(self._handle))
 
-    def pair_with(self, other):
-        """Combine this batch's forward-backward launches with `other`'s while both are sweeping on their own host threads
-        (rmx_pair_batches); None dissolves the pair."""
-        self._ck(self._lib.rmx_pair_batches(self._handle, other._handle if other is not None else None))
-
-    def pair_stats(self):
-        """(joint launches, solo launches while paired, seconds waited at forward-backward points) of this batch's pair."""
-        return self.info(64), self.info(65), self.info(66) * 1e-9
-
     def set_option(self, name, value):
         """Tuning option of this batch (include/remixt_amd.h rmx_option_id): which equivalent kernel / launch shape runs."""
         self._ck(self._lib.rmx_set_option(self._handle, OPTION_IDS[name], int(value)))

@@ -37,12 +37,12 @@ static inline long long now_ns() { return std::chrono::duration_cast<std::chrono
 enum KernelId {
     KID_STATE_TABLES = 0, KID_SEG_CONST, KID_FRAMELOGPROB, KID_FB, KID_MARGINALS, KID_MARGINALS_AB, KID_OUTLIER_TOTAL,
     KID_OUTLIER_ALLELE, KID_ALLELE_SWAP, KID_BRK_LUT, KID_PAIRWISE, KID_BRK_UPDATE, KID_ELBO_SEG, KID_ELBO_FINAL,
-    KID_ELL_LIST, KID_ELL_FINAL, KID_ELL_FULL, KID_VITERBI, KID_BACKTRACE, KID_OTHER, KID_FB_JOINT, KID_COUNT
+    KID_ELL_LIST, KID_ELL_FINAL, KID_ELL_FULL, KID_VITERBI, KID_BACKTRACE, KID_OTHER, KID_COUNT
 };
 static const char *kKernelNames[KID_COUNT] = {
     "k_state_tables", "k_seg_const", "k_framelogprob", "k_fb", "k_marginals<true>", "k_marginals<false>", "k_update_outlier_total",
     "k_update_outlier_allele", "k_update_allele_swap", "k_brk_lut", "k_pairwise", "k_brk_update", "k_elbo_seg", "k_elbo_final",
-    "k_ell_list", "k_ell_final", "k_ell_full", "k_viterbi", "k_backtrace", "other", "k_fb_joint"};
+    "k_ell_list", "k_ell_final", "k_ell_full", "k_viterbi", "k_backtrace", "other"};
 
 struct ProfRec { int id; hipEvent_t a, b; };
 
@@ -50,28 +50,8 @@ struct ProfRec { int id; hipEvent_t a, b; };
 static int g_opt_default[RMX_OPT_COUNT] = {0, 0, 1, 1, 1, 0, 0, 0, 1, 1, 1, 0, 0, 0};
 static std::mutex g_opt_mu;
 
-// Two batches of one device and one experiment whose sweeps run on different host threads (the two restart groups of a GPU):
-// when both are inside rmx_variational_update, their forward-backward launches are combined into ONE launch (k_fbm2) -- at
-// 8 restarts a launch has 92 workgroups for 256 CUs, and launches of two streams were measured to run one after the other.
-// The side that reaches its forward-backward point first posts its arguments and waits (host); the second launches for both
-// on its own stream behind the first side's `ready` event and records `done`, which the first side's stream then waits for.
-struct FbPair {
-    std::mutex mu; std::condition_variable cv;
-    rmx_batch *side[2] = {nullptr, nullptr};
-    int fb_left[2] = {0, 0};          // forward-backward points a side will still reach in its current rmx_variational_update (0: not sweeping)
-    int posted[2] = {0, 0};           // the side has posted a launch and waits
-    int joined[2] = {0, 0};           // ... and the other side has launched it
-    FbmArgs args[2]; int ny[2] = {0, 0}, kb[2] = {0, 0}, nct[2] = {0, 0}, kind[2] = {0, 0}; size_t lds[2] = {0, 0};      // kind: 1 k_fbm, 4 k_fbq
-    const double *wk[2] = {nullptr, nullptr}; const uint32_t *cnpack[2] = {nullptr, nullptr}, *totpack[2] = {nullptr, nullptr};      // (k_fbq's tables)
-    hipEvent_t ready[2] = {nullptr, nullptr}, done[2] = {nullptr, nullptr};
-    long long n_joint = 0, n_solo = 0, wait_ns = 0;
-};
-
 struct rmx_batch {
-    std::shared_ptr<FbPair> pair; int pair_side = 0;
-    bool pair_sweeping = false;        // inside rmx_variational_update with the pair protocol on
-    bool pair_point_passed = false;
-    hipEvent_t ev_pair_fb = nullptr;   // the forward-backward of the previous sweep of this call has been queued up to here
+    hipEvent_t ev_pace = nullptr;      // pace_sweeps: the forward-backward of the previous sweep of this call has been queued up to here
     int opt[RMX_OPT_COUNT];
     int device = 0;
     hipStream_t stream = nullptr;
@@ -207,7 +187,7 @@ struct ProfScope {
     // per EM iteration -- the M-step objective kernels are launched thousands of times and two event
     // records per launch would slow the host loop being measured)
     static bool sweep_kernel(int id) {
-        return id == KID_FRAMELOGPROB || id == KID_FB || id == KID_FB_JOINT || id == KID_MARGINALS || id == KID_PAIRWISE || id == KID_BRK_LUT ||
+        return id == KID_FRAMELOGPROB || id == KID_FB || id == KID_MARGINALS || id == KID_PAIRWISE || id == KID_BRK_LUT ||
                id == KID_BRK_UPDATE || id == KID_OUTLIER_TOTAL || id == KID_OUTLIER_ALLELE || id == KID_ALLELE_SWAP;
     }
     ProfScope(rmx_batch *b_, int id_) : b(b_), id(id_) {
@@ -685,8 +665,8 @@ int rmx_last_error_restarts(int32_t *out, int32_t cap) {
 
 static bool option_value_ok(int id, int v) {
     switch (id) {
-    case RMX_OPT_FB_KERNEL: return v >= 0 && v <= 2;
-    case RMX_OPT_FB_NV: return v == 0 || v == 1 || v == 2 || v == 4;      // the workgroup shapes that exist (k_fbv 1 / 2 / 4, k_fbm 4)
+    case RMX_OPT_FB_KERNEL: return v >= 0 && v <= 3;
+    case RMX_OPT_FB_NV: return v == 0 || v == 1 || v == 2 || v == 4;      // the workgroup shapes that exist (k_fbm and k_fbv / k_fbk 1 / 2 / 4, k_fbq 4)
     case RMX_OPT_SEARCH_MODE: return v >= 0 && v <= 4;
     case RMX_OPT_PAIRWISE_KERNEL: return v >= 0 && v <= 3;
     default: return v == 0 || v == 1;
@@ -966,40 +946,9 @@ int rmx_batch_create(const rmx_problem *pr, int32_t R, const double *h_init, con
     return RMX_OK;
 }
 
-static void unpair(rmx_batch *b) {
-    std::shared_ptr<FbPair> p = b->pair;
-    if (!p) return;
-    {
-        std::lock_guard<std::mutex> lk(p->mu);
-        for (int x = 0; x < 2; x++) if (p->side[x]) { p->fb_left[x] = 0; p->posted[x] = 0; }
-        p->cv.notify_all();
-    }
-    for (int x = 0; x < 2; x++) if (p->side[x]) { rmx_batch *q = p->side[x]; p->side[x] = nullptr; q->pair.reset(); }
-    if (p.use_count() == 1) for (int x = 0; x < 2; x++) { if (p->ready[x]) hipEventDestroy(p->ready[x]); if (p->done[x]) hipEventDestroy(p->done[x]); p->ready[x] = p->done[x] = nullptr; }
-}
-// Not to be called while either batch is inside a call on another thread.
-int rmx_pair_batches(rmx_batch *a, rmx_batch *b2) {
-    if (!a) return fail(RMX_EARG, "null batch");
-    { rmx_batch *b = a; BIND(b); }
-    if (!b2) { unpair(a); return RMX_OK; }
-    if (a == b2) return fail(RMX_EARG, "a batch cannot be paired with itself");
-    if (a->device != b2->device) return fail(RMX_EARG, "paired batches must live on one device");
-    const Dev &x = a->d, &y = b2->d;
-    if (x.S != y.S || x.N != y.N || x.M != y.M || x.NBE != y.NBE || x.NC != y.NC || x.C != y.C || a->n_fast != b2->n_fast || a->pe2p != b2->pe2p)
-        return fail(RMX_EARG, "paired batches must hold the same experiment");
-    if (a->stream == b2->stream) return fail(RMX_EARG, "paired batches need their own streams");
-    unpair(a); unpair(b2);
-    auto p = std::make_shared<FbPair>();
-    for (int i = 0; i < 2; i++) { HIPCHK(hipEventCreateWithFlags(&p->ready[i], hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&p->done[i], hipEventDisableTiming)); }
-    p->side[0] = a; p->side[1] = b2;
-    a->pair = p; a->pair_side = 0; b2->pair = p; b2->pair_side = 1;
-    return RMX_OK;
-}
-
 int rmx_batch_destroy(rmx_batch *b) { BIND(b);
     if (!b) return RMX_OK;
     hipSetDevice(b->device);
-    unpair(b);
     if (b->stream) hipStreamSynchronize(b->stream);
     prof_collect(b);
     for (void *p : b->allocs) hipFree(p);
@@ -1014,7 +963,7 @@ int rmx_batch_destroy(rmx_batch *b) { BIND(b);
     for (auto e : b->done_ev) hipEventDestroy(e);
     if (b->stream2) { hipStreamSynchronize(b->stream2); hipStreamDestroy(b->stream2); hipEventDestroy(b->ev_fb); hipEventDestroy(b->ev_brk); }
     if (b->ev_copy) hipEventDestroy(b->ev_copy);
-    if (b->ev_pair_fb) hipEventDestroy(b->ev_pair_fb);
+    if (b->ev_pace) hipEventDestroy(b->ev_pace);
     if (b->h_ind) { hipHostUnregister(b->h_ind); free(b->h_ind); }
     if (b->own_stream && b->stream) hipStreamDestroy(b->stream);
     delete b;
@@ -1037,8 +986,6 @@ int rmx_info(rmx_batch *b, int32_t what, int64_t *out) { BIND(b);
     case 4: *out = b->d.SP; break; case 5: *out = b->fbv_rpt; break; case 6: *out = b->fbG.P; break; case 7: *out = b->fbG.NT; break;
     case 8: *out = b->fbG.BLK; break; case 9: *out = (int64_t)b->fbG_lds; break; case 10: *out = b->n_fast; break; case 11: *out = b->n_generic; break;
     case 60: *out = b->t_launch_ns; break; case 61: *out = b->t_wait_ns; break; case 62: *out = b->t_post_ns; break; case 63: *out = b->n_rounds; break;
-    case 64: case 65: case 66: { std::shared_ptr<FbPair> p = b->pair; if (!p) { *out = 0; break; } std::lock_guard<std::mutex> lk(p->mu);
-        *out = what == 64 ? p->n_joint : (what == 65 ? p->n_solo : p->wait_ns); break; }
     case 12: *out = b->last_fb_kernel; break; case 13: *out = b->last_fb_nv; break; case 14: *out = b->last_viterbi; break;
     case 20: case 21: case 22: case 23: case 24: case 25: case 26: case 27: case 28: case 29: case 30: case 31: case 32: case 33: case 34: case 35: case 36: case 37: case 38: case 39:
     case 40: case 41: case 42: case 43: case 44: case 45: case 46: case 47: case 48: case 49: case 50: case 51:
@@ -1292,75 +1239,17 @@ static int do_framelogprob(rmx_batch *b, int r0, int r1) {
 // the breakend adjacencies; (3) marginals.  (2) and (3) only read what (1) wrote and write disjoint arrays
 // (a fused marginal pass puts the next sweep's fe into the second buffer), so rmx_variational_update runs
 // (2) -- and update_p_breakpoint behind it -- on a second stream next to (3).
-// The forward-backward point of a paired batch inside rmx_variational_update (FbPair).  *launched: the forward-backward of
-// m's range has been queued, by this side (for both) or by the other.
-static int fb_joint(rmx_batch *b, ProfScope &ps, int kind, const FbmArgs &m, int KB, int NCT, size_t lds, int ny, bool *launched) {
-    FbPair *p = b->pair.get();
-    const int x = b->pair_side, y = 1 - x;
-    std::unique_lock<std::mutex> lk(p->mu);
-    if (p->fb_left[x] > 0) p->fb_left[x]--;
-    b->pair_point_passed = true;
-    if (p->posted[y]) {
-        const FbmArgs &o = p->args[y];
-        const bool same = p->kind[y] == kind && p->kb[y] == KB && p->nct[y] == NCT && p->lds[y] == lds && o.S == m.S && o.SP == m.SP && o.M == m.M && o.D == m.D && o.C == m.C &&
-                          o.N == m.N && o.NBE == m.NBE && o.cn_max == m.cn_max && o.PE2P == m.PE2P && o.SPC == m.SPC && o.VR == m.VR && o.pad_ == m.pad_ && o.pen == m.pen;
-        if (!same) { p->posted[y] = 0; p->n_solo++; p->cv.notify_all(); return RMX_OK; }      // both launch alone
-        HIPCHK(hipStreamWaitEvent(b->stream, p->ready[y], 0));
-        ps.restart(KID_FB_JOINT);
-        if (kind == 1) {
-            FbmArgs2 a2; a2.s[0] = m; a2.s[1] = o; a2.ny0 = ny;
-            void (*kf)(FbmArgs2) = KB == 8 ? k_fbm2<8> : (KB == 16 ? k_fbm2<16> : (KB == 28 ? k_fbm2<28> : (KB == 36 ? k_fbm2<36> : (KB == 42 ? k_fbm2<42> : k_fbm2<44>))));
-            HIPCHK(hipFuncSetAttribute((const void *)kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            hipLaunchKernelGGL(kf, dim3(b->n_fast, ny + p->ny[y], 2), dim3(64 * NCT), lds, b->stream, a2);
-        } else {
-            FbqArgs2 a2; a2.s[0] = m; a2.s[1] = o; a2.ny0 = ny;
-            a2.wk[0] = b->d_wk; a2.cnpack[0] = b->d_cnpack; a2.totpack[0] = b->d_totpack;
-            a2.wk[1] = p->wk[y]; a2.cnpack[1] = p->cnpack[y]; a2.totpack[1] = p->totpack[y];
-            void (*kf)(FbqArgs2) = KB == 64 ? k_fbq2<64> : k_fbq2<90>;
-            HIPCHK(hipFuncSetAttribute((const void *)kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            hipLaunchKernelGGL(kf, dim3(b->n_fast, ny + p->ny[y], 2), dim3(64 * NCT), lds, b->stream, a2);
-        }
-        HIPCHK(hipGetLastError());
-        HIPCHK(hipEventRecord(p->done[y], b->stream));
-        p->posted[y] = 0; p->joined[y] = 1; p->n_joint++;
-        p->cv.notify_all();
-        *launched = true;
-        return RMX_OK;
-    }
-    if (p->fb_left[y] <= 0) { p->n_solo++; return RMX_OK; }       // the other side is not sweeping
-    // first at the point: post, wait for the other side to arrive (it is inside a sweep: at most about one sweep away)
-    HIPCHK(hipEventRecord(p->ready[x], b->stream));
-    p->args[x] = m; p->ny[x] = ny; p->kb[x] = KB; p->nct[x] = NCT; p->lds[x] = lds; p->kind[x] = kind; p->posted[x] = 1; p->joined[x] = 0;
-    p->wk[x] = b->d_wk; p->cnpack[x] = b->d_cnpack; p->totpack[x] = b->d_totpack;
-    const long long t0 = now_ns();
-    p->cv.wait_for(lk, std::chrono::milliseconds(50), [&] { return !p->posted[x] || p->fb_left[y] <= 0; });
-    p->wait_ns += now_ns() - t0;
-    if (p->joined[x]) {
-        p->joined[x] = 0;
-        HIPCHK(hipStreamWaitEvent(b->stream, p->done[x], 0));
-        ps.cancel();
-        *launched = true;
-        return RMX_OK;
-    }
-    p->posted[x] = 0; p->n_solo++;
-    return RMX_OK;
+// workgroups of a forward-backward launch that run side by side (one per CU: the weights fill the register file)
+static const int g_fb_wg_budget = 256;
+#define FBM_KERNEL_CASE(NV_) switch (KB) { case 8: return k_fbm<8, NV_>; case 16: return k_fbm<16, NV_>; case 28: return k_fbm<28, NV_>; \
+                                           case 36: return k_fbm<36, NV_>; case 42: return k_fbm<42, NV_>; case 44: return k_fbm<44, NV_>; } return nullptr;
+static void (*fbm_kernel_for(int KB, int NV))(FbmArgs) {
+    if (NV == 4) { FBM_KERNEL_CASE(4) }
+    if (NV == 2) { FBM_KERNEL_CASE(2) }
+    if (NV == 1) { FBM_KERNEL_CASE(1) }
+    return nullptr;
 }
-// leaves the pair protocol when rmx_variational_update returns, whichever way
-struct PairSweepGuard {
-    rmx_batch *b;
-    PairSweepGuard(rmx_batch *b_, int iters) : b(b_) {
-        if (!b->pair) return;
-        std::lock_guard<std::mutex> lk(b->pair->mu);
-        b->pair->fb_left[b->pair_side] = iters; b->pair_sweeping = true;
-    }
-    ~PairSweepGuard() {
-        if (!b->pair_sweeping) return;
-        b->pair_sweeping = false;
-        std::lock_guard<std::mutex> lk(b->pair->mu);
-        b->pair->fb_left[b->pair_side] = 0; b->pair->posted[b->pair_side] = 0;
-        b->pair->cv.notify_all();
-    }
-};
+#undef FBM_KERNEL_CASE
 static int p_cn_front(rmx_batch *b, int r0, int r1, bool skip_frame, bool snapshot_done = false) {
     int rc = skip_frame ? ensure_tables(b, r0, r1) : do_framelogprob(b, r0, r1);
     if (rc) return rc;
@@ -1379,14 +1268,19 @@ static int p_cn_front(rmx_batch *b, int r0, int r1, bool skip_frame, bool snapsh
         a.fa = d.fa; a.fb = d.fb; a.mrow = d.mrow; a.err = d.err; a.dbg = b->d_dbg;
         bool fast = false;
         bool done_fast = false;
-        // the matrix-core kernel: four restarts per workgroup whatever the batch size (a 4x4x4 MFMA carries four vectors);
-        // needs the clone-product tables for breakend steps.  Option fb_nv = 1 / 2 selects the vector kernel below instead.
+        // k_fbm: four restarts per workgroup on the matrix cores (a 4x4x4 MFMA carries four vectors), or two / one on the vector ALU where
+        // that many workgroups still fit the chip in one round -- a step of the vector form is shorter (fewer products per CU and step), and a
+        // launch is a chain of dependent steps.  Needs the clone-product tables for breakend steps.  Option fb_nv = 1 / 2 / 4 pins the shape;
+        // fb_kernel = 3 selects the two-phase vector kernel below instead.
         if (b->fbv_rpt > 0 && b->n_fast > 0 && (d.NBE == 0 || (d.pe2_lt != nullptr && b->max_adist < 64 && b->opt[RMX_OPT_FB_BREAKEND_CODES])) &&
-            (b->opt[RMX_OPT_FB_NV] == 0 || b->opt[RMX_OPT_FB_NV] == 4)) {
-            const int nr = r1 - r0;
+            b->opt[RMX_OPT_FB_KERNEL] != 3) {
             int KB = 0;
             for (int v : {8, 16, 28, 36, 42, 44}) if (4 * v >= d.S) { KB = v; break; }
             const int NCT = (d.S + 14) / 15;                          // waves: 15 state columns + the ones column each
+            auto units = [&](int nv) { return (r1 - 1) / nv - r0 / nv + 1; };      // absolute units of nv restarts that [r0, r1) touches
+            int NV = 4;
+            if (b->opt[RMX_OPT_FB_NV] == 1 || b->opt[RMX_OPT_FB_NV] == 2 || b->opt[RMX_OPT_FB_NV] == 4) NV = b->opt[RMX_OPT_FB_NV];
+            else { for (int nv : {2, 1}) if ((long)b->n_fast * 2 * units(nv) <= g_fb_wg_budget) NV = nv; }
             FbmArgs m;
             memset(&m, 0, sizeof m);
             m.S = d.S; m.SP = d.SP; m.M = d.M; m.D = d.D; m.C = d.C; m.N = d.N; m.NBE = d.NBE; m.cn_max = d.cn_max; m.r0 = r0; m.r1 = r1;
@@ -1396,17 +1290,11 @@ static int p_cn_front(rmx_batch *b, int r0, int r1, bool skip_frame, bool snapsh
             m.be_n = d.be_n; m.chain_be = d.chain_be; m.fe = d.fe; m.Wf = d.Wf; m.Wb = d.Wb; m.pe2_lt = d.pe2x_lt; m.af = d.af; m.ab = d.ab; m.tot = d.tot;
             m.fa = d.fa; m.fb = d.fb; m.mrow = d.mrow; m.err = d.err; m.dbg = b->d_dbg;
             const size_t lds = (size_t)2 * m.VR * 4 * 8 + (size_t)2 * 4 * m.PE2P * 8 + (size_t)6 * m.PE2P * 8 + 64 * 8 + (size_t)(KB / 2) * 4 * m.SPC * 4 + (size_t)b->be_cap * 4 + 64;
-            void (*kf)(FbmArgs) = KB == 8 ? k_fbm<8> : (KB == 16 ? k_fbm<16> : (KB == 28 ? k_fbm<28> : (KB == 36 ? k_fbm<36> : (KB == 42 ? k_fbm<42> : k_fbm<44>))));
-            if (KB > 0 && NCT <= 12 && lds <= kLdsBudget) {
-                const int ny = ((r1 - 1) >> 2) - (r0 >> 2) + 1;
-                bool queued = false;
-
-                if (b->pair_sweeping && (rc = fb_joint(b, ps, 1, m, KB, NCT, lds, ny, &queued))) return rc;
-                if (!queued) {
-                    HIPCHK(hipFuncSetAttribute((const void *)kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-                    hipLaunchKernelGGL(kf, dim3(b->n_fast, ny, 2), dim3(64 * NCT), lds, b->stream, m);
-                }
-                done_fast = true; fast = true; b->last_fb_kernel = 1; b->last_fb_nv = 4;
+            void (*kf)(FbmArgs) = fbm_kernel_for(KB, NV);
+            if (kf && NCT <= 12 && lds <= kLdsBudget) {
+                HIPCHK(hipFuncSetAttribute((const void *)kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                hipLaunchKernelGGL(kf, dim3(b->n_fast, units(NV), 2), dim3(64 * NCT), lds, b->stream, m);
+                done_fast = true; fast = true; b->last_fb_kernel = 1; b->last_fb_nv = NV;
             }
         }
         if (!done_fast && b->fbv_rpt > 0 && b->n_fast > 0) {
@@ -1457,10 +1345,9 @@ static int p_cn_front(rmx_batch *b, int r0, int r1, bool skip_frame, bool snapsh
                 done_fast = true; fast = true; b->last_fb_kernel = 2; b->last_fb_nv = NV;
             }
         }
-        if (!done_fast && b->fbv_rpt == 0 && b->fbk_ok && d.pe2x_lt && b->n_fast > 0 && b->opt[RMX_OPT_FB_KERNEL] == 0 && d.S <= 360 &&
-            (b->opt[RMX_OPT_FB_NV] == 0 || b->opt[RMX_OPT_FB_NV] == 4)) {
+        if (!done_fast && b->fbv_rpt == 0 && b->fbk_ok && d.pe2x_lt && b->n_fast > 0 && b->opt[RMX_OPT_FB_KERNEL] == 0 && d.S <= 360) {
             // state grid too large for register-resident weights, matrix cores: 8-bit distances in registers, B operands
-            // looked up in a 64-entry LDS table (k_fbq); fb_nv = 1 / 2 selects the vector kernel k_fbk below instead
+            // looked up in a 64-entry LDS table (k_fbq); fb_kernel = 3 selects the vector kernel k_fbk below instead
             const int KB = d.S <= 256 ? 64 : 90;
             const int NWq = (d.S + 29) / 30;
             FbmArgs m;
@@ -1474,17 +1361,13 @@ static int p_cn_front(rmx_batch *b, int r0, int r1, bool skip_frame, bool snapsh
             void (*kf)(FbmArgs, const double *, const uint32_t *, const uint32_t *) = KB == 64 ? k_fbq<64> : k_fbq<90>;
             if (NWq <= 12 && 4 * KB >= d.S && lds <= kLdsBudget) {
                 const int ny = ((r1 - 1) >> 2) - (r0 >> 2) + 1;
-                bool queued = false;
-                if (b->pair_sweeping && (rc = fb_joint(b, ps, 4, m, KB, NWq, lds, ny, &queued))) return rc;
-                if (!queued) {
-                    HIPCHK(hipFuncSetAttribute((const void *)kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-                    hipLaunchKernelGGL(kf, dim3(b->n_fast, ny, 2), dim3(64 * NWq), lds, b->stream, m,
-                                       (const double *)b->d_wk, (const uint32_t *)b->d_cnpack, (const uint32_t *)b->d_totpack);
-                }
+                HIPCHK(hipFuncSetAttribute((const void *)kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                hipLaunchKernelGGL(kf, dim3(b->n_fast, ny, 2), dim3(64 * NWq), lds, b->stream, m,
+                                   (const double *)b->d_wk, (const uint32_t *)b->d_cnpack, (const uint32_t *)b->d_totpack);
                 done_fast = true; fast = true; b->last_fb_kernel = 4; b->last_fb_nv = 4;
             }
         }
-        if (!done_fast && b->fbv_rpt == 0 && b->fbk_ok && d.pe2_lt && b->n_fast > 0 && b->opt[RMX_OPT_FB_KERNEL] == 0) {
+        if (!done_fast && b->fbv_rpt == 0 && b->fbk_ok && d.pe2_lt && b->n_fast > 0 && (b->opt[RMX_OPT_FB_KERNEL] == 0 || b->opt[RMX_OPT_FB_KERNEL] == 3)) {
             // state grid too large for register-resident weights: weights from packed copy numbers on the fly
             const int nr = r1 - r0;
             int NV = 1;
@@ -1513,12 +1396,6 @@ static int p_cn_front(rmx_batch *b, int r0, int r1, bool skip_frame, bool snapsh
             }
         }
         if (!fast) { b->last_fb_kernel = 0; b->last_fb_nv = 1; }
-        if (b->pair_sweeping && !b->pair_point_passed) {      // a launch shape the pair protocol does not combine: the point still counts
-            std::lock_guard<std::mutex> lk(b->pair->mu);
-            if (b->pair->fb_left[b->pair_side] > 0) b->pair->fb_left[b->pair_side]--;
-            b->pair->cv.notify_all();
-        }
-        b->pair_point_passed = false;
         const int ngen = fast ? b->n_generic : d.NC;
         if (ngen > 0) {
             a.amat_lds = 0; a.P = b->fbG.P; a.BLK = b->fbG.BLK; a.SPAD = b->fbG.SPAD; a.chain_list = fast ? d.chain_list_generic : d.chain_list_all;
@@ -1604,19 +1481,19 @@ int rmx_variational_update(rmx_batch *b, int32_t r0, int32_t r1, int32_t iters) 
         HIPCHK(hipEventCreateWithFlags(&b->ev_brk, hipEventDisableTiming));
     }
     bool snapshot_done = false;
-    // paired batches: a sweep's forward-backward point is reached in (device) real time -- not before the previous sweep's
-    // forward-backward has finished -- so that the other side, arriving from its M-step, finds launches still to combine
-    PairSweepGuard pair_guard(b, iters);
-    const bool paced = b->pair_sweeping || b->opt[RMX_OPT_PACE_SWEEPS];
-    if (paced && !b->ev_pair_fb) HIPCHK(hipEventCreateWithFlags(&b->ev_pair_fb, hipEventDisableTiming));
+    // pace_sweeps: a sweep's forward-backward point is reached in (device) real time -- not before the previous sweep's
+    // forward-backward has finished -- instead of queueing the call's sweeps at once (what the restart groups
+    // of a GPU gain from it depends on the state grid and the group size)
+    const bool paced = b->opt[RMX_OPT_PACE_SWEEPS] != 0;
+    if (paced && !b->ev_pace) HIPCHK(hipEventCreateWithFlags(&b->ev_pace, hipEventDisableTiming));
     for (int it = 0; it < iters; it++) {
         int rc;
-        if (paced && it > 0) HIPCHK(hipEventSynchronize(b->ev_pair_fb));
+        if (paced && it > 0) HIPCHK(hipEventSynchronize(b->ev_pace));
         const bool fused_in = fusable && it > 0, fuse_out = fusable && it + 1 < iters;
         if (!fused_in && (rc = do_indicator(b, r0, r1, 2))) return rc;
         if (two_streams) {
             if ((rc = p_cn_front(b, r0, r1, fused_in, snapshot_done))) return rc;
-            if (paced) HIPCHK(hipEventRecord(b->ev_pair_fb, b->stream));
+            if (paced) HIPCHK(hipEventRecord(b->ev_pace, b->stream));
             // breakend branch on the second stream: pairwise reductions -> p_breakpoint -> cached transition tables
             hipStream_t main_stream = b->stream;
             HIPCHK(hipEventRecord(b->ev_fb, main_stream));
@@ -1633,7 +1510,7 @@ int rmx_variational_update(rmx_batch *b, int32_t r0, int32_t r1, int32_t iters) 
             HIPCHK(hipStreamWaitEvent(main_stream, b->ev_brk, 0));
         } else {
             if ((rc = do_update_p_cn(b, r0, r1, fused_in, fuse_out)) || (rc = do_update_p_breakpoint(b, r0, r1))) return rc;
-            if (paced) HIPCHK(hipEventRecord(b->ev_pair_fb, b->stream));
+            if (paced) HIPCHK(hipEventRecord(b->ev_pace, b->stream));
         }
         if (!fuse_out && ((rc = do_indicator(b, r0, r1, 0)) || (rc = do_indicator(b, r0, r1, 1)))) return rc;
     }

@@ -850,15 +850,38 @@ template <int PI, int KB> struct fbm_chain {
     }
 };
 
-// by: the workgroup's row of quads inside a's range (blockIdx.y of a launch over one batch)
-template <int KB>
+// The same products on the vector ALU, for workgroups that carry NV = 1 or 2 restarts (k_fbm<KB, NV>): lane (kq, c) owns rows 4 kb + kq of
+// column c -- its B-operand registers -- and accumulates acc_j += a_j[4 kb + kq] w[kb]; restart j's vector element reaches the 16 lanes of a
+// DPP row through the FMA's own DPP operand (row_newbcast:j on the A-operand image: lane (kq, 4 b + i) holds a_i).  Even and odd k-blocks
+// go to two accumulators per restart (independent FMA chains).
+template <int J> __device__ __forceinline__ void fbm_vfma(double &acc, const double a, const double x) {
+    asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(a), "v"(x), "n"(J));
+}
+template <int PI, int KB, int NV> struct fbw_chain {
+    static __device__ __forceinline__ void run(fbm_d2 (&ring)[FBM_RING], const double (&w)[KB], unsigned addr, double (&acc)[NV][2]) {
+        constexpr int NP = KB / 2;
+        constexpr int younger = (NP - 1 - PI) < (FBM_DEPTH - 1) ? (NP - 1 - PI) : (FBM_DEPTH - 1);
+        fbm_wait<younger>(ring[PI % FBM_RING]);
+        fbm_vfma<0>(acc[0][0], ring[PI % FBM_RING].x, w[2 * PI]);
+        if constexpr (NV > 1) fbm_vfma<1>(acc[1][0], ring[PI % FBM_RING].x, w[2 * PI]);
+        fbm_vfma<0>(acc[0][1], ring[PI % FBM_RING].y, w[2 * PI + 1]);
+        if constexpr (NV > 1) fbm_vfma<1>(acc[1][1], ring[PI % FBM_RING].y, w[2 * PI + 1]);
+        if constexpr (PI + FBM_DEPTH < NP) fbm_rd<(PI + FBM_DEPTH) * 256>(ring[(PI + FBM_DEPTH) % FBM_RING], addr);
+        if constexpr (PI + 1 < NP) fbw_chain<PI + 1, KB, NV>::run(ring, w, addr, acc);
+    }
+};
+
+// by: the workgroup's row of restart units (NV restarts each) inside a's range (blockIdx.y)
+template <int KB, int NV>
 __device__ __forceinline__ void fbm_body(const FbmArgs &a, const int by) {
     extern __shared__ __align__(16) unsigned char smem_raw[];
     static_assert(KB % 2 == 0 && KB / 2 >= FBM_DEPTH, "k-blocks come in pairs; ring no deeper than the chain");
     const int chain = a.chain_list[blockIdx.x], dir = blockIdx.z;
-    // restarts in absolute quads (4 g .. 4 g + 3: the interleave of the breakend tables); of a quad, those inside [r0, r1)
-    const int quad = (a.r0 >> 2) + by, rg0 = quad * FBM_NV;
-    const int v_lo = max(a.r0 - rg0, 0), v_hi = min(a.r1 - rg0, FBM_NV);      // present: v_lo <= i < v_hi
+    static_assert(NV == 1 || NV == 2 || NV == 4, "restarts per workgroup");
+    // restarts in absolute units of NV (NV u .. NV u + NV - 1) inside absolute quads (4 g .. 4 g + 3: the interleave of the breakend
+    // tables); of a unit, those inside [r0, r1).  The unit's restarts take slots 0 .. NV - 1 of the vector image.
+    const int unit = a.r0 / NV + by, rg0 = unit * NV, quad = rg0 >> 2, I0 = rg0 & 3;
+    const int v_lo = max(a.r0 - rg0, 0), v_hi = min(a.r1 - rg0, NV);          // present: v_lo <= i < v_hi
     const int S = a.S, SP = a.SP, M = a.M, D = a.D, VR = a.VR, SPC = a.SPC;
     const int n0 = a.chain_start[chain], n1 = a.chain_end[chain], len = n1 - n0 + 1;
     const int t = threadIdx.x, NT = blockDim.x, lane = t & 63;
@@ -867,6 +890,8 @@ __device__ __forceinline__ void fbm_body(const FbmArgs &a, const int by) {
     const int id = lane >> 4;                                   // result role: restart (numerically kq)
     const bool is_sum = c16 == 15;                              // the tile's 16th column is the all-ones column: its result is the vector's sum
     const int col = wave * 15 + c16;                            // (state columns 15 w .. 15 w + 14)
+    const double sel0 = ib == 0 ? 1.0 : 0.0, sel1 = ib == 1 ? 1.0 : 0.0;   // (NV < 4) A operands that pick restart slot 0 / 1 as result row
+    (void)sel0; (void)sel1;
     // ---- LDS carve-up ---------------------------------------------------------------------------
     double *vec = (double *)smem_raw;                           // [2][VR][4]   vectors, restart-interleaved, double-buffered by step parity
     double *tab = vec + (size_t)2 * VR * 4;                     // [2][PE2P][4] clone-product weights of the current and the next breakend, restart-interleaved (LDS-DMA)
@@ -984,12 +1009,24 @@ __device__ __forceinline__ void fbm_body(const FbmArgs &a, const int by) {
             double e;
             gload8(e, eptr);                                     // consumed in FBM_FINISH, after the products
             eptr += rstep;
-            double acc[4] = {0., 0., 0., 0.};
             fbm_d2 ring[FBM_RING];
             const unsigned apc = ap0 + (unsigned)((k - 1) & 1) * (unsigned)(VR * 32);
             fbm_chain<0, KB>::template fill<0>(ring, apc);
-            fbm_chain<0, KB>::run(ring, w, apc, acc);
-            const double sum = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+            double sum;
+            if constexpr (NV == 4) {
+                double acc[4] = {0., 0., 0., 0.};
+                fbm_chain<0, KB>::run(ring, w, apc, acc);
+                sum = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+            } else {
+                double acc[NV][2];
+#pragma unroll
+                for (int j = 0; j < NV; j++) acc[j][0] = acc[j][1] = 0.;
+                fbw_chain<0, KB, NV>::run(ring, w, apc, acc);
+                // the four row groups kq of a column, and the move to the result lanes (lane 16 i + c: restart slot i), in one matrix
+                // instruction per restart: A = (row i == slot j) for every k, B = this lane's partial sum  ->  D[i][c] = [i == j] sum_kq p_j[kq][c]
+                sum = __builtin_amdgcn_mfma_f64_4x4x4f64(sel0, acc[0][0] + acc[0][1], 0., 0, 0, 0);
+                if constexpr (NV > 1) sum = __builtin_amdgcn_mfma_f64_4x4x4f64(sel1, acc[1][0] + acc[1][1], sum, 0, 0, 0);
+            }
             FBM_FINISH(sum, e, k)
         }
         if (k < len) {
@@ -1032,12 +1069,14 @@ __device__ __forceinline__ void fbm_body(const FbmArgs &a, const int by) {
             // useful row): the products run on the vector ALU instead.  Lane (kq, c) owns rows 4 kb + kq of column c -- exactly its B-operand
             // registers w[kb] -- and accumulates acc_i += a_i[q] (w[kb] tab2_i[ix(q, c)]) for the four restarts; the four lanes of a column
             // (kq = 0..3) are added at the end in a fixed order.  19 000 -> ~8 000 cycles per breakend step.
-            double acc[FBM_NV] = {0., 0., 0., 0.};
+            double acc[NV];
+#pragma unroll
+            for (int j = 0; j < NV; j++) acc[j] = 0.;
             const unsigned *cw = codel + (size_t)kq * SPC + (wave * 16 + c16);
-            const char *tbb = reinterpret_cast<const char *>(tab2);
+            const char *tbb = reinterpret_cast<const char *>(tab2) + I0 * 8;       // (the unit's restarts inside the quad's rows)
             (void)tb;
             // all row offsets first (one LDS round trip), then the pairs with the next pair's operands requested before this pair's
-            // products: a pair is otherwise two dependent LDS round trips (offsets, then rows) in front of 16 FMAs
+            // products: a pair is otherwise two dependent LDS round trips (offsets, then rows) in front of 4 NV FMAs
             constexpr int NPAIR = KB / 2, CH0 = (NPAIR + 1) / 2;      // the offsets in two chunks (register budget)
             unsigned cpk[CH0];
             // vector elements: the MFMA A-operand image (lane (kq, c) reads a_{c mod 4}[4 kb + kq], two k-blocks per 16 bytes); restart i's
@@ -1045,15 +1084,23 @@ __device__ __forceinline__ void fbm_body(const FbmArgs &a, const int by) {
             // instead of 64
             const fbm_d2 *apd = reinterpret_cast<const fbm_d2 *>(vec + (size_t)((k - 1) & 1) * VR * 4 + (kq * 4 + ib) * 2);     // pair p: + 16 p
             fbm_d2 an;
-            double2 tn[4];
+            double tn[2][NV];                                          // table entries of the unit's restarts: rows of k-block 2 p and 2 p + 1
 #define FBM_BE_LOAD(p_, c_)                                                                                                        \
             {                                                                                                                      \
                 an = apd[(p_) * 16];                                                                                               \
                 const char *r0_ = tbb + ((c_) & 0xffffu), *r1_ = tbb + ((c_) >> 16);                                               \
-                tn[0] = *reinterpret_cast<const double2 *>(r0_); tn[1] = *reinterpret_cast<const double2 *>(r0_ + 16);             \
-                tn[2] = *reinterpret_cast<const double2 *>(r1_); tn[3] = *reinterpret_cast<const double2 *>(r1_ + 16);             \
+                if constexpr (NV == 4) {                                                                                           \
+                    const double2 u0_ = *reinterpret_cast<const double2 *>(r0_), u1_ = *reinterpret_cast<const double2 *>(r0_ + 16); \
+                    const double2 u2_ = *reinterpret_cast<const double2 *>(r1_), u3_ = *reinterpret_cast<const double2 *>(r1_ + 16); \
+                    tn[0][0] = u0_.x; tn[0][1] = u0_.y; tn[0][2] = u1_.x; tn[0][3] = u1_.y;                                        \
+                    tn[1][0] = u2_.x; tn[1][1] = u2_.y; tn[1][2] = u3_.x; tn[1][3] = u3_.y;                                        \
+                } else if constexpr (NV == 2) {                                                                                    \
+                    const double2 u0_ = *reinterpret_cast<const double2 *>(r0_), u2_ = *reinterpret_cast<const double2 *>(r1_);    \
+                    tn[0][0] = u0_.x; tn[0][1] = u0_.y; tn[1][0] = u2_.x; tn[1][1] = u2_.y;                                        \
+                } else {                                                                                                           \
+                    tn[0][0] = *reinterpret_cast<const double *>(r0_); tn[1][0] = *reinterpret_cast<const double *>(r1_);          \
+                }                                                                                                                  \
             }
-#define FBM_BE_FMA(acc_, a_, x_, i_) asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:" #i_ " row_mask:0xf bank_mask:0xf" : "+v"(acc_) : "v"(a_), "v"(x_))
 #pragma unroll
             for (int c0 = 0; c0 < NPAIR; c0 += CH0) {
 #pragma unroll
@@ -1064,21 +1111,29 @@ __device__ __forceinline__ void fbm_body(const FbmArgs &a, const int by) {
                     const int p = c0 + u;
                     if (p >= NPAIR) break;
                     const double ax = an.x, ay = an.y;                                 // k-blocks 2 p and 2 p + 1
-                    const double2 t0 = tn[0], t1 = tn[1], t2 = tn[2], t3 = tn[3];      // rows of k-block 2 p (t0, t1) and 2 p + 1 (t2, t3)
+                    double t0[NV], t1[NV];                                             // rows of k-block 2 p and 2 p + 1
+#pragma unroll
+                    for (int j = 0; j < NV; j++) { t0[j] = tn[0][j]; t1[j] = tn[1][j]; }
                     if (u + 1 < CH0 && p + 1 < NPAIR) FBM_BE_LOAD(p + 1, cpk[u + 1])
                     const double w0 = w[2 * p], w1 = w[2 * p + 1];
-                    const double x0 = w0 * t0.x, x1 = w0 * t0.y, x2 = w0 * t1.x, x3 = w0 * t1.y;
-                    const double y0 = w1 * t2.x, y1 = w1 * t2.y, y2 = w1 * t3.x, y3 = w1 * t3.y;
-                    FBM_BE_FMA(acc[0], ax, x0, 0); FBM_BE_FMA(acc[1], ax, x1, 1); FBM_BE_FMA(acc[2], ax, x2, 2); FBM_BE_FMA(acc[3], ax, x3, 3);
-                    FBM_BE_FMA(acc[0], ay, y0, 0); FBM_BE_FMA(acc[1], ay, y1, 1); FBM_BE_FMA(acc[2], ay, y2, 2); FBM_BE_FMA(acc[3], ay, y3, 3);
+                    double xs[NV], ys[NV];
+#pragma unroll
+                    for (int j = 0; j < NV; j++) { xs[j] = w0 * t0[j]; ys[j] = w1 * t1[j]; }
+                    fbm_vfma<0>(acc[0], ax, xs[0]);
+                    if constexpr (NV > 1) fbm_vfma<1>(acc[1], ax, xs[1]);
+                    if constexpr (NV > 2) { fbm_vfma<2>(acc[2], ax, xs[2]); fbm_vfma<3>(acc[3], ax, xs[3]); }
+                    fbm_vfma<0>(acc[0], ay, ys[0]);
+                    if constexpr (NV > 1) fbm_vfma<1>(acc[1], ay, ys[1]);
+                    if constexpr (NV > 2) { fbm_vfma<2>(acc[2], ay, ys[2]); fbm_vfma<3>(acc[3], ay, ys[3]); }
                 }
             }
-#undef FBM_BE_FMA
 #undef FBM_BE_LOAD
             // the four row groups of a column: ((kq 0 + kq 1) + (kq 2 + kq 3)), the same value in all four lanes (a + b == b + a)
 #pragma unroll
-            for (int i = 0; i < FBM_NV; i++) { acc[i] += __shfl_xor(acc[i], 16); acc[i] += __shfl_xor(acc[i], 32); }
-            const double sum = id == 0 ? acc[0] : (id == 1 ? acc[1] : (id == 2 ? acc[2] : acc[3]));   // result lane (i, c) keeps restart i
+            for (int j = 0; j < NV; j++) { acc[j] += __shfl_xor(acc[j], 16); acc[j] += __shfl_xor(acc[j], 32); }
+            double sum = acc[0];                                                       // result lane (i, c) keeps restart slot i
+#pragma unroll
+            for (int j = 1; j < NV; j++) if (id == j) sum = acc[j];
             FB_STAMP(2)
             FBM_FINISH(sum, e, k)
             FB_STAMP(3)
@@ -1107,18 +1162,8 @@ __device__ __forceinline__ void fbm_body(const FbmArgs &a, const int by) {
 #undef ROW
 #undef ADJ
 }
-template <int KB>
-__global__ __launch_bounds__(768) void k_fbm(FbmArgs a) { fbm_body<KB>(a, blockIdx.y); }
-// One launch over the ranges of TWO batches of the same experiment (rmx_pair_batches): rows of quads [0, ny0) belong to side 0,
-// the rest to side 1.  Each workgroup runs exactly the code of a launch over its own batch (the side is uniform per workgroup:
-// the arguments stay scalar loads from the kernel-argument segment), so results are bit-identical to two launches; what changes
-// is that 2 x 92 workgroups fill 184 of the 256 CUs at once instead of one after the other.
-struct FbmArgs2 { FbmArgs s[2]; int ny0; };
-template <int KB>
-__global__ __launch_bounds__(768) void k_fbm2(FbmArgs2 p) {
-    const int side = (int)blockIdx.y >= p.ny0 ? 1 : 0;
-    fbm_body<KB>(p.s[side], (int)blockIdx.y - (side ? p.ny0 : 0));
-}
+template <int KB, int NV>
+__global__ __launch_bounds__(768) void k_fbm(FbmArgs a) { fbm_body<KB, NV>(a, blockIdx.y); }
 
 // =============================================================================
 // k_fbq: the matrix-core forward-backward kernel for state grids whose S x S weights do not fit the register file
@@ -1423,12 +1468,6 @@ __device__ __forceinline__ void fbq_body(const FbmArgs &a, const double *wk, con
 template <int KB>
 __global__ __launch_bounds__(768) void k_fbq(FbmArgs a, const double *wk, const uint32_t *cnpack, const uint32_t *totpack) { fbq_body<KB>(a, wk, cnpack, totpack, blockIdx.y); }
 // one launch over the ranges of two paired batches (see k_fbm2)
-struct FbqArgs2 { FbmArgs s[2]; const double *wk[2]; const uint32_t *cnpack[2], *totpack[2]; int ny0; };
-template <int KB>
-__global__ __launch_bounds__(768) void k_fbq2(FbqArgs2 p) {
-    const int side = (int)blockIdx.y >= p.ny0 ? 1 : 0;
-    fbq_body<KB>(p.s[side], p.wk[side], p.cnpack[side], p.totpack[side], (int)blockIdx.y - (side ? p.ny0 : 0));
-}
 
 // =============================================================================
 // k_fbk: forward-backward for state grids whose S x S weight matrix does not fit the register file

@@ -608,7 +608,7 @@ class RestartGroups(object):
     Restarts are independent (reference remixt/workflow.py:329-340) and every restart owns its RNG
     stream, so the results do not depend on the grouping."""
 
-    def __init__(self, experiment, init_params, max_copy_number, groups=2, seeds=None, pair_fb='auto', **kwargs):
+    def __init__(self, experiment, init_params, max_copy_number, groups=2, seeds=None, paced='auto', **kwargs):
         init_params = list(init_params)
         R = len(init_params)
         groups = max(1, min(int(groups), R))
@@ -623,23 +623,19 @@ class RestartGroups(object):
         self.init_params = init_params
         self.experiment = experiment
         self._pool = None
-        # pair_fb (two groups, rmx_pair_batches): 2 = pacing only -- a group reaches each sweep's forward-backward point after its previous
-        # forward-backward launch has finished on the device, instead of queueing all its sweeps at once; 1 = pacing plus ONE launch for both
-        # groups when both are at the point; 0 = free-running.  Measured (tools/s355_groups.sh): at 165 states free-running wins
-        # (407 it/s; paced 369, combined 403: the groups already hide each one's marginal pass under the other's forward-backward); at 355
-        # states, where a forward-backward launch is 13 ms, free-running groups serialise (118 it/s, one group of 16: 134) and pacing wins
-        # (144).  Groups of at most 4 restarts (a rank's share of 8 when 64 restarts are sharded over 8 GPUs) also gain from pacing at 165 states
-        # (2 x 4: 256 -> 272 it/s, 2 x 2: 148 -> 169; 2 x 6: 337 -> 326, 2 x 8: 407 -> 369).  'auto': pacing above 200 states or up to 4 restarts per group.
-        if pair_fb == 'auto':
+        # paced: a group reaches each sweep's forward-backward point after its previous forward-backward launch has finished on the
+        # device (library option pace_sweeps), instead of queueing all its sweeps at once; False = free-running.  Measured (DESIGN 4.6,
+        # tools/s355_groups.sh): at 165 states free-running wins (407 it/s; paced 369: the groups already hide each one's marginal pass
+        # under the other's forward-backward); at 355 states, where a forward-backward launch is 13 ms, free-running groups serialise
+        # (118 it/s, one group of 16: 134) and pacing wins (144).  Groups of at most 4 restarts (a rank's share of 8 when 64 restarts are
+        # sharded over 8 GPUs) also gain from pacing at 165 states.  'auto': pacing above 200 states or up to 4 restarts per group.
+        if paced == 'auto':
             b0 = self.sets[0].batch
             small = max(len(rs.models) for rs in self.sets) <= 4
-            pair_fb = 2 if (len(self.sets) >= 2 and b0 is not None and (getattr(b0, 'num_cn_states', 0) > 200 or small)) else 0
-        native = all(getattr(rs.batch, 'pair_with', None) is not None for rs in self.sets)
-        self.paired = int(pair_fb) == 1 and len(self.sets) == 2 and native
-        self.paced = int(pair_fb) == 2 and len(self.sets) >= 2 and native
-        if self.paired:
-            self.sets[0].batch.pair_with(self.sets[1].batch)
-        elif self.paced:
+            paced = len(self.sets) >= 2 and b0 is not None and (getattr(b0, 'num_cn_states', 0) > 200 or small)
+        native = all(getattr(rs.batch, 'set_option', None) is not None for rs in self.sets)
+        self.paced = bool(paced) and len(self.sets) >= 2 and native
+        if self.paced:
             for rs in self.sets:
                 rs.batch.set_option('pace_sweeps', 1)
 

@@ -71,21 +71,51 @@ def _compare_after_every_update(dev, ora, sweeps=2, elbo_rtol=1e-8, rtol=1e-8, t
         assert np.array_equal(cn[r], ref), 'Viterbi path of restart %d differs' % r
 
 
-@pytest.mark.parametrize('R,NV', [(4, 4), (8, 2), (8, 4), (3, 2)])
-def test_s165_restart_batch_with_dense_breakends_matches_oracle(hip, oracle_mod, R, NV):
+@pytest.mark.parametrize('R,NV,two_phase', [(4, 4, 0), (8, 4, 0), (8, 2, 0), (3, 2, 0), (7, 2, 0), (5, 1, 0), (3, 0, 0), (8, 2, 1), (3, 2, 1)])
+def test_s165_restart_batch_with_dense_breakends_matches_oracle(hip, oracle_mod, R, NV, two_phase):
     """165 states, R restarts in one batch, 24 breakpoints + two sharing a boundary on 110 segments -> ~50 breakend adjacencies, i.e.
-    every other step takes the breakend branch, and k_pairwise_be2 / k_brk_lut see all of them.  NV = 4: the production kernel
-    k_fbm (FP64 matrix cores, quads of restarts; R = 4 one full quad, R = 8 two); NV = 2: the vector-FMA kernel k_fbv with two
-    restarts per workgroup ((3, 2): a ragged last workgroup).  Which one ran is asserted through rmx_info(12 / 13)."""
+    every other step takes the breakend branch, and k_pairwise_be2 / k_brk_lut see all of them.  The production kernel k_fbm in its three
+    workgroup shapes -- NV = 4: FP64 matrix cores, quads of restarts (R = 4 one full quad, R = 8 two); NV = 2 / 1: the same step on the
+    vector ALU, two / one restarts per workgroup ((3, 2), (7, 2): a ragged last unit inside a quad; (5, 1): every slot of a quad and a
+    quad with one restart); NV = 0: what a launch of three restarts selects by itself -- and the two-phase vector kernel k_fbv
+    (fb_kernel = 3).  Which one ran is asserted through rmx_info(12 / 13)."""
     from remixt_amd import synthetic
     e = synthetic.make_experiment(110, num_clones=3, max_copy_number=8, num_chains=2, seed=31, num_breakpoints=24)
     e.breakpoints = H.add_shared_boundary_breakpoints(e)
     ps = synthetic.make_init_params(e, R, 8)
-    dev, ora = _two_sets(oracle_mod, e, ps, 8, 3, options={'fb_nv': NV})
+    dev, ora = _two_sets(oracle_mod, e, ps, 8, 3, options={'fb_nv': NV, 'fb_kernel': 3 if two_phase else 0})
     b = dev.batch
     assert b.num_cn_states == 165 and b.info(3) >= 48 and b.info(10) == 2 and b.info(11) == 0      # breakend adjacencies; both chains on the register-resident kernels
     _compare_after_every_update(dev, ora)
-    assert (b.info(12), b.info(13)) == ((1, 4) if NV == 4 else (2, 2))                              # k_fbm / k_fbv<., 2>
+    assert (b.info(12), b.info(13)) == ((2, 2) if two_phase else (1, NV or 1))                     # k_fbv<., 2> / k_fbm<., NV> (3 restarts x 2 chains x 2 directions: one per workgroup)
+
+
+def test_s165_workgroup_shapes_agree_and_subranges_are_bit_identical(hip):
+    """k_fbm<., 4> (matrix cores) and k_fbm<., 2> / <., 1> (vector ALU) sum a column in different orders: posteriors agree to 1e-10, not
+    to the bit.  Inside ONE shape a restart's result does not depend on the range of restarts a launch covers (units are absolute:
+    restarts NV u .. NV u + NV - 1), which is what keeps restart groups and shards bit-identical."""
+    from remixt_amd import synthetic
+    from remixt_amd.restarts import RestartSet
+    e = synthetic.make_experiment(300, num_clones=3, max_copy_number=8, num_chains=3, seed=35, num_breakpoints=10)
+    ps = synthetic.make_init_params(e, 7, 8)
+    post = {}
+    for nv in (4, 2, 1):
+        rs = RestartSet(e, ps, 8, num_clones=3, quiet=True, options={'fb_nv': nv})
+        b = rs.batch
+        b.variational_update(2)
+        assert (b.info(12), b.info(13)) == (1, nv)
+        post[nv] = [b.get_array(r, 'posterior_marginals') for r in range(7)]
+        # the same sweeps over sub-ranges that cut units and quads differently
+        rs2 = RestartSet(e, ps, 8, num_clones=3, quiet=True, options={'fb_nv': nv})
+        for r0, r1 in ((0, 3), (3, 6), (6, 7)):
+            rs2.batch.variational_update(2, r0, r1)
+        for r in range(7):
+            assert np.array_equal(rs2.batch.get_array(r, 'posterior_marginals'), post[nv][r]), (nv, r)
+    for nv in (2, 1):
+        for r in range(7):
+            assert H.close(post[nv][r], post[4][r], rtol=1e-10, atol=1e-13), (nv, r, H.maxerr(post[nv][r], post[4][r]))
+    for r in range(7):
+        assert np.array_equal(post[2][r], post[1][r]), ('vector shapes', r)      # two and one restart per workgroup: the same arithmetic per restart
 
 
 def test_s165_generic_kernel_and_plain_breakend_tables_match_oracle(hip, oracle_mod):
@@ -95,12 +125,12 @@ def test_s165_generic_kernel_and_plain_breakend_tables_match_oracle(hip, oracle_
     e = synthetic.make_experiment(90, num_clones=3, max_copy_number=8, num_chains=2, seed=33, num_breakpoints=12)
     e.breakpoints = H.add_shared_boundary_breakpoints(e)
     ps = synthetic.make_init_params(e, 2, 8)
-    for options in ({'fb_kernel': 1}, {'fb_breakend_codes': 0, 'fb_nv': 2}, {'pairwise_kernel': 1}, {'pairwise_kernel': 3}):      # (3: the sparse pairwise kernel, auto only above 200 states)
+    for options in ({'fb_kernel': 1}, {'fb_breakend_codes': 0, 'fb_nv': 2}, {'fb_kernel': 3, 'fb_nv': 1}, {'pairwise_kernel': 1}, {'pairwise_kernel': 3}):      # (3: the sparse pairwise kernel, auto only above 200 states)
         dev, ora = _two_sets(oracle_mod, e, ps, 8, 3, options=options)
         _compare_after_every_update(dev, ora, sweeps=1)
 
 
-@pytest.mark.parametrize('options,fb', [({}, 4), ({'fb_nv': 4}, 4), ({'fb_nv': 2}, 3), ({'fb_nv': 1}, 3), ({'fb_kernel': 2}, 0), ({'viterbi_plain': 1}, 4), ({'pairwise_kernel': 2}, 4)])
+@pytest.mark.parametrize('options,fb', [({}, 4), ({'fb_nv': 4}, 4), ({'fb_kernel': 3, 'fb_nv': 2}, 3), ({'fb_kernel': 3, 'fb_nv': 1}, 3), ({'fb_kernel': 2}, 0), ({'viterbi_plain': 1}, 4), ({'pairwise_kernel': 2}, 4)])
 def test_s355_matches_oracle(hip, oracle_mod, options, fb):
     """355 states (max_cn = 12, the "~400 states" of BASELINE's metric): k_fbq (FP64 matrix cores, B operands looked up from 8-bit
     distances; a quad with two and with four restarts present), k_fbk (vector FMA, weights rebuilt from packed copy numbers), the
@@ -441,14 +471,17 @@ def test_kernel_selection_at_the_benchmark_grids(hip):
     """Which kernels the parametrisations above really run (docstrings named k_fbv where k_fbm runs)."""
     from remixt_amd import synthetic
     from remixt_amd.restarts import RestartSet
-    want = {(8, None): (1, 4, 1), (8, 2): (2, 2, 1), (8, 1): (2, 1, 1), (12, None): (4, 4, 2), (12, 2): (3, 2, 2)}
-    for (max_cn, nv), (fb, nvx, vit) in want.items():
+    # (max_cn, fb_nv, fb_kernel) -> (forward-backward kernel, restarts per workgroup, lattice kernel); 4 restarts x 2 chains x 2 directions
+    # leave room for one restart per workgroup, which is what the automatic choice takes at 165 states
+    want = {(8, None, 0): (1, 1, 1), (8, 4, 0): (1, 4, 1), (8, 2, 0): (1, 2, 1), (8, 2, 3): (2, 2, 1), (8, 1, 3): (2, 1, 1),
+            (12, None, 0): (4, 4, 2), (12, 2, 3): (3, 2, 2)}
+    for (max_cn, nv, fk), (fb, nvx, vit) in want.items():
         e = synthetic.make_experiment(60, num_clones=3, max_copy_number=max_cn, num_chains=2, seed=3, num_breakpoints=4)
-        rs = RestartSet(e, synthetic.make_init_params(e, 4, max_cn), max_cn, num_clones=3, quiet=True, options=({'fb_nv': nv} if nv else None))
+        rs = RestartSet(e, synthetic.make_init_params(e, 4, max_cn), max_cn, num_clones=3, quiet=True, options={'fb_nv': nv or 0, 'fb_kernel': fk})
         rs.batch.variational_update(1)
         rs.batch.infer_cn_batch(0, 2)
         got = (rs.batch.info(12), rs.batch.info(13), rs.batch.info(14))
-        assert got[0] == fb and got[2] == vit and (nvx is None or got[1] == nvx), (max_cn, nv, got)
+        assert got[0] == fb and got[2] == vit and (nvx is None or got[1] == nvx), (max_cn, nv, fk, got)
 
 
 # ---- ADVICE r2 ------------------------------------------------------------------------------------------------------------------
@@ -580,31 +613,22 @@ def test_components_after_a_mixed_h_accept_need_no_refresh_pass(hip):
 
 
 @pytest.mark.parametrize('max_cn,kernel', [(12, 4), (8, 1)])
-def test_paired_groups_launch_one_forward_backward_kernel_for_both(hip, max_cn, kernel):
-    """rmx_pair_batches: while both restart groups are inside a sweep their forward-backward launches go out as ONE launch (k_fbq2 at 355
-    states, k_fbm2 at 165): the posteriors of every restart equal the one-group run's bit for bit, with combined launches (pair_fb=1), with the
-    pacing alone (pair_fb=2) and free-running (pair_fb=0)."""
+def test_paced_and_free_running_groups_equal_one_group(hip, max_cn, kernel):
+    """Restart groups of a GPU (own stream, own host thread), free-running and paced (pace_sweeps: a group reaches a sweep's forward-backward
+    point only after its previous forward-backward launch has finished): the posteriors of every restart equal the one-group run's bit for bit."""
     from remixt_amd import synthetic
     from remixt_amd.restarts import RestartGroups
-    # (long enough chains that a forward-backward launch takes about a millisecond: the second group's thread is then inside its call by the time
-    # the first reaches its second forward-backward point, so combined launches must happen)
     e = synthetic.make_experiment(2400, num_clones=3, max_copy_number=max_cn, num_chains=3, seed=12, num_breakpoints=6)
     ps = synthetic.make_init_params(e, 8, max_cn)
     out = {}
-    for groups, pair in ((1, 0), (2, 0), (2, 2), (2, 1)):
-        rs = RestartGroups(e, ps, max_cn, groups=groups, num_clones=3, quiet=True, seeds=list(range(8)), pair_fb=pair)
+    for groups, paced in ((1, False), (2, False), (2, True)):
+        rs = RestartGroups(e, ps, max_cn, groups=groups, num_clones=3, quiet=True, seeds=list(range(8)), paced=paced, options={'fb_nv': 4})
         rs.variational_update(3)                      # both groups' threads enter their sweeps together
         b = rs.batches[0]
         assert b.info(12) == kernel and b.info(13) == 4
-        joint, solo, _ = b.pair_stats()
-        if pair == 1:
-            assert joint > 0 and 2 * joint + solo == 2 * 3
-        elif pair == 2:
-            assert rs.paced and (joint, solo) == (0, 0) and b.get_option('pace_sweeps') == 1
-        else:
-            assert (joint, solo) == (0, 0)
-        out[groups, pair] = [(np.array(m.model.posterior_marginals), np.array(m.model.p_breakpoint), np.array(m.model.p_allele_swap)) for m in rs.models]
-    for key in ((2, 0), (2, 2), (2, 1)):
+        assert rs.paced == paced and b.get_option('pace_sweeps') == int(paced)
+        out[groups, paced] = [(np.array(m.model.posterior_marginals), np.array(m.model.p_breakpoint), np.array(m.model.p_allele_swap)) for m in rs.models]
+    for key in ((2, False), (2, True)):
         for r in range(8):
-            for x, y in zip(out[key][r], out[1, 0][r]):
+            for x, y in zip(out[key][r], out[1, False][r]):
                 assert np.array_equal(x, y), (key, r)

@@ -78,27 +78,19 @@ def test_config2_bench_shape_em_iterations_with_msteps(workload):
     e, _, p64 = workload
     ids = list(range(16))
     out = {}
-    for groups, pair in ((2, 1), (2, 2), (2, 0), (1, 0)):
-        rs = RestartGroups(e, [p64[i] for i in ids], MAX_CN, groups=groups, num_clones=M, quiet=True, seeds=_seeds(ids), pair_fb=pair)
+    for groups, paced in ((2, True), (2, False), (1, False)):
+        rs = RestartGroups(e, [p64[i] for i in ids], MAX_CN, groups=groups, num_clones=M, quiet=True, seeds=_seeds(ids), paced=paced,
+                           options={'fb_nv': 4})        # (one group launches 16 restarts, two groups 8 each: the workgroup shape is pinned, see test_fb_workgroup_shapes_*)
         b = rs.batches[0]
         assert b.num_cn_states == 165 and b.num_segments >= SEG
         e0, e2 = _run(rs, iters=2)
         assert b.info(12) == 1 and b.info(13) == 4          # k_fbm, four restarts per workgroup
-        joint, solo, waited = b.pair_stats()
-        if pair == 1:
-            # the two groups start their sweeps together: launches over both groups' restarts (k_fbm2) must have happened,
-            # and every forward-backward point of both groups is accounted for (2 iterations x 5 sweeps x 2 groups)
-            assert rs.paired and joint > 0 and 2 * joint + solo == 2 * 5 * 2, (joint, solo, waited)
-        elif pair == 2:
-            assert rs.paced and not rs.paired and (joint, solo) == (0, 0) and b.get_option('pace_sweeps') == 1      # pacing only: no pair
-        else:
-            assert not rs.paired and (joint, solo) == (0, 0)
-        out[groups, pair] = _state(rs)
+        assert rs.paced == paced and b.get_option('pace_sweeps') == int(paced)
+        out[groups, paced] = _state(rs)
         _release(rs)
     for r in ids:
-        assert _same(out[2, 1][r], out[1, 0][r]), ('restart %d: 2 paired groups vs 1 group' % r, out[2, 1][r], out[1, 0][r])
-        assert _same(out[2, 0][r], out[1, 0][r]), ('restart %d: 2 groups vs 1 group' % r, out[2, 0][r], out[1, 0][r])
-        assert _same(out[2, 2][r], out[1, 0][r]), ('restart %d: 2 paced groups vs 1 group' % r, out[2, 2][r], out[1, 0][r])
+        assert _same(out[2, False][r], out[1, False][r]), ('restart %d: 2 groups vs 1 group' % r, out[2, False][r], out[1, False][r])
+        assert _same(out[2, True][r], out[1, False][r]), ('restart %d: 2 paced groups vs 1 group' % r, out[2, True][r], out[1, False][r])
 
 
 def test_config3_per_gpu_share_and_the_whole_job_on_one_gpu(workload):

@@ -1,6 +1,6 @@
 #!/bin/bash
-# restart groups sharing the GPU: one group of 16, two / three / four free-running groups, the same paced (pair_fb=2: a group reaches a sweep's
-# forward-backward point only after its previous forward-backward finished), two groups with combined launches (pair_fb=1);
+# restart groups sharing the GPU: one group of 16, two / three / four free-running groups, the same paced (paced: a group reaches a sweep's
+# forward-backward point only after its previous forward-backward finished);
 # at 355 states (default) or with "165" as first argument at the headline grid
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 cd /tmp
@@ -12,8 +12,7 @@ d=json.loads(sys.stdin.read().strip().splitlines()[-1])
 k=d['kernels']
 print('%-22s %.1f it/s %.2f ms/step | k_fb %s joint %s' % ('$tag', d['value'], d['ms_per_step'], k.get('k_fb'), k.get('k_fb_joint')))"; done; }
 run one_group --groups 1
-run two_groups --groups 2 --host-option pair_fb=0
-run two_groups_paced --groups 2 --host-option pair_fb=2
-run two_groups_joint --groups 2 --host-option pair_fb=1
-run three_groups_paced --groups 3 --host-option pair_fb=2
-run four_groups_paced --groups 4 --host-option pair_fb=2
+run two_groups --groups 2 --host-option paced=0
+run two_groups_paced --groups 2 --host-option paced=1
+run three_groups_paced --groups 3 --host-option paced=1
+run four_groups_paced --groups 4 --host-option paced=1
