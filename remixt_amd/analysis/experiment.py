@@ -7,61 +7,72 @@ import numpy as np
 import pandas as pd
 
 
+def _segment_columns(experiment):
+    """The per-segment columns of the result tables as an ordered list of (name, array): identification, length, the three read counts,
+    the minor-allele ratio (0 where no allele reads were counted) and the depths that follow from it.  The names and formulas are the
+    reference's table schema (remixt/analysis/experiment.py:323-351); the arrays are computed once, in numpy."""
+    x = np.asarray(experiment.x, dtype=float)
+    length = np.asarray(experiment.l, dtype=float)
+    major, minor, total = x[:, 0], x[:, 1], x[:, 2]
+    allele_reads = major + minor
+    with np.errstate(divide='ignore', invalid='ignore'):
+        ratio = np.where(allele_reads != 0, minor / allele_reads, np.nan)
+    ratio = np.where(np.isnan(ratio), 0., ratio)
+    with np.errstate(divide='ignore', invalid='ignore'):
+        depth = total / length
+        depths = (total * (1. - ratio) / length, total * ratio / length, depth)
+    return [
+        ('chromosome', experiment.segment_chromosome_id), ('start', experiment.segment_start), ('end', experiment.segment_end),
+        ('major_is_allele_a', experiment.segment_major_is_allele_a), ('length', experiment.l),
+        ('major_readcount', major), ('minor_readcount', minor), ('readcount', total), ('allele_ratio', ratio),
+        ('major_depth', depths[0]), ('minor_depth', depths[1]), ('total_depth', depths[2]),
+    ]
+
+
+def _frame(columns):
+    return pd.DataFrame({name: np.asarray(values) for name, values in columns}, columns=[name for name, _ in columns])
+
+
 def create_segment_table(experiment):
-    """experiment.py:323-351: per-segment read counts, allele ratio and depths."""
-    x = np.asarray(experiment.x)
-    data = pd.DataFrame({
-        'chromosome': experiment.segment_chromosome_id,
-        'start': experiment.segment_start,
-        'end': experiment.segment_end,
-        'major_is_allele_a': experiment.segment_major_is_allele_a,
-        'length': experiment.l,
-        'major_readcount': x[:, 0],
-        'minor_readcount': x[:, 1],
-        'readcount': x[:, 2],
-    })
-    data['allele_ratio'] = data['minor_readcount'] / (data['major_readcount'] + data['minor_readcount'])
-    data['allele_ratio'] = data['allele_ratio'].fillna(0)
-    data['major_depth'] = data['readcount'] * (1. - data['allele_ratio']) / data['length']
-    data['minor_depth'] = data['readcount'] * data['allele_ratio'] / data['length']
-    data['total_depth'] = data['readcount'] / data['length']
-    return data
+    """Per-segment read counts, allele ratio and depths (schema of experiment.py:323-351)."""
+    return _frame(_segment_columns(experiment))
 
 
 def create_cn_table(experiment, cn, h, phi=None):
-    """experiment.py:354-394: segment table + clone copy number, raw and expected depths."""
-    cn = np.asarray(cn); h = np.asarray(h)
-    data = create_segment_table(experiment)
-    for m in range(0, cn.shape[1]):
-        data['major_{0}'.format(m)] = cn[:, m, 0]
-        data['minor_{0}'.format(m)] = cn[:, m, 1]
-    data['major_raw'] = (data['major_depth'] - data['major_0'] * h[0]) / h[1:].sum()
-    data['minor_raw'] = (data['minor_depth'] - data['minor_0'] * h[0]) / h[1:].sum()
-    data['major_depth_e'] = (cn[:, :, 0] * h[np.newaxis, :]).sum(axis=-1)
-    data['minor_depth_e'] = (cn[:, :, 1] * h[np.newaxis, :]).sum(axis=-1)
-    data['total_depth_e'] = (cn.sum(axis=-1) * h[np.newaxis, :]).sum(axis=-1)
-    data['major_e'] = data['major_depth_e'] * experiment.l
-    data['minor_e'] = data['minor_depth_e'] * experiment.l
-    data['total_e'] = data['total_depth_e'] * experiment.l
-    data['major_raw_e'] = (data['major_depth_e'] - data['major_0'] * h[0]) / h[1:].sum()
-    data['minor_raw_e'] = (data['minor_depth_e'] - data['minor_0'] * h[0]) / h[1:].sum()
-    if 'major_2' in data:
-        data['major_diff'] = np.absolute(data['major_1'] - data['major_2'])
-        data['minor_diff'] = np.absolute(data['minor_1'] - data['minor_2'])
-    return data
+    """Segment table + clone copy number, tumour-only ("raw") depths and the depths / read counts the fitted mixture expects
+    (schema of experiment.py:354-394).  cn: (N, M, 2) [segment, clone, allele]; h: (M,) haploid depths, clone 0 = normal."""
+    cn = np.asarray(cn); h = np.asarray(h, dtype=float)
+    cols = _segment_columns(experiment)
+    seg = dict(cols)
+    length = np.asarray(experiment.l, dtype=float)
+    tumour_depth = h[1:].sum()
+    allele_names = ('major', 'minor')
+    for m in range(cn.shape[1]):
+        cols += [('%s_%d' % (allele_names[a], m), cn[:, m, a]) for a in range(2)]
+    # observed depth less the normal clone's share, per unit of tumour depth
+    cols += [('%s_raw' % allele_names[a], (seg['%s_depth' % allele_names[a]] - cn[:, 0, a] * h[0]) / tumour_depth) for a in range(2)]
+    # what the mixture h expects: depths, then read counts, then the tumour-only form of the expected depths
+    expected = [(cn[:, :, a] * h[np.newaxis, :]).sum(axis=-1) for a in range(2)] + [(cn.sum(axis=-1) * h[np.newaxis, :]).sum(axis=-1)]
+    kinds = allele_names + ('total',)
+    cols += [('%s_depth_e' % kinds[i], expected[i]) for i in range(3)]
+    cols += [('%s_e' % kinds[i], expected[i] * length) for i in range(3)]
+    cols += [('%s_raw_e' % allele_names[a], (expected[a] - cn[:, 0, a] * h[0]) / tumour_depth) for a in range(2)]
+    if cn.shape[1] > 2:      # two tumour clones: where they differ
+        cols += [('%s_diff' % allele_names[a], np.absolute(cn[:, 1, a] - cn[:, 2, a])) for a in range(2)]
+    return _frame(cols)
 
 
 def create_brk_cn_table(brk_cn, breakpoint_segment_data):
-    """experiment.py:397-422: breakpoint copy number joined to the breakpoint / segment mapping
-    (`breakpoint_segment_data` needs a 'prediction_id' column)."""
+    """Breakpoint copy number (dict prediction_id -> (M,) per-clone copies) as columns cn_0 .. cn_{M-1} beside the breakpoint / segment
+    mapping, one row per breakpoint that has both (schema of experiment.py:397-422; `breakpoint_segment_data` needs 'prediction_id')."""
     if len(brk_cn) == 0:
         return pd.DataFrame(columns=['prediction_id'])
-    brk_cn_table = pd.DataFrame(list(brk_cn.values()), index=list(brk_cn.keys()))
-    brk_cn_table.columns = ['cn_{}'.format(m) for m in brk_cn_table.columns]
-    brk_cn_table.index.name = 'prediction_id'
-    brk_cn_table = brk_cn_table.reset_index()
-    brk_cn_table = brk_cn_table.merge(breakpoint_segment_data, on='prediction_id').fillna(0.)
-    return brk_cn_table
+    ids = list(brk_cn.keys())
+    copies = np.asarray([np.asarray(brk_cn[i]) for i in ids])
+    table = pd.DataFrame({'prediction_id': ids})
+    for m in range(copies.shape[1]):
+        table['cn_%d' % m] = copies[:, m]
+    return table.merge(breakpoint_segment_data, on='prediction_id').fillna(0.)
 
 
 # ---------------------------------------------------------------------------------

@@ -59,6 +59,27 @@ def fit(experiment, init_params, config, device=0, quiet=False):
     return collect_fit_results(model, experiment, init_params)
 
 
+def fit_task(results_filename, experiment_filename, init_params, config, device=0, quiet=True):
+    """analysis/pipeline.py:112-124 with the reference's arguments: one restart, experiment pickle in, pickled fit results out (the
+    file `collate` reads).  The reference runs one such job per init_id; `fit_restarts_task` below is the batched form."""
+    with open(experiment_filename, 'rb') as f:
+        experiment = pickle.load(f)
+    fit_results = fit(experiment, init_params, config, device=device, quiet=quiet)
+    with open(results_filename, 'wb') as f:
+        pickle.dump(fit_results, f)
+
+
+def fit_restarts_task(results_filenames, experiment_filename, init_params_by_id, config, device=0, quiet=True, seeds=None, groups=2):
+    """Every init_id of the `fit` axis (workflow.py:329-340) in one device batch: `results_filenames` maps init_id -> the pickle
+    `fit_task` would have written for it, so that `collate` reads them unchanged."""
+    with open(experiment_filename, 'rb') as f:
+        experiment = pickle.load(f)
+    results = fit_restarts(experiment, init_params_by_id, config, device=device, quiet=quiet, seeds=seeds, groups=groups)
+    for init_id, filename in results_filenames.items():
+        with open(filename, 'wb') as f:
+            pickle.dump(results[init_id], f)
+
+
 def fit_restarts(experiment, init_params_by_id, config, device=0, quiet=True, seeds=None, groups=2):
     """All restarts of one GPU in lockstep; returns {init_id: fit_results} like one
     `fit_task` per init_id (workflow.py:329-340).  With per-restart seeds the restarts run as

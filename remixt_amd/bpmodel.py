@@ -240,7 +240,7 @@ class RemixtBatch(object):
 
     def fetch_indicators(self, r0=None, r1=None):
         """(p_outlier_total, p_outlier_allele) of restarts [r0, r1) as [r1 - r0][N][2] float64 arrays: views of pinned memory
-        the batch owns, overwritten by the next call (rmx_fetch_indicators: one transfer on a copy stream)."""
+        the batch owns, overwritten by the next call (rmx_fetch_indicators: two copies queued in order on the batch stream -- behind everything already queued there -- and waited for)."""
         r0, r1 = self._range(r0, r1)
         pt, pa = _dp(), _dp()
         self._ck(self._lib.rmx_fetch_indicators(self._handle, r0, r1, C.byref(pt), C.byref(pa)))

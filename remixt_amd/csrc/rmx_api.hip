@@ -124,6 +124,7 @@ struct rmx_batch {
     // profiling
     bool fbk_ok = false;   // k_fbk usable: log-weights of every uniform class equal -pen * min(SAD, SAD swapped)
     std::vector<double> trial_comp; int trial_comp_r0 = -1, trial_comp_r1 = -1;   // component sums of the last rmx_expected_ll_full_trial's scratch expectations
+    int scratch_r0 = -1, scratch_r1 = -1;   // restarts whose scratch expectations (d_A2, d_Bv2) the last trial pass wrote (-1: none)
     double *d_A2 = nullptr, *d_Bv2 = nullptr;   // [R][N][2], [R][N][4]: (A, B) of a trial parameter value (rmx_expected_ll_full_trial)
     uint32_t *d_cnpack = nullptr, *d_totpack = nullptr; double *d_wk = nullptr;   // [C][S], [C][S], [TC][64]
     int pe2p = 0;     // padded row length of pe2_lt (0: no product table)
@@ -624,7 +625,7 @@ static int launch_pairwise_breakends(rmx_batch *b, int r0, int r1, int mode) {
     // (auto: above ~200 states, where the dense kernel's S^2 pairs per adjacency outweigh the sparse kernel's per-block latency chain; at 165 states the
     // two are within 2 % of each other in the benchmark, the dense one ahead)
     const bool want_sp = b->opt[RMX_OPT_PAIRWISE_KERNEL] == 3 || (b->opt[RMX_OPT_PAIRWISE_KERNEL] == 0 && d.S > 200);
-    if (mode == 0 && b->pcode_ok && want_sp && lds_sp <= 64 * 1024) {
+    if (mode == 0 && b->pcode_ok && want_sp && lds_sp + 512 <= 64 * 1024) {      // (+ the kernel's static __shared__: no opt-in above 64 KiB, the dense kernels take over)
         hipLaunchKernelGGL(k_pairwise_sp, dim3(d.NBE, r1 - r0), dim3(256), lds_sp, b->stream, b->d, r0, b->pe2p, b->spc);
     } else if (mode == 0 && b->pcode_ok && lds2 <= 150 * 1024 && (b->opt[RMX_OPT_PAIRWISE_KERNEL] == 0 || b->opt[RMX_OPT_PAIRWISE_KERNEL] == 2)) {
         HIPCHK(hipFuncSetAttribute((const void *)k_pairwise_be2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
@@ -2229,6 +2230,7 @@ int rmx_expected_ll_full(rmx_batch *b, int32_t r0, int32_t r1, double *out) { BI
 // the stale components of (A, B) of restarts [r0, r1) at their current (trial) parameter values into the scratch copy d2
 static int trial_pass(rmx_batch *b, int r0, int r1, Dev &d2) {
     b->trial_comp_r0 = b->trial_comp_r1 = -1;      // the scratch expectations are about to change
+    b->scratch_r0 = b->scratch_r1 = -1;
     int rc = ensure_tables(b, r0, r1);
     if (rc) return rc;
     const Dev &d = b->d;
@@ -2260,6 +2262,7 @@ static int trial_pass(rmx_batch *b, int r0, int r1, Dev &d2) {
         }
         r = e;
     }
+    b->scratch_r0 = r0; b->scratch_r1 = r1;
     return RMX_OK;
 }
 int rmx_expected_ll_full_trial(rmx_batch *b, int32_t r0, int32_t r1, double *out) { BIND(b);
@@ -2319,7 +2322,10 @@ int rmx_expected_ll_components(rmx_batch *b, int32_t r0, int32_t r1, int32_t tri
             for (int c = 0; c < 4; c++) out[(r - r0) * 4 + c] = b->comp_dirty[r] != 0 ? b->trial_comp[(size_t)(r - r0) * 4 + c] : b->h_pinned[(r - r0) * 4 + c];
         return RMX_OK;
     }
-    if (trial == 2) { d2.A = b->d_A2; d2.Bv = b->d_Bv2; }      // the scratch expectations of the last trial pass over this range, as they are
+    if (trial == 2) {      // the scratch expectations of the last trial pass over this range, as they are
+        if (b->scratch_r0 != r0 || b->scratch_r1 != r1) return fail(RMX_EUNSUPPORTED, "no trial pass over this range to take the expectations from");
+        d2.A = b->d_A2; d2.Bv = b->d_Bv2;
+    }
     else if (trial) { if ((rc = trial_pass(b, r0, r1, d2))) return rc; }
     else if ((rc = ensure_ab(b, r0, r1))) return rc;
     const int nr = r1 - r0;

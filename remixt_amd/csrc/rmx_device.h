@@ -355,10 +355,12 @@ __device__ __forceinline__ double wave_max_nonneg(double v) {
 // reduction only has to find the largest HIGH DWORD of the (non-negative) values -- a 32-bit integer
 // maximum, single-instruction DPP steps instead of a 64-bit floating-point butterfly.
 __device__ __forceinline__ void pow2_scale(unsigned hi, double &scale, double &inv) {
+    // (selects, not branches: this sits in the tail of every forward-backward step)
     const unsigned ef = (hi >> 20) & 0x7ffu;
-    if (ef == 0x7ffu) { scale = INFINITY; inv = 0.; }        // inf / nan in the vector (a nan's sign bit only raises the key)
-    else if (ef == 0u) { scale = 0.; inv = 0.; }             // zero or denormal maximum: the row vanished
-    else { scale = __hiloint2double((int)(ef << 20), 0); inv = __hiloint2double((int)((2046u - ef) << 20), 0); }
+    const bool ok = ef - 1u < 0x7feu;                        // a normal number; else inf / nan (a nan's sign bit only raises the key) or a vanished row (zero / denormal)
+    const int hs = ok ? (int)(ef << 20) : (ef == 0x7ffu ? 0x7ff00000 : 0);
+    const int hv = ok ? (int)((2046u - ef) << 20) : 0;
+    scale = __hiloint2double(hs, 0); inv = __hiloint2double(hv, 0);
 }
 // maximum over the 64 lanes of a wave of unsigned keys (wave-uniform result)
 __device__ __forceinline__ unsigned wave_max_u32(unsigned v) {

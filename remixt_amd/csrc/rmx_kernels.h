@@ -202,6 +202,9 @@ __device__ __forceinline__ void gload8(double &dst, const double *src) {
     asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(dst) : "v"(src) : "memory");
 }
 __device__ __forceinline__ void gwait8(double &v) { asm volatile("s_waitcnt vmcnt(0)" : "+v"(v) :: "memory"); }
+// ... placed behind the computation of `after` (the products of a step are non-volatile asm: without the tie the compiler is free to sink
+// them below the wait -- it did, and every step then began with the load's HBM round trip)
+__device__ __forceinline__ void gwait8_after(double &v, double &after) { asm volatile("s_waitcnt vmcnt(0)" : "+v"(v), "+v"(after) :: "memory"); }
 __device__ __forceinline__ void gstore8(double *dst, double v) {
     asm volatile("global_store_dwordx2 %0, %1, off\n\ts_nop 1" ::"v"(dst), "v"(v) : "memory");
 }
@@ -851,23 +854,42 @@ template <int PI, int KB> struct fbm_chain {
 };
 
 // The same products on the vector ALU, for workgroups that carry NV = 1 or 2 restarts (k_fbm<KB, NV>): lane (kq, c) owns rows 4 kb + kq of
-// column c -- its B-operand registers -- and accumulates acc_j += a_j[4 kb + kq] w[kb]; restart j's vector element reaches the 16 lanes of a
-// DPP row through the FMA's own DPP operand (row_newbcast:j on the A-operand image: lane (kq, 4 b + i) holds a_i).  Even and odd k-blocks
-// go to two accumulators per restart (independent FMA chains).
+// column c -- its B-operand registers -- and accumulates acc_j += a_j[4 kb + kq] w[kb].  The vector elements never come as LDS
+// broadcasts (one read per k-block is bound by LDS latency: a pair of FMAs is ten cycles, a read a hundred): lane c of a DPP row holds
+// a_j[4 (16 g + c) + kq] for g < ceil(KB / 16) -- 3 eight-byte reads per restart and step -- and the FMA of k-block kb takes its multiplier
+// from lane kb % 16 of the row through its own DPP operand (row_newbcast).  Even and odd k-blocks go to two accumulators per restart.
 template <int J> __device__ __forceinline__ void fbm_vfma(double &acc, const double a, const double x) {
     asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(a), "v"(x), "n"(J));
 }
-template <int PI, int KB, int NV> struct fbw_chain {
-    static __device__ __forceinline__ void run(fbm_d2 (&ring)[FBM_RING], const double (&w)[KB], unsigned addr, double (&acc)[NV][2]) {
-        constexpr int NP = KB / 2;
-        constexpr int younger = (NP - 1 - PI) < (FBM_DEPTH - 1) ? (NP - 1 - PI) : (FBM_DEPTH - 1);
-        fbm_wait<younger>(ring[PI % FBM_RING]);
-        fbm_vfma<0>(acc[0][0], ring[PI % FBM_RING].x, w[2 * PI]);
-        if constexpr (NV > 1) fbm_vfma<1>(acc[1][0], ring[PI % FBM_RING].x, w[2 * PI]);
-        fbm_vfma<0>(acc[0][1], ring[PI % FBM_RING].y, w[2 * PI + 1]);
-        if constexpr (NV > 1) fbm_vfma<1>(acc[1][1], ring[PI % FBM_RING].y, w[2 * PI + 1]);
-        if constexpr (PI + FBM_DEPTH < NP) fbm_rd<(PI + FBM_DEPTH) * 256>(ring[(PI + FBM_DEPTH) % FBM_RING], addr);
-        if constexpr (PI + 1 < NP) fbw_chain<PI + 1, KB, NV>::run(ring, w, addr, acc);
+#define FBW_G(KB_) (((KB_) + 15) / 16)
+template <int KBI, int KB, int NV> struct fbw_chain {
+    static __device__ __forceinline__ void run(const double (&av)[NV][FBW_G(KB)], const double (&w)[KB], double (&acc)[NV][2]) {
+        fbm_vfma<KBI % 16>(acc[0][KBI & 1], av[0][KBI / 16], w[KBI]);
+        if constexpr (NV > 1) fbm_vfma<KBI % 16>(acc[1][KBI & 1], av[1][KBI / 16], w[KBI]);
+        if constexpr (KBI + 1 < KB) fbw_chain<KBI + 1, KB, NV>::run(av, w, acc);
+    }
+};
+// position (in doubles) of state q in a restart's plain vector image: 64-blocks, inside a block the four row groups kq one after the
+// other -- lane (kq, c) reads 64 g + 16 kq + c, a wave consecutive doubles
+__device__ __forceinline__ int fbw_pos(int q) { return 64 * (q >> 6) + 16 * (q & 3) + ((q >> 2) & 15); }
+// a breakend step's products in that form: pair P of k-blocks; the weight of (row, column) is the resident plain weight times the
+// restart's rescaled clone-product entry (tab2: rows of a quad's four restarts, 48 bytes apart; the pair's two 16-bit row offsets in one word)
+template <int P, int KB, int NV> struct fbw_be {
+    static __device__ __forceinline__ void run(const double (&av)[NV][FBW_G(KB)], const double (&w)[KB], const unsigned *cw, const int pstride,
+                                               const char *tbb, double (&acc)[NV][2]) {
+        const unsigned c_ = cw[(size_t)P * pstride];
+        const char *r0_ = tbb + (c_ & 0xffffu), *r1_ = tbb + (c_ >> 16);
+        double t0[NV], t1[NV];
+        if constexpr (NV == 2) {
+            const double2 u0_ = *reinterpret_cast<const double2 *>(r0_), u1_ = *reinterpret_cast<const double2 *>(r1_);
+            t0[0] = u0_.x; t0[1] = u0_.y; t1[0] = u1_.x; t1[1] = u1_.y;
+        } else { t0[0] = *reinterpret_cast<const double *>(r0_); t1[0] = *reinterpret_cast<const double *>(r1_); }
+        constexpr int k0 = 2 * P, k1 = 2 * P + 1;
+        fbm_vfma<k0 % 16>(acc[0][0], av[0][k0 / 16], w[k0] * t0[0]);
+        if constexpr (NV > 1) fbm_vfma<k0 % 16>(acc[1][0], av[1][k0 / 16], w[k0] * t0[1]);
+        fbm_vfma<k1 % 16>(acc[0][1], av[0][k1 / 16], w[k1] * t1[0]);
+        if constexpr (NV > 1) fbm_vfma<k1 % 16>(acc[1][1], av[1][k1 / 16], w[k1] * t1[1]);
+        if constexpr (P + 1 < KB / 2) fbw_be<P + 1, KB, NV>::run(av, w, cw, pstride, tbb, acc);
     }
 };
 
@@ -884,6 +906,7 @@ __device__ __forceinline__ void fbm_body(const FbmArgs &a, const int by) {
     const int v_lo = max(a.r0 - rg0, 0), v_hi = min(a.r1 - rg0, NV);          // present: v_lo <= i < v_hi
     const int S = a.S, SP = a.SP, M = a.M, D = a.D, VR = a.VR, SPC = a.SPC;
     const int n0 = a.chain_start[chain], n1 = a.chain_end[chain], len = n1 - n0 + 1;
+    constexpr int G = FBW_G(KB), VRP = 64 * G;                  // (NV < 4) groups of 16 k-blocks, doubles of a restart's plain vector image
     const int t = threadIdx.x, NT = blockDim.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6), NW = NT >> 6;
     const int kq = lane >> 4, c16 = lane & 15, ib = lane & 3;   // operand roles: k inside the k-block, column inside the tile, restart of the A element
@@ -947,14 +970,22 @@ __device__ __forceinline__ void fbm_body(const FbmArgs &a, const int by) {
     int be_i = dir == 0 ? be_lo : be_hi - 1;                                   // slot of the next breakend step
     int be_adj = (be_i >= be_lo && be_i < be_hi) ? __builtin_amdgcn_readfirstlane(bel[be_i - be_lo]) : -2;   // its adjacency
     const int rstep = dir == 0 ? SP : -SP;
-    const bool mine = !is_sum && col < VR;                      // this lane publishes a vector element (possibly a padding column: zero)
+    const bool mine = !is_sum && (NV == 4 ? col < VR : (col < VRP && id < NV));      // this lane publishes a vector element (possibly a padding column: zero)
     const bool present = id >= v_lo && id < v_hi;
     const bool live = !is_sum && col < S && present;            // ... of an existing column and restart
     const size_t lane_off = ((size_t)(rg0 + (present ? id : v_lo)) * a.N + ROW(0)) * SP + (col < S ? col : S - 1);
     double *outp = (dir == 0 ? a.fa : a.fb) + lane_off;
-    const double *eptr = a.fe + lane_off;
-    double *vput = vec + fbm_pos(mine ? col : 0, id);            // this lane's element of the vector image (buffer 0)
-    const unsigned ap0 = lds_addr(vec + (kq * 4 + ib) * 2);      // A operands of k-blocks 0 and 1 (buffer 0); pair p: + 256 p bytes
+    // The emission value a result lane needs in step k: one 8-byte global load issued at the top of the step through untracked asm, consumed after
+    // the products.  (Round 4 measured the alternative -- rows staged three steps ahead in an LDS ring by LDS-DMA from one wave, retired by counted
+    // vmcnt -- and dropped it: with one restart per workgroup a step without ANY emission load is 80 cycles shorter than with this load, the ring's
+    // transfers cost the issuing wave 60 cycles each, and every shape got slower: 2 950 -> 3 410 cycles per step at four restarts per workgroup.)
+    const double *eptr = a.fe + lane_off + rstep;
+#define FBM_EGET(e_, k_) double e_; gload8(e_, eptr); eptr += rstep;
+    // vector image: NV = 4 the MFMA A-operand layout (fbm_pos), buffers VR * 4 doubles apart; NV < 4 one plain image of VRP doubles per restart (fbw_pos)
+    const int vbuf = NV == 4 ? VR * 4 : NV * VRP;                // doubles between the two buffers (step parity)
+    double *vput = vec + (NV == 4 ? fbm_pos(mine ? col : 0, id) : (mine ? id * VRP + fbw_pos(col) : 0));      // this lane's element of the vector image (buffer 0)
+    const unsigned ap0 = lds_addr(vec + (kq * 4 + ib) * 2);      // (NV = 4) A operands of k-blocks 0 and 1 (buffer 0); pair p: + 256 p bytes
+    const double *avp = vec + 16 * kq + c16;                     // (NV < 4) this lane's vector elements: restart j, group g at + j VRP + 64 g
     const bool scribe = dir == 0 && wave == 0 && is_sum && present;   // this lane records the forward scales of restart id
     double *mptr = a.mrow + (size_t)(rg0 + (present ? id : v_lo)) * a.N + ROW(0);
     // the three waves of a SIMD (w, w + 4, w + 8) at different issue priorities
@@ -974,10 +1005,9 @@ __device__ __forceinline__ void fbm_body(const FbmArgs &a, const int by) {
     // ---- step 0 ------------------------------------------------------------------------------------------------
     {
         double e0 = 0.;
-        if (live) { e0 = *eptr; gstore8(outp, (dir == 0) ? e0 : 1.0); }
+        if (live) { e0 = a.fe[lane_off]; gstore8(outp, (dir == 0) ? e0 : 1.0); }
         if (mine) *vput = live ? e0 : 0.;
     }
-    eptr += rstep;
     FB_BARRIER();
     if (a.dbg && t == 0 && blockIdx.x == 0 && by == 0 && blockIdx.z == 0) { a.dbg[0] = clock64(); a.dbg[1] = wall_clock64(); a.dbg[4] = len; }
     // the tail of a step, common to plain and breakend steps: `sum` = this lane's product (lane 15 of every DPP row: the
@@ -989,44 +1019,58 @@ __device__ __forceinline__ void fbm_body(const FbmArgs &a, const int by) {
         double m_, inv_;                                                                                                           \
         pow2_scale(hs_, m_, inv_);                                                                                                 \
         outp += rstep;                                                                                                             \
-        gwait8(e_);        /* a step old by now, like this wave's previous result store */                                        \
-        const double val_ = (sum_) * inv_;                                                                                         \
+        double val_ = (sum_) * inv_;                                                                                               \
+        gwait8_after(e_, val_);        /* issued at the top of the step */                                                         \
         const double vecv_ = val_ * (e_);                                                                                          \
+        if (mine) vput[(size_t)((k_) & 1) * vbuf] = live ? vecv_ : 0.;      /* (first: its LDS round trip runs under the stores' issue) */ \
         if (live) gstore8(outp, (dir == 0) ? vecv_ : val_);                                                                        \
-        if (mine) vput[(size_t)((k_) & 1) * VR * 4] = live ? vecv_ : 0.;                                                           \
         if (scribe) gstore8(mptr, m_);                           /* the scale of row k-1 for hmm_log_norm_const */                \
         mptr += dir == 0 ? 1 : -1;                                                                                                 \
+        PST(1)                                                                                                                     \
         FB_BARRIER();                                                                                                              \
     }
     // Plain steps run in their own tight loops between the chain's breakend steps: nothing of the breakend code (tracked
     // loads, a second barrier, the walk over the chain's breakends) is inside them -- with it in the same loop body every
     // plain step paid ~750 cycles for the compiler's conservative waits at the merge.
+#ifdef RMX_FB_PSTAMPS
+    // diagnostic build (tools/fb_only.py PSTAMPS): cycles a wave spends from the top of a plain step to the end of its products (0), from
+    // there to its arrival at the barrier (1), and in the barrier (2)
+    unsigned long long pst_acc[3] = {0, 0, 0}, pst_last;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(pst_last) :: "memory");
+#define PST(i_) { unsigned long long t_; asm volatile("s_waitcnt lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); pst_acc[i_] += t_ - pst_last; pst_last = t_; }
+#else
+#define PST(i_)
+#endif
     int k = 1;
     while (k < len) {
         const int k_be = be_adj >= 0 ? (dir == 0 ? be_adj - n0 + 1 : n1 - be_adj) : len;      // step that crosses the next breakend adjacency
         const int k_stop = k_be < len ? k_be : len;
         for (; k < k_stop; k++) {
-            double e;
-            gload8(e, eptr);                                     // consumed in FBM_FINISH, after the products
-            eptr += rstep;
-            fbm_d2 ring[FBM_RING];
-            const unsigned apc = ap0 + (unsigned)((k - 1) & 1) * (unsigned)(VR * 32);
-            fbm_chain<0, KB>::template fill<0>(ring, apc);
+            PST(2)
+            FBM_EGET(e, k)
             double sum;
             if constexpr (NV == 4) {
+                fbm_d2 ring[FBM_RING];
+                const unsigned apc = ap0 + (unsigned)((k - 1) & 1) * (unsigned)(VR * 32);
+                fbm_chain<0, KB>::template fill<0>(ring, apc);
                 double acc[4] = {0., 0., 0., 0.};
                 fbm_chain<0, KB>::run(ring, w, apc, acc);
                 sum = (acc[0] + acc[1]) + (acc[2] + acc[3]);
             } else {
-                double acc[NV][2];
+                double av[NV][G], acc[NV][2];
 #pragma unroll
-                for (int j = 0; j < NV; j++) acc[j][0] = acc[j][1] = 0.;
-                fbw_chain<0, KB, NV>::run(ring, w, apc, acc);
+                for (int j = 0; j < NV; j++) {
+                    acc[j][0] = acc[j][1] = 0.;
+#pragma unroll
+                    for (int g = 0; g < G; g++) av[j][g] = avp[(size_t)((k - 1) & 1) * vbuf + j * VRP + 64 * g];
+                }
+                fbw_chain<0, KB, NV>::run(av, w, acc);
                 // the four row groups kq of a column, and the move to the result lanes (lane 16 i + c: restart slot i), in one matrix
                 // instruction per restart: A = (row i == slot j) for every k, B = this lane's partial sum  ->  D[i][c] = [i == j] sum_kq p_j[kq][c]
                 sum = __builtin_amdgcn_mfma_f64_4x4x4f64(sel0, acc[0][0] + acc[0][1], 0., 0, 0, 0);
                 if constexpr (NV > 1) sum = __builtin_amdgcn_mfma_f64_4x4x4f64(sel1, acc[1][0] + acc[1][1], sum, 0, 0, 0);
             }
+            PST(0)
             FBM_FINISH(sum, e, k)
         }
         if (k < len) {
@@ -1062,19 +1106,33 @@ __device__ __forceinline__ void fbm_body(const FbmArgs &a, const int by) {
                 }
             }
             FB_BARRIER();
-            double e;
-            gload8(e, eptr);
-            eptr += rstep;
+            FBM_EGET(e, k)
             // The weights differ per restart, so the four rows of an MFMA cannot share a B operand (four MFMAs per k-block, each with one
             // useful row): the products run on the vector ALU instead.  Lane (kq, c) owns rows 4 kb + kq of column c -- exactly its B-operand
             // registers w[kb] -- and accumulates acc_i += a_i[q] (w[kb] tab2_i[ix(q, c)]) for the four restarts; the four lanes of a column
             // (kq = 0..3) are added at the end in a fixed order.  19 000 -> ~8 000 cycles per breakend step.
-            double acc[NV];
-#pragma unroll
-            for (int j = 0; j < NV; j++) acc[j] = 0.;
+            double sum;
             const unsigned *cw = codel + (size_t)kq * SPC + (wave * 16 + c16);
             const char *tbb = reinterpret_cast<const char *>(tab2) + I0 * 8;       // (the unit's restarts inside the quad's rows)
             (void)tb;
+            if constexpr (NV < 4) {
+                double av[NV][G], acc[NV][2];
+#pragma unroll
+                for (int j = 0; j < NV; j++) {
+                    acc[j][0] = acc[j][1] = 0.;
+#pragma unroll
+                    for (int g = 0; g < G; g++) av[j][g] = avp[(size_t)((k - 1) & 1) * vbuf + j * VRP + 64 * g];
+                }
+                fbw_be<0, KB, NV>::run(av, w, cw, 4 * SPC, tbb, acc);
+                // (as in a plain step.  The accumulators are written by inline-asm FMAs the hazard recognizer cannot see into: a matrix
+                // instruction must not take one of them as an operand directly -- it read a stale value now and then; the additions are
+                // ordinary vector instructions, whose hazards against the matrix instruction the compiler covers)
+                sum = __builtin_amdgcn_mfma_f64_4x4x4f64(sel0, acc[0][0] + acc[0][1], 0., 0, 0, 0);
+                if constexpr (NV > 1) sum = __builtin_amdgcn_mfma_f64_4x4x4f64(sel1, acc[1][0] + acc[1][1], sum, 0, 0, 0);
+            } else {
+            double acc[NV];
+#pragma unroll
+            for (int j = 0; j < NV; j++) acc[j] = 0.;
             // all row offsets first (one LDS round trip), then the pairs with the next pair's operands requested before this pair's
             // products: a pair is otherwise two dependent LDS round trips (offsets, then rows) in front of 4 NV FMAs
             constexpr int NPAIR = KB / 2, CH0 = (NPAIR + 1) / 2;      // the offsets in two chunks (register budget)
@@ -1131,9 +1189,10 @@ __device__ __forceinline__ void fbm_body(const FbmArgs &a, const int by) {
             // the four row groups of a column: ((kq 0 + kq 1) + (kq 2 + kq 3)), the same value in all four lanes (a + b == b + a)
 #pragma unroll
             for (int j = 0; j < NV; j++) { acc[j] += __shfl_xor(acc[j], 16); acc[j] += __shfl_xor(acc[j], 32); }
-            double sum = acc[0];                                                       // result lane (i, c) keeps restart slot i
+            sum = acc[0];                                                              // result lane (i, c) keeps restart slot i
 #pragma unroll
             for (int j = 1; j < NV; j++) if (id == j) sum = acc[j];
+            }
             FB_STAMP(2)
             FBM_FINISH(sum, e, k)
             FB_STAMP(3)
@@ -1145,12 +1204,20 @@ __device__ __forceinline__ void fbm_body(const FbmArgs &a, const int by) {
     }
 #undef FBM_FINISH
 #undef FBM_FETCH
+#undef FBM_EGET
+#ifdef RMX_FB_PSTAMPS
+    if (a.dbg && blockIdx.x == 0 && by == 0 && blockIdx.z == 0 && lane == 0) {
+        const int slot = wave == 0 ? 0 : (wave == 4 ? 1 : (wave == 8 ? 2 : (wave == 3 ? 3 : (wave == 7 ? 4 : (wave == NW - 1 ? 5 : -1)))));
+        if (slot >= 0) for (int i = 0; i < 3; i++) a.dbg[8 + slot * 3 + i] = pst_acc[i];
+    }
+#endif
+#undef PST
     if (a.dbg && t == 0 && blockIdx.x == 0 && by == 0 && blockIdx.z == 0) { a.dbg[2] = clock64(); a.dbg[3] = wall_clock64(); }
     // last row of each chain: its scale is not consumed by a later step, but the vanishing-row check needs the row's sum
     if (wave == 0) {
-        const double *vb = vec + (size_t)((len - 1) & 1) * VR * 4;
+        const double *vb = vec + (size_t)((len - 1) & 1) * vbuf;
         double ps = 0.;
-        for (int q = c16; q < S; q += 16) ps += vb[fbm_pos(q, id)];
+        for (int q = c16; q < S; q += 16) ps += vb[NV == 4 ? fbm_pos(q, id) : (id < NV ? id : 0) * VRP + fbw_pos(q)];
         ps = group_sum(ps, 16);
         if (c16 == 0 && present) {
             double m_, inv;

@@ -24,3 +24,10 @@ def get_param(config, name):
     if config is not None and name in config:
         return config[name]
     return globals()[name]
+
+
+def get_sample_config(config, sample_id):
+    """remixt/config.py:56-59: the config with the `sample_specific[sample_id]` overrides applied on top."""
+    sample_config = dict(config or {})
+    sample_config.update((config or {}).get('sample_specific', dict()).get(sample_id, dict()))
+    return sample_config

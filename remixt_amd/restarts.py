@@ -914,6 +914,17 @@ def gather_result_records(local, experiment, init_params, num_clones, param_name
     brk_ids = list(experiment.breakpoints.keys()); K = len(brk_ids)
     nparams = len(param_names)
     per_rank = (len(init_params) + world - 1) // world
+    if local_ids is not None:
+        # shares that are not shard_indices' (units of several datasets cut over the ranks) need not be balanced per dataset: every rank's
+        # buffer takes the largest share
+        per_rank = max(per_rank, len(local_ids), 1)
+        if distributed:
+            dev_ = torch.device('cuda', device if device is not None else torch.cuda.current_device()) if dist.get_backend() == 'nccl' else torch.device('cpu')
+            cnt_ = torch.tensor([per_rank], dtype=torch.int64, device=dev_)
+            dist.all_reduce(cnt_, op=dist.ReduceOp.MAX)
+            per_rank = int(cnt_.item())
+    if len(local) > per_rank:
+        raise ValueError('gather_result_records: %d local results for a share of %d (pass local_ids for shares that are not shard_indices\')' % (len(local), per_rank))
     flen = _HDR + M + nparams + 4 * N
     ilen = N * M * 2 + K * M + 2 * N
     fbuf = np.full((per_rank, flen), np.nan); ibuf = np.zeros((per_rank, ilen), dtype=np.int8)

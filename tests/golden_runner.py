@@ -165,8 +165,16 @@ def replay_grid(name, kernel, rtol, atol, elbo_every_step=True, mixed_elbo=False
     return m
 
 
-def replay_fit(name, kernel, rtol_elbo=1e-6, rtol_h=1e-4, rtol_param=1e-3):
-    """Seeded EM trajectory (global numpy RNG, like the reference)."""
+# The one accepted escape of the device fit replays, pinned: (fixture, parameter) pairs whose search objective --
+# a sample of N / 10 segments -- is flat to the last bits, so that the Nelder-Mead polish is steered by the rounding of the sums (the
+# reference accumulates cell by cell, the device per segment and then over segments) and the two end a reflection or an expansion step
+# apart (5 - 10 %).  Accepted only for these pairs, only where the caller asks for it (the HIP replay; the oracle replay is strict), and only
+# if the FULL-DATA objective does not tell the two values apart (1e-9 relative).  A new pair showing up is a regression until proven flat.
+FLAT_PARAMETERS = {('model_nonormal', 'betabin_loh_M_1')}
+
+
+def replay_fit(name, kernel, rtol_elbo=1e-6, rtol_h=1e-4, rtol_param=1e-3, allow_flat=False):
+    """Seeded EM trajectory (global numpy RNG, like the reference).  Returns (model, the parameters that took the flat-objective escape)."""
     g = load(name)
     m = build(g, kernel)
     m.num_em_iter = 2; m.num_update_iter = 2
@@ -177,22 +185,21 @@ def replay_fit(name, kernel, rtol_elbo=1e-6, rtol_h=1e-4, rtol_param=1e-3):
     check(m.h, g['fit/h'], rtol_h, 1e-9, 'fit h')
     pv = m.get_likelihood_param_values()
     ones = np.ones(m.N1, dtype=np.int64)
+    escaped = []
     for k, v in zip(g['fit/param_names'], g['fit/param_values']):
         k = str(k)
         if np.allclose(pv[k], v, rtol=rtol_param, atol=1e-9):
             continue
-        # A parameter the data do not constrain: its search runs on a sample of N / 10 segments, and where that objective is
-        # flat to the last bits, the Nelder-Mead polish is steered by the rounding of the sums (the reference accumulates
-        # cell by cell, the device per segment and then over segments), so the two can end a reflection or an expansion
-        # step apart (5 - 10 %).  Accepted only if the full-data objective does not tell the two values apart (1e-9 relative).
+        assert allow_flat and (name, k) in FLAT_PARAMETERS, 'fit %s of %s: %r vs reference %r (not on the list of flat parameters)' % (k, name, pv[k], float(v))
         here = float(getattr(m.model, k))
         e_here = m.model.calculate_expected_log_likelihood(ones)
         setattr(m.model, k, float(v))
         e_gold = m.model.calculate_expected_log_likelihood(ones)
         setattr(m.model, k, here)
         assert abs(e_here - e_gold) <= 1e-9 * abs(e_gold), 'fit %s: %r vs reference %r, and E[ll] tells them apart (%r vs %r)' % (k, pv[k], float(v), e_here, e_gold)
+        escaped.append(k)
     cn, brk = m.optimal_cn()
     assert np.array_equal(cn, g['fit/cn'])
     assert np.array_equal(np.array([brk[str(k)] for k in g['breakpoint_ids']]), g['fit/brk_cn'])
     check(m.p_outlier_total, g['fit/p_outlier_total'], 1e-4, 1e-7, 'fit p_outlier_total')
-    return m
+    return m, escaped

@@ -39,7 +39,11 @@ def test_hip_replays_reference_at_bench_grids_and_dark_corners(hip, name):
 def test_hip_full_fit_trajectory(hip, name):
     """Seeded EM trajectories recorded from the reference, the ten-parameter no-normal-contamination M-step included.  ELBO 1e-6;
     h 1e-4 and parameters 1e-3: two EM iterations of scipy optimisers amplify the kernels' last-bit differences."""
-    GR.replay_fit(name, hip, rtol_elbo=1e-6, rtol_h=1e-4, rtol_param=1e-3)
+    _, escaped = GR.replay_fit(name, hip, rtol_elbo=1e-6, rtol_h=1e-4, rtol_param=1e-3, allow_flat=True)
+    # parameters that ended elsewhere than the reference's on an objective flat to the last bits: only the pinned ones (golden_runner.FLAT_PARAMETERS)
+    assert set((name, k) for k in escaped) <= GR.FLAT_PARAMETERS
+    if escaped:
+        print('fit %s: flat-objective escape taken by %s' % (name, escaped))
 
 
 def test_hip_chain_kats(hip):

@@ -43,5 +43,9 @@ if DEBUG:
     c0, w0, c1, w1, ln = [b.info(i) for i in (20, 21, 22, 23, 24)]
     print('debug: steps', ln, 'shader cycles/step', (c1 - c0) / max(ln - 1, 1), 'wall us/step', (w1 - w0) / 100.0 / max(ln - 1, 1), 'clock GHz', (c1 - c0) / ((w1 - w0) * 10.0))
     nbe = max(b.info(25), 1)
+    if os.environ.get('PSTAMPS'):      # a -DRMX_FB_PSTAMPS build: per-wave cycles of a plain step (products / tail to the barrier / in the barrier)
+        for slot, wv in enumerate(('0', '4', '8', '3', '7', 'last')):
+            print('plain-step stamps wave %-4s: products %6d  tail %6d  barrier %6d  (cycles per step)' % ((wv,) + tuple(round(b.info(28 + 3 * slot + i) / max(ln - 1, 1)) for i in range(3))))
+        sys.exit(0)
     for wv in range(3):
         print('breakend-step stamps wave %d (cycles per breakend step of chain 0: entry wait+barrier / walk+fetch issue / products / finish):' % (4 * wv), [round(b.info(28 + 6 * wv + i) / nbe) for i in range(4)], 'breakend steps', nbe)

@@ -1,13 +1,13 @@
 #!/bin/bash
 # forward-backward launch shapes at the bench workload: restarts per launch x restarts per workgroup (k_fbm<., NV>), with the kernel's
-# cycle counters.  Usage: tools/fb_shapes.sh [MAXCN]
+# cycle counters.  Usage: tools/fb_shapes.sh [MAXCN [variant]]   (variant: an alternative build tools/micro/lib_<variant>.so)
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 cd /tmp
 MAXCN=${1:-8}
 for rst in 4 8 16; do
   for nv in 1 2 4; do
     if [ $((rst / nv * 46)) -gt 400 ]; then continue; fi
-    echo "== restarts per launch $rst, per workgroup $nv"
-    RST=$rst NV=$nv MAXCN=$MAXCN FB_DEBUG=1 ITERS=3 python3 $ROOT/tools/fb_only.py 2>&1 | grep -E "k_fb |debug|stamps wave 0|raised" || exit 1
+    echo "== restarts per launch $rst, per workgroup $nv ${2:+(library $2)}"
+    STAMPS=$2 RST=$rst NV=$nv MAXCN=$MAXCN FB_DEBUG=1 ITERS=3 python3 $ROOT/tools/fb_only.py 2>&1 | grep -E "k_fb |debug|raised" || exit 1
   done
 done
