@@ -1351,6 +1351,13 @@ static int p_cn_front(rmx_batch *b, int r0, int r1, bool skip_frame, bool snapsh
             // looked up in a 64-entry LDS table (k_fbq); fb_kernel = 3 selects the vector kernel k_fbk below instead
             const int KB = d.S <= 256 ? 64 : 90;
             const int NWq = (d.S + 29) / 30;
+            auto units = [&](int nv) { return (r1 - 1) / nv - r0 / nv + 1; };      // absolute units of nv restarts that [r0, r1) touches
+            int NV = 4;                                                             // (as for k_fbm: two / one per workgroup on the vector ALU where the chip has room)
+            if (b->opt[RMX_OPT_FB_NV] == 1 || b->opt[RMX_OPT_FB_NV] == 2 || b->opt[RMX_OPT_FB_NV] == 4) NV = b->opt[RMX_OPT_FB_NV];
+            else { for (int nv : {2, 1}) if ((long)b->n_fast * 2 * units(nv) <= g_fb_wg_budget) NV = nv; }
+            // above 256 states (90 k-blocks) two restarts per workgroup do not fit the register file next to the 90 address registers (measured: spills,
+            // 12 200 cycles per step against 13 500 with four): one per workgroup where that fits the chip, else four
+            if (KB == 90 && NV == 2) NV = (b->opt[RMX_OPT_FB_NV] == 0 && (long)b->n_fast * 2 * units(1) <= g_fb_wg_budget) ? 1 : 4;
             FbmArgs m;
             memset(&m, 0, sizeof m);
             m.S = d.S; m.SP = d.SP; m.M = d.M; m.D = d.D; m.C = d.C; m.N = d.N; m.NBE = d.NBE; m.cn_max = d.cn_max; m.r0 = r0; m.r1 = r1;
@@ -1359,13 +1366,13 @@ static int p_cn_front(rmx_batch *b, int r0, int r1, bool skip_frame, bool snapsh
             m.be_n = d.be_n; m.chain_be = d.chain_be; m.fe = d.fe; m.Wf = d.Wf; m.Wb = d.Wb; m.pe2_lt = d.pe2x_lt; m.af = d.af; m.ab = d.ab; m.tot = d.tot;
             m.fa = d.fa; m.fb = d.fb; m.mrow = d.mrow; m.err = d.err; m.dbg = b->d_dbg;
             const size_t lds = (size_t)2 * m.VR * 4 * 8 + (size_t)2 * 4 * m.PE2P * 8 + 64 * 32 * 8 + 64 * 8 + (size_t)4 * KB * 4 + (size_t)b->be_cap * 4 + 64;
-            void (*kf)(FbmArgs, const double *, const uint32_t *, const uint32_t *) = KB == 64 ? k_fbq<64> : k_fbq<90>;
+            void (*kf)(FbmArgs, const double *, const uint32_t *, const uint32_t *) =
+                KB == 64 ? (NV == 4 ? k_fbq<64, 4> : (NV == 2 ? k_fbq<64, 2> : k_fbq<64, 1>)) : (NV == 4 ? k_fbq<90, 4> : k_fbq<90, 1>);
             if (NWq <= 12 && 4 * KB >= d.S && lds <= kLdsBudget) {
-                const int ny = ((r1 - 1) >> 2) - (r0 >> 2) + 1;
                 HIPCHK(hipFuncSetAttribute((const void *)kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-                hipLaunchKernelGGL(kf, dim3(b->n_fast, ny, 2), dim3(64 * NWq), lds, b->stream, m,
+                hipLaunchKernelGGL(kf, dim3(b->n_fast, units(NV), 2), dim3(64 * NWq), lds, b->stream, m,
                                    (const double *)b->d_wk, (const uint32_t *)b->d_cnpack, (const uint32_t *)b->d_totpack);
-                done_fast = true; fast = true; b->last_fb_kernel = 4; b->last_fb_nv = 4;
+                done_fast = true; fast = true; b->last_fb_kernel = 4; b->last_fb_nv = NV;
             }
         }
         if (!done_fast && b->fbv_rpt == 0 && b->fbk_ok && d.pe2_lt && b->n_fast > 0 && (b->opt[RMX_OPT_FB_KERNEL] == 0 || b->opt[RMX_OPT_FB_KERNEL] == 3)) {

@@ -1301,14 +1301,84 @@ template <int KB> struct fbq_chain {
     }
 };
 
-template <int KB>
+// k_fbq with NV = 1 or 2 restarts per workgroup: the same lookups, the products on the vector ALU (k_fbm's fbw_chain: plain vector images,
+// the multiplier of k-block kb from lane kb % 16 of the DPP row).  Per k-block and tile one address extraction, one table lookup and NV FMAs;
+// the lookups are ordinary (tracked) LDS loads, a few k-blocks ahead of their FMAs (the scheduling barriers bound the look-ahead).
+#define FBQW_DEPTH 2
+#define FBQW_RING (FBQW_DEPTH + 1)
+struct fbqw_slot { double b[4]; };               // B operands [k-block of the pair][tile]
+template <int CNT> __device__ __forceinline__ void fbqw_wait(fbqw_slot &x) {
+    asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(x.b[0]), "+v"(x.b[1]), "+v"(x.b[2]), "+v"(x.b[3]) : "n"(CNT) : "memory");
+}
+template <int KB, int NV> struct fbqw_chain {
+    static constexpr int NP = KB / 2;
+    // the four lookups of pair P (k-blocks 2 P, 2 P + 1, tiles 0 and 1) through untracked reads, FBQW_DEPTH pairs ahead of the FMAs that consume
+    // them, retired by counted waits -- left to the compiler the reads were waited for one by one (a third of the FMAs behind an lgkmcnt(0))
+    template <int P> static __device__ __forceinline__ void issue(fbqw_slot &s, const unsigned (&c0)[KB / 2], const unsigned (&c1)[KB / 2]) {
+        constexpr int k0 = 2 * P, k1 = 2 * P + 1;
+        unsigned a0 = FBQ_ADDR(c0, k0), a1 = FBQ_ADDR(c1, k0), a2 = FBQ_ADDR(c0, k1), a3 = FBQ_ADDR(c1, k1);
+        asm volatile("" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3));
+        __builtin_amdgcn_sched_barrier(0);
+        fbq_rd64(s.b[0], a0); fbq_rd64(s.b[1], a1); fbq_rd64(s.b[2], a2); fbq_rd64(s.b[3], a3);
+    }
+    template <int P> static __device__ __forceinline__ void run(fbqw_slot (&ring)[FBQW_RING], const double (&av)[NV][FBW_G(KB)], const unsigned (&c0)[KB / 2],
+                                                                const unsigned (&c1)[KB / 2], double (&acc0)[NV][2], double (&acc1)[NV][2]) {
+        constexpr int younger = (NP - 1 - P) < (FBQW_DEPTH - 1) ? (NP - 1 - P) : (FBQW_DEPTH - 1);
+        constexpr int k0 = 2 * P, k1 = 2 * P + 1;
+        fbqw_slot &s = ring[P % FBQW_RING];
+        fbqw_wait<4 * younger>(s);
+        // (one restart: even and odd k-blocks in two accumulators per tile; two restarts: one accumulator per tile and restart -- four
+        // independent FMA chains either way, and the register file has no room for eight)
+        constexpr int O = NV > 1 ? 0 : 1;
+        fbm_vfma<k0 % 16>(acc0[0][0], av[0][k0 / 16], s.b[0]);
+        if constexpr (NV > 1) fbm_vfma<k0 % 16>(acc0[1][0], av[1][k0 / 16], s.b[0]);
+        fbm_vfma<k0 % 16>(acc1[0][0], av[0][k0 / 16], s.b[1]);
+        if constexpr (NV > 1) fbm_vfma<k0 % 16>(acc1[1][0], av[1][k0 / 16], s.b[1]);
+        fbm_vfma<k1 % 16>(acc0[0][O], av[0][k1 / 16], s.b[2]);
+        if constexpr (NV > 1) fbm_vfma<k1 % 16>(acc0[1][O], av[1][k1 / 16], s.b[2]);
+        fbm_vfma<k1 % 16>(acc1[0][O], av[0][k1 / 16], s.b[3]);
+        if constexpr (NV > 1) fbm_vfma<k1 % 16>(acc1[1][O], av[1][k1 / 16], s.b[3]);
+        // (the FMAs are plain asm: pinned between the wait above and the slot's next request below by their operands, and here)
+        asm volatile("" : "+v"(acc0[0][0]), "+v"(acc0[0][O]), "+v"(acc1[0][0]), "+v"(acc1[0][O]));
+        if constexpr (NV > 1) asm volatile("" : "+v"(acc0[1][0]), "+v"(acc1[1][0]));
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (P + FBQW_DEPTH < NP) issue<P + FBQW_DEPTH>(ring[(P + FBQW_DEPTH) % FBQW_RING], c0, c1);
+        if constexpr (P + 1 < NP) run<P + 1>(ring, av, c0, c1, acc0, acc1);
+    }
+    template <int I> static __device__ __forceinline__ void fill(fbqw_slot (&ring)[FBQW_RING], const unsigned (&c0)[KB / 2], const unsigned (&c1)[KB / 2]) {
+        issue<I>(ring[I], c0, c1);
+        if constexpr (I + 1 < FBQW_DEPTH && I + 1 < NP) fill<I + 1>(ring, c0, c1);
+    }
+};
+// ... and a breakend step's: the plain weight (the same lookup) times the restart's entry of the quad's rescaled clone-product table, whose row is
+// sgn 32 (U_q - U_o) + const bytes into the table (k_fbq's scheme), the unit's restarts at + 8 I0
+template <int KBI, int KB, int NV> struct fbqw_be {
+    static __device__ __forceinline__ void run(const double (&av)[NV][FBW_G(KB)], const char *wtb, const unsigned (&c0)[KB / 2], const unsigned (&c1)[KB / 2],
+                                               const int *uplq, const int umul, const int uoff0, const int uoff1, const char *tbb,
+                                               double (&acc0)[NV][2], double (&acc1)[NV][2]) {
+        const double w0 = *reinterpret_cast<const double *>(wtb + FBQ_ADDR(c0, KBI)), w1 = *reinterpret_cast<const double *>(wtb + FBQ_ADDR(c1, KBI));
+        const int uq = __mul24(uplq[4 * KBI], umul);
+        const double *r0 = reinterpret_cast<const double *>(tbb + (uq + uoff0)), *r1 = reinterpret_cast<const double *>(tbb + (uq + uoff1));
+        fbm_vfma<KBI % 16>(acc0[0][KBI & 1], av[0][KBI / 16], w0 * r0[0]);
+        if constexpr (NV > 1) fbm_vfma<KBI % 16>(acc0[1][KBI & 1], av[1][KBI / 16], w0 * r0[1]);
+        fbm_vfma<KBI % 16>(acc1[0][KBI & 1], av[0][KBI / 16], w1 * r1[0]);
+        if constexpr (NV > 1) fbm_vfma<KBI % 16>(acc1[1][KBI & 1], av[1][KBI / 16], w1 * r1[1]);
+        if constexpr (KBI % 2 == 1) __builtin_amdgcn_sched_barrier(0);
+        if constexpr (KBI + 1 < KB) fbqw_be<KBI + 1, KB, NV>::run(av, wtb, c0, c1, uplq, umul, uoff0, uoff1, tbb, acc0, acc1);
+    }
+};
+
+template <int KB, int NV>
 __device__ __forceinline__ void fbq_body(const FbmArgs &a, const double *wk, const uint32_t *cnpack, const uint32_t *totpack, const int by) {
     extern __shared__ __align__(16) unsigned char smem_raw[];
     static_assert(KB % 2 == 0 && KB / 2 >= FBQ_DEPTH, "k-blocks come in pairs; ring no deeper than the chain");
     constexpr int NW32 = KB / 2;
     const int chain = a.chain_list[blockIdx.x], dir = blockIdx.z;
-    const int quad = (a.r0 >> 2) + by, rg0 = quad * FBM_NV;
-    const int v_lo = max(a.r0 - rg0, 0), v_hi = min(a.r1 - rg0, FBM_NV);
+    static_assert(NV == 1 || NV == 2 || NV == 4, "restarts per workgroup");
+    constexpr int G = FBW_G(KB), VRP = 64 * G;                  // (NV < 4) groups of 16 k-blocks, doubles of a restart's plain vector image
+    // restarts in absolute units of NV inside absolute quads (k_fbm); the unit's restarts take slots 0 .. NV - 1 of the vector image
+    const int unit = a.r0 / NV + by, rg0 = unit * NV, quad = rg0 >> 2, I0 = rg0 & 3;
+    const int v_lo = max(a.r0 - rg0, 0), v_hi = min(a.r1 - rg0, NV);
     const int S = a.S, SP = a.SP, M = a.M, D = a.D, VR = a.VR;
     const int n0 = a.chain_start[chain], n1 = a.chain_end[chain], len = n1 - n0 + 1;
     const int t = threadIdx.x, NT = blockDim.x, lane = t & 63;
@@ -1364,14 +1434,19 @@ __device__ __forceinline__ void fbq_body(const FbmArgs &a, const double *wk, con
     int be_adj = (be_i >= be_lo && be_i < be_hi) ? __builtin_amdgcn_readfirstlane(bel[be_i - be_lo]) : -2;
     const int rstep = dir == 0 ? SP : -SP;
     const bool present = id >= v_lo && id < v_hi;
-    const bool mine0 = !is_sum && col0 < VR, mine1 = !is_sum && col1 < VR;
+    const bool mine0 = !is_sum && (NV == 4 ? col0 < VR : (col0 < VRP && id < NV)), mine1 = !is_sum && (NV == 4 ? col1 < VR : (col1 < VRP && id < NV));
     const bool live0 = !is_sum && col0 < S && present, live1 = !is_sum && col1 < S && present;
     const size_t row_off = ((size_t)(rg0 + (present ? id : v_lo)) * a.N + ROW(0)) * SP;
     const size_t off0 = row_off + (col0 < S ? col0 : S - 1), off1 = row_off + (col1 < S ? col1 : S - 1);
     double *outp0 = (dir == 0 ? a.fa : a.fb) + off0, *outp1 = (dir == 0 ? a.fa : a.fb) + off1;
     const double *eptr0 = a.fe + off0, *eptr1 = a.fe + off1;
-    double *vput0 = vec + fbm_pos(mine0 ? col0 : 0, id), *vput1 = vec + fbm_pos(mine1 ? col1 : 0, id);
+    const int vbuf = NV == 4 ? VR * 4 : NV * VRP;                // doubles between the two buffers (step parity)
+    double *vput0 = vec + (NV == 4 ? fbm_pos(mine0 ? col0 : 0, id) : (mine0 ? id * VRP + fbw_pos(col0) : 0));
+    double *vput1 = vec + (NV == 4 ? fbm_pos(mine1 ? col1 : 0, id) : (mine1 ? id * VRP + fbw_pos(col1) : 0));
     const unsigned ap0 = lds_addr(vec + (kq * 4 + ib) * 2);
+    const double *avp = vec + 16 * kq + c16;                     // (NV < 4) this lane's vector elements: restart j, group g at + j VRP + 64 g
+    const double sel0 = ib == 0 ? 1.0 : 0.0, sel1 = ib == 1 ? 1.0 : 0.0;   // (NV < 4) A operands that pick restart slot 0 / 1 as result row
+    (void)sel0; (void)sel1; (void)avp; (void)I0;
     const unsigned wt = lds_addr(wtab);
     if (wt != 0u) {      // (uniform) the lookups address the table from LDS address 0: this kernel must not have static LDS in front of it
         if (t == 0) atomicOr(&a.err[rg0 + v_lo], RMX_ERR_NAN_AB);
@@ -1407,13 +1482,13 @@ __device__ __forceinline__ void fbq_body(const FbmArgs &a, const double *wk, con
         double m_, inv_;                                                                                                           \
         pow2_scale(hs_, m_, inv_);                                                                                                 \
         outp0 += rstep; outp1 += rstep;                                                                                            \
-        gwait8(e0_); gwait8(e1_);                                                                                                  \
-        const double val0_ = (s0_) * inv_, val1_ = (s1_) * inv_;                                                                   \
+        double val0_ = (s0_) * inv_, val1_ = (s1_) * inv_;                                                                         \
+        gwait8_after(e0_, val0_); gwait8_after(e1_, val1_);      /* (behind the products: see gwait8_after) */                     \
         const double vv0_ = val0_ * (e0_), vv1_ = val1_ * (e1_);                                                                   \
         if (live0) gstore8(outp0, (dir == 0) ? vv0_ : val0_);                                                                      \
         if (live1) gstore8(outp1, (dir == 0) ? vv1_ : val1_);                                                                      \
-        if (mine0) vput0[(size_t)((k_) & 1) * VR * 4] = live0 ? vv0_ : 0.;                                                         \
-        if (mine1) vput1[(size_t)((k_) & 1) * VR * 4] = live1 ? vv1_ : 0.;                                                         \
+        if (mine0) vput0[(size_t)((k_) & 1) * vbuf] = live0 ? vv0_ : 0.;                                                           \
+        if (mine1) vput1[(size_t)((k_) & 1) * vbuf] = live1 ? vv1_ : 0.;                                                           \
         if (scribe) gstore8(mptr, m_);                                                                                             \
         mptr += dir == 0 ? 1 : -1;                                                                                                 \
         FB_BARRIER();                                                                                                              \
@@ -1440,12 +1515,34 @@ __device__ __forceinline__ void fbq_body(const FbmArgs &a, const double *wk, con
             // the step loop and spills them)
 #pragma unroll
             for (int i = 0; i < NW32; i++) asm volatile("" : "+v"(c0[i]), "+v"(c1[i]));
-            double acc[4] = {0., 0., 0., 0.};
-            fbq_slot ring[FBQ_RING];
-            const unsigned apc = ap0 + (unsigned)((k - 1) & 1) * (unsigned)(VR * 32);
-            fbq_chain<KB>::template fill<0>(ring, apc, wt, c0, c1);
-            fbq_chain<KB>::template run<0>(ring, apc, wt, c0, c1, acc);
-            const double s0 = acc[0] + acc[2], s1 = acc[1] + acc[3];
+            double s0, s1;
+            if constexpr (NV == 4) {
+                double acc[4] = {0., 0., 0., 0.};
+                fbq_slot ring[FBQ_RING];
+                const unsigned apc = ap0 + (unsigned)((k - 1) & 1) * (unsigned)(VR * 32);
+                fbq_chain<KB>::template fill<0>(ring, apc, wt, c0, c1);
+                fbq_chain<KB>::template run<0>(ring, apc, wt, c0, c1, acc);
+                s0 = acc[0] + acc[2]; s1 = acc[1] + acc[3];
+            } else {
+                double av[NV][G], acc0[NV][2], acc1[NV][2];
+#pragma unroll
+                for (int j = 0; j < NV; j++) {
+                    acc0[j][0] = acc0[j][1] = acc1[j][0] = acc1[j][1] = 0.;
+#pragma unroll
+                    for (int g = 0; g < G; g++) av[j][g] = avp[(size_t)((k - 1) & 1) * vbuf + j * VRP + 64 * g];
+                }
+                fbqw_slot ring[FBQW_RING];
+                fbqw_chain<KB, NV>::template fill<0>(ring, c0, c1);      // (the table sits at LDS address 0: the fields are the addresses)
+                fbqw_chain<KB, NV>::template run<0>(ring, av, c0, c1, acc0, acc1);
+                // (the row groups kq of a column and the move to the result lanes in one matrix instruction per restart, as in k_fbm; the
+                // additions in front keep the inline-asm accumulators away from the matrix instruction's operands)
+                s0 = __builtin_amdgcn_mfma_f64_4x4x4f64(sel0, acc0[0][0] + acc0[0][1], 0., 0, 0, 0);
+                s1 = __builtin_amdgcn_mfma_f64_4x4x4f64(sel0, acc1[0][0] + acc1[0][1], 0., 0, 0, 0);
+                if constexpr (NV > 1) {
+                    s0 = __builtin_amdgcn_mfma_f64_4x4x4f64(sel1, acc0[1][0] + acc0[1][1], s0, 0, 0, 0);
+                    s1 = __builtin_amdgcn_mfma_f64_4x4x4f64(sel1, acc1[1][0] + acc1[1][1], s1, 0, 0, 0);
+                }
+            }
             FBQ_FINISH(s0, s1, e0, e1, k)
         }
         if (k < len) {
@@ -1476,6 +1573,24 @@ __device__ __forceinline__ void fbq_body(const FbmArgs &a, const double *wk, con
             // Four restarts with four different weights leave an MFMA one useful row in four: these steps run on the vector ALU (as
             // k_fbm's).  Lane (kq, c) owns rows 4 kb + kq of its two columns; restart i's vector element reaches the 16 lanes of the row
             // through the FMA's DPP operand; the four lanes of a column are added at the end in a fixed order.
+            double s0, s1;
+            if constexpr (NV < 4) {
+                double av[NV][G], acc0[NV][2], acc1[NV][2];
+#pragma unroll
+                for (int j = 0; j < NV; j++) {
+                    acc0[j][0] = acc0[j][1] = acc1[j][0] = acc1[j][1] = 0.;
+#pragma unroll
+                    for (int g = 0; g < G; g++) av[j][g] = avp[(size_t)((k - 1) & 1) * vbuf + j * VRP + 64 * g];
+                }
+                fbqw_be<0, KB, NV>::run(av, reinterpret_cast<const char *>(wtab), c0, c1, upl + kq, umul, uoff0, uoff1,
+                                        reinterpret_cast<const char *>(tb) + I0 * 8, acc0, acc1);
+                s0 = __builtin_amdgcn_mfma_f64_4x4x4f64(sel0, acc0[0][0] + acc0[0][1], 0., 0, 0, 0);
+                s1 = __builtin_amdgcn_mfma_f64_4x4x4f64(sel0, acc1[0][0] + acc1[0][1], 0., 0, 0, 0);
+                if constexpr (NV > 1) {
+                    s0 = __builtin_amdgcn_mfma_f64_4x4x4f64(sel1, acc0[1][0] + acc0[1][1], s0, 0, 0, 0);
+                    s1 = __builtin_amdgcn_mfma_f64_4x4x4f64(sel1, acc1[1][0] + acc1[1][1], s1, 0, 0, 0);
+                }
+            } else {
             double acc0[FBM_NV] = {0., 0., 0., 0.}, acc1[FBM_NV] = {0., 0., 0., 0.};
             const fbm_d2 *apc = reinterpret_cast<const fbm_d2 *>(vec + (size_t)((k - 1) & 1) * VR * 4 + (kq * 4 + ib) * 2);     // pair p: + 16 p
             const char *tbb = reinterpret_cast<const char *>(tb);
@@ -1509,8 +1624,9 @@ __device__ __forceinline__ void fbq_body(const FbmArgs &a, const double *wk, con
                 acc0[i] += __shfl_xor(acc0[i], 16); acc0[i] += __shfl_xor(acc0[i], 32);
                 acc1[i] += __shfl_xor(acc1[i], 16); acc1[i] += __shfl_xor(acc1[i], 32);
             }
-            const double s0 = id == 0 ? acc0[0] : (id == 1 ? acc0[1] : (id == 2 ? acc0[2] : acc0[3]));
-            const double s1 = id == 0 ? acc1[0] : (id == 1 ? acc1[1] : (id == 2 ? acc1[2] : acc1[3]));
+            s0 = id == 0 ? acc0[0] : (id == 1 ? acc0[1] : (id == 2 ? acc0[2] : acc0[3]));
+            s1 = id == 0 ? acc1[0] : (id == 1 ? acc1[1] : (id == 2 ? acc1[2] : acc1[3]));
+            }
             FBQ_FINISH(s0, s1, e0, e1, k)
             k++;
         }
@@ -1519,9 +1635,9 @@ __device__ __forceinline__ void fbq_body(const FbmArgs &a, const double *wk, con
 #undef FBQ_FETCH
     if (a.dbg && t == 0 && blockIdx.x == 0 && by == 0 && blockIdx.z == 0) { a.dbg[2] = clock64(); a.dbg[3] = wall_clock64(); }
     if (wave == 0) {
-        const double *vb = vec + (size_t)((len - 1) & 1) * VR * 4;
+        const double *vb = vec + (size_t)((len - 1) & 1) * vbuf;
         double ps = 0.;
-        for (int q = c16; q < S; q += 16) ps += vb[fbm_pos(q, id)];
+        for (int q = c16; q < S; q += 16) ps += vb[NV == 4 ? fbm_pos(q, id) : (id < NV ? id : 0) * VRP + fbw_pos(q)];
         ps = group_sum(ps, 16);
         if (c16 == 0 && present) {
             double m_, inv;
@@ -1532,9 +1648,8 @@ __device__ __forceinline__ void fbq_body(const FbmArgs &a, const double *wk, con
     }
 #undef ROW
 }
-template <int KB>
-__global__ __launch_bounds__(768) void k_fbq(FbmArgs a, const double *wk, const uint32_t *cnpack, const uint32_t *totpack) { fbq_body<KB>(a, wk, cnpack, totpack, blockIdx.y); }
-// one launch over the ranges of two paired batches (see k_fbm2)
+template <int KB, int NV>
+__global__ __launch_bounds__(768) void k_fbq(FbmArgs a, const double *wk, const uint32_t *cnpack, const uint32_t *totpack) { fbq_body<KB, NV>(a, wk, cnpack, totpack, blockIdx.y); }
 
 // =============================================================================
 // k_fbk: forward-backward for state grids whose S x S weight matrix does not fit the register file

@@ -130,11 +130,13 @@ def test_s165_generic_kernel_and_plain_breakend_tables_match_oracle(hip, oracle_
         _compare_after_every_update(dev, ora, sweeps=1)
 
 
-@pytest.mark.parametrize('options,fb', [({}, 4), ({'fb_nv': 4}, 4), ({'fb_kernel': 3, 'fb_nv': 2}, 3), ({'fb_kernel': 3, 'fb_nv': 1}, 3), ({'fb_kernel': 2}, 0), ({'viterbi_plain': 1}, 4), ({'pairwise_kernel': 2}, 4)])
+@pytest.mark.parametrize('options,fb', [({}, 4), ({'fb_nv': 4}, 4), ({'fb_nv': 1}, 4), ({'fb_kernel': 3, 'fb_nv': 2}, 3), ({'fb_kernel': 3, 'fb_nv': 1}, 3), ({'fb_kernel': 2}, 0), ({'viterbi_plain': 1}, 4),
+                                        ({'pairwise_kernel': 2}, 4)])
 def test_s355_matches_oracle(hip, oracle_mod, options, fb):
-    """355 states (max_cn = 12, the "~400 states" of BASELINE's metric): k_fbq (FP64 matrix cores, B operands looked up from 8-bit
-    distances; a quad with two and with four restarts present), k_fbk (vector FMA, weights rebuilt from packed copy numbers), the
-    general kernel on tabulated weights, k_viterbi_code and the plain lattice, each against the oracle -- not against each other."""
+    """355 states (max_cn = 12, the "~400 states" of BASELINE's metric): k_fbq (B operands looked up from 8-bit distances; four restarts per
+    workgroup on the FP64 matrix cores -- a quad with two and with four restarts present -- and one per workgroup on the vector ALU
+    (two per workgroup exist up to 256 states: test_grids_between_the_benchmark_grids_match_oracle)), k_fbk (two-phase vector FMA, weights rebuilt from packed copy numbers), the general kernel on tabulated weights,
+    k_viterbi_code and the plain lattice, each against the oracle -- not against each other."""
     from remixt_amd import synthetic
     R = 4 if options.get('fb_nv') == 4 else (3 if options.get('fb_nv') == 1 else 2)
     e = synthetic.make_experiment(44, num_clones=3, max_copy_number=12, num_chains=2, seed=41, num_breakpoints=8)
@@ -144,20 +146,22 @@ def test_s355_matches_oracle(hip, oracle_mod, options, fb):
     assert dev.batch.num_cn_states == 355 and dev.batch.info(3) >= 16
     _compare_after_every_update(dev, ora)
     assert dev.batch.info(12) == fb, ('forward-backward kernel', dev.batch.info(12), dev.batch.info(13))
+    if fb == 4:
+        assert dev.batch.info(13) == (options.get('fb_nv') or 1)      # (two restarts x two chains x two directions: the automatic choice is one per workgroup)
 
 
-@pytest.mark.parametrize('max_cn,S,R', [(9, 205, 5), (10, 251, 4), (11, 300, 6)])
-def test_grids_between_the_benchmark_grids_match_oracle(hip, oracle_mod, max_cn, S, R):
+@pytest.mark.parametrize('max_cn,S,R,nv', [(9, 205, 5, 4), (10, 251, 4, 4), (11, 300, 6, 4), (9, 205, 5, 2), (10, 251, 3, 1), (11, 300, 6, 0), (11, 300, 5, 1)])
+def test_grids_between_the_benchmark_grids_match_oracle(hip, oracle_mod, max_cn, S, R, nv):
     """k_fbq's other instantiations and ragged shapes: 205 / 251 states (64 k-blocks), 300 states (90 k-blocks, 10 of 12 column
     waves), restart counts that leave the last quad with one or two restarts."""
     from remixt_amd import synthetic
     e = synthetic.make_experiment(40, num_clones=3, max_copy_number=max_cn, num_chains=2, seed=80 + max_cn, num_breakpoints=6)
     e.breakpoints = H.add_shared_boundary_breakpoints(e)
     ps = synthetic.make_init_params(e, R, max_cn)
-    dev, ora = _two_sets(oracle_mod, e, ps, max_cn, 3)
+    dev, ora = _two_sets(oracle_mod, e, ps, max_cn, 3, options={'fb_nv': nv})
     assert dev.batch.num_cn_states == S
     _compare_after_every_update(dev, ora)
-    assert (dev.batch.info(12), dev.batch.info(13)) == (4, 4)
+    assert (dev.batch.info(12), dev.batch.info(13)) == (4, nv or 1)
 
 
 @pytest.mark.parametrize('max_cn', [3, 6])
@@ -474,7 +478,7 @@ def test_kernel_selection_at_the_benchmark_grids(hip):
     # (max_cn, fb_nv, fb_kernel) -> (forward-backward kernel, restarts per workgroup, lattice kernel); 4 restarts x 2 chains x 2 directions
     # leave room for one restart per workgroup, which is what the automatic choice takes at 165 states
     want = {(8, None, 0): (1, 1, 1), (8, 4, 0): (1, 4, 1), (8, 2, 0): (1, 2, 1), (8, 2, 3): (2, 2, 1), (8, 1, 3): (2, 1, 1),
-            (12, None, 0): (4, 4, 2), (12, 2, 3): (3, 2, 2)}
+            (12, None, 0): (4, 1, 2), (12, 4, 0): (4, 4, 2), (12, 2, 0): (4, 4, 2), (12, 2, 3): (3, 2, 2)}
     for (max_cn, nv, fk), (fb, nvx, vit) in want.items():
         e = synthetic.make_experiment(60, num_clones=3, max_copy_number=max_cn, num_chains=2, seed=3, num_breakpoints=4)
         rs = RestartSet(e, synthetic.make_init_params(e, 4, max_cn), max_cn, num_clones=3, quiet=True, options={'fb_nv': nv or 0, 'fb_kernel': fk})

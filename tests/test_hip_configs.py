@@ -175,3 +175,47 @@ def test_config4_two_datasets_at_the_workload(workload):
                 assert np.array_equal(res[1][r]['cn'], sres[r]['cn'])
                 assert all(np.array_equal(res[1][r]['brk_cn'][k], sres[r]['brk_cn'][k]) for k in sres[r]['brk_cn'])
         _release(alone)
+
+
+# ---- the metric string's own configuration: 50 000 segments x 355 states (max_cn = 12, remixt/defaults.py:117) -----------------------------
+@pytest.fixture(scope='module')
+def workload355(hip):
+    from remixt_amd import synthetic
+    e = synthetic.make_experiment(SEG, num_clones=M, max_copy_number=12, num_chains=23, seed=0)
+    return e, synthetic.make_init_params(e, 16, 12, num_clones=M)
+
+
+def test_states355_bench_shape_em_iterations_with_msteps(workload355):
+    """The `states_355` line of the bench at its workload: 16 restarts as two paced restart groups of 8, EM iterations
+    WITH M-steps, 50 000 x 355 -- k_fbq, the sparse pairwise kernel, paced groups.  An EM iteration never lowers a restart's ELBO; every
+    restart's trajectory (ELBO, h, parameters) equals the one-group run's bit for bit; posteriors and breakpoint probabilities are
+    distributions; and the batched decode (k_viterbi_code) equals the plain lattice."""
+    from remixt_amd.restarts import RestartGroups
+    e, p16 = workload355
+    ids = list(range(16))
+    out = {}
+    for groups in (2, 1):
+        rs = RestartGroups(e, p16, 12, groups=groups, num_clones=M, quiet=True, seeds=_seeds(ids), options={'fb_nv': 4})
+        b = rs.batches[0]
+        assert b.num_cn_states == 355 and b.num_segments >= SEG
+        assert rs.paced == (groups == 2)                      # what RestartGroups chooses above 200 states
+        _run(rs, iters=2)
+        assert b.info(12) == 4                                # k_fbq
+        out[groups] = _state(rs)
+        if groups == 2:
+            b = rs.batches[1]
+            for r in (0, 7):
+                post = b.get_array(r, 'posterior_marginals')
+                assert post.shape[1] == 355 and post.min() >= 0. and np.allclose(post.sum(axis=1), 1., rtol=0, atol=1e-12)
+                pb = b.get_array(r, 'p_breakpoint')
+                assert pb.min() >= 0. and np.allclose(pb.sum(axis=1), 1., rtol=0, atol=1e-12)
+            cn_all, lp_all = b.infer_cn_batch(0, 8)
+            assert b.info(14) == 2                            # k_viterbi_code
+            b.set_option('viterbi_plain', 1)
+            for r in (0, 5):
+                cn, lp = b.infer_cn(r)
+                assert b.info(14) == 3 and np.array_equal(cn, cn_all[r]) and lp == lp_all[r]
+            b.set_option('viterbi_plain', 0)
+        _release(rs)
+    for r in ids:
+        assert _same(out[2][r], out[1][r]), ('restart %d: 2 paced groups vs 1 group at 355 states' % r, out[2][r], out[1][r])
