@@ -74,6 +74,7 @@ def parse(argv=None):
     ap.add_argument('--groups', type=int, default=2, help='restart groups per GPU and dataset (own stream + host thread each; results do not depend on it)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-sample-segments', type=int, default=160)
+    ap.add_argument('--cpu-sample-segments-355', type=int, default=40, help='segments of the CPU baseline sample at 355 states (0 = skip)')
     ap.add_argument('--profile-all', action='store_true', help='HIP-event every kernel (default: only the variational-sweep kernels; the M-step objective kernels are ~3000 tiny launches per step)')
     ap.add_argument('--no-extra-states', action='store_true', help='skip the additional 355-state (max_cn = 12) measurement at N = 1')
     ap.add_argument('--no-fit-from-init', action='store_true', help='skip the construct -> 5 EM iterations -> decode wall-clock measurement at N = 1')
@@ -198,6 +199,28 @@ def cpu_leg(args):
     if multi:
         out['all_cores'] = {'value': multi['value'], 'unit': 'EM iterations/s', 'cores': multi['cores'],
                             'sample': 'the same sample, one restart per core on %d cores at once (%.1f s wall)' % (multi['cores'], multi['wall_s'])}
+    if args.max_cn == 8 and args.cpu_sample_segments_355 > 0:
+        # the 355-state configuration of the metric string (max_cn = 12, remixt/defaults.py:117): its own sample (the dense S x S work per
+        # segment is 4.6 x the 165-state grid's), one core and one restart per core
+        ns5 = args.cpu_sample_segments_355
+        job5 = (ns5, args.clones, 12, args.update_iters)
+        scale5 = float(args.segments) / float(ns5)
+        ft5 = lambda r: (r['total_s'] - r['sample_s']) * scale5 + r['sample_s'] * (float(full_sample) / max(1, r['sample_size']))
+        if cores > 1:
+            ctx = mp.get_context('fork')
+            t0 = time.perf_counter()
+            with ctx.Pool(cores) as pool:
+                rs5 = pool.map(_cpu_one, [job5 + (i,) for i in range(cores)])
+            wall5 = time.perf_counter() - t0
+        else:
+            t0 = time.perf_counter(); rs5 = [_cpu_one(job5 + (0,))]; wall5 = time.perf_counter() - t0
+        one5 = rs5[0]
+        out['states_355'] = {'value': 1.0 / ft5(one5), 'unit': 'EM iterations/s', 'cores': 1, 'kind': 'port',
+                             'sample': 'one EM iteration of one restart of oracle/remixt_oracle.c on %d segments (%d after breakend remap) x %d states: %.2f s (timed with '
+                                       'one restart on each of %d cores at once, %.1f s wall); scaled to %d segments (linear part x %.0f)'
+                                       % (ns5, one5['N1'], one5['S'], one5['total_s'], len(rs5), wall5, args.segments, scale5),
+                             'seconds_per_em_iteration_full_size': ft5(one5),
+                             'all_cores': {'value': len(rs5) / max(ft5(r) for r in rs5), 'unit': 'EM iterations/s', 'cores': len(rs5)}}
     print('CPU_LEG ' + json.dumps(out), flush=True)
 
 
@@ -205,7 +228,8 @@ def cpu_baseline(args):
     """Run the CPU leg as a child process (no GPU in it) and attach the port-vs-reference calibration measured in
     the build container by oracle/calibrate.py (the reference itself never travels to the GPU box)."""
     cmd = [sys.executable, os.path.abspath(__file__), '--cpu-leg', '--segments', str(args.segments), '--clones', str(args.clones),
-           '--max-cn', str(args.max_cn), '--update-iters', str(args.update_iters), '--cpu-sample-segments', str(args.cpu_sample_segments)]
+           '--max-cn', str(args.max_cn), '--update-iters', str(args.update_iters), '--cpu-sample-segments', str(args.cpu_sample_segments),
+           '--cpu-sample-segments-355', str(0 if args.no_extra_states else args.cpu_sample_segments_355)]
     env = dict(os.environ, OMP_NUM_THREADS='1', OPENBLAS_NUM_THREADS='1', MKL_NUM_THREADS='1')
     try:
         res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
@@ -221,6 +245,9 @@ def cpu_baseline(args):
                               'note': 'compiled reference kernel (remixt/bpmodel.pyx) vs this port on the same sample in the build container; '
                                       'reference-equivalent value = value x this ratio'}
         out['reference_equivalent_value'] = out['value'] * cal['port_over_reference']
+        if isinstance(out.get('states_355'), dict):
+            out['states_355']['reference_equivalent_value'] = out['states_355']['value'] * cal['port_over_reference']
+            out['states_355']['calibration_note'] = 'the ratio port / reference was measured at 165 states (profiles/cpu_calibration.json); both are dominated by the same dense S x S loops'
     except Exception:
         out['calibration'] = None
     return out
@@ -479,8 +506,16 @@ def main(argv=None, kernel_module=None, dist_backend='nccl', script=None):
                 line['strong_scaling_proxy'] = strong_scaling_proxy(args, rs, device)
             except Exception as err:
                 line['strong_scaling_proxy'] = {'error': str(err)}
+        if single and not args.no_extra_states and args.max_cn == 8:
+            try:
+                line['unequal_chains'] = unequal_chains(args, rs, device, line['value'])
+            except Exception as err:
+                line['unequal_chains'] = {'error': str(err)}
         if cpu is not None:
+            cpu355 = cpu.pop('states_355', None) if isinstance(cpu, dict) else None
             line['cpu_baseline'] = cpu
+            if cpu355 is not None and isinstance(line.get('states_355'), dict):
+                line['states_355']['cpu_baseline'] = cpu355
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()
@@ -592,13 +627,13 @@ def one_group_roofline(args, rs_main, device, traffic_file='traffic_r03_16.json'
     return out
 
 
-def _timed_run(args, device, restarts, groups, max_cn, nsteps, warm, seeds_base=1000):
+def _timed_run(args, device, restarts, groups, max_cn, nsteps, warm, seeds_base=1000, chain_fractions=None):
     """Build `restarts` restarts of the headline experiment (at max_cn) in `groups` restart groups, run `warm` untimed and
     `nsteps` timed EM iterations with HIP-event kernel times: (rs, S, N1, seconds, elbo, profile)."""
     import torch
     from remixt_amd import synthetic
     from remixt_amd.restarts import RestartGroups
-    e = synthetic.make_experiment(args.segments, num_clones=args.clones, max_copy_number=max_cn, num_chains=23, seed=0)
+    e = synthetic.make_experiment(args.segments, num_clones=args.clones, max_copy_number=max_cn, num_chains=23, seed=0, chain_fractions=chain_fractions)
     params = synthetic.make_init_params(e, restarts, max_cn, num_clones=args.clones)
     rs = RestartGroups(e, params, max_cn, groups=groups, num_clones=args.clones, device=device, quiet=True, seeds=[seeds_base + i for i in range(restarts)])
     b = rs.batches[0]
@@ -623,7 +658,7 @@ def extra_states(args, rs_main, device):
     BASELINE.json's metric string is quoted on), everything else as the headline workload; 20 timed steps like the headline."""
     _release(rs_main)
     max_cn, R, nsteps = 12, args.restarts, 20
-    # two restart groups, paced (RestartGroups pair_fb 'auto' above 200 states): 144 EM iterations/s against 134 for one group of 16 and 118
+    # two restart groups, paced (RestartGroups paced='auto' above 200 states): 144 EM iterations/s against 134 for one group of 16 and 118
     # for two free-running groups (tools/s355_groups.sh)
     G355 = 2
     rs, S, N1, dt, elbo, prof = _timed_run(args, device, R, G355, max_cn, nsteps, 2)
@@ -642,6 +677,28 @@ def extra_states(args, rs_main, device):
         out['roofline_one_group'] = one_group_roofline(a355, None, device, traffic_file='traffic_r03_s355.json', nsteps=3)
     except Exception as err:
         out['roofline_one_group'] = {'error': str(err)}
+    return out
+
+
+def unequal_chains(args, rs_main, device, headline_value):
+    """The headline workload on chains in the proportions of a genome's chromosomes (GRCh37 lengths of 1 .. 22, X: 5 : 1) instead of 23 equal
+    chains (the reference cuts chains at gaps, remixt/analysis/experiment.py:124-143): same segments, states, restarts,
+    restart groups and step definition.  A forward-backward launch lasts as long as its slowest chain; k_fbm gives a long chain fewer
+    restarts per workgroup (shorter steps) than a short one (rmx_api.hip fb_items_for)."""
+    from remixt_amd import synthetic
+    _release(rs_main)
+    nsteps = 10
+    rs, S, N1, dt, elbo, prof = _timed_run(args, device, args.restarts, args.groups, args.max_cn, nsteps, 2, chain_fractions=synthetic.HUMAN_CHROMOSOME_MB)
+    fb = prof.get('k_fb', (0., 1))
+    b = rs.batches[0]
+    lens = sorted(int(round(f / float(sum(synthetic.HUMAN_CHROMOSOME_MB)) * args.segments)) for f in synthetic.HUMAN_CHROMOSOME_MB)
+    out = {'workload': '%d segments in 23 chains proportional to the human chromosomes (longest %d, shortest %d segments; the headline has 23 x %d), %d states, %d restarts, %d restart groups'
+                       % (args.segments, lens[-1], lens[0], args.segments // 23, S, args.restarts, args.groups),
+           'value': args.restarts * nsteps / dt, 'unit': 'EM iterations/s', 'ms_per_step': dt / nsteps * 1e3, 'steps': nsteps, 'warmup': 2,
+           'fb_avg_launch_ms': fb[0] / max(fb[1], 1), 'fb_restarts_per_workgroup': [b.info(13), b.info(15)],
+           'ratio_to_headline': (args.restarts * nsteps / dt) / headline_value if headline_value else None,
+           'elbo_best': float(np.nanmax(elbo))}
+    _release(rs)
     return out
 
 
@@ -704,8 +761,9 @@ def strong_scaling_proxy(args, rs_main, device):
             'one_rank_share_8_restarts': {'value': its8, 'unit': 'EM iterations/s', 'ms_per_step': dt8 / nsteps * 1e3, 'restart_groups': args.groups,
                                           'fb_avg_launch_ms': fb8[0] / max(fb8[1], 1), 'fb_restarts_per_launch': 8 // max(1, args.groups)},
             'predicted_speedup_8_gpus_over_1': 8. * its8 / its64, 'target': 6.0,
-            'note': 'a forward-backward launch takes the same time for 4, 8 or 16 restarts (a chain of 2 173 dependent steps per chromosome): one GPU '
-                    'amortises that latency over 64 restarts, a rank holding 8 cannot'}
+            'note': 'a forward-backward launch is a chain of 2 173 dependent steps per chromosome: with 16 restarts per launch a workgroup carries four restarts on the '
+                    'matrix cores (2.8 ms), a rank\'s 4-restart launches carry one per workgroup on the vector ALU (1.5 ms) -- shorter, but not four times shorter: one '
+                    'GPU amortises the chain over 64 restarts, a rank holding 8 cannot'}
 
 
 if __name__ == '__main__':

@@ -126,7 +126,8 @@ int rmx_synchronize(rmx_batch *b);
  * forward-backward kernels / on the general one; 12 the forward-backward kernel the last update_p_cn launched for the
  * former (1 k_fbm: FP64 matrix cores at 4 restarts per workgroup, vector FMA at 2 / 1; 2 k_fbv: two-phase vector FMA, 3 k_fbk: weights from packed copy numbers, 4 k_fbq: matrix cores with
  * weights from 8-bit codes; 0: general kernel k_fb<0> only), 13 restarts per workgroup of that launch, 14 the lattice kernel of
- * the last decode (1 k_viterbi_reg, 2 k_viterbi_code, 3 k_viterbi) */
+ * the last decode (1 k_viterbi_reg, 2 k_viterbi_code, 3 k_viterbi); 15 the largest number of restarts per workgroup of that launch (13 is the
+ * smallest: k_fbm gives long chains fewer restarts per workgroup than short ones) */
 int rmx_info(rmx_batch *b, int32_t what, int64_t *out);
 /* -- tuning options ------------------------------------------------------- */
 /* Not part of the reference protocol: which of this library's equivalent kernels / launch shapes run.  Results do not
@@ -155,6 +156,8 @@ enum rmx_option_id {
     RMX_OPT_PACE_SWEEPS,        /* 1: rmx_variational_update reaches each sweep's forward-backward point only after the previous sweep's
                                    forward-backward launch has finished on the device, instead of queueing all its sweeps at once; for restart groups that share a GPU -- at 355 states two paced groups of 8
                                    make 144 EM iterations/s, free-running ones 118 */
+    RMX_OPT_FB_WG_BUDGET,       /* workgroups a forward-backward launch may have side by side when the shapes of its chains are chosen (0: 256, one per CU
+                                   of an MI355X): tests set a small number to put a small problem on the mixed shapes a genome gets */
     RMX_OPT_COUNT
 };
 int rmx_set_default_option(int32_t option_id, int32_t value);

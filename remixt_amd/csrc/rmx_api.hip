@@ -47,7 +47,7 @@ static const char *kKernelNames[KID_COUNT] = {
 struct ProfRec { int id; hipEvent_t a, b; };
 
 // tuning options (include/remixt_amd.h rmx_option_id): process-wide defaults, copied into a batch at creation
-static int g_opt_default[RMX_OPT_COUNT] = {0, 0, 1, 1, 1, 0, 0, 0, 1, 1, 1, 0, 0, 0};
+static int g_opt_default[RMX_OPT_COUNT] = {0, 0, 1, 1, 1, 0, 0, 0, 1, 1, 1, 0, 0, 0, 0};
 static std::mutex g_opt_mu;
 
 struct rmx_batch {
@@ -111,8 +111,11 @@ struct rmx_batch {
     // FB launch configuration
     FbLaunch fbG{}; size_t fbG_lds = 0;   // generic kernel configuration
     int n_fast = 0, n_generic = 0;
+    std::vector<int32_t> h_list_fast, h_chain_len;       // chains on the register-resident kernels; segments of every chain
+    struct FbItems { int n = 0; int4 *dev = nullptr; int nv_min = 4, nv_max = 1; };
+    std::map<std::tuple<int, int, int>, FbItems> fb_items;   // work-item tables of k_fbm launches by (r0, r1, pinned restarts per workgroup)
     // which kernels the last update_p_cn / decode launched (rmx_info 12..14; tests assert the shape they mean to cover)
-    int last_fb_kernel = 0, last_fb_nv = 0, last_viterbi = 0;
+    int last_fb_kernel = 0, last_fb_nv = 0, last_fb_nv_max = 0, last_viterbi = 0;
     // host-side stage clocks of the batched sampled-objective rounds (rmx_info 60..63): ns spent preparing + launching, ns waiting for the
     // device, ns after the wait, rounds
     long long t_launch_ns = 0, t_wait_ns = 0, t_post_ns = 0, n_rounds = 0;
@@ -670,6 +673,7 @@ static bool option_value_ok(int id, int v) {
     case RMX_OPT_FB_NV: return v == 0 || v == 1 || v == 2 || v == 4;      // the workgroup shapes that exist (k_fbm and k_fbv / k_fbk 1 / 2 / 4, k_fbq 4)
     case RMX_OPT_SEARCH_MODE: return v >= 0 && v <= 4;
     case RMX_OPT_PAIRWISE_KERNEL: return v >= 0 && v <= 3;
+    case RMX_OPT_FB_WG_BUDGET: return v >= 0 && v <= 4096;
     default: return v == 0 || v == 1;
     }
 }
@@ -812,6 +816,9 @@ int rmx_batch_create(const rmx_problem *pr, int32_t R, const double *h_init, con
     for (int c = 0; c < d.NC; c++) b->be_cap = std::max(b->be_cap, (int)(chain_be[2 * c + 1] - chain_be[2 * c]) + 4);
     for (int s_ = 0; s_ < d.NBE; s_++) { be_cls[2 * s_] = b->seg_class[b->be_n[s_]]; be_cls[2 * s_ + 1] = b->seg_class[b->be_n[s_] + 1]; }
     b->n_fast = (int)list_fast.size(); b->n_generic = (int)list_gen.size();
+    b->h_list_fast.assign(list_fast.begin(), list_fast.end());
+    b->h_chain_len.resize(d.NC);
+    for (int c = 0; c < d.NC; c++) b->h_chain_len[c] = cend[c] - cstart[c] + 1;
     if (d.TC > 4096) { delete b; return fail(RMX_EUNSUPPORTED, "too many transition classes"); }
     std::vector<int32_t> bk_ptr(K + 1, 0), bk_slots(d.NBE);
     for (int s = 0; s < d.NBE; s++) bk_ptr[b->brk_idx[b->be_n[s]] + 1]++;
@@ -987,7 +994,7 @@ int rmx_info(rmx_batch *b, int32_t what, int64_t *out) { BIND(b);
     case 4: *out = b->d.SP; break; case 5: *out = b->fbv_rpt; break; case 6: *out = b->fbG.P; break; case 7: *out = b->fbG.NT; break;
     case 8: *out = b->fbG.BLK; break; case 9: *out = (int64_t)b->fbG_lds; break; case 10: *out = b->n_fast; break; case 11: *out = b->n_generic; break;
     case 60: *out = b->t_launch_ns; break; case 61: *out = b->t_wait_ns; break; case 62: *out = b->t_post_ns; break; case 63: *out = b->n_rounds; break;
-    case 12: *out = b->last_fb_kernel; break; case 13: *out = b->last_fb_nv; break; case 14: *out = b->last_viterbi; break;
+    case 12: *out = b->last_fb_kernel; break; case 13: *out = b->last_fb_nv; break; case 14: *out = b->last_viterbi; break; case 15: *out = b->last_fb_nv_max; break;
     case 20: case 21: case 22: case 23: case 24: case 25: case 26: case 27: case 28: case 29: case 30: case 31: case 32: case 33: case 34: case 35: case 36: case 37: case 38: case 39:
     case 40: case 41: case 42: case 43: case 44: case 45: case 46: case 47: case 48: case 49: case 50: case 51:
         { if (!b->d_dbg) { *out = 0; break; } unsigned long long v[32]; HIPCHK(hipStreamSynchronize(b->stream)); HIPCHK(hipMemcpy(v, b->d_dbg, 256, hipMemcpyDeviceToHost)); *out = (int64_t)v[what - 20]; break; }
@@ -1242,15 +1249,60 @@ static int do_framelogprob(rmx_batch *b, int r0, int r1) {
 // (2) -- and update_p_breakpoint behind it -- on a second stream next to (3).
 // workgroups of a forward-backward launch that run side by side (one per CU: the weights fill the register file)
 static const int g_fb_wg_budget = 256;
-#define FBM_KERNEL_CASE(NV_) switch (KB) { case 8: return k_fbm<8, NV_>; case 16: return k_fbm<16, NV_>; case 28: return k_fbm<28, NV_>; \
-                                           case 36: return k_fbm<36, NV_>; case 42: return k_fbm<42, NV_>; case 44: return k_fbm<44, NV_>; } return nullptr;
-static void (*fbm_kernel_for(int KB, int NV))(FbmArgs) {
-    if (NV == 4) { FBM_KERNEL_CASE(4) }
-    if (NV == 2) { FBM_KERNEL_CASE(2) }
-    if (NV == 1) { FBM_KERNEL_CASE(1) }
+static inline int fb_wg_budget(const rmx_batch *b) { return b->opt[RMX_OPT_FB_WG_BUDGET] > 0 ? b->opt[RMX_OPT_FB_WG_BUDGET] : g_fb_wg_budget; }
+static void (*fbm_kernel_for(int KB))(FbmArgs) {
+    switch (KB) { case 8: return k_fbm<8>; case 16: return k_fbm<16>; case 28: return k_fbm<28>; case 36: return k_fbm<36>; case 42: return k_fbm<42>; case 44: return k_fbm<44>; }
     return nullptr;
 }
-#undef FBM_KERNEL_CASE
+// The workgroups of a k_fbm launch over restarts [r0, r1): per chain a shape -- 4 restarts per workgroup on the matrix cores, 2 or 1 on the vector
+// ALU -- and per (chain, unit of that many restarts, direction) one work item.  A launch is a bundle of independent chains of dependent steps and
+// lasts as long as its slowest workgroup; a step costs about 1 500 / 2 110 / 2 845 cycles with 1 / 2 / 4 restarts per workgroup (fb_launch_shapes),
+// and a workgroup fills a CU.  So: the smallest T for which every chain has a shape with (segments x step cost) <= T while all workgroups together fit
+// the chip at once, and for every chain the LARGEST such shape (fewest CUs).  Equal chains get one shape (23 chains x 8 restarts: two per
+// workgroup, 184 workgroups); chromosomes of a real genome (lengths 5 : 1) get one restart per workgroup on the long ones and four on the
+// short ones.  `pin` (option fb_nv) fixes the shape of every chain.  Items are ordered longest first.
+static int fb_items_for(rmx_batch *b, int r0, int r1, int pin, rmx_batch::FbItems **out) {
+    auto key = std::make_tuple(r0, r1, pin * 4096 + fb_wg_budget(b));
+    auto it = b->fb_items.find(key);
+    if (it != b->fb_items.end()) { *out = &it->second; return RMX_OK; }
+    static const double cost[5] = {0., 1500., 2110., 0., 2845.};
+    static const int shapes[3] = {4, 2, 1};
+    const int nc = (int)b->h_list_fast.size();
+    auto units = [&](int nv) { return (r1 - 1) / nv - r0 / nv + 1; };
+    std::vector<int> nv_of(nc, 4);
+    if (pin == 1 || pin == 2 || pin == 4) std::fill(nv_of.begin(), nv_of.end(), pin);
+    else {
+        std::vector<double> cand;
+        for (int c = 0; c < nc; c++) for (int nv : shapes) cand.push_back(b->h_chain_len[b->h_list_fast[c]] * cost[nv]);
+        std::sort(cand.begin(), cand.end());
+        for (double T : cand) {
+            long wg = 0; bool ok = true;
+            for (int c = 0; c < nc && ok; c++) {
+                int pick = 0;
+                for (int nv : shapes) if (b->h_chain_len[b->h_list_fast[c]] * cost[nv] <= T) { pick = nv; break; }      // largest shape within T
+                if (!pick) ok = false; else { nv_of[c] = pick; wg += 2L * units(pick); }
+            }
+            if (ok && wg <= fb_wg_budget(b)) break;
+            std::fill(nv_of.begin(), nv_of.end(), 4);      // (no T fits the chip in one round: four per workgroup everywhere)
+        }
+    }
+    std::vector<int> order(nc);
+    for (int c = 0; c < nc; c++) order[c] = c;
+    std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return b->h_chain_len[b->h_list_fast[x]] * cost[nv_of[x]] > b->h_chain_len[b->h_list_fast[y]] * cost[nv_of[y]]; });
+    std::vector<int4> items;
+    rmx_batch::FbItems f;
+    for (int c : order) {
+        const int nv = nv_of[c];
+        f.nv_min = std::min(f.nv_min, nv); f.nv_max = std::max(f.nv_max, nv);
+        for (int u = r0 / nv; u <= (r1 - 1) / nv; u++) for (int dir = 0; dir < 2; dir++) items.push_back(make_int4(b->h_list_fast[c], u * nv, nv, dir));
+    }
+    f.n = (int)items.size();
+    int rc = dalloc(b, &f.dev, items.size());
+    if (rc) return rc;
+    HIPCHK(hipMemcpy(f.dev, items.data(), items.size() * sizeof(int4), hipMemcpyHostToDevice));
+    *out = &(b->fb_items[key] = f);
+    return RMX_OK;
+}
 static int p_cn_front(rmx_batch *b, int r0, int r1, bool skip_frame, bool snapshot_done = false) {
     int rc = skip_frame ? ensure_tables(b, r0, r1) : do_framelogprob(b, r0, r1);
     if (rc) return rc;
@@ -1278,10 +1330,8 @@ static int p_cn_front(rmx_batch *b, int r0, int r1, bool skip_frame, bool snapsh
             int KB = 0;
             for (int v : {8, 16, 28, 36, 42, 44}) if (4 * v >= d.S) { KB = v; break; }
             const int NCT = (d.S + 14) / 15;                          // waves: 15 state columns + the ones column each
-            auto units = [&](int nv) { return (r1 - 1) / nv - r0 / nv + 1; };      // absolute units of nv restarts that [r0, r1) touches
-            int NV = 4;
-            if (b->opt[RMX_OPT_FB_NV] == 1 || b->opt[RMX_OPT_FB_NV] == 2 || b->opt[RMX_OPT_FB_NV] == 4) NV = b->opt[RMX_OPT_FB_NV];
-            else { for (int nv : {2, 1}) if ((long)b->n_fast * 2 * units(nv) <= g_fb_wg_budget) NV = nv; }
+            rmx_batch::FbItems *items = nullptr;
+            if ((rc = fb_items_for(b, r0, r1, b->opt[RMX_OPT_FB_NV], &items))) return rc;
             FbmArgs m;
             memset(&m, 0, sizeof m);
             m.S = d.S; m.SP = d.SP; m.M = d.M; m.D = d.D; m.C = d.C; m.N = d.N; m.NBE = d.NBE; m.cn_max = d.cn_max; m.r0 = r0; m.r1 = r1;
@@ -1291,11 +1341,12 @@ static int p_cn_front(rmx_batch *b, int r0, int r1, bool skip_frame, bool snapsh
             m.be_n = d.be_n; m.chain_be = d.chain_be; m.fe = d.fe; m.Wf = d.Wf; m.Wb = d.Wb; m.pe2_lt = d.pe2x_lt; m.af = d.af; m.ab = d.ab; m.tot = d.tot;
             m.fa = d.fa; m.fb = d.fb; m.mrow = d.mrow; m.err = d.err; m.dbg = b->d_dbg;
             const size_t lds = (size_t)2 * m.VR * 4 * 8 + (size_t)2 * 4 * m.PE2P * 8 + (size_t)6 * m.PE2P * 8 + 64 * 8 + (size_t)(KB / 2) * 4 * m.SPC * 4 + (size_t)b->be_cap * 4 + 64;
-            void (*kf)(FbmArgs) = fbm_kernel_for(KB, NV);
+            m.items = items->dev;
+            void (*kf)(FbmArgs) = fbm_kernel_for(KB);
             if (kf && NCT <= 12 && lds <= kLdsBudget) {
                 HIPCHK(hipFuncSetAttribute((const void *)kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-                hipLaunchKernelGGL(kf, dim3(b->n_fast, units(NV), 2), dim3(64 * NCT), lds, b->stream, m);
-                done_fast = true; fast = true; b->last_fb_kernel = 1; b->last_fb_nv = NV;
+                hipLaunchKernelGGL(kf, dim3(items->n), dim3(64 * NCT), lds, b->stream, m);
+                done_fast = true; fast = true; b->last_fb_kernel = 1; b->last_fb_nv = items->nv_min; b->last_fb_nv_max = items->nv_max;
             }
         }
         if (!done_fast && b->fbv_rpt > 0 && b->n_fast > 0) {
@@ -1354,10 +1405,10 @@ static int p_cn_front(rmx_batch *b, int r0, int r1, bool skip_frame, bool snapsh
             auto units = [&](int nv) { return (r1 - 1) / nv - r0 / nv + 1; };      // absolute units of nv restarts that [r0, r1) touches
             int NV = 4;                                                             // (as for k_fbm: two / one per workgroup on the vector ALU where the chip has room)
             if (b->opt[RMX_OPT_FB_NV] == 1 || b->opt[RMX_OPT_FB_NV] == 2 || b->opt[RMX_OPT_FB_NV] == 4) NV = b->opt[RMX_OPT_FB_NV];
-            else { for (int nv : {2, 1}) if ((long)b->n_fast * 2 * units(nv) <= g_fb_wg_budget) NV = nv; }
+            else { for (int nv : {2, 1}) if ((long)b->n_fast * 2 * units(nv) <= fb_wg_budget(b)) NV = nv; }
             // above 256 states (90 k-blocks) two restarts per workgroup do not fit the register file next to the 90 address registers (measured: spills,
             // 12 200 cycles per step against 13 500 with four): one per workgroup where that fits the chip, else four
-            if (KB == 90 && NV == 2) NV = (b->opt[RMX_OPT_FB_NV] == 0 && (long)b->n_fast * 2 * units(1) <= g_fb_wg_budget) ? 1 : 4;
+            if (KB == 90 && NV == 2) NV = (b->opt[RMX_OPT_FB_NV] == 0 && (long)b->n_fast * 2 * units(1) <= fb_wg_budget(b)) ? 1 : 4;
             FbmArgs m;
             memset(&m, 0, sizeof m);
             m.S = d.S; m.SP = d.SP; m.M = d.M; m.D = d.D; m.C = d.C; m.N = d.N; m.NBE = d.NBE; m.cn_max = d.cn_max; m.r0 = r0; m.r1 = r1;

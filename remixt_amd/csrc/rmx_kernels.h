@@ -814,6 +814,7 @@ struct FbmArgs {
     double *fa, *fb, *mrow;
     uint32_t *err;
     unsigned long long *dbg;
+    const int4 *items;      // k_fbm: one workgroup each -- {chain, first restart of the unit, restarts per workgroup (1 / 2 / 4), direction}
 };
 // maximum over the 16 lanes of a DPP row (every lane of the row gets it)
 __device__ __forceinline__ unsigned row_max_u32(unsigned v) {
@@ -893,16 +894,15 @@ template <int P, int KB, int NV> struct fbw_be {
     }
 };
 
-// by: the workgroup's row of restart units (NV restarts each) inside a's range (blockIdx.y)
+// one workgroup: chain `chain`, direction `dir`, the unit of NV restarts that starts at restart `rg0` (a multiple of NV)
 template <int KB, int NV>
-__device__ __forceinline__ void fbm_body(const FbmArgs &a, const int by) {
+__device__ __forceinline__ void fbm_body(const FbmArgs &a, const int chain, const int rg0, const int dir) {
     extern __shared__ __align__(16) unsigned char smem_raw[];
     static_assert(KB % 2 == 0 && KB / 2 >= FBM_DEPTH, "k-blocks come in pairs; ring no deeper than the chain");
-    const int chain = a.chain_list[blockIdx.x], dir = blockIdx.z;
     static_assert(NV == 1 || NV == 2 || NV == 4, "restarts per workgroup");
     // restarts in absolute units of NV (NV u .. NV u + NV - 1) inside absolute quads (4 g .. 4 g + 3: the interleave of the breakend
     // tables); of a unit, those inside [r0, r1).  The unit's restarts take slots 0 .. NV - 1 of the vector image.
-    const int unit = a.r0 / NV + by, rg0 = unit * NV, quad = rg0 >> 2, I0 = rg0 & 3;
+    const int quad = rg0 >> 2, I0 = rg0 & 3;
     const int v_lo = max(a.r0 - rg0, 0), v_hi = min(a.r1 - rg0, NV);          // present: v_lo <= i < v_hi
     const int S = a.S, SP = a.SP, M = a.M, D = a.D, VR = a.VR, SPC = a.SPC;
     const int n0 = a.chain_start[chain], n1 = a.chain_end[chain], len = n1 - n0 + 1;
@@ -1009,7 +1009,7 @@ __device__ __forceinline__ void fbm_body(const FbmArgs &a, const int by) {
         if (mine) *vput = live ? e0 : 0.;
     }
     FB_BARRIER();
-    if (a.dbg && t == 0 && blockIdx.x == 0 && by == 0 && blockIdx.z == 0) { a.dbg[0] = clock64(); a.dbg[1] = wall_clock64(); a.dbg[4] = len; }
+    if (a.dbg && t == 0 && blockIdx.x == 0) { a.dbg[0] = clock64(); a.dbg[1] = wall_clock64(); a.dbg[4] = len; }
     // the tail of a step, common to plain and breakend steps: `sum` = this lane's product (lane 15 of every DPP row: the
     // sum of the previous row, from the ones column, whose power of two is this step's scale -- broadcast inside the
     // row, no LDS, no reduction)
@@ -1197,7 +1197,7 @@ __device__ __forceinline__ void fbm_body(const FbmArgs &a, const int by) {
             FBM_FINISH(sum, e, k)
             FB_STAMP(3)
 #ifdef RMX_FB_STAMPS
-            if (a.dbg && blockIdx.x == 0 && by == 0 && blockIdx.z == 0 && lane == 0 && (wave & 3) == 0) { for (int i = 0; i < 4; i++) a.dbg[8 + (wave >> 2) * 6 + i] += stamp_acc[i]; if (wave == 0) a.dbg[5] += 1; }
+            if (a.dbg && blockIdx.x == 0 && lane == 0 && (wave & 3) == 0) { for (int i = 0; i < 4; i++) a.dbg[8 + (wave >> 2) * 6 + i] += stamp_acc[i]; if (wave == 0) a.dbg[5] += 1; }
 #endif
             k++;
         }
@@ -1206,13 +1206,13 @@ __device__ __forceinline__ void fbm_body(const FbmArgs &a, const int by) {
 #undef FBM_FETCH
 #undef FBM_EGET
 #ifdef RMX_FB_PSTAMPS
-    if (a.dbg && blockIdx.x == 0 && by == 0 && blockIdx.z == 0 && lane == 0) {
+    if (a.dbg && blockIdx.x == 0 && lane == 0) {
         const int slot = wave == 0 ? 0 : (wave == 4 ? 1 : (wave == 8 ? 2 : (wave == 3 ? 3 : (wave == 7 ? 4 : (wave == NW - 1 ? 5 : -1)))));
         if (slot >= 0) for (int i = 0; i < 3; i++) a.dbg[8 + slot * 3 + i] = pst_acc[i];
     }
 #endif
 #undef PST
-    if (a.dbg && t == 0 && blockIdx.x == 0 && by == 0 && blockIdx.z == 0) { a.dbg[2] = clock64(); a.dbg[3] = wall_clock64(); }
+    if (a.dbg && t == 0 && blockIdx.x == 0) { a.dbg[2] = clock64(); a.dbg[3] = wall_clock64(); }
     // last row of each chain: its scale is not consumed by a later step, but the vanishing-row check needs the row's sum
     if (wave == 0) {
         const double *vb = vec + (size_t)((len - 1) & 1) * vbuf;
@@ -1229,8 +1229,16 @@ __device__ __forceinline__ void fbm_body(const FbmArgs &a, const int by) {
 #undef ROW
 #undef ADJ
 }
-template <int KB, int NV>
-__global__ __launch_bounds__(768) void k_fbm(FbmArgs a) { fbm_body<KB, NV>(a, blockIdx.y); }
+// grid (work items): every workgroup takes its chain, unit of restarts and direction from a.items -- and with them its SHAPE: the host gives a
+// long chain fewer restarts per workgroup (shorter steps) than a short one, so that the workgroups of a launch end together (rmx_api.hip
+// fb_items).  The three shapes are three bodies in one kernel; a workgroup runs one of them from start to end.
+template <int KB>
+__global__ __launch_bounds__(768) void k_fbm(FbmArgs a) {
+    const int4 it = a.items[blockIdx.x];
+    if (it.z == 4) fbm_body<KB, 4>(a, it.x, it.y, it.w);
+    else if (it.z == 2) fbm_body<KB, 2>(a, it.x, it.y, it.w);
+    else fbm_body<KB, 1>(a, it.x, it.y, it.w);
+}
 
 // =============================================================================
 // k_fbq: the matrix-core forward-backward kernel for state grids whose S x S weights do not fit the register file

@@ -73,12 +73,26 @@ def _true_copy_number(rng, N, M, max_cn, chain_of):
     return cn
 
 
+# lengths of the chromosomes 1 .. 22, X of the human genome in Mb (GRCh37): the proportions of the chains a real genome gives (5 : 1)
+HUMAN_CHROMOSOME_MB = (249, 243, 198, 191, 181, 171, 159, 146, 141, 136, 135, 134, 115, 107, 103, 90, 81, 78, 59, 63, 48, 51, 155)
+
+
 def make_experiment(num_segments, num_clones=3, max_copy_number=8, num_chains=23, seed=0,
-                    h_total=0.1, num_breakpoints=None):
+                    h_total=0.1, num_breakpoints=None, chain_fractions=None):
+    """`chain_fractions`: relative lengths of the chains (default: equal chains; HUMAN_CHROMOSOME_MB: the chromosomes
+    of a genome).  The random draws do not depend on it."""
     rng = np.random.default_rng(seed)
     N, M = int(num_segments), int(num_clones)
     num_chains = max(1, min(num_chains, N // 2))
-    bounds = np.linspace(0, N, num_chains + 1).astype(int)
+    if chain_fractions is not None:
+        fr = np.asarray(chain_fractions, dtype=float)[:num_chains]
+        num_chains = len(fr)
+        bounds = np.concatenate([[0], np.round(np.cumsum(fr) / fr.sum() * N)]).astype(int)
+        for c in range(1, num_chains + 1):      # at least two segments per chain
+            bounds[c] = max(bounds[c], bounds[c - 1] + 2)
+        bounds[-1] = N
+    else:
+        bounds = np.linspace(0, N, num_chains + 1).astype(int)
     chain_of = np.zeros(N, dtype=int)
     for c in range(num_chains):
         chain_of[bounds[c]:bounds[c + 1]] = c

@@ -90,6 +90,29 @@ def test_s165_restart_batch_with_dense_breakends_matches_oracle(hip, oracle_mod,
     assert (b.info(12), b.info(13)) == ((2, 2) if two_phase else (1, NV or 1))                     # k_fbv<., 2> / k_fbm<., NV> (3 restarts x 2 chains x 2 directions: one per workgroup)
 
 
+def test_s165_unequal_chains_get_mixed_workgroup_shapes_and_match_oracle(hip, oracle_mod):
+    """Chains of unequal length (chromosomes): k_fbm gives the long chains fewer restarts per workgroup than the short ones, all shapes in
+    ONE launch (rmx_api.hip fb_items_for).  A workgroup budget of 40 puts this small problem (5 chains, 6 restarts, breakends on every
+    chain) on the mix a genome gets on 256 CUs -- asserted through rmx_info(13 / 15) -- and every coordinate update agrees with the oracle."""
+    from remixt_amd import synthetic
+    e = synthetic.make_experiment(200, num_clones=3, max_copy_number=8, num_chains=5, seed=37, num_breakpoints=14, chain_fractions=(10, 6, 3, 2, 1))
+    e.breakpoints = H.add_shared_boundary_breakpoints(e)
+    ps = synthetic.make_init_params(e, 6, 8)
+    dev, ora = _two_sets(oracle_mod, e, ps, 8, 3, options={'fb_wg_budget': 40})
+    b = dev.batch
+    assert b.num_cn_states == 165 and b.info(10) == 5 and b.info(11) == 0
+    _compare_after_every_update(dev, ora)
+    assert b.info(12) == 1 and (b.info(13), b.info(15)) == (1, 4), (b.info(13), b.info(15))      # one restart per workgroup on the longest chain, four on the shortest
+    # the launch's bits do not depend on how the chip is shared out, as long as a chain keeps its side of the matrix / vector divide:
+    # pinned shapes reproduce the unpinned equal-budget run chain by chain (vector shapes 1 and 2 are bit-identical)
+    post = [b.get_array(r, 'posterior_marginals') for r in range(6)]
+    dev2, _ = _two_sets(oracle_mod, e, ps, 8, 3, options={'fb_wg_budget': 40})
+    for step in STEPS * 2:
+        getattr(dev2.batch, step)()
+    for r in range(6):
+        assert np.array_equal(dev2.batch.get_array(r, 'posterior_marginals'), post[r]), r
+
+
 def test_s165_workgroup_shapes_agree_and_subranges_are_bit_identical(hip):
     """k_fbm<., 4> (matrix cores) and k_fbm<., 2> / <., 1> (vector ALU) sum a column in different orders: posteriors agree to 1e-10, not
     to the bit.  Inside ONE shape a restart's result does not depend on the range of restarts a launch covers (units are absolute:

@@ -6,7 +6,8 @@ from remixt_amd import synthetic
 from remixt_amd.restarts import RestartSet
 N = int(os.environ.get('SEG', 50000)); R = int(os.environ.get('RST', 16)); K = os.environ.get('NBRK'); it = int(os.environ.get('ITERS', 2))
 mcn = int(os.environ.get('MAXCN', 8))
-e = synthetic.make_experiment(N, num_clones=3, max_copy_number=mcn, num_chains=int(os.environ.get('CHAINS', 23)), seed=0, num_breakpoints=int(K) if K else None)
+e = synthetic.make_experiment(N, num_clones=3, max_copy_number=mcn, num_chains=int(os.environ.get('CHAINS', 23)), seed=0, num_breakpoints=int(K) if K else None,
+                              chain_fractions=synthetic.HUMAN_CHROMOSOME_MB if os.environ.get('UNEQUAL') else None)
 ps = synthetic.make_init_params(e, R, mcn)
 from remixt_amd import _lib
 if os.environ.get('STAMPS'):      # an alternative build of the library (per-phase cycle counters, experiments): STAMPS=<name> -> tools/micro/lib_<name>.so
@@ -36,6 +37,7 @@ b.synchronize(); t0 = time.time()
 sweep(it)
 b.synchronize(); dt = time.time() - t0
 print('wall ms per sweep', dt / it * 1e3)
+print('forward-backward kernel %d, restarts per workgroup (shapes) %d .. %d' % (b.info(12), b.info(13), b.info(15)))
 for k, v in sorted(b.profile().items(), key=lambda kv: -kv[1][0]):
     print('%-28s %9.3f ms  n=%d  avg %.3f' % (k, v[0], v[1], v[0] / v[1]))
 

@@ -11,3 +11,6 @@ for rst in 4 8 16; do
     STAMPS=$2 RST=$rst NV=$nv MAXCN=$MAXCN FB_DEBUG=1 ITERS=3 python3 $ROOT/tools/fb_only.py 2>&1 | grep -E "k_fb |debug|raised" || exit 1
   done
 done
+echo "== chains in the proportions of the human chromosomes (5 : 1), 8 and 16 restarts per launch: shapes chosen per chain"
+for rst in 8 16; do RST=$rst MAXCN=$MAXCN UNEQUAL=1 FB_DEBUG=1 ITERS=3 python3 $ROOT/tools/fb_only.py 2>&1 | grep -E "k_fb |debug|shapes|raised"; done
+for nv in 2 4; do echo "   (pinned: $nv per workgroup, 8 per launch)"; RST=8 NV=$nv MAXCN=$MAXCN UNEQUAL=1 FB_DEBUG=1 ITERS=3 python3 $ROOT/tools/fb_only.py 2>&1 | grep -E "k_fb |debug|raised"; done
