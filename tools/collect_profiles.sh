@@ -1,8 +1,8 @@
 #!/bin/bash
-# Everything under profiles/ for one round, on a GPU box: bash tools/collect_profiles.sh r03
+# Everything under profiles/ for one round, on a GPU box: bash tools/collect_profiles.sh r04
 # (rocprofv3 gets the program itself after `--`; counters are collected in their own passes, without trace domains.)
 set -u
-TAG=${1:-r03}
+TAG=${1:-r04}
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out/profiles_$TAG
 mkdir -p "$OUT"
@@ -11,7 +11,7 @@ F="--steps 20 --warmup 5"
 python3 $ROOT/bench.py $F > $OUT/bench_line.json 2> $OUT/bench.err
 echo "bench done: $(cut -c1-120 $OUT/bench_line.json)"
 rocprofv3 --kernel-trace --stats -d $OUT/prof_bench -o b --output-format csv -- python3 $ROOT/bench.py $F --no-cpu-baseline --no-extra-states --no-fit-from-init > $OUT/bench_line_under_rocprof.json 2> $OUT/prof_bench.err
-python3 $ROOT/tools/timeline.py $(find $OUT/prof_bench -name "b_kernel_trace.csv" | head -1) "k_fbm<42>" > $OUT/timeline.txt 2>&1
+python3 $ROOT/tools/timeline.py $(find $OUT/prof_bench -name "b_kernel_trace.csv" | head -1) "k_fbm<42" > $OUT/timeline.txt 2>&1
 cp $(find $OUT/prof_bench -name "b_kernel_stats.csv" | head -1) $OUT/bench_kernel_stats.csv
 pmc() { # tag, restarts, max_cn, states
   export ITERS=3 RST=$2 MAXCN=$3
@@ -25,13 +25,14 @@ pmc s355 16 12 355
 pmc s355_8 8 12 355
 rocprofv3 --kernel-trace --stats -d $OUT/prof_s355 -o s --output-format csv -- python3 $ROOT/tools/fb_only.py > $OUT/prof_s355.log 2>&1
 cp $(find $OUT/prof_s355 -name "s_kernel_stats.csv" | head -1) $OUT/s355_kernel_stats.csv
-unset MAXCN
-export ITERS=5
-{ echo "# 16 restarts per launch (one restart group)"; RST=16 FB_DEBUG=1 python3 $ROOT/tools/fb_only.py 2>&1 | grep -v amdgpu.ids
-  echo; echo "# 8 restarts per launch (the bench: two restart groups of 8)"; RST=8 FB_DEBUG=1 python3 $ROOT/tools/fb_only.py 2>&1 | grep -v amdgpu.ids
-  echo; echo "# 8 restarts per launch, one breakpoint (plain steps only)"; RST=8 NBRK=1 FB_DEBUG=1 python3 $ROOT/tools/fb_only.py 2>&1 | grep -v amdgpu.ids
-  echo; echo "# 355 states (max_cn = 12), 16 restarts per launch"; ITERS=3 RST=16 MAXCN=12 FB_DEBUG=1 python3 $ROOT/tools/fb_only.py 2>&1 | grep -v amdgpu.ids
-  echo; echo "# 355 states, one breakpoint (plain steps only)"; ITERS=3 RST=16 MAXCN=12 NBRK=1 FB_DEBUG=1 python3 $ROOT/tools/fb_only.py 2>&1 | grep -v amdgpu.ids; } > $OUT/fb_launch_shapes.txt
+unset MAXCN ITERS RST
+bash $ROOT/tools/fb_shapes.sh 8 2>&1 | grep -v amdgpu.ids > $OUT/fb_launch_shapes.txt
+{ echo; echo "# 355 states (max_cn = 12)"; bash $ROOT/tools/fb_shapes.sh 12 2>&1 | grep -v amdgpu.ids; } >> $OUT/fb_launch_shapes.txt
+# FETCH_SIZE / WRITE_SIZE on kernels of known bytes (8- and 16-byte loads per lane, the row pattern of the strip kernels)
+rocprofv3 --pmc FETCH_SIZE -d $OUT/calib_f -o c --output-format csv -- $ROOT/tools/micro/pmc_calib > $OUT/calib_f.log 2>&1
+rocprofv3 --pmc WRITE_SIZE -d $OUT/calib_w -o c --output-format csv -- $ROOT/tools/micro/pmc_calib > $OUT/calib_w.log 2>&1
+python3 $ROOT/tools/pmc_calib_summary.py $OUT/calib_f $OUT/calib_w > $OUT/pmc_calibration.txt 2>&1
+rm -rf $OUT/calib_f $OUT/calib_w
 python3 $ROOT/tools/mstep_marks.py 2>&1 | grep -v amdgpu.ids > $OUT/mstep_stage_times.txt
 python3 $ROOT/tools/h_rounds.py 2>&1 | grep -v amdgpu.ids >> $OUT/mstep_stage_times.txt
 python3 $ROOT/tools/prep_time.py 2>&1 | grep -v amdgpu.ids >> $OUT/mstep_stage_times.txt
