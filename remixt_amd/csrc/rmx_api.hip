@@ -929,11 +929,11 @@ int rmx_batch_create(const rmx_problem *pr, int32_t R, const double *h_init, con
             for (int r = 0; r < R; r++) HIPCHK(hipMemcpy(d.pbrk + (size_t)r * K * B, pb.data(), pb.size() * 8, hipMemcpyHostToDevice));
         }
         // framelogprob = 1, posterior = 1/S, logZ rows = 0 (bpmodel.pyx:556-567)
-        std::vector<double> row((size_t)N * d.SP);
-        for (auto &x_ : row) x_ = 1.0;
-        for (int r = 0; r < R; r++) HIPCHK(hipMemcpy(d.f + (size_t)r * N * d.SP, row.data(), row.size() * 8, hipMemcpyHostToDevice));
-        for (auto &x_ : row) x_ = 1.0 / (double)S;
-        for (int r = 0; r < R; r++) HIPCHK(hipMemcpy(d.post + (size_t)r * N * d.SP, row.data(), row.size() * 8, hipMemcpyHostToDevice));
+        // (filled on the device: as pageable host copies these two planes were 1 GB over PCIe, half of the constructor's time at 50 000 x 165 x 8)
+        hipLaunchKernelGGL(k_fill_f64, dim3(2048), dim3(256), 0, b->stream, d.f, RNS, 1.0);
+        hipLaunchKernelGGL(k_fill_f64, dim3(2048), dim3(256), 0, b->stream, d.post, RNS, 1.0 / (double)S);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipStreamSynchronize(b->stream));
         HIPCHK(hipMemset(d.rowZ, 0, RN * 8)); HIPCHK(hipMemset(d.fmax, 0, RN * 8)); HIPCHK(hipMemset(d.mrow, 0, RN * 8));
         HIPCHK(hipMemset(d.fa, 0, RNS * 8)); HIPCHK(hipMemset(d.fb, 0, RNS * 8)); HIPCHK(hipMemset(d.fe, 0, RNS * 8)); HIPCHK(hipMemset(d.fe_alt, 0, RNS * 8));
         HIPCHK(hipMemset(d.err, 0, R * 4)); HIPCHK(hipMemset(b->d_lt_valid, 0, R * 4));

@@ -770,6 +770,10 @@ __global__ __launch_bounds__(NTMAX) void k_fbv(FbvArgs a) {
 #undef BE_SLOT
 }
 
+__global__ void k_fill_f64(double *p, size_t n, double v) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = v;
+}
+
 // =============================================================================
 // k_fbm: the production forward-backward kernel for S <= 176 -- the S x S product of a step on the FP64 matrix cores.
 //
@@ -3544,6 +3548,8 @@ template <int K> __device__ __forceinline__ void vit_rd2(vit_d2 &dst, unsigned a
 }
 template <int CNT> __device__ __forceinline__ void vit_wait(vit_d2 &x) { asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(x) : "n"(CNT) : "memory"); }
 template <int G, int NG, int DEPTH> struct vit_pipe {
+    // (one running maximum: four independent ones merged at the end -- shorter dependent chains, the same tie rule -- were measured
+    // in round 4 and are slower, 164 against 153 ms per 50 000-step lattice: the step is not bound by the compare -> select chain)
     template <int QMAX>
     static __device__ __forceinline__ void step(vit_d2 (&buf)[DEPTH], const double (&T)[QMAX], unsigned addr, double &best, int &bi, int i0) {
         constexpr int younger = (NG - 1 - G) < (DEPTH - 1) ? (NG - 1 - G) : (DEPTH - 1);

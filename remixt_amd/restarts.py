@@ -617,8 +617,23 @@ class RestartGroups(object):
         bounds = [(R * g) // groups for g in range(groups + 1)]
         self.slices = [slice(bounds[g], bounds[g + 1]) for g in range(groups)]
         remap_cache = dict()
-        self.sets = [RestartSet(experiment, init_params[sl], max_copy_number, remap_cache=remap_cache,
-                                seeds=(list(seeds)[sl] if seeds is not None else None), **kwargs) for sl in self.slices]
+
+        def build(sl):
+            return RestartSet(experiment, init_params[sl], max_copy_number, remap_cache=remap_cache,
+                              seeds=(list(seeds)[sl] if seeds is not None else None), **kwargs)
+        if groups > 1:
+            # the groups are built side by side (a batch's construction is mostly device allocation and table building inside one C call,
+            # which releases the GIL) once the segment remap they share is in the cache: one model built ahead of them fills it
+            mk = dict((k, v) for k, v in kwargs.items() if k not in ('strict', 'mstep_threads', 'lockstep', 'native_search', 'sample_prep', 'options', 'h_init',
+                                                                     'joint_accept', 'num_clones', 'device', 'quiet', 'kernel_module'))
+            BreakpointModel(experiment.x, experiment.l, experiment.adjacencies, experiment.breakpoints, max_copy_number=max_copy_number,
+                            divergence_weight=init_params[0]['divergence_weight'], max_depth=init_params[0]['max_depth'],
+                            kernel_module=kwargs.get('kernel_module'), device=kwargs.get('device', 0), quiet=True, remap_cache=remap_cache, **mk)
+            from concurrent.futures import ThreadPoolExecutor
+            with ThreadPoolExecutor(max_workers=groups) as pool:
+                self.sets = list(pool.map(build, self.slices))
+        else:
+            self.sets = [build(self.slices[0])]
         self.models = [m for rs in self.sets for m in rs.models]
         self.init_params = init_params
         self.experiment = experiment
@@ -788,8 +803,10 @@ def collect_fit_results(model, experiment, init_params, cn=None):
     stats['error_message'] = ''
     stats.update(model.get_likelihood_param_values())
     l = np.asarray(experiment.l)
-    ploidy = (cn[:, 1:, :].mean(axis=1).T * l).sum() / l.sum()
-    divergent = (cn[:, 1:, :].max(axis=1) != cn[:, 1:, :].min(axis=1)) * 1.
+    # analysis/pipeline.py:215-217: ploidy = (cn[:,1:,:].mean(axis=1).T * l).sum() / l.sum(), divergent = (max over the tumour clones != min).
+    # Reductions over an axis of two or three elements are numpy's slow case (23 ms of a 9 ms-per-restart budget at 50 000 segments): the
+    # same operations clone by clone -- the same floating-point values in the same order (tests/test_host_golden.py compares the bits)
+    ploidy, divergent = tumour_ploidy_and_divergence(cn, l)
     stats['num_clones'] = len(model.h)
     stats['num_segments'] = len(experiment.x)
     stats['ploidy'] = ploidy
@@ -798,6 +815,19 @@ def collect_fit_results(model, experiment, init_params, cn=None):
     stats['divergence_weight'] = init_params['divergence_weight']
     res['stats'] = stats
     return res
+
+
+def tumour_ploidy_and_divergence(cn, l):
+    """(length-weighted mean tumour copies per allele, per-segment-and-allele indicator of clones that differ) of a decoded copy number
+    cn (N, M, 2) -- the two statistics of analysis/pipeline.py:215-217, bit for bit."""
+    t = np.asarray(cn)[:, 1:, :]
+    acc = t[:, 0, :].astype(float)
+    lo = t[:, 0, :].copy(); hi = t[:, 0, :].copy()
+    for m in range(1, t.shape[1]):
+        acc = acc + t[:, m, :]
+        np.minimum(lo, t[:, m, :], out=lo); np.maximum(hi, t[:, m, :], out=hi)
+    mean = acc / t.shape[1]
+    return (mean.T * l).sum() / l.sum(), (hi != lo) * 1.
 
 
 # ---------------------------------------------------------------------------------
