@@ -1261,12 +1261,14 @@ static void (*fbm_kernel_for(int KB))(FbmArgs) {
 // the chip at once, and for every chain the LARGEST such shape (fewest CUs).  Equal chains get one shape (23 chains x 8 restarts: two per
 // workgroup, 184 workgroups); chromosomes of a real genome (lengths 5 : 1) get one restart per workgroup on the long ones and four on the
 // short ones.  `pin` (option fb_nv) fixes the shape of every chain.  Items are ordered longest first.
-static int fb_items_for(rmx_batch *b, int r0, int r1, int pin, rmx_batch::FbItems **out) {
+// (`cost`: cycles per step with 1 / 2 / 4 restarts per workgroup at [1] / [2] / [4]; 0 = the kernel has no such shape)
+static int fb_items_for(rmx_batch *b, int r0, int r1, int pin, const double (&cost)[5], rmx_batch::FbItems **out) {
+    if ((pin == 1 || pin == 2 || pin == 4) && cost[pin] == 0.) pin = 4;
     auto key = std::make_tuple(r0, r1, pin * 4096 + fb_wg_budget(b));
     auto it = b->fb_items.find(key);
     if (it != b->fb_items.end()) { *out = &it->second; return RMX_OK; }
-    static const double cost[5] = {0., 1500., 2110., 0., 2845.};
-    static const int shapes[3] = {4, 2, 1};
+    std::vector<int> shapes;
+    for (int nv : {4, 2, 1}) if (cost[nv] > 0.) shapes.push_back(nv);
     const int nc = (int)b->h_list_fast.size();
     auto units = [&](int nv) { return (r1 - 1) / nv - r0 / nv + 1; };
     std::vector<int> nv_of(nc, 4);
@@ -1331,7 +1333,8 @@ static int p_cn_front(rmx_batch *b, int r0, int r1, bool skip_frame, bool snapsh
             for (int v : {8, 16, 28, 36, 42, 44}) if (4 * v >= d.S) { KB = v; break; }
             const int NCT = (d.S + 14) / 15;                          // waves: 15 state columns + the ones column each
             rmx_batch::FbItems *items = nullptr;
-            if ((rc = fb_items_for(b, r0, r1, b->opt[RMX_OPT_FB_NV], &items))) return rc;
+            static const double fbm_cost[5] = {0., 1500., 2110., 0., 2845.};      // cycles per step (profiles/r04_fb_launch_shapes.txt)
+            if ((rc = fb_items_for(b, r0, r1, b->opt[RMX_OPT_FB_NV], fbm_cost, &items))) return rc;
             FbmArgs m;
             memset(&m, 0, sizeof m);
             m.S = d.S; m.SP = d.SP; m.M = d.M; m.D = d.D; m.C = d.C; m.N = d.N; m.NBE = d.NBE; m.cn_max = d.cn_max; m.r0 = r0; m.r1 = r1;
@@ -1394,7 +1397,7 @@ static int p_cn_front(rmx_batch *b, int r0, int r1, bool skip_frame, bool snapsh
             if (kf && nt <= 768 && lds <= kLdsBudget) {
                 HIPCHK(hipFuncSetAttribute((const void *)kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
                 hipLaunchKernelGGL(kf, dim3(b->n_fast, (nr + NV - 1) / NV, 2), dim3(nt), lds, b->stream, v);
-                done_fast = true; fast = true; b->last_fb_kernel = 2; b->last_fb_nv = NV;
+                done_fast = true; fast = true; b->last_fb_kernel = 2; b->last_fb_nv = b->last_fb_nv_max = NV;
             }
         }
         if (!done_fast && b->fbv_rpt == 0 && b->fbk_ok && d.pe2x_lt && b->n_fast > 0 && b->opt[RMX_OPT_FB_KERNEL] == 0 && d.S <= 360) {
@@ -1402,13 +1405,11 @@ static int p_cn_front(rmx_batch *b, int r0, int r1, bool skip_frame, bool snapsh
             // looked up in a 64-entry LDS table (k_fbq); fb_kernel = 3 selects the vector kernel k_fbk below instead
             const int KB = d.S <= 256 ? 64 : 90;
             const int NWq = (d.S + 29) / 30;
-            auto units = [&](int nv) { return (r1 - 1) / nv - r0 / nv + 1; };      // absolute units of nv restarts that [r0, r1) touches
-            int NV = 4;                                                             // (as for k_fbm: two / one per workgroup on the vector ALU where the chip has room)
-            if (b->opt[RMX_OPT_FB_NV] == 1 || b->opt[RMX_OPT_FB_NV] == 2 || b->opt[RMX_OPT_FB_NV] == 4) NV = b->opt[RMX_OPT_FB_NV];
-            else { for (int nv : {2, 1}) if ((long)b->n_fast * 2 * units(nv) <= fb_wg_budget(b)) NV = nv; }
-            // above 256 states (90 k-blocks) two restarts per workgroup do not fit the register file next to the 90 address registers (measured: spills,
-            // 12 200 cycles per step against 13 500 with four): one per workgroup where that fits the chip, else four
-            if (KB == 90 && NV == 2) NV = (b->opt[RMX_OPT_FB_NV] == 0 && (long)b->n_fast * 2 * units(1) <= fb_wg_budget(b)) ? 1 : 4;
+            // (as for k_fbm: a shape per chain from the work-item table; above 256 states -- 90 k-blocks -- two restarts per workgroup do not fit the
+            // register file next to the 90 address registers (measured: spills, 12 200 cycles per step against 13 500 with four): one or four)
+            static const double fbq_cost64[5] = {0., 5040., 8440., 0., 9520.}, fbq_cost90[5] = {0., 7150., 0., 0., 13550.};
+            rmx_batch::FbItems *items = nullptr;
+            if ((rc = fb_items_for(b, r0, r1, b->opt[RMX_OPT_FB_NV], KB == 64 ? fbq_cost64 : fbq_cost90, &items))) return rc;
             FbmArgs m;
             memset(&m, 0, sizeof m);
             m.S = d.S; m.SP = d.SP; m.M = d.M; m.D = d.D; m.C = d.C; m.N = d.N; m.NBE = d.NBE; m.cn_max = d.cn_max; m.r0 = r0; m.r1 = r1;
@@ -1417,13 +1418,13 @@ static int p_cn_front(rmx_batch *b, int r0, int r1, bool skip_frame, bool snapsh
             m.be_n = d.be_n; m.chain_be = d.chain_be; m.fe = d.fe; m.Wf = d.Wf; m.Wb = d.Wb; m.pe2_lt = d.pe2x_lt; m.af = d.af; m.ab = d.ab; m.tot = d.tot;
             m.fa = d.fa; m.fb = d.fb; m.mrow = d.mrow; m.err = d.err; m.dbg = b->d_dbg;
             const size_t lds = (size_t)2 * m.VR * 4 * 8 + (size_t)2 * 4 * m.PE2P * 8 + 64 * 32 * 8 + 64 * 8 + (size_t)4 * KB * 4 + (size_t)b->be_cap * 4 + 64;
-            void (*kf)(FbmArgs, const double *, const uint32_t *, const uint32_t *) =
-                KB == 64 ? (NV == 4 ? k_fbq<64, 4> : (NV == 2 ? k_fbq<64, 2> : k_fbq<64, 1>)) : (NV == 4 ? k_fbq<90, 4> : k_fbq<90, 1>);
+            m.items = items->dev;
+            void (*kf)(FbmArgs, const double *, const uint32_t *, const uint32_t *) = KB == 64 ? k_fbq<64> : k_fbq<90>;
             if (NWq <= 12 && 4 * KB >= d.S && lds <= kLdsBudget) {
                 HIPCHK(hipFuncSetAttribute((const void *)kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-                hipLaunchKernelGGL(kf, dim3(b->n_fast, units(NV), 2), dim3(64 * NWq), lds, b->stream, m,
+                hipLaunchKernelGGL(kf, dim3(items->n), dim3(64 * NWq), lds, b->stream, m,
                                    (const double *)b->d_wk, (const uint32_t *)b->d_cnpack, (const uint32_t *)b->d_totpack);
-                done_fast = true; fast = true; b->last_fb_kernel = 4; b->last_fb_nv = NV;
+                done_fast = true; fast = true; b->last_fb_kernel = 4; b->last_fb_nv = items->nv_min; b->last_fb_nv_max = items->nv_max;
             }
         }
         if (!done_fast && b->fbv_rpt == 0 && b->fbk_ok && d.pe2_lt && b->n_fast > 0 && (b->opt[RMX_OPT_FB_KERNEL] == 0 || b->opt[RMX_OPT_FB_KERNEL] == 3)) {
@@ -1451,10 +1452,10 @@ static int p_cn_front(rmx_batch *b, int r0, int r1, bool skip_frame, bool snapsh
                 void (*kf)(FbvArgs, const double *, const uint32_t *, const uint32_t *) = NV == 1 ? k_fbk<1, 768> : (NV == 2 ? k_fbk<2, 768> : k_fbk<4, 768>);
                 HIPCHK(hipFuncSetAttribute((const void *)kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
                 hipLaunchKernelGGL(kf, dim3(b->n_fast, (nr + NV - 1) / NV, 2), dim3(nt), lds, b->stream, v, (const double *)b->d_wk, (const uint32_t *)b->d_cnpack, (const uint32_t *)b->d_totpack);
-                done_fast = true; fast = true; b->last_fb_kernel = 3; b->last_fb_nv = NV;
+                done_fast = true; fast = true; b->last_fb_kernel = 3; b->last_fb_nv = b->last_fb_nv_max = NV;
             }
         }
-        if (!fast) { b->last_fb_kernel = 0; b->last_fb_nv = 1; }
+        if (!fast) { b->last_fb_kernel = 0; b->last_fb_nv = b->last_fb_nv_max = 1; }
         const int ngen = fast ? b->n_generic : d.NC;
         if (ngen > 0) {
             a.amat_lds = 0; a.P = b->fbG.P; a.BLK = b->fbG.BLK; a.SPAD = b->fbG.SPAD; a.chain_list = fast ? d.chain_list_generic : d.chain_list_all;

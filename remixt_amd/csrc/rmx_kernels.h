@@ -1381,15 +1381,14 @@ template <int KBI, int KB, int NV> struct fbqw_be {
 };
 
 template <int KB, int NV>
-__device__ __forceinline__ void fbq_body(const FbmArgs &a, const double *wk, const uint32_t *cnpack, const uint32_t *totpack, const int by) {
+__device__ __forceinline__ void fbq_body(const FbmArgs &a, const double *wk, const uint32_t *cnpack, const uint32_t *totpack, const int chain, const int rg0, const int dir) {
     extern __shared__ __align__(16) unsigned char smem_raw[];
     static_assert(KB % 2 == 0 && KB / 2 >= FBQ_DEPTH, "k-blocks come in pairs; ring no deeper than the chain");
     constexpr int NW32 = KB / 2;
-    const int chain = a.chain_list[blockIdx.x], dir = blockIdx.z;
     static_assert(NV == 1 || NV == 2 || NV == 4, "restarts per workgroup");
     constexpr int G = FBW_G(KB), VRP = 64 * G;                  // (NV < 4) groups of 16 k-blocks, doubles of a restart's plain vector image
     // restarts in absolute units of NV inside absolute quads (k_fbm); the unit's restarts take slots 0 .. NV - 1 of the vector image
-    const int unit = a.r0 / NV + by, rg0 = unit * NV, quad = rg0 >> 2, I0 = rg0 & 3;
+    const int quad = rg0 >> 2, I0 = rg0 & 3;
     const int v_lo = max(a.r0 - rg0, 0), v_hi = min(a.r1 - rg0, NV);
     const int S = a.S, SP = a.SP, M = a.M, D = a.D, VR = a.VR;
     const int n0 = a.chain_start[chain], n1 = a.chain_end[chain], len = n1 - n0 + 1;
@@ -1486,7 +1485,7 @@ __device__ __forceinline__ void fbq_body(const FbmArgs &a, const double *wk, con
     }
     eptr0 += rstep; eptr1 += rstep;
     FB_BARRIER();
-    if (a.dbg && t == 0 && blockIdx.x == 0 && by == 0 && blockIdx.z == 0) { a.dbg[0] = clock64(); a.dbg[1] = wall_clock64(); a.dbg[4] = len; }
+    if (a.dbg && t == 0 && blockIdx.x == 0) { a.dbg[0] = clock64(); a.dbg[1] = wall_clock64(); a.dbg[4] = len; }
     // tail of a step (k_fbm's FBM_FINISH for two tiles): tile 0's ones column holds the sum of the previous row
 #define FBQ_FINISH(s0_, s1_, e0_, e1_, k_)                                                                                         \
     {                                                                                                                              \
@@ -1645,7 +1644,7 @@ __device__ __forceinline__ void fbq_body(const FbmArgs &a, const double *wk, con
     }
 #undef FBQ_FINISH
 #undef FBQ_FETCH
-    if (a.dbg && t == 0 && blockIdx.x == 0 && by == 0 && blockIdx.z == 0) { a.dbg[2] = clock64(); a.dbg[3] = wall_clock64(); }
+    if (a.dbg && t == 0 && blockIdx.x == 0) { a.dbg[2] = clock64(); a.dbg[3] = wall_clock64(); }
     if (wave == 0) {
         const double *vb = vec + (size_t)((len - 1) & 1) * vbuf;
         double ps = 0.;
@@ -1660,8 +1659,14 @@ __device__ __forceinline__ void fbq_body(const FbmArgs &a, const double *wk, con
     }
 #undef ROW
 }
-template <int KB, int NV>
-__global__ __launch_bounds__(768) void k_fbq(FbmArgs a, const double *wk, const uint32_t *cnpack, const uint32_t *totpack) { fbq_body<KB, NV>(a, wk, cnpack, totpack, blockIdx.y); }
+// grid (work items), as k_fbm: a workgroup's chain, unit of restarts, shape and direction come from a.items (above 256 states the shapes are four and one)
+template <int KB>
+__global__ __launch_bounds__(768) void k_fbq(FbmArgs a, const double *wk, const uint32_t *cnpack, const uint32_t *totpack) {
+    const int4 it = a.items[blockIdx.x];
+    if (it.z == 4) fbq_body<KB, 4>(a, wk, cnpack, totpack, it.x, it.y, it.w);
+    else if (KB <= 64 && it.z == 2) fbq_body<(KB <= 64 ? KB : 64), 2>(a, wk, cnpack, totpack, it.x, it.y, it.w);
+    else fbq_body<KB, 1>(a, wk, cnpack, totpack, it.x, it.y, it.w);
+}
 
 // =============================================================================
 // k_fbk: forward-backward for state grids whose S x S weight matrix does not fit the register file

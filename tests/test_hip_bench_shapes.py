@@ -113,6 +113,19 @@ def test_s165_unequal_chains_get_mixed_workgroup_shapes_and_match_oracle(hip, or
         assert np.array_equal(dev2.batch.get_array(r, 'posterior_marginals'), post[r]), r
 
 
+def test_s355_unequal_chains_get_mixed_workgroup_shapes_and_match_oracle(hip, oracle_mod):
+    """The same at 355 states (k_fbq: one restart per workgroup on the long chains, four on the short ones, in one launch)."""
+    from remixt_amd import synthetic
+    e = synthetic.make_experiment(70, num_clones=3, max_copy_number=12, num_chains=4, seed=43, num_breakpoints=8, chain_fractions=(8, 4, 2, 1))
+    e.breakpoints = H.add_shared_boundary_breakpoints(e)
+    ps = synthetic.make_init_params(e, 5, 12)
+    dev, ora = _two_sets(oracle_mod, e, ps, 12, 3, options={'fb_wg_budget': 24})
+    b = dev.batch
+    assert b.num_cn_states == 355 and b.info(10) == 4 and b.info(11) == 0
+    _compare_after_every_update(dev, ora)
+    assert b.info(12) == 4 and (b.info(13), b.info(15)) == (1, 4), (b.info(13), b.info(15))
+
+
 def test_s165_workgroup_shapes_agree_and_subranges_are_bit_identical(hip):
     """k_fbm<., 4> (matrix cores) and k_fbm<., 2> / <., 1> (vector ALU) sum a column in different orders: posteriors agree to 1e-10, not
     to the bit.  Inside ONE shape a restart's result does not depend on the range of restarts a launch covers (units are absolute:
