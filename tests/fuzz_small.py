@@ -18,8 +18,12 @@ def draw_case(seed, big=False):
     rng = np.random.RandomState(100003 * seed + 17)
     if big:
         N = int(rng.choice([12, 20, 33, 40]))
-        return dict(seed=seed, N=N, chains=int(rng.randint(1, 4)), M=3, max_cn=int(rng.choice([8, 12])), nbrk=int(rng.choice([1, 3, N // 4])),
+        case = dict(seed=seed, N=N, chains=int(rng.randint(1, 4)), M=3, max_cn=int(rng.choice([8, 12])), nbrk=int(rng.choice([1, 3, N // 4])),
                     R=int(rng.randint(1, 10)), fb_nv=int(rng.choice([0, 0, 0, 1, 2, 4])), shared=bool(rng.randint(0, 2)))
+        # (round 4) chains of unequal length and a small workgroup budget: the mix of workgroup shapes a genome gets on 256 CUs
+        case['budget'] = int(rng.choice([0, 0, 6, 12, 24]))
+        case['fractions'] = [float(x) for x in rng.choice([1., 1., 2., 4., 7.], size=case['chains'])] if rng.randint(0, 2) else None
+        return case
     N = int(rng.choice([4, 5, 7, 12, 20, 33, 64, 90]))
     chains = int(rng.randint(1, min(6, N // 2) + 1))
     M = int(rng.choice([2, 3, 3]))
@@ -28,25 +32,39 @@ def draw_case(seed, big=False):
     R = int(rng.randint(1, 8))
     nv = int(rng.choice([0, 0, 1, 2, 4]))
     shared = bool(rng.randint(0, 2))
-    return dict(seed=seed, N=N, chains=chains, M=M, max_cn=max_cn, nbrk=nbrk, R=R, fb_nv=nv, shared=shared)
+    budget = int(rng.choice([0, 0, 4, 10, 30]))
+    fractions = [float(x) for x in rng.choice([1., 1., 2., 4., 7.], size=chains)] if rng.randint(0, 2) else None
+    return dict(seed=seed, N=N, chains=chains, M=M, max_cn=max_cn, nbrk=nbrk, R=R, fb_nv=nv, shared=shared, budget=budget, fractions=fractions)
 
 
 def run_case(case, oracle_mod):
     from remixt_amd import synthetic
     from tests import helpers as H
     from tests.test_hip_bench_shapes import _two_sets, _compare_after_every_update
+    from tests.test_hip_bench_shapes import STEPS
+    fr = case.get('fractions')
+    if fr is not None and case['N'] < 2 * len(fr) + 2:
+        fr = None
     e = synthetic.make_experiment(case['N'], num_clones=case['M'], max_copy_number=case['max_cn'], num_chains=case['chains'],
-                                  seed=case['seed'], num_breakpoints=case['nbrk'])
+                                  seed=case['seed'], num_breakpoints=case['nbrk'], chain_fractions=fr)
     if case['shared']:
         try:
             e.breakpoints = H.add_shared_boundary_breakpoints(e)
         except RuntimeError:        # every boundary of a very small problem already carries a breakpoint
             pass
     ps = synthetic.make_init_params(e, case['R'], case['max_cn'], num_clones=case['M'])
-    dev, ora = _two_sets(oracle_mod, e, ps, case['max_cn'], case['M'], options={'fb_nv': case['fb_nv']})
+    options = {'fb_nv': case['fb_nv'], 'fb_wg_budget': case.get('budget', 0)}
+    dev, ora = _two_sets(oracle_mod, e, ps, case['max_cn'], case['M'], options=options)
     _compare_after_every_update(dev, ora, rtol=1e-7, elbo_rtol=1e-7, ties_ok=True)
     b = dev.batch
-    return b.num_cn_states, b.info(12), b.info(13)
+    # the same sweeps once more on a fresh batch: bit-identical (what caught the stale matrix-instruction operand of round 4)
+    post = [b.get_array(r, 'posterior_marginals') for r in range(case['R'])]
+    dev2, _ = _two_sets(oracle_mod, e, ps, case['max_cn'], case['M'], options=options)
+    for step in STEPS * 2:
+        getattr(dev2.batch, step)()
+    for r in range(case['R']):
+        assert np.array_equal(dev2.batch.get_array(r, 'posterior_marginals'), post[r]), 'restart %d: a repeated run differs in its bits' % r
+    return b.num_cn_states, b.info(12), (b.info(13), b.info(15))
 
 
 def run_fit_case(case, oracle_mod, em_iters=2):
