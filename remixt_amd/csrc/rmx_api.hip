@@ -111,6 +111,7 @@ struct rmx_batch {
     // FB launch configuration
     FbLaunch fbG{}; size_t fbG_lds = 0;   // generic kernel configuration
     int n_fast = 0, n_generic = 0;
+    int num_cus = 256;                                   // compute units of the batch's device
     std::vector<int32_t> h_list_fast, h_chain_len;       // chains on the register-resident kernels; segments of every chain
     struct FbItems { int n = 0; int4 *dev = nullptr; int nv_min = 4, nv_max = 1; };
     std::map<std::tuple<int, int, int>, FbItems> fb_items;   // work-item tables of k_fbm launches by (r0, r1, pinned restarts per workgroup)
@@ -727,6 +728,7 @@ int rmx_batch_create(const rmx_problem *pr, int32_t R, const double *h_init, con
     rmx_batch *b = new rmx_batch();
     { std::lock_guard<std::mutex> lk(g_opt_mu); memcpy(b->opt, g_opt_default, sizeof b->opt); }
     b->device = device; b->R = R;
+    { int cus = 0; if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) b->num_cus = cus; }
     HIPCHK(hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking));
     b->own_stream = true;
     Dev &d = b->d;
@@ -1247,9 +1249,8 @@ static int do_framelogprob(rmx_batch *b, int r0, int r1) {
 // the breakend adjacencies; (3) marginals.  (2) and (3) only read what (1) wrote and write disjoint arrays
 // (a fused marginal pass puts the next sweep's fe into the second buffer), so rmx_variational_update runs
 // (2) -- and update_p_breakpoint behind it -- on a second stream next to (3).
-// workgroups of a forward-backward launch that run side by side (one per CU: the weights fill the register file)
-static const int g_fb_wg_budget = 256;
-static inline int fb_wg_budget(const rmx_batch *b) { return b->opt[RMX_OPT_FB_WG_BUDGET] > 0 ? b->opt[RMX_OPT_FB_WG_BUDGET] : g_fb_wg_budget; }
+// workgroups of a forward-backward launch that run side by side: one per CU (the weights fill the register file) -- the device's CU count (256 on an MI355X)
+static inline int fb_wg_budget(const rmx_batch *b) { return b->opt[RMX_OPT_FB_WG_BUDGET] > 0 ? b->opt[RMX_OPT_FB_WG_BUDGET] : b->num_cus; }
 static void (*fbm_kernel_for(int KB))(FbmArgs) {
     switch (KB) { case 8: return k_fbm<8>; case 16: return k_fbm<16>; case 28: return k_fbm<28>; case 36: return k_fbm<36>; case 42: return k_fbm<42>; case 44: return k_fbm<44>; }
     return nullptr;

@@ -2037,8 +2037,12 @@ __global__ __launch_bounds__(256) void k_cells(Dev d, int r0) {
             for (int k = 0; k < NS; k++) { const int s = lane + 64 * k; if (s < d.SP) d.fe[ro + s] = s < S ? exp(fv[k] - vmax) : 0.; }
         } else {
             constexpr bool M1 = MODE == 1 || MODE == 3;
-            constexpr bool STASH = MODE == 3 && NS <= 3;
-            __shared__ double lsm[STASH ? 4 : 1][STASH ? NS * 6 * 64 : 1];
+            // planes of the cell cache kept in a wave-private LDS stash between the pass's two reads of them (expectations, then the next sweep's
+            // frame values): all six up to 192 states (36 KB per block); three of six up to 384 (round 4: at 355 states the second read of all six missed
+            // L2 -- 512 waves per XCD x 17 KB -- and the pass moved 1.46 x its algorithmic bytes); the other three are read again
+            constexpr int NSTASH = MODE != 3 ? 0 : (NS <= 3 ? 6 : (NS <= 6 ? 3 : 0));
+            constexpr bool STASH = NSTASH > 0;
+            __shared__ double lsm[STASH ? 4 : 1][STASH ? NS * NSTASH * 64 : 1];
             double pv[NS];
             double sum = 0.;
             if (M1) {
@@ -2091,11 +2095,11 @@ __global__ __launch_bounds__(256) void k_cells(Dev d, int r0) {
                     double LT[2], LA[4];
                     cell(sc, st[k], (size_t)n * d.SP + s, LT, LA);
                     const double ps = pv[k];
-                    if (STASH) {
+                    if (STASH) {      // planes 0, 1: LT; 2 .. 5: LA -- the first NSTASH of them
 #pragma unroll
-                        for (int q_ = 0; q_ < 2; q_++) lsm[wave][(k * 6 + q_) * 64 + lane] = LT[q_];
+                        for (int q_ = 0; q_ < 2; q_++) if (q_ < NSTASH) lsm[wave][(k * NSTASH + q_) * 64 + lane] = LT[q_];
 #pragma unroll
-                        for (int q_ = 0; q_ < 4; q_++) lsm[wave][(k * 6 + 2 + q_) * 64 + lane] = LA[q_];
+                        for (int q_ = 0; q_ < 4; q_++) if (2 + q_ < NSTASH) lsm[wave][(k * NSTASH + 2 + q_) * 64 + lane] = LA[q_];
                     }
                     a0 += ps * LT[0]; a1 += ps * LT[1];
                     b0 += ps * LA[0]; b1 += ps * LA[1]; b2 += ps * LA[2]; b3 += ps * LA[3];
@@ -2182,10 +2186,11 @@ __global__ __launch_bounds__(256) void k_cells(Dev d, int r0) {
                         // MALL).  Keeping 6 x NS doubles live in registers would cost a wave per SIMD of occupancy.
                         double LT[2], LA[4];
                         if (STASH) {
+                            const size_t off_ = (size_t)n * d.SP + s;
 #pragma unroll
-                            for (int q_ = 0; q_ < 2; q_++) LT[q_] = lsm[wave][(k * 6 + q_) * 64 + lane];
+                            for (int q_ = 0; q_ < 2; q_++) LT[q_] = q_ < NSTASH ? lsm[wave][(k * NSTASH + q_) * 64 + lane] : lcr[q_ * plane + off_];
 #pragma unroll
-                            for (int q_ = 0; q_ < 4; q_++) LA[q_] = lsm[wave][(k * 6 + 2 + q_) * 64 + lane];
+                            for (int q_ = 0; q_ < 4; q_++) LA[q_] = 2 + q_ < NSTASH ? lsm[wave][(k * NSTASH + 2 + q_) * 64 + lane] : lcr[(2 + q_) * plane + off_];
                         } else cell(sc, st[k], (size_t)n * d.SP + s, LT, LA);
                         double f = 0.;
                         f += qt0 * LT[0]; f += qt1 * LT[1];

@@ -200,6 +200,20 @@ def test_grids_between_the_benchmark_grids_match_oracle(hip, oracle_mod, max_cn,
     assert (dev.batch.info(12), dev.batch.info(13)) == (4, nv or 1)
 
 
+@pytest.mark.parametrize('nv', [0, 4, 2])
+def test_two_clones_at_169_states_match_oracle(hip, oracle_mod, nv):
+    """Two clones at max_cn = 24: 169 states -- between the three-clone grids (165, 205).  The copy-number range is beyond the breakend tables of
+    k_fbm (2 max_cn + 3 = 51 > 31 table entries per clone), so with breakends this grid runs the two-phase vector kernel k_fbv with per-clone tables."""
+    from remixt_amd import synthetic
+    e = synthetic.make_experiment(36, num_clones=2, max_copy_number=24, num_chains=2, seed=71, num_breakpoints=6)
+    e.breakpoints = H.add_shared_boundary_breakpoints(e)
+    ps = synthetic.make_init_params(e, 5, 24, num_clones=2)
+    dev, ora = _two_sets(oracle_mod, e, ps, 24, 2, options={'fb_nv': nv})
+    assert dev.batch.num_cn_states == 169
+    _compare_after_every_update(dev, ora)
+    assert dev.batch.info(12) == 2 and dev.batch.info(13) == (nv or 1)
+
+
 @pytest.mark.parametrize('max_cn', [3, 6])
 def test_transition_model_1_matches_oracle(hip, oracle_mod, max_cn):
     """transition_model = 1 (bpmodel.pyx:606-616: 0/1 cost per changed copy number instead of |d|), set after construction
