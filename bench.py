@@ -73,8 +73,8 @@ def parse(argv=None):
     ap.add_argument('--update-iters', type=int, default=5)
     ap.add_argument('--groups', type=int, default=2, help='restart groups per GPU and dataset (own stream + host thread each; results do not depend on it)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--cpu-sample-segments', type=int, default=160)
-    ap.add_argument('--cpu-sample-segments-355', type=int, default=40, help='segments of the CPU baseline sample at 355 states (0 = skip)')
+    ap.add_argument('--cpu-sample-segments', type=int, default=800, help='segments of the CPU baseline sample at the headline grid (about 10 s of one core)')
+    ap.add_argument('--cpu-sample-segments-355', type=int, default=120, help='segments of the CPU baseline sample at 355 states (0 = skip)')
     ap.add_argument('--profile-all', action='store_true', help='HIP-event every kernel (default: only the variational-sweep kernels; the M-step objective kernels are ~3000 tiny launches per step)')
     ap.add_argument('--no-extra-states', action='store_true', help='skip the additional 355-state (max_cn = 12) measurement at N = 1')
     ap.add_argument('--no-fit-from-init', action='store_true', help='skip the construct -> 5 EM iterations -> decode wall-clock measurement at N = 1')
