@@ -846,7 +846,7 @@ int rmx_batch_create(const rmx_problem *pr, int32_t R, const double *h_init, con
 #define DA(field, type, count) { type *p_ = nullptr; if ((rc = dalloc(b, &p_, (size_t)(count)))) { rmx_batch_destroy(b); return rc; } d.field = p_; }
     DA(Tval, double, SS * d.TC) DA(Wf, double, SS * d.TC) DA(Wb, double, SS * d.TC) DA(af, int8_t, SS * d.TC) DA(ab, int8_t, SS * d.TC)
     const size_t RN = (size_t)R * N, RNS = RN * d.SP, RCS = (size_t)R * C * d.SP;
-    DA(rp, RestartParams, R) DA(stLogD, double, RCS) DA(stD, double, RCS) DA(stP, double, RCS) DA(stM, double, RCS * 2) DA(stLg, double, RCS * 4) DA(stFlags, uint32_t, RCS)
+    DA(rp, RestartParams, R) DA(stLogD, double, RCS) DA(stD, double, RCS) DA(stP, double, RCS) DA(stM, double, RCS * 2) DA(stLg, double, RCS * 4) DA(stFlags, uint32_t, RCS) DA(stFlagsAgg, uint32_t, (size_t)R * C)
     DA(segc, double, RN * 8) DA(qt, double, RN * 2) DA(qa, double, RN * 2) DA(qs, double, RN * 2) DA(pbrk, double, (size_t)R * K * B)
     DA(f, double, RNS) DA(fe, double, RNS) DA(fe_alt, double, RNS) DA(fa, double, RNS) DA(fb, double, RNS) DA(post, double, RNS) DA(fmax, double, RN) DA(mrow, double, RN)
     DA(A, double, RN * 2) DA(Bv, double, RN * 4) DA(rowPF, double, RN) DA(rowPP, double, RN) DA(rowZ, double, RN)

@@ -72,6 +72,7 @@ struct Dev {
     double *stD, *stP, *stM, *stLg;      // [R][C][SP]; stM [R][C][2][SP]; stLg [R][C][4][SP]
     double *stLogD;                      // [R][C][SP] log of the state's expected depth
     uint32_t *stFlags;                   // [R][C][SP]
+    uint32_t *stFlagsAgg;                // [R][C] what the states of a table raise together: 1 some ST_E_TD, 2 some ST_E_LOH, 4 some ST_E_BADP without either
     double *segc;                        // [R][8][N]
     double *qt, *qa, *qs;                // [R][N][2]
     double *pbrk;                        // [R][K][B]
@@ -284,6 +285,17 @@ __device__ __forceinline__ void cell_static_errors(const SegCtx &sc, unsigned fl
         if (fl & ST_E_TD) err |= RMX_ERR_TOTAL_DEPTH;
         if (fl & ST_E_LOH) err |= RMX_ERR_LOH_P;
         if (!(sc.ys == 0. || (fl & (ST_E_TD | ST_E_LOH))) && (fl & ST_E_BADP)) err |= RMX_ERR_BAD_P;
+    }
+}
+
+// ... for ALL states of a (restart, class) table at once, from the aggregate k_state_tables leaves in d.stFlagsAgg: what the loop of
+// cell_static_errors over the S states of a segment's table reports (the sparse M-step kernels walked 660 bytes of flags per sampled segment for it)
+template <int MASK>
+__device__ __forceinline__ void table_static_errors(const SegCtx &sc, unsigned agg, unsigned &err) {
+    if ((MASK & (CM_LA0 | CM_LA1)) && sc.ma) {
+        if (agg & 1u) err |= RMX_ERR_TOTAL_DEPTH;
+        if (agg & 2u) err |= RMX_ERR_LOH_P;
+        if (sc.ys != 0. && (agg & 4u)) err |= RMX_ERR_BAD_P;
     }
 }
 

@@ -26,6 +26,10 @@
 // state tables: depth, allele ratio, dispersion and lgamma(M p), lgamma(M (1-p))
 // per (restart, class, state).  grid (C, nr), block 256.
 __device__ __forceinline__ void state_tables_body(const Dev &d, int cls, int r, const RestartParams &rp) {
+    __shared__ unsigned agg_sh;
+    if (threadIdx.x == 0) agg_sh = 0u;
+    __syncthreads();
+    unsigned agg = 0u;
     for (int s = threadIdx.x; s < d.S; s += blockDim.x) {
         const int8_t *cn = d.cn + ((size_t)cls * d.S + s) * d.M * 2;
         const int8_t *tot = d.tot + ((size_t)cls * d.S + s) * d.M;
@@ -68,7 +72,11 @@ __device__ __forceinline__ void state_tables_body(const Dev &d, int cls, int r, 
         d.stLg[(base * 4 + 2) * d.SP + s] = ok ? lgamma_pos(M1 * p) : 0.;
         d.stLg[(base * 4 + 3) * d.SP + s] = ok ? lgamma_pos(M1 * (1 - p)) : 0.;
         d.stFlags[si] = fl;
+        agg |= ((fl & ST_E_TD) ? 1u : 0u) | ((fl & ST_E_LOH) ? 2u : 0u) | (((fl & ST_E_BADP) && !(fl & (ST_E_TD | ST_E_LOH))) ? 4u : 0u);
     }
+    if (agg) atomicOr(&agg_sh, agg);
+    __syncthreads();
+    if (threadIdx.x == 0) d.stFlagsAgg[(size_t)r * d.C + cls] = agg_sh;
 }
 __global__ void k_state_tables(Dev d, int r0) {
     const int cls = blockIdx.x, r = r0 + blockIdx.y;
@@ -2243,7 +2251,7 @@ __global__ __launch_bounds__(256) void k_trial_sparse(Dev d, int r0) {
     if (cnt == 255) { for (int s = j; s < d.S; s += TRIAL_SEGL) one(s); }
     else {
         for (int jj = j; jj < cnt; jj += TRIAL_SEGL) one((int)d.sig_idx[rn * RMX_SIGK + jj]);
-        if (MASK & (CM_LA0 | CM_LA1)) for (int s = j; s < d.S; s += TRIAL_SEGL) cell_static_errors<MASK>(sc, d.stFlags[((size_t)r * d.C + cls) * d.SP + s], err);
+        if ((MASK & (CM_LA0 | CM_LA1)) && j == 0) table_static_errors<MASK>(sc, d.stFlagsAgg[(size_t)r * d.C + cls], err);
     }
     if (MASK & CM_LT0) { a0 = group_sum(a0, TRIAL_SEGL); if (j == 0) d.A[rn * 2] = a0; }
     if (MASK & CM_LT1) { a1 = group_sum(a1, TRIAL_SEGL); if (j == 0) d.A[rn * 2 + 1] = a1; }
@@ -3072,7 +3080,7 @@ __device__ __forceinline__ void ell_segment_sparse(const Dev &d, const RestartPa
     if (cnt == 255) { for (int s = lane; s < d.S; s += SEGL) one(s); }
     else {
         for (int jj = lane; jj < cnt; jj += SEGL) one((int)d.sig_idx[rn * RMX_SIGK + jj]);
-        for (int s = lane; s < d.S; s += SEGL) cell_static_errors<MASK>(sc, d.stFlags[((size_t)r * d.C + cls) * d.SP + s], err);
+        if (lane == 0) table_static_errors<MASK>(sc, d.stFlagsAgg[(size_t)r * d.C + cls], err);
     }
     acc = group_sum(acc, SEGL);
     if (lane == 0) prow[0] = acc;
@@ -3099,7 +3107,7 @@ __device__ __forceinline__ void ell_segment_sparse_grad(const Dev &d, const Rest
     if (cnt == 255) { for (int s = lane; s < d.S; s += SEGL) ell_state_terms<true, CM_ALL, false>(d, rp, sc, r, cls, s, post[s], qt0, qt1, qa0, qa1, qs0, qs1, acc, g, err); }
     else {
         for (int jj = lane; jj < cnt; jj += SEGL) { const int s = (int)d.sig_idx[rn * RMX_SIGK + jj]; ell_state_terms<true, CM_ALL, false>(d, rp, sc, r, cls, s, post[s], qt0, qt1, qa0, qa1, qs0, qs1, acc, g, err); }
-        for (int s = lane; s < d.S; s += SEGL) cell_static_errors<CM_ALL>(sc, d.stFlags[((size_t)r * d.C + cls) * d.SP + s], err);
+        if (lane == 0) table_static_errors<CM_ALL>(sc, d.stFlagsAgg[(size_t)r * d.C + cls], err);
     }
     acc = group_sum(acc, SEGL);
     if (lane == 0) prow[0] = acc;
