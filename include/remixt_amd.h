@@ -144,8 +144,11 @@ enum rmx_option_id {
     RMX_OPT_FUSE_SWEEPS,        /* 1 (default): marginals + indicator updates + next frame pass as one kernel between sweeps */
     RMX_OPT_TWO_STREAMS,        /* 1 (default): breakend branch of a sweep on a second stream next to the marginal pass */
     RMX_OPT_VITERBI_PLAIN,      /* 1: decode with the table-reading lattice kernel */
-    RMX_OPT_SEARCH_MODE,        /* parameter searches: 0 shared rounds, table-free (default); 1 one parameter at a time; 2 with
-                                   table rebuilds per candidate; 3 with look-ahead evaluations; 4 on the full objective */
+    RMX_OPT_SEARCH_MODE,        /* parameter searches: 0 the four standard searches together in shared rounds driven from the host (default);
+                                   5 in rounds the device drives: optimiser state on the device, a kernel pair per round, queued back to back
+                                   (half the latency; for a batch that has the GPU to itself);
+                                   1 one parameter at a time; 2 with table rebuilds per candidate; 3 with look-ahead evaluations;
+                                   4 on the full objective */
     RMX_OPT_ELL_DENSE,          /* 1: sampled objectives over all states instead of the lists of states with posterior mass */
     RMX_OPT_STRIP,              /* 1 (default): strip kernels for the (segment x state) passes when 32 < S <= 384 */
     RMX_OPT_CELL_CACHE,         /* creation time, 1 (default): cache the six likelihood values of every cell */

@@ -95,6 +95,8 @@ struct rmx_batch {
     hipEvent_t ev_lists = nullptr;     // the scatter kernel that last read h_lists
     uint32_t *h_err = nullptr;         // pinned [4R+64]: landing area of check_errors / per-request error words
     int32_t *d_sample = nullptr;       // [R][N] index lists of the current M-step samples
+    NmState *d_nm_state = nullptr;      // [64]: optimiser state of the device-driven search rounds (k_search_round / k_search_advance)
+    NmLayout nm_lay = {nullptr, nullptr, nullptr}; double *d_nm_partial = nullptr; size_t nm_partial_cap = 0;      // their cell layout and per-block sums
     int32_t *d_msample = nullptr, *d_mcounts = nullptr;   // [4][R][N], [4][R]: per parameter slot, for rmx_param_search_multi
     std::vector<int> msample_count;    // [4][R], -1 = not set
     double *d_mpartial = nullptr; size_t mpartial_cap = 0;
@@ -672,7 +674,7 @@ static bool option_value_ok(int id, int v) {
     switch (id) {
     case RMX_OPT_FB_KERNEL: return v >= 0 && v <= 3;
     case RMX_OPT_FB_NV: return v == 0 || v == 1 || v == 2 || v == 4;      // the workgroup shapes that exist (k_fbm and k_fbv / k_fbk 1 / 2 / 4, k_fbq 4)
-    case RMX_OPT_SEARCH_MODE: return v >= 0 && v <= 4;
+    case RMX_OPT_SEARCH_MODE: return v >= 0 && v <= 5;
     case RMX_OPT_PAIRWISE_KERNEL: return v >= 0 && v <= 3;
     case RMX_OPT_FB_WG_BUDGET: return v >= 0 && v <= 4096;
     default: return v == 0 || v == 1;
@@ -2222,6 +2224,79 @@ int rmx_param_search_multi(rmx_batch *b, int32_t nreq, const int32_t *restarts, 
     };
     std::vector<int> all(Q);
     for (int q = 0; q < Q; q++) all[q] = q;
+    // search_mode 5: rounds the device drives (k_search_round / k_search_advance) -- the optimisers' state lives on the device, a round
+    // is a kernel pair, and the host queues the grid round and a batch of rounds back to back without waiting in between; then it looks
+    // at the finished flags and queues more while any optimiser still runs (at most Nm1::maxfun rounds).  Half the latency of the rounds
+    // driven from the host below (1.15 against 2.5 ms for 8 restarts alone on the GPU), which is what a batch that has the GPU to itself
+    // wants (RestartGroups sets it for a single group: 34.4-35.0 against 36.9-40.7 ms per EM iteration of 8 restarts); next to another
+    // group's sweeps the GPU is throughput-bound and the dense run of kernels costs that group what it saves this one (415-416 against
+    // 424-426 EM iterations/s at the benchmark's two groups of 8), so it is not the default.
+    if (b->opt[RMX_OPT_SEARCH_MODE] == 5 && maxcnt <= NM_MAX_SAMPLE) {
+        if (!b->d_nm_state) {
+            if ((rc = dalloc(b, &b->d_nm_state, (size_t)64)) ||
+                (rc = dalloc(b, &b->nm_lay.pre, (size_t)64 * (NM_MAX_SAMPLE + 1))) || (rc = dalloc(b, &b->nm_lay.fix, (size_t)64 * NM_MAX_SAMPLE)) ||
+                (rc = dalloc(b, &b->nm_lay.k1, (size_t)64 * NM_MAX_SAMPLE))) return rc;
+        }
+        NmArgs na;
+        memset(&na, 0, sizeof(na));
+        for (int j = 0; j < nparams; j++) {
+            na.lo[j] = lo[j]; na.hi[j] = hi[j]; na.maskbit[j] = mv.maskbit[j];
+            for (int g = 0; g < G; g++) { na.gv[j][g] = mv.gv[j][g]; na.glv[j][g] = mv.glv[j][g]; }
+        }
+        for (int q = 0; q < 64; q++) { na.rlist[q] = mv.rlist[q < Q ? q : 0]; na.slot[q] = mv.slot[q < Q ? q : 0]; }
+        na.G = G; na.nreq = Q;
+        // the requests' cells (one wait: the rounds' grid holds exactly the blocks that have cells)
+        double *cells = b->h_pinned + 2 * 64;
+        {
+            std::lock_guard<std::mutex> lk(b->mu);
+            ProfScope ps(b, KID_ELL_LIST);
+            hipLaunchKernelGGL(k_search_setup, dim3(Q), dim3(256), 0, b->stream, b->d, na, (const int32_t *)b->d_msample, (const int32_t *)b->d_mcounts, b->nm_lay, cells);
+            HIPCHK(hipGetLastError());
+        }
+        HIPCHK(hipStreamSynchronize(b->stream));
+        for (int q = 0; q < Q; q++) na.blk0[q + 1] = na.blk0[q] + ((int)cells[q] + 255) / 256;
+        for (int q = Q; q < 64; q++) na.blk0[q + 1] = na.blk0[Q];
+        const int TB = std::max(na.blk0[Q], 1);
+        const size_t pneed = (size_t)G * TB;
+        if (b->nm_partial_cap < pneed) {
+            dfree(b, b->d_nm_partial); b->d_nm_partial = nullptr; b->nm_partial_cap = 0;
+            if ((rc = dalloc(b, &b->d_nm_partial, pneed * 2))) return rc;
+            b->nm_partial_cap = pneed * 2;
+        }
+        uint32_t *done = b->h_err;                  // [Q]: 0 while the request's optimiser runs, then 1 + the restart's error word
+        for (int q = 0; q < Q; q++) done[q] = 0;
+        int queued = 0;
+        bool all_done = false;
+        while (!all_done) {
+            const int batch = queued == 0 ? 52 : 12;      // (the slowest of 32 optimisers needs about 50 evaluations; a round too many is a kernel pair of blocks that return)
+            {
+                std::lock_guard<std::mutex> lk(b->mu);
+                ProfScope ps(b, KID_ELL_LIST);
+                if (queued == 0) {
+                    na.grid_stage = 1;
+                    hipLaunchKernelGGL(k_search_round, dim3(TB, G), dim3(256), 0, b->stream, b->d, na, (const int32_t *)b->d_msample, (const int32_t *)b->d_mcounts,
+                                       b->nm_lay, b->d_nm_partial, (const NmState *)b->d_nm_state);
+                    hipLaunchKernelGGL(k_search_advance, dim3(Q), dim3(256), 0, b->stream, b->d, na, (const double *)b->d_nm_partial, b->d_nm_state, b->h_pinned, done);
+                    na.grid_stage = 0;
+                }
+                for (int k = 0; k < batch; k++) {
+                    hipLaunchKernelGGL(k_search_round, dim3(TB, 1), dim3(256), 0, b->stream, b->d, na, (const int32_t *)b->d_msample, (const int32_t *)b->d_mcounts,
+                                       b->nm_lay, b->d_nm_partial, (const NmState *)b->d_nm_state);
+                    hipLaunchKernelGGL(k_search_advance, dim3(Q), dim3(256), 0, b->stream, b->d, na, (const double *)b->d_nm_partial, b->d_nm_state, b->h_pinned, done);
+                }
+                HIPCHK(hipGetLastError());
+            }
+            queued += batch;
+            HIPCHK(hipStreamSynchronize(b->stream));
+            all_done = true;
+            for (int q = 0; q < Q; q++) all_done = all_done && done[q] != 0;
+            if (queued > Nm1::maxfun + 16) return fail(RMX_EDEVICE, "rmx_param_search_multi: an optimiser did not finish");      // (cannot happen: Nm1 stops at maxfun evaluations)
+        }
+        for (int q = 0; q < Q; q++) done[q] -= 1u;
+        if (int rc_ = report_request_errors(b, Q, done, [&](int q) { return (int)mv.rlist[q]; })) return rc_;
+        for (int q = 0; q < Q; q++) { xopt[q] = b->h_pinned[2 * q]; lastval[q] = b->h_pinned[2 * q + 1]; }
+        return RMX_OK;
+    }
     if ((rc = round(Q, all.data(), nullptr, true))) return rc;
     std::vector<double> x0(Q), best(Q, INFINITY);
     for (int q = 0; q < Q; q++) {

@@ -15,6 +15,13 @@
 #include <cstring>
 #include <vector>
 
+// (Nm1 also runs inside a kernel: k_param_search_nm)
+#if defined(__HIPCC__)
+#define RMX_HD __host__ __device__
+#else
+#define RMX_HD
+#endif
+
 namespace rmxh {
 
 inline int compress_cn_states(const int64_t *cn_states, int32_t N, int32_t S, int32_t M, int32_t max_classes,
@@ -93,10 +100,10 @@ struct Nm1 {
     int fcalls = 0, iters = 0, state = START;
     static constexpr int maxfun = 200, maxiter = 200;
     static constexpr double xatol = 1e-4, fatol = 1e-4;
-    bool request(double x, int next) { if (fcalls >= maxfun) return false; fcalls++; req = x; last = x; state = next; return true; }
-    void sort() { if (f1 < f0) { std::swap(f0, f1); std::swap(s0, s1); } }
+    RMX_HD bool request(double x, int next) { if (fcalls >= maxfun) return false; fcalls++; req = x; last = x; state = next; return true; }
+    RMX_HD void sort() { if (f1 < f0) { double t_ = f0; f0 = f1; f1 = t_; t_ = s0; s0 = s1; s1 = t_; } }
     // feed the value of the last request (ignored on the first call); true = `req` holds the next point
-    bool advance(double x0, double f) {
+    RMX_HD bool advance(double x0, double f) {
 #pragma clang fp contract(off)
         switch (state) {
         case START:
@@ -165,7 +172,7 @@ struct Nm1 {
         state = DONE;
         return false;
     }
-    double xopt() const { return s0; }
+    RMX_HD double xopt() const { return s0; }
     // the points the NEXT call of advance() can request, whatever value the pending request gets (same
     // expressions as above): after the first initial point the second one; after a reflection the
     // expansion, the outside and the inside contraction

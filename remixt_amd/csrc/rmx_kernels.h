@@ -10,6 +10,7 @@
 // the breakpoint update and the ELBO actually need it.
 #pragma once
 #include "rmx_device.h"
+#include "rmx_host.h"      // rmxh::Nm1 (k_param_search_nm)
 // Lanes per segment in the kernels that walk the per-segment lists of states with posterior mass (mean 13 listed states, at most 32).
 // The sampled objectives of the M-step rounds (<= 200 segments per request: one workgroup wave, latency-bound) keep half a wave per
 // segment -- every listed state in one step; the trial passes over all segments (throughput-bound) take a quarter wave and a second
@@ -3352,6 +3353,195 @@ __global__ void k_ell_multi_final(Dev d, MultiVals mv, const int32_t *counts, co
     for (int i = threadIdx.x; i < cnt; i += 256) a += partial[(size_t)blockIdx.x * maxcnt + i];
     a = block_sum<256>(a, scratch);
     if (threadIdx.x == 0) out[blockIdx.x] = a;
+}
+// ---- those searches in rounds the DEVICE drives (round 4; search_mode 5) ---------------------------------------------
+// The rounds above cost a launch pair, a stream wait and the host's optimiser step each, fifty times per M-step, and their kernel
+// is as long as its slowest half-wave: a sampled segment whose list of states overflowed walks six cells per lane, and the
+// samples of the outlier dispersions are weighted towards exactly those segments (30 us for 10 us of work).  Here
+//   * the optimisers' state (rmxh::Nm1, the state machine the host drives in the round-based path) lives in device memory and a
+//     round is a kernel pair with nothing in between (back-to-back kernels of a stream start within a microsecond of each other):
+//     k_search_round evaluates, k_search_advance (a block per request) sums the blocks' partial sums in a fixed order, feeds the
+//     value to the request's optimiser and leaves the next point in its state -- or, when it is finished, the result in
+//     host-visible memory.  The host queues the grid round and a batch of rounds back to back without waiting, then looks at the
+//     finished flags (a round of a finished request is blocks that return).  (One kernel per round with a last-block ticket was
+//     measured first: a release fence per block -- an L2 write-back -- made the round longer than the kernel pair.);
+//   * a request's (sampled segment, listed state) CELLS are laid out flat, one per thread (k_search_setup: prefix sums of the
+//     segments' cell counts, and the candidate-free parts of the per-segment constants); a block first evaluates the candidate's
+//     constant for the few segments its 256 cells belong to (LDS), then its cells.
+// Same per-cell expressions as ell_segment_sparse (cell_ll_regs and the register override of the betabin tables); the sum runs
+// over blocks of cells instead of segments and log(candidate) of the Nelder-Mead points is the device's: values differ from the
+// round-based path's by rounding.  Points outside [lo, hi] are +inf without an evaluation (cn_model.py:542-543).
+struct NmState {
+    rmxh::Nm1 nm;
+    double x0, last, v, lv;
+    int32_t done, pad0;
+};
+struct NmArgs {
+    double lo[4], hi[4];
+    double gv[4][RMX_MULTI_G], glv[4][RMX_MULTI_G];
+    int16_t rlist[64];
+    int8_t slot[64];
+    int32_t maskbit[4];
+    int32_t G, grid_stage;
+    int32_t blk0[65];             // blocks of 256 cells before request q (k_search_round's grid is the requests' blocks one after the other)
+    int32_t nreq;
+};
+#define NM_MAX_SAMPLE 1024
+struct NmLayout {                 // per request q, rows of pitch NM_MAX_SAMPLE (+ 1)
+    int32_t *pre;                 // [64][NM_MAX_SAMPLE + 1] cells before sampled segment i; pre[cnt] = the request's cells
+    double *fix, *k1;             // [64][NM_MAX_SAMPLE] candidate-free part of the component's constant; constant of the other dispersion
+};
+__device__ __forceinline__ int nm_const_index(int mask) { return mask == CM_LT0 ? 0 : (mask == CM_LT1 ? 2 : (mask == CM_LA0 ? 4 : 6)); }
+// grid (nreq), block 256
+__global__ __launch_bounds__(256) void k_search_setup(Dev d, NmArgs na, const int32_t *samples, const int32_t *counts, NmLayout lay, double *cells_out) {
+    __shared__ int cl[NM_MAX_SAMPLE + 1];
+    const int req = blockIdx.x, r = na.rlist[req], sl = na.slot[req], mask = na.maskbit[sl];
+    const int cnt = counts[sl * d.R + r];
+    const int32_t *smp = samples + ((size_t)sl * d.R + r) * d.N;
+    const bool nb = (mask & (CM_LT0 | CM_LT1)) != 0;
+    const RestartParams &rp = d.rp[r];
+    unsigned err = 0;
+    for (int i = threadIdx.x; i < cnt; i += 256) {
+        const int n = smp[i];
+        const int c = d.sig_cnt[(size_t)r * d.N + n];
+        cl[i + 1] = c == 255 ? d.S : c;
+        const double x = d.x[n], y0 = d.y[2 * (size_t)n], ys = y0 + d.y[2 * (size_t)n + 1];
+        lay.k1[(size_t)req * NM_MAX_SAMPLE + i] = seg_const_value(rp, x, y0, ys, nm_const_index(mask) + 1);
+        lay.fix[(size_t)req * NM_MAX_SAMPLE + i] = nb ? lgamma_pos(x + 1) : (lgamma_pos(ys + 1) - lgamma_pos(y0 + 1) - lgamma_pos(ys - y0 + 1));
+        // the table flags of the states off the list (ell_segment_sparse reports them per evaluation)
+        if (c != 255 && !nb) { SegCtx sc; sc.ma = d.mask_a[n]; sc.ys = ys; table_static_errors<CM_LA0>(sc, d.stFlagsAgg[(size_t)r * d.C + d.seg_class[n]], err); }
+    }
+    if (threadIdx.x == 0) cl[0] = 0;
+    __syncthreads();
+    if (threadIdx.x == 0) for (int i = 0; i < cnt; i++) cl[i + 1] += cl[i];
+    __syncthreads();
+    for (int i = threadIdx.x; i <= cnt; i += 256) lay.pre[(size_t)req * (NM_MAX_SAMPLE + 1) + i] = cl[i];
+    if (threadIdx.x == 0) cells_out[req] = (double)cl[cnt];      // (host-visible: the host sizes the rounds' grid from it)
+    if (err) atomicOr(&d.err[r], err);
+}
+template <int MASK>
+__device__ __forceinline__ double nm_cell(const Dev &d, int r, int n, int s, double v, double lv, double k0, double k1, unsigned &err) {
+    RestartParams rp = d.rp[r];
+    if (MASK == CM_LT0) { rp.p[RMX_P_NEGBIN_R_0] = v; rp.logr[0] = lv; }
+    if (MASK == CM_LT1) { rp.p[RMX_P_NEGBIN_R_1] = v; rp.logr[1] = lv; }
+    if (MASK == CM_LA0) rp.p[RMX_P_BETABIN_M_0] = v;
+    if (MASK == CM_LA1) rp.p[RMX_P_BETABIN_M_1] = v;
+    SegCtx sc;
+    sc.x = d.x[n]; sc.l = d.l[n]; sc.logl = d.logl[n]; sc.y0 = d.y[2 * (size_t)n]; sc.y1 = d.y[2 * (size_t)n + 1]; sc.ys = sc.y0 + sc.y1;
+    sc.mt = d.mask_t[n]; sc.ma = d.mask_a[n];
+#pragma unroll
+    for (int k = 0; k < 4; k++) { sc.cnb[k] = 0.; sc.cbb[k] = 0.; }
+    if (MASK == CM_LT0) { sc.cnb[0] = k0; sc.cnb[1] = k1; }
+    if (MASK == CM_LT1) { sc.cnb[2] = k0; sc.cnb[3] = k1; }
+    if (MASK == CM_LA0) { sc.cbb[0] = k0; sc.cbb[1] = k1; }
+    if (MASK == CM_LA1) { sc.cbb[2] = k0; sc.cbb[3] = k1; }
+    const size_t rn = (size_t)r * d.N + n;
+    StateRegs st_; load_state_regs(d, r, d.seg_class[n], s, st_);
+    if ((MASK & (CM_LA0 | CM_LA1)) && !(st_.fl & ST_LOH_M)) {
+        const bool ok_ = !(st_.fl & (ST_E_BADP | ST_E_TD | ST_E_LOH));      // as state_tables_body
+        if (MASK & CM_LA0) { st_.M0 = v; st_.lgA0 = ok_ ? lgamma_pos(v * st_.p) : 0.; st_.lgB0 = ok_ ? lgamma_pos(v * (1 - st_.p)) : 0.; }
+        if (MASK & CM_LA1) { st_.M1 = v; st_.lgA1 = ok_ ? lgamma_pos(v * st_.p) : 0.; st_.lgB1 = ok_ ? lgamma_pos(v * (1 - st_.p)) : 0.; }
+    }
+    double LT[2], LA[4];
+    cell_ll_regs<MASK>(rp, sc, st_, LT, LA, err);
+    const double ps = d.post[rs_off(d, r, n) + s];
+    double acc = 0.;
+    if (MASK & CM_LT0) acc += ps * d.qt[rn * 2] * LT[0];
+    if (MASK & CM_LT1) acc += ps * d.qt[rn * 2 + 1] * LT[1];
+    if (MASK & CM_LA0) { const double qa0 = d.qa[rn * 2]; acc += ps * qa0 * d.qs[rn * 2] * LA[0]; acc += ps * qa0 * d.qs[rn * 2 + 1] * LA[1]; }
+    if (MASK & CM_LA1) { const double qa1 = d.qa[rn * 2 + 1]; acc += ps * qa1 * d.qs[rn * 2] * LA[2]; acc += ps * qa1 * d.qs[rn * 2 + 1] * LA[3]; }
+    return acc;
+}
+// grid (blk0[nreq], grid_stage ? G : 1), block 256.  partial [Gz][blk0[nreq]].
+__global__ __launch_bounds__(256) void k_search_round(Dev d, NmArgs na, const int32_t *samples, const int32_t *counts, NmLayout lay, double *partial, const NmState *state) {
+    __shared__ int pre[NM_MAX_SAMPLE + 1];
+    __shared__ double k0s[NM_MAX_SAMPLE];
+    __shared__ double scratch[8];
+    const int gz = blockIdx.y, tid = threadIdx.x;
+    int req = 0;
+    while (req + 1 < na.nreq && (int)blockIdx.x >= na.blk0[req + 1]) req++;
+    const NmState &st = state[req];
+    if (!na.grid_stage && st.done) return;
+    const int r = na.rlist[req], sl = na.slot[req], mask = na.maskbit[sl];
+    const int cnt = counts[sl * d.R + r];
+    const int T = lay.pre[(size_t)req * (NM_MAX_SAMPLE + 1) + cnt];
+    const int c0 = ((int)blockIdx.x - na.blk0[req]) * 256;
+    if (c0 >= T) return;
+    const int32_t *smp = samples + ((size_t)sl * d.R + r) * d.N;
+    const double v = na.grid_stage ? na.gv[sl][gz] : st.v, lv = na.grid_stage ? na.glv[sl][gz] : st.lv;
+    for (int i = tid; i <= cnt; i += 256) pre[i] = lay.pre[(size_t)req * (NM_MAX_SAMPLE + 1) + i];
+    __syncthreads();
+    auto segment_of = [&](int c) {      // the last segment i with pre[i] <= c (empty segments are skipped: pre[i + 1] > c)
+        int lo_ = 0, hi_ = cnt;
+        while (hi_ - lo_ > 1) { const int mid = (lo_ + hi_) >> 1; if (pre[mid] <= c) lo_ = mid; else hi_ = mid; }
+        return lo_;
+    };
+    const int i_first = segment_of(c0), i_last = segment_of(min(c0 + 255, T - 1));
+    // the candidate's constant of the segments this block's cells belong to: seg_const_value with its candidate-free part from the setup
+    const bool nb = (mask & (CM_LT0 | CM_LT1)) != 0;
+    for (int k = tid; k <= i_last - i_first; k += 256) {
+        const int i = i_first + k, n = smp[i];
+        const double fx = lay.fix[(size_t)req * NM_MAX_SAMPLE + i];
+        if (nb) k0s[k] = lgamma_pos(d.x[n] + v) - fx - lgamma_pos(v);
+        else { const double ys = d.y[2 * (size_t)n] + d.y[2 * (size_t)n + 1]; k0s[k] = fx - lgamma_pos(ys + v) + lgamma_pos(v); }
+    }
+    __syncthreads();
+    double acc = 0.;
+    unsigned err = 0;
+    const int c = c0 + tid;
+    if (c < T) {
+        const int i = segment_of(c), jj = c - pre[i], n = smp[i];
+        const size_t rn = (size_t)r * d.N + n;
+        const int s = d.sig_cnt[rn] == 255 ? jj : (int)d.sig_idx[rn * RMX_SIGK + jj];
+        const double k0 = k0s[i - i_first], k1 = lay.k1[(size_t)req * NM_MAX_SAMPLE + i];
+        switch (mask) {
+        case CM_LT0: acc = nm_cell<CM_LT0>(d, r, n, s, v, lv, k0, k1, err); break;
+        case CM_LT1: acc = nm_cell<CM_LT1>(d, r, n, s, v, lv, k0, k1, err); break;
+        case CM_LA0: acc = nm_cell<CM_LA0>(d, r, n, s, v, lv, k0, k1, err); break;
+        default:     acc = nm_cell<CM_LA1>(d, r, n, s, v, lv, k0, k1, err); break;
+        }
+    }
+    if (err) atomicOr(&d.err[r], err);
+    acc = block_sum<256>(acc, scratch);
+    if (tid == 0) partial[(size_t)gz * gridDim.x + blockIdx.x] = acc;
+}
+// grid (nreq), block 256.  out[q] = {xopt, last point evaluated}; done_out[q] = 1 + the restart's error word
+__global__ __launch_bounds__(256) void k_search_advance(Dev d, NmArgs na, const double *partial, NmState *state, double *out, uint32_t *done_out) {
+    __shared__ double scratch[8];
+    const int req = blockIdx.x, tid = threadIdx.x;
+    NmState &st = state[req];
+    if (!na.grid_stage && st.done) return;
+    const int Gz = na.grid_stage ? na.G : 1;
+    const int r = na.rlist[req], sl = na.slot[req];
+    const int b0 = na.blk0[req], nbq = na.blk0[req + 1] - b0, TB = na.blk0[na.nreq];
+    double f = 0., x0 = 0., best = INFINITY;
+    for (int g = 0; g < Gz; g++) {
+        double a = 0.;
+        for (int k = tid; k < nbq; k += 256) a += partial[(size_t)g * TB + b0 + k];
+        a = block_sum<256>(a, scratch);
+        if (tid == 0) {
+            if (na.grid_stage) { const double J = -a; if (g == 0 || J < best) { best = J; x0 = na.gv[sl][g]; } }      // np.argmin: first minimum
+            else f = -a;
+        }
+    }
+    if (tid != 0) return;
+    rmxh::Nm1 nm;                      // (a copy in registers: advancing it in place is a chain of dependent global accesses)
+    double last;
+    if (na.grid_stage) { last = na.gv[sl][na.G - 1]; st.x0 = x0; }
+    else { nm = st.nm; x0 = st.x0; last = st.last; }
+    const double lo = na.lo[sl], hi = na.hi[sl];
+    bool go = false;
+    while (nm.advance(x0, f)) {
+        const double v = nm.req;
+        if (v < lo || v > hi) { f = INFINITY; continue; }
+        st.v = v; st.lv = log(v); last = v; go = true;
+        break;
+    }
+    st.nm = nm; st.last = last; st.done = go ? 0 : 1;
+    if (!go) {
+        out[2 * req] = nm.xopt(); out[2 * req + 1] = last;
+        done_out[req] = 1u + d.err[r];
+    }
 }
 // grid (nreq * Gz): the sum of k_ell_final_batch over the partials of (request, candidate)
 __global__ void k_ell_search_final(Dev d, SearchVals sv, const int32_t *counts, const double *partial, int maxcnt, double *out, uint32_t *err_out) {

@@ -218,7 +218,7 @@ class RestartSet(object):
             if name not in self._MULTI_PARAMS or len(first) == 4:
                 break
             first.append(name)
-        sequential = b is not None and hasattr(b, 'get_option') and b.get_option('search_mode') != 0
+        sequential = b is not None and hasattr(b, 'get_option') and b.get_option('search_mode') not in (0, 5)
         if not (first and self.native_search and b is not None and hasattr(b, 'param_search_multi')) or sequential:
             return []
         return first
@@ -653,6 +653,11 @@ class RestartGroups(object):
         if self.paced:
             for rs in self.sets:
                 rs.batch.set_option('pace_sweeps', 1)
+        # A single group has the GPU to itself: its parameter searches run as rounds the device drives (library option search_mode 5: half the
+        # latency of the rounds driven from the host; next to another group's sweeps the GPU is throughput-bound and they gain nothing) -- unless
+        # the caller chose a search mode
+        if len(self.sets) == 1 and native and 'search_mode' not in (kwargs.get('options') or {}):
+            self.sets[0].batch.set_option('search_mode', 5)
 
     @property
     def num_restarts(self):

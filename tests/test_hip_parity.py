@@ -382,6 +382,7 @@ def test_lockstep_mstep_equals_per_restart_mstep(hip):
         (True, True, 3),      # 4: native, one at a time, rounds that also evaluate the optimisers' possible next points
         (True, True, 1),      # 5: native, one at a time, table-free rounds
         (True, True, 0),      # 6: as 0, but one accept pass over the cells per parameter instead of one for all four
+        (True, True, 5),      # 7: the shared rounds driven by the device (cells laid out flat over the threads)
     ]
     out = []
     for ci, (lock, native, mode) in enumerate(configs):
@@ -402,7 +403,7 @@ def test_lockstep_mstep_equals_per_restart_mstep(hip):
         assert e1 == e2 and np.array_equal(h1, h2) and p1 == p2
     # the native searches evaluate only the likelihood component the parameter moves (plus, one at a time, the
     # rest as a constant from one full evaluation; none in the shared rounds): same objective up to rounding
-    for a_, b_ in ((0, 1), (5, 1), (0, 5)):
+    for a_, b_ in ((0, 1), (5, 1), (0, 5), (7, 0), (7, 5)):
         for (e1, h1, p1), (e2, h2, p2) in zip(out[a_], out[b_]):
             assert abs(e1 - e2) <= 1e-8 * abs(e2)
             np.testing.assert_allclose(h1, h2, rtol=1e-6)
