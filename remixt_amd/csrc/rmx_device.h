@@ -143,6 +143,36 @@ __device__ __forceinline__ double fast_log_pos(double x) {
     return dk * 6.93147180369123816490e-01 - ((hfsq - (s_ * (hfsq + R) + dk * 1.90821492927058770002e-10)) - f);
 }
 
+// ---- exponential for the indicator updates and the scaled emissions -------------------------------
+// exp(x) for x <= ~700: k = rint(x / ln 2), r = x - k ln 2 (two-part constant), Taylor polynomial of degree 13 on |r| <= 0.35,
+// v_ldexp_f64 (which also rounds into the subnormals); below -746 the result is 0 (covers -inf), NaN stays NaN.  21 instructions
+// against 48 for the library routine; 0.88 ulp worst case over 2e7 arguments in [-700, 0] (tools/micro/exp_fast_check.cpp; libm: 0.51).
+// The fused marginal pass is bound by VALU issue (one instruction = 4 cycles of a SIMD whatever it does): seven of these and two
+// logarithms per segment were 500 of its 1 350 instructions.
+__device__ __forceinline__ double exp_fast(double x) {
+    const double k = __builtin_rint(x * 1.4426950408889634074);
+    double r = fma(-k, 6.93147180369123816490e-01, x);
+    r = fma(-k, 1.90821492927058770002e-10, r);
+    double p = 1.6059043836821613e-10;              // 1/13! ... 1/2!
+    p = fma(p, r, 2.08767569878681e-09);
+    p = fma(p, r, 2.505210838544172e-08);
+    p = fma(p, r, 2.755731922398589e-07);
+    p = fma(p, r, 2.7557319223985893e-06);
+    p = fma(p, r, 2.48015873015873e-05);
+    p = fma(p, r, 1.984126984126984e-04);
+    p = fma(p, r, 1.388888888888889e-03);
+    p = fma(p, r, 8.333333333333333e-03);
+    p = fma(p, r, 4.1666666666666664e-02);
+    p = fma(p, r, 1.6666666666666666e-01);
+    p = fma(p, r, 0.5);
+    p = fma(p, r, 1.0);
+    p = fma(p, r, 1.0);
+    const double v = ldexp(p, (int)k);
+    return x < -746. ? 0. : v;
+}
+// log of a prior probability: the lean routine inside (0, 1), the library's at the ends (log(0) = -inf as numpy gives it)
+__device__ __forceinline__ double log_prior(double p) { return (p > 1e-300 && p < 1.) ? fast_log_pos(p) : log(p); }
+
 // log(1 + t) for t > 0 with the rounding of 1 + t compensated
 __device__ __forceinline__ double fast_log1p_pos(double t) {
     const double u = 1.0 + t;
@@ -318,11 +348,27 @@ __device__ __forceinline__ double cell_prior(const Dev &d, const RestartParams &
 // two-element _exp_normalize (bpmodel.pyx:120-128), same operation order
 __device__ __forceinline__ void exp_normalize2(double lp0, double lp1, double &y0, double &y1) {
     const double vmax = lp0 > lp1 ? lp0 : lp1;   // _max: strict > from -inf
-    double ps = 0.; ps += exp(lp0 - vmax); ps += exp(lp1 - vmax);
-    const double norm = log(ps) + vmax;
-    y0 = exp(lp0 - norm); y1 = exp(lp1 - norm);
+    double ps = 0.; ps += exp_fast(lp0 - vmax); ps += exp_fast(lp1 - vmax);
+    const double norm = fast_log_pos(ps) + vmax;      // (ps in [1, 2], or NaN)
+    y0 = exp_fast(lp0 - norm); y1 = exp_fast(lp1 - norm);
     const double s = y0 + y1;
     y0 /= s; y1 /= s;
+}
+
+// The logits of update_p_outlier_allele (bpmodel.pyx:1005-1023) and update_p_allele_swap (:1025-1042) from the four allele expectations:
+// sums of two products, which the compiler is free to contract into fused multiply-adds either way round -- it did so differently in
+// different kernels, visible where one product is 1e-60 of the other (one indicator in 4 200 off by an ulp).  One helper for the
+// stand-alone kernels and the fused passes, with the fused multiply-adds written out.
+__device__ __forceinline__ void outlier_allele_logits(double prior0, double prior1, double qs0, double qs1, double b0, double b1, double b2, double b3,
+                                                      double &lp0, double &lp1) {
+#pragma clang fp contract(off)
+    lp0 = fma(qs0, b0, prior0); lp0 = fma(qs1, b1, lp0);
+    lp1 = fma(qs0, b2, prior1); lp1 = fma(qs1, b3, lp1);
+}
+__device__ __forceinline__ void allele_swap_logits(double qa0, double qa1, double b0, double b1, double b2, double b3, double &lp0, double &lp1) {
+#pragma clang fp contract(off)
+    lp0 = qa0 * b0; lp1 = qa0 * b1;
+    lp0 = fma(qa1, b2, lp0); lp1 = fma(qa1, b3, lp1);
 }
 
 __device__ __forceinline__ double xlogx(double v) { return v > 0. ? v * log(v) : 0.; }

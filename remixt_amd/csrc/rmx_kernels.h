@@ -144,7 +144,7 @@ __global__ void k_framelogprob(Dev d, int r0, int G) {
     if (gl == 0) d.fmax[(size_t)r * d.N + n] = vmax;
     // scaled linear-domain emissions for the forward-backward kernel (each lane re-reads its own stores)
     double *erow = d.fe + rs_off(d, r, n);
-    for (int s = gl; s < d.SP; s += G) erow[s] = s < d.S ? exp(frow[s] - vmax) : 0.;
+    for (int s = gl; s < d.SP; s += G) erow[s] = s < d.S ? exp_fast(frow[s] - vmax) : 0.;
     if (err) atomicOr(&d.err[r], err);
 }
 
@@ -1996,7 +1996,7 @@ __global__ __launch_bounds__(256) void k_cells(Dev d, int r0) {
     double lp_prior[4] = {0., 0., 0., 0.};
     if (MODE == 3) {
         const double pt_ = rp.p[RMX_P_PRIOR_OUTLIER_TOTAL], pa_ = rp.p[RMX_P_PRIOR_OUTLIER_ALLELE];
-        lp_prior[0] = log(1. - pt_); lp_prior[1] = log(pt_); lp_prior[2] = log(1. - pa_); lp_prior[3] = log(pa_);
+        lp_prior[0] = log_prior(1. - pt_); lp_prior[1] = log_prior(pt_); lp_prior[2] = log_prior(1. - pa_); lp_prior[3] = log_prior(pa_);
     }
     // posterior passes: the forward / backward rows of the NEXT segment of the strip are requested while this one is processed
     // (the pass is a chain of dependent steps per segment: rows -> sum -> six planes -> sums -> indicators -> write)
@@ -2043,7 +2043,7 @@ __global__ __launch_bounds__(256) void k_cells(Dev d, int r0) {
             vmax = group_max(vmax, 64);
             if (lane == 0) d.fmax[rn] = vmax;
 #pragma unroll
-            for (int k = 0; k < NS; k++) { const int s = lane + 64 * k; if (s < d.SP) d.fe[ro + s] = s < S ? exp(fv[k] - vmax) : 0.; }
+            for (int k = 0; k < NS; k++) { const int s = lane + 64 * k; if (s < d.SP) d.fe[ro + s] = s < S ? exp_fast(fv[k] - vmax) : 0.; }
         } else {
             constexpr bool M1 = MODE == 1 || MODE == 3;
             // planes of the cell cache kept in a wave-private LDS stash between the pass's two reads of them (expectations, then the next sweep's
@@ -2152,30 +2152,28 @@ __global__ __launch_bounds__(256) void k_cells(Dev d, int r0) {
                 lpt0 += a0; lpt1 += a1;
                 // update_p_outlier_allele (:1005-1023), with this sweep's allele-swap indicator
                 const double qs0o = d.qs[rn * 2], qs1o = d.qs[rn * 2 + 1];
-                double lpa0 = lp_prior[2], lpa1 = lp_prior[3];
-                lpa0 += qs0o * b0; lpa0 += qs1o * b1;
-                lpa1 += qs0o * b2; lpa1 += qs1o * b3;
+                double lpa0, lpa1;
+                outlier_allele_logits(lp_prior[2], lp_prior[3], qs0o, qs1o, b0, b1, b2, b3, lpa0, lpa1);
                 const double vmt = lpt0 > lpt1 ? lpt0 : lpt1, vma = lpa0 > lpa1 ? lpa0 : lpa1;       // _max: strict > from -inf
                 const double lp_l = lane == 0 ? lpt0 : (lane == 1 ? lpt1 : (lane == 2 ? lpa0 : lpa1));
                 const double vm_l = lane < 2 ? vmt : vma;
-                const double ex = exp(lp_l - vm_l);
+                const double ex = exp_fast(lp_l - vm_l);
                 double pst = 0.; pst += lane_of(ex, 0); pst += lane_of(ex, 1);
                 double psa = 0.; psa += lane_of(ex, 2); psa += lane_of(ex, 3);
-                const double lg = log(lane < 2 ? pst : psa);
+                const double lg = fast_log_pos(lane < 2 ? pst : psa);
                 const double norm_l = lg + vm_l;
-                const double y_l = exp(lp_l - norm_l);
+                const double y_l = exp_fast(lp_l - norm_l);
                 double qt0 = lane_of(y_l, 0), qt1 = lane_of(y_l, 1), qa0 = lane_of(y_l, 2), qa1 = lane_of(y_l, 3);
                 { const double st_ = qt0 + qt1; qt0 /= st_; qt1 /= st_; const double sa_ = qa0 + qa1; qa0 /= sa_; qa1 /= sa_; }
                 // the next sweep's update_p_allele_swap (:1025-1042)
-                double lps0 = 0., lps1 = 0.;
-                lps0 += qa0 * b0; lps1 += qa0 * b1;
-                lps0 += qa1 * b2; lps1 += qa1 * b3;
+                double lps0, lps1;
+                allele_swap_logits(qa0, qa1, b0, b1, b2, b3, lps0, lps1);
                 const double vms = lps0 > lps1 ? lps0 : lps1;
                 const double lps_l = (lane & 1) ? lps1 : lps0;
-                const double exs = exp(lps_l - vms);
+                const double exs = exp_fast(lps_l - vms);
                 double pss = 0.; pss += lane_of(exs, 0); pss += lane_of(exs, 1);
-                const double norms = log(pss) + vms;
-                const double ys_l = exp(lps_l - norms);
+                const double norms = fast_log_pos(pss) + vms;
+                const double ys_l = exp_fast(lps_l - norms);
                 double qs0 = lane_of(ys_l, 0), qs1 = lane_of(ys_l, 1);
                 { const double ss_ = qs0 + qs1; qs0 /= ss_; qs1 /= ss_; }
                 if (lane == 0) {
@@ -2213,7 +2211,7 @@ __global__ __launch_bounds__(256) void k_cells(Dev d, int r0) {
                 vmax = group_max(vmax, 64);
                 if (lane == 0) d.fmax[rn] = vmax;
 #pragma unroll
-                for (int k = 0; k < NS; k++) { const int s = lane + 64 * k; if (s < d.SP) d.fe_alt[ro + s] = s < S ? exp(fv[k] - vmax) : 0.; }
+                for (int k = 0; k < NS; k++) { const int s = lane + 64 * k; if (s < d.SP) d.fe_alt[ro + s] = s < S ? exp_fast(fv[k] - vmax) : 0.; }
             }
         }
     }
@@ -2269,7 +2267,7 @@ __global__ void k_update_outlier_total(Dev d, int r0) {   // bpmodel.pyx:987-100
     if (n >= d.N) return;
     const size_t rn = (size_t)r * d.N + n;
     const double prior = d.rp[r].p[RMX_P_PRIOR_OUTLIER_TOTAL];
-    double lp0 = log(1. - prior), lp1 = log(prior);
+    double lp0 = log_prior(1. - prior), lp1 = log_prior(prior);
     lp0 += d.A[rn * 2]; lp1 += d.A[rn * 2 + 1];
     double y0, y1; exp_normalize2(lp0, lp1, y0, y1);
     d.qt[rn * 2] = y0; d.qt[rn * 2 + 1] = y1;
@@ -2280,9 +2278,8 @@ __global__ void k_update_outlier_allele(Dev d, int r0) {  // bpmodel.pyx:1005-10
     const size_t rn = (size_t)r * d.N + n;
     const double prior = d.rp[r].p[RMX_P_PRIOR_OUTLIER_ALLELE];
     const double qs0 = d.qs[rn * 2], qs1 = d.qs[rn * 2 + 1];
-    double lp0 = log(1. - prior), lp1 = log(prior);
-    lp0 += qs0 * d.Bv[rn * 4 + 0]; lp0 += qs1 * d.Bv[rn * 4 + 1];
-    lp1 += qs0 * d.Bv[rn * 4 + 2]; lp1 += qs1 * d.Bv[rn * 4 + 3];
+    double lp0, lp1;
+    outlier_allele_logits(log_prior(1. - prior), log_prior(prior), qs0, qs1, d.Bv[rn * 4 + 0], d.Bv[rn * 4 + 1], d.Bv[rn * 4 + 2], d.Bv[rn * 4 + 3], lp0, lp1);
     double y0, y1; exp_normalize2(lp0, lp1, y0, y1);
     d.qa[rn * 2] = y0; d.qa[rn * 2 + 1] = y1;
 }
@@ -2291,9 +2288,8 @@ __global__ void k_update_allele_swap(Dev d, int r0) {     // bpmodel.pyx:1025-10
     if (n >= d.N) return;
     const size_t rn = (size_t)r * d.N + n;
     const double qa0 = d.qa[rn * 2], qa1 = d.qa[rn * 2 + 1];
-    double lp0 = 0., lp1 = 0.;
-    lp0 += qa0 * d.Bv[rn * 4 + 0]; lp1 += qa0 * d.Bv[rn * 4 + 1];
-    lp0 += qa1 * d.Bv[rn * 4 + 2]; lp1 += qa1 * d.Bv[rn * 4 + 3];
+    double lp0, lp1;
+    allele_swap_logits(qa0, qa1, d.Bv[rn * 4 + 0], d.Bv[rn * 4 + 1], d.Bv[rn * 4 + 2], d.Bv[rn * 4 + 3], lp0, lp1);
     double y0, y1; exp_normalize2(lp0, lp1, y0, y1);
     d.qs[rn * 2] = y0; d.qs[rn * 2 + 1] = y1;
 }
