@@ -246,7 +246,7 @@ __device__ __forceinline__ void load_state_regs(const Dev &d, int r, int cls, in
 // >= 1 -- far under half an ulp, the rounded sum is the same.  (Posteriors concentrate on a few
 // neighbouring states; whole 64-state groups are skipped on most segments.)
 #define RMX_POST_EPS 1e-30
-#define RMX_SIGK 32        // capacity of the per-segment list of states with posterior mass
+#define RMX_SIGK 64        // capacity of the per-segment list of states with posterior mass (32 until round 4: the weighted M-step samples pick the segments with the longest lists, and an overflowed list walks all states)
 
 // component mask of cell_ll_regs: which of the six values the caller needs
 #define CM_LT0 1
