@@ -559,7 +559,9 @@ def _release(rs_main):
     import gc
     if rs_main is None:
         return
-    for s_ in rs_main.sets:          # release the headline batches' device memory
+    for s_ in rs_main.sets:          # release the batches' device memory, streams and events NOW (the next measurement's streams are to find the hardware queues free)
+        if hasattr(s_, 'close'):
+            s_.close()
         s_.batch = None
         for m in s_.models:
             m.model = None

@@ -574,6 +574,14 @@ class RestartSet(object):
         results = lockstep.run_lockstep([lockstep.fmin_1d(xmin[r]) for r in ids_all], evaluate)
         return np.array([float(res[0][0]) for res in results])
 
+    def close(self):
+        """Destroy the device batch now (its memory, streams and events) instead of whenever the last reference goes."""
+        b, self.batch = self.batch, None
+        for m in self.models:
+            m.model = None
+        if b is not None and hasattr(b, 'close'):
+            b.close()
+
     def fit(self, num_em_iter=5, num_update_iter=5):
         elbo0 = self.calculate_elbo()
         for m, e in zip(self.models, elbo0):
@@ -659,6 +667,10 @@ class RestartGroups(object):
         if len(self.sets) == 1 and native and 'search_mode' not in (kwargs.get('options') or {}):
             self.sets[0].batch.set_option('search_mode', 5)
 
+    def close(self):
+        for rs in self.sets:
+            rs.close()
+
     @property
     def num_restarts(self):
         return len(self.models)
@@ -733,6 +745,10 @@ class DatasetGroups(object):
         self.init_params = [p for part in self.parts for p in part.init_params]
         self.experiments = list(experiments)
         self._pool = None
+
+    def close(self):
+        for rs in self.sets:
+            rs.close()
 
     @property
     def num_restarts(self):
