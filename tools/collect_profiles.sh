@@ -39,5 +39,16 @@ python3 $ROOT/tools/prep_time.py 2>&1 | grep -v amdgpu.ids >> $OUT/mstep_stage_t
 python3 $ROOT/tools/e2e_time.py 2>&1 | grep -v amdgpu.ids > $OUT/e2e_wall.txt
 python3 $ROOT/tools/large_grids.py 2>&1 | grep -v amdgpu.ids > $OUT/large_grids.txt
 (cd $ROOT/tools/micro && ./mfma64_bench throughput) > $OUT/mfma64_throughput.txt 2>&1
+# the memory system's answer to the fused marginal pass's access pattern (tools/micro/stream_rows.hip), and the pass itself beside it
+{ $ROOT/tools/micro/stream_rows; echo; echo "# the passes themselves on the same box (8 restarts, tools/fb_only.py: k_marginals<true> = four fused passes and the call's last, unfused one)"; RST=8 ITERS=5 python3 $ROOT/tools/fb_only.py 2>&1 | grep "k_marginals\|k_framelog"; } > $OUT/stream_rows.txt 2>&1
+# SQ counters of the sweep kernels (their own run: no trace domains)
+export ITERS=3 RST=8
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAVES SQ_BUSY_CYCLES -d $OUT/pmc_sq -o p --output-format csv -- python3 $ROOT/tools/fb_only.py > $OUT/pmc_sq.log 2>&1
+python3 $ROOT/tools/sq_counters.py $OUT/pmc_sq > $OUT/sweep_sq_counters.txt 2>&1
+rm -rf $OUT/pmc_sq
+unset ITERS RST
+# the two groups' M-step stages with the search rounds driven by the device (search_mode 5) beside the default above
+{ echo "# OPTS=search_mode=5"; OPTS=search_mode=5 python3 $ROOT/tools/mstep_marks.py 2>&1 | grep -v amdgpu.ids; echo "# RST=8 NGROUPS=1 (RestartGroups picks search_mode 5 for a single group)"; RST=8 NGROUPS=1 python3 $ROOT/tools/mstep_marks.py 2>&1 | grep -v amdgpu.ids; } > $OUT/mstep_stage_times_search5.txt 2>&1
+REPS=6 python3 $ROOT/tools/s355_repeat.py 2>&1 | grep "^run" > $OUT/s355_repeat.txt
 rm -rf $OUT/prof_bench $OUT/prof_s355 $OUT/pmc_fetch_* $OUT/pmc_write_*
 ls -la $OUT
