@@ -82,8 +82,9 @@ def run_fit_case(case, oracle_mod, em_iters=2):
     seeds = [1000 * case['seed'] + r for r in range(case['R'])]
     out = []
     for kern, native in ((oracle_mod, False), (None, True)):
+        # (odd seeds: the parameter searches in rounds the device drives, library option search_mode 5)
         rs = RestartSet(e, ps, max_copy_number=case['max_cn'], num_clones=case['M'], quiet=True, seeds=seeds, kernel_module=kern,
-                        native_search=native, mstep_threads=1)
+                        native_search=native, mstep_threads=1, options=({'search_mode': 5} if (native and case['seed'] % 2) else None))
         try:
             rs.fit(num_em_iter=em_iters, num_update_iter=2)
             out.append(('ok', [m.prev_elbo for m in rs.models], [np.array(m.h) for m in rs.models], dict(rs.error_messages)))
