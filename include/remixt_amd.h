@@ -155,7 +155,7 @@ enum rmx_option_id {
     RMX_OPT_SPARSE_TRIAL,       /* creation time, 1 (default): keep per-segment lists of states with posterior mass */
     RMX_OPT_FB_DEBUG,           /* creation time, 1: cycle counters of the forward-backward kernel through rmx_info(20..) */
     RMX_OPT_PAIRWISE_KERNEL,    /* breakend pairwise reductions: 0 auto (above 200 states k_pairwise_sp: the state pairs above the posterior threshold; else k_pairwise_be2), 1 general kernel
-                                   (k_pairwise), 2 the dense pair-code kernel (k_pairwise_be2), 3 k_pairwise_sp */
+                                   (k_pairwise), 2 the dense pair-code kernel (k_pairwise_be2), 3 k_pairwise_sp, 4 k_pairwise_sp with a block of one wave per adjacency */
     RMX_OPT_PACE_SWEEPS,        /* 1: rmx_variational_update reaches each sweep's forward-backward point only after the previous sweep's
                                    forward-backward launch has finished on the device, instead of queueing all its sweeps at once; for restart groups that share a GPU -- at 355 states two paced groups of 8
                                    make 144 EM iterations/s, free-running ones 118 */

@@ -626,13 +626,15 @@ static int launch_pairwise_breakends(rmx_batch *b, int r0, int r1, int mode) {
     const int nt = ((d.S + 63) / 64) * 64;
     const size_t lds2 = ((size_t)((d.S + 7) & ~7) + b->pe2p + 128 + (size_t)nt * (d.M - 1) * (d.cn_max + 2) + nt + 3 * d.M * d.D) * 8 + (size_t)((d.S + 7) & ~7) * 4 + (size_t)d.S * 4 + 64;
     const int S8p = (d.S + 7) & ~7;
-    const size_t lds_sp = (size_t)(4 * S8p + PSP_ROWS * 2 * (d.cn_max + 2) + 2 * PSP_ROWS + (d.M * d.D + 4) + 64) * 8 + (size_t)3 * S8p * 4 + 64;
+    const int sp_rows = PSP_ROWS;
+    const size_t lds_sp = (size_t)(4 * S8p + sp_rows * 2 * (d.cn_max + 2) + 2 * sp_rows + (d.M * d.D + 4) + 64) * 8 + (size_t)3 * S8p * 4 + (size_t)sp_rows * 4 + 64;
     // the sparse kernel (state pairs above the posterior threshold only) wherever the pair codes exist: auto, or option 3; 2 = the dense kernel
     // (auto: above ~200 states, where the dense kernel's S^2 pairs per adjacency outweigh the sparse kernel's per-block latency chain; at 165 states the
     // two are within 2 % of each other in the benchmark, the dense one ahead)
-    const bool want_sp = b->opt[RMX_OPT_PAIRWISE_KERNEL] == 3 || (b->opt[RMX_OPT_PAIRWISE_KERNEL] == 0 && d.S > 200);
+    const bool want_sp = b->opt[RMX_OPT_PAIRWISE_KERNEL] >= 3 || (b->opt[RMX_OPT_PAIRWISE_KERNEL] == 0 && d.S > 200);
+    const int sp_threads = b->opt[RMX_OPT_PAIRWISE_KERNEL] >= 4 ? 64 : 256;
     if (mode == 0 && b->pcode_ok && want_sp && lds_sp + 512 <= 64 * 1024) {      // (+ the kernel's static __shared__: no opt-in above 64 KiB, the dense kernels take over)
-        hipLaunchKernelGGL(k_pairwise_sp, dim3(d.NBE, r1 - r0), dim3(256), lds_sp, b->stream, b->d, r0, b->pe2p, b->spc);
+        hipLaunchKernelGGL(k_pairwise_sp, dim3(d.NBE, r1 - r0), dim3(sp_threads), lds_sp, b->stream, b->d, r0, b->pe2p, b->spc);
     } else if (mode == 0 && b->pcode_ok && lds2 <= 150 * 1024 && (b->opt[RMX_OPT_PAIRWISE_KERNEL] == 0 || b->opt[RMX_OPT_PAIRWISE_KERNEL] == 2)) {
         HIPCHK(hipFuncSetAttribute((const void *)k_pairwise_be2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
         hipLaunchKernelGGL(k_pairwise_be2, dim3(d.NBE, r1 - r0), dim3(nt), lds2, b->stream, b->d, r0, b->pe2p, b->spc);
@@ -675,7 +677,7 @@ static bool option_value_ok(int id, int v) {
     case RMX_OPT_FB_KERNEL: return v >= 0 && v <= 3;
     case RMX_OPT_FB_NV: return v == 0 || v == 1 || v == 2 || v == 4;      // the workgroup shapes that exist (k_fbm and k_fbv / k_fbk 1 / 2 / 4, k_fbq 4)
     case RMX_OPT_SEARCH_MODE: return v >= 0 && v <= 5;
-    case RMX_OPT_PAIRWISE_KERNEL: return v >= 0 && v <= 3;
+    case RMX_OPT_PAIRWISE_KERNEL: return v >= 0 && v <= 4;
     case RMX_OPT_FB_WG_BUDGET: return v >= 0 && v <= 4096;
     default: return v == 0 || v == 1;
     }

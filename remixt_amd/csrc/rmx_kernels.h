@@ -2459,7 +2459,9 @@ __global__ void k_pairwise(Dev d, int r0, int mode, const int32_t *list, double 
 // tumour-clone totals and flushes a run of equal totals into its private LDS bins; passes of 64 rows; one thread per histogram bin folds a
 // pass's rows in list order.  Any list length is handled (a flat posterior -- short segments with few reads -- makes it the dense product,
 // at the dense kernel's cost per pair).  Outputs as k_pairwise_be2: hist [M][D], be_ja, be_jt.  M in {2, 3}, pair codes as k_pairwise_be2.
-// grid (NBE, nr), block 256, dynamic LDS.
+// grid (NBE, nr), block 256 or 64 (round 4, option pairwise_kernel 4: one wave per adjacency -- a dozen of its threads have a listed row and its barriers are
+// free; measured within the noise of the 256-thread block at 165 and 355 states, as was a variant with 16 rows per pass whose 11 KB of LDS fit next to
+// four workgroups of the marginal pass: removing the kernel altogether would gain 2.5 % of the step), dynamic LDS.
 // =============================================================================
 #define PSP_ROWS 64         // rows per pass (a thread per row with private histogram bins in LDS)
 __global__ __launch_bounds__(256) void k_pairwise_sp(Dev d, int r0, int PE2P, int SPC) {
@@ -2485,6 +2487,7 @@ __global__ __launch_bounds__(256) void k_pairwise_sp(Dev d, int r0, int PE2P, in
     int *li = (int *)(wa + 64);                           // [S8] rows above the threshold
     int *lj = li + S8;                                    // [S8] columns (positions in jord order) above the threshold
     int *lm = lj + S8;                                    // [S8] per listed column: t1 | t2 << 8 | run flags << 16 (as jmeta, flags for the LIST)
+    int *rtot = lm + S8;                                  // [PSP_ROWS] totals of a pass's rows, a byte per clone (the fold reads them from here, not through a chain of global loads)
     const double *fa0 = d.fa + rs_off(d, r, n), *fb0 = d.fb + rs_off(d, r, n);
     const double *fa1 = d.fa + rs_off(d, r, n + 1), *fb1 = d.fb + rs_off(d, r, n + 1), *fe1 = d.fe + rs_off(d, r, n + 1);
     double sn = 0., sm = 0.;
@@ -2507,10 +2510,11 @@ __global__ __launch_bounds__(256) void k_pairwise_sp(Dev d, int r0, int PE2P, in
     if (t == 0) { double x = 0., y = 0.; for (int w_ = 0; w_ < NT / 64; w_++) { x += scratch[w_]; y += scratch[8 + w_]; } tot_n = x; tot_m = y; }
     __syncthreads();
     // compaction in index order: wave 0 the rows, wave 1 the columns (ballot + prefix count per group of 64)
-    if (wave < 2) {
-        const double *pp = wave == 0 ? pn : pm;
-        const double thr = RMX_POST_EPS * (wave == 0 ? tot_n : tot_m);
-        int *lst = wave == 0 ? li : lj;
+    // (a block of one wave -- round 4: an adjacency per wave -- does both lists)
+    for (int which = wave; which < 2; which += NT >> 6) {
+        const double *pp = which == 0 ? pn : pm;
+        const double thr = RMX_POST_EPS * (which == 0 ? tot_n : tot_m);
+        int *lst = which == 0 ? li : lj;
         int base = 0;
         for (int s0 = 0; s0 < S; s0 += 64) {
             const int s = s0 + lane;
@@ -2519,7 +2523,7 @@ __global__ __launch_bounds__(256) void k_pairwise_sp(Dev d, int r0, int PE2P, in
             if (keep) lst[base + __popcll(bal & ((1ull << lane) - 1ull))] = s;
             base += __popcll(bal);
         }
-        if (lane == 0) { if (wave == 0) NI = base; else NJ = base; }
+        if (lane == 0) { if (which == 0) NI = base; else NJ = base; }
     }
     __syncthreads();
     const int ni = NI, nj = NJ;
@@ -2545,6 +2549,7 @@ __global__ __launch_bounds__(256) void k_pairwise_sp(Dev d, int r0, int PE2P, in
             for (int i = 0; i < (M - 1) * NB; i++) mybins[i] = 0.;
             const int i = li[u0 + t];
             const double fai = fav[i];
+            { int pk = 0; for (int c = 0; c < M; c++) pk |= ((int)tota[i * M + c] & 0xff) << (8 * c); rtot[t] = pk; }
             double z = 0., ja = 0., acc1 = 0., acc2 = 0.;
             // chunks of 16 listed columns: their 16 codes are requested together, then their 16 table entries -- two memory round trips
             // per chunk instead of two per column
@@ -2576,32 +2581,24 @@ __global__ __launch_bounds__(256) void k_pairwise_sp(Dev d, int r0, int PE2P, in
         }
         __syncthreads();
         // fold this pass's rows into the histogram, one thread per bin, rows in list order; total mass and allele-distance sum likewise
-        if (t < M * D) {
-            const int c = t / D, dv = t % D - off;
-            double acc = hacc[t];
-            for (int u = 0; u < nu; u++) {
-                const int tj = (int)tota[li[u0 + u] * M + c] - dv;      // the column total this bin pairs with the row's
-                if (c == 0) { if (tj == t0b) acc += zrow[u]; }
-                else if (tj >= 0 && tj < NB) acc += bins[((size_t)u * 2 + (c - 1)) * NB + tj];
-            }
-            hacc[t] = acc;
-        } else if (t == M * D) {
-            double acc = hacc[t];
-            for (int u = 0; u < nu; u++) acc += zrow[u];
-            hacc[t] = acc;
-        } else if (t == M * D + 1) {
-            double acc = hacc[t];
-            for (int u = 0; u < nu; u++) acc += zrow[PSP_ROWS + u];
-            hacc[t] = acc;
+        for (int tt = t; tt < M * D + 2; tt += NT) {
+            double acc = hacc[tt];
+            if (tt < M * D) {
+                const int c = tt / D, dv = tt % D - off;
+                for (int u = 0; u < nu; u++) {
+                    const int tj = ((rtot[u] >> (8 * c)) & 0xff) - dv;      // the column total this bin pairs with the row's
+                    if (c == 0) { if (tj == t0b) acc += zrow[u]; }
+                    else if (tj >= 0 && tj < NB) acc += bins[((size_t)u * 2 + (c - 1)) * NB + tj];
+                }
+            } else if (tt == M * D) { for (int u = 0; u < nu; u++) acc += zrow[u]; }
+            else { for (int u = 0; u < nu; u++) acc += zrow[PSP_ROWS + u]; }
+            hacc[tt] = acc;
         }
         __syncthreads();
     }
     const double zz = hacc[M * D];
     double *hist = d.hist + ((size_t)r * d.NBE + slot) * M * D;
-    double hv = 0.;
-    if (t < M * D) { hv = hacc[t] / zz; hist[t] = hv; }
-    __syncthreads();
-    if (t < M * D) hacc[t] = hv;
+    for (int tt = t; tt < M * D; tt += NT) { const double hv = hacc[tt] / zz; hist[tt] = hv; hacc[tt] = hv; }      // (entry tt is this thread's alone; zz = hacc[M * D] stays)
     __syncthreads();
     if (t < 64) {
         double jt = 0.;

@@ -161,7 +161,7 @@ def test_s165_generic_kernel_and_plain_breakend_tables_match_oracle(hip, oracle_
     e = synthetic.make_experiment(90, num_clones=3, max_copy_number=8, num_chains=2, seed=33, num_breakpoints=12)
     e.breakpoints = H.add_shared_boundary_breakpoints(e)
     ps = synthetic.make_init_params(e, 2, 8)
-    for options in ({'fb_kernel': 1}, {'fb_breakend_codes': 0, 'fb_nv': 2}, {'fb_kernel': 3, 'fb_nv': 1}, {'pairwise_kernel': 1}, {'pairwise_kernel': 3}):      # (3: the sparse pairwise kernel, auto only above 200 states)
+    for options in ({'fb_kernel': 1}, {'fb_breakend_codes': 0, 'fb_nv': 2}, {'fb_kernel': 3, 'fb_nv': 1}, {'pairwise_kernel': 1}, {'pairwise_kernel': 3}, {'pairwise_kernel': 4}):      # (3 / 4: the sparse pairwise kernel, a block of 256 threads / of one wave per adjacency)
         dev, ora = _two_sets(oracle_mod, e, ps, 8, 3, options=options)
         _compare_after_every_update(dev, ora, sweeps=1)
 
