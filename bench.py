@@ -87,6 +87,7 @@ def parse(argv=None):
     ap.add_argument('--lib', default=None, help='A/B measurements: an alternative build of libremixt_hip.so for this run')
     ap.add_argument('--switch-interval-us', type=float, default=0., help='A/B measurements: sys.setswitchinterval for the restart groups\' host threads (0 = leave Python\'s 5 ms)')
     ap.add_argument('--cpu-leg', action='store_true', help=argparse.SUPPRESS)       # internal: the CPU baseline child process
+    ap.add_argument('--sub-run', default=None, help=argparse.SUPPRESS)              # internal: one additional measurement in a process of its own (restarts,groups,max_cn,nsteps,warm,unequal)
     return ap.parse_args(argv)
 
 
@@ -273,6 +274,8 @@ def main(argv=None, kernel_module=None, dist_backend='nccl', script=None):
     args = parse(argv)
     if args.cpu_leg:
         return cpu_leg(args)
+    if args.sub_run:
+        return sub_run(args)
     if args.switch_interval_us > 0:
         sys.setswitchinterval(args.switch_interval_us * 1e-6)
     env_world = os.environ.get('WORLD_SIZE')
@@ -655,6 +658,70 @@ def _timed_run(args, device, restarts, groups, max_cn, nsteps, warm, seeds_base=
     return rs, S, N1, dt, elbo, rs.profile()
 
 
+class _RunInfo(object):
+    """What the additional measurements read off the restart groups of a timed run, when the run was made in a child process."""
+    class _B(object):
+        def __init__(self, info):
+            self._info = info
+
+        def info(self, k):
+            return self._info[str(k)]
+
+    def __init__(self, paced, info):
+        self.paced, self.batches, self.sets = paced, [self._B(info)], []
+
+
+def _timed_run_isolated(args, device, restarts, groups, max_cn, nsteps, warm, unequal=False):
+    """_timed_run in a process of its own (started here as a child; this process has released its batches and idles meanwhile).
+    The restart groups of a process's FIRST measurement find the hardware queues unused and every stream gets its own; groups
+    built later in the same process shared queues now and then even with their predecessors destroyed (states_355 110 instead of 150 EM
+    it/s in one run of five).  A fit is a process of its own in production (the reference's `fit` task): that is what is measured.
+    Falls back to the in-process run if the child fails."""
+    cmd = [sys.executable, os.path.abspath(__file__), '--sub-run', '%d,%d,%d,%d,%d,%d' % (restarts, groups, max_cn, nsteps, warm, 1 if unequal else 0),
+           '--segments', str(args.segments), '--clones', str(args.clones), '--update-iters', str(args.update_iters)]
+    for item in args.option:
+        cmd += ['--option', item]
+    for item in args.host_option:
+        cmd += ['--host-option', item]
+    if args.lib:
+        cmd += ['--lib', args.lib]
+    try:
+        res = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+        line = [l for l in res.stdout.splitlines() if l.startswith('SUB_RUN ')]
+        if not line:
+            raise RuntimeError((res.stderr or res.stdout)[-300:])
+        j = json.loads(line[-1][len('SUB_RUN '):])
+        prof = dict((k, (v[0], v[1])) for k, v in j['prof'].items())
+        return _RunInfo(j['paced'], j['info']), j['S'], j['N1'], j['dt'], np.array([j['elbo_best']]), prof
+    except Exception as err:
+        sys.stderr.write('bench.py: additional measurement in a child process failed (%s); measuring in this process\n' % str(err)[:200])
+        from remixt_amd import synthetic
+        return _timed_run(args, device, restarts, groups, max_cn, nsteps, warm, chain_fractions=synthetic.HUMAN_CHROMOSOME_MB if unequal else None)
+
+
+def sub_run(args):
+    """The child of _timed_run_isolated: one timed run, its numbers as one line."""
+    import torch
+    restarts, groups, max_cn, nsteps, warm, unequal = [int(v) for v in args.sub_run.split(',')]
+    torch.cuda.set_device(0)
+    if args.lib:
+        from remixt_amd import _lib as _libmod
+        _libmod.LIB_PATH = os.path.abspath(args.lib)
+    from remixt_amd import synthetic
+    if args.option:
+        from remixt_amd import bpmodel
+        for item in args.option:
+            name, value = item.split('=')
+            bpmodel.set_default_option(name, int(value))
+    rs, S, N1, dt, elbo, prof = _timed_run(args, 0, restarts, groups, max_cn, nsteps, warm, chain_fractions=synthetic.HUMAN_CHROMOSOME_MB if unequal else None)
+    b = rs.batches[0]
+    out = {'S': S, 'N1': N1, 'dt': dt, 'elbo_best': float(np.nanmax(elbo)), 'paced': bool(getattr(rs, 'paced', False)),
+           'prof': dict((k, [v[0], v[1]]) for k, v in prof.items()), 'info': dict((str(k), b.info(k)) for k in (12, 13, 14, 15))}
+    _release(rs)
+    print('SUB_RUN ' + json.dumps(out), flush=True)
+    return 0
+
+
 def extra_states(args, rs_main, device):
     """EM iterations/s at max_cn = 12 (355 states: the reference's default max_copy_number, defaults.py:117, and the "~400 states"
     BASELINE.json's metric string is quoted on), everything else as the headline workload; 20 timed steps like the headline."""
@@ -663,7 +730,7 @@ def extra_states(args, rs_main, device):
     # two restart groups, paced (RestartGroups paced='auto' above 200 states): 144 EM iterations/s against 134 for one group of 16 and 118
     # for two free-running groups (tools/s355_groups.sh)
     G355 = 2
-    rs, S, N1, dt, elbo, prof = _timed_run(args, device, R, G355, max_cn, nsteps, 2)
+    rs, S, N1, dt, elbo, prof = _timed_run_isolated(args, device, R, G355, max_cn, nsteps, 2)
     hot = [(k, prof[k]) for k in ALG_BYTES_PER_CELL if k in prof]
     dom = max(hot, key=lambda kv: kv[1][0]) if hot else (None, (0., 0))
     a355 = argparse.Namespace(**vars(args)); a355.max_cn = max_cn
@@ -690,7 +757,7 @@ def unequal_chains(args, rs_main, device, headline_value):
     from remixt_amd import synthetic
     _release(rs_main)
     nsteps = 10
-    rs, S, N1, dt, elbo, prof = _timed_run(args, device, args.restarts, args.groups, args.max_cn, nsteps, 2, chain_fractions=synthetic.HUMAN_CHROMOSOME_MB)
+    rs, S, N1, dt, elbo, prof = _timed_run_isolated(args, device, args.restarts, args.groups, args.max_cn, nsteps, 2, unequal=True)
     fb = prof.get('k_fb', (0., 1))
     b = rs.batches[0]
     lens = sorted(int(round(f / float(sum(synthetic.HUMAN_CHROMOSOME_MB)) * args.segments)) for f in synthetic.HUMAN_CHROMOSOME_MB)
@@ -750,10 +817,10 @@ def strong_scaling_proxy(args, rs_main, device):
     8 x the one-share rate: predicted speed-up of 8 GPUs over 1 on the fixed job = 8 x it/s(8) / it/s(64)."""
     _release(rs_main)
     nsteps = 8
-    rs, S, N1, dt64, _, prof64 = _timed_run(args, device, 64, 4, args.max_cn, nsteps, 2)
+    rs, S, N1, dt64, _, prof64 = _timed_run_isolated(args, device, 64, 4, args.max_cn, nsteps, 2)
     fb64 = prof64.get('k_fb', (0., 1))
     _release(rs)
-    rs, S, N1, dt8, _, prof8 = _timed_run(args, device, 8, args.groups, args.max_cn, nsteps, 2)
+    rs, S, N1, dt8, _, prof8 = _timed_run_isolated(args, device, 8, args.groups, args.max_cn, nsteps, 2)
     fb8 = prof8.get('k_fb', (0., 1))
     _release(rs)
     its64, its8 = 64 * nsteps / dt64, 8 * nsteps / dt8
