@@ -1453,8 +1453,10 @@ static int p_cn_front(rmx_batch *b, int r0, int r1, bool skip_frame, bool snapsh
             int nt = ((FBK_P * v.G2 + v.SPW - 1) / v.SPW) * v.SPW;
             const size_t lds = ((size_t)NV * 2 * v.SPAD + (size_t)NV * FBK_P * d.SP + NV * 4 + (size_t)NV * b->pe2p + 64) * 8 + (size_t)2 * v.SPAD * 4 + (size_t)b->be_cap * 4 + 64;
             const int vpp = nt / v.SPW;
-            if (nt <= 768 && lds <= kLdsBudget && (NV + vpp - 1) / vpp <= 2 && ((b->pe2p + 1) / 2) <= 384) {
-                void (*kf)(FbvArgs, const double *, const uint32_t *, const uint32_t *) = NV == 1 ? k_fbk<1, 768> : (NV == 2 ? k_fbk<2, 768> : k_fbk<4, 768>);
+            // (round 4, late: blocks of up to 1 024 threads -- the kernel needs 59 / 82 / 117 registers at 1 / 2 / 4 vectors -- take it from 360 to 512 states)
+            if (nt <= 1024 && lds <= kLdsBudget && (NV + vpp - 1) / vpp <= 2 && ((b->pe2p + 1) / 2) <= nt) {
+                void (*kf)(FbvArgs, const double *, const uint32_t *, const uint32_t *) =
+                    nt <= 768 ? (NV == 1 ? k_fbk<1, 768> : (NV == 2 ? k_fbk<2, 768> : k_fbk<4, 768>)) : (NV == 1 ? k_fbk<1, 1024> : (NV == 2 ? k_fbk<2, 1024> : k_fbk<4, 1024>));
                 HIPCHK(hipFuncSetAttribute((const void *)kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
                 hipLaunchKernelGGL(kf, dim3(b->n_fast, (nr + NV - 1) / NV, 2), dim3(nt), lds, b->stream, v, (const double *)b->d_wk, (const uint32_t *)b->d_cnpack, (const uint32_t *)b->d_totpack);
                 done_fast = true; fast = true; b->last_fb_kernel = 3; b->last_fb_nv = b->last_fb_nv_max = NV;

@@ -1825,7 +1825,7 @@ __global__ __launch_bounds__(NTMAX) void k_fbk(FbvArgs a, const double *wk, cons
                     if (v < nv && t * 2 < a.PE2P) glds16(a.pe2_lt + ((size_t)(rg0 + v) * a.NBE + bs) * a.PE2P + t * 2, dpe);
                 }
             }
-            if (t < 384) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (t < (((a.PE2P + 1) / 2 + 63) & ~63)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (the waves that issued a transfer)
             FB_BARRIER();
         }
         if (act) {      // wave-uniform: FBK_P * G2 is a multiple of 64
