@@ -132,7 +132,7 @@ struct rmx_batch {
     std::vector<double> trial_comp; int trial_comp_r0 = -1, trial_comp_r1 = -1;   // component sums of the last rmx_expected_ll_full_trial's scratch expectations
     int scratch_r0 = -1, scratch_r1 = -1;   // restarts whose scratch expectations (d_A2, d_Bv2) the last trial pass wrote (-1: none)
     double *d_A2 = nullptr, *d_Bv2 = nullptr;   // [R][N][2], [R][N][4]: (A, B) of a trial parameter value (rmx_expected_ll_full_trial)
-    uint32_t *d_cnpack = nullptr, *d_totpack = nullptr; double *d_wk = nullptr;   // [C][S], [C][S], [TC][64]
+    uint32_t *d_cnpack = nullptr, *d_totpack = nullptr, *d_cnpack2 = nullptr; double *d_wk = nullptr;   // [C][S], [C][S], [C][S] (third tumour clone), [TC][64]
     int pe2p = 0;     // padded row length of pe2_lt (0: no product table)
     int spc = 0;      // row stride of the pair-code table
     bool pcode_ok = false;
@@ -353,18 +353,20 @@ static int build_transitions(rmx_batch *b) {
     // tumour clones per class, exp(-pen*k) per transition class, and the check that the closed form
     // -pen * min(SAD(cn_q, cn_o), SAD(cn_q, swap(cn_o))) reproduces the tabulated log-weights exactly
     b->fbk_ok = false;
-    if (TC > 0 && (M == 2 || M == 3) && model == 0 && b->d.cn_max <= 15 && b->d_cnpack) {
+    if (TC > 0 && M >= 2 && M <= 4 && model == 0 && b->d.cn_max <= 15 && b->d_cnpack) {
         const int C = b->d.C;
-        std::vector<uint32_t> cnp((size_t)C * S), ttp((size_t)C * S);
+        std::vector<uint32_t> cnp((size_t)C * S), ttp((size_t)C * S), cnp2((size_t)C * S, 0u);      // (cnp2: the third tumour clone's alleles, four clones only)
         for (int cls = 0; cls < C; cls++)
             for (int s_ = 0; s_ < S; s_++) {
                 const int64_t *t_ = b->cn_classes.data() + ((size_t)cls * S + s_) * M * 2;
                 uint32_t cp = 0, tp = 0;
+                uint32_t cp2 = 0;
                 for (int c = 1; c < M; c++) {
-                    cp |= ((uint32_t)t_[c * 2] & 0xff) << (16 * (c - 1)); cp |= ((uint32_t)t_[c * 2 + 1] & 0xff) << (16 * (c - 1) + 8);
+                    if (c <= 2) { cp |= ((uint32_t)t_[c * 2] & 0xff) << (16 * (c - 1)); cp |= ((uint32_t)t_[c * 2 + 1] & 0xff) << (16 * (c - 1) + 8); }
+                    else { cp2 |= ((uint32_t)t_[c * 2] & 0xff); cp2 |= ((uint32_t)t_[c * 2 + 1] & 0xff) << 8; }
                     tp |= ((uint32_t)(t_[c * 2] + t_[c * 2 + 1]) & 0xff) << (8 * (c - 1));
                 }
-                cnp[(size_t)cls * S + s_] = cp; ttp[(size_t)cls * S + s_] = tp;
+                cnp[(size_t)cls * S + s_] = cp; ttp[(size_t)cls * S + s_] = tp; cnp2[(size_t)cls * S + s_] = cp2;
             }
         auto sad = [](uint32_t x, uint32_t y) { int r_ = 0; for (int i = 0; i < 4; i++) r_ += std::abs((int)((x >> (8 * i)) & 0xff) - (int)((y >> (8 * i)) & 0xff)); return r_; };
         auto swp = [](uint32_t x) { return ((x & 0x00ff00ffu) << 8) | ((x >> 8) & 0x00ff00ffu); };
@@ -376,7 +378,8 @@ static int build_transitions(rmx_batch *b) {
             if (ca != cb) continue;      // only chains of one class use the kernel
             for (int i = 0; i < S && ok; i++)
                 for (int j = 0; j < S; j++) {
-                    const int k = std::min(sad(cnp[(size_t)ca * S + i], cnp[(size_t)cb * S + j]), sad(cnp[(size_t)ca * S + i], swp(cnp[(size_t)cb * S + j])));
+                    const int k = std::min(sad(cnp[(size_t)ca * S + i], cnp[(size_t)cb * S + j]) + sad(cnp2[(size_t)ca * S + i], cnp2[(size_t)cb * S + j]),
+                                           sad(cnp[(size_t)ca * S + i], swp(cnp[(size_t)cb * S + j])) + sad(cnp2[(size_t)ca * S + i], swp(cnp2[(size_t)cb * S + j])));
                     const int kt = sad(ttp[(size_t)ca * S + i], ttp[(size_t)cb * S + j]);
                     if (k >= 64 || Tval[tc * SS + (size_t)i * S + j] != -pen * (double)k || (int)af[tc * SS + (size_t)i * S + j] != k - kt ||
                         Wf[tc * SS + (size_t)i * S + j] != wk[(size_t)tc * 64 + k]) { ok = false; break; }
@@ -384,6 +387,7 @@ static int build_transitions(rmx_batch *b) {
         }
         if (ok) {
             HIPCHK(hipMemcpy(b->d_cnpack, cnp.data(), cnp.size() * 4, hipMemcpyHostToDevice));
+            HIPCHK(hipMemcpy(b->d_cnpack2, cnp2.data(), cnp2.size() * 4, hipMemcpyHostToDevice));
             HIPCHK(hipMemcpy(b->d_totpack, ttp.data(), ttp.size() * 4, hipMemcpyHostToDevice));
             HIPCHK(hipMemcpy(b->d_wk, wk.data(), wk.size() * 8, hipMemcpyHostToDevice));
             b->fbk_ok = true;
@@ -865,9 +869,15 @@ int rmx_batch_create(const rmx_problem *pr, int32_t R, const double *h_init, con
         HIPCHK(hipMemset(d.pe2x_lt, 0, ((size_t)((R + 3) / 4) * d.NBE * b->pe2p * 4 + 2) * 8));
         b->spc = ((S + 63) / 64) * 64;
         DA(pcode, uint16_t, (size_t)std::max(d.TC, 1) * ((S + 7) & ~7) * b->spc) DA(jord, int32_t, (size_t)C * S) DA(jmeta, int32_t, (size_t)C * S)
-    } else { d.pcode = nullptr; d.jord = nullptr; d.jmeta = nullptr; }
+    } else {
+        d.pcode = nullptr; d.jord = nullptr; d.jmeta = nullptr;
+        if (M == 4 && d.D <= 15 && d.NBE > 0) {      // four clones: the clone-product table of a breakend has D^3 entries; k_fbk is its only reader (round 4)
+            b->pe2p = (d.D * d.D * d.D + 1) & ~1;
+            DA(pe2_lt, double, (size_t)R * d.NBE * b->pe2p + 2)
+        }
+    }
     if ((rc = dalloc(b, &b->d_A2, RN * 2)) || (rc = dalloc(b, &b->d_Bv2, RN * 4))) { rmx_batch_destroy(b); return rc; }
-    if ((rc = dalloc(b, &b->d_cnpack, (size_t)C * S)) || (rc = dalloc(b, &b->d_totpack, (size_t)C * S)) || (rc = dalloc(b, &b->d_wk, (size_t)std::max(d.TC, 1) * 64))) { rmx_batch_destroy(b); return rc; }
+    if ((rc = dalloc(b, &b->d_cnpack, (size_t)C * S)) || (rc = dalloc(b, &b->d_cnpack2, (size_t)C * S)) || (rc = dalloc(b, &b->d_totpack, (size_t)C * S)) || (rc = dalloc(b, &b->d_wk, (size_t)std::max(d.TC, 1) * 64))) { rmx_batch_destroy(b); return rc; }
     DA(pd_cached, double, BEW) DA(hist, double, BEW) DA(be_jt, double, (size_t)R * d.NBE) DA(be_ja, double, (size_t)R * d.NBE)
     DA(err, uint32_t, R)
 #undef DA
@@ -1332,7 +1342,7 @@ static int p_cn_front(rmx_batch *b, int r0, int r1, bool skip_frame, bool snapsh
         // that many workgroups still fit the chip in one round -- a step of the vector form is shorter (fewer products per CU and step), and a
         // launch is a chain of dependent steps.  Needs the clone-product tables for breakend steps.  Option fb_nv = 1 / 2 / 4 pins the shape;
         // fb_kernel = 3 selects the two-phase vector kernel below instead.
-        if (b->fbv_rpt > 0 && b->n_fast > 0 && (d.NBE == 0 || (d.pe2_lt != nullptr && b->max_adist < 64 && b->opt[RMX_OPT_FB_BREAKEND_CODES])) &&
+        if (b->fbv_rpt > 0 && b->n_fast > 0 && d.M <= 3 && (d.NBE == 0 || (d.pe2_lt != nullptr && b->max_adist < 64 && b->opt[RMX_OPT_FB_BREAKEND_CODES])) &&
             b->opt[RMX_OPT_FB_KERNEL] != 3) {
             int KB = 0;
             for (int v : {8, 16, 28, 36, 42, 44}) if (4 * v >= d.S) { KB = v; break; }
@@ -1382,7 +1392,7 @@ static int p_cn_front(rmx_batch *b, int r0, int r1, bool skip_frame, bool snapsh
                 // breakend fast path: product tables + pair codes in LDS (the allele-distance matrix is then
                 // not needed there)
                 const size_t code_bytes = (size_t)FBV_P * rpt * d.SP * 2;
-                const bool want_code = d.pe2_lt != nullptr && b->max_adist < 64 && (d.SP & 1) == 0 && b->opt[RMX_OPT_FB_BREAKEND_CODES];
+                const bool want_code = d.pe2_lt != nullptr && d.M <= 3 && b->max_adist < 64 && (d.SP & 1) == 0 && b->opt[RMX_OPT_FB_BREAKEND_CODES];
                 size_t base_ = ((size_t)NV * 2 * v.SPAD + (size_t)NV * FBV_P * d.SP + NV * 4 + 128) * 8 +
                                (((size_t)d.C * d.S * d.M + 15) & ~(size_t)15) + 64 + (size_t)b->be_cap * 4;
                 size_t fixed;
@@ -1451,14 +1461,19 @@ static int p_cn_front(rmx_batch *b, int r0, int r1, bool skip_frame, bool snapsh
             v.fe = d.fe; v.Wf = d.Wf; v.Wb = d.Wb; v.pe_lt = d.pe_lt; v.af = d.af; v.ab = d.ab; v.tot = d.tot;
             v.fa = d.fa; v.fb = d.fb; v.mrow = d.mrow; v.err = d.err; v.dbg = b->d_dbg;
             int nt = ((FBK_P * v.G2 + v.SPW - 1) / v.SPW) * v.SPW;
-            const size_t lds = ((size_t)NV * 2 * v.SPAD + (size_t)NV * FBK_P * d.SP + NV * 4 + (size_t)NV * b->pe2p + 64) * 8 + (size_t)2 * v.SPAD * 4 + (size_t)b->be_cap * 4 + 64;
+            const bool m4 = d.M == 4;
+            auto lds_of = [&](int nv_) { return ((size_t)nv_ * 2 * v.SPAD + (size_t)nv_ * FBK_P * d.SP + nv_ * 4 + (size_t)nv_ * b->pe2p + 64) * 8 + (size_t)(m4 ? 3 : 2) * v.SPAD * 4 + (size_t)b->be_cap * 4 + 64; };
+            // (four clones: a breakend's table is D^3 entries per vector -- 27 KB at max_cn 6 -- so fewer vectors per workgroup where four do not fit the LDS)
+            while (NV > 1 && lds_of(NV) > kLdsBudget && b->opt[RMX_OPT_FB_NV] == 0) NV /= 2;
+            const size_t lds = lds_of(NV);
             const int vpp = nt / v.SPW;
             // (round 4, late: blocks of up to 1 024 threads -- the kernel needs 59 / 82 / 117 registers at 1 / 2 / 4 vectors -- take it from 360 to 512 states)
-            if (nt <= 1024 && lds <= kLdsBudget && (NV + vpp - 1) / vpp <= 2 && ((b->pe2p + 1) / 2) <= nt) {
-                void (*kf)(FbvArgs, const double *, const uint32_t *, const uint32_t *) =
-                    nt <= 768 ? (NV == 1 ? k_fbk<1, 768> : (NV == 2 ? k_fbk<2, 768> : k_fbk<4, 768>)) : (NV == 1 ? k_fbk<1, 1024> : (NV == 2 ? k_fbk<2, 1024> : k_fbk<4, 1024>));
+            if (nt <= 1024 && lds <= kLdsBudget && (NV + vpp - 1) / vpp <= 2) {
+                void (*kf)(FbvArgs, const double *, const uint32_t *, const uint32_t *, const uint32_t *) =
+                    m4 ? (nt <= 768 ? (NV == 1 ? k_fbk<1, 768, true> : (NV == 2 ? k_fbk<2, 768, true> : k_fbk<4, 768, true>)) : (NV == 1 ? k_fbk<1, 1024, true> : (NV == 2 ? k_fbk<2, 1024, true> : k_fbk<4, 1024, true>)))
+                       : (nt <= 768 ? (NV == 1 ? k_fbk<1, 768, false> : (NV == 2 ? k_fbk<2, 768, false> : k_fbk<4, 768, false>)) : (NV == 1 ? k_fbk<1, 1024, false> : (NV == 2 ? k_fbk<2, 1024, false> : k_fbk<4, 1024, false>)));
                 HIPCHK(hipFuncSetAttribute((const void *)kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-                hipLaunchKernelGGL(kf, dim3(b->n_fast, (nr + NV - 1) / NV, 2), dim3(nt), lds, b->stream, v, (const double *)b->d_wk, (const uint32_t *)b->d_cnpack, (const uint32_t *)b->d_totpack);
+                hipLaunchKernelGGL(kf, dim3(b->n_fast, (nr + NV - 1) / NV, 2), dim3(nt), lds, b->stream, v, (const double *)b->d_wk, (const uint32_t *)b->d_cnpack, (const uint32_t *)b->d_totpack, (const uint32_t *)b->d_cnpack2);
                 done_fast = true; fast = true; b->last_fb_kernel = 3; b->last_fb_nv = b->last_fb_nv_max = NV;
             }
         }

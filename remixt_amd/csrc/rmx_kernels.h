@@ -1691,8 +1691,10 @@ __global__ __launch_bounds__(768) void k_fbq(FbmArgs a, const double *wk, const 
 //   thread t (phase 2):  vector t / SPW + pass * (NT / SPW), state t % SPW
 // =============================================================================
 #define FBK_P 4
-template <int NV, int NTMAX>
-__global__ __launch_bounds__(NTMAX) void k_fbk(FbvArgs a, const double *wk, const uint32_t *cnpack, const uint32_t *totpack) {
+// M4 (round 4): four clones -- the third tumour clone's allele copies in a second packed word (cnpack2), its total in the third byte of totpack, the
+// clone-product table of a breakend D^3 entries (loaded by as many transfers per thread as it takes)
+template <int NV, int NTMAX, bool M4>
+__global__ __launch_bounds__(NTMAX) void k_fbk(FbvArgs a, const double *wk, const uint32_t *cnpack, const uint32_t *totpack, const uint32_t *cnpack2) {
     extern __shared__ __align__(16) unsigned char smem_raw[];
     const int chain = a.chain_list[blockIdx.x], dir = blockIdx.z;
     const int rg0 = a.r0 + blockIdx.y * NV;
@@ -1719,8 +1721,9 @@ __global__ __launch_bounds__(NTMAX) void k_fbk(FbvArgs a, const double *wk, cons
     double *wtab = pel + (size_t)NV * a.PE2P;                   // [64] exp(-pen * k)
     uint32_t *cnl = (uint32_t *)(wtab + 64);                    // [SPAD] packed allele copies of the row states (0 past S)
     uint32_t *tpl = cnl + SPAD;                                 // [SPAD] packed totals
-    int *bel = (int *)(tpl + SPAD);                             // adjacencies of this chain's breakends
-    for (int i = t; i < SPAD; i += NT) { cnl[i] = i < S ? cnpack[(size_t)cls * S + i] : 0u; tpl[i] = i < S ? totpack[(size_t)cls * S + i] : 0u; }
+    uint32_t *cnl2 = tpl + SPAD;                                // [SPAD] (M4) packed allele copies of the third tumour clone
+    int *bel = (int *)(cnl2 + (M4 ? SPAD : 0));                 // adjacencies of this chain's breakends
+    for (int i = t; i < SPAD; i += NT) { cnl[i] = i < S ? cnpack[(size_t)cls * S + i] : 0u; tpl[i] = i < S ? totpack[(size_t)cls * S + i] : 0u; if (M4) cnl2[i] = i < S ? cnpack2[(size_t)cls * S + i] : 0u; }
     const int be_lo = a.chain_be[2 * chain], be_hi = a.chain_be[2 * chain + 1];
     for (int i = t; i < be_hi - be_lo; i += NT) bel[i] = a.be_n[be_lo + i];
     for (int i = t; i < NV * 2 * SPAD; i += NT) vec[i] = 0.;
@@ -1730,6 +1733,8 @@ __global__ __launch_bounds__(NTMAX) void k_fbk(FbvArgs a, const double *wk, cons
     auto swap_alleles = [](uint32_t x) { return ((x & 0x00ff00ffu) << 8) | ((x >> 8) & 0x00ff00ffu); };
     const uint32_t co0 = o0 < S ? cnpack[(size_t)cls * S + o0] : 0u, co1 = o1 < S ? cnpack[(size_t)cls * S + o1] : 0u;
     const uint32_t co0s = swap_alleles(co0), co1s = swap_alleles(co1);
+    const uint32_t cb0 = (M4 && o0 < S) ? cnpack2[(size_t)cls * S + o0] : 0u, cb1 = (M4 && o1 < S) ? cnpack2[(size_t)cls * S + o1] : 0u;
+    const uint32_t cb0s = swap_alleles(cb0), cb1s = swap_alleles(cb1);
     const uint32_t to0 = o0 < S ? totpack[(size_t)cls * S + o0] : 0u, to1 = o1 < S ? totpack[(size_t)cls * S + o1] : 0u;
     __syncthreads();
 
@@ -1781,16 +1786,19 @@ __global__ __launch_bounds__(NTMAX) void k_fbk(FbvArgs a, const double *wk, cons
 #define FBK_ROW(rr_, BE_)                                                                                  \
     {                                                                                                      \
         const uint32_t cq_ = cnl[q0 + (rr_)];                                                              \
-        const unsigned k0_ = min(__builtin_amdgcn_sad_u8(cq_, co0, 0u), __builtin_amdgcn_sad_u8(cq_, co0s, 0u)); \
-        const unsigned k1_ = min(__builtin_amdgcn_sad_u8(cq_, co1, 0u), __builtin_amdgcn_sad_u8(cq_, co1s, 0u)); \
+        const uint32_t cq2_ = M4 ? cnl2[q0 + (rr_)] : 0u;                                                  \
+        const unsigned k0_ = min(__builtin_amdgcn_sad_u8(cq_, co0, M4 ? __builtin_amdgcn_sad_u8(cq2_, cb0, 0u) : 0u), __builtin_amdgcn_sad_u8(cq_, co0s, M4 ? __builtin_amdgcn_sad_u8(cq2_, cb0s, 0u) : 0u)); \
+        const unsigned k1_ = min(__builtin_amdgcn_sad_u8(cq_, co1, M4 ? __builtin_amdgcn_sad_u8(cq2_, cb1, 0u) : 0u), __builtin_amdgcn_sad_u8(cq_, co1s, M4 ? __builtin_amdgcn_sad_u8(cq2_, cb1s, 0u) : 0u)); \
         double w0_, w1_;                                                                                   \
         if (!(BE_)) { w0_ = wtab[k0_]; w1_ = wtab[k1_]; }                                                  \
         else {                                                                                             \
             const uint32_t tq_ = tpl[q0 + (rr_)];                                                          \
             const unsigned a0_ = k0_ - __builtin_amdgcn_sad_u8(tq_, to0, 0u), a1_ = k1_ - __builtin_amdgcn_sad_u8(tq_, to1, 0u); \
             int i0_ = sgn * ((int)(tq_ & 0xff) - (int)(to0 & 0xff)) + off, i1_ = sgn * ((int)(tq_ & 0xff) - (int)(to1 & 0xff)) + off; \
-            if (M == 3) { i0_ = i0_ * D + sgn * ((int)((tq_ >> 8) & 0xff) - (int)((to0 >> 8) & 0xff)) + off;  \
+            if (M >= 3) { i0_ = i0_ * D + sgn * ((int)((tq_ >> 8) & 0xff) - (int)((to0 >> 8) & 0xff)) + off;  \
                           i1_ = i1_ * D + sgn * ((int)((tq_ >> 8) & 0xff) - (int)((to1 >> 8) & 0xff)) + off; } \
+            if (M4)     { i0_ = i0_ * D + sgn * ((int)((tq_ >> 16) & 0xff) - (int)((to0 >> 16) & 0xff)) + off; \
+                          i1_ = i1_ * D + sgn * ((int)((tq_ >> 16) & 0xff) - (int)((to1 >> 16) & 0xff)) + off; } \
             w0_ = wtab[a0_]; w1_ = wtab[a1_];                                                              \
             _Pragma("unroll") for (int v = 0; v < NV; v++) { wbe0[v] = w0_ * pel[(size_t)v * a.PE2P + i0_]; wbe1[v] = w1_ * pel[(size_t)v * a.PE2P + i1_]; } \
         }                                                                                                  \
@@ -1819,13 +1827,16 @@ __global__ __launch_bounds__(NTMAX) void k_fbk(FbvArgs a, const double *wk, cons
         FBV_SCALE(cb, ROW(k - 1))
         if (bs >= 0) {
             // clone-product tables of this breakend, one per vector (k_brk_lut), by LDS-DMA
-            if (t < (a.PE2P + 1) / 2) {
-                for (int v = 0; v < NV; v++) {
-                    const unsigned dpe = __builtin_amdgcn_readfirstlane(lds_addr(pel + (size_t)v * a.PE2P) + (unsigned)(((t >> 6) << 6) * 16));
-                    if (v < nv && t * 2 < a.PE2P) glds16(a.pe2_lt + ((size_t)(rg0 + v) * a.NBE + bs) * a.PE2P + t * 2, dpe);
+            for (int e0 = 0; e0 < (a.PE2P + 1) / 2; e0 += NT) {      // (one round up to 2 NT entries: all grids of two or three clones)
+                const int e = e0 + t;
+                if (e - (t & 63) < (a.PE2P + 1) / 2) {                 // wave-uniform: the wave's first element is inside
+                    for (int v = 0; v < NV; v++) {
+                        const unsigned dpe = __builtin_amdgcn_readfirstlane(lds_addr(pel + (size_t)v * a.PE2P) + (unsigned)(((e >> 6) << 6) * 16));
+                        if (v < nv && e * 2 < a.PE2P) glds16(a.pe2_lt + ((size_t)(rg0 + v) * a.NBE + bs) * a.PE2P + e * 2, dpe);
+                    }
                 }
             }
-            if (t < (((a.PE2P + 1) / 2 + 63) & ~63)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (the waves that issued a transfer)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             FB_BARRIER();
         }
         if (act) {      // wave-uniform: FBK_P * G2 is a multiple of 64
@@ -2323,17 +2334,18 @@ __device__ __forceinline__ void brk_lut_body(const Dev &d, int r, int slot, cons
         if (exp_base) { const double ev = exp(-d.pen * acc); exp_base[((size_t)r * d.NBE + slot) * ((d.M * d.D + 1) & ~1) + i] = ev; if (prod_base && d.D <= 64) pes[m * 64 + dd] = ev; }
     }
     if (exp_base && prod_base && d.D <= 64) {
-        // product over the clones for the forward-backward kernels' breakend steps (M <= 3): entry
-        // (d_1 [, d_2]) = pe_0[normal-clone difference of the two classes] * pe_1[d_1] [* pe_2[d_2]]
+        // product over the clones for the forward-backward kernels' breakend steps: entry
+        // (d_1 [, d_2 [, d_3]]) = pe_0[normal-clone difference of the two classes] * pe_1[d_1] [* pe_2[d_2] [* pe_3[d_3]]]  (four clones: k_fbk only)
         __syncthreads();
         double *pr = prod_base + ((size_t)r * d.NBE + slot) * PE2P;
         // (normal clone: every state of a class has the same total, so its difference is a property of the adjacency)
         const int d0 = (int)d.tot[(size_t)d.be_cls[2 * slot] * d.S * d.M] - (int)d.tot[(size_t)d.be_cls[2 * slot + 1] * d.S * d.M];
         const double p0 = pes[d0 + d.cn_max + 1];
-        const int n2 = d.M == 2 ? d.D : d.D * d.D;
+        const int n2 = d.M == 2 ? d.D : (d.M == 3 ? d.D * d.D : d.D * d.D * d.D);
         for (int i = threadIdx.x; i < PE2P; i += blockDim.x) {
             double v = 0.;
-            if (i < n2) v = d.M == 2 ? p0 * pes[64 + i] : (p0 * pes[64 + i / d.D]) * pes[128 + i % d.D];
+            if (i < n2) v = d.M == 2 ? p0 * pes[64 + i] : (d.M == 3 ? (p0 * pes[64 + i / d.D]) * pes[128 + i % d.D]
+                                                                     : ((p0 * pes[64 + i / (d.D * d.D)]) * pes[128 + (i / d.D) % d.D]) * pes[192 + i % d.D]);
             pr[i] = v;
             if (d.pe2x_lt) d.pe2x_lt[((((size_t)(r >> 2) * d.NBE + slot) * PE2P + i) << 2) + (r & 3)] = i == n2 ? 1.0 : v;   // (entry n2, the pad: weight of k_fbm's ones column)
         }

@@ -495,8 +495,8 @@ def test_baseline_config1_shape_matches_oracle(hip, oracle_mod):
 
 # ---- state grids beyond the benchmark's (kernels generic in S <= 1024, M <= 4) ------------------------------------
 @pytest.mark.parametrize('M,max_cn,S,N,fb,vit', [
-    (4, 4, 207, 30, None, None),   # four clones with breakends above 176 states
-    (4, 6, 457, 28, None, None),
+    (4, 4, 207, 30, 3, 2),         # four clones with breakends above 176 states: k_fbk (round 4: the third tumour clone in a second packed word, clone-product tables of D^3 entries)
+    (4, 6, 457, 28, 3, 3),
     (3, 13, 413, 30, 3, 3),        # three clones above 355 states: k_fbk (weights from packed copy numbers; blocks of 896 threads), the plain lattice
     (3, 14, 477, 26, 3, 3),        # ... of 1 024 threads: the largest grid k_fbk takes (max_cn 15: 544 states, 1 088 threads)
     (3, 16, 617, 26, 0, 3),        # the general kernel k_fb<0> (weights from L2)
