@@ -661,11 +661,14 @@ class RestartGroups(object):
         if self.paced:
             for rs in self.sets:
                 rs.batch.set_option('pace_sweeps', 1)
-        # A single group has the GPU to itself: its parameter searches run as rounds the device drives (library option search_mode 5: half the
-        # latency of the rounds driven from the host; next to another group's sweeps the GPU is throughput-bound and they gain nothing) -- unless
-        # the caller chose a search mode
-        if len(self.sets) == 1 and native and 'search_mode' not in (kwargs.get('options') or {}):
-            self.sets[0].batch.set_option('search_mode', 5)
+        # A single group has the GPU to itself, and paced groups (small, or on a large state grid) leave it room: their parameter searches run as
+        # rounds the device drives (library option search_mode 5: half the latency of the rounds driven from the host -- 8 restarts as two paced
+        # groups 352-358 against 333-346 EM it/s, 355 states 153-155 against 149-150).  Free-running groups of 6 or more restarts at 165 states keep
+        # the GPU throughput-bound: there the dense run of kernels costs the other group what it saves this one (415-416 against 424-426), and the
+        # host keeps driving.  Not if the caller chose a search mode.
+        if (len(self.sets) == 1 or self.paced) and native and 'search_mode' not in (kwargs.get('options') or {}):
+            for rs in self.sets:
+                rs.batch.set_option('search_mode', 5)
 
     def close(self):
         for rs in self.sets:
