@@ -8,15 +8,16 @@ if os.environ.get('MARKS_LIB'):      # an alternative build of the library (A/B)
     from remixt_amd import _lib as _libmod
     _libmod.LIB_PATH = os.path.abspath(os.environ['MARKS_LIB'])
 from remixt_amd.restarts import RestartGroups, RestartSet
-e = synthetic.make_experiment(50000, num_clones=3, max_copy_number=8, num_chains=23, seed=0)
+MAXCN = int(os.environ.get('MAXCN', 8))
+e = synthetic.make_experiment(50000, num_clones=3, max_copy_number=MAXCN, num_chains=23, seed=0)
 R, G = int(os.environ.get('RST', 16)), int(os.environ.get('NGROUPS', 2))
-ps = synthetic.make_init_params(e, R, 8)
+ps = synthetic.make_init_params(e, R, MAXCN)
 kw = {}
 if os.environ.get('H_HALVES'):
     kw['h_halves'] = bool(int(os.environ['H_HALVES']))
 if os.environ.get('OPTS'):           # e.g. OPTS=search_mode=5
     kw['options'] = dict((k, int(v)) for k, v in (kv.split('=') for kv in os.environ['OPTS'].split(',')))
-rs = RestartGroups(e, ps, 8, groups=G, num_clones=3, quiet=True, seeds=[1000 + i for i in range(R)], **kw)
+rs = RestartGroups(e, ps, MAXCN, groups=G, num_clones=3, quiet=True, seeds=[1000 + i for i in range(R)], **kw)
 for m, v in zip(rs.models, rs.calculate_elbo()):
     m.prev_elbo = float(v)
 rs.run(3, 0, 5)
