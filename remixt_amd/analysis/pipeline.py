@@ -95,7 +95,9 @@ def fit_restarts(experiment, init_params_by_id, config, device=0, quiet=True, se
         rs = RestartSet(experiment, params, max_cn, num_clones=3, device=device, quiet=quiet, seeds=seeds,
                         **_model_kwargs(experiment, config))
     rs.fit(defaults.get_param(config, 'num_em_iter'), defaults.get_param(config, 'num_update_iter'))
-    return dict(zip(ids, rs.results()))
+    out = dict(zip(ids, rs.results()))
+    rs.close()      # (the batches' device memory and streams now, not when the collector gets to them: DESIGN 4.6)
+    return out
 
 
 # ---------------------------------------------------------------------------------

@@ -943,6 +943,7 @@ def fit_restarts_distributed(experiment, init_params, max_copy_number, num_clone
         rs.fit(num_em_iter, num_update_iter)
         local = rs.results()
         param_names = list(rs.models[0].likelihood_params)
+        rs.close()      # (the batches' device memory and streams now, not when the collector gets to them: DESIGN 4.6)
     if param_names is None:
         nc = model_kwargs.get('normal_contamination', True)
         param_names = ['negbin_r_0', 'negbin_r_1', 'betabin_M_0', 'betabin_M_1'] + (
