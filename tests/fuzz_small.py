@@ -23,6 +23,9 @@ def draw_case(seed, big=False):
         # (round 4) chains of unequal length and a small workgroup budget: the mix of workgroup shapes a genome gets on 256 CUs
         case['budget'] = int(rng.choice([0, 0, 6, 12, 24]))
         case['fractions'] = [float(x) for x in rng.choice([1., 1., 2., 4., 7.], size=case['chains'])] if rng.randint(0, 2) else None
+        # (round 4, late) one case in five: FOUR clones at max copy number 4 -- 207 states, k_fbk with the third tumour clone in its second packed word
+        if rng.randint(0, 5) == 0:
+            case['M'], case['max_cn'], case['R'] = 4, 4, min(case['R'], 4)
         return case
     N = int(rng.choice([4, 5, 7, 12, 20, 33, 64, 90]))
     chains = int(rng.randint(1, min(6, N // 2) + 1))
@@ -54,12 +57,15 @@ def run_case(case, oracle_mod):
             pass
     ps = synthetic.make_init_params(e, case['R'], case['max_cn'], num_clones=case['M'])
     options = {'fb_nv': case['fb_nv'], 'fb_wg_budget': case.get('budget', 0)}
-    dev, ora = _two_sets(oracle_mod, e, ps, case['max_cn'], case['M'], options=options)
+    kw = {}
+    if case['M'] == 4:      # (make_init_params describes three clones: the tumour depth split three ways)
+        kw['h_init'] = [np.array([p_['h_normal']] + [p_['h_tumour'] * f_ for f_ in (0.5, 0.3, 0.2)]) for p_ in ps]
+    dev, ora = _two_sets(oracle_mod, e, ps, case['max_cn'], case['M'], options=options, **kw)
     _compare_after_every_update(dev, ora, rtol=1e-7, elbo_rtol=1e-7, ties_ok=True)
     b = dev.batch
     # the same sweeps once more on a fresh batch: bit-identical (what caught the stale matrix-instruction operand of round 4)
     post = [b.get_array(r, 'posterior_marginals') for r in range(case['R'])]
-    dev2, _ = _two_sets(oracle_mod, e, ps, case['max_cn'], case['M'], options=options)
+    dev2, _ = _two_sets(oracle_mod, e, ps, case['max_cn'], case['M'], options=options, **kw)
     for step in STEPS * 2:
         getattr(dev2.batch, step)()
     for r in range(case['R']):
