@@ -3,8 +3,9 @@
 TEST INFRASTRUCTURE ONLY (build container; /root/reference never travels).
 
 * `load_ref_bpmodel()`  -> the compiled reference kernel module built by
-  oracle/build_ref.py (binary only; may also run on the GPU box as the
-  "reference" CPU baseline because it is a plain CPython extension).
+  oracle/build_ref.py (binary only, build container only: `.gpurunignore`
+  lists oracle/_ref/, so the reference never goes to the GPU box in any form;
+  the bench's CPU baseline there is the oracle port, `kind: "port"`).
 * `load_ref_cn_model()` -> the reference's Python host class module
   (`remixt/cn_model.py`), imported from /root/reference *in place*.  Only
   possible in the build container.
