@@ -71,7 +71,7 @@ def parse(argv=None):
     ap.add_argument('--strong-total', type=int, default=64, help='N > 1 in the default (weak) mode also times the fixed job of BASELINE configs[3] with this many restarts in total; 0 = skip')
     ap.add_argument('--datasets', type=int, default=1, help='2 = BASELINE configs[4]: two tumour samples on the same segmentation / breakpoints, fitted independently')
     ap.add_argument('--update-iters', type=int, default=5)
-    ap.add_argument('--groups', type=int, default=2, help='restart groups per GPU and dataset (own stream + host thread each; results do not depend on it)')
+    ap.add_argument('--groups', type=int, default=2, help='restart groups per GPU and dataset (own stream + host thread each; a restart\'s result is bit-identical across groupings per search mode and forward-backward workgroup shape, which RestartGroups picks by group size: DESIGN 4.6)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-sample-segments', type=int, default=800, help='segments of the CPU baseline sample at the headline grid (about 10 s of one core)')
     ap.add_argument('--cpu-sample-segments-355', type=int, default=120, help='segments of the CPU baseline sample at 355 states (0 = skip)')
@@ -490,30 +490,30 @@ def main(argv=None, kernel_module=None, dist_backend='nccl', script=None):
             try:
                 line['fit_from_init'] = fit_from_init(args, rs, device)
             except Exception as err:
-                line['fit_from_init'] = {'error': str(err)}
+                line['fit_from_init'] = _error_object(err)
         if single and not args.no_extra_states and args.groups != 1:
             # the forward-backward kernel at its other launch shape: all 16 restarts of the GPU in one launch (one restart group)
             try:
                 line['roofline_one_group'] = one_group_roofline(args, rs, device)
             except Exception as err:
-                line['roofline_one_group'] = {'error': str(err)}
+                line['roofline_one_group'] = _error_object(err)
         if single and not args.no_extra_states and args.max_cn == 8:
             # "also report S = 355 at max_cn = 12" (the reference's default max_copy_number):
             # same segments / restarts / step definition, reported next to the headline configuration
             try:
                 line['states_355'] = extra_states(args, rs, device)
             except Exception as err:      # never let the extra measurement hide the headline number
-                line['states_355'] = {'error': str(err)}
+                line['states_355'] = _error_object(err)
         if single and not args.no_extra_states and args.max_cn == 8 and args.restarts == 16:
             try:
                 line['strong_scaling_proxy'] = strong_scaling_proxy(args, rs, device)
             except Exception as err:
-                line['strong_scaling_proxy'] = {'error': str(err)}
+                line['strong_scaling_proxy'] = _error_object(err)
         if single and not args.no_extra_states and args.max_cn == 8:
             try:
                 line['unequal_chains'] = unequal_chains(args, rs, device, line['value'])
             except Exception as err:
-                line['unequal_chains'] = {'error': str(err)}
+                line['unequal_chains'] = _error_object(err)
         if cpu is not None:
             cpu355 = cpu.pop('states_355', None) if isinstance(cpu, dict) else None
             line['cpu_baseline'] = cpu
@@ -676,7 +676,7 @@ def _timed_run_isolated(args, device, restarts, groups, max_cn, nsteps, warm, un
     The restart groups of a process's FIRST measurement find the hardware queues unused and every stream gets its own; groups
     built later in the same process shared queues now and then even with their predecessors destroyed (states_355 110 instead of 150 EM
     it/s in one run of five).  A fit is a process of its own in production (the reference's `fit` task): that is what is measured.
-    Falls back to the in-process run if the child fails."""
+    A child that fails raises SubRunFailed: the caller reports {'error', 'child_rc', 'child_stderr_tail'} in the measurement's object."""
     cmd = [sys.executable, os.path.abspath(__file__), '--sub-run', '%d,%d,%d,%d,%d,%d' % (restarts, groups, max_cn, nsteps, warm, 1 if unequal else 0),
            '--segments', str(args.segments), '--clones', str(args.clones), '--update-iters', str(args.update_iters)]
     for item in args.option:
@@ -687,16 +687,42 @@ def _timed_run_isolated(args, device, restarts, groups, max_cn, nsteps, warm, un
         cmd += ['--lib', args.lib]
     try:
         res = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
-        line = [l for l in res.stdout.splitlines() if l.startswith('SUB_RUN ')]
-        if not line:
-            raise RuntimeError((res.stderr or res.stdout)[-300:])
-        j = json.loads(line[-1][len('SUB_RUN '):])
-        prof = dict((k, (v[0], v[1])) for k, v in j['prof'].items())
-        return _RunInfo(j['paced'], j['info']), j['S'], j['N1'], j['dt'], np.array([j['elbo_best']]), prof
-    except Exception as err:
-        sys.stderr.write('bench.py: additional measurement in a child process failed (%s); measuring in this process\n' % str(err)[:200])
-        from remixt_amd import synthetic
-        return _timed_run(args, device, restarts, groups, max_cn, nsteps, warm, chain_fractions=synthetic.HUMAN_CHROMOSOME_MB if unequal else None)
+    except subprocess.TimeoutExpired as err:
+        # (subprocess.run has killed the child in the middle of its GPU work: reported, never measured again in this process -- a hang is a finding)
+        raise SubRunFailed('additional measurement: child process killed after %d s' % 600, None, _tail(err.stderr))
+    line = [l for l in res.stdout.splitlines() if l.startswith('SUB_RUN ')]
+    if res.returncode != 0 or not line:
+        raise SubRunFailed('additional measurement: child process failed (rc %s)' % res.returncode, res.returncode, _tail(res.stderr or res.stdout))
+    j = json.loads(line[-1][len('SUB_RUN '):])
+    prof = dict((k, (v[0], v[1])) for k, v in j['prof'].items())
+    return _RunInfo(j['paced'], j['info']), j['S'], j['N1'], j['dt'], np.array([j['elbo_best']]), prof
+
+
+class SubRunFailed(RuntimeError):
+    """A --sub-run child that exited non-zero, printed no result or ran into the time limit.  There is NO in-process fallback:
+    the in-process regime differs and a GPU fault or hang in an additional measurement must be visible in the bench line."""
+
+    def __init__(self, message, rc, stderr_tail):
+        RuntimeError.__init__(self, message)
+        self.rc, self.stderr_tail = rc, stderr_tail
+
+
+def _tail(text, n=600):
+    if text is None:
+        return ''
+    if isinstance(text, bytes):
+        text = text.decode('utf-8', 'replace')
+    return text[-n:]
+
+
+def _error_object(err):
+    """What an additional measurement's object holds when it failed."""
+    out = {'error': str(err)}
+    if isinstance(err, SubRunFailed):
+        out['measured_in'] = 'child process'
+        out['child_rc'] = err.rc
+        out['child_stderr_tail'] = err.stderr_tail
+    return out
 
 
 def sub_run(args):
@@ -739,13 +765,14 @@ def extra_states(args, rs_main, device):
            'seg_state_cells_per_s': float(N1) * S * R * args.update_iters * nsteps / dt, 'elbo_best': float(np.nanmax(elbo)),
            'forward_backward_kernel': {1: 'k_fbm', 2: 'k_fbv', 3: 'k_fbk', 4: 'k_fbq', 0: 'k_fb<0>'}.get(rs.batches[0].info(12)),
            'roofline': roofline_object(dom, float(N1) * S * R / G355, S, a355, R // G355, traffic_file='traffic_r04_s355_8.json'),
-           'kernels': dict((k, {'ms': round(v[0], 3), 'n': v[1]}) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0]))}
+           'kernels': dict((k, {'ms': round(v[0], 3), 'n': v[1]}) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])),
+           'measured_in': 'child process (rc 0)'}
     _release(rs)
     # the forward-backward kernel at its other launch shape here too: all 16 restarts in one launch (one restart group)
     try:
         out['roofline_one_group'] = one_group_roofline(a355, None, device, traffic_file='traffic_r04_s355.json', nsteps=3)
     except Exception as err:
-        out['roofline_one_group'] = {'error': str(err)}
+        out['roofline_one_group'] = _error_object(err)
     return out
 
 
@@ -766,7 +793,7 @@ def unequal_chains(args, rs_main, device, headline_value):
            'value': args.restarts * nsteps / dt, 'unit': 'EM iterations/s', 'ms_per_step': dt / nsteps * 1e3, 'steps': nsteps, 'warmup': 2,
            'fb_avg_launch_ms': fb[0] / max(fb[1], 1), 'fb_restarts_per_workgroup': [b.info(13), b.info(15)],
            'ratio_to_headline': (args.restarts * nsteps / dt) / headline_value if headline_value else None,
-           'elbo_best': float(np.nanmax(elbo))}
+           'elbo_best': float(np.nanmax(elbo)), 'measured_in': 'child process (rc 0)'}
     _release(rs)
     return out
 
@@ -829,7 +856,7 @@ def strong_scaling_proxy(args, rs_main, device):
                                     'fb_avg_launch_ms': fb64[0] / max(fb64[1], 1), 'fb_restarts_per_launch': 16},
             'one_rank_share_8_restarts': {'value': its8, 'unit': 'EM iterations/s', 'ms_per_step': dt8 / nsteps8 * 1e3, 'restart_groups': args.groups,
                                           'fb_avg_launch_ms': fb8[0] / max(fb8[1], 1), 'fb_restarts_per_launch': 8 // max(1, args.groups)},
-            'predicted_speedup_8_gpus_over_1': 8. * its8 / its64, 'target': 6.0,
+            'predicted_speedup_8_gpus_over_1': 8. * its8 / its64, 'target': 6.0, 'measured_in': 'two child processes (rc 0, 0)',
             'note': 'a forward-backward launch is a chain of 2 173 dependent steps per chromosome: with 16 restarts per launch a workgroup carries four restarts on the '
                     'matrix cores (2.8 ms), a rank\'s 4-restart launches carry one per workgroup on the vector ALU (1.5 ms) -- shorter, but not four times shorter: one '
                     'GPU amortises the chain over 64 restarts, a rank holding 8 cannot'}

@@ -11,7 +11,8 @@ def _segment_columns(experiment):
     """The per-segment columns of the result tables as an ordered list of (name, array): identification, length, the three read counts,
     the minor-allele ratio (0 where no allele reads were counted) and the depths that follow from it.  The names and formulas are the
     reference's table schema (remixt/analysis/experiment.py:323-351); the arrays are computed once, in numpy."""
-    x = np.asarray(experiment.x, dtype=float)
+    counts = np.asarray(experiment.x)                 # the three count columns keep experiment.x's own dtype, as in the reference (:333-342)
+    x = counts.astype(float)
     length = np.asarray(experiment.l, dtype=float)
     major, minor, total = x[:, 0], x[:, 1], x[:, 2]
     allele_reads = major + minor
@@ -24,7 +25,7 @@ def _segment_columns(experiment):
     return [
         ('chromosome', experiment.segment_chromosome_id), ('start', experiment.segment_start), ('end', experiment.segment_end),
         ('major_is_allele_a', experiment.segment_major_is_allele_a), ('length', experiment.l),
-        ('major_readcount', major), ('minor_readcount', minor), ('readcount', total), ('allele_ratio', ratio),
+        ('major_readcount', counts[:, 0]), ('minor_readcount', counts[:, 1]), ('readcount', counts[:, 2]), ('allele_ratio', ratio),
         ('major_depth', depths[0]), ('minor_depth', depths[1]), ('total_depth', depths[2]),
     ]
 

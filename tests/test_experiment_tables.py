@@ -64,3 +64,16 @@ def test_create_experiment_from_tsv_and_model_construction(tmp_path):
     assert len(e4.breakpoint_segment_data) == 0 and e4.breakpoints == {}
     seg = ex.create_segment_table(e)
     assert len(seg) == len(counts) and np.all(np.isfinite(seg['total_depth']))
+    # the three count columns keep experiment.x's dtype (the reference builds them from experiment.x[:, i] unchanged, analysis/experiment.py:333-342)
+    for col, i in (('major_readcount', 0), ('minor_readcount', 1), ('readcount', 2)):
+        assert seg[col].dtype == np.asarray(e.x).dtype and np.array_equal(seg[col].values, np.asarray(e.x)[:, i]), col
+
+    class IntCounts(object):
+        pass
+    ei = IntCounts()
+    for name in ('segment_chromosome_id', 'segment_start', 'segment_end', 'segment_major_is_allele_a', 'l'):
+        setattr(ei, name, getattr(e, name))
+    ei.x = np.asarray(e.x).astype(np.int64)
+    segi = ex.create_segment_table(ei)
+    assert segi['readcount'].dtype == np.int64 and segi['major_readcount'].dtype == np.int64 and segi['allele_ratio'].dtype == np.float64
+    np.testing.assert_allclose(segi['total_depth'].values, ei.x[:, 2] / np.asarray(e.l, dtype=float))

@@ -82,18 +82,33 @@ def test_config2_bench_shape_em_iterations_with_msteps(workload):
         # two groups launch 8 restarts at a time: two per forward-backward workgroup (k_fbm<., 2>, vector ALU; 184 workgroups), chosen by the
         # library; the one-group run (16 per launch: four per workgroup by itself) is pinned to the same shape -- bit-identity across launch
         # sizes holds per workgroup shape (test_s165_workgroup_shapes_agree_and_subranges_are_bit_identical)
-        rs = RestartGroups(e, [p64[i] for i in ids], MAX_CN, groups=groups, num_clones=M, quiet=True, seeds=_seeds(ids), paced=paced,
-                           options=({'fb_nv': 2} if groups == 1 else None))
+        # The parameter-search driver is pinned too: RestartGroups gives a single group and paced groups the device-driven rounds
+        # (search_mode 5: device log(), per-block cell sums) and free-running groups the host-driven ones (0); the two agree to rounding, not to
+        # the bit, so bit-identity across groupings holds per search mode and workgroup shape.
+        opts = {'search_mode': 0}
+        if groups == 1:
+            opts['fb_nv'] = 2
+        rs = RestartGroups(e, [p64[i] for i in ids], MAX_CN, groups=groups, num_clones=M, quiet=True, seeds=_seeds(ids), paced=paced, options=opts)
         b = rs.batches[0]
         assert b.num_cn_states == 165 and b.num_segments >= SEG
         e0, e2 = _run(rs, iters=2)
         assert b.info(12) == 1 and b.info(13) == 2          # k_fbm, two restarts per workgroup
-        assert rs.paced == paced and b.get_option('pace_sweeps') == int(paced)
+        assert rs.paced == paced and b.get_option('pace_sweeps') == int(paced) and b.get_option('search_mode') == 0
         out[groups, paced] = _state(rs)
         _release(rs)
     for r in ids:
         assert _same(out[2, False][r], out[1, False][r]), ('restart %d: 2 groups vs 1 group' % r, out[2, False][r], out[1, False][r])
         assert _same(out[2, True][r], out[1, False][r]), ('restart %d: 2 paced groups vs 1 group' % r, out[2, True][r], out[1, False][r])
+    # the automatic choice for one group (device-driven search rounds, four restarts per workgroup) against the pinned runs: at tolerance
+    rs = RestartGroups(e, [p64[i] for i in ids], MAX_CN, groups=1, num_clones=M, quiet=True, seeds=_seeds(ids))
+    _run(rs, iters=2)
+    assert rs.batches[0].get_option('search_mode') == 5 and rs.batches[0].info(13) == 4
+    auto = _state(rs)
+    _release(rs)
+    for r in ids:
+        assert abs(auto[r][0] - out[1, False][r][0]) <= 1e-7 * abs(auto[r][0]), (r, auto[r][0], out[1, False][r][0])
+        np.testing.assert_allclose(auto[r][1], out[1, False][r][1], rtol=1e-5)
+        np.testing.assert_allclose(auto[r][2], out[1, False][r][2], rtol=1e-3)
 
 
 def test_config3_per_gpu_share_and_the_whole_job_on_one_gpu(workload):
@@ -112,14 +127,15 @@ def test_config3_per_gpu_share_and_the_whole_job_on_one_gpu(workload):
     part_auto = dict(zip(share, _state(rs)))
     _release(rs)
     # ... and with the workgroup shape of the whole job's 16-restart launches (four per workgroup, matrix cores): the shapes sum a column in
-    # different orders, so bit-identity across launch sizes holds per shape
-    rs = RestartGroups(e, [p64[i] for i in share], MAX_CN, groups=2, num_clones=M, quiet=True, seeds=_seeds(share), options={'fb_nv': 4})
+    # different orders, so bit-identity across launch sizes holds per shape -- and per search driver: two paced groups of 4 get the device-driven
+    # rounds (search_mode 5) by themselves, the whole job's free-running groups of 16 the host-driven ones (0)
+    rs = RestartGroups(e, [p64[i] for i in share], MAX_CN, groups=2, num_clones=M, quiet=True, seeds=_seeds(share), options={'fb_nv': 4, 'search_mode': 0})
     _run(rs, iters=1)
     part = dict(zip(share, _state(rs)))
     _release(rs)
 
     ids = list(range(64))
-    rs = RestartGroups(e, p64, MAX_CN, groups=4, num_clones=M, quiet=True, seeds=_seeds(ids))
+    rs = RestartGroups(e, p64, MAX_CN, groups=4, num_clones=M, quiet=True, seeds=_seeds(ids), options={'search_mode': 0})
     assert len(rs.batches) == 4 and all(b.num_restarts == 16 for b in rs.batches)
     _run(rs, iters=1)
     whole = _state(rs)
@@ -195,7 +211,7 @@ def test_states355_bench_shape_em_iterations_with_msteps(workload355):
     ids = list(range(16))
     out = {}
     for groups in (2, 1):
-        rs = RestartGroups(e, p16, 12, groups=groups, num_clones=M, quiet=True, seeds=_seeds(ids), options={'fb_nv': 4})
+        rs = RestartGroups(e, p16, 12, groups=groups, num_clones=M, quiet=True, seeds=_seeds(ids), options={'fb_nv': 4, 'search_mode': 5})      # (both pinned: bit-identity is per workgroup shape and search driver)
         b = rs.batches[0]
         assert b.num_cn_states == 355 and b.num_segments >= SEG
         assert rs.paced == (groups == 2)                      # what RestartGroups chooses above 200 states

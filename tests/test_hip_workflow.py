@@ -92,3 +92,40 @@ def test_file_level_tasks_reproduce_the_one_call_form(case):
             assert a['solutions/solution_%d/h' % i].shape == b['solutions/solution_%d/h' % i].shape == (3,)
             assert list(a['solutions/solution_%d/cn' % i].columns) == list(b['solutions/solution_%d/cn' % i].columns)
         assert set(k.lstrip('/') for k in a.keys()) == set(k.lstrip('/') for k in b.keys())
+
+
+def test_fit_model_on_the_device_equals_fit_model_over_the_oracle(case, oracle_mod):
+    """The workflow-level parity check (remixt/workflow.py:307-354 → analysis/pipeline.py:231-293): `workflow.fit_model` on the HIP library
+    against the SAME call over the CPU oracle kernel (`kernel_module=oracle`: one model per restart, scipy per restart) on the same experiment
+    pickle, config and seeds -- the same optimal init_id, every solution's ELBO to 1e-6 and h to 1e-4, and the `cn` / `brk_cn` tables of every
+    solution equal (copy numbers, their differences and masks exactly, the float columns derived from h to 1e-4)."""
+    from remixt_amd import workflow
+    from remixt_amd.analysis import pipeline
+    tmp, e, exp_file, config = case
+    seeds = [41, 42, 43]
+    best_hip = workflow.fit_model(exp_file, str(tmp / 'parity_hip.store'), config, None, 'tumour_b', seeds=seeds)
+    best_cpu = workflow.fit_model(exp_file, str(tmp / 'parity_cpu.store'), config, None, 'tumour_b', seeds=seeds, kernel_module=oracle_mod)
+    assert best_hip == best_cpu
+    with pipeline._Store(str(tmp / 'parity_hip.store'), 'r') as a, pipeline._Store(str(tmp / 'parity_cpu.store'), 'r') as b:
+        assert set(k.lstrip('/') for k in a.keys()) == set(k.lstrip('/') for k in b.keys())
+        sa, sb = a['stats'].sort_values('init_id').reset_index(drop=True), b['stats'].sort_values('init_id').reset_index(drop=True)
+        assert list(sa['init_id']) == list(sb['init_id']) == [0, 1, 2]
+        np.testing.assert_allclose(sa['elbo'].values, sb['elbo'].values, rtol=1e-6)
+        np.testing.assert_allclose(sa['elbo_diff'].values, sb['elbo_diff'].values, rtol=1e-4, atol=1e-6 * np.abs(sb['elbo'].values).max())
+        for col in ('ploidy', 'proportion_divergent', 'negbin_r_0', 'negbin_r_1', 'betabin_M_0', 'betabin_M_1'):
+            np.testing.assert_allclose(sa[col].values, sb[col].values, rtol=1e-3, err_msg=col)
+        assert list(sa['error_message'].astype(str)) == list(sb['error_message'].astype(str))
+        tables = ['cn', 'brk_cn', 'mix'] + ['solutions/solution_%d/%s' % (i, t) for i in range(3) for t in SOLUTION_TABLES]
+        for key in tables:
+            ta, tb = a[key], b[key]
+            if not hasattr(ta, 'columns'):                      # h, mix: series
+                np.testing.assert_allclose(np.asarray(ta, dtype=float), np.asarray(tb, dtype=float), rtol=1e-4, err_msg=key)
+                continue
+            assert list(ta.columns) == list(tb.columns) and len(ta) == len(tb), key
+            for col in ta.columns:
+                va, vb = ta[col].values, tb[col].values
+                if va.dtype.kind == 'f':                        # depths, raw copies, outlier probabilities: functions of h and the posteriors
+                    np.testing.assert_allclose(va, vb, rtol=1e-4, atol=1e-7, err_msg='%s.%s' % (key, col))
+                else:                                           # decoded copy numbers (int64), masks, major/minor differences, ids, positions: exact
+                    assert np.array_equal(va, vb), '%s.%s' % (key, col)
+        np.testing.assert_allclose(a['read_depth'].values.astype(float), b['read_depth'].values.astype(float), rtol=1e-12)

@@ -64,3 +64,11 @@ def test_oracle_scalar_kats(oracle_mod):
     from scipy.special import digamma
     for x in [1e-7, 0.3, 1.0, 4.2, 8.5, 20., 1234.5]:
         assert np.isclose(oracle_mod.digamma(x), digamma(x), rtol=1e-9)
+
+
+@pytest.mark.parametrize('case', ['m2', 'm3_nonormal'])
+def test_oracle_kernel_object_replays_the_reference_fit_call_trace(oracle_mod, case):
+    """The call trace of the reference's own BreakpointModel.fit (oracle/make_protocol_trace.py) against the oracle's kernel object:
+    pins the oracle's object protocol call by call, and the replay the GPU suite runs against the HIP kernel object."""
+    from .protocol_replay import replay
+    replay(oracle_mod.RemixtModel, case, check_dir=False)
