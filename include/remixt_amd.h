@@ -144,11 +144,12 @@ enum rmx_option_id {
     RMX_OPT_FUSE_SWEEPS,        /* 1 (default): marginals + indicator updates + next frame pass as one kernel between sweeps */
     RMX_OPT_TWO_STREAMS,        /* 1 (default): breakend branch of a sweep on a second stream next to the marginal pass */
     RMX_OPT_VITERBI_PLAIN,      /* 1: decode with the table-reading lattice kernel */
-    RMX_OPT_SEARCH_MODE,        /* parameter searches: 0 the four standard searches together in shared rounds driven from the host (default);
-                                   5 in rounds the device drives: optimiser state on the device, a kernel pair per round, queued back to back
-                                   (half the latency; for a batch that has the GPU to itself);
+    RMX_OPT_SEARCH_MODE,        /* parameter searches: 5 (default since round 5) the four standard searches together in rounds the device drives: optimiser
+                                   state on the device, a kernel pair per round, queued back to back (half the latency of the host-driven rounds);
+                                   0 the same shared rounds driven from the host (the default until round 4);
                                    1 one parameter at a time; 2 with table rebuilds per candidate; 3 with look-ahead evaluations;
-                                   4 on the full objective */
+                                   4 on the full objective; 6 = 0 with the final sums of a Nelder-Mead round folded into the objective kernel (last-block ticket: same bits, one launch
+                                   fewer per round, but a release fence per block -- measured 5 % slower on the headline, not the default) */
     RMX_OPT_ELL_DENSE,          /* 1: sampled objectives over all states instead of the lists of states with posterior mass */
     RMX_OPT_STRIP,              /* 1 (default): strip kernels for the (segment x state) passes when 32 < S <= 384 */
     RMX_OPT_CELL_CACHE,         /* creation time, 1 (default): cache the six likelihood values of every cell */
@@ -161,6 +162,11 @@ enum rmx_option_id {
                                    make 144 EM iterations/s, free-running ones 118 */
     RMX_OPT_FB_WG_BUDGET,       /* workgroups a forward-backward launch may have side by side when the shapes of its chains are chosen (0: 256, one per CU
                                    of an MI355X): tests set a small number to put a small problem on the mixed shapes a genome gets */
+    RMX_OPT_TRIAL_KERNEL,       /* M-step trial passes over the lists of states with posterior mass: 0 (default) cells laid out flat over the threads
+                                   (k_trial_flat: a segmented sum in list order), 1 a quarter wave per segment (k_trial_sparse) */
+    RMX_OPT_GRAD_KERNEL,        /* h M-step rounds (objective + gradient on the samples): 0 (default) the lane chains laid out flat over the threads
+                                   (k_gradflat_round; the same per-segment sums to the bit), 1 half a wave per sampled segment with the final sums
+                                   folded in (round 4's form), 2 half a wave per segment and the final sums as a kernel of their own */
     RMX_OPT_COUNT
 };
 int rmx_set_default_option(int32_t option_id, int32_t value);

@@ -47,7 +47,7 @@ static const char *kKernelNames[KID_COUNT] = {
 struct ProfRec { int id; hipEvent_t a, b; };
 
 // tuning options (include/remixt_amd.h rmx_option_id): process-wide defaults, copied into a batch at creation
-static int g_opt_default[RMX_OPT_COUNT] = {0, 0, 1, 1, 1, 0, 0, 0, 1, 1, 1, 0, 0, 0, 0};
+static int g_opt_default[RMX_OPT_COUNT] = {0, 0, 1, 1, 1, 0, 5, 0, 1, 1, 1, 0, 0, 0, 0, 0, 0};      // (search_mode 5 since round 5)
 static std::mutex g_opt_mu;
 
 struct rmx_batch {
@@ -102,7 +102,12 @@ struct rmx_batch {
     double *d_mpartial = nullptr; size_t mpartial_cap = 0;
     std::vector<std::vector<int64_t>> sample_cache; std::vector<int> sample_count;
     double *d_grid_out = nullptr;      // [R][64][1+MAXC]
-    unsigned *d_done = nullptr;        // [R] per-request completion tickets of the fused objective kernels (zero between launches)
+    GradFlatLayout gf_lay = {nullptr, nullptr, nullptr, nullptr};      // layout of the flat h-round kernel (made once per M-step: gf_sig)
+    std::vector<double> gf_sig;        // what the layout was made for: request list, sample / list epochs, likelihood parameters
+    std::vector<long long> sample_epoch, sig_epoch;
+    int32_t *gf_nblk_host = nullptr;   // [16] host-visible: blocks per request
+    bool gf_first = false;
+    unsigned *d_done = nullptr;        // [max(R, 64)] per-request completion tickets of the fused objective kernels (zero between launches)
     int32_t *d_rlist = nullptr, *d_counts = nullptr; RestartParams *d_rp_stage = nullptr; double *d_batch_out = nullptr;   // [R] each
     void *h_batch = nullptr;           // pinned staging for the batched objective
     std::vector<int32_t> plain_list; int32_t *d_plain_list = nullptr; double *d_plain_jt = nullptr;
@@ -680,9 +685,10 @@ static bool option_value_ok(int id, int v) {
     switch (id) {
     case RMX_OPT_FB_KERNEL: return v >= 0 && v <= 3;
     case RMX_OPT_FB_NV: return v == 0 || v == 1 || v == 2 || v == 4;      // the workgroup shapes that exist (k_fbm and k_fbv / k_fbk 1 / 2 / 4, k_fbq 4)
-    case RMX_OPT_SEARCH_MODE: return v >= 0 && v <= 5;
+    case RMX_OPT_SEARCH_MODE: return v >= 0 && v <= 6;
     case RMX_OPT_PAIRWISE_KERNEL: return v >= 0 && v <= 4;
     case RMX_OPT_FB_WG_BUDGET: return v >= 0 && v <= 4096;
+    case RMX_OPT_GRAD_KERNEL: return v >= 0 && v <= 2;
     default: return v == 0 || v == 1;
     }
 }
@@ -894,8 +900,8 @@ int rmx_batch_create(const rmx_problem *pr, int32_t R, const double *h_init, con
     if ((rc = dalloc(b, &b->d_lt_valid, R)) || (rc = dalloc(b, &b->d_partial, (size_t)R * ELBO_BLOCKS * 5)) || (rc = dalloc(b, &b->d_be_e, (size_t)R * std::max(d.NBE, 1))) || (rc = dalloc(b, &b->d_out4, (size_t)R * 5)) ||
         (rc = dalloc(b, &b->d_ell_partial, (size_t)R * std::max(N, ELBO_BLOCKS) * (1 + RMX_MAX_CLONES))) || (rc = dalloc(b, &b->d_ell_out, (size_t)R * 8)) ||
         (rc = dalloc(b, &b->d_sample, (size_t)R * N)) || (rc = dalloc(b, &b->d_grid_out, (size_t)R * 64 * (1 + RMX_MAX_CLONES))) ||
-        (rc = dalloc(b, &b->d_done, std::max(R, 16))) || (rc = dalloc(b, &b->d_rlist, R)) || (rc = dalloc(b, &b->d_counts, R)) || (rc = dalloc(b, &b->d_rp_stage, R)) || (rc = dalloc(b, &b->d_batch_out, (size_t)R * 8))) { rmx_batch_destroy(b); return rc; }
-    HIPCHK(hipMemset(b->d_done, 0, sizeof(unsigned) * (size_t)std::max(R, 16)));
+        (rc = dalloc(b, &b->d_done, std::max(R, 64))) || (rc = dalloc(b, &b->d_rlist, R)) || (rc = dalloc(b, &b->d_counts, R)) || (rc = dalloc(b, &b->d_rp_stage, R)) || (rc = dalloc(b, &b->d_batch_out, (size_t)R * 8))) { rmx_batch_destroy(b); return rc; }
+    HIPCHK(hipMemset(b->d_done, 0, sizeof(unsigned) * (size_t)std::max(R, 64)));
     HIPCHK(hipHostMalloc((void **)&b->h_pinned, sizeof(double) * (size_t)(R + 1) * 64 * (1 + RMX_MAX_CLONES)));
     HIPCHK(hipHostMalloc((void **)&b->h_err, sizeof(uint32_t) * ((size_t)R * 4 + 64)));      // one word per request of a round (<= 4R in rmx_param_search_multi)
     HIPCHK(hipHostMalloc(&b->h_batch, (size_t)R * (sizeof(RestartParams) + 64) + 4096));
@@ -917,7 +923,7 @@ int rmx_batch_create(const rmx_problem *pr, int32_t R, const double *h_init, con
 
     // per-restart initial state (bpmodel.pyx:546-597)
     b->sample_cache.assign(R, std::vector<int64_t>()); b->sample_count.assign(R, -1);
-    b->rp.resize(R); b->tables_dirty.assign(R, 1); b->segc_dirty.assign(R, 1); b->ab_dirty.assign(R, 1); b->comp_dirty.assign(R, 31); b->comp_base.assign(R, 31); b->cache_stale.assign(R, 15); b->sig_valid.assign(R, 0); b->lt_valid.assign(R, 0); b->lt_model.assign(R, 0); b->cached_model.assign(R, 0); b->logZ.assign(R, 0.); b->logz_dirty.assign(R, 0);
+    b->rp.resize(R); b->tables_dirty.assign(R, 1); b->segc_dirty.assign(R, 1); b->ab_dirty.assign(R, 1); b->comp_dirty.assign(R, 31); b->comp_base.assign(R, 31); b->cache_stale.assign(R, 15); b->sig_valid.assign(R, 0); b->sample_epoch.assign(R, 0); b->sig_epoch.assign(R, 0); b->lt_valid.assign(R, 0); b->lt_model.assign(R, 0); b->cached_model.assign(R, 0); b->logZ.assign(R, 0.); b->logz_dirty.assign(R, 0);
     for (int r = 0; r < R; r++) {
         RestartParams &p = b->rp[r];
         memset(&p, 0, sizeof p);
@@ -981,6 +987,7 @@ int rmx_batch_destroy(rmx_batch *b) { BIND(b);
     if (b->ev_lists) hipEventDestroy(b->ev_lists);
     if (b->h_err) hipHostFree(b->h_err);
     if (b->h_batch) hipHostFree(b->h_batch);
+    if (b->gf_nblk_host) hipHostFree(b->gf_nblk_host);
     for (auto e : b->ev_pool) hipEventDestroy(e);
     if (b->tm_a) hipEventDestroy(b->tm_a);
     if (b->tm_b) hipEventDestroy(b->tm_b);
@@ -1080,7 +1087,7 @@ int rmx_set_array(rmx_batch *b, int32_t r, int32_t id, const void *src) { BIND(b
     case RMX_A_P_OUTLIER_ALLELE: HIPCHK(hipMemcpyAsync(d.qa + RN * 2, src, (size_t)d.N * 16, hipMemcpyHostToDevice, b->stream)); break;
     case RMX_A_POSTERIOR_MARGINALS:
         HIPCHK(hipMemcpy2DAsync(d.post + RN * d.SP, (size_t)d.SP * 8, src, (size_t)d.S * 8, (size_t)d.S * 8, d.N, hipMemcpyHostToDevice, b->stream));
-        b->ab_dirty[r] = 1; b->comp_dirty[r] = 31; b->comp_base[r] = 31; b->sig_valid[r] = 0; break;
+        b->ab_dirty[r] = 1; b->comp_dirty[r] = 31; b->comp_base[r] = 31; b->sig_valid[r] = 0; b->sig_epoch[r]++; break;
     case RMX_A_TOTAL_LIKELIHOOD_MASK: case RMX_A_ALLELE_LIKELIHOOD_MASK: {
         std::vector<uint8_t> m8(d.N);
         for (int n = 0; n < d.N; n++) m8[n] = ((const int64_t *)src)[n] != 0;
@@ -1497,7 +1504,7 @@ static int p_cn_marginals(rmx_batch *b, int r0, int r1, bool fuse_next) {
         HIPCHK(hipGetLastError());
     }
     if (fuse_next && use_strip(b)) std::swap(b->d.fe, b->d.fe_alt);      // the fused pass left the next sweep's scaled emissions in the second buffer
-    for (int r = r0; r < r1; r++) { b->ab_dirty[r] = 0; b->comp_dirty[r] = 0; b->comp_base[r] = 0; b->logz_dirty[r] = 1; b->sig_valid[r] = (!fuse_next && use_strip(b) && b->d.sig_cnt) ? 1 : 0; }
+    for (int r = r0; r < r1; r++) { b->ab_dirty[r] = 0; b->comp_dirty[r] = 0; b->comp_base[r] = 0; b->logz_dirty[r] = 1; b->sig_valid[r] = (!fuse_next && use_strip(b) && b->d.sig_cnt) ? 1 : 0; b->sig_epoch[r]++; }
     return RMX_OK;
 }
 static int do_update_p_cn(rmx_batch *b, int r0, int r1, bool skip_frame = false, bool fuse_next = false) {
@@ -1728,7 +1735,7 @@ static int set_sample(rmx_batch *b, int r, const int64_t *sample) {
     std::vector<int32_t> idx;
     idx.reserve(256);
     for (int n = 0; n < d.N; n++) if (sample[n] != 0) idx.push_back(n);
-    b->sample_count[r] = (int)idx.size();
+    b->sample_count[r] = (int)idx.size(); b->sample_epoch[r]++;
     { int32_t c32 = (int32_t)idx.size(); HIPCHK(hipMemcpy(b->d_counts + r, &c32, 4, hipMemcpyHostToDevice)); }
     if (!idx.empty()) HIPCHK(hipMemcpy(b->d_sample + (size_t)r * d.N, idx.data(), idx.size() * 4, hipMemcpyHostToDevice));
     return RMX_OK;
@@ -1829,6 +1836,30 @@ int rmx_expected_ll_param_grid(rmx_batch *b, int32_t r, int32_t param_id, const 
 // one host round trip for the whole list.
 // shared tail of the batched objective calls: stage the listed restarts' parameters, rebuild their
 // state tables, evaluate every restart's sample, reduce, copy back nout values per request
+// The layout of k_gradflat_round for this request list: made (k_gradflat_setup, queued on the batch stream ahead of the round that needs it) when
+// the requests, their samples, their lists of states with posterior mass or their likelihood parameters differ from what the current layout was
+// made for -- i.e. once per h M-step; the L-BFGS-B rounds that follow change h only.  Call with b->mu held.
+static bool gradflat_ready(rmx_batch *b, int nreq, const int32_t *restarts, const StageArgs &sa) {
+    if (!b->gf_lay.upre) {
+        const size_t R = (size_t)b->R;
+        if (dalloc(b, &b->gf_lay.upre, R * (NM_MAX_SAMPLE + 1)) != RMX_OK || dalloc(b, &b->gf_lay.blk, R * (NM_MAX_SAMPLE + 2)) != RMX_OK ||
+            dalloc(b, &b->gf_lay.nblk, R) != RMX_OK || dalloc(b, &b->gf_lay.k8, R * NM_MAX_SAMPLE * 8) != RMX_OK) { b->gf_lay.upre = nullptr; return false; }
+        if (hipHostMalloc((void **)&b->gf_nblk_host, 16 * sizeof(int32_t), hipHostMallocDefault) != hipSuccess) { b->gf_lay.upre = nullptr; return false; }
+    }
+    std::vector<double> sig;
+    sig.reserve((size_t)nreq * (3 + RMX_P_HMM_LOG_NORM_CONST));
+    for (int i = 0; i < nreq; i++) {
+        const int r = restarts[i];
+        sig.push_back((double)r); sig.push_back((double)b->sample_epoch[r]); sig.push_back((double)b->sig_epoch[r]);
+        for (int k = 0; k < RMX_P_HMM_LOG_NORM_CONST; k++) sig.push_back(sa.rp[i].p[k]);
+    }
+    if (sig == b->gf_sig) return true;
+    hipLaunchKernelGGL(k_gradflat_setup, dim3(nreq), dim3(256), 0, b->stream, b->d, sa, (const int32_t *)b->d_sample, (const int32_t *)b->d_counts, b->gf_lay, b->gf_nblk_host);
+    if (hipGetLastError() != hipSuccess) return false;
+    b->gf_sig.swap(sig);
+    b->gf_first = true;
+    return true;
+}
 static int run_ell_batch(rmx_batch *b, int nreq, const int32_t *restarts, bool grad, double *out, int mask = CM_ALL) {
     const Dev &d = b->d;
     const long long t_in = now_ns();
@@ -1865,7 +1896,20 @@ static int run_ell_batch(rmx_batch *b, int nreq, const int32_t *restarts, bool g
         bool final_done = false;
         if (maxcnt > 0) {
             ProfScope ps(b, KID_ELL_LIST);
-            if (grad && ell_sparse_ok(b, nreq, restarts)) {
+            if (grad && by_value && ell_sparse_ok(b, nreq, restarts) && b->opt[RMX_OPT_GRAD_KERNEL] == 0 && maxcnt <= NM_MAX_SAMPLE && gradflat_ready(b, nreq, restarts, sa)) {
+                // the lane chains of the half-wave kernel flat over the threads (k_gradflat_round): the layout and the per-segment constants
+                // were made when this M-step's first round came through (gradflat_ready), the rounds only evaluate
+                int nb = 0;
+                if (b->gf_first) nb = (maxcnt * SEGL + 255) / 256 + 1;      // (an upper bound until the setup's block counts have come back with the first round)
+                else for (int i = 0; i < nreq; i++) nb = std::max(nb, (int)b->gf_nblk_host[i]);
+                b->gf_first = false;
+                hipLaunchKernelGGL(k_gradflat_round, dim3(std::max(nb, 1), nreq), dim3(256), 0, b->stream, b->d, (const int32_t *)b->d_rlist, (const RestartParams *)b->d_rp_stage,
+                                   (const int32_t *)b->d_sample, (const int32_t *)b->d_counts, b->gf_lay, b->d_ell_partial, pstride);
+            }
+            else if (grad && ell_sparse_ok(b, nreq, restarts) && b->opt[RMX_OPT_GRAD_KERNEL] != 1)
+                hipLaunchKernelGGL(k_ell_list_batch_sparse_grad, dim3((maxcnt + SEG_PER_BLOCK - 1) / SEG_PER_BLOCK, nreq), dim3(256), 0, b->stream, b->d, (const int32_t *)b->d_rlist,
+                                   (const RestartParams *)b->d_rp_stage, (const int32_t *)b->d_sample, (const int32_t *)b->d_counts, b->d_ell_partial, pstride);
+            else if (grad && ell_sparse_ok(b, nreq, restarts)) {
                 // (the final sums ride in the same launch: the block that finishes a request last reduces its partials)
                 hipLaunchKernelGGL(k_ell_list_batch_sparse_grad_final, dim3((maxcnt + SEG_PER_BLOCK - 1) / SEG_PER_BLOCK, nreq), dim3(256), 0, b->stream, b->d, (const int32_t *)b->d_rlist,
                                    (const RestartParams *)b->d_rp_stage, (const int32_t *)b->d_sample, (const int32_t *)b->d_counts, b->d_ell_partial, pstride,
@@ -2141,7 +2185,7 @@ int rmx_set_sample_lists(rmx_batch *b, int32_t nlists, const int32_t *restarts, 
     for (int i = 0; i < nlists; i++) {
         const int cnt = offsets[i + 1] - offsets[i], r = restarts[i];
         hd[4 * i] = r; hd[4 * i + 1] = slots[i]; hd[4 * i + 2] = cnt; hd[4 * i + 3] = offsets[i];
-        if (slots[i] < 0) { b->sample_count[r] = cnt; b->sample_cache[r].clear(); }
+        if (slots[i] < 0) { b->sample_count[r] = cnt; b->sample_cache[r].clear(); b->sample_epoch[r]++; }
         else b->msample_count[(size_t)slots[i] * b->R + r] = cnt;
     }
     if (total) memcpy(body, indices, total * 4);
@@ -2227,6 +2271,16 @@ int rmx_param_search_multi(rmx_batch *b, int32_t nreq, const int32_t *restarts, 
         for (int k = n_; k < 64; k++) { m2.rlist[k] = m2.rlist[0]; m2.slot[k] = m2.slot[0]; m2.v[k] = m2.v[0]; m2.lv[k] = m2.lv[0]; }
         {
             std::lock_guard<std::mutex> lk(b->mu);
+            if (mc > 0 && !grid_stage && b->opt[RMX_OPT_SEARCH_MODE] == 6) {
+                // search_mode 6 (round 5, measured and NOT the default): a Nelder-Mead round whose objective kernel sums its own partials (the last block of a
+                // request, behind a release fence per block).  One launch fewer per round -- and 5 % off the headline (397 against 418-421 EM it/s, two
+                // alternating runs each on one box): an agent-scope release writes the XCD's dirty L2 lines back, and next to the other restart
+                // group's forward-backward and marginal passes the L2s are full of their rows; 800 blocks x 52 rounds of that per M-step
+                ProfScope ps(b, KID_ELL_LIST);
+                hipLaunchKernelGGL(k_ell_search_multi_final, dim3((mc + SEG_PER_BLOCK - 1) / SEG_PER_BLOCK, n_), dim3(256), 0, b->stream, b->d, m2, (const int32_t *)b->d_msample,
+                                   (const int32_t *)b->d_mcounts, b->d_mpartial, std::max(mc, 1), b->d_done, b->h_pinned, b->h_err);
+                HIPCHK(hipGetLastError());
+            } else {
             if (mc > 0) {
                 ProfScope ps(b, KID_ELL_LIST);
                 hipLaunchKernelGGL(k_ell_search_multi, dim3((mc + SEG_PER_BLOCK - 1) / SEG_PER_BLOCK, n_, m2.Gz), dim3(256), 0, b->stream, b->d, m2, (const int32_t *)b->d_msample,
@@ -2235,6 +2289,7 @@ int rmx_param_search_multi(rmx_batch *b, int32_t nreq, const int32_t *restarts, 
             { ProfScope ps(b, KID_ELL_FINAL); hipLaunchKernelGGL(k_ell_multi_final, dim3(n_ * m2.Gz), dim3(256), 0, b->stream, b->d, m2, (const int32_t *)b->d_mcounts,
                                                                  (const double *)b->d_mpartial, std::max(mc, 1), b->h_pinned, b->h_err); }
             HIPCHK(hipGetLastError());
+            }
         }
         HIPCHK(hipStreamSynchronize(b->stream));
         if (int rc_ = report_request_errors(b, n_, b->h_err, [&](int k) { return (int)m2.rlist[k]; })) return rc_;
@@ -2243,13 +2298,13 @@ int rmx_param_search_multi(rmx_batch *b, int32_t nreq, const int32_t *restarts, 
     };
     std::vector<int> all(Q);
     for (int q = 0; q < Q; q++) all[q] = q;
-    // search_mode 5: rounds the device drives (k_search_round / k_search_advance) -- the optimisers' state lives on the device, a round
-    // is a kernel pair, and the host queues the grid round and a batch of rounds back to back without waiting in between; then it looks
-    // at the finished flags and queues more while any optimiser still runs (at most Nm1::maxfun rounds).  Half the latency of the rounds
-    // driven from the host below (1.15 against 2.5 ms for 8 restarts alone on the GPU), which is what a batch that has the GPU to itself
-    // wants (RestartGroups sets it for a single group: 34.4-35.0 against 36.9-40.7 ms per EM iteration of 8 restarts); next to another
-    // group's sweeps the GPU is throughput-bound and the dense run of kernels costs that group what it saves this one (415-416 against
-    // 424-426 EM iterations/s at the benchmark's two groups of 8), so it is not the default.
+    // search_mode 5 (the default since round 5): rounds the device drives (k_search_round / k_search_advance) -- the optimisers' state lives on
+    // the device, a round is a kernel pair, and the host queues the grid round and a batch of rounds back to back without waiting in between;
+    // then it looks at the finished flags and queues more while any optimiser still runs (at most Nm1::maxfun rounds).  Half the latency of
+    // the rounds driven from the host below (1.15 against 2.5 ms for 8 restarts alone on the GPU).  Round 4 kept it for batches that have
+    // the GPU to themselves (next to another group's sweeps 415-416 against 424-426 EM it/s for the host rounds); with round 5's flat trial
+    // passes it wins there too -- 440.7 / 440.8 against 402-422 EM it/s, alternating runs on one box (profiles/r05_mstep_ab.txt): a restart
+    // group's EM period is its sweeps plus its OWN M-step chain (the other group's sweeps hide it only while it is the shorter of the two).
     if (b->opt[RMX_OPT_SEARCH_MODE] == 5 && maxcnt <= NM_MAX_SAMPLE) {
         if (!b->d_nm_state) {
             if ((rc = dalloc(b, &b->d_nm_state, (size_t)64)) ||
@@ -2404,12 +2459,21 @@ static int trial_pass(rmx_batch *b, int r0, int r1, Dev &d2) {
             for (int i = r; i < e; i++) if (!b->sig_valid[i]) sparse = false;
             if (sparse) {
                 void (*kf)(Dev, int) = nullptr;
-                switch (mask) {
-                case 1: kf = k_trial_sparse<1>; break; case 2: kf = k_trial_sparse<2>; break; case 3: kf = k_trial_sparse<3>; break;
-                case 4: kf = k_trial_sparse<4>; break; case 8: kf = k_trial_sparse<8>; break; case 12: kf = k_trial_sparse<12>; break;
-                default: kf = k_trial_sparse<15>; break;
+                if (b->opt[RMX_OPT_TRIAL_KERNEL] == 0) {      // cells flat over the threads, segmented sum in list order (round 5)
+                    switch (mask) {
+                    case 1: kf = k_trial_flat<1>; break; case 2: kf = k_trial_flat<2>; break; case 3: kf = k_trial_flat<3>; break;
+                    case 4: kf = k_trial_flat<4>; break; case 8: kf = k_trial_flat<8>; break; case 12: kf = k_trial_flat<12>; break;
+                    default: kf = k_trial_flat<15>; break;
+                    }
+                    hipLaunchKernelGGL(kf, dim3((d.N + TF_SEGB - 1) / TF_SEGB, e - r), dim3(256), 0, b->stream, d2, r);
+                } else {
+                    switch (mask) {
+                    case 1: kf = k_trial_sparse<1>; break; case 2: kf = k_trial_sparse<2>; break; case 3: kf = k_trial_sparse<3>; break;
+                    case 4: kf = k_trial_sparse<4>; break; case 8: kf = k_trial_sparse<8>; break; case 12: kf = k_trial_sparse<12>; break;
+                    default: kf = k_trial_sparse<15>; break;
+                    }
+                    hipLaunchKernelGGL(kf, dim3((d.N + TRIAL_SEG_PER_BLOCK - 1) / TRIAL_SEG_PER_BLOCK, e - r), dim3(256), 0, b->stream, d2, r);
                 }
-                hipLaunchKernelGGL(kf, dim3((d.N + TRIAL_SEG_PER_BLOCK - 1) / TRIAL_SEG_PER_BLOCK, e - r), dim3(256), 0, b->stream, d2, r);
             }
             else if (use_strip(b)) hipLaunchKernelGGL(cells_kernel(b, 2, mask, 0), strip_grid(b, e - r), dim3(256), 0, b->stream, d2, r);
             else hipLaunchKernelGGL(k_marginals<false>, row_grid(b, e - r), dim3(256), 0, b->stream, d2, r, b->G);

@@ -18,6 +18,7 @@
 #define SEGL 32
 #define SEG_PER_BLOCK (256 / SEGL)
 #define TRIAL_SEGL 16
+#define NM_MAX_SAMPLE 1024      // sampled segments per request in the layouts of the flat M-step kernels (the reference samples min(200, N / 10))
 #define TRIAL_SEG_PER_BLOCK (256 / TRIAL_SEGL)
 
 // =============================================================================
@@ -458,6 +459,10 @@ __global__ __launch_bounds__(NTMAX) void k_fb(FbArgs a) {
 // on 64-bit operands supports exactly this control (row_newbcast).  Rows ascend per accumulator (the
 // summation order of the LDS-broadcast formulation) and the 2*NV accumulators give the FMA pipe
 // independent chains.
+// WAIT STATES (asm site 1 of 5; tools/asm_hazards.py checks the built code): the DPP source av[] comes from LDS reads (no VALU write,
+// the s_waitcnt is the only dependency); the accumulators are asm-written and next read by compiler code -- fbv's row reduction, whose first
+// consumer is a DPP v_mov.  A VALU write -> DPP read needs two states the compiler cannot know about here: the static check over the
+// disassembly (CPU test tests/test_asm_hazards.py) is what enforces them for every build.
 template <int RPT, int NV, int NA, int RR>
 __device__ __forceinline__ void fbv_row_fma(const double (&av)[NV][NA], const double (&w0)[RPT], const double (&w1)[RPT],
                                             double (&acc0)[NV], double (&acc1)[NV]) {
@@ -872,6 +877,9 @@ template <int PI, int KB> struct fbm_chain {
 // broadcasts (one read per k-block is bound by LDS latency: a pair of FMAs is ten cycles, a read a hundred): lane c of a DPP row holds
 // a_j[4 (16 g + c) + kq] for g < ceil(KB / 16) -- 3 eight-byte reads per restart and step -- and the FMA of k-block kb takes its multiplier
 // from lane kb % 16 of the row through its own DPP operand (row_newbcast).  Even and odd k-blocks go to two accumulators per restart.
+// WAIT STATES (asm site 2 of 5): the accumulators written here reach a matrix instruction (the row-group reduce of the vector forms) only
+// through a compiler-visible v_add_f64 (even + odd k-blocks, fbw_chain / fbw_be): VALU -> VALU is interlocked, and the compiler pads its own
+// v_add -> v_mfma.  The DPP source `a` is an LDS read's destination.  tools/asm_hazards.py verifies both on the built code.
 template <int J> __device__ __forceinline__ void fbm_vfma(double &acc, const double a, const double x) {
     asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(a), "v"(x), "n"(J));
 }
@@ -1360,6 +1368,8 @@ template <int KB, int NV> struct fbqw_chain {
         fbm_vfma<k1 % 16>(acc1[0][O], av[0][k1 / 16], s.b[3]);
         if constexpr (NV > 1) fbm_vfma<k1 % 16>(acc1[1][O], av[1][k1 / 16], s.b[3]);
         // (the FMAs are plain asm: pinned between the wait above and the slot's next request below by their operands, and here)
+        // WAIT STATES (asm site 3 of 5): fbm_vfma's products at 355 states; the accumulators meet the matrix instruction of the row-group reduce behind
+        // compiler-visible additions (site 2's rule); the DPP sources are LDS reads' destinations.  tools/asm_hazards.py checks the built code.
         asm volatile("" : "+v"(acc0[0][0]), "+v"(acc0[0][O]), "+v"(acc1[0][0]), "+v"(acc1[0][O]));
         if constexpr (NV > 1) asm volatile("" : "+v"(acc0[1][0]), "+v"(acc1[1][0]));
         __builtin_amdgcn_sched_barrier(0);
@@ -1615,6 +1625,8 @@ __device__ __forceinline__ void fbq_body(const FbmArgs &a, const double *wk, con
             const fbm_d2 *apc = reinterpret_cast<const fbm_d2 *>(vec + (size_t)((k - 1) & 1) * VR * 4 + (kq * 4 + ib) * 2);     // pair p: + 16 p
             const char *tbb = reinterpret_cast<const char *>(tb);
             const char *wtb = reinterpret_cast<const char *>(wtab);
+// WAIT STATES (asm site 4 of 5): breakend steps of k_fbq on the vector ALU; accumulators are folded by compiler-visible adds and __shfl_xor
+// before anything else reads them; the DPP source is an LDS read's destination (checked on the built code: tools/asm_hazards.py)
 #define FBQ_BE_FMA(acc_, a_, x_, i_) asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:" #i_ " row_mask:0xf bank_mask:0xf" : "+v"(acc_) : "v"(a_), "v"(x_))
 #define FBQ_BE_TILE(acc_, c_, uoff_, ak_)                                                                                          \
             {                                                                                                                      \
@@ -1808,6 +1820,9 @@ __global__ __launch_bounds__(NTMAX) void k_fbk(FbvArgs a, const double *wk, cons
             asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:" #rr_ " row_mask:0xf bank_mask:0xf" : "+v"(acc1[v]) : "v"(av[v]), "v"(x1_)); \
         }                                                                                                  \
     }
+// WAIT STATES (asm site 5 of 5): k_fbk's products (FBK_ROW: v_fmac_f64_dpp on weights formed from packed copy numbers by compiler code); the
+// accumulators are read next by phase 2's compiler code (LDS writes after additions), the DPP source av[] is an LDS read's destination; as for
+// the other four sites the built code is checked by tools/asm_hazards.py (tests/test_asm_hazards.py)
 #define FBK_CHUNK(BE_)                                                                                     \
     FBK_ROW(0, BE_) FBK_ROW(1, BE_) FBK_ROW(2, BE_) FBK_ROW(3, BE_) FBK_ROW(4, BE_) FBK_ROW(5, BE_) FBK_ROW(6, BE_) FBK_ROW(7, BE_) \
     FBK_ROW(8, BE_) FBK_ROW(9, BE_) FBK_ROW(10, BE_) FBK_ROW(11, BE_) FBK_ROW(12, BE_) FBK_ROW(13, BE_) FBK_ROW(14, BE_) FBK_ROW(15, BE_)
@@ -2267,6 +2282,101 @@ __global__ __launch_bounds__(256) void k_trial_sparse(Dev d, int r0) {
     if (MASK & CM_LT1) { a1 = group_sum(a1, TRIAL_SEGL); if (j == 0) d.A[rn * 2 + 1] = a1; }
     if (MASK & CM_LA0) { b0 = group_sum(b0, TRIAL_SEGL); b1 = group_sum(b1, TRIAL_SEGL); if (j == 0) { d.Bv[rn * 4] = b0; d.Bv[rn * 4 + 1] = b1; } }
     if (MASK & CM_LA1) { b2 = group_sum(b2, TRIAL_SEGL); b3 = group_sum(b3, TRIAL_SEGL); if (j == 0) { d.Bv[rn * 4 + 2] = b2; d.Bv[rn * 4 + 3] = b3; } }
+    if (err) atomicOr(&d.err[r], err);
+}
+
+// =============================================================================
+// k_trial_flat (round 5): k_trial_sparse's sums with the (segment, listed state) CELLS laid out flat over the threads.  A quarter wave per
+// segment runs as many steps as its longest list asks for (mean 13 listed states, p99 36, an overflowed list 165) with the lanes past a list's
+// end idle, and a cell is 8 lgamma + 2 log1p of FP64: the pass took 0.47 ms for 0.07 ms of arithmetic.  Here a block owns TF_SEGB consecutive
+// segments of one restart: the list lengths are prefix-summed in LDS, thread t evaluates cells t, t + 256, ... (segment by binary search in the
+// 32 prefix sums, segment constants from LDS), the six products post * ll go to LDS, and one thread per (segment, component) adds its segment's
+// products IN LIST ORDER (state order) -- a fixed order that depends on nothing but the segment's own list, so a restart's sums do not depend on
+// the launch's range or on chunking (TF_CAP cells per chunk).  grid (ceil(N / TF_SEGB), nr), block 256.
+// =============================================================================
+#define TF_SEGB 32
+#define TF_CAP 512
+template <int MASK>
+__global__ __launch_bounds__(256) void k_trial_flat(Dev d, int r0) {
+    __shared__ int offs[TF_SEGB + 1];
+    __shared__ int cnts[TF_SEGB];
+    __shared__ double segv[15][TF_SEGB];          // x, l, logl, y0, y1, mask_t, mask_a, segc[0..7]
+    __shared__ int segcls[TF_SEGB];
+    __shared__ double prod[6][TF_CAP];
+    const int r = r0 + blockIdx.y, nb = blockIdx.x * TF_SEGB, tid = threadIdx.x;
+    const int nseg = min(TF_SEGB, d.N - nb);
+    const RestartParams &rp = d.rp[r];
+    if (tid < TF_SEGB) {
+        int c = 0;
+        if (tid < nseg) { c = d.sig_cnt[(size_t)r * d.N + nb + tid]; segcls[tid] = d.seg_class[nb + tid]; }
+        cnts[tid] = c;
+    }
+    for (int t = tid; t < 15 * TF_SEGB; t += 256) {
+        const int k = t / TF_SEGB, i = t % TF_SEGB;
+        double v = 0.;
+        if (i < nseg) {
+            const int n = nb + i;
+            switch (k) {
+            case 0: v = d.x[n]; break; case 1: v = d.l[n]; break; case 2: v = d.logl[n]; break;
+            case 3: v = d.y[2 * (size_t)n]; break; case 4: v = d.y[2 * (size_t)n + 1]; break;
+            case 5: v = (double)d.mask_t[n]; break; case 6: v = (double)d.mask_a[n]; break;
+            default: v = d.segc[((size_t)r * 8 + (k - 7)) * d.N + n]; break;
+            }
+        }
+        segv[k][i] = v;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int a = 0;
+        for (int i = 0; i < TF_SEGB; i++) { offs[i] = a; a += cnts[i] == 255 ? d.S : cnts[i]; }
+        offs[TF_SEGB] = a;
+    }
+    __syncthreads();
+    const int total = offs[TF_SEGB];
+    unsigned err = 0;
+    // owner of (segment oi, component ok): the first 6 * TF_SEGB threads
+    const int oi = tid / 6, ok = tid % 6;
+    const bool owner = tid < 6 * TF_SEGB && oi < nseg;
+    const bool okm = ok == 0 ? (MASK & CM_LT0) : (ok == 1 ? (MASK & CM_LT1) : (ok < 4 ? (MASK & CM_LA0) : (MASK & CM_LA1)));
+    double acc = 0.;
+    for (int c0 = 0; c0 < total; c0 += TF_CAP) {
+        const int c1 = min(total, c0 + TF_CAP);
+        for (int c = c0 + tid; c < c1; c += 256) {
+            int lo = 0, hi = TF_SEGB;                       // largest i with offs[i] <= c
+            while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (offs[mid] <= c) lo = mid; else hi = mid; }
+            const int i = lo, jj = c - offs[i];
+            const size_t rn = (size_t)r * d.N + nb + i;
+            const int s = cnts[i] == 255 ? jj : (int)d.sig_idx[rn * RMX_SIGK + jj];
+            SegCtx sc;
+            sc.x = segv[0][i]; sc.l = segv[1][i]; sc.logl = segv[2][i]; sc.y0 = segv[3][i]; sc.y1 = segv[4][i]; sc.ys = sc.y0 + sc.y1;
+            sc.mt = (int)segv[5][i]; sc.ma = (int)segv[6][i];
+#pragma unroll
+            for (int q = 0; q < 4; q++) { sc.cnb[q] = segv[7 + q][i]; sc.cbb[q] = segv[11 + q][i]; }
+            StateRegs st; load_state_regs(d, r, segcls[i], s, st);
+            double LT[2], LA[4];
+            cell_ll_regs<MASK>(rp, sc, st, LT, LA, err);
+            const double ps = d.post[rn * d.SP + s];
+            const int cc = c - c0;
+            if (MASK & CM_LT0) prod[0][cc] = ps * LT[0];
+            if (MASK & CM_LT1) prod[1][cc] = ps * LT[1];
+            if (MASK & CM_LA0) { prod[2][cc] = ps * LA[0]; prod[3][cc] = ps * LA[1]; }
+            if (MASK & CM_LA1) { prod[4][cc] = ps * LA[2]; prod[5][cc] = ps * LA[3]; }
+        }
+        __syncthreads();
+        if (owner && okm) {
+            const int a = max(offs[oi], c0), b = min(offs[oi + 1], c1);
+            for (int c = a; c < b; c++) acc += prod[ok][c - c0];
+        }
+        __syncthreads();
+    }
+    if (owner) {
+        const size_t rn = (size_t)r * d.N + nb + oi;
+        if (okm) { if (ok < 2) d.A[rn * 2 + ok] = acc; else d.Bv[rn * 4 + (ok - 2)] = acc; }
+        if (ok == 0 && (MASK & (CM_LA0 | CM_LA1)) && cnts[oi] != 255) {
+            SegCtx sc; sc.ma = (int)segv[6][oi]; sc.ys = segv[3][oi] + segv[4][oi];
+            table_static_errors<MASK>(sc, d.stFlagsAgg[(size_t)r * d.C + segcls[oi]], err);
+        }
+    }
     if (err) atomicOr(&d.err[r], err);
 }
 
@@ -3172,6 +3282,114 @@ __global__ __launch_bounds__(256) void k_ell_list_batch_sparse_grad_final(Dev d,
         if (threadIdx.x == 0) out[(size_t)blockIdx.y * nout + c] = a;
     }
 }
+// ---- the h M-step's objective + gradient with the work laid out flat (round 5) -----------------------------------------------------
+// k_ell_list_batch_sparse_grad gives every sampled segment half a wave, a lane per listed state: 13 of 32 lanes work on average, a request
+// is 25 blocks, and next to the other restart group's forward-backward launch (184 of 256 CUs held whole) the 200 blocks of a round crowd
+// onto the 72 free CUs four to a CU -- 180-250 us per round in the bench's trace against 76 alone, thirteen rounds per M-step.  Here the
+// LANE CHAINS of that kernel (segment i, lane l: listed states l, l + 32, ...) are the units of work, laid out flat over the threads of as
+// few blocks as hold them (whole segments per block, at most 256 units), and a half-wave then adds a segment's units with the SAME
+// group_sum the half-wave kernel uses (absent lanes contribute the same zeros): every per-segment partial sum is bit-identical to
+// ell_segment_sparse_grad's, the final sums are k_ell_final_batch's.  The per-segment constants (functions of the likelihood parameters,
+// not of h) and the block layout are made once per M-step by k_gradflat_setup, not in every round.
+struct StageArgs { int32_t rlist[16]; RestartParams rp[16]; };      // up to 16 requests travel by value in the kernel arguments
+struct GradFlatLayout {
+    int32_t *upre;                // [R][NM_MAX_SAMPLE + 1]  units before sampled segment i
+    int32_t *blk;                 // [R][NM_MAX_SAMPLE + 2]  first sampled segment of block b; blk[nblk] = cnt
+    int32_t *nblk;                // [R]
+    double *k8;                   // [R][NM_MAX_SAMPLE][8]   seg_const_value(rp, ., k)
+};
+// grid (nreq), block 256
+__global__ __launch_bounds__(256) void k_gradflat_setup(Dev d, StageArgs sa, const int32_t *samples, const int32_t *counts, GradFlatLayout lay, int32_t *nblk_host) {
+    __shared__ int un[NM_MAX_SAMPLE + 1];
+    const int r = sa.rlist[blockIdx.x];
+    const RestartParams &rp = sa.rp[blockIdx.x];
+    const int cnt = counts[r];
+    const int32_t *smp = samples + (size_t)r * d.N;
+    for (int i = threadIdx.x; i < cnt; i += 256) {
+        const int n = smp[i];
+        const int c = d.sig_cnt[(size_t)r * d.N + n];
+        const int cells = c == 255 ? d.S : c;
+        un[i + 1] = cells < 1 ? 1 : (cells < SEGL ? cells : SEGL);      // (lane 0 always exists: it reports the table's error flags)
+    }
+    for (int t = threadIdx.x; t < cnt * 8; t += 256) {
+        const int i = t >> 3, k = t & 7, n = smp[i];
+        const double x = d.x[n], y0 = d.y[2 * (size_t)n], ys = y0 + d.y[2 * (size_t)n + 1];
+        lay.k8[((size_t)r * NM_MAX_SAMPLE + i) * 8 + k] = seg_const_value(rp, x, y0, ys, k);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int32_t *up = lay.upre + (size_t)r * (NM_MAX_SAMPLE + 1), *bl = lay.blk + (size_t)r * (NM_MAX_SAMPLE + 2);
+        int a = 0, nb = 0, inblk = 0;
+        up[0] = 0;
+        if (cnt > 0) bl[nb++] = 0;
+        for (int i = 0; i < cnt; i++) {
+            const int u = un[i + 1];
+            if (inblk + u > 256) { bl[nb++] = i; inblk = 0; }      // whole segments per block
+            inblk += u; a += u; up[i + 1] = a;
+        }
+        bl[nb] = cnt;
+        lay.nblk[r] = nb;
+        nblk_host[blockIdx.x] = nb;
+    }
+}
+// grid (blocks, nreq), block 256: block b of request j evaluates the units of the sampled segments blk[b] .. blk[b + 1] - 1
+__global__ __launch_bounds__(256) void k_gradflat_round(Dev d, const int32_t *rlist, const RestartParams *stage, const int32_t *samples, const int32_t *counts,
+                                                        GradFlatLayout lay, double *partial, int pstride) {
+    __shared__ int lpre[257];
+    __shared__ double vals[1 + RMX_MAX_CLONES][256];
+    const int r = rlist[blockIdx.y], tid = threadIdx.x;
+    if ((int)blockIdx.x >= lay.nblk[r]) return;
+    const RestartParams &rp = stage[blockIdx.y];
+    const int32_t *bl = lay.blk + (size_t)r * (NM_MAX_SAMPLE + 2), *up = lay.upre + (size_t)r * (NM_MAX_SAMPLE + 1);
+    const int i0 = bl[blockIdx.x], i1 = bl[blockIdx.x + 1], nseg = i1 - i0;
+    const int u0 = up[i0];
+    for (int k = tid; k <= nseg; k += 256) lpre[k] = up[i0 + k] - u0;
+    __syncthreads();
+    const int nunits = lpre[nseg];
+    const int32_t *smp = samples + (size_t)r * d.N;
+    unsigned err = 0;
+    double acc = 0., g[RMX_MAX_CLONES] = {0., 0., 0., 0.};
+    if (tid < nunits) {
+        int lo = 0, hi = nseg;                                  // the segment k with lpre[k] <= tid < lpre[k + 1] (segments without units are skipped)
+        while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (lpre[mid] <= tid) lo = mid; else hi = mid; }
+        const int i = i0 + lo, lane = tid - lpre[lo], n = smp[i];
+        SegCtx sc;
+        sc.x = d.x[n]; sc.l = d.l[n]; sc.logl = d.logl[n]; sc.y0 = d.y[2 * (size_t)n]; sc.y1 = d.y[2 * (size_t)n + 1]; sc.ys = sc.y0 + sc.y1;
+        sc.mt = d.mask_t[n]; sc.ma = d.mask_a[n];
+        const double *k8 = lay.k8 + ((size_t)r * NM_MAX_SAMPLE + i) * 8;
+#pragma unroll
+        for (int q = 0; q < 4; q++) { sc.cnb[q] = k8[q]; sc.cbb[q] = k8[4 + q]; }
+        const int cls = d.seg_class[n];
+        const size_t rn = (size_t)r * d.N + n;
+        const double qt0 = d.qt[rn * 2], qt1 = d.qt[rn * 2 + 1], qa0 = d.qa[rn * 2], qa1 = d.qa[rn * 2 + 1];
+        const double qs0 = d.qs[rn * 2], qs1 = d.qs[rn * 2 + 1];
+        const double *post = d.post + rs_off(d, r, n);
+        const int cnt_s = d.sig_cnt[rn];
+        if (cnt_s == 255) { for (int s_ = lane; s_ < d.S; s_ += SEGL) ell_state_terms<true, CM_ALL, false>(d, rp, sc, r, cls, s_, post[s_], qt0, qt1, qa0, qa1, qs0, qs1, acc, g, err); }
+        else {
+            for (int jj = lane; jj < cnt_s; jj += SEGL) { const int s_ = (int)d.sig_idx[rn * RMX_SIGK + jj]; ell_state_terms<true, CM_ALL, false>(d, rp, sc, r, cls, s_, post[s_], qt0, qt1, qa0, qa1, qs0, qs1, acc, g, err); }
+            if (lane == 0) table_static_errors<CM_ALL>(sc, d.stFlagsAgg[(size_t)r * d.C + cls], err);
+        }
+    }
+    vals[0][tid] = acc;
+#pragma unroll
+    for (int m = 0; m < RMX_MAX_CLONES; m++) vals[1 + m][tid] = g[m];
+    __syncthreads();
+    // a half-wave per segment: lane l takes unit l's sums (zero past the segment's units, as the idle lanes of the half-wave kernel hold) and
+    // group_sum adds them in that kernel's order
+    const int hw = tid / SEGL, l = tid & (SEGL - 1);
+    for (int k = hw; k < nseg; k += 256 / SEGL) {
+        const int ub = lpre[k], nu = lpre[k + 1] - ub;
+        double *prow = partial + (size_t)r * pstride + (size_t)(i0 + k) * (1 + RMX_MAX_CLONES);
+#pragma unroll
+        for (int c = 0; c < 1 + RMX_MAX_CLONES; c++) {
+            double v = l < nu ? vals[c][ub + l] : 0.;
+            v = group_sum(v, SEGL);
+            if (l == 0) prow[c] = v;
+        }
+    }
+    if (err) atomicOr(&d.err[r], err);
+}
 template <bool GRAD>
 __global__ void k_ell_list(Dev d, int r, const int32_t *list, double *partial) {
     ell_segment<GRAD>(d, d.rp[r], r, list[blockIdx.x], partial + (size_t)blockIdx.x * (1 + RMX_MAX_CLONES));
@@ -3216,7 +3434,6 @@ __global__ void k_state_tables_list(Dev d, const int32_t *rlist, const RestartPa
 // (<= 16 requests: 2.5 KB of the 4 KB argument segment): no host-to-device staging copies -- each one
 // is a copy kernel serialised on the stream -- in front of every evaluation round.  The list is also
 // written to the device staging buffers for the kernels that follow on the stream.
-struct StageArgs { int32_t rlist[16]; RestartParams rp[16]; };
 __global__ void k_state_tables_list_v(Dev d, StageArgs sa, int32_t *rlist_dev, RestartParams *stage_dev) {
     const int r = sa.rlist[blockIdx.y];
     const RestartParams rp = sa.rp[blockIdx.y];
@@ -3359,6 +3576,42 @@ __global__ void k_ell_multi_final(Dev d, MultiVals mv, const int32_t *counts, co
     a = block_sum<256>(a, scratch);
     if (threadIdx.x == 0) out[blockIdx.x] = a;
 }
+// k_ell_search_multi with k_ell_multi_final folded in (round 5; the Nelder-Mead rounds, Gz = 1): the block that finishes a request's partial sums
+// last (ticket from a per-request counter, which it resets: the scheme of k_ell_list_batch_sparse_grad_final) adds them in k_ell_multi_final's
+// order -- the same bits -- and writes the request's value and error word to host-visible memory: one launch and one kernel boundary fewer
+// in each of the ~50 rounds of an M-step.  Selected by search_mode 6 only: the release fence every block pays (an L2 write-back on a chip whose
+// XCDs' L2s are not coherent) cost the headline 5 % next to the other restart group's sweeps.  grid (ceil(maxcount / 8), nreq), block 256.
+__global__ __launch_bounds__(256) void k_ell_search_multi_final(Dev d, MultiVals mv, const int32_t *samples, const int32_t *counts, double *partial, int maxcnt,
+                                                                unsigned *done, double *out, uint32_t *err_out) {
+    __shared__ double scratch[8];
+    __shared__ int last;
+    const int req = blockIdx.y;
+    const int r = mv.rlist[req], sl = mv.slot[req];
+    const int i = blockIdx.x * SEG_PER_BLOCK + (threadIdx.x / SEGL);
+    const int cnt = counts[sl * d.R + r];
+    if (i < cnt) {
+        const int n = samples[((size_t)sl * d.R + r) * d.N + i];
+        const double v = mv.v[req], lv = mv.lv[req];
+        double *prow = partial + ((size_t)req * maxcnt + i);
+        switch (mv.maskbit[sl]) {
+        case CM_LT0: { RestartParams rp = d.rp[r]; rp.p[RMX_P_NEGBIN_R_0] = v; rp.logr[0] = lv; ell_segment_sparse<CM_LT0, true>(d, rp, r, n, prow); break; }
+        case CM_LT1: { RestartParams rp = d.rp[r]; rp.p[RMX_P_NEGBIN_R_1] = v; rp.logr[1] = lv; ell_segment_sparse<CM_LT1, true>(d, rp, r, n, prow); break; }
+        case CM_LA0: { RestartParams rp = d.rp[r]; rp.p[RMX_P_BETABIN_M_0] = v; ell_segment_sparse<CM_LA0, true>(d, rp, r, n, prow); break; }
+        default:     { RestartParams rp = d.rp[r]; rp.p[RMX_P_BETABIN_M_1] = v; ell_segment_sparse<CM_LA1, true>(d, rp, r, n, prow); break; }
+        }
+    }
+    __syncthreads();      // (one release per block, behind the barrier that orders the block's partial sums before it)
+    if (threadIdx.x == 0) { __threadfence(); last = atomicAdd(&done[req], 1u) == gridDim.x - 1; }
+    __syncthreads();
+    if (!last) return;
+    if (threadIdx.x == 0) __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) { done[req] = 0; if (err_out) err_out[req] = __hip_atomic_load(&d.err[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+    double a = 0.;
+    for (int k = threadIdx.x; k < cnt; k += 256) a += __hip_atomic_load(&partial[(size_t)req * maxcnt + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    a = block_sum<256>(a, scratch);
+    if (threadIdx.x == 0) out[req] = a;
+}
 // ---- those searches in rounds the DEVICE drives (round 4; search_mode 5) ---------------------------------------------
 // The rounds above cost a launch pair, a stream wait and the host's optimiser step each, fifty times per M-step, and their kernel
 // is as long as its slowest half-wave: a sampled segment whose list of states overflowed walks six cells per lane, and the
@@ -3391,7 +3644,6 @@ struct NmArgs {
     int32_t blk0[65];             // blocks of 256 cells before request q (k_search_round's grid is the requests' blocks one after the other)
     int32_t nreq;
 };
-#define NM_MAX_SAMPLE 1024
 struct NmLayout {                 // per request q, rows of pitch NM_MAX_SAMPLE (+ 1)
     int32_t *pre;                 // [64][NM_MAX_SAMPLE + 1] cells before sampled segment i; pre[cnt] = the request's cells
     double *fix, *k1;             // [64][NM_MAX_SAMPLE] candidate-free part of the component's constant; constant of the other dispersion

@@ -218,7 +218,7 @@ class RestartSet(object):
             if name not in self._MULTI_PARAMS or len(first) == 4:
                 break
             first.append(name)
-        sequential = b is not None and hasattr(b, 'get_option') and b.get_option('search_mode') not in (0, 5)
+        sequential = b is not None and hasattr(b, 'get_option') and b.get_option('search_mode') not in (0, 5, 6)
         if not (first and self.native_search and b is not None and hasattr(b, 'param_search_multi')) or sequential:
             return []
         return first
@@ -615,11 +615,11 @@ class RestartGroups(object):
     run concurrently on the device (a 184-workgroup forward-backward launch leaves CUs idle).
     Restarts are independent (reference remixt/workflow.py:329-340) and every restart owns its RNG
     stream, so a restart's fit does not depend on which group it runs in -- to the bit PER search mode and
-    forward-backward workgroup shape.  Both follow the grouping unless the caller pins them (`options=`):
-    the library picks the workgroup shape (`fb_nv`) by launch size, and this class gives a single group and
-    paced groups the device-driven parameter-search rounds (`search_mode` 5: device log(), per-block cell
-    sums) and free-running groups the host-driven ones (0).  Across those choices results agree to rounding
-    (posteriors 1e-10; after an EM iteration's optimisers ELBO 1e-7, h 1e-5, parameters 1e-3), not to the bit."""
+    forward-backward workgroup shape.  The shape follows the grouping unless the caller pins it (`options=`):
+    the library picks `fb_nv` by launch size.  (The search mode did too until round 4; the device-driven
+    rounds, `search_mode` 5, are every batch's default now.)  Across shapes and search modes results agree
+    to rounding (posteriors 1e-10; after an EM iteration's optimisers ELBO 1e-7, h 1e-5, parameters 1e-3),
+    not to the bit."""
 
     def __init__(self, experiment, init_params, max_copy_number, groups=2, seeds=None, paced='auto', **kwargs):
         init_params = list(init_params)
@@ -666,14 +666,9 @@ class RestartGroups(object):
         if self.paced:
             for rs in self.sets:
                 rs.batch.set_option('pace_sweeps', 1)
-        # A single group has the GPU to itself, and paced groups (small, or on a large state grid) leave it room: their parameter searches run as
-        # rounds the device drives (library option search_mode 5: half the latency of the rounds driven from the host -- 8 restarts as two paced
-        # groups 352-358 against 333-346 EM it/s, 355 states 153-155 against 149-150).  Free-running groups of 6 or more restarts at 165 states keep
-        # the GPU throughput-bound: there the dense run of kernels costs the other group what it saves this one (415-416 against 424-426), and the
-        # host keeps driving.  Not if the caller chose a search mode.
-        if (len(self.sets) == 1 or self.paced) and native and 'search_mode' not in (kwargs.get('options') or {}):
-            for rs in self.sets:
-                rs.batch.set_option('search_mode', 5)
+        # (Until round 4 this class also picked the parameter-search driver by grouping -- device-driven rounds for a single group and paced
+        # groups, host-driven ones for free-running groups.  The device-driven rounds are the library's default for every batch now
+        # (include/remixt_amd.h RMX_OPT_SEARCH_MODE): the search arithmetic no longer depends on the grouping.)
 
     def close(self):
         for rs in self.sets:

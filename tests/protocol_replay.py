@@ -11,7 +11,10 @@ GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
 RTOL = 1e-6
 # dense arrays whose entries span hundreds of nats / many decades: compared with an absolute floor in their own units
 ATOL = {'posterior_marginals': 1e-12, 'joint_posterior_marginals': 1e-12, 'p_breakpoint': 1e-12, 'p_outlier_total': 1e-12, 'p_outlier_allele': 1e-12,
-        'p_allele_swap': 1e-12, 'framelogprob': 1e-9, 'log_transmat': 1e-9, 'cached_log_transmat': 1e-9}
+        'p_allele_swap': 1e-12, 'framelogprob': 1e-9, 'log_transmat': 1e-9, 'cached_log_transmat': 1e-9,
+        # dE[ll]/dh near the optimum L-BFGS-B walks to: per-cell terms of magnitude 1e2 .. 1e3 cancel down to 1e-5, so an element is
+        # held to 1e-6 of ITSELF only above this floor (observed: 1.5e-10 absolute between the two digamma / accumulation orders)
+        'calculate_expected_log_likelihood_partial_h': 1e-8}
 
 
 def _value(d, ref):
@@ -83,7 +86,7 @@ def replay(kernel_cls, case, check_dir=True):
                 if ev['name'] == 'infer_cn':
                     assert np.array_equal(args[int(i)], want), where
                 else:
-                    _same(where, args[int(i)], want)
+                    _same(ev['name'] if ev['name'] in ATOL else where, args[int(i)], want)
         else:
             raise AssertionError(op)
     # the fixture really is a whole fit: sweeps, both M-steps, ELBO, decode, the attribute walk

@@ -667,6 +667,119 @@ def test_components_after_a_mixed_h_accept_need_no_refresh_pass(hip):
     np.testing.assert_allclose(tried, dense, rtol=1e-10)                # (nothing on trial: the same expectations)
 
 
+@pytest.mark.parametrize('N,max_cn,R', [(2400, 8, 5), (700, 6, 3), (420, 12, 2)])
+def test_h_round_kernels_give_the_same_bits(hip, N, max_cn, R):
+    """Round 5: the objective + gradient rounds of the lock-step h M-step with the lane chains laid out flat over the threads
+    (k_gradflat_round, option grad_kernel 0, the default; layout and per-segment constants made once per M-step) against half a wave
+    per sampled segment with the final sums folded in (1, round 4's form) and with the sums as a kernel of their own (2): the flat kernel
+    adds a segment's units with the half-wave kernel's own reduction, so every value and every gradient component is BIT-identical --
+    over several rounds on one layout, on a subset of the restarts, after the lists of states with posterior mass changed (another sweep)
+    and after new samples; and the per-restart entry point (scipy's driver) still returns the same bits as the batched one."""
+    from remixt_amd import synthetic
+    from remixt_amd.restarts import RestartSet
+    e = synthetic.make_experiment(N, num_clones=3, max_copy_number=max_cn, num_chains=3, seed=N + 1)
+    ps = synthetic.make_init_params(e, R, max_cn)
+    rs = RestartSet(e, ps, max_copy_number=max_cn, num_clones=3, quiet=True, seeds=list(range(10, 10 + R)))
+    b = rs.batch
+    rng = np.random.RandomState(5)
+
+    def rounds(live, hs):
+        out = {}
+        for kern in (0, 1, 2, 0):
+            b.set_option('grad_kernel', kern)
+            res = [b.expected_log_likelihood_h_batch(live, h) for h in hs]
+            key = kern if kern not in out else 'again'
+            out[key] = res
+        for kern in (1, 2, 'again'):
+            for (f0, g0), (f1, g1) in zip(out[0], out[kern]):
+                assert np.array_equal(f0, f1) and np.array_equal(g0, g1), (kern, f0, f1, g0, g1)
+        return out[0]
+
+    for sweep in range(2):
+        b.variational_update(1 + sweep)
+        h0 = np.array([b.get_array(r, 'h') for r in range(R)])
+        samples, lists = rs._samples_and_lists()
+        b.set_sample_lists([(r, -1, samples[r], lists[r]) for r in range(R)])
+        hs = [h0 * (1. + 0.02 * rng.rand(R, 3)) for _ in range(3)]
+        full = rounds(list(range(R)), hs)
+        assert all(np.all(np.isfinite(f)) and np.all(np.isfinite(g)) for f, g in full)
+        if R > 2:
+            live = [0, R - 1]
+            sub = rounds(live, [h[live] for h in hs])
+            for (f0, g0), (f1, g1) in zip(full, sub):      # a request's sums do not depend on which other requests travel with it
+                assert np.array_equal(f0[live], f1) and np.array_equal(g0[live], g1)
+        # the per-restart entry point (what scipy's own driver calls): the same bits as the batched round
+        b.set_option('grad_kernel', 0)
+        f_b, g_b = b.expected_log_likelihood_h_batch(list(range(R)), hs[1])
+        for r in range(R):
+            rs.models[r].model.h = hs[1][r]
+            f1 = rs.models[r].model.calculate_expected_log_likelihood(samples[r])
+            g1 = np.zeros(3); rs.models[r].model.calculate_expected_log_likelihood_partial_h(samples[r], g1)
+            assert f1 == f_b[r] and np.array_equal(g1, g_b[r]), (r, f1, f_b[r], g1, g_b[r])
+        for r in range(R):
+            rs.models[r].model.h = h0[r]
+
+
+@pytest.mark.parametrize('N,max_cn', [(403, 6), (90, 8), (1000, 4)])
+def test_trial_pass_kernels_agree_with_each_other_and_with_the_dense_refresh(hip, N, max_cn):
+    """Round 5: the M-step's trial passes with the (segment, listed state) cells laid out flat over the threads (k_trial_flat, option
+    trial_kernel 0, the default: a segmented sum in list order) against the quarter-wave-per-segment kernel (k_trial_sparse, 1) and against
+    the dense refresh of the same expectations: for h on trial (all four components), for one and for two likelihood parameters on trial
+    (component masks 1 / 4 / 12 ...), on segment counts that leave a ragged last block -- the same sums to rounding (1e-12 of the restart's
+    E[ll]; the kernels add a segment's products in different orders), bit-identical when repeated and across batch ranges."""
+    from remixt_amd import synthetic
+    from remixt_amd.restarts import RestartSet
+    e = synthetic.make_experiment(N, num_clones=3, max_copy_number=max_cn, num_chains=3, seed=N)
+    ps = synthetic.make_init_params(e, 3, max_cn)
+    R = 3
+    trials = [('h', None), ('negbin_r_0', 310.), ('betabin_M_0', 1200.), (('betabin_M_0', 'betabin_M_1'), (900., 14.)), (('negbin_r_0', 'negbin_r_1', 'betabin_M_1'), (250., 7., 33.))]
+    got = {}
+    for kern in (0, 1):
+        rs = RestartSet(e, ps, max_copy_number=max_cn, num_clones=3, quiet=True, seeds=[1, 2, 3], options={'trial_kernel': kern})
+        b = rs.batch
+        b.variational_update(2)
+        assert b.get_option('trial_kernel') == kern
+        h0 = [np.array(b.get_array(r, 'h')) for r in range(R)]
+        for name, value in trials:
+            if name == 'h':
+                for r in range(R):
+                    rs.models[r].model.h = h0[r] * (1.03 + 0.01 * r)
+                full = b.expected_log_likelihood_full_trial(0, R)
+                comp = b.expected_log_likelihood_components(0, R, trial=2)
+                again = b.expected_log_likelihood_full_trial(0, R)
+                part = b.expected_log_likelihood_full_trial(1, R)              # a sub-range of the batch: the same bits
+                assert np.array_equal(full, again) and np.array_equal(full[1:], part)
+                for r in range(R):
+                    b.rollback_h(r, h0[r])
+                dense = []
+                for r in range(R):
+                    rs.models[r].model.h = h0[r] * (1.03 + 0.01 * r)
+                dense = b.expected_log_likelihood_components(0, R)             # the dense refresh pass at the same h
+                np.testing.assert_allclose(comp, dense, rtol=1e-10)
+                for r in range(R):
+                    rs.models[r].model.h = h0[r]
+                b.expected_log_likelihood_components(0, R)
+                got[kern, name] = (full, comp)
+            else:
+                names = (name,) if isinstance(name, str) else name
+                values = (value,) if isinstance(name, str) else value
+                before = [[b.get_param(r, nm) for r in range(R)] for nm in names]
+                for nm, v in zip(names, values):
+                    for r in range(R):
+                        b.set_param(r, nm, float(v) * (1. + 0.02 * r))
+                tried = b.expected_log_likelihood_components(0, R, trial=True)
+                again = b.expected_log_likelihood_components(0, R, trial=True)
+                assert np.array_equal(tried, again)
+                for nm, bv in zip(names, before):
+                    for r in range(R):
+                        b.rollback_param(r, nm, bv[r])
+                got[kern, name] = (tried,)
+    for name, _ in trials:
+        for x, y in zip(got[0, name], got[1, name]):
+            scale = np.abs(np.asarray(y)).sum(axis=-1, keepdims=True) if np.ndim(y) > 1 else np.abs(y)
+            assert np.all(np.abs(np.asarray(x) - np.asarray(y)) <= 1e-12 * scale), (name, x, y)
+
+
 @pytest.mark.parametrize('max_cn,kernel', [(12, 4), (8, 1)])
 def test_paced_and_free_running_groups_equal_one_group(hip, max_cn, kernel):
     """Restart groups of a GPU (own stream, own host thread), free-running and paced (pace_sweeps: a group reaches a sweep's forward-backward

@@ -1,0 +1,87 @@
+"""GPU: the END-TO-END Viterbi agreement rate.  north_star asks for "Viterbi state paths bit-exact".  What the suite proves:
+
+  (1) on the SAME inputs (injected f and T; every golden decode) the device lattice and the reference's max_product pick the same path, ties
+      included -- tests/test_hip_chain_kats / test_hip_golden / test_batched_decode_matches_oracle_paths: bit-exact;
+  (2) end to end -- each side decodes from ITS OWN sweeps' output, whose frame log-probabilities differ by ~5e-11 relative between the two
+      lgamma implementations -- the paths can differ only where the model itself ties to rounding.  THIS test states how often, at a size the
+      oracle can run at the benchmark's grid: 2 000 segments x 165 states, 4 restarts, after two sweeps.  Every maximal run of segments where
+      the two paths differ is shown to be a tie: swapping the run into the other path changes the path's log-probability by less than
+      1e-11 of its magnitude under the device's arrays AND under the oracle's; and the fraction of differing segments is bounded."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+N_SEG, MAX_CN, R = 2000, 8, 4
+MAX_DIFFERING_FRACTION = 0.02
+
+
+def _states(table, cn):
+    """State index of every segment of a decoded copy-number path (table: cn_states [N][S][M][2])."""
+    eq = (table == cn[:, None, :, :]).all(axis=(2, 3))
+    assert eq.any(axis=1).all()
+    return eq.argmax(axis=1)
+
+
+def _runs(diff):
+    idx = np.flatnonzero(diff)
+    if len(idx) == 0:
+        return []
+    cuts = np.flatnonzero(np.diff(idx) > 1)
+    starts = np.concatenate([[idx[0]], idx[cuts + 1]]); ends = np.concatenate([idx[cuts], [idx[-1]]])
+    return list(zip(starts.tolist(), ends.tolist()))
+
+
+def _score(f, lt, st, a, b):
+    """log-probability terms of path `st` that involve segments a .. b (emissions of a .. b, transitions a-1 -> a ... b -> b+1)."""
+    n1 = f.shape[0]
+    s = f[np.arange(a, b + 1), st[a:b + 1]].sum()
+    lo, hi = max(a - 1, 0), min(b, n1 - 2)
+    if hi >= lo:
+        k = np.arange(lo, hi + 1)
+        s += lt[k, st[k], st[k + 1]].sum()
+    return float(s)
+
+
+def test_end_to_end_viterbi_agreement_rate_at_the_benchmark_grid(oracle_mod):
+    from concurrent.futures import ThreadPoolExecutor
+    from remixt_amd import synthetic
+    from tests.test_hip_bench_shapes import _two_sets, STEPS
+    e = synthetic.make_experiment(N_SEG, num_clones=3, max_copy_number=MAX_CN, num_chains=4, seed=77, num_breakpoints=20)
+    ps = synthetic.make_init_params(e, R, MAX_CN)
+    dev, ora = _two_sets(oracle_mod, e, ps, MAX_CN, 3)
+    assert dev.batch.num_cn_states == 165
+    for _ in range(2):
+        for step in STEPS:
+            getattr(dev.batch, step)()
+
+    def sweeps(m):                                   # (the oracle is plain C behind ctypes: the four restarts run side by side)
+        for _ in range(2):
+            for step in STEPS:
+                getattr(m.model, step)()
+    with ThreadPoolExecutor(max_workers=R) as pool:
+        list(pool.map(sweeps, ora.models))
+    cn_dev, _ = dev.batch.infer_cn_batch(0, R)
+    total, differing, nruns = 0, 0, 0
+    table = np.asarray(dev.models[0].model.cn_states)
+    for r in range(R):
+        ref = np.zeros_like(cn_dev[r]); ora.models[r].model.infer_cn(ref)
+        n1 = ref.shape[0]
+        total += n1
+        diff = (cn_dev[r] != ref).any(axis=(1, 2))
+        if not diff.any():
+            continue
+        st_d, st_o = _states(table, cn_dev[r]), _states(table, ref)
+        for mdl in (dev.models[r].model, ora.models[r].model):
+            f = np.asarray(mdl.framelogprob)
+            lt = np.zeros((n1 - 1, 165, 165)); mdl.calculate_log_transmat(lt)
+            whole = abs(_score(f, lt, st_o, 0, n1 - 1))
+            for a, b in _runs(diff):
+                d, o = _score(f, lt, st_d, a, b), _score(f, lt, st_o, a, b)
+                # the run's terms may be large and of either sign: the tie is measured against the path's log-probability, as max_product's sums are
+                assert abs(d - o) <= 1e-11 * whole, 'restart %d segments %d..%d: the paths differ and do not tie: %.17g vs %.17g (path %.6g)' % (r, a, b, d, o, whole)
+            del lt
+        differing += int(diff.sum()); nruns += len(_runs(diff))
+    frac = differing / float(total)
+    print('end-to-end Viterbi: %d of %d segments differ from the oracle\'s path (%.3g), in %d tied runs' % (differing, total, frac, nruns))
+    assert frac <= MAX_DIFFERING_FRACTION, frac
