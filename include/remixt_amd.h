@@ -143,7 +143,9 @@ enum rmx_option_id {
     RMX_OPT_FB_BREAKEND_CODES,  /* 1 (default): breakend steps from pair codes + clone-product tables; 0: per-clone distance tables */
     RMX_OPT_FUSE_SWEEPS,        /* 1 (default): marginals + indicator updates + next frame pass as one kernel between sweeps */
     RMX_OPT_TWO_STREAMS,        /* 1 (default): breakend branch of a sweep on a second stream next to the marginal pass */
-    RMX_OPT_VITERBI_PLAIN,      /* 1: decode with the table-reading lattice kernel */
+    RMX_OPT_VITERBI_PLAIN,      /* decode: 0 (default) the reference's own formulation -- maxima forward, the lattice rows kept, arg-maxima recomputed in the
+                                   trace-back (k_viterbi_max / k_viterbi_code_max + k_backtrace_max, round 5); 1 the table-reading lattice kernel with
+                                   back-pointers (k_viterbi); 2 round 4's register / code-table lattices with back-pointers */
     RMX_OPT_SEARCH_MODE,        /* parameter searches: 5 (default since round 5) the four standard searches together in rounds the device drives: optimiser
                                    state on the device, a kernel pair per round, queued back to back (half the latency of the host-driven rounds);
                                    0 the same shared rounds driven from the host (the default until round 4);

@@ -112,9 +112,11 @@ struct rmx_batch {
     void *h_batch = nullptr;           // pinned staging for the batched objective
     std::vector<int32_t> plain_list; int32_t *d_plain_list = nullptr; double *d_plain_jt = nullptr;
     // viterbi
+    int32_t *d_vit_special = nullptr; int n_vit_special = -1;      // adjacencies that are not plain class-0 ones, ascending (k_viterbi_max)
+    double *d_vrow = nullptr; size_t vrow_cap = 0;      // [nr][N][SR] lattice rows of k_viterbi_max / k_viterbi_code_max (pads 0)
     uint16_t *d_bp = nullptr; double *d_final = nullptr; int64_t *d_path = nullptr; double *d_logprob = nullptr;
-    std::vector<int64_t> last_path; int vit_cap = 0;
-    uint8_t *d_vit_code = nullptr; double *d_vit_val = nullptr; bool vit_code_ok = false;   // 8-bit codes of T(i, o) of class 0 + their values (k_viterbi_code)
+    std::vector<int64_t> last_path; int vit_cap = 0; size_t bp_cap = 0;
+    uint8_t *d_vit_code = nullptr; double *d_vit_val = nullptr; bool vit_code_ok = false, vit_mul_ok = false;   // 8-bit codes of T(i, o) of class 0 + their values (k_viterbi_code)
     // FB launch configuration
     FbLaunch fbG{}; size_t fbG_lds = 0;   // generic kernel configuration
     int n_fast = 0, n_generic = 0;
@@ -400,18 +402,32 @@ static int build_transitions(rmx_batch *b) {
     }
     // Viterbi lattice for grids beyond the register-resident kernel: codes of the distinct values of class 0
     b->vit_code_ok = false;
-    if (TC > 0 && S > 176 && S <= 384) {
+    if (TC > 0 && S <= 384) {      // (all grids since round 5: the trace-back of the maxima lattice looks its transition values up in the same table)
         std::map<double, int> ids;
         std::vector<uint8_t> code(SS);
         std::vector<double> vals(256, 0.);
         bool ok = true;
+        // the multiple form first: every value is (-pen) * k for an integer k <= 254, bit for bit (integer multiples of the penalty: true for
+        // both transition models whenever the reference's term-by-term accumulation is exact, e.g. the default penalty 10) -- then the code IS k,
+        // and a consumer may form the value with one multiplication instead of a table lookup (k_backtrace_max)
+        bool mul = pen > 0.;
+        for (int i = 0; i < S && mul; i++)
+            for (int j = 0; j < S; j++) {
+                const double T = Tval[(size_t)i * S + j];
+                const double kk = std::nearbyint(-T / pen);
+                if (!(kk >= 0. && kk <= 254.) || kk * (-pen) != T) { mul = false; break; }
+            }
+        b->vit_mul_ok = mul;
         for (int i = 0; i < S && ok; i++)
             for (int j = 0; j < S; j++) {
                 const double T = Tval[(size_t)i * S + j];
-                auto it = ids.find(T);
                 int id;
-                if (it == ids.end()) { id = (int)ids.size(); if (id >= 255) { ok = false; break; } ids[T] = id; vals[id] = T; }
-                else id = it->second;
+                if (mul) { id = (int)std::nearbyint(-T / pen); vals[id] = T; }
+                else {
+                    auto it = ids.find(T);
+                    if (it == ids.end()) { id = (int)ids.size(); if (id >= 255) { ok = false; break; } ids[T] = id; vals[id] = T; }
+                    else id = it->second;
+                }
                 code[(size_t)j * S + i] = (uint8_t)id;       // transposed: row = target state o, column = source state i
             }
         if (ok) {
@@ -689,6 +705,7 @@ static bool option_value_ok(int id, int v) {
     case RMX_OPT_PAIRWISE_KERNEL: return v >= 0 && v <= 4;
     case RMX_OPT_FB_WG_BUDGET: return v >= 0 && v <= 4096;
     case RMX_OPT_GRAD_KERNEL: return v >= 0 && v <= 2;
+    case RMX_OPT_VITERBI_PLAIN: return v >= 0 && v <= 2;
     default: return v == 0 || v == 1;
     }
 }
@@ -2617,37 +2634,96 @@ static int viterbi_paths(rmx_batch *b, int r0, int nr, std::vector<int64_t> &pat
     const Dev &d = b->d;
     const int N = d.N, S = d.S, M = d.M;
     int rc;
+    const int Pr = viterbi_reg_P(S), QPT = (S + Pr - 1) / Pr;
+    const int QPT4 = ((QPT + 3) / 4) * 4;
+    const int vopt = b->opt[RMX_OPT_VITERBI_PLAIN];      // 0: maxima forward + arg-maxima in the trace-back (round 5); 1: k_viterbi; 2: round 4's back-pointer lattices
+    const bool reg = QPT <= 44 && vopt != 1;
+    // code-table lattice (k_viterbi_code): V rows, breakend table, value table, S rows of P * QPT4 codes
+    const size_t code_lds = b->vit_code_ok ? (size_t)(2 * (Pr * QPT4 + 4) + ((M * d.D + 1) & ~1) + 256) * 8 + (size_t)S * Pr * QPT4 : (size_t)1 << 30;
+    const bool coded = !reg && cur_model && code_lds <= kLdsBudget && vopt != 1;
+    const bool maxima = vopt == 0 && (reg || coded);
+    const int SR = (S + 3) & ~3;
+    if (maxima && reg && b->n_vit_special < 0) {
+        std::vector<int32_t> sp;
+        for (int n = 0; n + 1 < N; n++) if (!(b->tclass[n] == 0 && b->brk_slot[n] < 0)) sp.push_back(n);
+        if ((rc = dalloc(b, &b->d_vit_special, std::max<size_t>(sp.size(), 1)))) return rc;
+        if (!sp.empty()) HIPCHK(hipMemcpyAsync(b->d_vit_special, sp.data(), sp.size() * 4, hipMemcpyHostToDevice, b->stream));
+        HIPCHK(hipStreamSynchronize(b->stream));      // (sp is a local)
+        b->n_vit_special = (int)sp.size();
+    }
+    // (the list lives in the workgroup's LDS next to two lattice rows: a dataset with more special adjacencies than fit takes round 4's kernel)
+    // breakend steps inside transition class 0 from LDS tables (totals, allele-flip bytes): the current model's tables only (d.ab has no per-model copy)
+    const bool be_tab = cur_model && !b->tc_pairs.empty() && M <= 4;
+    const int ca0 = b->tc_pairs.empty() ? 0 : b->tc_pairs[0].first, cb0 = b->tc_pairs.empty() ? 0 : b->tc_pairs[0].second;
+    const bool reg_max = maxima && reg && (size_t)(2 * (Pr * ((QPT + 1) & ~1) + 44) + M * d.D + 2) * 8 + (size_t)b->n_vit_special * 4 + (be_tab ? (size_t)S * 8 + (size_t)S * SR : 0) + 64 <= kLdsBudget;
     if (b->vit_cap < nr) {
-        dfree(b, b->d_bp); dfree(b, b->d_final); dfree(b, b->d_path); dfree(b, b->d_logprob);
-        b->d_bp = nullptr; b->d_final = nullptr; b->d_path = nullptr; b->d_logprob = nullptr; b->vit_cap = 0;
-        if ((rc = dalloc(b, &b->d_bp, (size_t)nr * N * S)) || (rc = dalloc(b, &b->d_final, (size_t)nr * S)) || (rc = dalloc(b, &b->d_path, (size_t)nr * N)) || (rc = dalloc(b, &b->d_logprob, nr))) return rc;
+        dfree(b, b->d_final); dfree(b, b->d_path); dfree(b, b->d_logprob);
+        b->d_final = nullptr; b->d_path = nullptr; b->d_logprob = nullptr; b->vit_cap = 0;
+        if ((rc = dalloc(b, &b->d_final, (size_t)nr * S)) || (rc = dalloc(b, &b->d_path, (size_t)nr * N)) || (rc = dalloc(b, &b->d_logprob, nr))) return rc;
         b->vit_cap = nr;
     }
-    const int Pr = viterbi_reg_P(S), QPT = (S + Pr - 1) / Pr;
-    const bool reg = QPT <= 44 && !b->opt[RMX_OPT_VITERBI_PLAIN];
-    // code-table lattice (k_viterbi_code): V rows, breakend table, value table, S rows of P * QPT4 codes
-    const int QPT4 = ((QPT + 3) / 4) * 4;
-    const size_t code_lds = b->vit_code_ok ? (size_t)(2 * (Pr * QPT4 + 4) + ((M * d.D + 1) & ~1) + 256) * 8 + (size_t)S * Pr * QPT4 : (size_t)1 << 30;
+    const bool lattice_rows = maxima && (reg_max || coded);      // rows of the lattice kept (trace-back recomputes the arg-maxima) instead of back-pointers
+    if (lattice_rows && b->vrow_cap < (size_t)nr * N * SR) {
+        dfree(b, b->d_vrow); b->d_vrow = nullptr; b->vrow_cap = 0;
+        if ((rc = dalloc(b, &b->d_vrow, (size_t)nr * N * SR))) return rc;
+        b->vrow_cap = (size_t)nr * N * SR;
+        HIPCHK(hipMemsetAsync(b->d_vrow, 0, b->vrow_cap * 8, b->stream));      // (the pads of a row stay 0: code 255 = -inf makes them lose every comparison)
+    }
+    if (!lattice_rows && b->bp_cap < (size_t)nr * N * S) {
+        dfree(b, b->d_bp); b->d_bp = nullptr; b->bp_cap = 0;
+        if ((rc = dalloc(b, &b->d_bp, (size_t)nr * N * S))) return rc;
+        b->bp_cap = (size_t)nr * N * S;
+    }
     { ProfScope ps(b, KID_VITERBI);
-      b->last_viterbi = reg ? 1 : ((cur_model && code_lds <= kLdsBudget && !b->opt[RMX_OPT_VITERBI_PLAIN]) ? 2 : 3);
+      b->last_viterbi = reg ? (reg_max ? 4 : 1) : (coded ? (maxima ? 5 : 2) : 3);
       if (reg) {
           const int NT = ((S * Pr + 63) / 64) * 64;
-#define VREG(Q) hipLaunchKernelGGL(k_viterbi_reg<Q>, dim3(nr), dim3(NT), (size_t)(2 * (Pr * QPT + Q) + M * d.D) * 8, b->stream, dv, r0, Pr, b->d_bp, b->d_final)
-          if (QPT <= 8) VREG(8); else if (QPT <= 16) VREG(16); else if (QPT <= 24) VREG(24); else if (QPT <= 32) VREG(32);
-          else if (QPT <= 36) VREG(36); else if (QPT <= 40) VREG(40); else VREG(44);
+#define VREG(Q) { if (reg_max) { const size_t lds_ = (size_t)(2 * (Pr * ((QPT + 1) & ~1) + Q) + ((M * d.D + 1) & ~1)) * 8 + (size_t)b->n_vit_special * 4 + (be_tab ? (size_t)S * 8 + (size_t)S * SR : 0) + 16; \
+                    HIPCHK(hipFuncSetAttribute((const void *)k_viterbi_max<Q>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_)); \
+                    hipLaunchKernelGGL(k_viterbi_max<Q>, dim3(nr), dim3(NT), lds_, b->stream, dv, r0, Pr, SR, b->d_vrow, (const int32_t *)b->d_vit_special, b->n_vit_special, be_tab ? 1 : 0, ca0, cb0, b->d_dbg); } \
+                  else hipLaunchKernelGGL(k_viterbi_reg<Q>, dim3(nr), dim3(NT), (size_t)(2 * (Pr * QPT + Q) + M * d.D) * 8, b->stream, dv, r0, Pr, b->d_bp, b->d_final); }
+          if (QPT <= 8) VREG(8) else if (QPT <= 16) VREG(16) else if (QPT <= 24) VREG(24) else if (QPT <= 32) VREG(32)
+          else if (QPT <= 36) VREG(36) else if (QPT <= 40) VREG(40) else VREG(44)
 #undef VREG
-      } else if (cur_model && code_lds <= kLdsBudget && !b->opt[RMX_OPT_VITERBI_PLAIN]) {
+      } else if (coded) {
           const int NT = ((S * Pr + 63) / 64) * 64;
-          HIPCHK(hipFuncSetAttribute((const void *)k_viterbi_code, hipFuncAttributeMaxDynamicSharedMemorySize, (int)code_lds));
-          hipLaunchKernelGGL(k_viterbi_code, dim3(nr), dim3(NT), code_lds, b->stream, b->d, r0, Pr, QPT4,
-                             (const uint8_t *)b->d_vit_code, (const double *)b->d_vit_val, b->d_bp, b->d_final);
+          if (maxima) {
+              HIPCHK(hipFuncSetAttribute((const void *)k_viterbi_code_max, hipFuncAttributeMaxDynamicSharedMemorySize, (int)code_lds));
+              hipLaunchKernelGGL(k_viterbi_code_max, dim3(nr), dim3(NT), code_lds, b->stream, b->d, r0, Pr, QPT4,
+                                 (const uint8_t *)b->d_vit_code, (const double *)b->d_vit_val, SR, b->d_vrow);
+          } else {
+              HIPCHK(hipFuncSetAttribute((const void *)k_viterbi_code, hipFuncAttributeMaxDynamicSharedMemorySize, (int)code_lds));
+              hipLaunchKernelGGL(k_viterbi_code, dim3(nr), dim3(NT), code_lds, b->stream, b->d, r0, Pr, QPT4,
+                                 (const uint8_t *)b->d_vit_code, (const double *)b->d_vit_val, b->d_bp, b->d_final);
+          }
       } else {
           const int P = viterbi_P(S), NT = ((S * P + 63) / 64) * 64;
           hipLaunchKernelGGL(k_viterbi, dim3(nr), dim3(NT), (size_t)(2 * S + M * d.D) * 8, b->stream, dv, r0, P, b->d_bp, b->d_final);
       } }
+    if (lattice_rows) {
+        // the trace-back recomputes lattice[n, i] + log_transmat[n, i, state[n+1]] (bpmodel.pyx:1327-1331); class-0 plain adjacencies from the
+        // code table of the CURRENT model (a snapshot of the other model goes through trans_value on the snapshot's tables)
+        const bool tcode = cur_model && b->vit_code_ok;
+        const size_t code_b = tcode ? (((size_t)S * SR + 7) & ~(size_t)7) : 0;
+        const size_t be_b = (size_t)((M * d.D + 1) & ~1) * 8 + (size_t)S * 8 + (size_t)S * SR;
+        // (the breakend-step tables only where they fit next to the code table and a few lattice rows: 355 states take the plain expression there)
+        const bool be_bt = be_tab && (size_t)256 * 8 + code_b + be_b + (size_t)8 * (SR * 8 + 4) + 128 <= kLdsBudget;
+        const size_t tabs = code_b + (be_bt ? be_b : 0);
+        const size_t fixed = (size_t)256 * 8 + tabs + 64;
+        int rows = (int)((kLdsBudget - fixed) / ((size_t)SR * 8 + 4));
+        rows = std::max(2, std::min(rows, 96) & ~1);      // (even: the tables behind the per-row ints stay 8-byte aligned)
+        const size_t lds = (size_t)rows * SR * 8 + 256 * 8 + (size_t)rows * 4 + tabs + 16;
+        const bool mul = tcode && b->vit_mul_ok, two = SR > 256;
+        auto kf = mul ? (two ? k_backtrace_max<true, true> : k_backtrace_max<true, false>) : (two ? k_backtrace_max<false, true> : k_backtrace_max<false, false>);
+        ProfScope ps(b, KID_BACKTRACE);
+        HIPCHK(hipFuncSetAttribute((const void *)kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(kf, dim3(nr), dim3(256), lds, b->stream, dv, r0, SR, (const double *)b->d_vrow, tcode ? (const uint8_t *)b->d_vit_code : nullptr,
+                           (const double *)b->d_vit_val, mul ? -d.pen : 0., b->d_path, b->d_logprob, rows, be_bt ? 1 : 0, ca0, cb0);
+    } else {
     int rows = std::max(1, std::min(256, (48 * 1024) / (2 * S)));
     { ProfScope ps(b, KID_BACKTRACE);
       hipLaunchKernelGGL(k_backtrace, dim3(nr), dim3(256), (size_t)rows * S * 2, b->stream, b->d, (const uint16_t *)b->d_bp, (const double *)b->d_final, b->d_path, b->d_logprob, rows); }
+    }
     HIPCHK(hipGetLastError());
     paths.resize((size_t)nr * N); lps.resize(nr);
     HIPCHK(hipMemcpyAsync(paths.data(), b->d_path, (size_t)nr * N * 8, hipMemcpyDeviceToHost, b->stream));

@@ -4114,6 +4114,391 @@ __global__ __launch_bounds__(768) void k_viterbi_reg(Dev d, int r0, int P, uint1
     }
     if (t < S) final_all[(size_t)blockIdx.x * S + t] = V[((d.N - 1) & 1) * SV + t];
 }
+// ---- round 5: the lattice as the REFERENCE runs it -- maxima forward, arg-maxima in the trace-back ------------------------------------
+// max_product (bpmodel.pyx:1314-1331) keeps no back-pointers: its induction is viterbi_lattice[n, j] = _max(lattice[n-1, :] +
+// log_transmat[n-1, :, j]) + framelogprob[n, j], and the trace-back RECOMPUTES lattice[n, i] + log_transmat[n, i, state[n+1]] and takes its
+// first maximum.  k_viterbi_reg above records the arg-maximum of every (n, j) instead -- an add, a compare and three selects per state pair,
+// 2 500 cycles of vector ALU per step on the fullest SIMD, and nearly all of those arg-maxima are never looked at.  k_viterbi_max runs the
+// reference's induction literally: an add and a v_max_f64 per pair (the maximum of the same values is the same value whatever the order it
+// is taken in), the merge of a column's P partial maxima is a maximum too (no tie rule to carry), and the lattice ROW goes to memory
+// (8 bytes per state instead of a 2-byte pointer: 66 MB per restart at 50 000 x 165).  k_backtrace_max then does what the reference's
+// trace-back does, one arg-maximum over S values per segment, first maximum wins.  Same expressions, same values, same tie rule: bit-exact.
+// (the LDS reads as ds_read_b128: 4 LDS cycles per wave instruction, 256 B/clk, against 8 cycles and 128 B/clk for the ds_read2_b64 of
+// k_viterbi_reg -- MI355X_MICROARCH.md, LDS table -- and a step is 11 waves x 21 of them)
+template <int K> __device__ __forceinline__ void vitm_rd(vit_d2 &dst, unsigned addr) {
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(16 * K) : "memory");
+}
+template <int G, int NG, int DEPTH> struct vitm_pipe {
+    template <int QMAX>
+    static __device__ __forceinline__ void step(vit_d2 (&buf)[DEPTH], const double (&T)[QMAX], unsigned addr, double &b0, double &b1) {
+        constexpr int younger = (NG - 1 - G) < (DEPTH - 1) ? (NG - 1 - G) : (DEPTH - 1);
+        vit_wait<younger>(buf[G % DEPTH]);
+        const vit_d2 x = buf[G % DEPTH];
+        if constexpr (G + DEPTH < NG) vitm_rd<G + DEPTH>(buf[G % DEPTH], addr);
+        b0 = fmax(b0, x.x + T[2 * G]);                   // (two running maxima: independent chains; a maximum does not depend on the order it is taken in)
+        b1 = fmax(b1, x.y + T[2 * G + 1]);
+        if constexpr (G + 1 < NG) vitm_pipe<G + 1, NG, DEPTH>::step(buf, T, addr, b0, b1);
+    }
+    template <int QMAX>
+    static __device__ __forceinline__ void run(const double (&T)[QMAX], unsigned addr, double &best) {
+        static_assert(G == 0 && 2 * NG == QMAX && DEPTH <= NG, "pipeline shape");
+        vit_d2 buf[DEPTH];
+        fill<0>(buf, addr);
+        double b0 = -INFINITY, b1 = -INFINITY;
+        step(buf, T, addr, b0, b1);
+        best = fmax(b0, b1);
+    }
+    template <int I> static __device__ __forceinline__ void fill(vit_d2 (&buf)[DEPTH], unsigned addr) {
+        vitm_rd<I>(buf[I], addr);
+        if constexpr (I + 1 < DEPTH) fill<I + 1>(buf, addr);
+    }
+};
+// Vector-memory traffic of the step loop, kept to ONE request and ONE store per wave and step, both by the writer lanes only (p == 0: 16 of a
+// wave's 64).  The first version had every thread request its column's framelogprob value and the adjacency's class and breakend slot each
+// step -- 33 wave-level loads per step and workgroup -- and the step took 1 500 cycles longer than without them, whether they were issued
+// before or after the step's LDS reads (tools/vit_stamps.py, profiles/r05_decode.txt): waves queue for the CU's one address unit.  Now
+//   * the steps that are NOT plain class-0 adjacencies (breakends, telomeres, other classes: 4 % of them) come as a sorted list the host made
+//     once per dataset (d.tclass / d.brk_slot do not depend on the restart), held in LDS: a step compares its adjacency with the next entry;
+//   * a writer lane's framelogprob value is requested VM_K steps ahead into a ring of registers through loads the compiler does not track,
+//     and retired by a COUNTED s_waitcnt: memory operations of a wave complete in order, so when step n waits, its own request must have
+//     landed while the younger ones -- the requests of steps n + 1 .. n + VM_K - 1 and the row stores of the last VM_K steps -- stay in flight.
+#define VM_K 4
+template <int CNT> __device__ __forceinline__ void vm_wait(double &a) { asm volatile("s_waitcnt vmcnt(%1)" : "+v"(a) : "n"(CNT) : "memory"); }
+// maximum over the P lanes (a power of two, aligned) that hold the partial maxima of one target state; every lane of the group gets it.  The
+// lanes are neighbours (thread = o * P + p): quad permutes and row mirrors, single-instruction DPP moves -- __shfl_xor compiles to ds_bpermute,
+// an LDS round trip per step and 32-bit half (tools/micro/vit_loop_bench.hip: merge + row write 960 of a step's 2 100 cycles)
+__device__ __forceinline__ double group_max_p(double v, int P) {
+    if (P >= 2) v = fmax(v, dpp_mov_f64<0xB1>(v));     // quad_perm [1,0,3,2]
+    if (P >= 4) v = fmax(v, dpp_mov_f64<0x4E>(v));     // quad_perm [2,3,0,1]
+    if (P >= 8) v = fmax(v, dpp_mov_f64<0x141>(v));    // row_half_mirror (on quad-uniform values: xor 4)
+    if (P >= 16) v = fmax(v, dpp_mov_f64<0x140>(v));   // row_mirror (on half-row-uniform values: xor 8)
+    if (P >= 32) v = fmax(v, __shfl_xor(v, 16, 64));
+    if (P >= 64) v = fmax(v, __shfl_xor(v, 32, 64));
+    return v;
+}
+// grid (nr), block 64 * ceil(S * P / 64); lattice rows to vrow_all [nr][N][SR] (SR = S rounded up to 4, pads 0); special [nspecial]: the
+// adjacencies (ascending) that are not plain class-0 ones; dynamic LDS: 2 SV + M D doubles, then nspecial ints
+template <int QMAX>
+__global__ __launch_bounds__(768) void k_viterbi_max(Dev d, int r0, int P, int SR, double *vrow_all, const int32_t *special, int nspecial, int be_tables, int ca0, int cb0,
+                                                      unsigned long long *dbg) {
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    const int S = d.S, M = d.M, D = d.D, t = threadIdx.x, NT = blockDim.x, r = r0 + blockIdx.x;
+    const int QPT = (((S + P - 1) / P) + 1) & ~1;      // source states per thread, even: 16-byte aligned ds_read_b128
+    const int SV = P * QPT + QMAX;         // padded row: reads past S see 0 and are paired with T = -inf
+    double *V = (double *)smem_raw;        // [2][SV]
+    double *pdl = V + 2 * SV;              // [M*D]
+    int *spl = (int *)(pdl + ((M * D + 1) & ~1));      // [nspecial]
+    // tables of a breakend step inside transition class 0 (be_tables; classes ca0 -> cb0), so that the step's S x S transition values
+    // (bpmodel.pyx:659-668, accumulated in the reference's order: trans_value) are formed from LDS instead of 42 chains of dependent global
+    // loads per thread: the states' totals, one byte per clone, and the allele-flip term, row = target state
+    unsigned *totA = (unsigned *)(spl + nspecial), *totB = totA + S;      // [S] each
+    int8_t *abl = (int8_t *)(totB + S);                                    // [S][SR]
+    double *vrow = vrow_all + (size_t)blockIdx.x * d.N * SR;
+    const int o = t / P, p = t % P;
+    const bool act = o < S;
+    const int oc = act ? o : S - 1;
+    const int i0 = p * QPT;
+    const double *f = d.f + rs_off(d, r, 0);
+    double Treg[QMAX];
+#pragma unroll
+    for (int rr = 0; rr < QMAX; rr++) {
+        const int i = i0 + rr;
+        Treg[rr] = (act && rr < QPT && i < S && d.TC > 0) ? d.Tval[(size_t)i * S + o] : -INFINITY;
+    }
+#pragma unroll
+    for (int rr = 0; rr < QMAX; rr++) asm volatile("" : "+v"(Treg[rr]));      // their loads retire here, not at a vmcnt(0) inside the step loop
+    for (int i = t; i < 2 * SV; i += NT) V[i] = 0.;
+    for (int i = t; i < nspecial; i += NT) spl[i] = special[i];
+    if (be_tables) {
+        for (int i = t; i < S; i += NT) {
+            unsigned pa = 0, pb = 0;
+            for (int c = 0; c < M; c++) { pa |= ((unsigned)d.tot[((size_t)ca0 * S + i) * M + c] & 0xffu) << (8 * c); pb |= ((unsigned)d.tot[((size_t)cb0 * S + i) * M + c] & 0xffu) << (8 * c); }
+            totA[i] = pa; totB[i] = pb;
+        }
+        for (int k = t; k < S * SR; k += NT) { const int oo = k / SR, ii = k - oo * SR; abl[k] = ii < S ? d.ab[(size_t)oo * S + ii] : (int8_t)0; }
+    }
+    __syncthreads();
+    if (t < SR) { const double v0 = t < S ? f[t] : 0.; if (t < S) V[t] = v0; vrow[t] = v0; }
+    __syncthreads();
+    if (d.N > 1) {
+        const bool writer = act && p == 0;
+        // does this WAVE issue a request and a row store per step?  (both sit under `if (writer)`: a wave none of whose lanes writes skips the
+        // instructions, and has nothing to wait for)
+        const bool wave_stores = __builtin_amdgcn_readfirstlane((int)(__ballot(writer) != 0ull)) != 0;
+        double fnr[VM_K] = {0., 0., 0., 0.};
+#define VM_ISSUE(j_, n_) { if (writer) { const int nn_ = (n_) < d.N ? (n_) : d.N - 1; gload8(fnr[j_], f + (size_t)nn_ * d.SP + o); } }
+#pragma unroll
+        for (int j = 0; j < VM_K; j++) VM_ISSUE(j, 1 + j)
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(fnr[0]), "+v"(fnr[1]), "+v"(fnr[2]), "+v"(fnr[3]) :: "memory");
+        static_assert(VM_K == 4, "the ring is written out for four slots");
+        int sp_k = 0;
+        int next_sp = nspecial > 0 ? __builtin_amdgcn_readfirstlane(spl[0]) : 0x7fffffff;      // the next adjacency that is not a plain class-0 one
+#ifdef RMX_VIT_STAMPS
+        // diagnostic build (tools/vit_stamps.py): cycles a wave spends per step waiting for its ring slot (0), in the LDS reads + add / max of a
+        // plain step (1), in the merge of the P partial maxima (2), from there to its arrival at the barrier (3) and in the barrier (4)
+        unsigned long long vst_acc[5] = {0, 0, 0, 0, 0}, vst_last;
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(vst_last) :: "memory");
+#define VST(i_) { unsigned long long t_; asm volatile("s_waitcnt lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); vst_acc[i_] += t_ - vst_last; vst_last = t_; }
+#else
+#define VST(i_)
+#endif
+        // one step with ring slot J_: behind a writer wave's own request lie VM_K row stores and VM_K - 1 requests
+#define VM_STEP(J_)                                                                                                                \
+        {                                                                                                                          \
+            if (wave_stores) vm_wait<VM_K + (VM_K - 1)>(fnr[J_]);                                                                   \
+            VST(0)                                                                                                                 \
+            const int cur = (n - 1) & 1, nxt = n & 1, tn = n - 1;                                                                  \
+            const double fcur = fnr[J_];                                                                                           \
+            VM_ISSUE(J_, n + VM_K)                                                                                                 \
+            double best = -INFINITY;                                                                                               \
+            if (tn != next_sp) {                                                                                                   \
+                const double *Vc = V + cur * SV + i0;                                                                              \
+                vitm_pipe<0, QMAX / 2, (QMAX / 2 < 6 ? QMAX / 2 : 6)>::run(Treg, lds_addr(Vc), best);                              \
+            } else {                                                                                                               \
+                sp_k++;                                                                                                            \
+                next_sp = sp_k < nspecial ? __builtin_amdgcn_readfirstlane(spl[sp_k]) : 0x7fffffff;                                \
+                const int tc = d.tclass[tn], bs = d.brk_slot[tn];      /* (tracked loads: the compiler's own wait drains the ring too -- harmless, 4 % of the steps) */ \
+                const double *pd = nullptr;                                                                                        \
+                if (tc >= 0 && bs >= 0) {                                                                                          \
+                    const double *pdg = d.pd_lt + ((size_t)r * d.NBE + bs) * M * D;                                                \
+                    for (int i = t; i < M * D; i += NT) pdl[i] = pdg[i];                                                           \
+                    __syncthreads();                                                                                               \
+                    pd = pdl;                                                                                                      \
+                }                                                                                                                  \
+                if (be_tables && tc == 0 && pd != nullptr) {                                                                       \
+                    /* trans_value(d, tn, i, o, pd) from the LDS tables: the same products and sums in the same order */              \
+                    if (act) {                                                                                                     \
+                        const unsigned tb_ = totB[o];                                                                              \
+                        const int8_t *abr_ = abl + (size_t)o * SR;                                                                 \
+                        const int off_ = d.cn_max + 1;                                                                             \
+                        for (int rr = 0; rr < QPT; rr++) {                                                                         \
+                            const int i = i0 + rr;                                                                                 \
+                            if (i < S) {                                                                                           \
+                                const unsigned ta_ = totA[i];                                                                      \
+                                double T = 0.;                                                                                     \
+                                for (int c = 0; c < M; c++) {                                                                      \
+                                    const int dd = (int)(int8_t)((ta_ >> (8 * c)) & 0xffu) - (int)(int8_t)((tb_ >> (8 * c)) & 0xffu); \
+                                    T += -d.pen * pd[c * D + dd + off_];                                                           \
+                                }                                                                                                  \
+                                T += -d.pen * (double)abr_[i];                                                                     \
+                                best = fmax(best, V[cur * SV + i] + T);                                                            \
+                            }                                                                                                      \
+                        }                                                                                                          \
+                    }                                                                                                              \
+                } else if (act) for (int rr = 0; rr < QPT; rr++) {                                                                 \
+                    const int i = i0 + rr;                                                                                         \
+                    if (i < S) {                                                                                                   \
+                        const double T = (tc < 0) ? 0. : trans_value(d, tn, i, o, pd);                                             \
+                        best = fmax(best, V[cur * SV + i] + T);                                                                    \
+                    }                                                                                                              \
+                }                                                                                                                  \
+            }                                                                                                                      \
+            VST(1)                                                                                                                 \
+            best = group_max_p(best, P);                                                                                           \
+            VST(2)                                                                                                                 \
+            if (writer) {                                                                                                          \
+                const double vn = best + fcur;                                                                                     \
+                V[nxt * SV + o] = vn;                                                                                              \
+                gstore8(vrow + (size_t)n * SR + o, vn);                                                                            \
+            }                                                                                                                      \
+            VST(3)                                                                                                                 \
+            __syncthreads();                                                                                                       \
+            VST(4)                                                                                                                 \
+            n++;                                                                                                                   \
+        }
+        int n = 1;
+        while (n < d.N) {
+            VM_STEP(0)
+            if (n < d.N) VM_STEP(1)
+            if (n < d.N) VM_STEP(2)
+            if (n < d.N) VM_STEP(3)
+        }
+#undef VM_STEP
+#undef VM_ISSUE
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (the ring's last requests: nobody reads them, the registers must not be re-used under them)
+#ifdef RMX_VIT_STAMPS
+        if (dbg && blockIdx.x == 0 && (t & 63) == 0) {
+            const int w_ = t >> 6, nw_ = NT >> 6;
+            const int slot = w_ == 0 ? 0 : (w_ == nw_ / 2 ? 1 : (w_ == nw_ - 1 ? 2 : -1));
+            if (slot >= 0) for (int i = 0; i < 5; i++) dbg[8 + slot * 5 + i] = vst_acc[i];
+            if (w_ == 0) dbg[4] = d.N - 1;
+        }
+#endif
+#undef VST
+    }
+}
+// Trace-back of k_viterbi_max's lattice, one workgroup of 256 threads per restart (bpmodel.pyx:1320-1331): the final row's first maximum,
+// then per segment n = N-2 .. 0 the first maximum over i of lattice[n, i] + log_transmat[n, i, state[n+1]].  Rows of the lattice, the
+// adjacency classes and the breakend slots are staged through LDS a chunk at a time by the whole workgroup; the chain itself -- 50 000
+// dependent steps -- runs on wave 0, lane l owning source states 256 g + 4 l .. + 3, and is kept short:
+//   * a plain class-0 adjacency takes its transition values from the 8-bit code table of the class (row = target state, a 32-bit LDS read
+//     whose address is the only thing that depends on the previous step); the value is -pen * code where the host has verified that form
+//     bit for bit (mulpen != 0: one conversion and one multiplication), else a second LDS lookup in valtab -- the SAME doubles as d.Tval;
+//   * the lattice row of step n - 1 is read while step n's reduction runs (its address does not depend on the state);
+//   * the arg-maximum over the wave: the maximum by DPP row rotations and four v_readlane, then the LOWEST lane holding it (ballot + find-first)
+//     -- lanes ascend with the state index and a lane keeps the first of its own maxima, so this is the reference's first maximum.
+// Everything else (telomeres: log_transmat == 0; breakend and other-class adjacencies: trans_value) takes the plain expression.
+// dynamic LDS: ROWS * SR doubles, 256 doubles, 2 * ROWS ints, S * SR code bytes (0 if codeT == nullptr: every step through trans_value)
+__device__ __forceinline__ double wave_max_f64(double v) {      // maximum over the 64 lanes (wave-uniform result); any finite / -inf values
+    v = fmax(v, dpp_mov_f64<0x121>(v));   // row_ror:1
+    v = fmax(v, dpp_mov_f64<0x122>(v));   // row_ror:2
+    v = fmax(v, dpp_mov_f64<0x124>(v));   // row_ror:4
+    v = fmax(v, dpp_mov_f64<0x128>(v));   // row_ror:8  -> every lane holds its row's maximum
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    const double r0 = __hiloint2double(__builtin_amdgcn_readlane(hi, 0), __builtin_amdgcn_readlane(lo, 0));
+    const double r1 = __hiloint2double(__builtin_amdgcn_readlane(hi, 16), __builtin_amdgcn_readlane(lo, 16));
+    const double r2 = __hiloint2double(__builtin_amdgcn_readlane(hi, 32), __builtin_amdgcn_readlane(lo, 32));
+    const double r3 = __hiloint2double(__builtin_amdgcn_readlane(hi, 48), __builtin_amdgcn_readlane(lo, 48));
+    return fmax(fmax(r0, r1), fmax(r2, r3));
+}
+// MUL: transition value = mulpen * code (verified by the host), else valtab[code]; TWO: a second group of 256 states (256 < S <= 512)
+template <bool MUL, bool TWO>
+__global__ __launch_bounds__(256) void k_backtrace_max(Dev d, int r0, int SR, const double *vrow_all, const uint8_t *codeT, const double *valtab, double mulpen,
+                                                        int64_t *path_all, double *logprob_all, int ROWS, int be_tables, int ca0, int cb0) {
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    __shared__ int cur_state;
+    const int S = d.S, M = d.M, D = d.D, t = threadIdx.x, NT = blockDim.x, r = r0 + blockIdx.x;
+    double *Vc = (double *)smem_raw;                  // [ROWS][SR]  (pads: -inf)
+    double *val = Vc + (size_t)ROWS * SR;             // [256]
+    int *tcl = (int *)(val + 256);                    // [ROWS]  1 = plain class-0 adjacency (the coded fast path), 0 = anything else
+    uint8_t *cl = (uint8_t *)(tcl + ROWS);            // [S][SR] codes (coded), then the breakend-step tables (be_tables): pd [M*D], totals [2][S], allele-flip bytes [S][SR]
+    const double *vrow = vrow_all + (size_t)blockIdx.x * d.N * SR;
+    int64_t *path = path_all + (size_t)blockIdx.x * d.N;
+    const bool coded = codeT != nullptr;
+    double *pdl = (double *)(cl + (coded ? (((size_t)S * SR + 7) & ~(size_t)7) : 0));
+    unsigned *totA = (unsigned *)(pdl + ((M * D + 1) & ~1)), *totB = totA + S;
+    int8_t *abl = (int8_t *)(totB + S);
+    if (be_tables) {
+        for (int i = t; i < S; i += NT) {
+            unsigned pa = 0, pb = 0;
+            for (int c = 0; c < M; c++) { pa |= ((unsigned)d.tot[((size_t)ca0 * S + i) * M + c] & 0xffu) << (8 * c); pb |= ((unsigned)d.tot[((size_t)cb0 * S + i) * M + c] & 0xffu) << (8 * c); }
+            totA[i] = pa; totB[i] = pb;
+        }
+        for (int k = t; k < S * SR; k += NT) { const int oo = k / SR, ii = k - oo * SR; abl[k] = ii < S ? d.ab[(size_t)oo * S + ii] : (int8_t)0; }
+    }
+    if (coded) {
+        for (int k = t; k < S * SR; k += NT) { const int oo = k / SR, ii = k - oo * SR; cl[k] = ii < S ? codeT[(size_t)oo * S + ii] : (uint8_t)0; }      // (pad codes: any finite value; the lattice pads are -inf)
+        for (int i = t; i < 256; i += NT) val[i] = i < 255 ? valtab[i] : 0.;
+    }
+    const int lane = t & 63;
+    const bool in0 = 4 * lane < S, in1 = TWO && 256 + 4 * lane < S;
+    // first maximum of the candidates (a: states 4 lane .. + 3, b: 256 + 4 lane .. + 3): the state index, wave-uniform; mx = the maximum
+#define BT_FIRST_MAX(a0_, a1_, a2_, a3_, b0_, b1_, b2_, b3_, mx_, out_)                                                            \
+    {                                                                                                                              \
+        double best_ = a0_; int bi_ = 4 * lane;                                                                                    \
+        if (a1_ > best_) { best_ = a1_; bi_ = 4 * lane + 1; }                                                                      \
+        if (a2_ > best_) { best_ = a2_; bi_ = 4 * lane + 2; }                                                                      \
+        if (a3_ > best_) { best_ = a3_; bi_ = 4 * lane + 3; }                                                                      \
+        double m_ = wave_max_f64(best_);                                                                                           \
+        double best2_ = -INFINITY; int bi2_ = 0;                                                                                   \
+        if (TWO) {                                                                                                                 \
+            best2_ = b0_; bi2_ = 256 + 4 * lane;                                                                                   \
+            if (b1_ > best2_) { best2_ = b1_; bi2_ = 256 + 4 * lane + 1; }                                                         \
+            if (b2_ > best2_) { best2_ = b2_; bi2_ = 256 + 4 * lane + 2; }                                                         \
+            if (b3_ > best2_) { best2_ = b3_; bi2_ = 256 + 4 * lane + 3; }                                                         \
+            m_ = fmax(m_, wave_max_f64(best2_));                                                                                   \
+        }                                                                                                                          \
+        mx_ = m_;                                                                                                                  \
+        /* the lowest state holding the maximum: the first group's lanes (states 0 .. 255 in lane order), then the second group's */ \
+        const unsigned long long k1_ = __ballot(best_ == m_);                                                                      \
+        if (!TWO || k1_) out_ = __builtin_amdgcn_readlane(bi_, (int)__builtin_ctzll(k1_));                                         \
+        else { const unsigned long long k2_ = __ballot(best2_ == m_); out_ = __builtin_amdgcn_readlane(bi2_, (int)__builtin_ctzll(k2_)); } \
+    }
+    // the last row: np.argmax(viterbi_lattice[-1, :])
+    if (t < 64) {
+        double a[4], b2[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            a[k] = (4 * lane + k < S) ? vrow[(size_t)(d.N - 1) * SR + 4 * lane + k] : -INFINITY;
+            b2[k] = (TWO && 256 + 4 * lane + k < S) ? vrow[(size_t)(d.N - 1) * SR + 256 + 4 * lane + k] : -INFINITY;
+        }
+        double mx; int bi;
+        BT_FIRST_MAX(a[0], a[1], a[2], a[3], b2[0], b2[1], b2[2], b2[3], mx, bi)
+        if (t == 0) { cur_state = bi; path[d.N - 1] = bi; logprob_all[blockIdx.x] = mx; }
+    }
+    __syncthreads();
+    const double NEG = -INFINITY;
+    for (int hi = d.N - 2; hi >= 0; hi -= ROWS) {
+        const int lo = hi - ROWS + 1 > 0 ? hi - ROWS + 1 : 0;   // lattice rows lo .. hi, adjacencies lo .. hi
+        const int nrow = hi - lo + 1;
+        for (int i = t; i < nrow * SR; i += NT) { const int col = i % SR; Vc[i] = col < S ? vrow[(size_t)lo * SR + i] : NEG; }
+        for (int i = t; i < nrow; i += NT) tcl[i] = (coded && d.tclass[lo + i] == 0 && d.brk_slot[lo + i] < 0) ? 1 : 0;
+        __syncthreads();
+        if (t < 64) {
+            int s = cur_state;
+            // the lattice row and the kind of the step are read a step ahead (neither depends on the state)
+            double2 va0 = make_double2(NEG, NEG), vb0 = va0, va1 = va0, vb1 = va0;
+            int kind;
+#define BT_LOAD_ROW(n_)                                                                                                            \
+            {                                                                                                                      \
+                const double *Vn_ = Vc + (size_t)((n_) - lo) * SR + 4 * lane;                                                      \
+                if (in0) { va0 = *reinterpret_cast<const double2 *>(Vn_); vb0 = *reinterpret_cast<const double2 *>(Vn_ + 2); }      \
+                if (in1) { va1 = *reinterpret_cast<const double2 *>(Vn_ + 256); vb1 = *reinterpret_cast<const double2 *>(Vn_ + 258); } \
+                kind = tcl[(n_) - lo];                                                                                             \
+            }
+            BT_LOAD_ROW(hi)
+            for (int n = hi; n >= lo; n--) {
+                double a0 = va0.x, a1 = va0.y, a2 = vb0.x, a3 = vb0.y, b0 = va1.x, b1 = va1.y, b2 = vb1.x, b3 = vb1.y;
+                const int knd = __builtin_amdgcn_readfirstlane(kind);
+                if (n > lo) BT_LOAD_ROW(n - 1)
+                if (knd) {
+                    // plain class-0 adjacency: lattice + T(i, s), T from the code row of target state s (pads: -inf + finite)
+                    const unsigned c0 = in0 ? *reinterpret_cast<const unsigned *>(cl + (size_t)s * SR + 4 * lane) : 0u;
+                    if (MUL) {      // (mulpen * code is exact -- verified by the host -- so one fused multiply-add rounds like the reference's single addition)
+                        a0 = fma(mulpen, (double)(c0 & 255u), a0); a1 = fma(mulpen, (double)((c0 >> 8) & 255u), a1);
+                        a2 = fma(mulpen, (double)((c0 >> 16) & 255u), a2); a3 = fma(mulpen, (double)(c0 >> 24), a3);
+                    } else { a0 += val[c0 & 255u]; a1 += val[(c0 >> 8) & 255u]; a2 += val[(c0 >> 16) & 255u]; a3 += val[c0 >> 24]; }
+                    if (TWO) {
+                        const unsigned c1 = in1 ? *reinterpret_cast<const unsigned *>(cl + (size_t)s * SR + 256 + 4 * lane) : 0u;
+                        if (MUL) {
+                            b0 = fma(mulpen, (double)(c1 & 255u), b0); b1 = fma(mulpen, (double)((c1 >> 8) & 255u), b1);
+                            b2 = fma(mulpen, (double)((c1 >> 16) & 255u), b2); b3 = fma(mulpen, (double)(c1 >> 24), b3);
+                        } else { b0 += val[c1 & 255u]; b1 += val[(c1 >> 8) & 255u]; b2 += val[(c1 >> 16) & 255u]; b3 += val[c1 >> 24]; }
+                    }
+                } else {
+                    // telomere (log_transmat == 0), breakend or other-class adjacency: the plain expression
+                    const int tc = d.tclass[n], bs = d.brk_slot[n];
+                    const double *pd = (tc >= 0 && bs >= 0) ? d.pd_lt + ((size_t)r * d.NBE + bs) * M * D : nullptr;
+                    double *vv[8] = {&a0, &a1, &a2, &a3, &b0, &b1, &b2, &b3};
+                    if (be_tables && tc == 0 && pd != nullptr) {
+                        // a breakend adjacency inside class 0: trans_value's products and sums in its order, the operands from LDS (the breakend's distance
+                        // table first: M * D doubles, one round trip)
+                        for (int i = lane; i < M * D; i += 64) pdl[i] = pd[i];
+                        const unsigned tb_ = totB[s];
+                        const int off_ = d.cn_max + 1;
+#pragma unroll
+                        for (int q = 0; q < (TWO ? 8 : 4); q++) {
+                            const int i = (q < 4 ? 0 : 256) + 4 * lane + (q & 3);
+                            if (i < S) {
+                                const unsigned ta_ = totA[i];
+                                double T = 0.;
+                                for (int c = 0; c < M; c++) {
+                                    const int dd = (int)(int8_t)((ta_ >> (8 * c)) & 0xffu) - (int)(int8_t)((tb_ >> (8 * c)) & 0xffu);
+                                    T += -d.pen * pdl[c * D + dd + off_];
+                                }
+                                T += -d.pen * (double)abl[(size_t)s * SR + i];
+                                *vv[q] = *vv[q] + T;
+                            }
+                        }
+                    } else {
+#pragma unroll
+                    for (int q = 0; q < (TWO ? 8 : 4); q++) {
+                        const int i = (q < 4 ? 0 : 256) + 4 * lane + (q & 3);
+                        if (i < S) *vv[q] = *vv[q] + (tc < 0 ? 0. : trans_value(d, n, i, s, pd));
+                    }
+                    }
+                }
+                double mx;
+                BT_FIRST_MAX(a0, a1, a2, a3, b0, b1, b2, b3, mx, s)
+                if (lane == 0) path[n] = s;
+            }
+            if (lane == 0) cur_state = s;
+#undef BT_LOAD_ROW
+        }
+        __syncthreads();
+    }
+#undef BT_FIRST_MAX
+}
 // The same for grids whose S x S transition values do not fit the register file (176 < S <= ~380): the
 // plain-adjacency table of class 0 has few distinct values (sums of -pen x small integers), so the
 // workgroup keeps 8-bit CODES of all S x S values in LDS (126 KB at S = 355), row o = target state padded
@@ -4200,6 +4585,82 @@ __global__ __launch_bounds__(768) void k_viterbi_code(Dev d, int r0, int P, int 
         }
     }
     if (t < S) final_all[(size_t)blockIdx.x * S + t] = V[((d.N - 1) & 1) * SV + t];
+}
+// k_viterbi_code with the reference's induction (maxima forward, the lattice rows to memory; see k_viterbi_max): 176 < S <= ~380
+__global__ __launch_bounds__(768) void k_viterbi_code_max(Dev d, int r0, int P, int QPT /* multiple of 4 */, const uint8_t *codeT /* [S][S]: (o, i) */,
+                                                          const double *valtab /* [256] */, int SR, double *vrow_all) {
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    const int S = d.S, M = d.M, D = d.D, t = threadIdx.x, NT = blockDim.x, r = r0 + blockIdx.x;
+    const int SV = P * QPT + 4;
+    const int SC = P * QPT;                // code row stride (bytes), multiple of 4
+    double *V = (double *)smem_raw;        // [2][SV]
+    double *pdl = V + 2 * SV;              // [M*D]
+    double *val = pdl + ((M * D + 1) & ~1);   // [256]
+    uint8_t *cl = (uint8_t *)(val + 256);  // [S][SC]
+    double *vrow = vrow_all + (size_t)blockIdx.x * d.N * SR;
+    const int o = t / P, p = t % P;
+    const bool act = o < S;
+    const int oc = act ? o : S - 1;
+    const int i0 = p * QPT;
+    const double *f = d.f + rs_off(d, r, 0);
+    for (int k = t; k < S * SC; k += NT) { const int oo = k / SC, ii = k - oo * SC; cl[k] = (ii < S && d.TC > 0) ? codeT[(size_t)oo * S + ii] : (uint8_t)255; }
+    for (int i = t; i < 2 * SV; i += NT) V[i] = 0.;
+    for (int i = t; i < 256; i += NT) val[i] = valtab[i];
+    __syncthreads();
+    if (t < SR) { const double v0 = t < S ? f[t] : 0.; if (t < S) V[t] = v0; vrow[t] = v0; }
+    __syncthreads();
+    const unsigned *cw = (const unsigned *)(cl + (size_t)oc * SC + i0);
+    const int NW = QPT / 4;
+    if (d.N > 1) {
+        double fn; int tcv, bsv;
+        gload8(fn, f + (size_t)1 * d.SP + oc); gload4(tcv, d.tclass); gload4(bsv, d.brk_slot);
+        gwait_all(fn, tcv, bsv);
+        for (int n = 1; n < d.N; n++) {
+            const int cur = (n - 1) & 1, nxt = n & 1, tn = n - 1;
+            const int tc = __builtin_amdgcn_readfirstlane(tcv), bs = __builtin_amdgcn_readfirstlane(bsv);
+            const double fcur = fn;
+            {
+                const int nn = n + 1 < d.N ? n + 1 : n;
+                gload8(fn, f + (size_t)nn * d.SP + oc); gload4(tcv, d.tclass + (nn - 1)); gload4(bsv, d.brk_slot + (nn - 1));
+            }
+            double best = -INFINITY;
+            if (tc == 0 && bs < 0) {
+                if (act) {
+                    const double *Vc = V + cur * SV + i0;
+#pragma unroll 2
+                    for (int w = 0; w < NW; w++) {
+                        const unsigned c = cw[w];
+                        const double v0 = Vc[4 * w] + val[c & 255u], v1 = Vc[4 * w + 1] + val[(c >> 8) & 255u];
+                        const double v2 = Vc[4 * w + 2] + val[(c >> 16) & 255u], v3 = Vc[4 * w + 3] + val[c >> 24];
+                        best = fmax(fmax(best, v0), fmax(v1, fmax(v2, v3)));
+                    }
+                }
+            } else {
+                const double *pd = nullptr;
+                if (tc >= 0 && bs >= 0) {
+                    const double *pdg = d.pd_lt + ((size_t)r * d.NBE + bs) * M * D;
+                    for (int i = t; i < M * D; i += NT) pdl[i] = pdg[i];
+                    __syncthreads();
+                    pd = pdl;
+                }
+                if (act) for (int rr = 0; rr < QPT; rr++) {
+                    const int i = i0 + rr;
+                    if (i < S) {
+                        const double T = (tc < 0) ? 0. : trans_value(d, tn, i, o, pd);
+                        best = fmax(best, V[cur * SV + i] + T);
+                    }
+                }
+            }
+            for (int off = 1; off < P; off <<= 1) best = fmax(best, __shfl_xor(best, off, 64));
+            gwait_all(fn, tcv, bsv);
+            if (act && p == 0) {
+                const double vn = best + fcur;
+                V[nxt * SV + o] = vn;
+                gstore8(vrow + (size_t)n * SR + o, vn);
+            }
+            __syncthreads();
+        }
+    }
 }
 // trace-back: one workgroup per restart; chunks of back-pointer rows staged through LDS
 __global__ void k_backtrace(Dev d, const uint16_t *bp_all, const double *final_all, int64_t *path_all, double *logprob_all, int ROWS) {

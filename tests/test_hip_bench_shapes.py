@@ -166,7 +166,7 @@ def test_s165_generic_kernel_and_plain_breakend_tables_match_oracle(hip, oracle_
         _compare_after_every_update(dev, ora, sweeps=1)
 
 
-@pytest.mark.parametrize('options,fb', [({}, 4), ({'fb_nv': 4}, 4), ({'fb_nv': 1}, 4), ({'fb_kernel': 3, 'fb_nv': 2}, 3), ({'fb_kernel': 3, 'fb_nv': 1}, 3), ({'fb_kernel': 2}, 0), ({'viterbi_plain': 1}, 4),
+@pytest.mark.parametrize('options,fb', [({}, 4), ({'fb_nv': 4}, 4), ({'fb_nv': 1}, 4), ({'fb_kernel': 3, 'fb_nv': 2}, 3), ({'fb_kernel': 3, 'fb_nv': 1}, 3), ({'fb_kernel': 2}, 0), ({'viterbi_plain': 1}, 4), ({'viterbi_plain': 2}, 4),
                                         ({'pairwise_kernel': 2}, 4)])
 def test_s355_matches_oracle(hip, oracle_mod, options, fb):
     """355 states (max_cn = 12, the "~400 states" of BASELINE's metric): k_fbq (B operands looked up from 8-bit distances; four restarts per
@@ -495,7 +495,7 @@ def test_baseline_config1_shape_matches_oracle(hip, oracle_mod):
 
 # ---- state grids beyond the benchmark's (kernels generic in S <= 1024, M <= 4) ------------------------------------
 @pytest.mark.parametrize('M,max_cn,S,N,fb,vit', [
-    (4, 4, 207, 30, 3, 2),         # four clones with breakends above 176 states: k_fbk (round 4: the third tumour clone in a second packed word, clone-product tables of D^3 entries)
+    (4, 4, 207, 30, 3, 5),         # four clones with breakends above 176 states: k_fbk (round 4: the third tumour clone in a second packed word, clone-product tables of D^3 entries)
     (4, 6, 457, 28, 3, 3),
     (3, 13, 413, 30, 3, 3),        # three clones above 355 states: k_fbk (weights from packed copy numbers; blocks of 896 threads), the plain lattice
     (3, 14, 477, 26, 3, 3),        # ... of 1 024 threads: the largest grid k_fbk takes (max_cn 15: 544 states, 1 088 threads)
@@ -528,8 +528,10 @@ def test_kernel_selection_at_the_benchmark_grids(hip):
     from remixt_amd.restarts import RestartSet
     # (max_cn, fb_nv, fb_kernel) -> (forward-backward kernel, restarts per workgroup, lattice kernel); 4 restarts x 2 chains x 2 directions
     # leave room for one restart per workgroup, which is what the automatic choice takes at 165 states
-    want = {(8, None, 0): (1, 1, 1), (8, 4, 0): (1, 4, 1), (8, 2, 0): (1, 2, 1), (8, 2, 3): (2, 2, 1), (8, 1, 3): (2, 1, 1),
-            (12, None, 0): (4, 1, 2), (12, 4, 0): (4, 4, 2), (12, 2, 0): (4, 4, 2), (12, 2, 3): (3, 2, 2)}
+    # lattice kernel (rmx_info 14): 4 = k_viterbi_max (maxima forward, transition values in registers), 5 = k_viterbi_code_max (8-bit codes in LDS); the
+    # round-4 back-pointer forms 1 / 2 and the plain kernel 3 are reachable through option viterbi_plain = 2 / 1
+    want = {(8, None, 0): (1, 1, 4), (8, 4, 0): (1, 4, 4), (8, 2, 0): (1, 2, 4), (8, 2, 3): (2, 2, 4), (8, 1, 3): (2, 1, 4),
+            (12, None, 0): (4, 1, 5), (12, 4, 0): (4, 4, 5), (12, 2, 0): (4, 4, 5), (12, 2, 3): (3, 2, 5)}
     for (max_cn, nv, fk), (fb, nvx, vit) in want.items():
         e = synthetic.make_experiment(60, num_clones=3, max_copy_number=max_cn, num_chains=2, seed=3, num_breakpoints=4)
         rs = RestartSet(e, synthetic.make_init_params(e, 4, max_cn), max_cn, num_clones=3, quiet=True, options={'fb_nv': nv or 0, 'fb_kernel': fk})

@@ -153,11 +153,14 @@ def test_config3_per_gpu_share_and_the_whole_job_on_one_gpu(workload):
         pb = b.get_array(r, 'p_breakpoint')
         assert pb.min() >= 0. and np.allclose(pb.sum(axis=1), 1., rtol=0, atol=1e-12)
     cn_all, lp_all = b.infer_cn_batch(0, 16)
-    assert b.info(14) == 1                                   # k_viterbi_reg
+    assert b.info(14) == 4                                   # k_viterbi_max + k_backtrace_max (the reference's formulation: maxima forward, arg-maxima in the trace-back)
     b.set_option('viterbi_plain', 1)
     for r in (0, 7, 15):
         cn, lp = b.infer_cn(r)
-        assert np.array_equal(cn, cn_all[r]) and lp == lp_all[r]
+        assert b.info(14) == 3 and np.array_equal(cn, cn_all[r]) and lp == lp_all[r]
+    b.set_option('viterbi_plain', 2)                         # round 4's lattice with back-pointers, all restarts side by side
+    cn_bp, lp_bp = b.infer_cn_batch(0, 16)
+    assert b.info(14) == 1 and np.array_equal(cn_bp, cn_all) and np.array_equal(lp_bp, lp_all)
     b.set_option('viterbi_plain', 0)
     _release(rs)
 
@@ -226,11 +229,14 @@ def test_states355_bench_shape_em_iterations_with_msteps(workload355):
                 pb = b.get_array(r, 'p_breakpoint')
                 assert pb.min() >= 0. and np.allclose(pb.sum(axis=1), 1., rtol=0, atol=1e-12)
             cn_all, lp_all = b.infer_cn_batch(0, 8)
-            assert b.info(14) == 2                            # k_viterbi_code
+            assert b.info(14) == 5                            # k_viterbi_code_max + k_backtrace_max
             b.set_option('viterbi_plain', 1)
             for r in (0, 5):
                 cn, lp = b.infer_cn(r)
                 assert b.info(14) == 3 and np.array_equal(cn, cn_all[r]) and lp == lp_all[r]
+            b.set_option('viterbi_plain', 2)
+            cn_bp, lp_bp = b.infer_cn_batch(0, 8)
+            assert b.info(14) == 2 and np.array_equal(cn_bp, cn_all) and np.array_equal(lp_bp, lp_all)
             b.set_option('viterbi_plain', 0)
         _release(rs)
     for r in ids:

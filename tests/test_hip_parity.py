@@ -280,10 +280,40 @@ def test_decode_code_table_lattice_equals_plain_lattice(hip):
     assert b.num_cn_states == 355
     b.variational_update(2)
     cn, lp = b.infer_cn_batch(0, 2)
+    assert b.info(14) == 5                                                   # k_viterbi_code_max: maxima forward, arg-maxima in the trace-back
     b.set_option('viterbi_plain', 1)
     cn_plain, lp_plain = b.infer_cn_batch(0, 2)
     assert np.array_equal(cn, cn_plain) and np.array_equal(lp, lp_plain)
+    b.set_option('viterbi_plain', 2)                                         # round 4's code-table lattice with back-pointers
+    cn_bp, lp_bp = b.infer_cn_batch(0, 2)
+    assert b.info(14) == 2 and np.array_equal(cn, cn_bp) and np.array_equal(lp, lp_bp)
     assert len(np.unique(cn[0].reshape(len(cn[0]), -1), axis=0)) > 3        # a non-trivial path
+
+
+@pytest.mark.parametrize('max_cn,vit', [(4, 4), (8, 4), (12, 5)])
+def test_decode_with_exact_ties_everywhere_matches_oracle(hip, oracle_mod, max_cn, vit):
+    """Both likelihood masks off: a segment's frame log-probability is the subclonality prior alone (bpmodel.pyx:746-749, 898-919) -- the same
+    number for every state with the same count of subclonal alleles -- and the transition values are integer multiples of the penalty, so
+    the lattice is full of EXACT ties (the two sides compute identical doubles).  The reference breaks every one of them towards the lower
+    state index (_max / _argmax, bpmodel.pyx:21-75); the maxima-forward lattice with the arg-maxima recomputed in the trace-back (round 5),
+    round 4's back-pointer lattices and the plain kernel must all return the oracle's path, bit for bit."""
+    dev_m, h, e = H.make_model(hip, N=150, M=3, max_cn=max_cn, chains=3, seed=29)
+    ora_m, _, _ = H.make_model(oracle_mod, N=150, M=3, max_cn=max_cn, chains=3, seed=29, experiment=e)
+    dev, ora = H.attach(dev_m, h), H.attach(ora_m, h)
+    for mdl in (dev, ora):
+        mdl.total_likelihood_mask = np.zeros(mdl.num_segments, dtype=int)
+        mdl.allele_likelihood_mask = np.zeros(mdl.num_segments, dtype=int)
+    for _ in range(2):
+        dev_m.variational_update(); ora_m.variational_update()
+    assert np.array_equal(np.asarray(dev.framelogprob), np.asarray(ora.framelogprob))      # identical inputs: ties are ties on both sides
+    f = np.asarray(ora.framelogprob)
+    assert (np.array([len(np.unique(row)) for row in f]) <= 5).all()                        # one value per subclonal-allele count
+    want = np.zeros((ora.num_segments, 3, 2), dtype=np.int64); ora.infer_cn(want)
+    for opt, kern in ((0, vit), (2, 1 if vit == 4 else 2), (1, 3)):
+        dev._batch.set_option('viterbi_plain', opt)
+        got = np.zeros_like(want); dev.infer_cn(got)
+        assert dev._batch.info(14) == kern, (opt, dev._batch.info(14))
+        assert np.array_equal(got, want), ('viterbi_plain %d' % opt, int((got != want).any(axis=(1, 2)).sum()))
 
 
 def test_s165_matches_oracle(hip, oracle_mod):

@@ -6,6 +6,9 @@ import numpy as np
 from remixt_amd import synthetic
 from remixt_amd.restarts import RestartGroups
 mcn = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+if len(sys.argv) > 2:      # option viterbi_plain: 0 maxima forward + arg-maxima in the trace-back (default), 2 round 4's back-pointer lattices, 1 the plain kernel
+    from remixt_amd import bpmodel
+    bpmodel.set_default_option('viterbi_plain', int(sys.argv[2]))
 e = synthetic.make_experiment(50000, num_clones=3, max_copy_number=mcn, num_chains=23, seed=0)
 ps = synthetic.make_init_params(e, 16, mcn)
 rs = RestartGroups(e, ps, mcn, groups=2, num_clones=3, quiet=True, seeds=list(range(16)))
@@ -17,6 +20,14 @@ for rep in range(2):
     outs = rs._map(lambda s: s.batch.infer_cn_batch(0, len(s.models)))
     t1 = time.perf_counter()
     print('rep %d: batched lattice + backtrace + transfer, both groups side by side: %.1f ms (lattice kernel %d)' % (rep, (t1 - t0) * 1e3, rs.batches[0].info(14)))
+for b_ in rs.batches:
+    b_.profile_reset(); b_.profile_enable(1)
+rs._map(lambda s: s.batch.infer_cn_batch(0, len(s.models)))
+for k, (ms, n) in sorted(rs.profile().items()):
+    if 'viterbi' in k or 'backtrace' in k:
+        print('   %-14s %8.2f ms per launch of %d restarts (%d launches)' % (k, ms / max(n, 1), len(rs.sets[0].models), n))
+for b_ in rs.batches:
+    b_.profile_enable(0)
 pr = cProfile.Profile()
 t0 = time.perf_counter()
 pr.enable()
