@@ -169,6 +169,8 @@ enum rmx_option_id {
     RMX_OPT_GRAD_KERNEL,        /* h M-step rounds (objective + gradient on the samples): 0 (default) the lane chains laid out flat over the threads
                                    (k_gradflat_round; the same per-segment sums to the bit), 1 half a wave per sampled segment with the final sums
                                    folded in (round 4's form), 2 half a wave per segment and the final sums as a kernel of their own */
+    RMX_OPT_STREAM_POOL,        /* 1 (default): a batch's two streams come from a process-wide pool per device and return to it when the batch is destroyed
+                                   (streams are never destroyed: which hardware queue a role gets is decided once per process); 0: created and destroyed per batch */
     RMX_OPT_COUNT
 };
 int rmx_set_default_option(int32_t option_id, int32_t value);

@@ -46,8 +46,32 @@ static const char *kKernelNames[KID_COUNT] = {
 
 struct ProfRec { int id; hipEvent_t a, b; };
 
+// Process-wide pool of HIP streams per device and ROLE (0: a batch's main stream -- sweeps and M-step; 1: its second stream -- the breakend branch
+// of a sweep).  The runtime maps streams onto a handful of hardware queues when they are created (the least referenced queue), and streams that
+// share a queue run their kernels one after the other: with a stream pair created and destroyed per batch, WHICH streams of a later pair of
+// restart groups shared a queue depended on what earlier batches a Python program had dropped but not yet destroyed (two groups' forward-backward
+// launches serialised: 106-111 instead of 148 EM iterations/s at 355 states, profiles/r04_hw_queues.txt).  Pooled streams are created on demand,
+// handed back when their batch is destroyed and never destroyed themselves: a role's queue is decided once per process, and a batch built later
+// gets a stream with the placement the first ones got (profiles/r05_stream_pool.txt).
+struct StreamPool { std::mutex mu; std::vector<hipStream_t> idle[2]; int created[2] = {0, 0}; };
+static StreamPool g_stream_pool[16];
+static int pool_acquire(int dev, int role, hipStream_t *out) {
+    StreamPool &p = g_stream_pool[dev & 15];
+    std::lock_guard<std::mutex> lk(p.mu);
+    if (!p.idle[role].empty()) { *out = p.idle[role].front(); p.idle[role].erase(p.idle[role].begin()); return RMX_OK; }      // (the oldest first)
+    if (hipStreamCreateWithFlags(out, hipStreamNonBlocking) != hipSuccess) return RMX_EDEVICE;
+    p.created[role]++;
+    return RMX_OK;
+}
+static void pool_release(int dev, int role, hipStream_t s) {
+    hipStreamSynchronize(s);
+    StreamPool &p = g_stream_pool[dev & 15];
+    std::lock_guard<std::mutex> lk(p.mu);
+    p.idle[role].push_back(s);
+}
+
 // tuning options (include/remixt_amd.h rmx_option_id): process-wide defaults, copied into a batch at creation
-static int g_opt_default[RMX_OPT_COUNT] = {0, 0, 1, 1, 1, 0, 5, 0, 1, 1, 1, 0, 0, 0, 0, 0, 0};      // (search_mode 5 since round 5)
+static int g_opt_default[RMX_OPT_COUNT] = {0, 0, 1, 1, 1, 0, 5, 0, 1, 1, 1, 0, 0, 0, 0, 0, 0, 1};      // (search_mode 5 since round 5)
 static std::mutex g_opt_mu;
 
 struct rmx_batch {
@@ -57,7 +81,7 @@ struct rmx_batch {
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr;     // breakend branch of a sweep (pairwise reductions, p_breakpoint) next to the marginal pass
     hipEvent_t ev_fb = nullptr, ev_brk = nullptr;
-    bool own_stream = false;
+    bool own_stream = false, pooled_stream = false, pooled_stream2 = false;
     Dev d{};
     int R = 0;
     // host copies of the problem (for table rebuilds / decoding)
@@ -718,7 +742,7 @@ int rmx_set_default_option(int32_t id, int32_t value) {
 static void configure_fb(rmx_batch *b);
 int rmx_set_option(rmx_batch *b, int32_t id, int32_t value) {
     if (!b || id < 0 || id >= RMX_OPT_COUNT || !option_value_ok(id, value)) return fail(RMX_EARG, "bad option id / value");
-    if (id == RMX_OPT_CELL_CACHE || id == RMX_OPT_SPARSE_TRIAL || id == RMX_OPT_FB_DEBUG) return fail(RMX_EARG, "creation-time option: use rmx_set_default_option before rmx_batch_create");
+    if (id == RMX_OPT_CELL_CACHE || id == RMX_OPT_SPARSE_TRIAL || id == RMX_OPT_FB_DEBUG || id == RMX_OPT_STREAM_POOL) return fail(RMX_EARG, "creation-time option: use rmx_set_default_option before rmx_batch_create");
     BIND(b);      // configure_fb sets function attributes (the > 64 KiB LDS opt-in) on the calling thread's current device
     b->opt[id] = value;
     if (id == RMX_OPT_FB_KERNEL) configure_fb(b);
@@ -760,7 +784,8 @@ int rmx_batch_create(const rmx_problem *pr, int32_t R, const double *h_init, con
     { std::lock_guard<std::mutex> lk(g_opt_mu); memcpy(b->opt, g_opt_default, sizeof b->opt); }
     b->device = device; b->R = R;
     { int cus = 0; if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) b->num_cus = cus; }
-    HIPCHK(hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking));
+    if (b->opt[RMX_OPT_STREAM_POOL]) { if (pool_acquire(device, 0, &b->stream) != RMX_OK) { delete b; return fail(RMX_EDEVICE, "hipStreamCreate failed"); } b->pooled_stream = true; }
+    else HIPCHK(hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking));
     b->own_stream = true;
     Dev &d = b->d;
     d.N = N; d.S = S; d.SP = ((S + 7) / 8) * 8; d.M = M; d.K = K; d.B = B; d.C = C; d.nc = pr->normal_contamination ? 1 : 0;
@@ -1009,11 +1034,11 @@ int rmx_batch_destroy(rmx_batch *b) { BIND(b);
     if (b->tm_a) hipEventDestroy(b->tm_a);
     if (b->tm_b) hipEventDestroy(b->tm_b);
     for (auto e : b->done_ev) hipEventDestroy(e);
-    if (b->stream2) { hipStreamSynchronize(b->stream2); hipStreamDestroy(b->stream2); hipEventDestroy(b->ev_fb); hipEventDestroy(b->ev_brk); }
+    if (b->stream2) { hipStreamSynchronize(b->stream2); if (b->pooled_stream2) pool_release(b->device, 1, b->stream2); else hipStreamDestroy(b->stream2); hipEventDestroy(b->ev_fb); hipEventDestroy(b->ev_brk); }
     if (b->ev_copy) hipEventDestroy(b->ev_copy);
     if (b->ev_pace) hipEventDestroy(b->ev_pace);
     if (b->h_ind) { hipHostUnregister(b->h_ind); free(b->h_ind); }
-    if (b->own_stream && b->stream) hipStreamDestroy(b->stream);
+    if (b->own_stream && b->stream) { if (b->pooled_stream) pool_release(b->device, 0, b->stream); else hipStreamDestroy(b->stream); }
     delete b;
     return RMX_OK;
 }
@@ -1021,7 +1046,7 @@ int rmx_batch_destroy(rmx_batch *b) { BIND(b);
 int rmx_set_stream(rmx_batch *b, void *s) { BIND(b);
     if (!b) return fail(RMX_EARG, "null batch");
     HIPCHK(hipStreamSynchronize(b->stream));
-    if (b->own_stream) { hipStreamDestroy(b->stream); b->own_stream = false; }
+    if (b->own_stream) { if (b->pooled_stream) pool_release(b->device, 0, b->stream); else hipStreamDestroy(b->stream); b->own_stream = false; b->pooled_stream = false; }
     if (s) b->stream = (hipStream_t)s;
     else { HIPCHK(hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking)); b->own_stream = true; }
     return RMX_OK;
@@ -1035,6 +1060,8 @@ int rmx_info(rmx_batch *b, int32_t what, int64_t *out) { BIND(b);
     case 8: *out = b->fbG.BLK; break; case 9: *out = (int64_t)b->fbG_lds; break; case 10: *out = b->n_fast; break; case 11: *out = b->n_generic; break;
     case 60: *out = b->t_launch_ns; break; case 61: *out = b->t_wait_ns; break; case 62: *out = b->t_post_ns; break; case 63: *out = b->n_rounds; break;
     case 12: *out = b->last_fb_kernel; break; case 13: *out = b->last_fb_nv; break; case 14: *out = b->last_viterbi; break; case 15: *out = b->last_fb_nv_max; break;
+    case 16: { StreamPool &p_ = g_stream_pool[b->device & 15]; std::lock_guard<std::mutex> lk(p_.mu); *out = p_.created[0] + p_.created[1]; break; }      // streams the device's pool has created so far
+    case 17: { StreamPool &p_ = g_stream_pool[b->device & 15]; std::lock_guard<std::mutex> lk(p_.mu); *out = (int64_t)(p_.idle[0].size() + p_.idle[1].size()); break; }   // ... of them idle
     case 20: case 21: case 22: case 23: case 24: case 25: case 26: case 27: case 28: case 29: case 30: case 31: case 32: case 33: case 34: case 35: case 36: case 37: case 38: case 39:
     case 40: case 41: case 42: case 43: case 44: case 45: case 46: case 47: case 48: case 49: case 50: case 51:
         { if (!b->d_dbg) { *out = 0; break; } unsigned long long v[32]; HIPCHK(hipStreamSynchronize(b->stream)); HIPCHK(hipMemcpy(v, b->d_dbg, 256, hipMemcpyDeviceToHost)); *out = (int64_t)v[what - 20]; break; }
@@ -1582,7 +1609,8 @@ int rmx_variational_update(rmx_batch *b, int32_t r0, int32_t r1, int32_t iters) 
     // the breakend branch of a sweep (pairwise reductions, update_p_breakpoint) next to its marginal pass
     const bool two_streams = use_strip(b) && b->d.NBE > 0 && b->opt[RMX_OPT_TWO_STREAMS];
     if (two_streams && !b->stream2) {
-        HIPCHK(hipStreamCreateWithFlags(&b->stream2, hipStreamNonBlocking));
+        if (b->opt[RMX_OPT_STREAM_POOL]) { if (pool_acquire(b->device, 1, &b->stream2) != RMX_OK) return fail(RMX_EDEVICE, "hipStreamCreate failed"); b->pooled_stream2 = true; }
+        else HIPCHK(hipStreamCreateWithFlags(&b->stream2, hipStreamNonBlocking));
         HIPCHK(hipEventCreateWithFlags(&b->ev_fb, hipEventDisableTiming));
         HIPCHK(hipEventCreateWithFlags(&b->ev_brk, hipEventDisableTiming));
     }
