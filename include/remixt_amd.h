@@ -220,6 +220,11 @@ int rmx_variational_update(rmx_batch *b, int32_t r0, int32_t r1, int32_t iters);
 /* -- objectives ----------------------------------------------------------- */
 /* out: [r1-r0] */
 int rmx_calculate_elbo(rmx_batch *b, int32_t r0, int32_t r1, double *elbo_out);       /* :1119-1123 */
+/* calculate_elbo in two halves (round 5): _begin queues the ELBO of restarts [r0, r1) on the batch's stream -- kernels and the copy of the
+ * results -- and returns without waiting; _end waits for it and returns the values (and raises what rmx_calculate_elbo would have).  The
+ * batched EM driver queues the next iteration's sweeps in between: the value is only recorded (cn_model.py:420-428), nothing waits for it. */
+int rmx_calculate_elbo_begin(rmx_batch *b, int32_t r0, int32_t r1);
+int rmx_calculate_elbo_end(rmx_batch *b, double *elbo_out);
 int rmx_calculate_variational_energy(rmx_batch *b, int32_t r0, int32_t r1, double *out);  /* :1060-1117 */
 int rmx_calculate_variational_entropy(rmx_batch *b, int32_t r0, int32_t r1, double *out); /* :1044-1058 */
 /* sample: int64 [N] 0/1 mask as in the reference (:1125, :1159); partial_h_out may be

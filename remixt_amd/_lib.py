@@ -58,6 +58,8 @@ SYMBOLS = {
     "rmx_update_p_allele_swap": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32]),
     "rmx_variational_update": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32]),
     "rmx_calculate_elbo": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, _dp]),
+    "rmx_calculate_elbo_begin": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32]),
+    "rmx_calculate_elbo_end": (C.c_int, [C.c_void_p, _dp]),
     "rmx_calculate_variational_energy": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, _dp]),
     "rmx_calculate_variational_entropy": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, _dp]),
     "rmx_expected_log_likelihood": (C.c_int, [C.c_void_p, C.c_int32, _ip, _dp, _dp]),

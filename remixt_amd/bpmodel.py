@@ -321,6 +321,19 @@ class RemixtBatch(object):
     def calculate_elbo(self, r0=None, r1=None):
         return self._scalar_range(self._lib.rmx_calculate_elbo, r0, r1)
 
+    def calculate_elbo_begin(self, r0=None, r1=None):
+        """Queue the ELBO of restarts [r0, r1) without waiting (rmx_calculate_elbo_begin); calculate_elbo_end() returns the values."""
+        r0, r1 = self._range(r0, r1)
+        self._ck(self._lib.rmx_calculate_elbo_begin(self._handle, r0, r1))
+        self._elbo_pending = r1 - r0
+
+    def calculate_elbo_end(self):
+        n = getattr(self, '_elbo_pending', 0)
+        out = np.zeros(max(n, 1), dtype=np.float64)
+        self._elbo_pending = 0
+        self._ck(self._lib.rmx_calculate_elbo_end(self._handle, out.ctypes.data_as(_dp)))
+        return out[:n]
+
     def calculate_variational_energy(self, r0=None, r1=None):
         return self._scalar_range(self._lib.rmx_calculate_variational_energy, r0, r1)
 

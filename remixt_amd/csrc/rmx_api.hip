@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <cmath>
+#include <limits>
 #include <cstdio>
 #include <cstring>
 #include <map>
@@ -93,6 +94,7 @@ struct rmx_batch {
     // per-restart host state
     std::vector<RestartParams> rp;
     std::vector<char> tables_dirty, segc_dirty, ab_dirty;
+    std::vector<double> segc_built;      // [R][8] the dispersion parameters the per-segment constants on the device were built from
     std::vector<char> sig_valid;       // per restart: the lists of states with posterior mass belong to the current posterior
     std::vector<int> cache_stale;      // components of the cell cache that are not current (CM_* bits); 15 = nothing cached
     bool use_cache = false;
@@ -137,6 +139,7 @@ struct rmx_batch {
     std::vector<int32_t> plain_list; int32_t *d_plain_list = nullptr; double *d_plain_jt = nullptr;
     // viterbi
     int32_t *d_vit_special = nullptr; int n_vit_special = -1;      // adjacencies that are not plain class-0 ones, ascending (k_viterbi_max)
+    double *h_elbo = nullptr; hipEvent_t ev_elbo = nullptr; bool elbo_pending = false, elbo_sync = false; int elbo_r0 = 0, elbo_r1 = 0;      // rmx_calculate_elbo_begin / _end
     double *d_vrow = nullptr; size_t vrow_cap = 0;      // [nr][N][SR] lattice rows of k_viterbi_max / k_viterbi_code_max (pads 0)
     uint16_t *d_bp = nullptr; double *d_final = nullptr; int64_t *d_path = nullptr; double *d_logprob = nullptr;
     std::vector<int64_t> last_path; int vit_cap = 0; size_t bp_cap = 0;
@@ -568,9 +571,21 @@ static int ensure_tables(rmx_batch *b, int r0, int r1, bool need_segc = true) {
     if (need_segc) {
         int r = r0;
         while (r < r1) {
-            if (!b->segc_dirty[r]) { r++; continue; }
-            int e = r;
-            while (e < r1 && b->segc_dirty[e]) e++;
+            // the per-segment constants are functions of the eight dispersion parameters only (seg_const_value): a table rebuild for a new h, the h
+            // rounds and a rolled-back h leave them valid -- the flag says "maybe", the parameters they were last built from decide
+            auto stale = [&](int q) {
+                if (!b->segc_dirty[q]) return false;
+                static const int ids[8] = {RMX_P_NEGBIN_R_0, RMX_P_NEGBIN_HDEL_R_0, RMX_P_NEGBIN_R_1, RMX_P_NEGBIN_HDEL_R_1, RMX_P_BETABIN_M_0, RMX_P_BETABIN_LOH_M_0, RMX_P_BETABIN_M_1, RMX_P_BETABIN_LOH_M_1};
+                bool same = b->segc_built.size() == (size_t)b->R * 8;
+                for (int k = 0; same && k < 8; k++) same = memcmp(&b->segc_built[(size_t)q * 8 + k], &b->rp[q].p[ids[k]], 8) == 0;
+                if (same) { b->segc_dirty[q] = 0; return false; }
+                if (b->segc_built.size() != (size_t)b->R * 8) b->segc_built.assign((size_t)b->R * 8, std::numeric_limits<double>::quiet_NaN());
+                for (int k = 0; k < 8; k++) b->segc_built[(size_t)q * 8 + k] = b->rp[q].p[ids[k]];
+                return true;
+            };
+            if (!stale(r)) { r++; continue; }
+            int e = r + 1;
+            while (e < r1 && stale(e)) e++;
             { ProfScope ps(b, KID_SEG_CONST); hipLaunchKernelGGL(k_seg_const, dim3((b->d.N + 255) / 256, e - r), dim3(256), 0, b->stream, b->d, r); }
             for (int i = r; i < e; i++) b->segc_dirty[i] = 0;
             r = e;
@@ -1030,6 +1045,7 @@ int rmx_batch_destroy(rmx_batch *b) { BIND(b);
     if (b->h_err) hipHostFree(b->h_err);
     if (b->h_batch) hipHostFree(b->h_batch);
     if (b->gf_nblk_host) hipHostFree(b->gf_nblk_host);
+    if (b->h_elbo) { hipHostFree(b->h_elbo); hipEventDestroy(b->ev_elbo); }
     for (auto e : b->ev_pool) hipEventDestroy(e);
     if (b->tm_a) hipEventDestroy(b->tm_a);
     if (b->tm_b) hipEventDestroy(b->tm_b);
@@ -1753,6 +1769,60 @@ int rmx_calculate_elbo(rmx_batch *b, int32_t r0, int32_t r1, double *out) { BIND
     for (int i = 0; i < r1 - r0; i++) out[i] = o4[i * 4 + 2];
     return RMX_OK;
 }
+int rmx_calculate_elbo_begin(rmx_batch *b, int32_t r0, int32_t r1) { BIND(b);
+    RANGE_CHECK();
+    if (b->elbo_pending) return fail(RMX_EARG, "an ELBO is already pending: rmx_calculate_elbo_end first");
+    const int nr = r1 - r0;
+    if (!b->h_elbo) {
+        HIPCHK(hipHostMalloc((void **)&b->h_elbo, ((size_t)b->R * 4 + (size_t)b->R) * 8, hipHostMallocDefault));      // [R][4] results, then R error words
+        HIPCHK(hipEventCreateWithFlags(&b->ev_elbo, hipEventDisableTiming));
+    }
+    // the state in which the two transition snapshots belong to different models needs host-side sums between launches (elbo_parts): not deferred
+    bool mixed = false;
+    for (int r = r0; r < r1; r++) mixed |= b->lt_valid[r] && b->lt_model[r] != b->cached_model[r];
+    b->elbo_r0 = r0; b->elbo_r1 = r1; b->elbo_sync = mixed;
+    b->elbo_pending = true;
+    if (mixed) return RMX_OK;
+    int rc = ensure_ab(b, r0, r1);
+    if (rc) { b->elbo_pending = false; return rc; }
+    { ProfScope ps(b, KID_ELBO_SEG); hipLaunchKernelGGL(k_elbo_seg, dim3(ELBO_BLOCKS, nr), dim3(256), 0, b->stream, b->d, r0, b->d_partial, b->d_be_e); }
+    for (int r = r0; r < r1;) {
+        int e = r + 1;
+        while (e < r1 && b->plain_T_init[e] == b->plain_T_init[r]) e++;
+        ProfScope ps(b, KID_ELBO_FINAL);
+        hipLaunchKernelGGL(k_elbo_final, dim3(e - r), dim3(256), 0, b->stream, b->d, r, b->d_partial + (size_t)(r - r0) * ELBO_BLOCKS * 3,
+                           b->d_be_e + (size_t)(r - r0) * b->d.NBE, ELBO_BLOCKS,
+                           (const int *)b->d_lt_valid, b->plain_T_init[r], (const double *)nullptr, b->d_out4 + (size_t)(r - r0) * 4);
+        r = e;
+    }
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(b->h_elbo, b->d_out4, (size_t)nr * 32, hipMemcpyDeviceToHost, b->stream));
+    HIPCHK(hipMemcpyAsync(b->h_elbo + (size_t)b->R * 4, b->d.err, sizeof(uint32_t) * b->R, hipMemcpyDeviceToHost, b->stream));
+    HIPCHK(hipEventRecord(b->ev_elbo, b->stream));
+    return RMX_OK;
+}
+int rmx_calculate_elbo_end(rmx_batch *b, double *out) { BIND(b);
+    if (!b || !out) return fail(RMX_EARG, "bad argument");
+    if (!b->elbo_pending) return fail(RMX_EARG, "no ELBO pending");
+    b->elbo_pending = false;
+    const int r0 = b->elbo_r0, r1 = b->elbo_r1;
+    if (b->elbo_sync) return rmx_calculate_elbo(b, r0, r1, out);
+    HIPCHK(hipEventSynchronize(b->ev_elbo));
+    const uint32_t *e = reinterpret_cast<const uint32_t *>(b->h_elbo + (size_t)b->R * 4);
+    int first = -1;
+    for (int r = r0; r < r1; r++) if (e[r]) { if (first < 0) { first = r; g_err_restarts.clear(); } g_err_restarts.push_back(r); }
+    if (first >= 0) {
+        std::lock_guard<std::mutex> lk(b->mu);
+        HIPCHK(hipMemsetAsync(b->d.err + r0, 0, sizeof(uint32_t) * (size_t)(r1 - r0), b->stream));
+        return translate_error(b, first, e[first]);
+    }
+    for (int r = r0; r < r1; r++) {
+        const double *o = b->h_elbo + (size_t)(r - r0) * 4;
+        out[r - r0] = o[2];
+        // (logZ as of the ELBO's launch: valid only while no later update_p_cn has run -- the flag it would clear is left alone)
+    }
+    return RMX_OK;
+}
 int rmx_calculate_variational_energy(rmx_batch *b, int32_t r0, int32_t r1, double *out) { BIND(b);
     RANGE_CHECK();
     std::vector<double> o4((size_t)(r1 - r0) * 4);
@@ -2299,7 +2369,14 @@ int rmx_param_search_multi(rmx_batch *b, int32_t nreq, const int32_t *restarts, 
     // table rebuild of its first full evaluation)
     {
         std::lock_guard<std::mutex> lk(b->mu);
-        for (int i = 0; i < nreq; i++) if ((rc = ensure_tables(b, restarts[i], restarts[i] + 1, false))) return rc;
+        // (maximal runs of consecutive restarts in one call: ensure_tables batches up to 16 stale restarts per launch -- the request list of a restart
+        // group is its whole range, and eight one-restart launches were 0.8 ms of an M-step next to the other group's sweeps)
+        for (int i = 0; i < nreq;) {
+            int j = i + 1;
+            while (j < nreq && restarts[j] == restarts[j - 1] + 1) j++;
+            if ((rc = ensure_tables(b, restarts[i], restarts[j - 1] + 1, false))) return rc;
+            i = j;
+        }
     }
     // one round: requests cur[0..n) (indices q = j * nreq + i), their values vals[] (ignored in the grid stage)
     std::vector<double> out((size_t)Q * G);

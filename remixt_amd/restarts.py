@@ -110,9 +110,22 @@ class RestartSet(object):
                 for _ in range(iters):
                     m.variational_update()
 
-    def em_iteration(self, i=0, num_update_iter=5):
+    def _finish_pending_elbo(self):
+        """The ELBO a deferred em_iteration queued (calculate_elbo_begin): wait for it and record it (cn_model.py:420-428)."""
+        pending, self._elbo_pending_iter = getattr(self, '_elbo_pending_iter', None), None
+        if pending is None:
+            return None
+        elbo = self.batch.calculate_elbo_end()
+        for m, e in zip(self.models, elbo):
+            m.record_elbo(float(e), pending)
+        return elbo
+
+    def em_iteration(self, i=0, num_update_iter=5, defer_elbo=False):
         """cn_model.py:409-428 for every restart: batched variational sweeps, per-restart
-        scipy M-steps, batched ELBO."""
+        scipy M-steps, batched ELBO.  defer_elbo: the iteration's ELBO is only QUEUED on the device (nothing in the next iteration depends on
+        it: it is recorded, cn_model.py:420-428) and fetched behind the next iteration's sweeps -- or by _finish_pending_elbo(); the call then
+        returns None.  The half millisecond between the ELBO's last kernel and the next sweep's first (the wait, the host's bookkeeping) was
+        idle time of the restart group's stream in every EM iteration."""
         import time
         from . import lockstep as _ls
         t_ = [time.perf_counter()]
@@ -130,6 +143,7 @@ class RestartSet(object):
                 self._prep_pool = ThreadPoolExecutor(max_workers=1)
             self._h_prefetch = ([m.rng.get_state() for m in self.models], self._prep_pool.submit(self._samples_and_lists))
         self.variational_update(num_update_iter)
+        self._finish_pending_elbo()          # (the previous iteration's, if it was deferred: long finished behind these sweeps)
         t_.append(time.perf_counter())
 
         def mstep(r, with_h=True):
@@ -171,6 +185,12 @@ class RestartSet(object):
         if lockstep:
             self._update_params_lockstep()
         t_.append(time.perf_counter())
+        if defer_elbo and self.batch is not None and hasattr(self.batch, 'calculate_elbo_begin'):
+            self.batch.calculate_elbo_begin()
+            self._elbo_pending_iter = i
+            t_.append(time.perf_counter())
+            self.phase_times = t_
+            return None
         elbo = self.calculate_elbo()
         t_.append(time.perf_counter())
         self.phase_times = t_      # [start, after sweeps, after h M-step, after parameter M-steps, after ELBO]
@@ -576,6 +596,10 @@ class RestartSet(object):
 
     def close(self):
         """Destroy the device batch now (its memory, streams and events) instead of whenever the last reference goes."""
+        try:
+            self._finish_pending_elbo()
+        except Exception:
+            pass
         b, self.batch = self.batch, None
         for m in self.models:
             m.model = None
@@ -588,11 +612,13 @@ class RestartSet(object):
             if m.prev_elbo is None:
                 m.prev_elbo = float(e)
         for i in range(num_em_iter):
-            self.em_iteration(i, num_update_iter)
+            self.em_iteration(i, num_update_iter, defer_elbo=i + 1 < num_em_iter)      # (the last one waits for its ELBO)
+        self._finish_pending_elbo()
         return np.array([m.prev_elbo for m in self.models])
 
     def results(self):
         """Per-restart result dicts with the keys of analysis/pipeline.py:198-226."""
+        self._finish_pending_elbo()
         out = []
         cn_all = None
         if self.batch is not None and len(self.models) > 0:
@@ -708,7 +734,7 @@ class RestartGroups(object):
         def go(rs):
             elbo = None
             for i in range(num_em_iter):
-                elbo = rs.em_iteration(start + i, num_update_iter)
+                elbo = rs.em_iteration(start + i, num_update_iter, defer_elbo=i + 1 < num_em_iter)
             return np.asarray(elbo)
         return np.concatenate(self._map(go))
 
