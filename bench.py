@@ -525,7 +525,7 @@ def main(argv=None, kernel_module=None, dist_backend='nccl', script=None):
         dist.destroy_process_group()
 
 
-def roofline_object(dom, cells_per_launch, S, args, restarts_per_launch, traffic_file='traffic_r04.json'):
+def roofline_object(dom, cells_per_launch, S, args, restarts_per_launch, traffic_file='traffic_r05.json'):
     if dom[0] is None:
         return None
     name, (ms, n) = dom
@@ -598,7 +598,7 @@ def fit_from_init(args, rs_main, device):
     return out
 
 
-def one_group_roofline(args, rs_main, device, traffic_file='traffic_r04_16.json', nsteps=6):
+def one_group_roofline(args, rs_main, device, traffic_file='traffic_r05_16.json', nsteps=6):
     """The headline workload with ALL restarts of the GPU in one restart group: what the forward-backward kernel reaches when a
     launch carries 16 restarts instead of 8 (its duration is the latency of the chain of steps, not a function of the restart
     count), and what the step then costs (the M-steps are no longer hidden behind another group's sweeps)."""
@@ -764,13 +764,13 @@ def extra_states(args, rs_main, device):
            'value': R * nsteps / dt, 'unit': 'EM iterations/s', 'ms_per_step': dt / nsteps * 1e3, 'steps': nsteps, 'warmup': 2,
            'seg_state_cells_per_s': float(N1) * S * R * args.update_iters * nsteps / dt, 'elbo_best': float(np.nanmax(elbo)),
            'forward_backward_kernel': {1: 'k_fbm', 2: 'k_fbv', 3: 'k_fbk', 4: 'k_fbq', 0: 'k_fb<0>'}.get(rs.batches[0].info(12)),
-           'roofline': roofline_object(dom, float(N1) * S * R / G355, S, a355, R // G355, traffic_file='traffic_r04_s355_8.json'),
+           'roofline': roofline_object(dom, float(N1) * S * R / G355, S, a355, R // G355, traffic_file='traffic_r05_s355_8.json'),
            'kernels': dict((k, {'ms': round(v[0], 3), 'n': v[1]}) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])),
            'measured_in': 'child process (rc 0)'}
     _release(rs)
     # the forward-backward kernel at its other launch shape here too: all 16 restarts in one launch (one restart group)
     try:
-        out['roofline_one_group'] = one_group_roofline(a355, None, device, traffic_file='traffic_r04_s355.json', nsteps=3)
+        out['roofline_one_group'] = one_group_roofline(a355, None, device, traffic_file='traffic_r05_s355.json', nsteps=3)
     except Exception as err:
         out['roofline_one_group'] = _error_object(err)
     return out

@@ -667,7 +667,6 @@ class BreakpointModel(object):
         brk_states = np.asarray(m.brk_states)
         bidx = np.asarray(m.breakpoint_idx); borient = np.asarray(m.breakpoint_orient)
         log_breakpoint_p = np.zeros((m.num_breakpoints, m.num_brk_states))
-        tot = cn.sum(axis=-1)
         # the reference's loops over (n, clone, brk state): every entry of log_breakpoint_p accumulates
         # its terms in the same (n, clone) order here -- the j-th breakend (in n order) of all
         # breakpoints at once, clone by clone
@@ -681,8 +680,10 @@ class BreakpointModel(object):
             for j in range(int(rank.max()) + 1):
                 sel = rank == j
                 n_j = ns[sel]; k_j = ks[sel]
+                # (total copies at the breakend adjacencies only -- 2 % of the segments -- instead of a sum over the whole path)
+                tot_a = cn[n_j, :, 0] + cn[n_j, :, 1]; tot_b = cn[n_j + 1, :, 0] + cn[n_j + 1, :, 1]
                 for c in range(m.num_clones):
-                    d = tot[n_j, c] - tot[n_j + 1, c]
+                    d = tot_a[:, c] - tot_b[:, c]
                     log_breakpoint_p[k_j] += (-pen * np.abs(d[:, None] - borient[n_j][:, None] * brk_states[None, :, c]))
 
         brk_cn = dict()

@@ -621,10 +621,14 @@ class RestartSet(object):
         self._finish_pending_elbo()
         out = []
         cn_all = None
+        ind = None
         if self.batch is not None and len(self.models) > 0:
             cn_all, _ = self.batch.infer_cn_batch(0, len(self.models))     # all lattices side by side
+            if hasattr(self.batch, 'fetch_indicators'):
+                ind = self.batch.fetch_indicators()                        # the outlier indicators of all restarts in one transfer (views: copied below)
         for r, (m, p) in enumerate(zip(self.models, self.init_params)):
-            res = collect_fit_results(m, self.experiment, p, cn=None if cn_all is None else cn_all[r])
+            res = collect_fit_results(m, self.experiment, p, cn=None if cn_all is None else cn_all[r],
+                                      indicators=None if ind is None else (ind[0][r], ind[1][r]))
             res['stats']['error_message'] = self.error_messages.get(r, '')
             out.append(res)
         return out
@@ -832,9 +836,10 @@ class DatasetGroups(object):
         return out
 
 
-def collect_fit_results(model, experiment, init_params, cn=None):
+def collect_fit_results(model, experiment, init_params, cn=None, indicators=None):
     """fit_results of analysis/pipeline.py:196-226 from a fitted BreakpointModel (`cn`: its Viterbi
-    path if a batched decode already produced it)."""
+    path if a batched decode already produced it; `indicators`: its (p_outlier_total, p_outlier_allele) in model
+    segment order if a batched transfer already fetched them)."""
     from .cn_model import decode_breakpoints_naive
     cn, brk_cn = model.optimal_cn(cn) if cn is not None else model.optimal_cn()
     if model.disable_breakpoints:
@@ -843,8 +848,12 @@ def collect_fit_results(model, experiment, init_params, cn=None):
     res['h'] = np.array(model.h, dtype=float)       # a copy: a kernel model may hand out a view of its own buffer
     res['cn'] = cn
     res['brk_cn'] = brk_cn
-    res['p_outlier_total'] = np.array(model.p_outlier_total)
-    res['p_outlier_allele'] = np.array(model.p_outlier_allele)
+    if indicators is not None:
+        res['p_outlier_total'] = np.asarray(indicators[0])[model.seg_fwd_remap]          # (fancy indexing: a copy, as the properties return)
+        res['p_outlier_allele'] = np.asarray(indicators[1])[model.seg_fwd_remap]
+    else:
+        res['p_outlier_total'] = np.array(model.p_outlier_total)
+        res['p_outlier_allele'] = np.array(model.p_outlier_allele)
     res['total_likelihood_mask'] = np.array(model.total_likelihood_mask)
     res['allele_likelihood_mask'] = np.array(model.allele_likelihood_mask)
     stats = dict()

@@ -2,7 +2,7 @@
 # Everything under profiles/ for one round, on a GPU box: bash tools/collect_profiles.sh r04
 # (rocprofv3 gets the program itself after `--`; counters are collected in their own passes, without trace domains.)
 set -u
-TAG=${1:-r04}
+TAG=${1:-r05}
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out/profiles_$TAG
 mkdir -p "$OUT"
@@ -51,4 +51,10 @@ unset ITERS RST
 { echo "# OPTS=search_mode=5"; OPTS=search_mode=5 python3 $ROOT/tools/mstep_marks.py 2>&1 | grep -v amdgpu.ids; echo "# RST=8 NGROUPS=1 (RestartGroups picks search_mode 5 for a single group)"; RST=8 NGROUPS=1 python3 $ROOT/tools/mstep_marks.py 2>&1 | grep -v amdgpu.ids; } > $OUT/mstep_stage_times_search5.txt 2>&1
 REPS=6 python3 $ROOT/tools/s355_repeat.py 2>&1 | grep "^run" > $OUT/s355_repeat.txt
 rm -rf $OUT/prof_bench $OUT/prof_s355 $OUT/pmc_fetch_* $OUT/pmc_write_*
+# round 5: Gantt of one EM period, decode timing, repeated measurements in one process (stream pool), the 8-restart share's M-step stages
+rocprofv3 --kernel-trace -d $OUT/prof_g -o g --output-format csv -- python3 $ROOT/bench.py --steps 12 --warmup 4 --no-cpu-baseline --no-extra-states --no-fit-from-init > /dev/null 2>&1
+python3 $ROOT/tools/gantt.py $(find $OUT/prof_g -name "g_kernel_trace.csv" | head -1) 80 120 > $OUT/gantt.txt 2>&1
+rm -rf $OUT/prof_g
+{ python3 $ROOT/tools/decode_time.py 8; python3 $ROOT/tools/decode_time.py 8 2; python3 $ROOT/tools/decode_time.py 12; } 2>&1 | grep "rep \|k_viterbi\|k_backtrace\|results()\|collect_fit" > $OUT/decode_time.txt
+{ RST=8 python3 $ROOT/tools/mstep_marks.py; } 2>&1 | grep -v amdgpu.ids > $OUT/mstep_stage_times_share.txt
 ls -la $OUT

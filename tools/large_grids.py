@@ -6,7 +6,7 @@ import numpy as np
 from remixt_amd import synthetic
 from remixt_amd.restarts import RestartSet
 FB = {0: 'k_fb<0> (general, weights from L2)', 1: 'k_fbm', 2: 'k_fbv', 3: 'k_fbk', 4: 'k_fbq'}
-VIT = {1: 'k_viterbi_reg', 2: 'k_viterbi_code', 3: 'k_viterbi'}
+VIT = {1: 'k_viterbi_reg', 2: 'k_viterbi_code', 3: 'k_viterbi', 4: 'k_viterbi_max', 5: 'k_viterbi_code_max'}
 N, R = 20000, 4
 for M, max_cn in [(3, 8), (3, 10), (3, 12), (3, 13), (3, 14), (3, 16), (3, 20), (4, 3), (4, 4), (4, 6)]:
     e = synthetic.make_experiment(N, num_clones=M, max_copy_number=max_cn, num_chains=23, seed=0)

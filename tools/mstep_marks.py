@@ -24,9 +24,9 @@ rs.run(3, 0, 5)
 for s in rs.sets:
     s.marks = []
 orig = RestartSet.em_iteration
-def wrapped(self, i=0, n=5):
+def wrapped(self, i=0, n=5, **kw):
     self._mark('em:start')
-    out = orig(self, i, n)
+    out = orig(self, i, n, **kw)
     self._mark('em:end')
     return out
 RestartSet.em_iteration = wrapped

@@ -12,8 +12,8 @@ for m, v in zip(rs.models, rs.calculate_elbo()):
     m.prev_elbo = float(v)
 log = [[] for _ in rs.sets]
 orig = RestartSet.em_iteration
-def wrapped(self, i=0, n=5):
-    out = orig(self, i, n)
+def wrapped(self, i=0, n=5, **kw):
+    out = orig(self, i, n, **kw)
     log[rs.sets.index(self)].append([(self.phase_times[k + 1] - self.phase_times[k]) * 1e3 for k in range(4)])
     return out
 RestartSet.em_iteration = wrapped
