@@ -33,7 +33,9 @@ def _path_scores(model, paths, table):
     (table: cn_states [N][S][M][2])"""
     f = np.asarray(model.framelogprob)
     n1, S = f.shape
-    lt = np.zeros((n1 - 1, S, S)); model.calculate_log_transmat(lt)
+    # the lattice runs on the log_transmat SNAPSHOT of the last update_p_cn (bpmodel.pyx:939, 1201), not on calculate_log_transmat's matrix of the
+    # current p_breakpoint: at breakend adjacencies the two differ after update_p_breakpoint (found by fuzz seed 2041: 30 breakpoints on 90 segments)
+    lt = np.asarray(model.log_transmat)
     out = []
     for cn in paths:
         st = [int(np.nonzero((table[n] == cn[n][None]).all(axis=(1, 2)))[0][0]) for n in range(n1)]

@@ -74,7 +74,7 @@ def test_end_to_end_viterbi_agreement_rate_at_the_benchmark_grid(oracle_mod):
         st_d, st_o = _states(table, cn_dev[r]), _states(table, ref)
         for mdl in (dev.models[r].model, ora.models[r].model):
             f = np.asarray(mdl.framelogprob)
-            lt = np.zeros((n1 - 1, 165, 165)); mdl.calculate_log_transmat(lt)
+            lt = np.asarray(mdl.log_transmat)                 # the snapshot the lattice runs on (bpmodel.pyx:939, 1201), not the matrix of the current p_breakpoint
             whole = abs(_score(f, lt, st_o, 0, n1 - 1))
             for a, b in _runs(diff):
                 d, o = _score(f, lt, st_d, a, b), _score(f, lt, st_o, a, b)
