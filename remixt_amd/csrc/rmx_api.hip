@@ -2793,9 +2793,10 @@ static int viterbi_paths(rmx_batch *b, int r0, int nr, std::vector<int64_t> &pat
       } else if (coded) {
           const int NT = ((S * Pr + 63) / 64) * 64;
           if (maxima) {
-              HIPCHK(hipFuncSetAttribute((const void *)k_viterbi_code_max, hipFuncAttributeMaxDynamicSharedMemorySize, (int)code_lds));
-              hipLaunchKernelGGL(k_viterbi_code_max, dim3(nr), dim3(NT), code_lds, b->stream, b->d, r0, Pr, QPT4,
-                                 (const uint8_t *)b->d_vit_code, (const double *)b->d_vit_val, SR, b->d_vrow);
+              auto kfc = b->vit_mul_ok ? k_viterbi_code_max<true> : k_viterbi_code_max<false>;
+              HIPCHK(hipFuncSetAttribute((const void *)kfc, hipFuncAttributeMaxDynamicSharedMemorySize, (int)code_lds));
+              hipLaunchKernelGGL(kfc, dim3(nr), dim3(NT), code_lds, b->stream, b->d, r0, Pr, QPT4,
+                                 (const uint8_t *)b->d_vit_code, (const double *)b->d_vit_val, SR, b->d_vrow, b->vit_mul_ok ? -d.pen : 0.);
           } else {
               HIPCHK(hipFuncSetAttribute((const void *)k_viterbi_code, hipFuncAttributeMaxDynamicSharedMemorySize, (int)code_lds));
               hipLaunchKernelGGL(k_viterbi_code, dim3(nr), dim3(NT), code_lds, b->stream, b->d, r0, Pr, QPT4,

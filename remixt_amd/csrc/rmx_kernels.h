@@ -4587,8 +4587,11 @@ __global__ __launch_bounds__(768) void k_viterbi_code(Dev d, int r0, int P, int 
     if (t < S) final_all[(size_t)blockIdx.x * S + t] = V[((d.N - 1) & 1) * SV + t];
 }
 // k_viterbi_code with the reference's induction (maxima forward, the lattice rows to memory; see k_viterbi_max): 176 < S <= ~380
+// MUL: the transition value of a code is mulpen * code (verified by the host bit for bit against the table: then one conversion and one fused
+// multiply-add replace the second, bank-conflicted LDS lookup of every pair; pad codes 255 are paired with lattice pads of -inf)
+template <bool MUL>
 __global__ __launch_bounds__(768) void k_viterbi_code_max(Dev d, int r0, int P, int QPT /* multiple of 4 */, const uint8_t *codeT /* [S][S]: (o, i) */,
-                                                          const double *valtab /* [256] */, int SR, double *vrow_all) {
+                                                          const double *valtab /* [256] */, int SR, double *vrow_all, double mulpen) {
     extern __shared__ __align__(16) unsigned char smem_raw[];
     const int S = d.S, M = d.M, D = d.D, t = threadIdx.x, NT = blockDim.x, r = r0 + blockIdx.x;
     const int SV = P * QPT + 4;
@@ -4604,7 +4607,7 @@ __global__ __launch_bounds__(768) void k_viterbi_code_max(Dev d, int r0, int P, 
     const int i0 = p * QPT;
     const double *f = d.f + rs_off(d, r, 0);
     for (int k = t; k < S * SC; k += NT) { const int oo = k / SC, ii = k - oo * SC; cl[k] = (ii < S && d.TC > 0) ? codeT[(size_t)oo * S + ii] : (uint8_t)255; }
-    for (int i = t; i < 2 * SV; i += NT) V[i] = 0.;
+    for (int i = t; i < 2 * SV; i += NT) V[i] = MUL ? -INFINITY : 0.;
     for (int i = t; i < 256; i += NT) val[i] = valtab[i];
     __syncthreads();
     if (t < SR) { const double v0 = t < S ? f[t] : 0.; if (t < S) V[t] = v0; vrow[t] = v0; }
@@ -4630,8 +4633,19 @@ __global__ __launch_bounds__(768) void k_viterbi_code_max(Dev d, int r0, int P, 
 #pragma unroll 2
                     for (int w = 0; w < NW; w++) {
                         const unsigned c = cw[w];
-                        const double v0 = Vc[4 * w] + val[c & 255u], v1 = Vc[4 * w + 1] + val[(c >> 8) & 255u];
-                        const double v2 = Vc[4 * w + 2] + val[(c >> 16) & 255u], v3 = Vc[4 * w + 3] + val[c >> 24];
+                        double v0, v1, v2, v3;
+                        if (MUL) {
+                            // (mulpen * code is exact, so the fused multiply-add rounds once, like the reference's addition of the tabulated value; the
+                            //  code becomes a double through the 2^52 mantissa form: one full-rate subtraction instead of a quarter-rate conversion; a pad
+                            //  code stands next to a lattice pad of -inf)
+                            const double M52 = 4503599627370496.0;
+                            const double x0 = __hiloint2double(0x43300000, (int)(c & 255u)) - M52, x1 = __hiloint2double(0x43300000, (int)((c >> 8) & 255u)) - M52;
+                            const double x2 = __hiloint2double(0x43300000, (int)((c >> 16) & 255u)) - M52, x3 = __hiloint2double(0x43300000, (int)(c >> 24)) - M52;
+                            v0 = fma(mulpen, x0, Vc[4 * w]); v1 = fma(mulpen, x1, Vc[4 * w + 1]); v2 = fma(mulpen, x2, Vc[4 * w + 2]); v3 = fma(mulpen, x3, Vc[4 * w + 3]);
+                        } else {
+                            v0 = Vc[4 * w] + val[c & 255u]; v1 = Vc[4 * w + 1] + val[(c >> 8) & 255u];
+                            v2 = Vc[4 * w + 2] + val[(c >> 16) & 255u]; v3 = Vc[4 * w + 3] + val[c >> 24];
+                        }
                         best = fmax(fmax(best, v0), fmax(v1, fmax(v2, v3)));
                     }
                 }
