@@ -162,11 +162,12 @@ struct rmx_batch {
     // all device allocations (freed on destroy)
     std::vector<void *> allocs;
     // profiling
+    int fbk_kmax = 0;      // largest allele distance of a uniform class (k_fbq keeps 64 table entries, k_fbk FBK_WKN)
     bool fbk_ok = false;   // k_fbk usable: log-weights of every uniform class equal -pen * min(SAD, SAD swapped)
     std::vector<double> trial_comp; int trial_comp_r0 = -1, trial_comp_r1 = -1;   // component sums of the last rmx_expected_ll_full_trial's scratch expectations
     int scratch_r0 = -1, scratch_r1 = -1;   // restarts whose scratch expectations (d_A2, d_Bv2) the last trial pass wrote (-1: none)
     double *d_A2 = nullptr, *d_Bv2 = nullptr;   // [R][N][2], [R][N][4]: (A, B) of a trial parameter value (rmx_expected_ll_full_trial)
-    uint32_t *d_cnpack = nullptr, *d_totpack = nullptr, *d_cnpack2 = nullptr; double *d_wk = nullptr;   // [C][S], [C][S], [C][S] (third tumour clone), [TC][64]
+    uint32_t *d_cnpack = nullptr, *d_totpack = nullptr, *d_cnpack2 = nullptr; double *d_wk = nullptr;   // [C][S], [C][S], [C][S] (third tumour clone), [TC][FBK_WKN]
     int pe2p = 0;     // padded row length of pe2_lt (0: no product table)
     int spc = 0;      // row stride of the pair-code table
     bool pcode_ok = false;
@@ -387,7 +388,8 @@ static int build_transitions(rmx_batch *b) {
     // tumour clones per class, exp(-pen*k) per transition class, and the check that the closed form
     // -pen * min(SAD(cn_q, cn_o), SAD(cn_q, swap(cn_o))) reproduces the tabulated log-weights exactly
     b->fbk_ok = false;
-    if (TC > 0 && M >= 2 && M <= 4 && model == 0 && b->d.cn_max <= 15 && b->d_cnpack) {
+    b->fbk_kmax = 0;
+    if (TC > 0 && M >= 2 && M <= 4 && model == 0 && b->d.cn_max <= 30 && b->d_cnpack) {
         const int C = b->d.C;
         std::vector<uint32_t> cnp((size_t)C * S), ttp((size_t)C * S), cnp2((size_t)C * S, 0u);      // (cnp2: the third tumour clone's alleles, four clones only)
         for (int cls = 0; cls < C; cls++)
@@ -405,9 +407,10 @@ static int build_transitions(rmx_batch *b) {
         auto sad = [](uint32_t x, uint32_t y) { int r_ = 0; for (int i = 0; i < 4; i++) r_ += std::abs((int)((x >> (8 * i)) & 0xff) - (int)((y >> (8 * i)) & 0xff)); return r_; };
         auto swp = [](uint32_t x) { return ((x & 0x00ff00ffu) << 8) | ((x >> 8) & 0x00ff00ffu); };
         bool ok = true;
-        std::vector<double> wk((size_t)TC * 64, 0.);
+        std::vector<double> wk((size_t)TC * FBK_WKN, 0.);
+        int kmax = 0;
         for (int tc = 0; tc < TC && ok; tc++) {
-            for (int k = 0; k < 64; k++) wk[(size_t)tc * 64 + k] = std::exp(-pen * (double)k);
+            for (int k = 0; k < FBK_WKN; k++) wk[(size_t)tc * FBK_WKN + k] = std::exp(-pen * (double)k);
             const int ca = b->tc_pairs[tc].first, cb = b->tc_pairs[tc].second;
             if (ca != cb) continue;      // only chains of one class use the kernel
             for (int i = 0; i < S && ok; i++)
@@ -415,8 +418,9 @@ static int build_transitions(rmx_batch *b) {
                     const int k = std::min(sad(cnp[(size_t)ca * S + i], cnp[(size_t)cb * S + j]) + sad(cnp2[(size_t)ca * S + i], cnp2[(size_t)cb * S + j]),
                                            sad(cnp[(size_t)ca * S + i], swp(cnp[(size_t)cb * S + j])) + sad(cnp2[(size_t)ca * S + i], swp(cnp2[(size_t)cb * S + j])));
                     const int kt = sad(ttp[(size_t)ca * S + i], ttp[(size_t)cb * S + j]);
-                    if (k >= 64 || Tval[tc * SS + (size_t)i * S + j] != -pen * (double)k || (int)af[tc * SS + (size_t)i * S + j] != k - kt ||
-                        Wf[tc * SS + (size_t)i * S + j] != wk[(size_t)tc * 64 + k]) { ok = false; break; }
+                    if (k >= FBK_WKN || Tval[tc * SS + (size_t)i * S + j] != -pen * (double)k || (int)af[tc * SS + (size_t)i * S + j] != k - kt ||
+                        Wf[tc * SS + (size_t)i * S + j] != wk[(size_t)tc * FBK_WKN + k]) { ok = false; break; }
+                    kmax = std::max(kmax, k);
                 }
         }
         if (ok) {
@@ -424,7 +428,7 @@ static int build_transitions(rmx_batch *b) {
             HIPCHK(hipMemcpy(b->d_cnpack2, cnp2.data(), cnp2.size() * 4, hipMemcpyHostToDevice));
             HIPCHK(hipMemcpy(b->d_totpack, ttp.data(), ttp.size() * 4, hipMemcpyHostToDevice));
             HIPCHK(hipMemcpy(b->d_wk, wk.data(), wk.size() * 8, hipMemcpyHostToDevice));
-            b->fbk_ok = true;
+            b->fbk_ok = true; b->fbk_kmax = kmax;
         }
     }
     // Viterbi lattice for grids beyond the register-resident kernel: codes of the distinct values of class 0
@@ -924,23 +928,25 @@ int rmx_batch_create(const rmx_problem *pr, int32_t R, const double *h_init, con
     const size_t BEW = (size_t)R * d.NBE * M * d.D;
     DA(pd_lt, double, BEW) DA(pe_lt, double, (size_t)R * d.NBE * ((M * d.D + 1) & ~1) + 2)
     d.pe2_lt = nullptr; d.pe2x_lt = nullptr; b->pe2p = 0;
-    if (M >= 2 && M <= 3 && d.D <= 31 && d.NBE > 0) {
+    d.pcode = nullptr; d.jord = nullptr; d.jmeta = nullptr;
+    if (M >= 2 && M <= 3 && d.D <= 63 && d.NBE > 0) {
         int n2 = M == 2 ? d.D : d.D * d.D;
         b->pe2p = (n2 + 1) & ~1;
         DA(pe2_lt, double, (size_t)R * d.NBE * b->pe2p + 2)
-        DA(pe2x_lt, double, (size_t)((R + 3) / 4) * d.NBE * b->pe2p * 4 + 2)
-        HIPCHK(hipMemset(d.pe2x_lt, 0, ((size_t)((R + 3) / 4) * d.NBE * b->pe2p * 4 + 2) * 8));
-        b->spc = ((S + 63) / 64) * 64;
-        DA(pcode, uint16_t, (size_t)std::max(d.TC, 1) * ((S + 7) & ~7) * b->spc) DA(jord, int32_t, (size_t)C * S) DA(jmeta, int32_t, (size_t)C * S)
+        if (d.D <= 31) {      // (the matrix-core kernels' quad-interleaved copy and product codes: grids up to max_cn 14; above, k_fbk reads pe2_lt alone -- round 5)
+            DA(pe2x_lt, double, (size_t)((R + 3) / 4) * d.NBE * b->pe2p * 4 + 2)
+            HIPCHK(hipMemset(d.pe2x_lt, 0, ((size_t)((R + 3) / 4) * d.NBE * b->pe2p * 4 + 2) * 8));
+            b->spc = ((S + 63) / 64) * 64;
+            DA(pcode, uint16_t, (size_t)std::max(d.TC, 1) * ((S + 7) & ~7) * b->spc) DA(jord, int32_t, (size_t)C * S) DA(jmeta, int32_t, (size_t)C * S)
+        }
     } else {
-        d.pcode = nullptr; d.jord = nullptr; d.jmeta = nullptr;
-        if (M == 4 && d.D <= 15 && d.NBE > 0) {      // four clones: the clone-product table of a breakend has D^3 entries; k_fbk is its only reader (round 4)
+        if (M == 4 && d.D <= 21 && d.NBE > 0) {      // four clones: the clone-product table of a breakend has D^3 entries (max_cn 8: 6 859); k_fbk is its only reader (round 4)
             b->pe2p = (d.D * d.D * d.D + 1) & ~1;
             DA(pe2_lt, double, (size_t)R * d.NBE * b->pe2p + 2)
         }
     }
     if ((rc = dalloc(b, &b->d_A2, RN * 2)) || (rc = dalloc(b, &b->d_Bv2, RN * 4))) { rmx_batch_destroy(b); return rc; }
-    if ((rc = dalloc(b, &b->d_cnpack, (size_t)C * S)) || (rc = dalloc(b, &b->d_cnpack2, (size_t)C * S)) || (rc = dalloc(b, &b->d_totpack, (size_t)C * S)) || (rc = dalloc(b, &b->d_wk, (size_t)std::max(d.TC, 1) * 64))) { rmx_batch_destroy(b); return rc; }
+    if ((rc = dalloc(b, &b->d_cnpack, (size_t)C * S)) || (rc = dalloc(b, &b->d_cnpack2, (size_t)C * S)) || (rc = dalloc(b, &b->d_totpack, (size_t)C * S)) || (rc = dalloc(b, &b->d_wk, (size_t)std::max(d.TC, 1) * FBK_WKN))) { rmx_batch_destroy(b); return rc; }
     DA(pd_cached, double, BEW) DA(hist, double, BEW) DA(be_jt, double, (size_t)R * d.NBE) DA(be_ja, double, (size_t)R * d.NBE)
     DA(err, uint32_t, R)
 #undef DA
@@ -1482,7 +1488,7 @@ static int p_cn_front(rmx_batch *b, int r0, int r1, bool skip_frame, bool snapsh
                 done_fast = true; fast = true; b->last_fb_kernel = 2; b->last_fb_nv = b->last_fb_nv_max = NV;
             }
         }
-        if (!done_fast && b->fbv_rpt == 0 && b->fbk_ok && d.pe2x_lt && b->n_fast > 0 && b->opt[RMX_OPT_FB_KERNEL] == 0 && d.S <= 360) {
+        if (!done_fast && b->fbv_rpt == 0 && b->fbk_ok && b->fbk_kmax < 64 && d.pe2x_lt && b->n_fast > 0 && b->opt[RMX_OPT_FB_KERNEL] == 0 && d.S <= 360) {
             // state grid too large for register-resident weights, matrix cores: 8-bit distances in registers, B operands
             // looked up in a 64-entry LDS table (k_fbq); fb_kernel = 3 selects the vector kernel k_fbk below instead
             const int KB = d.S <= 256 ? 64 : 90;
@@ -1519,26 +1525,32 @@ static int p_cn_front(rmx_batch *b, int r0, int r1, bool skip_frame, bool snapsh
             memset(&v, 0, sizeof v);
             v.S = d.S; v.SP = d.SP; v.M = d.M; v.D = d.D; v.C = d.C; v.N = d.N; v.NBE = d.NBE; v.cn_max = d.cn_max;
             v.r0 = r0; v.r1 = r1; v.pen = d.pen;
-            v.G2 = (((d.S + 1) / 2 + 15) / 16) * 16; v.SPW = ((d.S + 63) / 64) * 64;
-            const int nch = (d.S + FBK_P * 16 - 1) / (FBK_P * 16);
-            v.SPAD = FBK_P * 16 * nch;
+            // (round 5: two row slices per column pair above 512 states -- blocks of PP * G2 <= 1 024 threads up to 1 024 states)
+            const int PP = d.S > 512 ? 2 : 4;
+            const int gq = 64 / PP;      // whole waves per block: PP * G2 a multiple of 64
+            v.G2 = (((d.S + 1) / 2 + gq - 1) / gq) * gq; v.SPW = ((d.S + 63) / 64) * 64;
+            const int nch = (d.S + PP * 16 - 1) / (PP * 16);
+            v.SPAD = PP * 16 * nch;
             v.PE2P = b->pe2p;
             v.chain_start = d.chain_start; v.chain_end = d.chain_end; v.tclass = d.tclass; v.brk_slot = d.brk_slot;
             v.chain_list = d.chain_list_fast; v.chain_tc = d.chain_tc; v.chain_cls = d.chain_cls; v.be_n = d.be_n; v.chain_be = d.chain_be; v.pe2_lt = d.pe2_lt;
             v.fe = d.fe; v.Wf = d.Wf; v.Wb = d.Wb; v.pe_lt = d.pe_lt; v.af = d.af; v.ab = d.ab; v.tot = d.tot;
             v.fa = d.fa; v.fb = d.fb; v.mrow = d.mrow; v.err = d.err; v.dbg = b->d_dbg;
-            int nt = ((FBK_P * v.G2 + v.SPW - 1) / v.SPW) * v.SPW;
+            int nt = ((PP * v.G2 + v.SPW - 1) / v.SPW) * v.SPW;
             const bool m4 = d.M == 4;
-            auto lds_of = [&](int nv_) { return ((size_t)nv_ * 2 * v.SPAD + (size_t)nv_ * FBK_P * d.SP + nv_ * 4 + (size_t)nv_ * b->pe2p + 64) * 8 + (size_t)(m4 ? 3 : 2) * v.SPAD * 4 + (size_t)b->be_cap * 4 + 64; };
-            // (four clones: a breakend's table is D^3 entries per vector -- 27 KB at max_cn 6 -- so fewer vectors per workgroup where four do not fit the LDS)
-            while (NV > 1 && lds_of(NV) > kLdsBudget && b->opt[RMX_OPT_FB_NV] == 0) NV /= 2;
-            const size_t lds = lds_of(NV);
+            auto lds_of = [&](int nv_) { return ((size_t)nv_ * 2 * v.SPAD + (size_t)nv_ * PP * d.SP + nv_ * 4 + (size_t)nv_ * b->pe2p + FBK_WKN) * 8 + (size_t)(m4 ? 3 : 2) * v.SPAD * 4 + (size_t)b->be_cap * 4 + 64; };
+            // (four clones: a breakend's table is D^3 entries per vector -- 27 KB at max_cn 6, 55 KB at 8 -- so fewer vectors per workgroup where four do not fit the LDS;
+            //  phase 2 publishes the vectors in at most two passes of nt / SPW each)
             const int vpp = nt / v.SPW;
+            while (NV > 1 && (lds_of(NV) > kLdsBudget || (NV + vpp - 1) / vpp > 2) && b->opt[RMX_OPT_FB_NV] == 0) NV /= 2;
+            const size_t lds = lds_of(NV);
             // (round 4, late: blocks of up to 1 024 threads -- the kernel needs 59 / 82 / 117 registers at 1 / 2 / 4 vectors -- take it from 360 to 512 states)
             if (nt <= 1024 && lds <= kLdsBudget && (NV + vpp - 1) / vpp <= 2) {
                 void (*kf)(FbvArgs, const double *, const uint32_t *, const uint32_t *, const uint32_t *) =
-                    m4 ? (nt <= 768 ? (NV == 1 ? k_fbk<1, 768, true> : (NV == 2 ? k_fbk<2, 768, true> : k_fbk<4, 768, true>)) : (NV == 1 ? k_fbk<1, 1024, true> : (NV == 2 ? k_fbk<2, 1024, true> : k_fbk<4, 1024, true>)))
-                       : (nt <= 768 ? (NV == 1 ? k_fbk<1, 768, false> : (NV == 2 ? k_fbk<2, 768, false> : k_fbk<4, 768, false>)) : (NV == 1 ? k_fbk<1, 1024, false> : (NV == 2 ? k_fbk<2, 1024, false> : k_fbk<4, 1024, false>)));
+                    PP == 2 ? (m4 ? (NV == 1 ? k_fbk<1, 1024, true, 2> : (NV == 2 ? k_fbk<2, 1024, true, 2> : k_fbk<4, 1024, true, 2>))
+                                  : (NV == 1 ? k_fbk<1, 1024, false, 2> : (NV == 2 ? k_fbk<2, 1024, false, 2> : k_fbk<4, 1024, false, 2>))) :
+                    m4 ? (nt <= 768 ? (NV == 1 ? k_fbk<1, 768, true, 4> : (NV == 2 ? k_fbk<2, 768, true, 4> : k_fbk<4, 768, true, 4>)) : (NV == 1 ? k_fbk<1, 1024, true, 4> : (NV == 2 ? k_fbk<2, 1024, true, 4> : k_fbk<4, 1024, true, 4>)))
+                       : (nt <= 768 ? (NV == 1 ? k_fbk<1, 768, false, 4> : (NV == 2 ? k_fbk<2, 768, false, 4> : k_fbk<4, 768, false, 4>)) : (NV == 1 ? k_fbk<1, 1024, false, 4> : (NV == 2 ? k_fbk<2, 1024, false, 4> : k_fbk<4, 1024, false, 4>)));
                 HIPCHK(hipFuncSetAttribute((const void *)kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
                 hipLaunchKernelGGL(kf, dim3(b->n_fast, (nr + NV - 1) / NV, 2), dim3(nt), lds, b->stream, v, (const double *)b->d_wk, (const uint32_t *)b->d_cnpack, (const uint32_t *)b->d_totpack, (const uint32_t *)b->d_cnpack2);
                 done_fast = true; fast = true; b->last_fb_kernel = 3; b->last_fb_nv = b->last_fb_nv_max = NV;

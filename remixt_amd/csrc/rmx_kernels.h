@@ -18,6 +18,7 @@
 #define SEGL 32
 #define SEG_PER_BLOCK (256 / SEGL)
 #define TRIAL_SEGL 16
+#define FBK_WKN 128      // entries of exp(-pen * k) per transition class (k = allele distance: < 64 up to max_cn 15, < 128 up to 31)
 #define NM_MAX_SAMPLE 1024      // sampled segments per request in the layouts of the flat M-step kernels (the reference samples min(200, N / 10))
 #define TRIAL_SEG_PER_BLOCK (256 / TRIAL_SEGL)
 
@@ -1432,7 +1433,7 @@ __device__ __forceinline__ void fbq_body(const FbmArgs &a, const double *wk, con
     }
     for (int i = t; i < 64; i += NT) wup[i] = exp(a.pen * (double)i);
     for (int i = t; i < 2 * VR * 4; i += NT) vec[i] = 0.;
-    for (int i = t; i < 64 * 32; i += NT) wtab[i] = wk[(size_t)a.chain_tc[chain] * 64 + (i >> 5)];
+    for (int i = t; i < 64 * 32; i += NT) wtab[i] = wk[(size_t)a.chain_tc[chain] * FBK_WKN + (i >> 5)];
     // ---- this lane's 8-bit distances: rows 4 kb + kq against its two columns, every k-block ---------------------
     // (rows past S multiply vector elements that are always 0, columns past S are never published: their codes only have to
     // be valid table indices; the ones columns' code is 0: weight exp(0) = 1)
@@ -1699,13 +1700,13 @@ __global__ __launch_bounds__(768) void k_fbq(FbmArgs a, const double *wk, const 
 // of the tumour clones' alleles packed one byte each -- two v_sad_u8 and a v_min per pair, then one
 // LDS lookup exp(-pen*k) (<= 64 entries).  M <= 3; the host verifies the identity against the
 // tabulated log-weights of the class before it selects this kernel.
-//   thread t (phase 1):  g = t % G2 (column pair), p = t / G2 (row slice, FBK_P slices of 16*NCH rows)
+//   thread t (phase 1):  g = t % G2 (column pair), p = t / G2 (row slice, PP slices of 16*NCH rows)
 //   thread t (phase 2):  vector t / SPW + pass * (NT / SPW), state t % SPW
 // =============================================================================
-#define FBK_P 4
 // M4 (round 4): four clones -- the third tumour clone's allele copies in a second packed word (cnpack2), its total in the third byte of totpack, the
 // clone-product table of a breakend D^3 entries (loaded by as many transfers per thread as it takes)
-template <int NV, int NTMAX, bool M4>
+// PP (round 5): row slices per column pair -- 4 up to 512 states (blocks of PP * G2 <= 1 024 threads), 2 from there to 1 024 states
+template <int NV, int NTMAX, bool M4, int PP>
 __global__ __launch_bounds__(NTMAX) void k_fbk(FbvArgs a, const double *wk, const uint32_t *cnpack, const uint32_t *totpack, const uint32_t *cnpack2) {
     extern __shared__ __align__(16) unsigned char smem_raw[];
     const int chain = a.chain_list[blockIdx.x], dir = blockIdx.z;
@@ -1716,22 +1717,22 @@ __global__ __launch_bounds__(NTMAX) void k_fbk(FbvArgs a, const double *wk, cons
     const int t = threadIdx.x, NT = blockDim.x;
     const int p = t / G2, g = t - p * G2;
     const int o0 = 2 * g, o1 = 2 * g + 1;
-    const bool act = p < FBK_P;
+    const bool act = p < PP;
     const int VPP = NT / SPW;                               // vectors published per pass of phase 2
     const int NPASS = (NV + VPP - 1) / VPP;
     const int pv0 = t / SPW, po = t - pv0 * SPW;
     const int lane = t & 63;
-    const int SPAD = a.SPAD;                                // = FBK_P * 16 * NCH (rows padded per slice)
-    const int NCH = SPAD / (FBK_P * 16);                    // 16-row chunks per slice
+    const int SPAD = a.SPAD;                                // = PP * 16 * NCH (rows padded per slice)
+    const int NCH = SPAD / (PP * 16);                    // 16-row chunks per slice
     const int cls = a.chain_cls[chain];
     // ---- LDS carve-up -----------------------------------------------------------------------
     double *vec = (double *)smem_raw;                           // [NV][2][SPAD]
-    double *part = vec + (size_t)NV * 2 * SPAD;                 // [NV][FBK_P][SP]
-    double *red = part + (size_t)NV * FBK_P * SP;               // [NV][4]
+    double *part = vec + (size_t)NV * 2 * SPAD;                 // [NV][PP][SP]
+    double *red = part + (size_t)NV * PP * SP;               // [NV][4]
     unsigned *red32 = (unsigned *)red;
     double *pel = red + NV * 4;                                 // [NV][PE2P]  clone-product weights of the current breakend
-    double *wtab = pel + (size_t)NV * a.PE2P;                   // [64] exp(-pen * k)
-    uint32_t *cnl = (uint32_t *)(wtab + 64);                    // [SPAD] packed allele copies of the row states (0 past S)
+    double *wtab = pel + (size_t)NV * a.PE2P;                   // [FBK_WKN] exp(-pen * k)
+    uint32_t *cnl = (uint32_t *)(wtab + FBK_WKN);                    // [SPAD] packed allele copies of the row states (0 past S)
     uint32_t *tpl = cnl + SPAD;                                 // [SPAD] packed totals
     uint32_t *cnl2 = tpl + SPAD;                                // [SPAD] (M4) packed allele copies of the third tumour clone
     int *bel = (int *)(cnl2 + (M4 ? SPAD : 0));                 // adjacencies of this chain's breakends
@@ -1739,7 +1740,7 @@ __global__ __launch_bounds__(NTMAX) void k_fbk(FbvArgs a, const double *wk, cons
     const int be_lo = a.chain_be[2 * chain], be_hi = a.chain_be[2 * chain + 1];
     for (int i = t; i < be_hi - be_lo; i += NT) bel[i] = a.be_n[be_lo + i];
     for (int i = t; i < NV * 2 * SPAD; i += NT) vec[i] = 0.;
-    for (int i = t; i < 64; i += NT) wtab[i] = wk[(size_t)a.chain_tc[chain] * 64 + i];
+    for (int i = t; i < FBK_WKN; i += NT) wtab[i] = wk[(size_t)a.chain_tc[chain] * FBK_WKN + i];
     if (t < NV * 4) red[t] = 0.;
     // this thread's two columns: allele copies as they are and with the alleles swapped, totals
     auto swap_alleles = [](uint32_t x) { return ((x & 0x00ff00ffu) << 8) | ((x >> 8) & 0x00ff00ffu); };
@@ -1854,7 +1855,7 @@ __global__ __launch_bounds__(NTMAX) void k_fbk(FbvArgs a, const double *wk, cons
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             FB_BARRIER();
         }
-        if (act) {      // wave-uniform: FBK_P * G2 is a multiple of 64
+        if (act) {      // wave-uniform: PP * G2 is a multiple of 64
             double wbe0[NV], wbe1[NV];
             for (int h = 0; h < NCH; h++) {
                 const int q0 = (p * NCH + h) * 16;
@@ -1868,7 +1869,7 @@ __global__ __launch_bounds__(NTMAX) void k_fbk(FbvArgs a, const double *wk, cons
 #pragma unroll
             for (int v = 0; v < NV; v++) {
                 double2 pr; pr.x = acc0[v]; pr.y = acc1[v];
-                *reinterpret_cast<double2 *>(part + ((size_t)v * FBK_P + p) * SP + o0) = pr;
+                *reinterpret_cast<double2 *>(part + ((size_t)v * PP + p) * SP + o0) = pr;
             }
         }
         FB_BARRIER();
@@ -1884,9 +1885,9 @@ __global__ __launch_bounds__(NTMAX) void k_fbk(FbvArgs a, const double *wk, cons
                 unsigned vmax_in = 0u;
                 if (pv < nv && po < S) {
                     const double inv = red[pv * 4];
-                    const double *pp_ = part + (size_t)pv * FBK_P * SP + po;
-                    const double s0 = pp_[0], s1 = pp_[SP], s2 = pp_[2 * SP], s3 = pp_[3 * SP];
-                    const double sum = ((s0 + s1) + s2) + s3;
+                    const double *pp_ = part + (size_t)pv * PP * SP + po;
+                    double sum = pp_[0] + pp_[SP];
+                    if (PP == 4) sum = (sum + pp_[2 * SP]) + pp_[3 * SP];
                     const double val = sum * inv;
                     const double vecv = val * e[ps];
                     vec[((size_t)pv * 2 + nb) * SPAD + po] = vecv;

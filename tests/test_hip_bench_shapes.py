@@ -501,8 +501,9 @@ def test_baseline_config1_shape_matches_oracle(hip, oracle_mod):
     (4, 6, 457, 28, 3, 3),
     (3, 13, 413, 30, 3, 3),        # three clones above 355 states: k_fbk (weights from packed copy numbers; blocks of 896 threads), the plain lattice
     (3, 14, 477, 26, 3, 3),        # ... of 1 024 threads: the largest grid k_fbk takes (max_cn 15: 544 states, 1 088 threads)
-    (3, 16, 617, 26, 0, 3),        # the general kernel k_fb<0> (weights from L2)
-    (3, 20, 951, 22, 0, 3),        # the largest three-clone grid below 1 024 states
+    (3, 16, 617, 26, 3, 3),        # above 512 states (round 5): k_fbk with two row slices per column pair (blocks of 640 threads); the general kernel k_fb<0> before
+    (3, 20, 951, 22, 3, 3),        # the largest three-clone grid below 1 024 states (960 threads; allele distances up to 80: 128 table entries)
+    (4, 8, 805, 20, 3, 3),         # four clones at max_cn 8 (clone-product tables of 19^3 entries, one vector per workgroup)
 ])
 def test_large_state_grids_match_oracle(hip, oracle_mod, M, max_cn, S, N, fb, vit):
     """every coordinate update of two sweeps and the decode against the oracle at the four-clone grids of
