@@ -126,7 +126,7 @@ int rmx_synchronize(rmx_batch *b);
  * forward-backward kernels / on the general one; 12 the forward-backward kernel the last update_p_cn launched for the
  * former (1 k_fbm: FP64 matrix cores at 4 restarts per workgroup, vector FMA at 2 / 1; 2 k_fbv: two-phase vector FMA, 3 k_fbk: weights from packed copy numbers, 4 k_fbq: matrix cores with
  * weights from 8-bit codes; 0: general kernel k_fb<0> only), 13 restarts per workgroup of that launch, 14 the lattice kernel of
- * the last decode (1 k_viterbi_reg, 2 k_viterbi_code, 3 k_viterbi); 15 the largest number of restarts per workgroup of that launch (13 is the
+ * the last decode (1 k_viterbi_reg, 2 k_viterbi_code, 3 k_viterbi, 4 k_viterbi_max, 5 k_viterbi_code_max, 6 k_viterbi_sad_max: above ~380 states); 18 workgroups per restart of that lattice; 15 the largest number of restarts per workgroup of that launch (13 is the
  * smallest: k_fbm gives long chains fewer restarts per workgroup than short ones) */
 int rmx_info(rmx_batch *b, int32_t what, int64_t *out);
 /* -- tuning options ------------------------------------------------------- */
@@ -144,7 +144,7 @@ enum rmx_option_id {
     RMX_OPT_FUSE_SWEEPS,        /* 1 (default): marginals + indicator updates + next frame pass as one kernel between sweeps */
     RMX_OPT_TWO_STREAMS,        /* 1 (default): breakend branch of a sweep on a second stream next to the marginal pass */
     RMX_OPT_VITERBI_PLAIN,      /* decode: 0 (default) the reference's own formulation -- maxima forward, the lattice rows kept, arg-maxima recomputed in the
-                                   trace-back (k_viterbi_max / k_viterbi_code_max + k_backtrace_max, round 5); 1 the table-reading lattice kernel with
+                                   trace-back (k_viterbi_max / k_viterbi_code_max + k_backtrace_max, k_viterbi_sad_max + k_backtrace_sad above ~380 states; round 5); 1 the table-reading lattice kernel with
                                    back-pointers (k_viterbi); 2 round 4's register / code-table lattices with back-pointers */
     RMX_OPT_SEARCH_MODE,        /* parameter searches: 5 (default since round 5) the four standard searches together in rounds the device drives: optimiser
                                    state on the device, a kernel pair per round, queued back to back (half the latency of the host-driven rounds);
@@ -171,6 +171,10 @@ enum rmx_option_id {
                                    folded in (round 4's form), 2 half a wave per segment and the final sums as a kernel of their own */
     RMX_OPT_STREAM_POOL,        /* 1 (default): a batch's two streams come from a process-wide pool per device and return to it when the batch is destroyed
                                    (streams are never destroyed: which hardware queue a role gets is decided once per process); 0: created and destroyed per batch */
+    RMX_OPT_VITERBI_CLUSTER,    /* lattice above 176 states (k_viterbi_sad_max, default transition model): 0 (default) 4 workgroups per restart up to 300 states, 8
+                                   above, each a share of the target states, the rows exchanged through memory step by step (halved while restarts x
+                                   workgroups > 64; one where the device already holds 192 such workgroups); 1 one workgroup per restart (up to ~380
+                                   states that is round 5's code-table lattice k_viterbi_code_max); 2 / 4 / 8 that many */
     RMX_OPT_COUNT
 };
 int rmx_set_default_option(int32_t option_id, int32_t value);

@@ -6,6 +6,7 @@
 #include <algorithm>
 #include <cmath>
 #include <limits>
+#include <atomic>
 #include <cstdio>
 #include <cstring>
 #include <map>
@@ -72,7 +73,7 @@ static void pool_release(int dev, int role, hipStream_t s) {
 }
 
 // tuning options (include/remixt_amd.h rmx_option_id): process-wide defaults, copied into a batch at creation
-static int g_opt_default[RMX_OPT_COUNT] = {0, 0, 1, 1, 1, 0, 5, 0, 1, 1, 1, 0, 0, 0, 0, 0, 0, 1};      // (search_mode 5 since round 5)
+static int g_opt_default[RMX_OPT_COUNT] = {0, 0, 1, 1, 1, 0, 5, 0, 1, 1, 1, 0, 0, 0, 0, 0, 0, 1, 0};      // (search_mode 5 since round 5)
 static std::mutex g_opt_mu;
 
 struct rmx_batch {
@@ -138,6 +139,7 @@ struct rmx_batch {
     void *h_batch = nullptr;           // pinned staging for the batched objective
     std::vector<int32_t> plain_list; int32_t *d_plain_list = nullptr; double *d_plain_jt = nullptr;
     // viterbi
+    int last_viterbi_wgs = 1;      // workgroups per restart of the last lattice (k_viterbi_sad_max<., true>: clusters)
     int32_t *d_vit_special = nullptr; int n_vit_special = -1;      // adjacencies that are not plain class-0 ones, ascending (k_viterbi_max)
     double *h_elbo = nullptr; hipEvent_t ev_elbo = nullptr; bool elbo_pending = false, elbo_sync = false; int elbo_r0 = 0, elbo_r1 = 0;      // rmx_calculate_elbo_begin / _end
     double *d_vrow = nullptr; size_t vrow_cap = 0;      // [nr][N][SR] lattice rows of k_viterbi_max / k_viterbi_code_max (pads 0)
@@ -748,6 +750,7 @@ static bool option_value_ok(int id, int v) {
     case RMX_OPT_PAIRWISE_KERNEL: return v >= 0 && v <= 4;
     case RMX_OPT_FB_WG_BUDGET: return v >= 0 && v <= 4096;
     case RMX_OPT_GRAD_KERNEL: return v >= 0 && v <= 2;
+    case RMX_OPT_VITERBI_CLUSTER: return v == 0 || v == 1 || v == 2 || v == 4 || v == 8;
     case RMX_OPT_VITERBI_PLAIN: return v >= 0 && v <= 2;
     default: return v == 0 || v == 1;
     }
@@ -1082,6 +1085,7 @@ int rmx_info(rmx_batch *b, int32_t what, int64_t *out) { BIND(b);
     case 8: *out = b->fbG.BLK; break; case 9: *out = (int64_t)b->fbG_lds; break; case 10: *out = b->n_fast; break; case 11: *out = b->n_generic; break;
     case 60: *out = b->t_launch_ns; break; case 61: *out = b->t_wait_ns; break; case 62: *out = b->t_post_ns; break; case 63: *out = b->n_rounds; break;
     case 12: *out = b->last_fb_kernel; break; case 13: *out = b->last_fb_nv; break; case 14: *out = b->last_viterbi; break; case 15: *out = b->last_fb_nv_max; break;
+    case 18: *out = b->last_viterbi_wgs; break;
     case 16: { StreamPool &p_ = g_stream_pool[b->device & 15]; std::lock_guard<std::mutex> lk(p_.mu); *out = p_.created[0] + p_.created[1]; break; }      // streams the device's pool has created so far
     case 17: { StreamPool &p_ = g_stream_pool[b->device & 15]; std::lock_guard<std::mutex> lk(p_.mu); *out = (int64_t)(p_.idle[0].size() + p_.idle[1].size()); break; }   // ... of them idle
     case 20: case 21: case 22: case 23: case 24: case 25: case 26: case 27: case 28: case 29: case 30: case 31: case 32: case 33: case 34: case 35: case 36: case 37: case 38: case 39:
@@ -1415,7 +1419,7 @@ static int p_cn_front(rmx_batch *b, int r0, int r1, bool skip_frame, bool snapsh
         // that many workgroups still fit the chip in one round -- a step of the vector form is shorter (fewer products per CU and step), and a
         // launch is a chain of dependent steps.  Needs the clone-product tables for breakend steps.  Option fb_nv = 1 / 2 / 4 pins the shape;
         // fb_kernel = 3 selects the two-phase vector kernel below instead.
-        if (b->fbv_rpt > 0 && b->n_fast > 0 && d.M <= 3 && (d.NBE == 0 || (d.pe2_lt != nullptr && b->max_adist < 64 && b->opt[RMX_OPT_FB_BREAKEND_CODES])) &&
+        if (b->fbv_rpt > 0 && b->n_fast > 0 && d.M <= 3 && (d.NBE == 0 || (d.pe2x_lt != nullptr && b->max_adist < 64 && b->opt[RMX_OPT_FB_BREAKEND_CODES])) &&
             b->opt[RMX_OPT_FB_KERNEL] != 3) {
             int KB = 0;
             for (int v : {8, 16, 28, 36, 42, 44}) if (4 * v >= d.S) { KB = v; break; }
@@ -1465,7 +1469,7 @@ static int p_cn_front(rmx_batch *b, int r0, int r1, bool skip_frame, bool snapsh
                 // breakend fast path: product tables + pair codes in LDS (the allele-distance matrix is then
                 // not needed there)
                 const size_t code_bytes = (size_t)FBV_P * rpt * d.SP * 2;
-                const bool want_code = d.pe2_lt != nullptr && d.M <= 3 && b->max_adist < 64 && (d.SP & 1) == 0 && b->opt[RMX_OPT_FB_BREAKEND_CODES];
+                const bool want_code = d.pe2_lt != nullptr && d.pcode != nullptr && d.M <= 3 && b->max_adist < 64 && (d.SP & 1) == 0 && b->opt[RMX_OPT_FB_BREAKEND_CODES];
                 size_t base_ = ((size_t)NV * 2 * v.SPAD + (size_t)NV * FBV_P * d.SP + NV * 4 + 128) * 8 +
                                (((size_t)d.C * d.S * d.M + 15) & ~(size_t)15) + 64 + (size_t)b->be_cap * 4;
                 size_t fixed;
@@ -2744,7 +2748,10 @@ static int viterbi_P(int S) { int P = 1; while (S * P * 2 <= 1024 && P < 64) P *
 static int viterbi_reg_P(int S) { int P = 1; while (S * P * 2 <= 768 && P < 64) P *= 2; return P; }
 
 // Viterbi paths of restarts r0 .. r0+nr-1: forward lattices side by side (one workgroup each), then the trace-backs
+static std::atomic<int> g_cluster_wgs[16];      // workgroups of lattice clusters (k_viterbi_sad_max<., true>) in flight per device
+struct ClusterHold { std::atomic<int> *c = nullptr; int n = 0; ~ClusterHold() { if (c && n) c->fetch_sub(n); } };
 static int viterbi_paths(rmx_batch *b, int r0, int nr, std::vector<int64_t> &paths, std::vector<double> &lps, int model) {
+    ClusterHold hold;      // (released when this call returns: it ends with a stream synchronisation)
     // the lattice runs on the log_transmat snapshot: plain tables of the transition model it was taken under
     const Dev dv = dev_for_model(b, model);
     const bool cur_model = model == b->d.tmodel;
@@ -2760,6 +2767,10 @@ static int viterbi_paths(rmx_batch *b, int r0, int nr, std::vector<int64_t> &pat
     const bool coded = !reg && cur_model && code_lds <= kLdsBudget && vopt != 1;
     const bool maxima = vopt == 0 && (reg || coded);
     const int SR = (S + 3) & ~3;
+    // grids whose codes do not fit the LDS (round 5): transition values of class 0 from the packed copies (k_fbk's closed form, verified at table build)
+    const int ca0 = b->tc_pairs.empty() ? 0 : b->tc_pairs[0].first, cb0 = b->tc_pairs.empty() ? 0 : b->tc_pairs[0].second;
+    const int vcl = b->opt[RMX_OPT_VITERBI_CLUSTER];
+    const bool sadmax = vopt == 0 && !reg && (!coded || vcl != 1) && cur_model && b->fbk_ok && !b->tc_pairs.empty() && ca0 == cb0 && S <= 1024;
     if (maxima && reg && b->n_vit_special < 0) {
         std::vector<int32_t> sp;
         for (int n = 0; n + 1 < N; n++) if (!(b->tclass[n] == 0 && b->brk_slot[n] < 0)) sp.push_back(n);
@@ -2771,7 +2782,6 @@ static int viterbi_paths(rmx_batch *b, int r0, int nr, std::vector<int64_t> &pat
     // (the list lives in the workgroup's LDS next to two lattice rows: a dataset with more special adjacencies than fit takes round 4's kernel)
     // breakend steps inside transition class 0 from LDS tables (totals, allele-flip bytes): the current model's tables only (d.ab has no per-model copy)
     const bool be_tab = cur_model && !b->tc_pairs.empty() && M <= 4;
-    const int ca0 = b->tc_pairs.empty() ? 0 : b->tc_pairs[0].first, cb0 = b->tc_pairs.empty() ? 0 : b->tc_pairs[0].second;
     const bool reg_max = maxima && reg && (size_t)(2 * (Pr * ((QPT + 1) & ~1) + 44) + M * d.D + 2) * 8 + (size_t)b->n_vit_special * 4 + (be_tab ? (size_t)S * 8 + (size_t)S * SR : 0) + 64 <= kLdsBudget;
     if (b->vit_cap < nr) {
         dfree(b, b->d_final); dfree(b, b->d_path); dfree(b, b->d_logprob);
@@ -2779,7 +2789,7 @@ static int viterbi_paths(rmx_batch *b, int r0, int nr, std::vector<int64_t> &pat
         if ((rc = dalloc(b, &b->d_final, (size_t)nr * S)) || (rc = dalloc(b, &b->d_path, (size_t)nr * N)) || (rc = dalloc(b, &b->d_logprob, nr))) return rc;
         b->vit_cap = nr;
     }
-    const bool lattice_rows = maxima && (reg_max || coded);      // rows of the lattice kept (trace-back recomputes the arg-maxima) instead of back-pointers
+    const bool lattice_rows = (maxima && (reg_max || coded)) || sadmax;      // rows of the lattice kept (trace-back recomputes the arg-maxima) instead of back-pointers
     if (lattice_rows && b->vrow_cap < (size_t)nr * N * SR) {
         dfree(b, b->d_vrow); b->d_vrow = nullptr; b->vrow_cap = 0;
         if ((rc = dalloc(b, &b->d_vrow, (size_t)nr * N * SR))) return rc;
@@ -2792,8 +2802,31 @@ static int viterbi_paths(rmx_batch *b, int r0, int nr, std::vector<int64_t> &pat
         b->bp_cap = (size_t)nr * N * S;
     }
     { ProfScope ps(b, KID_VITERBI);
-      b->last_viterbi = reg ? (reg_max ? 4 : 1) : (coded ? (maxima ? 5 : 2) : 3);
-      if (reg) {
+      b->last_viterbi = sadmax ? 6 : (reg ? (reg_max ? 4 : 1) : (coded ? (maxima ? 5 : 2) : 3));
+      b->last_viterbi_wgs = 1;
+      if (sadmax) {
+          // W workgroups per restart (each a share OW of the target states, the rows exchanged through memory step by step); all of them must be resident
+          // at once: at most 64 per launch (restart groups decode next to each other) and 192 per device
+          int W = 1;
+          if (vcl != 1) {
+              // (measured, profiles/r05_large_grids.txt: a step's exchange costs 2-3 us; 251 states are fastest with 4 workgroups, 355 and above with 8)
+              W = vcl >= 2 ? vcl : (S > 300 ? 8 : 4);
+              while (W > 1 && (long)nr * W > 64) W /= 2;
+              if (W > 1) {      // every cluster workgroup in flight on the device must be resident: a process-wide count, W = 1 when it would pass 192 of the 256 CUs
+                  const int want = nr * W, had = g_cluster_wgs[b->device & 15].fetch_add(want);
+                  if (had + want > 192) { g_cluster_wgs[b->device & 15].fetch_sub(want); W = 1; } else { hold.c = &g_cluster_wgs[b->device & 15]; hold.n = want; }
+              }
+          }
+          const int OW = W == 1 ? S : (((S + W - 1) / W + 63) / 64) * 64;
+          const int SO = ((OW + 63) / 64) * 64, P = std::max(1, 1024 / SO);
+          const int SQ = ((S + 4 * P - 1) / (4 * P)) * 4, SV = P * SQ;
+          const size_t lds_ = (size_t)(2 * SV + (P > 1 ? P * SO : 0) + ((M * d.D + 1) & ~1)) * 8 + (size_t)(M == 4 ? 2 : 1) * SV * 4 + 16;
+          auto kfs = W > 1 ? (M == 4 ? k_viterbi_sad_max<true, true> : k_viterbi_sad_max<false, true>) : (M == 4 ? k_viterbi_sad_max<true, false> : k_viterbi_sad_max<false, false>);
+          if (W > 1) HIPCHK(hipMemsetAsync(b->d_vrow, 0xff, (size_t)nr * N * SR * 8, b->stream));      // "not yet written" for the row exchange (k_viterbi_sad_max<., true>)
+          b->last_viterbi_wgs = W;
+          HIPCHK(hipFuncSetAttribute((const void *)kfs, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_));
+          hipLaunchKernelGGL(kfs, W > 1 ? dim3(W, nr) : dim3(nr), dim3(P * SO), lds_, b->stream, b->d, r0, P, SO, OW, SR, b->d_vrow, (const uint32_t *)b->d_cnpack, (const uint32_t *)b->d_cnpack2, -d.pen, ca0);
+      } else if (reg) {
           const int NT = ((S * Pr + 63) / 64) * 64;
 #define VREG(Q) { if (reg_max) { const size_t lds_ = (size_t)(2 * (Pr * ((QPT + 1) & ~1) + Q) + ((M * d.D + 1) & ~1)) * 8 + (size_t)b->n_vit_special * 4 + (be_tab ? (size_t)S * 8 + (size_t)S * SR : 0) + 16; \
                     HIPCHK(hipFuncSetAttribute((const void *)k_viterbi_max<Q>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_)); \
@@ -2818,7 +2851,19 @@ static int viterbi_paths(rmx_batch *b, int r0, int nr, std::vector<int64_t> &pat
           const int P = viterbi_P(S), NT = ((S * P + 63) / 64) * 64;
           hipLaunchKernelGGL(k_viterbi, dim3(nr), dim3(NT), (size_t)(2 * S + M * d.D) * 8, b->stream, dv, r0, P, b->d_bp, b->d_final);
       } }
-    if (lattice_rows) {
+    if (sadmax) {
+        const int NG = (SR + 255) / 256;
+        int rows = (int)((kLdsBudget - (size_t)2 * SR * 4 - 128) / ((size_t)SR * 8 + 4));
+        rows = std::max(2, std::min(rows, 96) & ~1);
+        const size_t lds = (size_t)rows * SR * 8 + (size_t)rows * 4 + (size_t)(M == 4 ? 2 : 1) * SR * 4 + 16;
+        void (*kf)(Dev, int, int, const double *, const uint32_t *, const uint32_t *, double, int, int64_t *, double *, int) =
+            M == 4 ? (NG <= 2 ? k_backtrace_sad<2, true> : (NG == 3 ? k_backtrace_sad<3, true> : k_backtrace_sad<4, true>))
+                   : (NG <= 2 ? k_backtrace_sad<2, false> : (NG == 3 ? k_backtrace_sad<3, false> : k_backtrace_sad<4, false>));
+        ProfScope ps(b, KID_BACKTRACE);
+        HIPCHK(hipFuncSetAttribute((const void *)kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(kf, dim3(nr), dim3(256), lds, b->stream, b->d, r0, SR, (const double *)b->d_vrow, (const uint32_t *)b->d_cnpack, (const uint32_t *)b->d_cnpack2,
+                           -d.pen, ca0, b->d_path, b->d_logprob, rows);
+    } else if (lattice_rows) {
         // the trace-back recomputes lattice[n, i] + log_transmat[n, i, state[n+1]] (bpmodel.pyx:1327-1331); class-0 plain adjacencies from the
         // code table of the CURRENT model (a snapshot of the other model goes through trans_value on the snapshot's tables)
         const bool tcode = cur_model && b->vit_code_ok;

@@ -4677,6 +4677,251 @@ __global__ __launch_bounds__(768) void k_viterbi_code_max(Dev d, int r0, int P, 
         }
     }
 }
+// ---- grids whose codes do not fit the LDS either (380 < S <= 1 024 states; round 5) ----------------------------------------------------
+// The transition value of a plain class-0 adjacency is -pen * k with k = min(SAD(cn_q, cn_o), SAD(cn_q, swap_alleles(cn_o))) over the
+// byte-packed allele copies of the tumour clones (k_fbk's closed form; the host has verified it against log_transmat's table bit for bit:
+// fbk_ok), so nothing S x S is kept: thread (o, p) holds its target state's packed copies in registers, the source states' copies and the
+// lattice row are wave-uniform LDS reads (128 bits: four states / two values), a pair is two v_sad_u8, a minimum, the 2^52 conversion, one
+// fused multiply-add (mulpen * k is exact: one rounding, as the reference's addition of the tabulated value) and v_max_f64.  Induction,
+// maxima, rows to memory, special steps as k_viterbi_code_max.  P slices of the source states per target (threads o + p * SO), merged
+// through LDS (a maximum: order-free).
+// dynamic LDS: 2 * SV doubles, P * SO doubles (P > 1), M * D doubles, (M4 ? 2 : 1) * SV words
+// CL: W workgroups per restart (grid (W, restarts)), each owning OW target states; a step ends with the exchange of the new row through memory --
+// every element stored and loaded as a relaxed agent-scope atomic (sc1: written through to / read at the level all XCDs share, no L2-wide write-back
+// or invalidate).  No flag and no counter: the host fills the rows with all-ones words before the launch, a consumer polls the element itself until
+// it is something else (8-byte stores land whole; a NaN result is stored as the canonical quiet NaN).  All W * restarts workgroups must be resident
+// together: the host keeps their number below the CU count.
+template <bool M4, bool CL>
+__global__ __launch_bounds__(1024) void k_viterbi_sad_max(Dev d, int r0, int P, int SO, int OW, int SR, double *vrow_all, const uint32_t *cnpack, const uint32_t *cnpack2,
+                                                          double mulpen, int cls0) {
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    const int S = d.S, M = d.M, D = d.D, t = threadIdx.x, NT = blockDim.x;
+    const int W = CL ? (int)gridDim.x : 1, wg = CL ? (int)blockIdx.x : 0, rb = CL ? (int)blockIdx.y : (int)blockIdx.x;
+    const int r = r0 + rb;
+    const int SQ = ((S + 4 * P - 1) / (4 * P)) * 4;   // source states per slice (a multiple of 4); SO: threads per slice (a multiple of 64, >= OW)
+    const int SV = P * SQ;
+    double *V = (double *)smem_raw;              // [2][SV]  (pads: -inf)
+    double *part = V + 2 * SV;                   // [P][SO]
+    double *pdl = part + (P > 1 ? P * SO : 0);   // [M*D]
+    uint32_t *cnl = (uint32_t *)(pdl + ((M * D + 1) & ~1));   // [SV]
+    uint32_t *cnl2 = cnl + SV;                   // [SV] (four clones: the third tumour clone)
+    double *vrow = vrow_all + (size_t)rb * d.N * SR;
+    const int p = t / SO, ol = t - p * SO;
+    const int o = wg * OW + ol;                  // this thread's target state
+    const bool act = p < P && ol < OW && o < S;
+    const int oc = act ? o : S - 1;
+    const int i0 = (p < P ? p : 0) * SQ;
+    const double *f = d.f + rs_off(d, r, 0);
+    auto swap_alleles = [](uint32_t x) { return ((x & 0x00ff00ffu) << 8) | ((x >> 8) & 0x00ff00ffu); };
+    for (int i = t; i < SV; i += NT) { cnl[i] = i < S ? cnpack[(size_t)cls0 * S + i] : 0u; if (M4) cnl2[i] = i < S ? cnpack2[(size_t)cls0 * S + i] : 0u; }
+    for (int i = t; i < 2 * SV; i += NT) V[i] = -INFINITY;
+    const uint32_t co = cnpack[(size_t)cls0 * S + oc], cos = swap_alleles(co);
+    const uint32_t cb = M4 ? cnpack2[(size_t)cls0 * S + oc] : 0u, cbs = swap_alleles(cb);
+    __syncthreads();
+    for (int i = t; i < SR; i += NT) { const double v0 = i < S ? f[i] : 0.; if (i < S) V[i] = v0; if (wg == 0) vrow[i] = v0; }      // (row 0 is every workgroup's own copy of f[0])
+    __syncthreads();
+    const int NW = SQ / 4;
+    const double M52 = 4503599627370496.0;
+    if (d.N > 1) {
+        double fn; int tcv, bsv;
+        gload8(fn, f + (size_t)1 * d.SP + oc); gload4(tcv, d.tclass); gload4(bsv, d.brk_slot);
+        gwait_all(fn, tcv, bsv);
+        for (int n = 1; n < d.N; n++) {
+            const int cur = (n - 1) & 1, nxt = n & 1, tn = n - 1;
+            const int tc = __builtin_amdgcn_readfirstlane(tcv), bs = __builtin_amdgcn_readfirstlane(bsv);
+            const double fcur = fn;
+            {
+                const int nn = n + 1 < d.N ? n + 1 : n;
+                gload8(fn, f + (size_t)nn * d.SP + oc); gload4(tcv, d.tclass + (nn - 1)); gload4(bsv, d.brk_slot + (nn - 1));
+            }
+            double best = -INFINITY;
+            if (tc == 0 && bs < 0) {
+                if (act) {
+                    const double *Vc = V + cur * SV + i0;
+                    const uint32_t *cq = cnl + i0, *cq2 = cnl2 + i0;
+#pragma unroll 2
+                    for (int w = 0; w < NW; w++) {
+                        const uint4 c4 = *reinterpret_cast<const uint4 *>(cq + 4 * w);
+                        uint4 e4 = make_uint4(0u, 0u, 0u, 0u);
+                        if (M4) e4 = *reinterpret_cast<const uint4 *>(cq2 + 4 * w);
+                        const double2 va = *reinterpret_cast<const double2 *>(Vc + 4 * w), vb = *reinterpret_cast<const double2 *>(Vc + 4 * w + 2);
+#define VS_K(c_, e_) min(__builtin_amdgcn_sad_u8(c_, co, M4 ? __builtin_amdgcn_sad_u8(e_, cb, 0u) : 0u), __builtin_amdgcn_sad_u8(c_, cos, M4 ? __builtin_amdgcn_sad_u8(e_, cbs, 0u) : 0u))
+                        const unsigned k0 = VS_K(c4.x, e4.x), k1 = VS_K(c4.y, e4.y), k2 = VS_K(c4.z, e4.z), k3 = VS_K(c4.w, e4.w);
+#undef VS_K
+                        const double x0 = __hiloint2double(0x43300000, (int)k0) - M52, x1 = __hiloint2double(0x43300000, (int)k1) - M52;
+                        const double x2 = __hiloint2double(0x43300000, (int)k2) - M52, x3 = __hiloint2double(0x43300000, (int)k3) - M52;
+                        const double v0 = fma(mulpen, x0, va.x), v1 = fma(mulpen, x1, va.y), v2 = fma(mulpen, x2, vb.x), v3 = fma(mulpen, x3, vb.y);
+                        best = fmax(fmax(best, v0), fmax(v1, fmax(v2, v3)));
+                    }
+                }
+            } else {
+                const double *pd = nullptr;
+                if (tc >= 0 && bs >= 0) {
+                    const double *pdg = d.pd_lt + ((size_t)r * d.NBE + bs) * M * D;
+                    for (int i = t; i < M * D; i += NT) pdl[i] = pdg[i];
+                    __syncthreads();
+                    pd = pdl;
+                }
+                if (act) for (int rr = 0; rr < SQ; rr++) {
+                    const int i = i0 + rr;
+                    if (i < S) {
+                        const double T = (tc < 0) ? 0. : trans_value(d, tn, i, o, pd);
+                        best = fmax(best, V[cur * SV + i] + T);
+                    }
+                }
+            }
+            if (P > 1) {
+                if (p < P) part[p * SO + ol] = best;
+                __syncthreads();
+                if (p == 0) for (int q = 1; q < P; q++) best = fmax(best, part[q * SO + ol]);
+            }
+            gwait_all(fn, tcv, bsv);
+            if (!CL) {
+                if (act && p == 0) {
+                    const double vn = best + fcur;
+                    V[nxt * SV + o] = vn;
+                    gstore8(vrow + (size_t)n * SR + o, vn);
+                }
+                __syncthreads();
+            } else {
+                if (act && p == 0) {
+                    double vn = best + fcur;
+                    if (vn != vn) vn = __longlong_as_double(0x7ff8000000000000ll);      // (never the all-ones word the fetch below waits on)
+                    __hip_atomic_store(vrow + (size_t)n * SR + o, vn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                // every thread fetches its share of the new row as the owners' stores arrive: the host filled the rows with all-ones words, which no stored
+                // value is, and an 8-byte store lands whole
+                for (int i = t; i < S; i += NT) {
+                    const unsigned long long *src = reinterpret_cast<const unsigned long long *>(vrow + (size_t)n * SR + i);
+                    unsigned long long u;
+                    while ((u = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == ~0ull) __builtin_amdgcn_s_sleep(1);
+                    V[nxt * SV + i] = __longlong_as_double((long long)u);
+                }
+                __syncthreads();
+            }
+        }
+    }
+}
+// Trace-back of k_viterbi_sad_max's lattice (k_backtrace_max's scheme: chunks of lattice rows through LDS, the chain on wave 0, first maximum by
+// wave maximum + ballot); lane l owns source states 256 g + 4 l .. + 3 of NG groups, a plain class-0 adjacency forms its transition values from
+// the packed copies (one dependent LDS read: the target state's word).
+// dynamic LDS: ROWS * SR doubles, ROWS ints, (M4 ? 2 : 1) * SR words
+template <int NG, bool M4>
+__global__ __launch_bounds__(256) void k_backtrace_sad(Dev d, int r0, int SR, const double *vrow_all, const uint32_t *cnpack, const uint32_t *cnpack2, double mulpen, int cls0,
+                                                        int64_t *path_all, double *logprob_all, int ROWS) {
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    __shared__ int cur_state;
+    const int S = d.S, M = d.M, D = d.D, t = threadIdx.x, NT = blockDim.x, r = r0 + blockIdx.x;
+    double *Vc = (double *)smem_raw;                  // [ROWS][SR]  (pads: -inf)
+    int *tcl = (int *)(Vc + (size_t)ROWS * SR);       // [ROWS]  1 = plain class-0 adjacency
+    uint32_t *cnl = (uint32_t *)(tcl + ROWS);         // [SR]
+    uint32_t *cnl2 = cnl + SR;                        // [SR] (M4)
+    const double *vrow = vrow_all + (size_t)blockIdx.x * d.N * SR;
+    int64_t *path = path_all + (size_t)blockIdx.x * d.N;
+    const int lane = t & 63;
+    const double NEG = -INFINITY, M52 = 4503599627370496.0;
+    auto swap_alleles = [](uint32_t x) { return ((x & 0x00ff00ffu) << 8) | ((x >> 8) & 0x00ff00ffu); };
+    for (int i = t; i < SR; i += NT) { cnl[i] = i < S ? cnpack[(size_t)cls0 * S + i] : 0u; if (M4) cnl2[i] = i < S ? cnpack2[(size_t)cls0 * S + i] : 0u; }
+    // this lane's source states' packed copies never change
+    uint32_t cq[NG][4], eq[NG][4];
+#pragma unroll
+    for (int g = 0; g < NG; g++)
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int i = 256 * g + 4 * lane + k;
+            cq[g][k] = i < S ? cnpack[(size_t)cls0 * S + i] : 0u; eq[g][k] = (M4 && i < S) ? cnpack2[(size_t)cls0 * S + i] : 0u;
+        }
+    // first maximum over the candidates a[g][k] (state 256 g + 4 lane + k): state index (wave-uniform) and the maximum
+#define BS_FIRST_MAX(a_, mx_, out_)                                                                                                \
+    {                                                                                                                              \
+        double bg_[NG]; int big_[NG];                                                                                              \
+        double m_ = -INFINITY;                                                                                                     \
+        _Pragma("unroll") for (int g = 0; g < NG; g++) {                                                                           \
+            double b_ = a_[g][0]; int bi_ = 256 * g + 4 * lane;                                                                    \
+            if (a_[g][1] > b_) { b_ = a_[g][1]; bi_ = 256 * g + 4 * lane + 1; }                                                    \
+            if (a_[g][2] > b_) { b_ = a_[g][2]; bi_ = 256 * g + 4 * lane + 2; }                                                    \
+            if (a_[g][3] > b_) { b_ = a_[g][3]; bi_ = 256 * g + 4 * lane + 3; }                                                    \
+            bg_[g] = b_; big_[g] = bi_;                                                                                            \
+            m_ = fmax(m_, wave_max_f64(b_));                                                                                       \
+        }                                                                                                                          \
+        mx_ = m_;                                                                                                                  \
+        bool found_ = false;                                                                                                       \
+        _Pragma("unroll") for (int g = 0; g < NG; g++) {                                                                           \
+            const unsigned long long kk_ = __ballot(bg_[g] == m_);                                                                 \
+            if (!found_ && kk_) { out_ = __builtin_amdgcn_readlane(big_[g], (int)__builtin_ctzll(kk_)); found_ = true; }           \
+        }                                                                                                                          \
+    }
+    if (t < 64) {
+        double a[NG][4];
+#pragma unroll
+        for (int g = 0; g < NG; g++)
+#pragma unroll
+            for (int k = 0; k < 4; k++) a[g][k] = (256 * g + 4 * lane + k < S) ? vrow[(size_t)(d.N - 1) * SR + 256 * g + 4 * lane + k] : NEG;
+        double mx; int bi = 0;
+        BS_FIRST_MAX(a, mx, bi)
+        if (t == 0) { cur_state = bi; path[d.N - 1] = bi; logprob_all[blockIdx.x] = mx; }
+    }
+    __syncthreads();
+    for (int hi = d.N - 2; hi >= 0; hi -= ROWS) {
+        const int lo = hi - ROWS + 1 > 0 ? hi - ROWS + 1 : 0;   // lattice rows lo .. hi, adjacencies lo .. hi
+        const int nrow = hi - lo + 1;
+        for (int i = t; i < nrow * SR; i += NT) { const int col = i % SR; Vc[i] = col < S ? vrow[(size_t)lo * SR + i] : NEG; }
+        for (int i = t; i < nrow; i += NT) tcl[i] = (d.tclass[lo + i] == 0 && d.brk_slot[lo + i] < 0) ? 1 : 0;
+        __syncthreads();
+        if (t < 64) {
+            int s = cur_state;
+            double2 va[NG], vb[NG];
+            int kind;
+#define BS_LOAD_ROW(n_)                                                                                                            \
+            {                                                                                                                      \
+                const double *Vn_ = Vc + (size_t)((n_) - lo) * SR + 4 * lane;                                                      \
+                _Pragma("unroll") for (int g = 0; g < NG; g++) {                                                                   \
+                    if (256 * g + 4 * lane < SR) { va[g] = *reinterpret_cast<const double2 *>(Vn_ + 256 * g); vb[g] = *reinterpret_cast<const double2 *>(Vn_ + 256 * g + 2); } \
+                    else { va[g] = make_double2(NEG, NEG); vb[g] = va[g]; }                                                        \
+                }                                                                                                                  \
+                kind = tcl[(n_) - lo];                                                                                             \
+            }
+            BS_LOAD_ROW(hi)
+            for (int n = hi; n >= lo; n--) {
+                double a[NG][4];
+#pragma unroll
+                for (int g = 0; g < NG; g++) { a[g][0] = va[g].x; a[g][1] = va[g].y; a[g][2] = vb[g].x; a[g][3] = vb[g].y; }
+                const int knd = __builtin_amdgcn_readfirstlane(kind);
+                if (n > lo) BS_LOAD_ROW(n - 1)
+                if (knd) {
+                    const uint32_t cs = cnl[s], css = swap_alleles(cs);
+                    const uint32_t es = M4 ? cnl2[s] : 0u, ess = swap_alleles(es);
+#pragma unroll
+                    for (int g = 0; g < NG; g++)
+#pragma unroll
+                        for (int k = 0; k < 4; k++) {
+                            const unsigned kk = min(__builtin_amdgcn_sad_u8(cq[g][k], cs, M4 ? __builtin_amdgcn_sad_u8(eq[g][k], es, 0u) : 0u),
+                                                    __builtin_amdgcn_sad_u8(cq[g][k], css, M4 ? __builtin_amdgcn_sad_u8(eq[g][k], ess, 0u) : 0u));
+                            a[g][k] = fma(mulpen, __hiloint2double(0x43300000, (int)kk) - M52, a[g][k]);
+                        }
+                } else {
+                    // telomere (log_transmat == 0), breakend or other-class adjacency: the plain expression
+                    const int tc = d.tclass[n], bs = d.brk_slot[n];
+                    const double *pd = (tc >= 0 && bs >= 0) ? d.pd_lt + ((size_t)r * d.NBE + bs) * M * D : nullptr;
+#pragma unroll
+                    for (int g = 0; g < NG; g++)
+#pragma unroll
+                        for (int k = 0; k < 4; k++) {
+                            const int i = 256 * g + 4 * lane + k;
+                            if (i < S) a[g][k] = a[g][k] + (tc < 0 ? 0. : trans_value(d, n, i, s, pd));
+                        }
+                }
+                double mx;
+                BS_FIRST_MAX(a, mx, s)
+                if (lane == 0) path[n] = s;
+            }
+            if (lane == 0) cur_state = s;
+#undef BS_LOAD_ROW
+        }
+        __syncthreads();
+    }
+#undef BS_FIRST_MAX
+}
 // trace-back: one workgroup per restart; chunks of back-pointer rows staged through LDS
 __global__ void k_backtrace(Dev d, const uint16_t *bp_all, const double *final_all, int64_t *path_all, double *logprob_all, int ROWS) {
     extern __shared__ __align__(16) unsigned char smem_raw[];

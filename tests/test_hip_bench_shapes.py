@@ -169,12 +169,12 @@ def test_s165_generic_kernel_and_plain_breakend_tables_match_oracle(hip, oracle_
 
 
 @pytest.mark.parametrize('options,fb', [({}, 4), ({'fb_nv': 4}, 4), ({'fb_nv': 1}, 4), ({'fb_kernel': 3, 'fb_nv': 2}, 3), ({'fb_kernel': 3, 'fb_nv': 1}, 3), ({'fb_kernel': 2}, 0), ({'viterbi_plain': 1}, 4), ({'viterbi_plain': 2}, 4),
-                                        ({'pairwise_kernel': 2}, 4)])
+                                        ({'pairwise_kernel': 2}, 4), ({'viterbi_cluster': 1}, 4), ({'viterbi_cluster': 4}, 4)])
 def test_s355_matches_oracle(hip, oracle_mod, options, fb):
     """355 states (max_cn = 12, the "~400 states" of BASELINE's metric): k_fbq (B operands looked up from 8-bit distances; four restarts per
     workgroup on the FP64 matrix cores -- a quad with two and with four restarts present -- and one per workgroup on the vector ALU
     (two per workgroup exist up to 256 states: test_grids_between_the_benchmark_grids_match_oracle)), k_fbk (two-phase vector FMA, weights rebuilt from packed copy numbers), the general kernel on tabulated weights,
-    k_viterbi_code and the plain lattice, each against the oracle -- not against each other."""
+    the lattice from the packed copies in clusters of 8 / 4 workgroups per restart (k_viterbi_sad_max), the code-table lattices and the plain one, each against the oracle -- not against each other."""
     from remixt_amd import synthetic
     R = 4 if options.get('fb_nv') == 4 else (3 if options.get('fb_nv') == 1 else 2)
     e = synthetic.make_experiment(44, num_clones=3, max_copy_number=12, num_chains=2, seed=41, num_breakpoints=8)
@@ -497,13 +497,13 @@ def test_baseline_config1_shape_matches_oracle(hip, oracle_mod):
 
 # ---- state grids beyond the benchmark's (kernels generic in S <= 1024, M <= 4) ------------------------------------
 @pytest.mark.parametrize('M,max_cn,S,N,fb,vit', [
-    (4, 4, 207, 30, 3, 5),         # four clones with breakends above 176 states: k_fbk (round 4: the third tumour clone in a second packed word, clone-product tables of D^3 entries)
-    (4, 6, 457, 28, 3, 3),
-    (3, 13, 413, 30, 3, 3),        # three clones above 355 states: k_fbk (weights from packed copy numbers; blocks of 896 threads), the plain lattice
-    (3, 14, 477, 26, 3, 3),        # ... of 1 024 threads: the largest grid k_fbk takes (max_cn 15: 544 states, 1 088 threads)
-    (3, 16, 617, 26, 3, 3),        # above 512 states (round 5): k_fbk with two row slices per column pair (blocks of 640 threads); the general kernel k_fb<0> before
-    (3, 20, 951, 22, 3, 3),        # the largest three-clone grid below 1 024 states (960 threads; allele distances up to 80: 128 table entries)
-    (4, 8, 805, 20, 3, 3),         # four clones at max_cn 8 (clone-product tables of 19^3 entries, one vector per workgroup)
+    (4, 4, 207, 30, 3, 6),         # four clones with breakends above 176 states: k_fbk (round 4: the third tumour clone in a second packed word, clone-product tables of D^3 entries)
+    (4, 6, 457, 28, 3, 6),
+    (3, 13, 413, 30, 3, 6),        # three clones above 355 states: k_fbk (weights from packed copy numbers; blocks of 896 threads); lattice from the packed copies (round 5; the plain lattice before)
+    (3, 14, 477, 26, 3, 6),        # ... of 1 024 threads: the largest grid with four row slices per column pair
+    (3, 16, 617, 26, 3, 6),        # above 512 states (round 5): k_fbk with two row slices per column pair (blocks of 640 threads); the general kernel k_fb<0> before
+    (3, 20, 951, 22, 3, 6),        # the largest three-clone grid below 1 024 states (960 threads; allele distances up to 80: 128 table entries)
+    (4, 8, 805, 20, 3, 6),         # four clones at max_cn 8 (clone-product tables of 19^3 entries, one vector per workgroup)
 ])
 def test_large_state_grids_match_oracle(hip, oracle_mod, M, max_cn, S, N, fb, vit):
     """every coordinate update of two sweeps and the decode against the oracle at the four-clone grids of
@@ -531,10 +531,10 @@ def test_kernel_selection_at_the_benchmark_grids(hip):
     from remixt_amd.restarts import RestartSet
     # (max_cn, fb_nv, fb_kernel) -> (forward-backward kernel, restarts per workgroup, lattice kernel); 4 restarts x 2 chains x 2 directions
     # leave room for one restart per workgroup, which is what the automatic choice takes at 165 states
-    # lattice kernel (rmx_info 14): 4 = k_viterbi_max (maxima forward, transition values in registers), 5 = k_viterbi_code_max (8-bit codes in LDS); the
+    # lattice kernel (rmx_info 14): 4 = k_viterbi_max (maxima forward, transition values in registers), 5 = k_viterbi_code_max (8-bit codes in LDS; option viterbi_cluster = 1), 6 = k_viterbi_sad_max (above 176 states: values from the packed copies, workgroup clusters); the
     # round-4 back-pointer forms 1 / 2 and the plain kernel 3 are reachable through option viterbi_plain = 2 / 1
     want = {(8, None, 0): (1, 1, 4), (8, 4, 0): (1, 4, 4), (8, 2, 0): (1, 2, 4), (8, 2, 3): (2, 2, 4), (8, 1, 3): (2, 1, 4),
-            (12, None, 0): (4, 1, 5), (12, 4, 0): (4, 4, 5), (12, 2, 0): (4, 4, 5), (12, 2, 3): (3, 2, 5)}
+            (12, None, 0): (4, 1, 6), (12, 4, 0): (4, 4, 6), (12, 2, 0): (4, 4, 6), (12, 2, 3): (3, 2, 6)}
     for (max_cn, nv, fk), (fb, nvx, vit) in want.items():
         e = synthetic.make_experiment(60, num_clones=3, max_copy_number=max_cn, num_chains=2, seed=3, num_breakpoints=4)
         rs = RestartSet(e, synthetic.make_init_params(e, 4, max_cn), max_cn, num_clones=3, quiet=True, options={'fb_nv': nv or 0, 'fb_kernel': fk})

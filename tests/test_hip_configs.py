@@ -229,7 +229,11 @@ def test_states355_bench_shape_em_iterations_with_msteps(workload355):
                 pb = b.get_array(r, 'p_breakpoint')
                 assert pb.min() >= 0. and np.allclose(pb.sum(axis=1), 1., rtol=0, atol=1e-12)
             cn_all, lp_all = b.infer_cn_batch(0, 8)
-            assert b.info(14) == 5                            # k_viterbi_code_max + k_backtrace_max
+            assert b.info(14) == 6 and b.info(18) == 8        # k_viterbi_sad_max, eight workgroups per restart (the rows exchanged through memory) + k_backtrace_sad
+            b.set_option('viterbi_cluster', 1)
+            cn_c, lp_c = b.infer_cn_batch(0, 8)
+            assert b.info(14) == 5 and np.array_equal(cn_c, cn_all) and np.array_equal(lp_c, lp_all)      # k_viterbi_code_max + k_backtrace_max (one workgroup per restart)
+            b.set_option('viterbi_cluster', 0)
             b.set_option('viterbi_plain', 1)
             for r in (0, 5):
                 cn, lp = b.infer_cn(r)

@@ -280,7 +280,12 @@ def test_decode_code_table_lattice_equals_plain_lattice(hip):
     assert b.num_cn_states == 355
     b.variational_update(2)
     cn, lp = b.infer_cn_batch(0, 2)
-    assert b.info(14) == 5                                                   # k_viterbi_code_max: maxima forward, arg-maxima in the trace-back
+    assert b.info(14) == 6 and b.info(18) == 8                               # k_viterbi_sad_max: transition values from the packed copies, eight workgroups per restart
+    for w in (1, 2, 4):                                                      # one workgroup per restart is k_viterbi_code_max (8-bit codes in LDS)
+        b.set_option('viterbi_cluster', w)
+        cn_w, lp_w = b.infer_cn_batch(0, 2)
+        assert b.info(14) == (5 if w == 1 else 6) and b.info(18) == w and np.array_equal(cn, cn_w) and np.array_equal(lp, lp_w), w
+    b.set_option('viterbi_cluster', 0)
     b.set_option('viterbi_plain', 1)
     cn_plain, lp_plain = b.infer_cn_batch(0, 2)
     assert np.array_equal(cn, cn_plain) and np.array_equal(lp, lp_plain)
@@ -290,7 +295,7 @@ def test_decode_code_table_lattice_equals_plain_lattice(hip):
     assert len(np.unique(cn[0].reshape(len(cn[0]), -1), axis=0)) > 3        # a non-trivial path
 
 
-@pytest.mark.parametrize('max_cn,vit', [(4, 4), (8, 4), (12, 5)])
+@pytest.mark.parametrize('max_cn,vit', [(4, 4), (8, 4), (12, 6)])
 def test_decode_with_exact_ties_everywhere_matches_oracle(hip, oracle_mod, max_cn, vit):
     """Both likelihood masks off: a segment's frame log-probability is the subclonality prior alone (bpmodel.pyx:746-749, 898-919) -- the same
     number for every state with the same count of subclonal alleles -- and the transition values are integer multiples of the penalty, so
@@ -314,6 +319,10 @@ def test_decode_with_exact_ties_everywhere_matches_oracle(hip, oracle_mod, max_c
         got = np.zeros_like(want); dev.infer_cn(got)
         assert dev._batch.info(14) == kern, (opt, dev._batch.info(14))
         assert np.array_equal(got, want), ('viterbi_plain %d' % opt, int((got != want).any(axis=(1, 2)).sum()))
+    if vit == 6:      # the code-table lattice (one workgroup per restart) as well
+        dev._batch.set_option('viterbi_plain', 0); dev._batch.set_option('viterbi_cluster', 1)
+        got = np.zeros_like(want); dev.infer_cn(got)
+        assert dev._batch.info(14) == 5 and np.array_equal(got, want)
 
 
 def test_s165_matches_oracle(hip, oracle_mod):

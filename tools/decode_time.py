@@ -1,5 +1,5 @@
 """Where the decode + result records of a fit go (bench `fit_from_init.decode_and_results_s`): the batched lattice kernels per restart group,
-then the host side of collect_fit_results, with cProfile's top entries.  Usage: python tools/decode_time.py [MAXCN]"""
+then the host side of collect_fit_results, with cProfile's top entries.  Usage: python tools/decode_time.py [MAXCN [VITERBI_PLAIN [option=value ...]]]"""
 import sys, os, time, cProfile, pstats, io
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -9,6 +9,9 @@ mcn = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 if len(sys.argv) > 2:      # option viterbi_plain: 0 maxima forward + arg-maxima in the trace-back (default), 2 round 4's back-pointer lattices, 1 the plain kernel
     from remixt_amd import bpmodel
     bpmodel.set_default_option('viterbi_plain', int(sys.argv[2]))
+for kv in sys.argv[3:]:      # further options as name=value (e.g. viterbi_cluster=4)
+    from remixt_amd import bpmodel
+    bpmodel.set_default_option(kv.split('=')[0], int(kv.split('=')[1]))
 e = synthetic.make_experiment(50000, num_clones=3, max_copy_number=mcn, num_chains=23, seed=0)
 ps = synthetic.make_init_params(e, 16, mcn)
 rs = RestartGroups(e, ps, mcn, groups=2, num_clones=3, quiet=True, seeds=list(range(16)))
