@@ -7,7 +7,8 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libremixt_hip.so")
+# (RMX_LIB_PATH: another build of the same library -- A/B measurements of two builds on one box, tools/ab_library.sh; never a fallback)
+LIB_PATH = os.environ.get("RMX_LIB_PATH") or os.path.join(HERE, "libremixt_hip.so")
 
 _dp = C.POINTER(C.c_double)
 _ip = C.POINTER(C.c_int64)

@@ -73,7 +73,7 @@ static void pool_release(int dev, int role, hipStream_t s) {
 }
 
 // tuning options (include/remixt_amd.h rmx_option_id): process-wide defaults, copied into a batch at creation
-static int g_opt_default[RMX_OPT_COUNT] = {0, 0, 1, 1, 1, 0, 5, 0, 1, 1, 1, 0, 0, 0, 0, 0, 0, 1, 0};      // (search_mode 5 since round 5)
+static int g_opt_default[RMX_OPT_COUNT] = {0, 0, 1, 1, 1, 0, 5, 0, 1, 1, 1, 0, 0, 0, 0, 0, 0, 1, 0, 0};      // (search_mode 5 since round 5)
 static std::mutex g_opt_mu;
 
 struct rmx_batch {
@@ -145,6 +145,7 @@ struct rmx_batch {
     double *d_vrow = nullptr; size_t vrow_cap = 0;      // [nr][N][SR] lattice rows of k_viterbi_max / k_viterbi_code_max (pads 0)
     uint16_t *d_bp = nullptr; double *d_final = nullptr; int64_t *d_path = nullptr; double *d_logprob = nullptr;
     std::vector<int64_t> last_path; int vit_cap = 0; size_t bp_cap = 0;
+    uint16_t *d_comp = nullptr; int32_t *d_ends = nullptr; size_t comp_cap = 0, ends_cap = 0; int last_traceback = 0;      // parallel trace-back: composed maps [nr][NBLK][S], block end states [nr][NBLK]
     uint8_t *d_vit_code = nullptr; double *d_vit_val = nullptr; bool vit_code_ok = false, vit_mul_ok = false;   // 8-bit codes of T(i, o) of class 0 + their values (k_viterbi_code)
     // FB launch configuration
     FbLaunch fbG{}; size_t fbG_lds = 0;   // generic kernel configuration
@@ -751,6 +752,7 @@ static bool option_value_ok(int id, int v) {
     case RMX_OPT_FB_WG_BUDGET: return v >= 0 && v <= 4096;
     case RMX_OPT_GRAD_KERNEL: return v >= 0 && v <= 2;
     case RMX_OPT_VITERBI_CLUSTER: return v == 0 || v == 1 || v == 2 || v == 4 || v == 8;
+    case RMX_OPT_TRACEBACK: return v == 0 || v == 1;
     case RMX_OPT_VITERBI_PLAIN: return v >= 0 && v <= 2;
     default: return v == 0 || v == 1;
     }
@@ -1085,7 +1087,7 @@ int rmx_info(rmx_batch *b, int32_t what, int64_t *out) { BIND(b);
     case 8: *out = b->fbG.BLK; break; case 9: *out = (int64_t)b->fbG_lds; break; case 10: *out = b->n_fast; break; case 11: *out = b->n_generic; break;
     case 60: *out = b->t_launch_ns; break; case 61: *out = b->t_wait_ns; break; case 62: *out = b->t_post_ns; break; case 63: *out = b->n_rounds; break;
     case 12: *out = b->last_fb_kernel; break; case 13: *out = b->last_fb_nv; break; case 14: *out = b->last_viterbi; break; case 15: *out = b->last_fb_nv_max; break;
-    case 18: *out = b->last_viterbi_wgs; break;
+    case 18: *out = b->last_viterbi_wgs; break; case 19: *out = b->last_traceback; break;
     case 16: { StreamPool &p_ = g_stream_pool[b->device & 15]; std::lock_guard<std::mutex> lk(p_.mu); *out = p_.created[0] + p_.created[1]; break; }      // streams the device's pool has created so far
     case 17: { StreamPool &p_ = g_stream_pool[b->device & 15]; std::lock_guard<std::mutex> lk(p_.mu); *out = (int64_t)(p_.idle[0].size() + p_.idle[1].size()); break; }   // ... of them idle
     case 20: case 21: case 22: case 23: case 24: case 25: case 26: case 27: case 28: case 29: case 30: case 31: case 32: case 33: case 34: case 35: case 36: case 37: case 38: case 39:
@@ -2796,7 +2798,9 @@ static int viterbi_paths(rmx_batch *b, int r0, int nr, std::vector<int64_t> &pat
         b->vrow_cap = (size_t)nr * N * SR;
         HIPCHK(hipMemsetAsync(b->d_vrow, 0, b->vrow_cap * 8, b->stream));      // (the pads of a row stay 0: code 255 = -inf makes them lose every comparison)
     }
-    if (!lattice_rows && b->bp_cap < (size_t)nr * N * S) {
+    // the trace-back in parallel (k_bp_all + k_chase_*): the lattice rows of this call, transition values of class 0 from the packed copies
+    const bool par_tb = lattice_rows && vopt == 0 && b->opt[RMX_OPT_TRACEBACK] == 0 && cur_model && b->fbk_ok && !b->tc_pairs.empty() && ca0 == cb0 && N >= 2 && S <= 1024;
+    if ((!lattice_rows || par_tb) && b->bp_cap < (size_t)nr * N * S) {
         dfree(b, b->d_bp); b->d_bp = nullptr; b->bp_cap = 0;
         if ((rc = dalloc(b, &b->d_bp, (size_t)nr * N * S))) return rc;
         b->bp_cap = (size_t)nr * N * S;
@@ -2851,7 +2855,26 @@ static int viterbi_paths(rmx_batch *b, int r0, int nr, std::vector<int64_t> &pat
           const int P = viterbi_P(S), NT = ((S * P + 63) / 64) * 64;
           hipLaunchKernelGGL(k_viterbi, dim3(nr), dim3(NT), (size_t)(2 * S + M * d.D) * 8, b->stream, dv, r0, P, b->d_bp, b->d_final);
       } }
-    if (sadmax) {
+    b->last_traceback = par_tb ? 1 : 0;
+    if (par_tb) {
+        const int SO = ((S + 63) / 64) * 64, P = std::max(1, 1024 / SO);
+        const int NB = P * (P >= 4 ? 2 : (P == 1 ? 8 : 4));
+        const int B = std::max(8, std::min(128, (96 * 1024) / (2 * S)));
+        const int NBLK = (N - 1 + B - 1) / B;
+        if (b->comp_cap < (size_t)nr * NBLK * S) { dfree(b, b->d_comp); b->d_comp = nullptr; b->comp_cap = 0; if ((rc = dalloc(b, &b->d_comp, (size_t)nr * NBLK * S))) return rc; b->comp_cap = (size_t)nr * NBLK * S; }
+        if (b->ends_cap < (size_t)nr * NBLK) { dfree(b, b->d_ends); b->d_ends = nullptr; b->ends_cap = 0; if ((rc = dalloc(b, &b->d_ends, (size_t)nr * NBLK))) return rc; b->ends_cap = (size_t)nr * NBLK; }
+        ProfScope ps(b, KID_BACKTRACE);
+        const size_t lds_a = (size_t)NB * SR * 8 + (size_t)(M == 4 ? 2 : 1) * SR * 4 + 16, lds_c = (size_t)B * S * 2 + 16;
+        auto ka = M == 4 ? k_bp_all<true> : k_bp_all<false>;
+        HIPCHK(hipFuncSetAttribute((const void *)ka, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_a));
+        hipLaunchKernelGGL(ka, dim3((N - 1 + NB - 1) / NB, nr), dim3(P * SO), lds_a, b->stream, b->d, r0, P, SO, NB, SR, (const double *)b->d_vrow,
+                           (const uint32_t *)b->d_cnpack, (const uint32_t *)b->d_cnpack2, -d.pen, ca0, b->d_bp);
+        HIPCHK(hipFuncSetAttribute((const void *)k_chase_compose, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_c));
+        HIPCHK(hipFuncSetAttribute((const void *)k_chase_fill, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_c));
+        hipLaunchKernelGGL(k_chase_compose, dim3(NBLK, nr), dim3(256), lds_c, b->stream, N, S, B, (const uint16_t *)b->d_bp, b->d_comp);
+        hipLaunchKernelGGL(k_chase_ends, dim3(nr), dim3(64), 0, b->stream, N, S, SR, NBLK, (const double *)b->d_vrow, (const uint16_t *)b->d_comp, b->d_ends, b->d_logprob);
+        hipLaunchKernelGGL(k_chase_fill, dim3(NBLK, nr), dim3(256), lds_c, b->stream, N, S, B, (const uint16_t *)b->d_bp, (const int32_t *)b->d_ends, b->d_path);
+    } else if (sadmax) {
         const int NG = (SR + 255) / 256;
         int rows = (int)((kLdsBudget - (size_t)2 * SR * 4 - 128) / ((size_t)SR * 8 + 4));
         rows = std::max(2, std::min(rows, 96) & ~1);

@@ -4922,6 +4922,121 @@ __global__ __launch_bounds__(256) void k_backtrace_sad(Dev d, int r0, int SR, co
     }
 #undef BS_FIRST_MAX
 }
+// ---- the trace-back in parallel (round 5, late) ------------------------------------------------------------------------------------
+// The reference walks N - 1 dependent steps, each the first maximum over i of lattice[n, i] + log_transmat[n, i, state[n + 1]]
+// (bpmodel.pyx:1327-1331); on one wave that is 0.6-1.3 us per step, a third of the decode.  The same arg-maxima for EVERY target state of
+// every row are independent of each other: k_bp_all computes them on the whole chip (the forward lattice's pair arithmetic once more --
+// -pen * k from the packed copies, one fused multiply-add -- with the first maximum kept: a strictly greater candidate replaces, within a
+// group of four the lowest equal one), then the walk itself is a composition of maps: k_chase_compose composes the B maps of a block of
+// rows for all S end states at once (LDS lookups, every block of every restart in parallel), k_chase_ends walks the N / B composed maps
+// from the final row's first maximum, k_chase_fill walks inside the blocks from their known end states.  Same path, bit for bit: the
+// candidates are the very doubles the sequential trace-back forms.
+// k_bp_all: grid (row blocks, restarts); thread (o, p): target state o, rows p, p + P, ... of the block (a wave has one p: its source-state
+// reads are broadcasts).  dynamic LDS: NB * SR doubles, (M4 ? 2 : 1) * SR words
+template <bool M4>
+__global__ __launch_bounds__(1024) void k_bp_all(Dev d, int r0, int P, int SO, int NB, int SR, const double *vrow_all, const uint32_t *cnpack, const uint32_t *cnpack2,
+                                                 double mulpen, int cls0, uint16_t *bp_all) {
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    const int S = d.S, M = d.M, D = d.D, t = threadIdx.x, NT = blockDim.x, rb = blockIdx.y, r = r0 + rb;
+    double *Vc = (double *)smem_raw;                       // [NB][SR]: lattice rows n0 - 1 .. (pads: -inf)
+    uint32_t *cnl = (uint32_t *)(Vc + (size_t)NB * SR);    // [SR]
+    uint32_t *cnl2 = cnl + SR;                             // [SR] (M4)
+    const double *vrow = vrow_all + (size_t)rb * d.N * SR;
+    uint16_t *bp = bp_all + (size_t)rb * d.N * S;
+    const int n0 = 1 + blockIdx.x * NB;                    // target rows n0 .. n0 + nrow - 1
+    const int nrow = min(NB, d.N - n0);
+    const double NEG = -INFINITY, M52 = 4503599627370496.0;
+    auto swap_alleles = [](uint32_t x) { return ((x & 0x00ff00ffu) << 8) | ((x >> 8) & 0x00ff00ffu); };
+    for (int i = t; i < nrow * SR; i += NT) { const int col = i % SR; Vc[i] = col < S ? vrow[(size_t)(n0 - 1) * SR + i] : NEG; }
+    for (int i = t; i < SR; i += NT) { cnl[i] = i < S ? cnpack[(size_t)cls0 * S + i] : 0u; if (M4) cnl2[i] = i < S ? cnpack2[(size_t)cls0 * S + i] : 0u; }
+    const int p = t / SO, o = t - p * SO;
+    const bool act = o < S;
+    const int oc = act ? o : S - 1;
+    const uint32_t co = cnpack[(size_t)cls0 * S + oc], cos = swap_alleles(co);
+    const uint32_t cb = M4 ? cnpack2[(size_t)cls0 * S + oc] : 0u, cbs = swap_alleles(cb);
+    __syncthreads();
+    const int NW = SR / 4;
+    for (int rr = p; rr < nrow; rr += P) {                 // (wave-uniform: SO is a multiple of 64)
+        const int n = n0 + rr, tn = n - 1;
+        const int tc = d.tclass[tn], bs = d.brk_slot[tn];
+        if (!act) continue;
+        const double *Vr = Vc + (size_t)rr * SR;
+        double best = NEG; int bi = 0;
+        if (tc == 0 && bs < 0) {
+#pragma unroll 2
+            for (int w = 0; w < NW; w++) {
+                const uint4 c4 = *reinterpret_cast<const uint4 *>(cnl + 4 * w);
+                uint4 e4 = make_uint4(0u, 0u, 0u, 0u);
+                if (M4) e4 = *reinterpret_cast<const uint4 *>(cnl2 + 4 * w);
+                const double2 va = *reinterpret_cast<const double2 *>(Vr + 4 * w), vb = *reinterpret_cast<const double2 *>(Vr + 4 * w + 2);
+#define VS_K(c_, e_) min(__builtin_amdgcn_sad_u8(c_, co, M4 ? __builtin_amdgcn_sad_u8(e_, cb, 0u) : 0u), __builtin_amdgcn_sad_u8(c_, cos, M4 ? __builtin_amdgcn_sad_u8(e_, cbs, 0u) : 0u))
+                const unsigned k0 = VS_K(c4.x, e4.x), k1 = VS_K(c4.y, e4.y), k2 = VS_K(c4.z, e4.z), k3 = VS_K(c4.w, e4.w);
+#undef VS_K
+                const double v0 = fma(mulpen, __hiloint2double(0x43300000, (int)k0) - M52, va.x), v1 = fma(mulpen, __hiloint2double(0x43300000, (int)k1) - M52, va.y);
+                const double v2 = fma(mulpen, __hiloint2double(0x43300000, (int)k2) - M52, vb.x), v3 = fma(mulpen, __hiloint2double(0x43300000, (int)k3) - M52, vb.y);
+                const double m4 = fmax(fmax(v0, v1), fmax(v2, v3));
+                if (m4 > best) { best = m4; bi = 4 * w + (v0 == m4 ? 0 : (v1 == m4 ? 1 : (v2 == m4 ? 2 : 3))); }
+            }
+        } else {
+            // telomere (log_transmat == 0), breakend or other-class adjacency: the plain expression
+            const double *pd = (tc >= 0 && bs >= 0) ? d.pd_lt + ((size_t)r * d.NBE + bs) * M * D : nullptr;
+            for (int i = 0; i < S; i++) {
+                const double v = Vr[i] + (tc < 0 ? 0. : trans_value(d, tn, i, o, pd));
+                if (v > best) { best = v; bi = i; }
+            }
+        }
+        bp[(size_t)n * S + o] = (uint16_t)bi;
+    }
+}
+// composed maps: block j covers rows j B + 1 .. min((j + 1) B, N - 1); comp[j][o] = the state at row j B on the path that is in state o at the block's last row
+__global__ __launch_bounds__(256) void k_chase_compose(int N, int S, int B, const uint16_t *bp_all, uint16_t *comp_all) {
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    uint16_t *chunk = (uint16_t *)smem_raw;
+    const int j = blockIdx.x, rb = blockIdx.y, NBLK = gridDim.x, t = threadIdx.x, NT = blockDim.x;
+    const int lo = j * B, hi = min(lo + B, N - 1);
+    const uint16_t *bp = bp_all + (size_t)rb * N * S + (size_t)(lo + 1) * S;
+    const int cnt = (hi - lo) * S;
+    for (int i = t; i < cnt; i += NT) chunk[i] = bp[i];
+    __syncthreads();
+    for (int o = t; o < S; o += NT) {
+        int s = o;
+        for (int n = hi; n > lo; n--) s = chunk[(n - lo - 1) * S + s];
+        comp_all[((size_t)rb * NBLK + j) * S + o] = (uint16_t)s;
+    }
+}
+// the final row's first maximum, then the state at every block's last row (ends[j]) through the composed maps; one wave per restart
+__global__ __launch_bounds__(64) void k_chase_ends(int N, int S, int SR, int NBLK, const double *vrow_all, const uint16_t *comp_all, int32_t *ends_all, double *logprob_all) {
+    const int rb = blockIdx.x, lane = threadIdx.x;
+    const double *last = vrow_all + ((size_t)rb * N + (N - 1)) * SR;
+    double best = -INFINITY; int bi = 0x7fffffff;
+    for (int i = lane; i < S; i += 64) { const double v = last[i]; if (v > best || bi == 0x7fffffff) { best = v; bi = i; } }      // (a lane's states ascend: its first maximum)
+    const double m = wave_max_f64(best);
+    int cand = (best == m && bi != 0x7fffffff) ? bi : 0x7fffffff;
+    for (int off = 32; off > 0; off >>= 1) cand = min(cand, __shfl_xor(cand, off, 64));
+    if (lane == 0) {
+        int s = cand == 0x7fffffff ? 0 : cand;
+        logprob_all[rb] = m;
+        const uint16_t *comp = comp_all + (size_t)rb * NBLK * S;
+        for (int j = NBLK - 1; j >= 0; j--) { ends_all[(size_t)rb * NBLK + j] = s; s = comp[(size_t)j * S + s]; }
+    }
+}
+// the path inside each block from its known end state
+__global__ __launch_bounds__(256) void k_chase_fill(int N, int S, int B, const uint16_t *bp_all, const int32_t *ends_all, int64_t *path_all) {
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    uint16_t *chunk = (uint16_t *)smem_raw;
+    const int j = blockIdx.x, rb = blockIdx.y, NBLK = gridDim.x, t = threadIdx.x, NT = blockDim.x;
+    const int lo = j * B, hi = min(lo + B, N - 1);
+    const uint16_t *bp = bp_all + (size_t)rb * N * S + (size_t)(lo + 1) * S;
+    const int cnt = (hi - lo) * S;
+    for (int i = t; i < cnt; i += NT) chunk[i] = bp[i];
+    __syncthreads();
+    if (t == 0) {
+        int64_t *path = path_all + (size_t)rb * N;
+        int s = ends_all[(size_t)rb * NBLK + j];
+        path[hi] = s;
+        for (int n = hi; n > lo; n--) { s = chunk[(n - lo - 1) * S + s]; path[n - 1] = s; }
+    }
+}
 // trace-back: one workgroup per restart; chunks of back-pointer rows staged through LDS
 __global__ void k_backtrace(Dev d, const uint16_t *bp_all, const double *final_all, int64_t *path_all, double *logprob_all, int ROWS) {
     extern __shared__ __align__(16) unsigned char smem_raw[];

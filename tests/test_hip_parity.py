@@ -295,6 +295,29 @@ def test_decode_code_table_lattice_equals_plain_lattice(hip):
     assert len(np.unique(cn[0].reshape(len(cn[0]), -1), axis=0)) > 3        # a non-trivial path
 
 
+@pytest.mark.parametrize('max_cn,N,R', [(4, 2, 2), (6, 3, 2), (8, 129, 3), (8, 130, 3), (8, 1500, 3), (10, 700, 2), (12, 400, 2), (14, 300, 2)])
+def test_parallel_traceback_equals_the_sequential_walk(hip, max_cn, N, R):
+    """The trace-back as arg-maxima of every target state (k_bp_all) + composed maps (k_chase_compose / _ends / _fill; blocks of up to 128
+    rows: two segments, three, a block exactly and one row past it, many blocks) against the sequential walk of bpmodel.pyx:1320-1331 on one wave
+    (k_backtrace_max / k_backtrace_sad, option traceback = 1): same paths and log-probabilities, bit for bit, breakend and telomere steps
+    included -- at 45 / 84 / 165 states (k_viterbi_max), 251 / 355 (workgroup clusters of 4 / 8) and 477 states."""
+    from remixt_amd import synthetic
+    from remixt_amd.restarts import RestartSet
+    e = synthetic.make_experiment(N, num_clones=3, max_copy_number=max_cn, num_chains=min(3, N), seed=31 + N, num_breakpoints=min(20, N // 2))
+    rs = RestartSet(e, synthetic.make_init_params(e, R, max_cn), max_cn, num_clones=3, quiet=True)
+    b = rs.batch
+    b.variational_update(2)
+    cn, lp = b.infer_cn_batch(0, R)
+    assert b.info(19) == 1
+    b.set_option('traceback', 1)
+    cn_seq, lp_seq = b.infer_cn_batch(0, R)
+    assert b.info(19) == 0
+    assert np.array_equal(cn, cn_seq) and np.array_equal(lp, lp_seq)
+    b.set_option('viterbi_plain', 1)                                        # and the table-reading lattice with back-pointers
+    cn_p, lp_p = b.infer_cn_batch(0, R)
+    assert np.array_equal(cn, cn_p) and np.array_equal(lp, lp_p)
+
+
 @pytest.mark.parametrize('max_cn,vit', [(4, 4), (8, 4), (12, 6)])
 def test_decode_with_exact_ties_everywhere_matches_oracle(hip, oracle_mod, max_cn, vit):
     """Both likelihood masks off: a segment's frame log-probability is the subclonality prior alone (bpmodel.pyx:746-749, 898-919) -- the same
@@ -319,6 +342,10 @@ def test_decode_with_exact_ties_everywhere_matches_oracle(hip, oracle_mod, max_c
         got = np.zeros_like(want); dev.infer_cn(got)
         assert dev._batch.info(14) == kern, (opt, dev._batch.info(14))
         assert np.array_equal(got, want), ('viterbi_plain %d' % opt, int((got != want).any(axis=(1, 2)).sum()))
+    dev._batch.set_option('viterbi_plain', 0); dev._batch.set_option('traceback', 1)      # the sequential walk (the loop above ran the parallel trace-back for option 0)
+    got = np.zeros_like(want); dev.infer_cn(got)
+    assert dev._batch.info(19) == 0 and np.array_equal(got, want)
+    dev._batch.set_option('traceback', 0)
     if vit == 6:      # the code-table lattice (one workgroup per restart) as well
         dev._batch.set_option('viterbi_plain', 0); dev._batch.set_option('viterbi_cluster', 1)
         got = np.zeros_like(want); dev.infer_cn(got)
