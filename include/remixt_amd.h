@@ -151,7 +151,9 @@ enum rmx_option_id {
                                    0 the same shared rounds driven from the host (the default until round 4);
                                    1 one parameter at a time; 2 with table rebuilds per candidate; 3 with look-ahead evaluations;
                                    4 on the full objective; 6 = 0 with the final sums of a Nelder-Mead round folded into the objective kernel (last-block ticket: same bits, one launch
-                                   fewer per round, but a release fence per block -- measured 5 % slower on the headline, not the default) */
+                                   fewer per round, but a release fence per block -- measured 5 % slower on the headline, not the default);
+                                   7 = 5 as ONE launch: a request's blocks stay resident, publish their partial sums (sc1 stores, no fence) and each advances its own
+                                   copy of the request's optimiser on all of them (same bits as 5) */
     RMX_OPT_ELL_DENSE,          /* 1: sampled objectives over all states instead of the lists of states with posterior mass */
     RMX_OPT_STRIP,              /* 1 (default): strip kernels for the (segment x state) passes when 32 < S <= 384 */
     RMX_OPT_CELL_CACHE,         /* creation time, 1 (default): cache the six likelihood values of every cell */

@@ -139,6 +139,7 @@ struct rmx_batch {
     void *h_batch = nullptr;           // pinned staging for the batched objective
     std::vector<int32_t> plain_list; int32_t *d_plain_list = nullptr; double *d_plain_jt = nullptr;
     // viterbi
+    int last_search_blocks = 0, last_search_persist = 0;
     int last_viterbi_wgs = 1;      // workgroups per restart of the last lattice (k_viterbi_sad_max<., true>: clusters)
     int32_t *d_vit_special = nullptr; int n_vit_special = -1;      // adjacencies that are not plain class-0 ones, ascending (k_viterbi_max)
     double *h_elbo = nullptr; hipEvent_t ev_elbo = nullptr; bool elbo_pending = false, elbo_sync = false; int elbo_r0 = 0, elbo_r1 = 0;      // rmx_calculate_elbo_begin / _end
@@ -747,7 +748,7 @@ static bool option_value_ok(int id, int v) {
     switch (id) {
     case RMX_OPT_FB_KERNEL: return v >= 0 && v <= 3;
     case RMX_OPT_FB_NV: return v == 0 || v == 1 || v == 2 || v == 4;      // the workgroup shapes that exist (k_fbm and k_fbv / k_fbk 1 / 2 / 4, k_fbq 4)
-    case RMX_OPT_SEARCH_MODE: return v >= 0 && v <= 6;
+    case RMX_OPT_SEARCH_MODE: return v >= 0 && v <= 7;
     case RMX_OPT_PAIRWISE_KERNEL: return v >= 0 && v <= 4;
     case RMX_OPT_FB_WG_BUDGET: return v >= 0 && v <= 4096;
     case RMX_OPT_GRAD_KERNEL: return v >= 0 && v <= 2;
@@ -1088,6 +1089,7 @@ int rmx_info(rmx_batch *b, int32_t what, int64_t *out) { BIND(b);
     case 60: *out = b->t_launch_ns; break; case 61: *out = b->t_wait_ns; break; case 62: *out = b->t_post_ns; break; case 63: *out = b->n_rounds; break;
     case 12: *out = b->last_fb_kernel; break; case 13: *out = b->last_fb_nv; break; case 14: *out = b->last_viterbi; break; case 15: *out = b->last_fb_nv_max; break;
     case 18: *out = b->last_viterbi_wgs; break; case 19: *out = b->last_traceback; break;
+    case 52: *out = b->last_search_blocks; break; case 53: *out = b->last_search_persist; break;      // blocks of the last device-driven search; 1: one launch (k_search_persist)
     case 16: { StreamPool &p_ = g_stream_pool[b->device & 15]; std::lock_guard<std::mutex> lk(p_.mu); *out = p_.created[0] + p_.created[1]; break; }      // streams the device's pool has created so far
     case 17: { StreamPool &p_ = g_stream_pool[b->device & 15]; std::lock_guard<std::mutex> lk(p_.mu); *out = (int64_t)(p_.idle[0].size() + p_.idle[1].size()); break; }   // ... of them idle
     case 20: case 21: case 22: case 23: case 24: case 25: case 26: case 27: case 28: case 29: case 30: case 31: case 32: case 33: case 34: case 35: case 36: case 37: case 38: case 39:
@@ -2445,7 +2447,7 @@ int rmx_param_search_multi(rmx_batch *b, int32_t nreq, const int32_t *restarts, 
     // the GPU to themselves (next to another group's sweeps 415-416 against 424-426 EM it/s for the host rounds); with round 5's flat trial
     // passes it wins there too -- 440.7 / 440.8 against 402-422 EM it/s, alternating runs on one box (profiles/r05_mstep_ab.txt): a restart
     // group's EM period is its sweeps plus its OWN M-step chain (the other group's sweeps hide it only while it is the shorter of the two).
-    if (b->opt[RMX_OPT_SEARCH_MODE] == 5 && maxcnt <= NM_MAX_SAMPLE) {
+    if ((b->opt[RMX_OPT_SEARCH_MODE] == 5 || b->opt[RMX_OPT_SEARCH_MODE] == 7) && maxcnt <= NM_MAX_SAMPLE) {
         if (!b->d_nm_state) {
             if ((rc = dalloc(b, &b->d_nm_state, (size_t)64)) ||
                 (rc = dalloc(b, &b->nm_lay.pre, (size_t)64 * (NM_MAX_SAMPLE + 1))) || (rc = dalloc(b, &b->nm_lay.fix, (size_t)64 * NM_MAX_SAMPLE)) ||
@@ -2471,13 +2473,41 @@ int rmx_param_search_multi(rmx_batch *b, int32_t nreq, const int32_t *restarts, 
         for (int q = 0; q < Q; q++) na.blk0[q + 1] = na.blk0[q] + ((int)cells[q] + 255) / 256;
         for (int q = Q; q < 64; q++) na.blk0[q + 1] = na.blk0[Q];
         const int TB = std::max(na.blk0[Q], 1);
+        uint32_t *done = b->h_err;                  // [Q]: 0 while the request's optimiser runs, then 1 + the restart's error word
+        // search_mode 7: the whole search as ONE launch of resident blocks (k_search_persist) -- where every request has cells
+        // (a block waits only for the blocks of its own request -- consecutive indices, dispatched in order --, so what must be resident together is one request's blocks)
+        bool persist = b->opt[RMX_OPT_SEARCH_MODE] == 7 && na.blk0[Q] >= 1;
+        for (int q = 0; q < Q && persist; q++) persist = na.blk0[q + 1] > na.blk0[q] && na.blk0[q + 1] - na.blk0[q] <= 128;
+        b->last_search_blocks = na.blk0[Q]; b->last_search_persist = persist ? 1 : 0;
+        if (persist) {
+            const size_t need = (size_t)(G + Nm1::maxfun + 2) * TB;
+            if (b->nm_partial_cap < need) {
+                dfree(b, b->d_nm_partial); b->d_nm_partial = nullptr; b->nm_partial_cap = 0;
+                if ((rc = dalloc(b, &b->d_nm_partial, need))) return rc;
+                b->nm_partial_cap = need;
+            }
+            na.grid_stage = 0;
+            {
+                std::lock_guard<std::mutex> lk(b->mu);
+                ProfScope ps(b, KID_ELL_LIST);
+                HIPCHK(hipMemsetAsync(b->d_nm_partial, 0xff, need * 8, b->stream));      // "not yet published"
+                hipLaunchKernelGGL(k_search_persist, dim3(TB), dim3(256), 0, b->stream, b->d, na, (const int32_t *)b->d_msample, (const int32_t *)b->d_mcounts,
+                                   b->nm_lay, b->d_nm_partial, b->h_pinned);
+                hipLaunchKernelGGL(k_search_flags, dim3(1), dim3(64), 0, b->stream, b->d, na, done);
+                HIPCHK(hipGetLastError());
+            }
+            HIPCHK(hipStreamSynchronize(b->stream));
+            for (int q = 0; q < Q; q++) done[q] -= 1u;
+            if (int rc_ = report_request_errors(b, Q, done, [&](int q) { return (int)mv.rlist[q]; })) return rc_;
+            for (int q = 0; q < Q; q++) { xopt[q] = b->h_pinned[2 * q]; lastval[q] = b->h_pinned[2 * q + 1]; }
+            return RMX_OK;
+        }
         const size_t pneed = (size_t)G * TB;
         if (b->nm_partial_cap < pneed) {
             dfree(b, b->d_nm_partial); b->d_nm_partial = nullptr; b->nm_partial_cap = 0;
             if ((rc = dalloc(b, &b->d_nm_partial, pneed * 2))) return rc;
             b->nm_partial_cap = pneed * 2;
         }
-        uint32_t *done = b->h_err;                  // [Q]: 0 while the request's optimiser runs, then 1 + the restart's error word
         for (int q = 0; q < Q; q++) done[q] = 0;
         int queued = 0;
         bool all_done = false;

@@ -3801,6 +3801,137 @@ __global__ __launch_bounds__(256) void k_search_advance(Dev d, NmArgs na, const 
         done_out[req] = 1u + d.err[r];
     }
 }
+// ---- the same searches as ONE launch (round 5, late; search_mode 7) ---------------------------------------------------------------
+// k_search_round / k_search_advance are a kernel pair per round, ~53 rounds per M-step; next to the other restart group's sweeps a pair takes
+// 69 us for 18 us of kernels (every launch waits for its predecessor to drain and for a slot).  Here a request's blocks stay resident for
+// the whole search: a block evaluates its 256 cells for the request's current point, publishes its partial sum (a relaxed agent-scope
+// store, sc1: no fence, no L2 write-back -- those cost the neighbours 5 %), then every block of the request fetches ALL the
+// request's partial sums of the round -- polling each slot until it is no longer the all-ones word the host filled the buffer with --
+// adds them in k_search_advance's order and advances ITS OWN copy of the request's optimiser: the copies see the same doubles in the
+// same order, so they stay identical and nothing but the partial sums crosses between blocks.  Same cells, same partition into blocks,
+// same sums as the kernel pair: the results are bit-identical to search_mode 5 (tests/test_hip_parity.py).  Blocks depend only on the
+// blocks of their own request (consecutive block indices), so the launch makes progress wherever one request's blocks are resident.
+// partial: [G + Nm1::maxfun + 2][gridDim.x], filled with 0xff bytes by the host.  out[2 q] = xopt, out[2 q + 1] = the last point.
+__device__ __forceinline__ double nm_poll(const double *p) {
+    const unsigned long long *src = reinterpret_cast<const unsigned long long *>(p);
+    unsigned long long u;
+    while ((u = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == ~0ull) __builtin_amdgcn_s_sleep(1);
+    return __longlong_as_double((long long)u);
+}
+__global__ __launch_bounds__(256) void k_search_persist(Dev d, NmArgs na, const int32_t *samples, const int32_t *counts, NmLayout lay, double *partial, double *out) {
+    __shared__ int pre[NM_MAX_SAMPLE + 1];
+    __shared__ double k0s[NM_MAX_SAMPLE];
+    __shared__ double scratch[8];
+    __shared__ double bc_v, bc_lv, bc_x0, bc_last;
+    __shared__ int bc_go;
+    __shared__ __align__(8) unsigned char nm_raw[sizeof(rmxh::Nm1)];      // the block's copy of the request's optimiser (thread 0 advances it; in LDS: the kernel's register budget decides how many blocks are resident)
+    rmxh::Nm1 &nm = *reinterpret_cast<rmxh::Nm1 *>(nm_raw);
+    const int tid = threadIdx.x, blk = blockIdx.x, TB = gridDim.x;
+    int req = 0;
+    while (req + 1 < na.nreq && blk >= na.blk0[req + 1]) req++;
+    const int r = na.rlist[req], sl = na.slot[req], mask = na.maskbit[sl];
+    const int cnt = counts[sl * d.R + r];
+    const int T = lay.pre[(size_t)req * (NM_MAX_SAMPLE + 1) + cnt];
+    const int b0 = na.blk0[req], nbq = na.blk0[req + 1] - b0;
+    const int c0 = (blk - b0) * 256;
+    const int32_t *smp = samples + ((size_t)sl * d.R + r) * d.N;
+    for (int i = tid; i <= cnt; i += 256) pre[i] = lay.pre[(size_t)req * (NM_MAX_SAMPLE + 1) + i];
+    __syncthreads();
+    auto segment_of = [&](int c) {
+        int lo_ = 0, hi_ = cnt;
+        while (hi_ - lo_ > 1) { const int mid = (lo_ + hi_) >> 1; if (pre[mid] <= c) lo_ = mid; else hi_ = mid; }
+        return lo_;
+    };
+    const bool any = c0 < T;      // (the host's grid holds exactly the blocks that have cells)
+    const int i_first = any ? segment_of(c0) : 0, i_last = any ? segment_of(min(c0 + 255, T - 1)) : -1;
+    const bool nb = (mask & (CM_LT0 | CM_LT1)) != 0;
+    // this thread's cell: the same for every point of the search
+    const int c = c0 + tid;
+    const bool has = c < T;
+    int ci = 0, n = 0, s = 0; double k1 = 0.;
+    if (has) {
+        ci = segment_of(c); n = smp[ci];
+        const int jj = c - pre[ci];
+        const size_t rn = (size_t)r * d.N + n;
+        s = d.sig_cnt[rn] == 255 ? jj : (int)d.sig_idx[rn * RMX_SIGK + jj];
+        k1 = lay.k1[(size_t)req * NM_MAX_SAMPLE + ci];
+    }
+    const double lo = na.lo[sl], hi = na.hi[sl];
+    const int G = na.G;
+    if (tid == 0) { nm = rmxh::Nm1(); bc_x0 = 0.; bc_last = 0.; }
+    double v = 0., lv = 0.;
+    unsigned err = 0;
+    for (int it = 0;; it++) {
+        if (it < G) { v = na.gv[sl][it]; lv = na.glv[sl][it]; }
+        // the candidate's constant of the segments this block's cells belong to, then the cells
+        __syncthreads();
+        for (int k = tid; k <= i_last - i_first; k += 256) {
+            const int i = i_first + k, n_ = smp[i];
+            const double fx = lay.fix[(size_t)req * NM_MAX_SAMPLE + i];
+            if (nb) k0s[k] = lgamma_pos(d.x[n_] + v) - fx - lgamma_pos(v);
+            else { const double ys = d.y[2 * (size_t)n_] + d.y[2 * (size_t)n_ + 1]; k0s[k] = fx - lgamma_pos(ys + v) + lgamma_pos(v); }
+        }
+        __syncthreads();
+        double acc = 0.;
+        if (has) {
+            const double k0 = k0s[ci - i_first];
+            // (the cell's operands are re-read every round: kept across the rounds they take the kernel to 142 registers, and the number of resident
+            //  blocks next to the other restart group's forward-backward workgroups is what the launch's length depends on)
+            int n_ = n, s_ = s;
+            asm volatile("" : "+v"(n_), "+v"(s_));
+            switch (mask) {
+            case CM_LT0: acc = nm_cell<CM_LT0>(d, r, n_, s_, v, lv, k0, k1, err); break;
+            case CM_LT1: acc = nm_cell<CM_LT1>(d, r, n_, s_, v, lv, k0, k1, err); break;
+            case CM_LA0: acc = nm_cell<CM_LA0>(d, r, n_, s_, v, lv, k0, k1, err); break;
+            default:     acc = nm_cell<CM_LA1>(d, r, n_, s_, v, lv, k0, k1, err); break;
+            }
+        }
+        acc = block_sum<256>(acc, scratch);
+        if (tid == 0) {
+            if (acc != acc) acc = __longlong_as_double(0x7ff8000000000000ll);      // (never the all-ones word)
+            __hip_atomic_store(partial + (size_t)it * TB + blk, acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (it < G - 1) continue;
+        double f = 0.;
+        if (it == G - 1) {
+            // the grid stage: np.argmin over the candidates' sums (first minimum), k_search_advance's order
+            double best = INFINITY;
+            for (int g = 0; g < G; g++) {
+                double a = 0.;
+                for (int k = tid; k < nbq; k += 256) a += nm_poll(partial + (size_t)g * TB + b0 + k);
+                a = block_sum<256>(a, scratch);
+                if (tid == 0) { const double J = -a; if (g == 0 || J < best) { best = J; bc_x0 = na.gv[sl][g]; } }
+            }
+            if (tid == 0) bc_last = na.gv[sl][G - 1];
+        } else {
+            double a = 0.;
+            for (int k = tid; k < nbq; k += 256) a += nm_poll(partial + (size_t)it * TB + b0 + k);
+            a = block_sum<256>(a, scratch);
+            f = -a;
+        }
+        if (tid == 0) {
+            bool go = false;
+            const double x0 = bc_x0;
+            while (nm.advance(x0, f)) {
+                const double vv = nm.req;
+                if (vv < lo || vv > hi) { f = INFINITY; continue; }
+                bc_v = vv; bc_lv = log(vv); bc_last = vv; go = true;
+                break;
+            }
+            bc_go = go ? 1 : 0;
+        }
+        __syncthreads();
+        if (!bc_go) break;
+        v = bc_v; lv = bc_lv;
+    }
+    if (err) atomicOr(&d.err[r], err);
+    if (tid == 0 && blk == b0) { out[2 * req] = nm.xopt(); out[2 * req + 1] = bc_last; }
+}
+// done_out[q] = 1 + the restart's error word, after k_search_persist (a kernel boundary: every block's flags are in)
+__global__ void k_search_flags(Dev d, NmArgs na, uint32_t *done_out) {
+    const int q = threadIdx.x;
+    if (q < na.nreq) done_out[q] = 1u + d.err[na.rlist[q]];
+}
 // grid (nreq * Gz): the sum of k_ell_final_batch over the partials of (request, candidate)
 __global__ void k_ell_search_final(Dev d, SearchVals sv, const int32_t *counts, const double *partial, int maxcnt, double *out, uint32_t *err_out) {
     __shared__ double scratch[8];

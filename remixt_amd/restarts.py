@@ -238,7 +238,7 @@ class RestartSet(object):
             if name not in self._MULTI_PARAMS or len(first) == 4:
                 break
             first.append(name)
-        sequential = b is not None and hasattr(b, 'get_option') and b.get_option('search_mode') not in (0, 5, 6)
+        sequential = b is not None and hasattr(b, 'get_option') and b.get_option('search_mode') not in (0, 5, 6, 7)
         if not (first and self.native_search and b is not None and hasattr(b, 'param_search_multi')) or sequential:
             return []
         return first

@@ -449,6 +449,7 @@ def test_lockstep_mstep_equals_per_restart_mstep(hip):
         (True, True, 1),      # 5: native, one at a time, table-free rounds
         (True, True, 0),      # 6: as 0, but one accept pass over the cells per parameter instead of one for all four
         (True, True, 5),      # 7: the shared rounds driven by the device (cells laid out flat over the threads)
+        (True, True, 7),      # 8: the same as ONE launch of resident blocks (partial sums published and polled, an optimiser copy per block)
     ]
     out = []
     for ci, (lock, native, mode) in enumerate(configs):
@@ -463,6 +464,9 @@ def test_lockstep_mstep_equals_per_restart_mstep(hip):
     # the joint accept test decides what the four sequential ones decide (its E[ll] values differ from theirs by rounding only),
     # and the decisions are all that reaches the model
     for (e1, h1, p1), (e2, h2, p2) in zip(out[0], out[6]):
+        assert e1 == e2 and np.array_equal(h1, h2) and p1 == p2
+    # the one-launch search evaluates the same cells in the same blocks and adds the same partial sums in the same order as the kernel pairs
+    for (e1, h1, p1), (e2, h2, p2) in zip(out[7], out[8]):
         assert e1 == e2 and np.array_equal(h1, h2) and p1 == p2
     # python lock-step == per-restart scipy path, bit for bit
     for (e1, h1, p1), (e2, h2, p2) in zip(out[1], out[2]):
@@ -561,7 +565,7 @@ def test_sample_lists_equal_dense_masks(hip):
         assert e1 == e2 and np.array_equal(g1, g2)
 
 
-@pytest.mark.parametrize('search_mode', [0, 5])
+@pytest.mark.parametrize('search_mode', [0, 5, 7])
 def test_restart_groups_do_not_change_results(hip, search_mode):
     """Restarts split into groups (own batch, stream and host thread each) give every restart the
     same fit as one batch of all restarts."""

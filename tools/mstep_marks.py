@@ -33,6 +33,7 @@ RestartSet.em_iteration = wrapped
 NIT = 8
 t0 = time.time(); rs.run(NIT, 3, 5); rs.synchronize(); dt = time.time() - t0
 print('%d groups: %.1f ms per step, %.0f EM iterations/s' % (G, dt / NIT * 1e3, R * NIT / dt))
+print('device-driven search: %d blocks, one launch: %d' % (rs.sets[0].batch.info(52), rs.sets[0].batch.info(53)))
 for g, s in enumerate(rs.sets):
     acc = collections.OrderedDict()
     prev = None
