@@ -2802,7 +2802,10 @@ static int viterbi_paths(rmx_batch *b, int r0, int nr, std::vector<int64_t> &pat
     // grids whose codes do not fit the LDS (round 5): transition values of class 0 from the packed copies (k_fbk's closed form, verified at table build)
     const int ca0 = b->tc_pairs.empty() ? 0 : b->tc_pairs[0].first, cb0 = b->tc_pairs.empty() ? 0 : b->tc_pairs[0].second;
     const int vcl = b->opt[RMX_OPT_VITERBI_CLUSTER];
-    const bool sadmax = vopt == 0 && !reg && (!coded || vcl != 1) && cur_model && b->fbk_ok && !b->tc_pairs.empty() && ca0 == cb0 && S <= 1024;
+    // (workgroups per restart the launch would get: with one -- the option, or too many restarts for clusters of two -- a grid whose codes fit keeps the code-table lattice)
+    int Wcl = 1;
+    if (vcl != 1) { Wcl = vcl >= 2 ? vcl : (S > 300 ? 8 : 4); while (Wcl > 1 && (long)nr * Wcl > 64) Wcl /= 2; }
+    const bool sadmax = vopt == 0 && !reg && (!coded || Wcl > 1) && cur_model && b->fbk_ok && !b->tc_pairs.empty() && ca0 == cb0 && S <= 1024;
     if (maxima && reg && b->n_vit_special < 0) {
         std::vector<int32_t> sp;
         for (int n = 0; n + 1 < N; n++) if (!(b->tclass[n] == 0 && b->brk_slot[n] < 0)) sp.push_back(n);
@@ -2841,11 +2844,8 @@ static int viterbi_paths(rmx_batch *b, int r0, int nr, std::vector<int64_t> &pat
       if (sadmax) {
           // W workgroups per restart (each a share OW of the target states, the rows exchanged through memory step by step); all of them must be resident
           // at once: at most 64 per launch (restart groups decode next to each other) and 192 per device
-          int W = 1;
-          if (vcl != 1) {
-              // (measured, profiles/r05_large_grids.txt: a step's exchange costs 2-3 us; 251 states are fastest with 4 workgroups, 355 and above with 8)
-              W = vcl >= 2 ? vcl : (S > 300 ? 8 : 4);
-              while (W > 1 && (long)nr * W > 64) W /= 2;
+          int W = Wcl;      // (measured, profiles/r05_large_grids.txt: a step's exchange costs 1.5-2 us; 251 states are fastest with 4 workgroups, 355 and above with 8)
+          {
               if (W > 1) {      // every cluster workgroup in flight on the device must be resident: a process-wide count, W = 1 when it would pass 192 of the 256 CUs
                   const int want = nr * W, had = g_cluster_wgs[b->device & 15].fetch_add(want);
                   if (had + want > 192) { g_cluster_wgs[b->device & 15].fetch_sub(want); W = 1; } else { hold.c = &g_cluster_wgs[b->device & 15]; hold.n = want; }

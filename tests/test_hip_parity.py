@@ -318,6 +318,23 @@ def test_parallel_traceback_equals_the_sequential_walk(hip, max_cn, N, R):
     assert np.array_equal(cn, cn_p) and np.array_equal(lp, lp_p)
 
 
+def test_decode_of_many_restarts_at_once_takes_one_workgroup_per_restart(hip):
+    """Lattice clusters wait for each other, so a launch holds at most 64 of their workgroups: 33 restarts of 355 states in one decode get one
+    workgroup each (the code-table lattice), 16 of them clusters of 4, 8 of them clusters of 8 -- the same paths."""
+    from remixt_amd import synthetic
+    from remixt_amd.restarts import RestartSet
+    e = synthetic.make_experiment(60, num_clones=3, max_copy_number=12, num_chains=2, seed=77, num_breakpoints=6)
+    rs = RestartSet(e, synthetic.make_init_params(e, 33, 12), max_copy_number=12, num_clones=3, quiet=True)
+    b = rs.batch
+    b.variational_update(1)
+    cn, lp = b.infer_cn_batch(0, 33)
+    assert (b.info(14), b.info(18)) == (5, 1)
+    cn16, lp16 = b.infer_cn_batch(0, 16)
+    assert (b.info(14), b.info(18)) == (6, 4) and np.array_equal(cn16, cn[:16]) and np.array_equal(lp16, lp[:16])
+    cn8, lp8 = b.infer_cn_batch(25, 8)
+    assert (b.info(14), b.info(18)) == (6, 8) and np.array_equal(cn8, cn[25:]) and np.array_equal(lp8, lp[25:])
+
+
 @pytest.mark.parametrize('max_cn,vit', [(4, 4), (8, 4), (12, 6)])
 def test_decode_with_exact_ties_everywhere_matches_oracle(hip, oracle_mod, max_cn, vit):
     """Both likelihood masks off: a segment's frame log-probability is the subclonality prior alone (bpmodel.pyx:746-749, 898-919) -- the same
