@@ -180,6 +180,8 @@ enum rmx_option_id {
     RMX_OPT_TRACEBACK,          /* trace-back of the kept lattice rows (default transition model): 0 (default) in parallel -- the first arg-maximum of every target
                                    state of every row on the whole chip (k_bp_all), then the walk as a composition of maps (k_chase_compose / _ends / _fill);
                                    1 the sequential walk on one wave per restart (k_backtrace_max / k_backtrace_sad) */
+    RMX_OPT_CU_PARTITION,       /* creation time: 0 (default) the batch's streams use the whole device; parts * 16 + index (parts 2 / 4 / 8): they are created with a CU mask
+                                   -- range `index` of `parts` equal ranges of the device's CUs (hipExtStreamCreateWithCUMask): restart groups that do not share CUs */
     RMX_OPT_COUNT
 };
 int rmx_set_default_option(int32_t option_id, int32_t value);

@@ -48,7 +48,7 @@ _STATE_TABLES = {'cn_states_total': 0, 'num_alleles_subclonal': 1, 'is_hdel': 2,
 # enum rmx_option_id (include/remixt_amd.h)
 OPTION_IDS = dict((n, i) for i, n in enumerate((
     'fb_kernel', 'fb_nv', 'fb_breakend_codes', 'fuse_sweeps', 'two_streams', 'viterbi_plain', 'search_mode', 'ell_dense', 'strip',
-    'cell_cache', 'sparse_trial', 'fb_debug', 'pairwise_kernel', 'pace_sweeps', 'fb_wg_budget', 'trial_kernel', 'grad_kernel', 'stream_pool', 'viterbi_cluster', 'traceback')))
+    'cell_cache', 'sparse_trial', 'fb_debug', 'pairwise_kernel', 'pace_sweeps', 'fb_wg_budget', 'trial_kernel', 'grad_kernel', 'stream_pool', 'viterbi_cluster', 'traceback', 'cu_partition')))
 
 
 def set_default_option(name, value):

@@ -55,25 +55,37 @@ struct ProfRec { int id; hipEvent_t a, b; };
 // launches serialised: 106-111 instead of 148 EM iterations/s at 355 states, profiles/r04_hw_queues.txt).  Pooled streams are created on demand,
 // handed back when their batch is destroyed and never destroyed themselves: a role's queue is decided once per process, and a batch built later
 // gets a stream with the placement the first ones got (profiles/r05_stream_pool.txt).
-struct StreamPool { std::mutex mu; std::vector<hipStream_t> idle[2]; int created[2] = {0, 0}; };
+// (pool key: role 0 / 1 and the CU partition of option cu_partition -- 0: the whole device; parts * 16 + index: partition `index` of `parts` equal ranges of the CU mask)
+struct StreamPool { std::mutex mu; std::map<int, std::vector<hipStream_t>> idle; int created[2] = {0, 0}; };
 static StreamPool g_stream_pool[16];
-static int pool_acquire(int dev, int role, hipStream_t *out) {
+static hipError_t create_stream_for(int dev, int part, hipStream_t *out) {
+    if (part <= 0) return hipStreamCreateWithFlags(out, hipStreamNonBlocking);
+    const int parts = part >> 4, idx = part & 15;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return hipErrorUnknown;
+    const int ncu = prop.multiProcessorCount, per = ncu / parts;
+    std::vector<uint32_t> mask((ncu + 31) / 32, 0u);
+    for (int c = idx * per; c < (idx + 1) * per; c++) mask[c >> 5] |= 1u << (c & 31);
+    return hipExtStreamCreateWithCUMask(out, (uint32_t)mask.size(), mask.data());
+}
+static int pool_acquire(int dev, int role, hipStream_t *out, int part = 0) {
     StreamPool &p = g_stream_pool[dev & 15];
     std::lock_guard<std::mutex> lk(p.mu);
-    if (!p.idle[role].empty()) { *out = p.idle[role].front(); p.idle[role].erase(p.idle[role].begin()); return RMX_OK; }      // (the oldest first)
-    if (hipStreamCreateWithFlags(out, hipStreamNonBlocking) != hipSuccess) return RMX_EDEVICE;
+    std::vector<hipStream_t> &idle = p.idle[role + 2 * part];
+    if (!idle.empty()) { *out = idle.front(); idle.erase(idle.begin()); return RMX_OK; }      // (the oldest first)
+    if (create_stream_for(dev, part, out) != hipSuccess) return RMX_EDEVICE;
     p.created[role]++;
     return RMX_OK;
 }
-static void pool_release(int dev, int role, hipStream_t s) {
+static void pool_release(int dev, int role, hipStream_t s, int part = 0) {
     hipStreamSynchronize(s);
     StreamPool &p = g_stream_pool[dev & 15];
     std::lock_guard<std::mutex> lk(p.mu);
-    p.idle[role].push_back(s);
+    p.idle[role + 2 * part].push_back(s);
 }
 
 // tuning options (include/remixt_amd.h rmx_option_id): process-wide defaults, copied into a batch at creation
-static int g_opt_default[RMX_OPT_COUNT] = {0, 0, 1, 1, 1, 0, 5, 0, 1, 1, 1, 0, 0, 0, 0, 0, 0, 1, 0, 0};      // (search_mode 5 since round 5)
+static int g_opt_default[RMX_OPT_COUNT] = {0, 0, 1, 1, 1, 0, 5, 0, 1, 1, 1, 0, 0, 0, 0, 0, 0, 1, 0, 0, 0};      // (search_mode 5 since round 5)
 static std::mutex g_opt_mu;
 
 struct rmx_batch {
@@ -754,6 +766,7 @@ static bool option_value_ok(int id, int v) {
     case RMX_OPT_GRAD_KERNEL: return v >= 0 && v <= 2;
     case RMX_OPT_VITERBI_CLUSTER: return v == 0 || v == 1 || v == 2 || v == 4 || v == 8;
     case RMX_OPT_TRACEBACK: return v == 0 || v == 1;
+    case RMX_OPT_CU_PARTITION: return v == 0 || (((v >> 4) == 2 || (v >> 4) == 4 || (v >> 4) == 8) && (v & 15) < (v >> 4));
     case RMX_OPT_VITERBI_PLAIN: return v >= 0 && v <= 2;
     default: return v == 0 || v == 1;
     }
@@ -767,7 +780,7 @@ int rmx_set_default_option(int32_t id, int32_t value) {
 static void configure_fb(rmx_batch *b);
 int rmx_set_option(rmx_batch *b, int32_t id, int32_t value) {
     if (!b || id < 0 || id >= RMX_OPT_COUNT || !option_value_ok(id, value)) return fail(RMX_EARG, "bad option id / value");
-    if (id == RMX_OPT_CELL_CACHE || id == RMX_OPT_SPARSE_TRIAL || id == RMX_OPT_FB_DEBUG || id == RMX_OPT_STREAM_POOL) return fail(RMX_EARG, "creation-time option: use rmx_set_default_option before rmx_batch_create");
+    if (id == RMX_OPT_CELL_CACHE || id == RMX_OPT_SPARSE_TRIAL || id == RMX_OPT_FB_DEBUG || id == RMX_OPT_STREAM_POOL || id == RMX_OPT_CU_PARTITION) return fail(RMX_EARG, "creation-time option: use rmx_set_default_option before rmx_batch_create");
     BIND(b);      // configure_fb sets function attributes (the > 64 KiB LDS opt-in) on the calling thread's current device
     b->opt[id] = value;
     if (id == RMX_OPT_FB_KERNEL) configure_fb(b);
@@ -809,8 +822,8 @@ int rmx_batch_create(const rmx_problem *pr, int32_t R, const double *h_init, con
     { std::lock_guard<std::mutex> lk(g_opt_mu); memcpy(b->opt, g_opt_default, sizeof b->opt); }
     b->device = device; b->R = R;
     { int cus = 0; if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) b->num_cus = cus; }
-    if (b->opt[RMX_OPT_STREAM_POOL]) { if (pool_acquire(device, 0, &b->stream) != RMX_OK) { delete b; return fail(RMX_EDEVICE, "hipStreamCreate failed"); } b->pooled_stream = true; }
-    else HIPCHK(hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking));
+    if (b->opt[RMX_OPT_STREAM_POOL]) { if (pool_acquire(device, 0, &b->stream, b->opt[RMX_OPT_CU_PARTITION]) != RMX_OK) { delete b; return fail(RMX_EDEVICE, "hipStreamCreate failed"); } b->pooled_stream = true; }
+    else HIPCHK(create_stream_for(device, b->opt[RMX_OPT_CU_PARTITION], &b->stream));
     b->own_stream = true;
     Dev &d = b->d;
     d.N = N; d.S = S; d.SP = ((S + 7) / 8) * 8; d.M = M; d.K = K; d.B = B; d.C = C; d.nc = pr->normal_contamination ? 1 : 0;
@@ -1062,11 +1075,11 @@ int rmx_batch_destroy(rmx_batch *b) { BIND(b);
     if (b->tm_a) hipEventDestroy(b->tm_a);
     if (b->tm_b) hipEventDestroy(b->tm_b);
     for (auto e : b->done_ev) hipEventDestroy(e);
-    if (b->stream2) { hipStreamSynchronize(b->stream2); if (b->pooled_stream2) pool_release(b->device, 1, b->stream2); else hipStreamDestroy(b->stream2); hipEventDestroy(b->ev_fb); hipEventDestroy(b->ev_brk); }
+    if (b->stream2) { hipStreamSynchronize(b->stream2); if (b->pooled_stream2) pool_release(b->device, 1, b->stream2, b->opt[RMX_OPT_CU_PARTITION]); else hipStreamDestroy(b->stream2); hipEventDestroy(b->ev_fb); hipEventDestroy(b->ev_brk); }
     if (b->ev_copy) hipEventDestroy(b->ev_copy);
     if (b->ev_pace) hipEventDestroy(b->ev_pace);
     if (b->h_ind) { hipHostUnregister(b->h_ind); free(b->h_ind); }
-    if (b->own_stream && b->stream) { if (b->pooled_stream) pool_release(b->device, 0, b->stream); else hipStreamDestroy(b->stream); }
+    if (b->own_stream && b->stream) { if (b->pooled_stream) pool_release(b->device, 0, b->stream, b->opt[RMX_OPT_CU_PARTITION]); else hipStreamDestroy(b->stream); }
     delete b;
     return RMX_OK;
 }
@@ -1074,7 +1087,7 @@ int rmx_batch_destroy(rmx_batch *b) { BIND(b);
 int rmx_set_stream(rmx_batch *b, void *s) { BIND(b);
     if (!b) return fail(RMX_EARG, "null batch");
     HIPCHK(hipStreamSynchronize(b->stream));
-    if (b->own_stream) { if (b->pooled_stream) pool_release(b->device, 0, b->stream); else hipStreamDestroy(b->stream); b->own_stream = false; b->pooled_stream = false; }
+    if (b->own_stream) { if (b->pooled_stream) pool_release(b->device, 0, b->stream, b->opt[RMX_OPT_CU_PARTITION]); else hipStreamDestroy(b->stream); b->own_stream = false; b->pooled_stream = false; }
     if (s) b->stream = (hipStream_t)s;
     else { HIPCHK(hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking)); b->own_stream = true; }
     return RMX_OK;
@@ -1091,7 +1104,7 @@ int rmx_info(rmx_batch *b, int32_t what, int64_t *out) { BIND(b);
     case 18: *out = b->last_viterbi_wgs; break; case 19: *out = b->last_traceback; break;
     case 52: *out = b->last_search_blocks; break; case 53: *out = b->last_search_persist; break;      // blocks of the last device-driven search; 1: one launch (k_search_persist)
     case 16: { StreamPool &p_ = g_stream_pool[b->device & 15]; std::lock_guard<std::mutex> lk(p_.mu); *out = p_.created[0] + p_.created[1]; break; }      // streams the device's pool has created so far
-    case 17: { StreamPool &p_ = g_stream_pool[b->device & 15]; std::lock_guard<std::mutex> lk(p_.mu); *out = (int64_t)(p_.idle[0].size() + p_.idle[1].size()); break; }   // ... of them idle
+    case 17: { StreamPool &p_ = g_stream_pool[b->device & 15]; std::lock_guard<std::mutex> lk(p_.mu); { size_t n_ = 0; for (auto &kv : p_.idle) n_ += kv.second.size(); *out = (int64_t)n_; } break; }   // ... of them idle
     case 20: case 21: case 22: case 23: case 24: case 25: case 26: case 27: case 28: case 29: case 30: case 31: case 32: case 33: case 34: case 35: case 36: case 37: case 38: case 39:
     case 40: case 41: case 42: case 43: case 44: case 45: case 46: case 47: case 48: case 49: case 50: case 51:
         { if (!b->d_dbg) { *out = 0; break; } unsigned long long v[32]; HIPCHK(hipStreamSynchronize(b->stream)); HIPCHK(hipMemcpy(v, b->d_dbg, 256, hipMemcpyDeviceToHost)); *out = (int64_t)v[what - 20]; break; }
@@ -1645,8 +1658,8 @@ int rmx_variational_update(rmx_batch *b, int32_t r0, int32_t r1, int32_t iters) 
     // the breakend branch of a sweep (pairwise reductions, update_p_breakpoint) next to its marginal pass
     const bool two_streams = use_strip(b) && b->d.NBE > 0 && b->opt[RMX_OPT_TWO_STREAMS];
     if (two_streams && !b->stream2) {
-        if (b->opt[RMX_OPT_STREAM_POOL]) { if (pool_acquire(b->device, 1, &b->stream2) != RMX_OK) return fail(RMX_EDEVICE, "hipStreamCreate failed"); b->pooled_stream2 = true; }
-        else HIPCHK(hipStreamCreateWithFlags(&b->stream2, hipStreamNonBlocking));
+        if (b->opt[RMX_OPT_STREAM_POOL]) { if (pool_acquire(b->device, 1, &b->stream2, b->opt[RMX_OPT_CU_PARTITION]) != RMX_OK) return fail(RMX_EDEVICE, "hipStreamCreate failed"); b->pooled_stream2 = true; }
+        else HIPCHK(create_stream_for(b->device, b->opt[RMX_OPT_CU_PARTITION], &b->stream2));
         HIPCHK(hipEventCreateWithFlags(&b->ev_fb, hipEventDisableTiming));
         HIPCHK(hipEventCreateWithFlags(&b->ev_brk, hipEventDisableTiming));
     }

@@ -35,6 +35,11 @@ class SampleList(object):
         return self.n
 
 
+import threading as _threading
+_creation_lock = _threading.Lock()
+_CREATION_OPTIONS = {'cu_partition': 0}      # creation-time options a batch may be given through options= (name -> the library's default)
+
+
 class RestartSet(object):
     """R restarts of one experiment advancing in lockstep on one device."""
 
@@ -79,11 +84,22 @@ class RestartSet(object):
         if hasattr(kern, 'RemixtBatch'):
             classes, seg_class = m0._state_tables(num_clones)
             brk_states = m0.create_brk_states(num_clones, m0.max_copy_number, m0.max_copy_number_diff)
-            self.batch = kern.RemixtBatch(
-                num_clones, m0.N1, m0.num_breakpoints, m0.normal_contamination, classes, seg_class, brk_states,
-                self.h_init, m0.l1, m0.x1[:, 2].copy(), m0.x1[:, 0:2].copy(), m0.is_telomere, m0.breakpoint_idx,
-                m0.breakpoint_orient, m0.transition_log_prob, [p['divergence_weight'] for p in self.init_params],
-                device=device)
+            # creation-time options of THIS batch (e.g. cu_partition): the library reads its process-wide defaults when a batch is created, so they are
+            # set and restored under a lock (restart groups are built side by side)
+            create_options = dict((k, options[k]) for k in list(options or {}) if k in _CREATION_OPTIONS)
+            options = dict((k, v) for k, v in (options or {}).items() if k not in _CREATION_OPTIONS)
+            with _creation_lock:
+                for k, v in create_options.items():
+                    kern.set_default_option(k, v)
+                try:
+                    self.batch = kern.RemixtBatch(
+                        num_clones, m0.N1, m0.num_breakpoints, m0.normal_contamination, classes, seg_class, brk_states,
+                        self.h_init, m0.l1, m0.x1[:, 2].copy(), m0.x1[:, 0:2].copy(), m0.is_telomere, m0.breakpoint_idx,
+                        m0.breakpoint_orient, m0.transition_log_prob, [p['divergence_weight'] for p in self.init_params],
+                        device=device)
+                finally:
+                    for k in create_options:
+                        kern.set_default_option(k, _CREATION_OPTIONS[k])
             for name, value in (options or {}).items():      # tuning options of the batch (tests, A/B measurements)
                 self.batch.set_option(name, value)
             for r, m in enumerate(self.models):
@@ -661,9 +677,15 @@ class RestartGroups(object):
         self.slices = [slice(bounds[g], bounds[g + 1]) for g in range(groups)]
         remap_cache = dict()
 
+        # cu_partition=True: every group's streams get their own range of the device's CUs (library option cu_partition; 2, 4 or 8 groups)
+        cu_partition = bool(kwargs.pop('cu_partition', False)) and groups in (2, 4, 8)
+
         def build(sl):
+            kw = dict(kwargs)
+            if cu_partition:
+                kw['options'] = dict(kw.get('options') or {}, cu_partition=groups * 16 + self.slices.index(sl))
             return RestartSet(experiment, init_params[sl], max_copy_number, remap_cache=remap_cache,
-                              seeds=(list(seeds)[sl] if seeds is not None else None), **kwargs)
+                              seeds=(list(seeds)[sl] if seeds is not None else None), **kw)
         if groups > 1:
             # the groups are built side by side (a batch's construction is mostly device allocation and table building inside one C call,
             # which releases the GIL) once the segment remap they share is in the cache: one model built ahead of them fills it
