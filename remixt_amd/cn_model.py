@@ -321,28 +321,39 @@ class BreakpointModel(object):
                 n, orient = _get_brkend_seg_orient(breakend)
                 at_boundary[n].add((bp_idx, be_idx, orient))
 
-        seg_rev, is_orig, is_tel, bidx, borient = [], [], [], [], []
-        fwd = np.zeros(self.N, dtype=int)
+        # The walk of cn_model.py:96-147 over the boundaries n = -1 .. N-1, without a Python iteration per segment (43 ms of a fit's 74 ms of
+        # construction at 50 000 segments): a boundary without breakends yields its original segment (n >= 0) and nothing else, so only the
+        # boundaries that carry breakends (two per breakpoint) are visited one by one -- in the iteration order of their sets, as the reference does.
+        N = self.N
+        adjacent = np.fromiter(((n, n + 1) in adjacencies for n in range(-1, N)), dtype=bool, count=N + 1)      # index n + 1
+        nbe = np.zeros(N + 1, dtype=int)
+        for n in [n for n in at_boundary if n < -1 or n >= N]:
+            del at_boundary[n]                # (a boundary the reference's walk never reaches: its breakends are missing below, and the count check says so)
+        for n, ends in at_boundary.items():
+            nbe[n + 1] = len(ends)
+        count = np.where(nbe > 0, nbe + (~adjacent).astype(int), 1)
+        if nbe[0] == 0:
+            count[0] = 0                      # n = -1 without a breakend: no segment
+        start = np.concatenate([[0], np.cumsum(count)])
+        total = int(start[-1])
+        seg_rev = np.repeat(np.arange(-1, N), count)
+        is_orig = np.zeros(total, dtype=bool)
+        is_tel = np.zeros(total, dtype=int)
+        bidx = np.full(total, -1, dtype=int)
+        borient = np.zeros(total, dtype=int)
+        plain = (nbe == 0) & (count == 1)     # original segment alone: a telomere unless the reference adjacency follows
+        is_orig[start[:-1][plain]] = True
+        is_tel[start[:-1][plain]] = np.where(adjacent[plain], 0, 1)
+        for n, ends in at_boundary.items():
+            at = int(start[n + 1])
+            for j, (bp_idx, be_idx, orient) in enumerate(ends):
+                is_orig[at + j] = (j == 0 and n >= 0)
+                bidx[at + j] = bp_idx; borient[at + j] = orient
+            if not adjacent[n + 1]:
+                is_tel[at + len(ends)] = 1
+        fwd = start[1:N + 1].copy()           # the first segment a boundary n >= 0 yields is the original one in either case
 
-        def push(n, original, telomere, bp=-1, orient=0):
-            seg_rev.append(n); is_orig.append(original); is_tel.append(telomere); bidx.append(bp); borient.append(orient)
-
-        for n in range(-1, self.N):
-            adjacent = (n, n + 1) in adjacencies
-            if n in at_boundary:
-                first = True
-                for bp_idx, be_idx, orient in at_boundary[n]:
-                    if first and n >= 0:
-                        fwd[n] = len(seg_rev)
-                    push(n, first and n >= 0, 0, bp_idx, orient)
-                    first = False
-                if not adjacent:
-                    push(n, False, 1)
-            elif n >= 0:
-                fwd[n] = len(seg_rev)
-                push(n, True, 0 if adjacent else 1)
-
-        self.N1 = len(seg_rev)
+        self.N1 = total
         self.seg_fwd_remap = fwd
         self.seg_is_original = np.array(is_orig, dtype=bool)
         # quirk kept: dummy segments created before segment 0 carry index -1 (cn_model.py:133)

@@ -35,6 +35,62 @@ def test_breakend_remap(layout):
         assert np.array_equal(np.asarray(getattr(m, a)), g[layout + '/' + a]), (layout, a)
 
 
+def _remap_walk(N, adjacencies, breakpoints):
+    """The reference's walk over the segment boundaries (cn_model.py:96-147), one Python iteration per segment: what BreakpointModel._remap_segments
+    computed until round 5 and now computes without the per-segment loop."""
+    import collections
+    at_boundary = collections.defaultdict(set)
+    for bp_idx, breakpoint in enumerate(breakpoints):
+        for be_idx, breakend in enumerate(breakpoint):
+            n, orient = cn_model._get_brkend_seg_orient(breakend)
+            at_boundary[n].add((bp_idx, be_idx, orient))
+    seg_rev, is_orig, is_tel, bidx, borient = [], [], [], [], []
+    fwd = np.zeros(N, dtype=int)
+
+    def push(n, original, telomere, bp=-1, orient=0):
+        seg_rev.append(n); is_orig.append(original); is_tel.append(telomere); bidx.append(bp); borient.append(orient)
+    for n in range(-1, N):
+        adjacent = (n, n + 1) in adjacencies
+        if n in at_boundary:
+            first = True
+            for bp_idx, be_idx, orient in at_boundary[n]:
+                if first and n >= 0:
+                    fwd[n] = len(seg_rev)
+                push(n, first and n >= 0, 0, bp_idx, orient)
+                first = False
+            if not adjacent:
+                push(n, False, 1)
+        elif n >= 0:
+            fwd[n] = len(seg_rev)
+            push(n, True, 0 if adjacent else 1)
+    return fwd, np.array(seg_rev), np.array(is_orig, dtype=bool), np.array(is_tel), np.array(bidx), np.array(borient)
+
+
+@pytest.mark.parametrize('seed', range(12))
+def test_breakend_remap_equals_the_walk_over_every_boundary(seed):
+    """Random layouts -- chains of one to many segments, breakends at the left edge (boundary -1), at chain ends, several at one boundary,
+    both ends of a breakpoint at the same boundary -- against the per-segment walk."""
+    rng = np.random.RandomState(seed)
+    N = int(rng.choice([1, 2, 3, 7, 40, 300]))
+    cuts = set(int(c) for c in rng.choice(N, size=min(N, int(rng.randint(0, 5))), replace=False)) if N > 1 else set()
+    adj = set((n, n + 1) for n in range(N - 1) if n not in cuts)
+    brk = []
+    for k in range(int(rng.randint(1, max(2, N // 2 + 1)))):
+        ends = []
+        for _ in range(2):
+            n = int(rng.randint(0, N)); side = int(rng.randint(0, 2))
+            ends.append((n, side))
+        if ends[0] == ends[1]:
+            ends[1] = (ends[1][0], 1 - ends[1][1])
+        brk.append(frozenset(ends))
+    x = np.tile(np.array([[6., 4., 100.]]), (N, 1)); l = np.ones(N) * 1e5
+    m = cn_model.BreakpointModel(x, l, adj, dict((str(i), b) for i, b in enumerate(brk)), max_copy_number=2, max_depth=1.0, min_segment_length=0., quiet=True)
+    fwd, rev, orig, tel, bidx, borient = _remap_walk(N, adj, list(m.breakpoints))
+    assert m.N1 == len(rev)
+    for mine, want in ((m.seg_fwd_remap, fwd), (m.seg_rev_remap, rev), (m.seg_is_original, orig), (m.is_telomere, tel), (m.breakpoint_idx, bidx), (m.breakpoint_orient, borient)):
+        assert np.asarray(mine).dtype == want.dtype and np.array_equal(np.asarray(mine), want)
+
+
 def test_constructor_errors():
     x = np.array([[6., 4., 100.]] * 3); l = np.ones(3) * 1e5
     with pytest.raises(ValueError):
