@@ -91,6 +91,24 @@ def test_breakend_remap_equals_the_walk_over_every_boundary(seed):
         assert np.asarray(mine).dtype == want.dtype and np.array_equal(np.asarray(mine), want)
 
 
+def test_state_tables_are_the_row_wise_unique_of_the_normal_copies():
+    """_state_tables finds the classes of segments (distinct rows of normal copies, lexicographic order) through an integer key per row; the
+    definition is numpy's row-wise unique (cn_model.py:359-364 builds the full [N1, S, M, 2] array the classes compress)."""
+    rng = np.random.RandomState(4)
+    N = 500
+    x = np.tile(np.array([[6., 4., 100.]]), (N, 1)); l = np.ones(N) * 1e5
+    adj = set((n, n + 1) for n in range(N - 1) if n % 97 != 96)
+    m = cn_model.BreakpointModel(x, l, adj, {'a': frozenset([(3, 1), (250, 0)]), 'b': frozenset([(0, 0), (499, 1)])}, max_copy_number=3, max_depth=1.0,
+                                 min_segment_length=0., quiet=True, normal_copies=rng.randint(0, 3, size=(N, 2)))
+    classes, seg_class = m._state_tables(3)
+    rows = np.asarray(m.normal_copies)[m.seg_rev_remap]
+    uniq, inv = np.unique(rows, axis=0, return_inverse=True)
+    assert classes.dtype == np.int64 and seg_class.dtype == np.int32 and len(classes) == len(uniq)
+    assert np.array_equal(classes[:, :, 0, :], np.repeat(uniq[:, None, :], classes.shape[1], axis=1)) and np.array_equal(seg_class, np.asarray(inv).reshape(-1))
+    full = classes[seg_class]                      # the reference's cn_states
+    assert np.array_equal(full[:, :, 0, :], np.repeat(rows[:, None, :], classes.shape[1], axis=1))
+
+
 def test_constructor_errors():
     x = np.array([[6., 4., 100.]] * 3); l = np.ones(3) * 1e5
     with pytest.raises(ValueError):
