@@ -583,7 +583,8 @@ def fit_from_init(args, rs_main, device):
     params = synthetic.make_init_params(e, R, args.max_cn, num_clones=args.clones)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    rs = RestartGroups(e, params, args.max_cn, groups=args.groups, num_clones=args.clones, device=device, quiet=True, seeds=[1000 + i for i in range(R)])
+    host_kw = dict((item.split('=')[0], int(item.split('=')[1])) for item in args.host_option)
+    rs = RestartGroups(e, params, args.max_cn, groups=args.groups, num_clones=args.clones, device=device, quiet=True, seeds=[1000 + i for i in range(R)], **host_kw)
     rs.synchronize()
     t1 = time.perf_counter()
     elbo = rs.fit(5, args.update_iters)
