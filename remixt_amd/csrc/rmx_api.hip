@@ -2872,7 +2872,7 @@ static int viterbi_paths(rmx_batch *b, int r0, int nr, std::vector<int64_t> &pat
           if (W > 1) HIPCHK(hipMemsetAsync(b->d_vrow, 0xff, (size_t)nr * N * SR * 8, b->stream));      // "not yet written" for the row exchange (k_viterbi_sad_max<., true>)
           b->last_viterbi_wgs = W;
           HIPCHK(hipFuncSetAttribute((const void *)kfs, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_));
-          hipLaunchKernelGGL(kfs, W > 1 ? dim3(W, nr) : dim3(nr), dim3(P * SO), lds_, b->stream, b->d, r0, P, SO, OW, SR, b->d_vrow, (const uint32_t *)b->d_cnpack, (const uint32_t *)b->d_cnpack2, -d.pen, ca0);
+          hipLaunchKernelGGL(kfs, W > 1 ? dim3(8 * W * ((nr + 7) / 8)) : dim3(nr), dim3(P * SO), lds_, b->stream, b->d, r0, P, SO, OW, SR, b->d_vrow, (const uint32_t *)b->d_cnpack, (const uint32_t *)b->d_cnpack2, -d.pen, ca0, W, nr);
       } else if (reg) {
           const int NT = ((S * Pr + 63) / 64) * 64;
 #define VREG(Q) { if (reg_max) { const size_t lds_ = (size_t)(2 * (Pr * ((QPT + 1) & ~1) + Q) + ((M * d.D + 1) & ~1)) * 8 + (size_t)b->n_vit_special * 4 + (be_tab ? (size_t)S * 8 + (size_t)S * SR : 0) + 16; \

@@ -4824,10 +4824,16 @@ __global__ __launch_bounds__(768) void k_viterbi_code_max(Dev d, int r0, int P, 
 // together: the host keeps their number below the CU count.
 template <bool M4, bool CL>
 __global__ __launch_bounds__(1024) void k_viterbi_sad_max(Dev d, int r0, int P, int SO, int OW, int SR, double *vrow_all, const uint32_t *cnpack, const uint32_t *cnpack2,
-                                                          double mulpen, int cls0) {
+                                                          double mulpen, int cls0, int Wcl, int nrst) {
     extern __shared__ __align__(16) unsigned char smem_raw[];
     const int S = d.S, M = d.M, D = d.D, t = threadIdx.x, NT = blockDim.x;
-    const int W = CL ? (int)gridDim.x : 1, wg = CL ? (int)blockIdx.x : 0, rb = CL ? (int)blockIdx.y : (int)blockIdx.x;
+    // CL: a 1-D grid of 8 * W * ceil(restarts / 8) workgroups, W passed in OW's neighbour argument: workgroup L works on restart 8 * (L / (8 W)) + L % 8 as
+    // member (L / 8) % W -- the members of a restart have the same L mod 8, which is the XCD a round-robin dispatch gives them (a placement hint:
+    // nothing depends on it)
+    const int W = CL ? Wcl : 1;
+    const int L = (int)blockIdx.x;
+    const int wg = CL ? (L >> 3) % W : 0, rb = CL ? 8 * (L / (8 * W)) + (L & 7) : L;
+    if (CL && rb >= nrst) return;
     const int r = r0 + rb;
     const int SQ = ((S + 4 * P - 1) / (4 * P)) * 4;   // source states per slice (a multiple of 4); SO: threads per slice (a multiple of 64, >= OW)
     const int SV = P * SQ;
