@@ -2812,7 +2812,7 @@ static int viterbi_paths(rmx_batch *b, int r0, int nr, std::vector<int64_t> &pat
     const bool coded = !reg && cur_model && code_lds <= kLdsBudget && vopt != 1;
     const bool maxima = vopt == 0 && (reg || coded);
     const int SR = (S + 3) & ~3;
-    // grids whose codes do not fit the LDS (round 5): transition values of class 0 from the packed copies (k_fbk's closed form, verified at table build)
+    // above 176 states (round 5): transition values of class 0 from the packed copies (k_fbk's closed form, verified at table build), workgroup clusters
     const int ca0 = b->tc_pairs.empty() ? 0 : b->tc_pairs[0].first, cb0 = b->tc_pairs.empty() ? 0 : b->tc_pairs[0].second;
     const int vcl = b->opt[RMX_OPT_VITERBI_CLUSTER];
     // (workgroups per restart the launch would get: with one -- the option, or too many restarts for clusters of two -- a grid whose codes fit keeps the code-table lattice)
