@@ -1769,6 +1769,9 @@ __global__ __launch_bounds__(NTMAX) void k_fbk(FbvArgs a, const double *wk, cons
     const size_t lane_off = ((size_t)(rg0 + (pv0 < nv ? pv0 : 0)) * a.N + ROW(0)) * SP + (po < S ? po : S - 1);
     double *outp = (dir == 0 ? a.fa : a.fb) + lane_off;
     const double *eptr = a.fe + lane_off;
+    // (the second pass's vector of a ragged unit -- fewer restarts than the workgroup shape holds -- does not exist: its emission request, issued every step
+    //  whether or not the value is used, then takes the first pass's address; found by the fuzz as a read two restarts past the end of the array)
+    const size_t e1_off = (pv0 + VPP < nv) ? vstride : 0;
     for (int ps = 0; ps < NPASS; ps++) {
         const int pv = pv0 + ps * VPP;
         if (pv < NV && pubwave) {      // wave-uniform
@@ -1834,7 +1837,7 @@ __global__ __launch_bounds__(NTMAX) void k_fbk(FbvArgs a, const double *wk, cons
         const int cb = (k - 1) & 1, nb = k & 1;
         double e[2] = {0., 0.};                                 // NPASS <= 2
         gload8(e[0], eptr);
-        if (NPASS > 1) gload8(e[1], eptr + vstride);
+        if (NPASS > 1) gload8(e[1], eptr + e1_off);
         eptr += rstep;
         // ============================ phase 1 ============================
         double acc0[NV], acc1[NV];

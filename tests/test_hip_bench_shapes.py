@@ -525,6 +525,21 @@ def test_large_state_grids_match_oracle(hip, oracle_mod, M, max_cn, S, N, fb, vi
         assert got == (fb, vit), ('kernel selection changed', got)
 
 
+@pytest.mark.parametrize('R', [1, 2, 3])
+def test_four_clones_ragged_unit_of_four_vectors_matches_oracle(hip, oracle_mod, R):
+    """k_fbk pinned to four vectors per workgroup with fewer restarts than that (207 states: blocks of 512 threads publish the vectors in two passes of
+    two): the absent vectors' emission requests must stay inside the arrays (a --big fuzz sequence faulted on a read two restarts past the end of the
+    emission array, round 5) and the present ones must match the oracle."""
+    from remixt_amd import synthetic
+    e = synthetic.make_experiment(33, num_clones=4, max_copy_number=4, num_chains=2, seed=4037, num_breakpoints=8, chain_fractions=[1., 2.])
+    ps = synthetic.make_init_params(e, R, 4, num_clones=4)
+    hs = [np.array([p['h_normal']] + [p['h_tumour'] * f for f in (0.5, 0.3, 0.2)]) for p in ps]
+    dev, ora = _two_sets(oracle_mod, e, ps, 4, 4, options={'fb_nv': 4, 'fb_wg_budget': 12}, h_init=hs)
+    assert dev.batch.num_cn_states == 207
+    _compare_after_every_update(dev, ora, sweeps=2)
+    assert (dev.batch.info(12), dev.batch.info(13)) == (3, 4)
+
+
 def test_kernel_selection_at_the_benchmark_grids(hip):
     """Which kernels the parametrisations above really run (docstrings named k_fbv where k_fbm runs)."""
     from remixt_amd import synthetic
