@@ -13,7 +13,17 @@ import traceback
 import numpy as np
 
 
-def draw_case(seed, big=False):
+def draw_case(seed, big=False, huge=False):
+    if huge:
+        # (round 5) the grids between and beyond the benchmark's on 10-24 segments: 205 / 251 / 300 states (k_fbq's other instantiations), 413 / 477 (k_fbk, four
+        # row slices), 617 (two row slices), four clones at 207 / 457 -- the lattice clusters of 4 / 8 workgroups and the parallel trace-back are their default decode
+        rng = np.random.RandomState(100003 * seed + 29)
+        M, max_cn = [(3, 9), (3, 10), (3, 11), (3, 13), (3, 14), (3, 16), (4, 4), (4, 6)][int(rng.randint(0, 8))]
+        N = int(rng.choice([10, 14, 19, 24]))
+        R = int(rng.randint(1, 6 if max_cn < 16 else 4))
+        return dict(seed=seed, N=N, chains=int(rng.randint(1, 4)), M=M, max_cn=max_cn, nbrk=int(rng.choice([1, 3, N // 4])), R=min(R, 4) if M == 4 else R,
+                    fb_nv=int(rng.choice([0, 0, 0, 1, 2, 4])), shared=bool(rng.randint(0, 2)), budget=int(rng.choice([0, 0, 12])),
+                    fractions=([float(x) for x in rng.choice([1., 2., 5.], size=3)] if rng.randint(0, 2) else None))
     """big: the benchmark's state grids (3 clones, max copy number 8 or 12: 165 / 355 states) on 12-40 segments"""
     rng = np.random.RandomState(100003 * seed + 17)
     if big:
@@ -123,6 +133,7 @@ def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument('--seeds', default='0:40')
     ap.add_argument('--big', action='store_true', help='165 / 355 states')
+    ap.add_argument('--huge', action='store_true', help='205 ... 617 states, four clones at 207 / 457 (coordinate updates only)')
     ap.add_argument('--fit', action='store_true', help='whole EM iterations through the restart drivers instead of single coordinate updates')
     args = ap.parse_args(argv)
     lo, hi = [int(v) for v in args.seeds.split(':')]
@@ -130,7 +141,7 @@ def main(argv=None):
     oracle.build()
     bad = 0
     for seed in range(lo, hi):
-        case = draw_case(seed, args.big)
+        case = draw_case(seed, args.big, args.huge)
         try:
             if args.fit:
                 if case['N'] < 20:
