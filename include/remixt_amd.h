@@ -126,7 +126,7 @@ int rmx_synchronize(rmx_batch *b);
  * forward-backward kernels / on the general one; 12 the forward-backward kernel the last update_p_cn launched for the
  * former (1 k_fbm: FP64 matrix cores at 4 restarts per workgroup, vector FMA at 2 / 1; 2 k_fbv: two-phase vector FMA, 3 k_fbk: weights from packed copy numbers, 4 k_fbq: matrix cores with
  * weights from 8-bit codes; 0: general kernel k_fb<0> only), 13 restarts per workgroup of that launch, 14 the lattice kernel of
- * the last decode (1 k_viterbi_reg, 2 k_viterbi_code, 3 k_viterbi, 4 k_viterbi_max, 5 k_viterbi_code_max, 6 k_viterbi_sad_max: above ~380 states); 18 workgroups per restart of that lattice, 19 the trace-back (1 parallel, 0 the sequential walk); 15 the largest number of restarts per workgroup of that launch (13 is the
+ * the last decode (1 k_viterbi_reg, 2 k_viterbi_code, 3 k_viterbi, 4 k_viterbi_max, 5 k_viterbi_code_max, 6 k_viterbi_sad_max: above ~380 states); 18 workgroups per restart of that lattice, 19 the trace-back (1 parallel, 0 the sequential walk), 54 decodes repeated after a lattice cluster's watchdog ran out; 15 the largest number of restarts per workgroup of that launch (13 is the
  * smallest: k_fbm gives long chains fewer restarts per workgroup than short ones) */
 int rmx_info(rmx_batch *b, int32_t what, int64_t *out);
 /* -- tuning options ------------------------------------------------------- */
@@ -176,7 +176,8 @@ enum rmx_option_id {
     RMX_OPT_VITERBI_CLUSTER,    /* lattice above 176 states (k_viterbi_sad_max, default transition model): 0 (default) 4 workgroups per restart up to 300 states, 8
                                    above, each a share of the target states, the rows exchanged through memory step by step (halved while restarts x
                                    workgroups > 64; one where the device already holds 192 such workgroups); 1 one workgroup per restart (up to ~380
-                                   states that is round 5's code-table lattice k_viterbi_code_max); 2 / 4 / 8 that many */
+                                   states that is round 5's code-table lattice k_viterbi_code_max); 2 / 4 / 8 that many; 102 / 104 / 108: a test of the clusters' watchdog (one member never
+                                   publishes its first row: the waits run out and the decode is repeated with one workgroup per restart) */
     RMX_OPT_TRACEBACK,          /* trace-back of the kept lattice rows (default transition model): 0 (default) in parallel -- the first arg-maximum of every target
                                    state of every row on the whole chip (k_bp_all), then the walk as a composition of maps (k_chase_compose / _ends / _fill);
                                    1 the sequential walk on one wave per restart (k_backtrace_max / k_backtrace_sad) */

@@ -152,6 +152,7 @@ struct rmx_batch {
     std::vector<int32_t> plain_list; int32_t *d_plain_list = nullptr; double *d_plain_jt = nullptr;
     // viterbi
     int last_search_blocks = 0, last_search_persist = 0;
+    unsigned *d_vflag = nullptr; int cluster_timeouts = 0;      // "a cluster member gave up waiting" of the last lattice launch; how often that has happened
     int last_viterbi_wgs = 1;      // workgroups per restart of the last lattice (k_viterbi_sad_max<., true>: clusters)
     int32_t *d_vit_special = nullptr; int n_vit_special = -1;      // adjacencies that are not plain class-0 ones, ascending (k_viterbi_max)
     double *h_elbo = nullptr; hipEvent_t ev_elbo = nullptr; bool elbo_pending = false, elbo_sync = false; int elbo_r0 = 0, elbo_r1 = 0;      // rmx_calculate_elbo_begin / _end
@@ -298,6 +299,7 @@ static int translate_error(rmx_batch *b, int r, uint32_t v) {
     if (v & RMX_ERR_BAD_P) { snprintf(buf, sizeof buf, "p <= 0 or (1 - p) <= 0. (restart %d)", r); return fail_flagged(RMX_EVALUE, buf); }
     if (v & RMX_ERR_DIGAMMA) { snprintf(buf, sizeof buf, "x <= 0.0 in digamma (restart %d)", r); return fail_flagged(RMX_EVALUE, buf); }
     if (v & RMX_ERR_NAN_GRAD) { snprintf(buf, sizeof buf, "partial derivative is nan (restart %d)", r); return fail_flagged(RMX_EVALUE, buf); }
+    if (v & RMX_ERR_WAIT) { snprintf(buf, sizeof buf, "a one-launch parameter search (search_mode 7) gave up waiting for a block that was not resident (restart %d)", r); return fail_flagged(RMX_EDEVICE, buf); }
     if (v & RMX_ERR_NAN_F) { snprintf(buf, sizeof buf, "nan in framelogprob (restart %d)", r); return fail_flagged(RMX_EASSERT, buf); }
     if (v & RMX_ERR_NAN_AB) { snprintf(buf, sizeof buf, "nan in alphas/betas (restart %d)", r); return fail_flagged(RMX_EASSERT, buf); }
     if (v & RMX_ERR_NAN_POST) { snprintf(buf, sizeof buf, "nan in posterior marginals (restart %d)", r); return fail_flagged(RMX_EASSERT, buf); }
@@ -764,7 +766,7 @@ static bool option_value_ok(int id, int v) {
     case RMX_OPT_PAIRWISE_KERNEL: return v >= 0 && v <= 4;
     case RMX_OPT_FB_WG_BUDGET: return v >= 0 && v <= 4096;
     case RMX_OPT_GRAD_KERNEL: return v >= 0 && v <= 2;
-    case RMX_OPT_VITERBI_CLUSTER: return v == 0 || v == 1 || v == 2 || v == 4 || v == 8;
+    case RMX_OPT_VITERBI_CLUSTER: return v == 0 || v == 1 || v == 2 || v == 4 || v == 8 || v == 102 || v == 104 || v == 108;
     case RMX_OPT_TRACEBACK: return v == 0 || v == 1;
     case RMX_OPT_CU_PARTITION: return v == 0 || (((v >> 4) == 2 || (v >> 4) == 4 || (v >> 4) == 8) && (v & 15) < (v >> 4));
     case RMX_OPT_VITERBI_PLAIN: return v >= 0 && v <= 2;
@@ -1102,6 +1104,7 @@ int rmx_info(rmx_batch *b, int32_t what, int64_t *out) { BIND(b);
     case 60: *out = b->t_launch_ns; break; case 61: *out = b->t_wait_ns; break; case 62: *out = b->t_post_ns; break; case 63: *out = b->n_rounds; break;
     case 12: *out = b->last_fb_kernel; break; case 13: *out = b->last_fb_nv; break; case 14: *out = b->last_viterbi; break; case 15: *out = b->last_fb_nv_max; break;
     case 18: *out = b->last_viterbi_wgs; break; case 19: *out = b->last_traceback; break;
+    case 54: *out = b->cluster_timeouts; break;      // decodes repeated with one workgroup per restart after a lattice cluster's watchdog ran out
     case 52: *out = b->last_search_blocks; break; case 53: *out = b->last_search_persist; break;      // blocks of the last device-driven search; 1: one launch (k_search_persist)
     case 16: { StreamPool &p_ = g_stream_pool[b->device & 15]; std::lock_guard<std::mutex> lk(p_.mu); *out = p_.created[0] + p_.created[1]; break; }      // streams the device's pool has created so far
     case 17: { StreamPool &p_ = g_stream_pool[b->device & 15]; std::lock_guard<std::mutex> lk(p_.mu); { size_t n_ = 0; for (auto &kv : p_.idle) n_ += kv.second.size(); *out = (int64_t)n_; } break; }   // ... of them idle
@@ -2795,8 +2798,9 @@ static int viterbi_reg_P(int S) { int P = 1; while (S * P * 2 <= 768 && P < 64) 
 // Viterbi paths of restarts r0 .. r0+nr-1: forward lattices side by side (one workgroup each), then the trace-backs
 static std::atomic<int> g_cluster_wgs[16];      // workgroups of lattice clusters (k_viterbi_sad_max<., true>) in flight per device
 struct ClusterHold { std::atomic<int> *c = nullptr; int n = 0; ~ClusterHold() { if (c && n) c->fetch_sub(n); } };
-static int viterbi_paths(rmx_batch *b, int r0, int nr, std::vector<int64_t> &paths, std::vector<double> &lps, int model) {
+static int viterbi_paths(rmx_batch *b, int r0, int nr, std::vector<int64_t> &paths, std::vector<double> &lps, int model, bool allow_cluster = true) {
     ClusterHold hold;      // (released when this call returns: it ends with a stream synchronisation)
+    bool cluster_launched = false;
     // the lattice runs on the log_transmat snapshot: plain tables of the transition model it was taken under
     const Dev dv = dev_for_model(b, model);
     const bool cur_model = model == b->d.tmodel;
@@ -2817,7 +2821,8 @@ static int viterbi_paths(rmx_batch *b, int r0, int nr, std::vector<int64_t> &pat
     const int vcl = b->opt[RMX_OPT_VITERBI_CLUSTER];
     // (workgroups per restart the launch would get: with one -- the option, or too many restarts for clusters of two -- a grid whose codes fit keeps the code-table lattice)
     int Wcl = 1;
-    if (vcl != 1) { Wcl = vcl >= 2 ? vcl : (S > 300 ? 8 : 4); while (Wcl > 1 && (long)nr * Wcl > 64) Wcl /= 2; }
+    const bool stall_test = vcl >= 100;      // (test hook: viterbi_cluster = 100 + W runs clusters of W with one member that never publishes its first row)
+    if (vcl != 1 && allow_cluster) { const int want = vcl >= 100 ? vcl - 100 : vcl; Wcl = want >= 2 ? want : (S > 300 ? 8 : 4); while (Wcl > 1 && (long)nr * Wcl > 64) Wcl /= 2; }
     const bool sadmax = vopt == 0 && !reg && (!coded || Wcl > 1) && cur_model && b->fbk_ok && !b->tc_pairs.empty() && ca0 == cb0 && S <= 1024;
     if (maxima && reg && b->n_vit_special < 0) {
         std::vector<int32_t> sp;
@@ -2869,10 +2874,13 @@ static int viterbi_paths(rmx_batch *b, int r0, int nr, std::vector<int64_t> &pat
           const int SQ = ((S + 4 * P - 1) / (4 * P)) * 4, SV = P * SQ;
           const size_t lds_ = (size_t)(2 * SV + (P > 1 ? P * SO : 0) + ((M * d.D + 1) & ~1)) * 8 + (size_t)(M == 4 ? 2 : 1) * SV * 4 + 16;
           auto kfs = W > 1 ? (M == 4 ? k_viterbi_sad_max<true, true> : k_viterbi_sad_max<false, true>) : (M == 4 ? k_viterbi_sad_max<true, false> : k_viterbi_sad_max<false, false>);
+          if (!b->d_vflag) { if ((rc = dalloc(b, &b->d_vflag, (size_t)1))) return rc; }
+          HIPCHK(hipMemsetAsync(b->d_vflag, 0, 4, b->stream));
           if (W > 1) HIPCHK(hipMemsetAsync(b->d_vrow, 0xff, (size_t)nr * N * SR * 8, b->stream));      // "not yet written" for the row exchange (k_viterbi_sad_max<., true>)
           b->last_viterbi_wgs = W;
           HIPCHK(hipFuncSetAttribute((const void *)kfs, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_));
-          hipLaunchKernelGGL(kfs, W > 1 ? dim3(8 * W * ((nr + 7) / 8)) : dim3(nr), dim3(P * SO), lds_, b->stream, b->d, r0, P, SO, OW, SR, b->d_vrow, (const uint32_t *)b->d_cnpack, (const uint32_t *)b->d_cnpack2, -d.pen, ca0, W, nr);
+          hipLaunchKernelGGL(kfs, W > 1 ? dim3(8 * W * ((nr + 7) / 8)) : dim3(nr), dim3(P * SO), lds_, b->stream, b->d, r0, P, SO, OW, SR, b->d_vrow, (const uint32_t *)b->d_cnpack, (const uint32_t *)b->d_cnpack2, -d.pen, ca0, W, nr, b->d_vflag, (stall_test && W > 1) ? 1 : 0);
+          cluster_launched = W > 1;
       } else if (reg) {
           const int NT = ((S * Pr + 63) / 64) * 64;
 #define VREG(Q) { if (reg_max) { const size_t lds_ = (size_t)(2 * (Pr * ((QPT + 1) & ~1) + Q) + ((M * d.D + 1) & ~1)) * 8 + (size_t)b->n_vit_special * 4 + (be_tab ? (size_t)S * 8 + (size_t)S * SR : 0) + 16; \
@@ -2957,7 +2965,16 @@ static int viterbi_paths(rmx_batch *b, int r0, int nr, std::vector<int64_t> &pat
     paths.resize((size_t)nr * N); lps.resize(nr);
     HIPCHK(hipMemcpyAsync(paths.data(), b->d_path, (size_t)nr * N * 8, hipMemcpyDeviceToHost, b->stream));
     HIPCHK(hipMemcpyAsync(lps.data(), b->d_logprob, (size_t)nr * 8, hipMemcpyDeviceToHost, b->stream));
+    uint32_t gave_up = 0;
+    if (cluster_launched) HIPCHK(hipMemcpyAsync(&gave_up, b->d_vflag, 4, hipMemcpyDeviceToHost, b->stream));
     HIPCHK(hipStreamSynchronize(b->stream));
+    if (gave_up) {
+        // a member of a lattice cluster waited for a row until its watchdog ran out (its partners were not resident, or gone): the decode is
+        // repeated with one workgroup per restart, which waits for nobody
+        b->cluster_timeouts++;
+        if (hold.c && hold.n) { hold.c->fetch_sub(hold.n); hold.n = 0; }
+        return viterbi_paths(b, r0, nr, paths, lps, model, false);
+    }
     return RMX_OK;
 }
 

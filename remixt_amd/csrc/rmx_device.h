@@ -25,6 +25,7 @@
 #define RMX_ERR_NAN_POST 64u     // AssertionError nan posterior marginals (:952, :962)
 #define RMX_ERR_DIGAMMA 128u     // ValueError 'x <= 0.0' in digamma (:207)
 #define RMX_ERR_NAN_GRAD 256u    // ValueError 'partial_* is nan' (:298, :391)
+#define RMX_ERR_WAIT 512u        // (no reference counterpart) a block of a one-launch search (search_mode 7) waited for a partner's partial sum until its watchdog ran out
 
 // state-table flag bits
 #define ST_HDEL_NB 1u      // use the hdel NB branch (:760)

@@ -18,6 +18,7 @@
 #define SEGL 32
 #define SEG_PER_BLOCK (256 / SEGL)
 #define TRIAL_SEGL 16
+#define RMX_CLUSTER_SPINS (1u << 22)      // polls of one element before a lattice cluster member gives up (each at least a memory round trip: seconds)
 #define FBK_WKN 128      // entries of exp(-pen * k) per transition class (k = allele distance: < 64 up to max_cn 15, < 128 up to 31)
 #define NM_MAX_SAMPLE 1024      // sampled segments per request in the layouts of the flat M-step kernels (the reference samples min(200, N / 10))
 #define TRIAL_SEG_PER_BLOCK (256 / TRIAL_SEGL)
@@ -3815,10 +3816,14 @@ __global__ __launch_bounds__(256) void k_search_advance(Dev d, NmArgs na, const 
 // same sums as the kernel pair: the results are bit-identical to search_mode 5 (tests/test_hip_parity.py).  Blocks depend only on the
 // blocks of their own request (consecutive block indices), so the launch makes progress wherever one request's blocks are resident.
 // partial: [G + Nm1::maxfun + 2][gridDim.x], filled with 0xff bytes by the host.  out[2 q] = xopt, out[2 q + 1] = the last point.
-__device__ __forceinline__ double nm_poll(const double *p) {
+__device__ __forceinline__ double nm_poll(const double *p, bool &dead) {      // (bounded like the lattice clusters' waits: RMX_CLUSTER_SPINS polls, then the block gives up)
     const unsigned long long *src = reinterpret_cast<const unsigned long long *>(p);
     unsigned long long u;
-    while ((u = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == ~0ull) __builtin_amdgcn_s_sleep(1);
+    unsigned spins = 0;
+    while ((u = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == ~0ull) {
+        __builtin_amdgcn_s_sleep(1);
+        if (++spins > RMX_CLUSTER_SPINS) { dead = true; return 0.; }
+    }
     return __longlong_as_double((long long)u);
 }
 __global__ __launch_bounds__(256) void k_search_persist(Dev d, NmArgs na, const int32_t *samples, const int32_t *counts, NmLayout lay, double *partial, double *out) {
@@ -3896,21 +3901,26 @@ __global__ __launch_bounds__(256) void k_search_persist(Dev d, NmArgs na, const 
         }
         if (it < G - 1) continue;
         double f = 0.;
+        bool dead = false;
         if (it == G - 1) {
             // the grid stage: np.argmin over the candidates' sums (first minimum), k_search_advance's order
             double best = INFINITY;
             for (int g = 0; g < G; g++) {
                 double a = 0.;
-                for (int k = tid; k < nbq; k += 256) a += nm_poll(partial + (size_t)g * TB + b0 + k);
+                for (int k = tid; k < nbq; k += 256) a += nm_poll(partial + (size_t)g * TB + b0 + k, dead);
                 a = block_sum<256>(a, scratch);
                 if (tid == 0) { const double J = -a; if (g == 0 || J < best) { best = J; bc_x0 = na.gv[sl][g]; } }
             }
             if (tid == 0) bc_last = na.gv[sl][G - 1];
         } else {
             double a = 0.;
-            for (int k = tid; k < nbq; k += 256) a += nm_poll(partial + (size_t)it * TB + b0 + k);
+            for (int k = tid; k < nbq; k += 256) a += nm_poll(partial + (size_t)it * TB + b0 + k, dead);
             a = block_sum<256>(a, scratch);
             f = -a;
+        }
+        if (__syncthreads_or(dead ? 1 : 0)) {      // a partial sum never came (a block of the request not resident, or gone): the request fails instead of hanging
+            if (tid == 0) atomicOr(&d.err[r], RMX_ERR_WAIT);
+            return;
         }
         if (tid == 0) {
             bool go = false;
@@ -4827,7 +4837,7 @@ __global__ __launch_bounds__(768) void k_viterbi_code_max(Dev d, int r0, int P, 
 // together: the host keeps their number below the CU count.
 template <bool M4, bool CL>
 __global__ __launch_bounds__(1024) void k_viterbi_sad_max(Dev d, int r0, int P, int SO, int OW, int SR, double *vrow_all, const uint32_t *cnpack, const uint32_t *cnpack2,
-                                                          double mulpen, int cls0, int Wcl, int nrst) {
+                                                          double mulpen, int cls0, int Wcl, int nrst, unsigned *fail_flag, int stall_test) {
     extern __shared__ __align__(16) unsigned char smem_raw[];
     const int S = d.S, M = d.M, D = d.D, t = threadIdx.x, NT = blockDim.x;
     // CL: a 1-D grid of 8 * W * ceil(restarts / 8) workgroups, W passed in OW's neighbour argument: workgroup L works on restart 8 * (L / (8 W)) + L % 8 as
@@ -4862,6 +4872,8 @@ __global__ __launch_bounds__(1024) void k_viterbi_sad_max(Dev d, int r0, int P, 
     __syncthreads();
     const int NW = SQ / 4;
     const double M52 = 4503599627370496.0;
+    unsigned budget = RMX_CLUSTER_SPINS;      // polls this thread may still spend waiting for partners' rows (CL)
+    bool flagged = false;
     if (d.N > 1) {
         double fn; int tcv, bsv;
         gload8(fn, f + (size_t)1 * d.SP + oc); gload4(tcv, d.tclass); gload4(bsv, d.brk_slot);
@@ -4924,18 +4936,25 @@ __global__ __launch_bounds__(1024) void k_viterbi_sad_max(Dev d, int r0, int P, 
                 }
                 __syncthreads();
             } else {
-                if (act && p == 0) {
+                if (act && p == 0 && !(stall_test && wg == 0 && rb == 0 && n == 1)) {      // (stall_test: a member that never publishes a row -- the watchdog's test)
                     double vn = best + fcur;
                     if (vn != vn) vn = __longlong_as_double(0x7ff8000000000000ll);      // (never the all-ones word the fetch below waits on)
                     __hip_atomic_store(vrow + (size_t)n * SR + o, vn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
                 // every thread fetches its share of the new row as the owners' stores arrive: the host filled the rows with all-ones words, which no stored
-                // value is, and an 8-byte store lands whole
+                // value is, and an 8-byte store lands whole.  The waits are bounded: a member that is not resident (a device shared with another process's
+                // resident kernels) or has gone would otherwise hold its partners for ever.  A thread has RMX_CLUSTER_SPINS polls (seconds) for one wait;
+                // when a wait uses them up it raises the launch's flag and from then on takes what it finds (-inf for a missing element) --
+                // the workgroup runs to its end without waiting, its partners get rows and are not held up, and the host, seeing the flag, decodes again with one
+                // workgroup per restart.
                 for (int i = t; i < S; i += NT) {
                     const unsigned long long *src = reinterpret_cast<const unsigned long long *>(vrow + (size_t)n * SR + i);
                     unsigned long long u;
-                    while ((u = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == ~0ull) __builtin_amdgcn_s_sleep(1);
-                    V[nxt * SV + i] = __longlong_as_double((long long)u);
+                    while ((u = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == ~0ull && budget) { __builtin_amdgcn_s_sleep(1); --budget; }
+                    if (u == ~0ull) {
+                        if (!flagged) { __hip_atomic_store(fail_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); flagged = true; }
+                        V[nxt * SV + i] = -INFINITY;
+                    } else { V[nxt * SV + i] = __longlong_as_double((long long)u); if (!flagged) budget = RMX_CLUSTER_SPINS; }      // (a wait that ends refills the budget)
                 }
                 __syncthreads();
             }

@@ -335,6 +335,26 @@ def test_decode_of_many_restarts_at_once_takes_one_workgroup_per_restart(hip):
     assert (b.info(14), b.info(18)) == (6, 8) and np.array_equal(cn8, cn[25:]) and np.array_equal(lp8, lp[25:])
 
 
+def test_lattice_cluster_watchdog_falls_back_to_one_workgroup_per_restart(hip):
+    """A member of a lattice cluster that never publishes a row (test hook: viterbi_cluster = 100 + W) must not hold its partners for ever: their waits run
+    out (seconds), the launch raises its flag, and the decode is repeated with one workgroup per restart -- same paths as the undisturbed decode."""
+    from remixt_amd import synthetic
+    from remixt_amd.restarts import RestartSet
+    e = synthetic.make_experiment(50, num_clones=3, max_copy_number=12, num_chains=2, seed=78, num_breakpoints=5)
+    rs = RestartSet(e, synthetic.make_init_params(e, 3, 12), max_copy_number=12, num_clones=3, quiet=True)
+    b = rs.batch
+    b.variational_update(1)
+    cn, lp = b.infer_cn_batch(0, 3)
+    assert (b.info(14), b.info(18), b.info(54)) == (6, 8, 0)
+    b.set_option('viterbi_cluster', 104)
+    cn_w, lp_w = b.infer_cn_batch(0, 3)
+    assert b.info(54) == 1 and b.info(18) == 1            # the watchdog fired once; the repeat ran one workgroup per restart
+    assert np.array_equal(cn_w, cn) and np.array_equal(lp_w, lp)
+    b.set_option('viterbi_cluster', 0)
+    cn2, lp2 = b.infer_cn_batch(0, 3)
+    assert (b.info(18), b.info(54)) == (8, 1) and np.array_equal(cn2, cn) and np.array_equal(lp2, lp)
+
+
 @pytest.mark.parametrize('max_cn,vit', [(4, 4), (8, 4), (12, 6)])
 def test_decode_with_exact_ties_everywhere_matches_oracle(hip, oracle_mod, max_cn, vit):
     """Both likelihood masks off: a segment's frame log-probability is the subclonality prior alone (bpmodel.pyx:746-749, 898-919) -- the same
