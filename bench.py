@@ -71,7 +71,7 @@ def parse(argv=None):
     ap.add_argument('--strong-total', type=int, default=64, help='N > 1 in the default (weak) mode also times the fixed job of BASELINE configs[3] with this many restarts in total; 0 = skip')
     ap.add_argument('--datasets', type=int, default=1, help='2 = BASELINE configs[4]: two tumour samples on the same segmentation / breakpoints, fitted independently')
     ap.add_argument('--update-iters', type=int, default=5)
-    ap.add_argument('--groups', type=int, default=2, help='restart groups per GPU and dataset (own stream + host thread each; a restart\'s result is bit-identical across groupings per search mode and forward-backward workgroup shape, which RestartGroups picks by group size: DESIGN 4.6)')
+    ap.add_argument('--groups', type=int, default=2, help='restart groups per GPU and dataset (default 2; with --datasets 2 and no --groups: one per dataset, i.e. two on the device; own stream + host thread each; a restart\'s result is bit-identical across groupings per search mode and forward-backward workgroup shape, which RestartGroups picks by group size: DESIGN 4.6)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-sample-segments', type=int, default=800, help='segments of the CPU baseline sample at the headline grid (about 10 s of one core)')
     ap.add_argument('--cpu-sample-segments-355', type=int, default=120, help='segments of the CPU baseline sample at 355 states (0 = skip)')
@@ -88,7 +88,10 @@ def parse(argv=None):
     ap.add_argument('--switch-interval-us', type=float, default=0., help='A/B measurements: sys.setswitchinterval for the restart groups\' host threads (0 = leave Python\'s 5 ms)')
     ap.add_argument('--cpu-leg', action='store_true', help=argparse.SUPPRESS)       # internal: the CPU baseline child process
     ap.add_argument('--sub-run', default=None, help=argparse.SUPPRESS)              # internal: one additional measurement in a process of its own (restarts,groups,max_cn,nsteps,warm,unequal)
-    return ap.parse_args(argv)
+    args = ap.parse_args(argv)
+    # (--groups given on the command line: honoured for several datasets too; otherwise DatasetGroups keeps two groups on the device at a time)
+    args.groups_given = any(a == '--groups' or a.startswith('--groups=') for a in (argv if argv is not None else sys.argv[1:]))
+    return args
 
 
 # ---------------------------------------------------------------------------------------------------
@@ -345,7 +348,7 @@ def main(argv=None, kernel_module=None, dist_backend='nccl', script=None):
         rs = RestartGroups(e, params, args.max_cn, groups=args.groups, num_clones=args.clones, device=device, quiet=True, seeds=seeds,
                            kernel_module=kernel_module, **host_kw)
     else:
-        rs = DatasetGroups([s[0] for s in sets], [s[1] for s in sets], args.max_cn, groups=args.groups, num_clones=args.clones, device=device,
+        rs = DatasetGroups([s[0] for s in sets], [s[1] for s in sets], args.max_cn, groups=(args.groups if args.groups_given else None), num_clones=args.clones, device=device,
                            quiet=True, seeds=[s[2] for s in sets], kernel_module=kernel_module, **host_kw)
     e = sets[0][0]
     on_gpu = kernel_module is None

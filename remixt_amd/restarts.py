@@ -787,12 +787,22 @@ class RestartGroups(object):
 class DatasetGroups(object):
     """Several datasets resident on one GPU at once (BASELINE configs[4]: the tumour samples of one patient share
     the segmentation and the breakpoints and are fitted independently, reference remixt/workflow.py:472-485): one
-    RestartGroups per dataset, all free-running on their own host threads and HIP streams.  Nothing is shared
-    between datasets on the device, so every dataset's results equal its single-dataset fit bit for bit."""
+    RestartGroups per dataset, free-running on their own host threads and HIP streams.  Nothing is shared
+    between datasets on the device, so every dataset's results equal its single-dataset fit bit for bit.
 
-    def __init__(self, experiments, init_params, max_copy_number, groups=2, seeds=None, **kwargs):
+    groups: restart groups PER DATASET; None (default) = as many as keep TWO restart groups on the device at a time -- two for one
+    dataset, one each from two datasets on.  More than two groups at once share the runtime's four hardware queues (a group has two
+    streams) and their kernels take turns: two datasets of 8 restarts measured 304-349 EM it/s as 2 x 2 groups against 449 as 2 x 1
+    (profiles/r05_grouping_experiments.txt).  For the same reason at most `concurrent_groups` (default 2) groups run at once: three
+    or more datasets are fitted two at a time, every one resident from the start."""
+
+    def __init__(self, experiments, init_params, max_copy_number, groups=None, seeds=None, concurrent_groups=2, **kwargs):
         if len(experiments) != len(init_params):
             raise ValueError('one list of restarts per dataset')
+        if groups is None:
+            groups = max(1, int(concurrent_groups) // max(1, len(experiments)))
+        self.groups_per_dataset = int(groups)
+        self._workers = max(1, min(len(experiments), int(concurrent_groups) // max(1, self.groups_per_dataset)))
         self.parts = [RestartGroups(e, p, max_copy_number, groups=groups, seeds=(seeds[i] if seeds is not None else None), **kwargs)
                       for i, (e, p) in enumerate(zip(experiments, init_params))]
         self.sets = [rs for part in self.parts for rs in part.sets]
@@ -818,7 +828,7 @@ class DatasetGroups(object):
             return [fn(self.parts[0])]
         if self._pool is None:
             from concurrent.futures import ThreadPoolExecutor
-            self._pool = ThreadPoolExecutor(max_workers=len(self.parts))
+            self._pool = ThreadPoolExecutor(max_workers=self._workers)
         return list(self._pool.map(fn, self.parts))
 
     def calculate_elbo(self):

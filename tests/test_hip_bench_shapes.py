@@ -396,6 +396,31 @@ def test_two_datasets_on_one_gpu_equal_their_single_dataset_fits(hip):
             assert np.array_equal(a['p_outlier_total'], b['p_outlier_total'])
 
 
+def test_datasets_keep_two_restart_groups_on_the_device_by_default(hip):
+    """DatasetGroups without groups=: one restart group per dataset from two datasets on, at most two groups running at once (three datasets: two at a
+    time) -- more than two groups share the runtime's four hardware queues.  Results equal the single-dataset fits with the same grouping, bit for bit."""
+    from remixt_amd import synthetic
+    from remixt_amd.restarts import DatasetGroups, RestartGroups
+    e0 = synthetic.make_experiment(300, num_clones=3, max_copy_number=4, num_chains=3, seed=15, num_breakpoints=8)
+    es = [e0, synthetic.resample_counts(e0, seed=102), synthetic.resample_counts(e0, seed=103)]
+    ps = [synthetic.make_init_params(e, 3, 4) for e in es]
+    seeds = [[1, 2, 3], [11, 12, 13], [21, 22, 23]]
+    one = DatasetGroups(es[:1], ps[:1], 4, num_clones=3, quiet=True, seeds=seeds[:1])
+    assert (one.groups_per_dataset, one._workers, len(one.sets)) == (2, 1, 2)
+    one.close()
+    three = DatasetGroups(es, ps, 4, num_clones=3, quiet=True, seeds=seeds)
+    assert (three.groups_per_dataset, three._workers, len(three.sets)) == (1, 2, 3)
+    elbo = three.fit(num_em_iter=2, num_update_iter=2)
+    res = three.results_by_dataset()
+    for i, e in enumerate(es):
+        ref = RestartGroups(e, ps[i], 4, groups=1, num_clones=3, quiet=True, seeds=seeds[i])
+        el = ref.fit(num_em_iter=2, num_update_iter=2)
+        assert np.array_equal(el, elbo[3 * i:3 * i + 3])
+        for a, b in zip(ref.results(), res[i]):
+            assert a['stats']['elbo'] == b['stats']['elbo'] and np.array_equal(a['h'], b['h']) and np.array_equal(a['cn'], b['cn'])
+        ref.close()
+
+
 def test_every_flagged_restart_is_reported_and_cleared(hip):
     """a batched call that flags several restarts used to clear only the first one's error word; the others
     surfaced in later, unrelated calls."""
